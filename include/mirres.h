@@ -1,0 +1,169 @@
+/* mirres.h — C ABI of libmirres.so: the MI355X (gfx950) engine behind the reference's ReSTIR path-tracing
+ * operator surface (brabbitdousha/MIRReS-ReSTIR_Nerf_mesh, nerf/renderer_restir.py + nerf/ScreenSpaceReSTIR/...).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless its name starts with h_; all tensors are contiguous
+ *     row-major fp32 / int32 exactly as the reference's torch tensors;
+ *   - `stream` is a hipStream_t passed as void*; every call only ENQUEUES work on it (no host sync) unless stated;
+ *   - return value: 0 = ok, negative = MIRRES_E_*; nothing is allocated inside a call except in *_create;
+ *   - pixelIndex = y * fx + x;  reservoir = (light_data f32[N,3], light_pdf f32[N], M i32[N], weight f32[N]).
+ * Each entry point cites the reference interface it replaces (file:line relative to the reference repo).
+ */
+#ifndef MIRRES_H
+#define MIRRES_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIRRES_OK 0
+#define MIRRES_E_ARG (-1)
+#define MIRRES_E_HIP (-2)
+#define MIRRES_E_STATE (-3)
+
+typedef struct mirres_bvh mirres_bvh_t; /* owns the traversal layout + build workspace  */
+typedef struct mirres_ctx mirres_ctx_t; /* owns per-frame-size ray queues + tables        */
+
+/* ReSTIR constants: load_m_for_restir defines (renderer_restir.py:151-181) + in-shader #defines
+ * (FinalShading.slang:7-9). max_bounce is a runtime parameter here (BASELINE config 5).                    */
+typedef struct mirres_config {
+    int light_tile_count;      /* 128  */
+    int light_tile_size;       /* 1024 */
+    int screen_tile_size;      /* 8    */
+    int initial_light_samples; /* 32   */
+    int initial_brdf_samples;  /* 1    */
+    int max_history;           /* 20   */
+    int neighbor_offset_count; /* 8192 */
+    int neighbor_count;        /* 5    */
+    float gather_radius;       /* 30   */
+    int max_bounce;            /* 2    */
+    float vis_near;            /* 0.01 */
+} mirres_config_t;
+void mirres_default_config(mirres_config_t* cfg);
+
+const char* mirres_version(void);
+const char* mirres_last_error(void);
+
+/* ------------------------------------------------------------------ LBVH  (restirbvhWorker, renderer_restir.py:13-94) */
+int mirres_bvh_create(mirres_bvh_t** out, int max_tris);
+void mirres_bvh_destroy(mirres_bvh_t* bvh);
+/* update_mesh + update_bvh (renderer_restir.py:25-94; kernels under nerf/bvhworkers). Writes the reference
+ * node arrays LBVHNode_info i32[2T-1,3] / LBVHNode_aabb f32[2T-1,6] and the internal traversal layout.
+ * sorted_codes i32[T,2] (code, elementIdx) may be NULL. No host synchronisation.                            */
+int mirres_bvh_build(mirres_bvh_t* bvh, const float* vert, int V, const int32_t* tri, int T, int32_t* info, float* aabb,
+                     int32_t* sorted_codes, void* stream);
+/* bvh_hit / bvh_hit_with_normal (utils/helperDi.slang:197-274, 313-395) over a batch of rays.
+ * rays f32[n,8] = (ox,oy,oz,t_min, dx,dy,dz,t_max). mode 0: any-hit (early exit; only `hit` is written),
+ * mode 1: closest by exhaustion in the reference's traversal order (hit,t,pos,normal,prim written; NULL skips).
+ * counters u32[n,4] (popped, entered-internal, leaves-tested, stack-overflow) may be NULL.                   */
+int mirres_bvh_trace(mirres_bvh_t* bvh, const float* rays, int n, int mode, int32_t* hit, float* t, float* pos, float* normal,
+                     int32_t* prim, uint32_t* counters, void* stream);
+
+/* ------------------------------------------------------------------ context (load_m_for_restir, renderer_restir.py:148-228) */
+int mirres_ctx_create(mirres_ctx_t** out, int fx, int fy, const mirres_config_t* cfg);
+void mirres_ctx_destroy(mirres_ctx_t* ctx);
+/* createNeighborOffsetTexture (make_sampleable.slang:186-205) / 127 -> f32[count,2]; ctx keeps a copy.      */
+int mirres_neighbor_offsets(mirres_ctx_t* ctx, float* out, void* stream);
+/* totals since the last reset: u64[8] = rays_any, rays_closest, popped, entered, leaves, overflow, -, - (host; synchronises) */
+int mirres_ctx_stats(mirres_ctx_t* ctx, uint64_t* h_out, int reset);
+int mirres_ctx_set_instrument(mirres_ctx_t* ctx, int on);
+
+/* ------------------------------------------------------------------ environment light */
+/* make_sampleable (GenerateLightTiles.py:4-29 + make_sampleable.slang:34-86). env_tex f32[Hc*Wc,3] is the
+ * vertically flipped, flattened map (renderer_restir.py:305-311). Outputs pdf[Hc*Wc], cdf[Hc*(Wc+1)], mpdf[Hc], mcdf[Hc+1]. */
+int mirres_env_make_sampleable(const float* env_tex, int Wc, int Hc, float* pdf, float* cdf, float* mpdf, float* mcdf, void* stream);
+/* GenerateLightTiles (GenerateLightTiles.py:31-52, GenerateLightTiles.slang:16-62).                          */
+int mirres_light_tiles(mirres_ctx_t* ctx, const float* env_tex, int Wc, int Hc, const float* pdf, const float* cdf, const float* mpdf,
+                       const float* mcdf, uint32_t frameIndex, float* light_data, int32_t* light_uv, float* light_inv_pdf, void* stream);
+
+typedef struct mirres_env { const float* tex; int Wc, Hc; const float *pdf, *cdf, *mpdf, *mcdf; } mirres_env_t;
+typedef struct mirres_gbuf { const float *occ, *pos, *normal_depth, *brdf, *ray_dir; } mirres_gbuf_t; /* [N],[N,3],[N,4],[N,3],[N,3] */
+typedef struct mirres_res { float* light_data; float* light_pdf; int32_t* M; float* weight; } mirres_res_t;
+
+/* ------------------------------------------------------------------ reservoir passes */
+/* restirbvhWorker.InitialResampling_ (renderer_restir.py:96-114; InitialResampling.slang:151-295)            */
+int mirres_restir_initial(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_env_t* env, const mirres_gbuf_t* g, const mirres_res_t* res,
+                          const float* light_data, const float* light_inv_pdf, uint32_t frameIndex, void* stream);
+/* TemporalResampling (Resampling.py:26-45; TemporalResampling.slang:23-135). motion may be NULL (= zeros).   */
+int mirres_restir_temporal(mirres_ctx_t* ctx, const mirres_env_t* env, const mirres_gbuf_t* g, const mirres_gbuf_t* prev_g,
+                           const mirres_res_t* res, const mirres_res_t* prev_res, const float* motion, uint32_t frameIndex, void* stream);
+/* restirbvhWorker.SpatialResampling_ (renderer_restir.py:116-131; SpatialResampling.slang:178-322)           */
+int mirres_restir_spatial(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_env_t* env, const mirres_gbuf_t* g, const mirres_res_t* res,
+                          const mirres_res_t* prev_res, const float* neighbor_offsets, uint32_t frameIndex, void* stream);
+/* restirbvhWorker.EvaluateFinalSamples_get_vis (renderer_restir.py:133-146; EvaluateFinalSamples.slang:84-124) */
+int mirres_restir_final_vis(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const float* pos, const mirres_res_t* res, float* vis_map, void* stream);
+/* EvaluateFinalSamples_di.forward/backward (Resampling.py:94-143; EvaluateFinalSamples.slang:129-188)        */
+int mirres_restir_eval_final(mirres_ctx_t* ctx, const mirres_env_t* env, const mirres_res_t* res, const float* vis_map, float* final_dir,
+                             float* final_dist, float* final_Li, void* stream);
+int mirres_restir_eval_final_bwd(mirres_ctx_t* ctx, const mirres_env_t* env, const mirres_res_t* res, const float* vis_map,
+                                 const float* grad_final_Li, float* grad_env /*[Hc*Wc,3], accumulated*/, void* stream);
+
+/* ------------------------------------------------------------------ shading / path tracing */
+/* FinalShading.forward/backward (Resampling.py:145-214; FinalShading.slang:14-109)                           */
+int mirres_final_shading(mirres_ctx_t* ctx, const mirres_env_t* env, const float* occ, const float* normal, const float* ray_dir,
+                         const float* kd, const float* rough_metal, const float* final_dir, const float* final_dist, const float* final_Li,
+                         float* color, float* diff_light, float* spec_light, void* stream);
+int mirres_final_shading_bwd(mirres_ctx_t* ctx, const float* occ, const float* normal, const float* ray_dir, const float* kd,
+                             const float* rough_metal, const float* final_dir, const float* final_dist, const float* final_Li,
+                             const float* g_color, const float* g_diff, const float* g_spec, float* g_normal, float* g_kd,
+                             float* g_rough_metal, float* g_final_Li, void* stream);
+typedef struct mirres_path {
+    const float *occ, *pos, *normal, *ray_dir, *kd, *rough_metal; /* vertex inputs                              */
+    float* prd;                                                   /* f32[N,5] throughput rgb, specularBounce, stop */
+    float *new_pos, *new_ray_d, *new_occ, *new_normal;            /* next-vertex outputs                        */
+} mirres_path_t;
+/* process_new_dir_for_pt (Resampling.py:216-232; FinalShading.slang:113-265)                                  */
+int mirres_pt_new_dir(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_path_t* p, uint32_t frameIndex, uint32_t bounce_count, void* stream);
+/* indirect_one_hit_divided_no_grad (Resampling.py:254-273; FinalShading.slang:641-1009). When acc_* are non-NULL
+ * the results are ADDED to them instead of overwriting color/diff/spec (fuses renderer_restir.py:420-422).     */
+int mirres_pt_bounce(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_env_t* env, const mirres_path_t* p, uint32_t frameIndex,
+                     uint32_t bounce_count, float* color, float* diff_color, float* spec_color, void* stream);
+
+/* ------------------------------------------------------------------ denoiser */
+/* EAWDenoise_run.forward / EAWDenoise_run_no_di (Denoising.py:10-60; EAWDenoise.slang:50-302)                 */
+int mirres_eaw(int fx, int fy, int step_width, float c_phi, float n_phi, float p_phi, const float* occ, const float* color,
+               const float* normal, const float* pos, float* out, void* stream);
+/* EAWDenoise_run.backward (Denoising.py:30-48): grads w.r.t. colour, normal and position are ACCUMULATED.      */
+int mirres_eaw_bwd(int fx, int fy, int step_width, float c_phi, float n_phi, float p_phi, const float* occ, const float* color,
+                   const float* normal, const float* pos, const float* grad_out, float* g_color, float* g_normal, float* g_pos, void* stream);
+
+/* ------------------------------------------------------------------ material field (MLPTexture3D, render_helper.py:53-124) */
+typedef struct mirres_matnet {
+    const uint16_t* grid_f16; /* fp16 hash-grid table, 6 299 960 x 2 entries (tcnn layout)                      */
+    const float *w0, *w1, *w2; /* torch Linear weights [32,32],[32,32],[6,32], row-major [out,in]                */
+    float aabb_min[3], aabb_max[3], out_min[6], out_max[6];
+} mirres_matnet_t;
+int mirres_matnet_grid_entries(void);                      /* 6 299 960                                        */
+int mirres_matnet_pack_grid(const float* params_f32, uint16_t* grid_f16, int64_t n, void* stream);
+/* MLPTexture3D.sample / sample_no_di: pos f32[n,3] -> out f32[n,6]; enc_out (fp16 bits [n,32]) may be NULL.     */
+int mirres_matnet_fwd(const mirres_matnet_t* m, const float* pos, int n, float* out, uint16_t* enc_out, void* stream);
+/* renderer_restir.py:398-408 fused: evaluate where occ>=0.5 and scatter kd / (roughness, metallic) in place.    */
+int mirres_matnet_scatter(const mirres_matnet_t* m, const float* occ, const float* pos, int n, float* kd, float* rough_metal,
+                          int use_scale, const float* h_scale3, void* stream);
+/* backward of sample(): grads to the fp32 master grid (atomic), MLP weights and nothing else.                    */
+int mirres_matnet_bwd(const mirres_matnet_t* m, const float* pos, int n, const float* grad_out, float* g_params_f32, float* g_w0,
+                      float* g_w1, float* g_w2, void* stream);
+
+/* ------------------------------------------------------------------ whole frame: run_restir_di_with_pt (renderer_restir.py:473-550) */
+typedef struct mirres_render_args {
+    int spp; uint32_t random_offset; /* np.random.randint(2**20) in the reference (renderer_restir.py:245)     */
+    int use_scale; float scale[3];
+    const float* env_map; int Wc, Hc; /* f32[Hc,Wc,3] as passed by the caller (not flipped)                     */
+    float* occ;                       /* f32[N]   modified in place (renderer_restir.py:484-485)                */
+    const float *normal, *depth, *kd, *rough_metal, *ray_dir, *pos;
+    const mirres_matnet_t* mat;       /* NULL -> const_kd / const_rm at indirect hits                           */
+    float const_kd[3], const_rm[2];
+    int denoise_iter, step_width; float c_phi, n_phi, p_phi;
+    float* outs[6];                   /* final_color, den_diffuse, den_spec, den_indirect, den_indirect_diff, den_indirect_spec */
+    int spp_begin, spp_end;           /* multi-GPU spp sharding: render samples [spp_begin, spp_end) and skip the
+                                         average/denoise/composite (raw sums are left in outs[0..5]); 0,0 = all  */
+    int y_begin, y_end;               /* reserved for strip sharding                                            */
+} mirres_render_args_t;
+int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args_t* a, void* stream);
+/* second half of run_restir_di_with_pt (:507-549) on already-summed accumulators (after an all-reduce).         */
+int mirres_render_finish(mirres_ctx_t* ctx, const mirres_render_args_t* a, float* sums[6], void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIRRES_H */

@@ -1,0 +1,59 @@
+"""Builds libmirres.so (gfx950) in-tree with hipcc. Incremental: one object per .hip, relinked when any object changes.
+
+    python mirres-restir_nerf_mesh_amd/csrc/build.py [--force]
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(os.path.dirname(HERE), "libmirres.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+# -ffp-contract=off: the traversal / reservoir decisions must not depend on the compiler's FMA choices (DESIGN.md §FP policy)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+         "-fgpu-rdc" if False else "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-but-set-variable",
+         "-I", os.path.join(HERE, "..", "..", "include")]
+
+
+def _newer(a, deps):
+    return (not os.path.exists(a)) or any(os.path.getmtime(d) > os.path.getmtime(a) for d in deps)
+
+
+def build(force=False, verbose=True):
+    srcs = sorted(f for f in os.listdir(HERE) if f.endswith(".hip"))
+    hdrs = [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith(".hpp")] + [os.path.join(HERE, "..", "..", "include", "mirres.h")]
+    objdir = os.path.join(HERE, "obj")
+    os.makedirs(objdir, exist_ok=True)
+    jobs = []
+    for s in srcs:
+        src = os.path.join(HERE, s)
+        obj = os.path.join(objdir, s[:-4] + ".o")
+        if force or _newer(obj, [src] + hdrs):
+            jobs.append((src, obj))
+
+    def cc(job):
+        src, obj = job
+        cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+        if verbose:
+            print("[mirres build]", os.path.basename(src), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
+        if verbose and r.stderr.strip():
+            print(r.stderr)
+    with ThreadPoolExecutor(max_workers=min(6, max(1, len(jobs)))) as ex:
+        list(ex.map(cc, jobs))
+    objs = [os.path.join(objdir, s[:-4] + ".o") for s in srcs]
+    if force or jobs or _newer(OUT, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+        if verbose:
+            print("[mirres build] linked", OUT)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,101 @@
+// device_math.hpp — gfx950 device-side scalar math for the ReSTIR path tracer.
+//
+// Floating-point contract (DESIGN.md §FP policy): fp32, IEEE division/sqrt (hipcc default
+// -fhip-fp32-correctly-rounded-divide-sqrt), FMA contraction OFF for the whole library (-ffp-contract=off) so
+// that traversal decisions are reproducible; explicit fmaf only where the algorithm asks for it (hash-grid
+// position, MLP accumulation = MFMA semantics). Formulas cite the reference Slang they implement.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MR_DEV __device__ __forceinline__
+
+namespace mr {
+
+struct v2 { float x, y; };
+struct v3 { float x, y, z; };
+
+MR_DEV v3 V3(float a, float b, float c) { v3 r; r.x = a; r.y = b; r.z = c; return r; }
+MR_DEV v3 V3(float a) { return V3(a, a, a); }
+MR_DEV v2 V2(float a, float b) { v2 r; r.x = a; r.y = b; return r; }
+MR_DEV v3 operator+(v3 a, v3 b) { return V3(a.x + b.x, a.y + b.y, a.z + b.z); }
+MR_DEV v3 operator-(v3 a, v3 b) { return V3(a.x - b.x, a.y - b.y, a.z - b.z); }
+MR_DEV v3 operator*(v3 a, v3 b) { return V3(a.x * b.x, a.y * b.y, a.z * b.z); }
+MR_DEV v3 operator*(v3 a, float s) { return V3(a.x * s, a.y * s, a.z * s); }
+MR_DEV v3 operator*(float s, v3 a) { return V3(s * a.x, s * a.y, s * a.z); }
+MR_DEV v3 operator/(v3 a, float s) { return V3(a.x / s, a.y / s, a.z / s); }
+MR_DEV v3 operator-(v3 a) { return V3(-a.x, -a.y, -a.z); }
+MR_DEV float dot(v3 a, v3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+MR_DEV float dot(v2 a, v2 b) { return a.x * b.x + a.y * b.y; }
+MR_DEV v3 cross(v3 a, v3 b) { return V3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+MR_DEV v3 normalize(v3 v) { float inv = 1.0f / sqrtf(dot(v, v)); return v * inv; }
+MR_DEV float saturate(float x) { return fminf(fmaxf(x, 0.f), 1.f); }
+MR_DEV float clampf(float x, float a, float b) { return fminf(fmaxf(x, a), b); }
+MR_DEV int clampi(int x, int a, int b) { return x < a ? a : (x > b ? b : x); }
+MR_DEV float lerpf(float a, float b, float t) { return a + (b - a) * t; }
+MR_DEV v3 reflect(v3 i, v3 n) { return i - n * (2.0f * dot(n, i)); }
+MR_DEV bool is_black(v3 v) { return !(v.x != 0.f) && !(v.y != 0.f) && !(v.z != 0.f); }
+MR_DEV float luminance(v3 v) { return v.x * 0.212671f + v.y * 0.715160f + v.z * 0.072169f; }  // helperDi.slang:104-107
+
+MR_DEV v3 ld3(const float* p, size_t i) { return V3(p[3 * i], p[3 * i + 1], p[3 * i + 2]); }
+MR_DEV void st3(float* p, size_t i, v3 v) { p[3 * i] = v.x; p[3 * i + 1] = v.y; p[3 * i + 2] = v.z; }
+
+// ---- RNG: TEA-16 seed + LCG stream (utils/random.slang:2-74)
+MR_DEV uint32_t interleave16(uint32_t vx, uint32_t vy) {
+    uint32_t x = vx & 0xffffu, y = vy & 0xffffu;
+    x = (x | (x << 8)) & 0x00FF00FFu; x = (x | (x << 4)) & 0x0F0F0F0Fu; x = (x | (x << 2)) & 0x33333333u; x = (x | (x << 1)) & 0x55555555u;
+    y = (y | (y << 8)) & 0x00FF00FFu; y = (y | (y << 4)) & 0x0F0F0F0Fu; y = (y | (y << 2)) & 0x33333333u; y = (y | (y << 1)) & 0x55555555u;
+    return x | (y << 1);
+}
+MR_DEV uint32_t seed_generator(uint32_t px, uint32_t py, uint32_t sampleNumber) {
+    uint32_t v0 = interleave16(px, py), v1 = sampleNumber, sum = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        sum += 0x9e3779b9u;
+        v0 += ((v1 << 4) + 0xa341316cu) ^ (v1 + sum) ^ ((v1 >> 5) + 0xc8013ea4u);
+        v1 += ((v0 << 4) + 0xad90777du) ^ (v0 + sum) ^ ((v0 >> 5) + 0x7e95761eu);
+    }
+    return v0;
+}
+MR_DEV float rnd(uint32_t& s) { s = 1664525u * s + 1013904223u; return (float)(s >> 8) * 0x1p-24f; }
+
+// ---- octahedral direction coding (helperDi.slang:109-134)
+MR_DEV v2 oct_encode(v3 n) {
+    float l1 = (fabsf(n.x) + fabsf(n.y)) + fabsf(n.z);
+    float nx = n.x / l1, ny = n.y / l1, nz = n.z / l1;
+    float wx = (1.0f - fabsf(ny)) * (nx >= 0.0f ? 1.0f : -1.0f);
+    float wy = (1.0f - fabsf(nx)) * (ny >= 0.0f ? 1.0f : -1.0f);
+    float ex = nz >= 0.0f ? nx : wx, ey = nz >= 0.0f ? ny : wy;
+    return V2(ex * 0.5f + 0.5f, ey * 0.5f + 0.5f);
+}
+MR_DEV v3 oct_decode(v2 f) {
+    float fx = f.x * 2.0f - 1.0f, fy = f.y * 2.0f - 1.0f;
+    v3 n = V3(fx, fy, (1.0f - fabsf(fx)) - fabsf(fy));
+    float t = clampf(-n.z, 0.0f, 1.0f);
+    n.x += (n.x >= 0.0f ? -t : t);
+    n.y += (n.y >= 0.0f ? -t : t);
+    return normalize(n);
+}
+MR_DEV v3 ngp_dir(v3 d) { return V3(-d.x, d.z, d.y); }  // lightDi.slang:432-436
+
+// ---- wave64 helpers
+MR_DEV int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+// compacted append: every lane with `want` gets a unique slot in [*counter, ...); one atomic per wave.
+MR_DEV uint32_t wave_append(uint32_t* counter, bool want, uint32_t n = 1) {
+    // n may differ per lane (exclusive prefix over the wave via shuffles)
+    uint32_t mine = want ? n : 0u;
+    uint32_t incl = mine;
+    const int lane = lane_id();
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+    }
+    uint32_t total = __shfl(incl, 63, 64);
+    uint32_t base = 0;
+    if (lane == 63 && total) base = atomicAdd(counter, total);
+    base = __shfl(base, 63, 64);
+    return base + incl - mine;
+}
+
+}  // namespace mr

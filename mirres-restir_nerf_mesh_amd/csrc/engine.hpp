@@ -1,0 +1,88 @@
+// engine.hpp — internal (non-ABI) declarations shared by the .hip translation units of libmirres.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/mirres.h"
+
+namespace mr {
+
+// ---- traversal layout (DESIGN.md §BVH layout). One 64-byte record per INTERNAL node holding both children's
+// boxes, so a node visit is a single 64 B fetch; leaves are not nodes: a negative child reference ~slot points
+// into the triangle table (slot = position in Morton order).
+struct __attribute__((aligned(64))) WideNode {
+    float lmin[3], lmax[3];
+    float rmin[3], rmax[3];
+    int32_t left, right;  // >=0 internal node index, <0 : ~leaf_slot
+    int32_t pad[2];
+};
+struct __attribute__((aligned(16))) TriRec {  // 48 B
+    float v0[3], e1[3], e2[3];
+    int32_t prim;
+    int32_t pad[2];
+};
+struct __attribute__((aligned(16))) Ray {  // 32 B  (ox,oy,oz,t_min, dx,dy,dz,t_max) — same as the ABI's rays[n,8]
+    float ox, oy, oz, tmin, dx, dy, dz, tmax;
+};
+struct __attribute__((aligned(16))) HitRec {  // 32 B closest-hit record
+    float px, py, pz; int32_t hit;
+    float nx, ny, nz; float t;
+};
+
+struct BvhView {
+    const WideNode* nodes; const TriRec* tris; const float* root_box;  // root_box -> aabb[0..5] of node 0
+    int T;
+};
+
+}  // namespace mr
+
+struct mirres_bvh {
+    int max_tris = 0, T = 0, V = 0;
+    // build workspace
+    float* ele_aabb = nullptr;      // [T,6]
+    uint32_t* extent = nullptr;     // [6] order-preserving uint encoding of min xyz / max xyz
+    uint32_t *keys_in = nullptr, *keys_out = nullptr, *vals_in = nullptr, *vals_out = nullptr;  // [T]
+    int32_t* parent = nullptr;      // [2T-1]
+    uint32_t* flags = nullptr;      // [T-1] refit arrival counters
+    void* sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
+    int32_t* own_info = nullptr; float* own_aabb = nullptr;  // used when the caller passes NULL
+    // traversal layout
+    mr::WideNode* nodes = nullptr;  // [T-1]
+    mr::TriRec* tris = nullptr;     // [T]
+    float* root_box = nullptr;      // [6]
+    mr::BvhView view() const { mr::BvhView v; v.nodes = nodes; v.tris = tris; v.root_box = root_box; v.T = T; return v; }
+};
+
+struct mirres_ctx {
+    int fx = 0, fy = 0; size_t N = 0;
+    mirres_config_t cfg;
+    // wavefront queues
+    mr::Ray* any_rays = nullptr;  size_t any_cap = 0;   // shadow rays (<= 10 per pixel in the spatial pass)
+    int32_t* any_hit = nullptr;
+    mr::Ray* cl_rays = nullptr;   size_t cl_cap = 0;    // closest-hit rays (<= 1 per pixel)
+    mr::HitRec* cl_hit = nullptr;
+    uint32_t* counters = nullptr;   // [8] device: any_count, closest_count, scratch...
+    unsigned long long* stats = nullptr;  // [8] device totals (see mirres_ctx_stats)
+    int instrument = 0;
+    // per-pixel scratch
+    int32_t* slot_a = nullptr;      // [N] first any-ray slot of the pixel (or -1)
+    uint32_t* mask_a = nullptr;     // [N] per-pass bit mask (spatial: accepted neighbours; bounce: ray kinds)
+    int32_t* slot_c = nullptr;      // [N] closest-ray slot (or -1)
+    float* pend = nullptr;          // [N,18] pending NEE / BSDF contributions of the bounce pass
+    float* noff = nullptr;          // [neighbor_offset_count,2]
+    // frame buffers of the fused loop (mirres_render)
+    float* pool = nullptr; size_t pool_floats = 0;
+};
+
+namespace mr {
+const char* set_error(const char* fmt, ...);
+int check_hip(hipError_t e, const char* what);
+#define MR_HIP(x) do { int _rc = mr::check_hip((x), #x); if (_rc) return _rc; } while (0)
+#define MR_LAUNCH_CHECK(name) MR_HIP(hipGetLastError())
+
+// queue tracing (bvh_trace.hip). count is read on the device; capacity bounds the grid-stride loop.
+int trace_any_queue(const mirres_bvh* bvh, const Ray* rays, const uint32_t* d_count, size_t capacity, int32_t* hit,
+                    unsigned long long* stats, hipStream_t s);
+int trace_closest_queue(const mirres_bvh* bvh, const Ray* rays, const uint32_t* d_count, size_t capacity, HitRec* out,
+                        unsigned long long* stats, hipStream_t s);
+inline int grid_for(size_t n, int block) { size_t g = (n + block - 1) / block; return (int)(g < 1 ? 1 : g); }
+}  // namespace mr

@@ -1,0 +1,332 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY. ctypes binding of oracle/liborc.so (the CPU restatement).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+PARITY UNPINNED: see oracle/orc_math.hpp.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+f32p = C.POINTER(C.c_float)
+i32p = C.POINTER(C.c_int32)
+u32p = C.POINTER(C.c_uint32)
+u16p = C.POINTER(C.c_uint16)
+u64p = C.POINTER(C.c_ulonglong)
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liborc.so")
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".cpp", ".hpp"))]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.orc_next1d.restype = C.c_float
+        _LIB.orc_f16_to_f32.restype = C.c_float
+        _LIB.orc_seed.restype = C.c_uint32
+        _LIB.orc_expand_bits.restype = C.c_uint32
+        _LIB.orc_morton3d.restype = C.c_uint32
+        _LIB.orc_morton3d.argtypes = [C.c_float] * 3
+        _LIB.orc_f32_to_f16.argtypes = [C.c_float]
+        _LIB.orc_f32_to_f16.restype = C.c_uint16
+    return _LIB
+
+
+def _p(a, t):
+    return None if a is None else a.ctypes.data_as(t)
+
+
+def _c(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+class Frame(C.Structure):
+    _fields_ = [("fx", C.c_int), ("fy", C.c_int),
+                ("occ", f32p), ("pos", f32p), ("normal_depth", f32p), ("brdf", f32p), ("ray_dir", f32p),
+                ("info", i32p), ("aabb", f32p), ("vert", f32p), ("tri", i32p),
+                ("env_tex", f32p), ("env_w", C.c_int), ("env_h", C.c_int),
+                ("pdf", f32p), ("cdf", f32p), ("mpdf", f32p), ("mcdf", f32p), ("max_bounce", C.c_int)]
+
+
+class Res(C.Structure):
+    _fields_ = [("light_data", f32p), ("light_pdf", f32p), ("M", i32p), ("weight", f32p)]
+
+
+class Path(C.Structure):
+    _fields_ = [(n, f32p) for n in ("occ", "pos", "normal", "ray_dir", "kd", "rs", "prd", "new_pos", "new_ray_d", "new_occ", "new_normal")]
+
+
+class MatNet(C.Structure):
+    _fields_ = [("params_f16", u16p), ("w0", f32p), ("w1", f32p), ("w2", f32p),
+                ("aabb_min", C.c_float * 3), ("aabb_max", C.c_float * 3), ("mn", C.c_float * 6), ("mx", C.c_float * 6)]
+
+
+class RenderArgs(C.Structure):
+    _fields_ = [("fx", C.c_int), ("fy", C.c_int), ("spp", C.c_int), ("random_offset", C.c_uint32), ("max_bounce", C.c_int),
+                ("use_scale", C.c_int), ("scale", C.c_float * 3),
+                ("info", i32p), ("aabb", f32p), ("vert", f32p), ("tri", i32p),
+                ("env_map", f32p), ("env_w", C.c_int), ("env_h", C.c_int),
+                ("occ", f32p), ("normal", f32p), ("depth", f32p), ("kd", f32p), ("rs", f32p), ("ray_dir", f32p), ("pos", f32p),
+                ("mat", C.POINTER(MatNet)), ("const_kd", C.c_float * 3), ("const_rs", C.c_float * 2),
+                ("denoise_iter", C.c_int), ("step_width", C.c_int), ("c_phi", C.c_float), ("n_phi", C.c_float), ("p_phi", C.c_float),
+                ("outs", f32p * 6), ("counters", u64p), ("ray_count", u64p), ("avg_direct", f32p)]
+
+
+# ------------------------------------------------------------------ scalar helpers
+def seed(px, py, n):
+    return int(lib().orc_seed(C.c_uint32(px), C.c_uint32(py), C.c_uint32(n)))
+
+
+def next1d(state):
+    s = C.c_uint32(state)
+    v = lib().orc_next1d(C.byref(s))
+    return float(v), int(s.value)
+
+
+def expand_bits(v):
+    return int(lib().orc_expand_bits(C.c_uint32(v)))
+
+
+def morton3d(x, y, z):
+    return int(lib().orc_morton3d(x, y, z))
+
+
+def oct_encode(n):
+    n = _c(n, np.float32); out = np.zeros(2, np.float32)
+    lib().orc_oct_encode(_p(n, f32p), _p(out, f32p)); return out
+
+
+def oct_decode(f):
+    f = _c(f, np.float32); out = np.zeros(3, np.float32)
+    lib().orc_oct_decode(_p(f, f32p), _p(out, f32p)); return out
+
+
+# ------------------------------------------------------------------ BVH
+def bvh_build(vert, tri):
+    vert = _c(vert, np.float32); tri = _c(tri, np.int32)
+    T = tri.shape[0]
+    info = np.zeros((2 * T - 1, 3), np.int32); aabb = np.zeros((2 * T - 1, 6), np.float32)
+    srt = np.zeros((T, 2), np.int32); mh = C.c_int(0)
+    rc = lib().orc_bvh_build(_p(vert, f32p), vert.shape[0], _p(tri, i32p), T, _p(info, i32p), _p(aabb, f32p), _p(srt, i32p), C.byref(mh))
+    assert rc == 0
+    return info, aabb, srt, mh.value
+
+
+def make_rays(o, d, tmin=0.0, tmax=1e7):
+    o = np.asarray(o, np.float32); d = np.asarray(d, np.float32)
+    n = o.shape[0]
+    r = np.zeros((n, 8), np.float32)
+    r[:, 0:3] = o; r[:, 3] = tmin; r[:, 4:7] = d; r[:, 7] = tmax
+    return r
+
+
+def trace(info, aabb, vert, tri, rays, want_normal=True, counters=False):
+    rays = _c(rays, np.float32); n = rays.shape[0]
+    hit = np.zeros(n, np.int32); t = np.zeros(n, np.float32); pos = np.zeros((n, 3), np.float32)
+    nrm = np.zeros((n, 3), np.float32); prim = np.zeros(n, np.int32)
+    cnt = np.zeros((n, 4), np.uint32) if counters else None
+    lib().orc_trace(_p(info, i32p), _p(aabb, f32p), _p(_c(vert, np.float32), f32p), _p(_c(tri, np.int32), i32p), _p(rays, f32p), n,
+                    int(want_normal), _p(hit, i32p), _p(t, f32p), _p(pos, f32p), _p(nrm, f32p), _p(prim, i32p), _p(cnt, u32p))
+    out = dict(hit=hit, t=t, pos=pos, normal=nrm, prim=prim)
+    if counters:
+        out["counters"] = cnt
+    return out
+
+
+# ------------------------------------------------------------------ environment
+def flip_env(env_map):
+    """renderer_restir.py:305-311: vertical flip + flatten to [Hc*Wc,3]."""
+    return np.ascontiguousarray(env_map[::-1].reshape(-1, 3), dtype=np.float32)
+
+
+def make_sampleable(tex_flat, W, H):
+    pdf = np.zeros(W * H, np.float32); cdf = np.zeros((W + 1) * H, np.float32); mpdf = np.zeros(H, np.float32); mcdf = np.zeros(H + 1, np.float32)
+    lib().orc_make_sampleable(_p(_c(tex_flat, np.float32), f32p), W, H, _p(pdf, f32p), _p(cdf, f32p), _p(mpdf, f32p), _p(mcdf, f32p))
+    return pdf, cdf, mpdf, mcdf
+
+
+def neighbor_offsets(count=8192):
+    out = np.zeros(2 * count, np.float32)
+    lib().orc_neighbor_offsets(count, _p(out, f32p))
+    return out.reshape(-1, 2)
+
+
+def env_le(tex_flat, W, H, dirs):
+    dirs = _c(dirs, np.float32); out = np.zeros_like(dirs)
+    lib().orc_env_le(_p(_c(tex_flat, np.float32), f32p), W, H, _p(dirs, f32p), dirs.shape[0], _p(out, f32p))
+    return out
+
+
+class Keep:
+    """Holds numpy arrays alive next to the ctypes struct that points into them."""
+    def __init__(self):
+        self.refs = []
+
+    def __call__(self, a, dt=np.float32):
+        a = _c(a, dt); self.refs.append(a); return a
+
+
+def make_frame(keep, fx, fy, occ, pos, normal_depth, brdf, ray_dir, bvh, vert, tri, env_tex, env_w, env_h, tables, max_bounce=2):
+    f = Frame()
+    f.fx, f.fy = fx, fy
+    f.occ = _p(keep(occ), f32p); f.pos = _p(keep(pos), f32p); f.normal_depth = _p(keep(normal_depth), f32p)
+    f.brdf = _p(keep(brdf), f32p); f.ray_dir = _p(keep(ray_dir), f32p)
+    f.info = _p(keep(bvh[0], np.int32), i32p); f.aabb = _p(keep(bvh[1]), f32p)
+    f.vert = _p(keep(vert), f32p); f.tri = _p(keep(tri, np.int32), i32p)
+    f.env_tex = _p(keep(env_tex), f32p); f.env_w, f.env_h = env_w, env_h
+    f.pdf, f.cdf, f.mpdf, f.mcdf = (_p(keep(t), f32p) for t in tables)
+    f.max_bounce = max_bounce
+    return f
+
+
+def new_reservoirs(N):
+    return [np.zeros((N, 3), np.float32), np.zeros(N, np.float32), np.zeros(N, np.int32), np.zeros(N, np.float32)]
+
+
+def res_struct(r):
+    s = Res(); s.light_data = _p(r[0], f32p); s.light_pdf = _p(r[1], f32p); s.M = _p(r[2], i32p); s.weight = _p(r[3], f32p); return s
+
+
+def light_tiles(frame, frameIndex, tile_count=128, tile_size=1024):
+    n = tile_count * tile_size
+    ld = np.zeros((n, 3), np.float32); uv = np.zeros((n, 2), np.int32); pdf = np.zeros(n, np.float32)
+    lib().orc_light_tiles(C.byref(frame), C.c_uint32(frameIndex), tile_count, tile_size, _p(ld, f32p), _p(uv, i32p), _p(pdf, f32p))
+    return ld, uv, pdf
+
+
+def initial(frame, res, tile_data, tile_pdf, frameIndex, counters=None):
+    rs = res_struct(res)
+    lib().orc_initial(C.byref(frame), C.byref(rs), _p(tile_data, f32p), _p(tile_pdf, f32p), C.c_uint32(frameIndex), _p(counters, u64p))
+
+
+def temporal(frame, res, prev, p_occ, p_nd, p_brdf, p_rd, frameIndex, motion=None):
+    rs, ps = res_struct(res), res_struct(prev)
+    lib().orc_temporal(C.byref(frame), C.byref(rs), C.byref(ps), _p(p_occ, f32p), _p(p_nd, f32p), _p(p_brdf, f32p), _p(p_rd, f32p),
+                       _p(motion, f32p), C.c_uint32(frameIndex))
+
+
+def spatial(frame, res, prev, noff, frameIndex, counters=None):
+    rs, ps = res_struct(res), res_struct(prev)
+    lib().orc_spatial(C.byref(frame), C.byref(rs), C.byref(ps), _p(noff, f32p), C.c_uint32(frameIndex), _p(counters, u64p))
+
+
+def final_vis(frame, res, counters=None):
+    N = frame.fx * frame.fy; vis = np.ones(N, np.float32); rs = res_struct(res)
+    lib().orc_final_vis(C.byref(frame), C.byref(rs), _p(vis, f32p), _p(counters, u64p))
+    return vis
+
+
+def eval_final(frame, res, vis):
+    N = frame.fx * frame.fy
+    fdir = np.zeros((N, 3), np.float32); fdist = np.zeros(N, np.float32); fLi = np.zeros((N, 3), np.float32); rs = res_struct(res)
+    lib().orc_eval_final(C.byref(frame), C.byref(rs), _p(vis, f32p), _p(fdir, f32p), _p(fdist, f32p), _p(fLi, f32p))
+    return fdir, fdist, fLi
+
+
+def final_shading(frame, normal, kd, rs_map, fdir, fdist, fLi):
+    N = frame.fx * frame.fy
+    c = np.zeros((N, 3), np.float32); d = np.zeros((N, 3), np.float32); s = np.zeros((N, 3), np.float32)
+    lib().orc_final_shading(C.byref(frame), _p(_c(normal, np.float32), f32p), _p(_c(kd, np.float32), f32p), _p(_c(rs_map, np.float32), f32p),
+                            _p(fdir, f32p), _p(fdist, f32p), _p(fLi, f32p), _p(c, f32p), _p(d, f32p), _p(s, f32p))
+    return c, d, s
+
+
+def path_struct(occ, pos, normal, ray_dir, kd, rs, prd, new_pos, new_ray_d, new_occ, new_normal):
+    p = Path()
+    for n, a in zip(("occ", "pos", "normal", "ray_dir", "kd", "rs", "prd", "new_pos", "new_ray_d", "new_occ", "new_normal"),
+                    (occ, pos, normal, ray_dir, kd, rs, prd, new_pos, new_ray_d, new_occ, new_normal)):
+        assert a.dtype == np.float32 and a.flags.c_contiguous
+        setattr(p, n, _p(a, f32p))
+    return p
+
+
+def new_dir(frame, path, frameIndex, bounce_count=0, counters=None):
+    lib().orc_new_dir(C.byref(frame), C.byref(path), C.c_uint32(frameIndex), C.c_uint32(bounce_count), _p(counters, u64p))
+
+
+def bounce(frame, path, frameIndex, bounce_count, counters=None):
+    N = frame.fx * frame.fy
+    c = np.zeros((N, 3), np.float32); d = np.zeros((N, 3), np.float32); s = np.zeros((N, 3), np.float32)
+    lib().orc_bounce(C.byref(frame), C.byref(path), C.c_uint32(frameIndex), C.c_uint32(bounce_count), _p(c, f32p), _p(d, f32p), _p(s, f32p), _p(counters, u64p))
+    return c, d, s
+
+
+def eaw(fx, fy, step, c_phi, n_phi, p_phi, occ, color, normal, pos):
+    out = np.zeros((fx * fy, 3), np.float32)
+    lib().orc_eaw(fx, fy, int(step), C.c_float(c_phi), C.c_float(n_phi), C.c_float(p_phi), _p(_c(occ, np.float32), f32p), _p(_c(color, np.float32), f32p),
+                  _p(_c(normal, np.float32), f32p), _p(_c(pos, np.float32), f32p), _p(out, f32p))
+    return out
+
+
+# ------------------------------------------------------------------ material field
+def hashgrid_layout():
+    off = np.zeros(17, np.uint32); res = np.zeros(16, np.uint32); sc = np.zeros(16, np.float32)
+    total = lib().orc_hashgrid_layout(_p(off, u32p), _p(res, u32p), _p(sc, f32p))
+    return total, off, res, sc
+
+
+def to_f16_bits(a):
+    a = _c(a, np.float32).ravel(); out = np.zeros(a.size, np.uint16)
+    lib().orc_f32_to_f16_array(_p(a, f32p), _p(out, u16p), C.c_longlong(a.size))
+    return out
+
+
+def matnet_struct(keep, params_f32, w0, w1, w2, aabb_min, aabb_max, mn, mx):
+    m = MatNet()
+    m.params_f16 = _p(keep(to_f16_bits(params_f32), np.uint16), u16p)
+    m.w0 = _p(keep(w0), f32p); m.w1 = _p(keep(w1), f32p); m.w2 = _p(keep(w2), f32p)
+    m.aabb_min[:] = list(map(float, aabb_min)); m.aabb_max[:] = list(map(float, aabb_max))
+    m.mn[:] = list(map(float, mn)); m.mx[:] = list(map(float, mx))
+    return m
+
+
+def hashgrid_encode(mat, x01):
+    x01 = _c(x01, np.float32); n = x01.shape[0]; out = np.zeros((n, 32), np.uint16)
+    lib().orc_hashgrid_encode(C.byref(mat), _p(x01, f32p), n, _p(out, u16p))
+    return out
+
+
+def matnet(mat, pos):
+    pos = _c(pos, np.float32); n = pos.shape[0]; out = np.zeros((n, 6), np.float32)
+    lib().orc_matnet(C.byref(mat), _p(pos, f32p), n, _p(out, f32p))
+    return out
+
+
+# ------------------------------------------------------------------ whole frame
+def render(fx, fy, spp, random_offset, bvh, vert, tri, env_map, occ, normal, depth, kd, rs, ray_dir, pos, mat=None, max_bounce=2,
+           use_scale=False, scale=(1, 1, 1), denoise_iter=2, step_width=2, c_phi=2.0, n_phi=0.1, p_phi=0.001, want_avg=False,
+           const_kd=(0.6, 0.6, 0.6), const_rs=(0.5, 0.0)):
+    keep = Keep(); N = fx * fy
+    a = RenderArgs()
+    a.fx, a.fy, a.spp, a.random_offset, a.max_bounce = fx, fy, spp, random_offset, max_bounce
+    a.use_scale = int(use_scale); a.scale[:] = list(map(float, scale))
+    a.info = _p(keep(bvh[0], np.int32), i32p); a.aabb = _p(keep(bvh[1]), f32p); a.vert = _p(keep(vert), f32p); a.tri = _p(keep(tri, np.int32), i32p)
+    env_map = keep(env_map); a.env_map = _p(env_map, f32p); a.env_h, a.env_w = env_map.shape[0], env_map.shape[1]
+    occ = keep(np.array(occ, np.float32).reshape(-1).copy()); a.occ = _p(occ, f32p)
+    a.normal = _p(keep(normal), f32p); a.depth = _p(keep(depth), f32p); a.kd = _p(keep(kd), f32p); a.rs = _p(keep(rs), f32p)
+    a.ray_dir = _p(keep(ray_dir), f32p); a.pos = _p(keep(pos), f32p)
+    a.mat = C.pointer(mat) if mat is not None else None
+    a.const_kd[:] = list(map(float, const_kd)); a.const_rs[:] = list(map(float, const_rs))
+    a.denoise_iter, a.step_width, a.c_phi, a.n_phi, a.p_phi = denoise_iter, step_width, c_phi, n_phi, p_phi
+    outs = [np.zeros((N, 3), np.float32) for _ in range(6)]
+    for i in range(6):
+        a.outs[i] = _p(outs[i], f32p)
+    cnt = np.zeros(4, np.uint64); a.counters = _p(cnt, u64p); a.ray_count = None
+    avg = np.zeros((N, 3), np.float32) if want_avg else None
+    a.avg_direct = _p(avg, f32p)
+    rc = lib().orc_render(C.byref(a)); assert rc == 0
+    return dict(final_color=outs[0], diffuse=outs[1], spec=outs[2], indirect=outs[3], indirect_diff=outs[4], indirect_spec=outs[5],
+                counters=cnt, occ=occ, avg_direct=avg)
+
+
+def num_threads():
+    return int(lib().orc_num_threads())
