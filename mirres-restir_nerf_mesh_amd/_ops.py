@@ -1,0 +1,107 @@
+"""Thin torch<->C-ABI glue shared by the reference-shaped modules. Every function enqueues on the current torch stream."""
+import ctypes as C
+import torch
+
+from . import _lib
+from ._lib import lib, check, ptr, stream_ptr
+
+
+class Module:
+    """Stands in for a slangpy module handle (`m`) of the reference: an opaque token that carries the engine context."""
+
+    def __init__(self, name, ctx):
+        self.name = name
+        self.ctx = ctx
+
+    def __repr__(self):
+        return "<mirres module %s>" % self.name
+
+
+class Context:
+    def __init__(self, fx, fy, cfg=None):
+        self.fx, self.fy, self.N = int(fx), int(fy), int(fx) * int(fy)
+        self.cfg = cfg if cfg is not None else _lib.default_config()
+        h = C.c_void_p()
+        check(lib().mirres_ctx_create(C.byref(h), self.fx, self.fy, C.byref(self.cfg)), "mirres_ctx_create")
+        self.h = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                lib().mirres_ctx_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def stats(self, reset=False):
+        out = (C.c_uint64 * 8)()
+        check(lib().mirres_ctx_stats(self.h, out, int(reset)), "mirres_ctx_stats")
+        v = list(out)
+        return dict(rays_any=v[0], rays_closest=v[1], popped=v[2], entered=v[3], leaves=v[4])
+
+    def set_instrument(self, on):
+        check(lib().mirres_ctx_set_instrument(self.h, int(on)), "mirres_ctx_set_instrument")
+
+
+_CTX_CACHE = {}
+
+
+def get_ctx(fx, fy, max_bounce=None):
+    key = (int(fx), int(fy), max_bounce)
+    if key not in _CTX_CACHE:
+        cfg = _lib.default_config()
+        if max_bounce is not None:
+            cfg.max_bounce = int(max_bounce)
+        _CTX_CACHE[key] = Context(fx, fy, cfg)
+    return _CTX_CACHE[key]
+
+
+def _f32(t):
+    if t.dtype != torch.float32 or not t.is_cuda:
+        raise _lib.MirresError("expected a CUDA float32 tensor, got %s on %s" % (t.dtype, t.device))
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def env_struct(env_tex, width, height, pdf_, cdf_, mpdf_, mcdf_, keep):
+    e = _lib.Env()
+    for name, t in (("tex", env_tex), ("pdf", pdf_), ("cdf", cdf_), ("mpdf", mpdf_), ("mcdf", mcdf_)):
+        if t is not None:
+            t = _f32(t); keep.append(t)
+            setattr(e, name, t.data_ptr())
+    e.Wc, e.Hc = int(width), int(height)
+    return e
+
+
+def gbuf_struct(occ, pos, normal_depth, brdf, ray_dir, keep):
+    g = _lib.GBuf()
+    for name, t in (("occ", occ), ("pos", pos), ("normal_depth", normal_depth), ("brdf", brdf), ("ray_dir", ray_dir)):
+        if t is not None:
+            t = _f32(t); keep.append(t)
+            setattr(g, name, t.data_ptr())
+    return g
+
+
+def res_struct(reservoirs, keep):
+    ld, pdf, M, w = reservoirs
+    if M.dtype != torch.int32:
+        raise _lib.MirresError("reservoir M must be int32")
+    for t in (ld, pdf, M, w):
+        if not t.is_contiguous():
+            raise _lib.MirresError("reservoir tensors are mutated in place and must be contiguous")
+    keep.extend([ld, pdf, M, w])
+    r = _lib.Res()
+    r.light_data, r.light_pdf, r.M, r.weight = ld.data_ptr(), pdf.data_ptr(), M.data_ptr(), w.data_ptr()
+    return r
+
+
+def path_struct(occ, pos, normal, ray_dir, kd, rm, prd, new_pos, new_ray_d, new_occ, new_normal, keep):
+    p = _lib.Path()
+    ins = (("occ", occ), ("pos", pos), ("normal", normal), ("ray_dir", ray_dir), ("kd", kd), ("rough_metal", rm))
+    outs = (("prd", prd), ("new_pos", new_pos), ("new_ray_d", new_ray_d), ("new_occ", new_occ), ("new_normal", new_normal))
+    for name, t in ins:
+        t = _f32(t); keep.append(t); setattr(p, name, t.data_ptr())
+    for name, t in outs:
+        if not t.is_contiguous() or t.dtype != torch.float32:
+            raise _lib.MirresError("%s is written in place and must be a contiguous float32 tensor" % name)
+        keep.append(t); setattr(p, name, t.data_ptr())
+    return p

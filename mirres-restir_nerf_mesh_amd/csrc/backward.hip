@@ -1,0 +1,295 @@
+// backward.hip — adjoints that the reference obtains from Slang autodiff / torch autograd, written by hand for gfx950:
+//   * mirres_final_shading_bwd : process_FinalShading.bwd (Resampling.py:179-214) — per-pixel forward-mode Jacobian
+//     (dual numbers, 3 partials per sweep over the input groups normal / kd / (roughness, metallic) / Li) contracted with
+//     the incoming cotangents. Same branch selection as the forward kernel, so it is the derivative of exactly what ran.
+//   * mirres_matnet_bwd        : backward of MLPTexture3D.sample (render_helper.py:93-104): fp32 MLP weight gradients
+//     (block-level LDS reduction, then one atomic per weight per block) and hash-grid gradients scattered with fp32 atomics
+//     into the fp32 master table (tcnn accumulates its grid gradient the same way).
+#include "engine.hpp"
+#include "device_math.hpp"
+#include <hip/hip_fp16.h>
+#include <cmath>
+
+namespace mr {
+
+#define MR_BLOCK 256
+
+// ---------------------------------------------------------------- dual numbers
+template <int NP> struct Dual { float v; float d[NP]; };
+template <int NP> MR_DEV Dual<NP> mk(float v) { Dual<NP> r; r.v = v;
+#pragma unroll
+    for (int i = 0; i < NP; i++) r.d[i] = 0.f; return r; }
+template <int NP> MR_DEV Dual<NP> operator+(Dual<NP> a, Dual<NP> b) { Dual<NP> r; r.v = a.v + b.v;
+#pragma unroll
+    for (int i = 0; i < NP; i++) r.d[i] = a.d[i] + b.d[i]; return r; }
+template <int NP> MR_DEV Dual<NP> operator-(Dual<NP> a, Dual<NP> b) { Dual<NP> r; r.v = a.v - b.v;
+#pragma unroll
+    for (int i = 0; i < NP; i++) r.d[i] = a.d[i] - b.d[i]; return r; }
+template <int NP> MR_DEV Dual<NP> operator-(Dual<NP> a) { Dual<NP> r; r.v = -a.v;
+#pragma unroll
+    for (int i = 0; i < NP; i++) r.d[i] = -a.d[i]; return r; }
+template <int NP> MR_DEV Dual<NP> operator*(Dual<NP> a, Dual<NP> b) { Dual<NP> r; r.v = a.v * b.v;
+#pragma unroll
+    for (int i = 0; i < NP; i++) r.d[i] = a.d[i] * b.v + a.v * b.d[i]; return r; }
+template <int NP> MR_DEV Dual<NP> operator*(Dual<NP> a, float s) { Dual<NP> r; r.v = a.v * s;
+#pragma unroll
+    for (int i = 0; i < NP; i++) r.d[i] = a.d[i] * s; return r; }
+template <int NP> MR_DEV Dual<NP> operator*(float s, Dual<NP> a) { return a * s; }
+template <int NP> MR_DEV Dual<NP> operator+(Dual<NP> a, float s) { a.v += s; return a; }
+template <int NP> MR_DEV Dual<NP> operator+(float s, Dual<NP> a) { a.v += s; return a; }
+template <int NP> MR_DEV Dual<NP> operator-(float s, Dual<NP> a) { return mk<NP>(s) - a; }
+template <int NP> MR_DEV Dual<NP> operator-(Dual<NP> a, float s) { a.v -= s; return a; }
+template <int NP> MR_DEV Dual<NP> operator/(Dual<NP> a, Dual<NP> b) { Dual<NP> r; r.v = a.v / b.v; float ib = 1.0f / b.v;
+#pragma unroll
+    for (int i = 0; i < NP; i++) r.d[i] = (a.d[i] - r.v * b.d[i]) * ib; return r; }
+template <int NP> MR_DEV Dual<NP> operator/(float s, Dual<NP> b) { return mk<NP>(s) / b; }
+template <int NP> MR_DEV Dual<NP> operator/(Dual<NP> a, float s) { return a * (1.0f / s); }
+template <int NP> MR_DEV Dual<NP> dsqrt(Dual<NP> a) { Dual<NP> r; r.v = sqrtf(a.v); float k = a.v > 0.f ? 0.5f / r.v : 0.f;
+#pragma unroll
+    for (int i = 0; i < NP; i++) r.d[i] = a.d[i] * k; return r; }
+template <int NP> MR_DEV Dual<NP> dmax0(Dual<NP> a) { return a.v > 0.f ? a : mk<NP>(0.f); }  // max(a, 0)
+template <int NP> MR_DEV Dual<NP> dpow5(Dual<NP> a) { Dual<NP> r; float a2 = a.v * a.v; r.v = a2 * a2 * a.v; float k = 5.f * a2 * a2;
+#pragma unroll
+    for (int i = 0; i < NP; i++) r.d[i] = a.d[i] * k; return r; }
+
+template <int NP> struct D3 { Dual<NP> x, y, z; };
+template <int NP> MR_DEV D3<NP> mk3(v3 v) { D3<NP> r; r.x = mk<NP>(v.x); r.y = mk<NP>(v.y); r.z = mk<NP>(v.z); return r; }
+template <int NP> MR_DEV Dual<NP> ddot(D3<NP> a, D3<NP> b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+template <int NP> MR_DEV D3<NP> operator+(D3<NP> a, D3<NP> b) { D3<NP> r; r.x = a.x + b.x; r.y = a.y + b.y; r.z = a.z + b.z; return r; }
+template <int NP> MR_DEV D3<NP> operator*(D3<NP> a, Dual<NP> s) { D3<NP> r; r.x = a.x * s; r.y = a.y * s; r.z = a.z * s; return r; }
+template <int NP> MR_DEV D3<NP> operator*(D3<NP> a, D3<NP> b) { D3<NP> r; r.x = a.x * b.x; r.y = a.y * b.y; r.z = a.z * b.z; return r; }
+
+template <int NP> MR_DEV Dual<NP> d_lambda(Dual<NP> a2, Dual<NP> c) {  // evalLambdaGGX brdfDi.slang:40-47
+    if (c.v <= 0) return mk<NP>(0.f);
+    Dual<NP> c2 = c * c;
+    Dual<NP> tan2 = dmax0(1.0f - c2) / c2;
+    return 0.5f * (-1.0f + dsqrt(1.0f + a2 * tan2));
+}
+
+// process_FinalShading (FinalShading.slang:14-109) on dual numbers. GROUP selects which inputs carry unit partials:
+// 0 normal, 1 kd, 2 (roughness, metallic, -), 3 Li.
+template <int GROUP>
+MR_DEV void shade_dual(v3 n_, v3 rd, v3 kd_, float rough_, float metal_, v3 dir, v3 Li_, D3<3>& color, D3<3>& dl, D3<3>& sl) {
+    constexpr int NP = 3;
+    D3<NP> n = mk3<NP>(n_), kd = mk3<NP>(kd_), Li = mk3<NP>(Li_);
+    Dual<NP> rough = mk<NP>(rough_), metal = mk<NP>(metal_);
+    if (GROUP == 0) { n.x.d[0] = 1.f; n.y.d[1] = 1.f; n.z.d[2] = 1.f; }
+    if (GROUP == 1) { kd.x.d[0] = 1.f; kd.y.d[1] = 1.f; kd.z.d[2] = 1.f; }
+    if (GROUP == 2) { rough.d[0] = 1.f; metal.d[1] = 1.f; }
+    if (GROUP == 3) { Li.x.d[0] = 1.f; Li.y.d[1] = 1.f; Li.z.d[2] = 1.f; }
+    // create_frame (helperDi.slang:18-28)
+    const float sign = (n.z.v > 0) ? 1.0f : -1.0f;
+    Dual<NP> a = -1.0f / (sign + n.z);
+    Dual<NP> b = n.x * n.y * a;
+    D3<NP> fx, fy;
+    fx.x = 1.0f + sign * (n.x * n.x * a); fx.y = sign * b; fx.z = -sign * n.x;
+    fy.x = b; fy.y = sign + n.y * n.y * a; fy.z = -n.y;
+    D3<NP> mrd = mk3<NP>(-rd), dd = mk3<NP>(dir);
+    D3<NP> wi, wo;
+    wi.x = ddot(fx, mrd); wi.y = ddot(fy, mrd); wi.z = ddot(n, mrd);
+    wo.x = ddot(fx, dd); wo.y = ddot(fy, dd); wo.z = ddot(n, dd);
+    // lobes (only gate the terms)
+    D3<NP> specular;
+    specular.x = 0.04f * (1.0f - metal) + kd.x * metal; specular.y = 0.04f * (1.0f - metal) + kd.y * metal; specular.z = 0.04f * (1.0f - metal) + kd.z * metal;
+    Dual<NP> alpha = rough * rough;
+    if (alpha.v < 0.01f * 0.01f) alpha = mk<NP>(0.f);
+    float pD = luminance(kd_) * (1.f - metal_);
+    float cosv = dot(-rd, n_);
+    float p5 = powf(fmaxf(1 - cosv, 0), 5);
+    v3 sp_ = V3(0.04f) * (1.0f - metal_) + kd_ * metal_;
+    float pS = luminance(V3(sp_.x + (1 - sp_.x) * p5, sp_.y + (1 - sp_.y) * p5, sp_.z + (1 - sp_.z) * p5)) * (metal_ + (1.f - metal_));
+    D3<NP> dv = mk3<NP>(V3(0.f)), sv = mk3<NP>(V3(0.f));
+    const bool low = fminf(wi.z.v, wo.z.v) < 1e-6f;
+    if (pD > 0.f && !low) {
+        Dual<NP> f = wo.z * 0.31830988f;
+        if (!(f.v > 0.f)) f = mk<NP>(fmaxf(f.v, 0.f));
+        dv = Li * f;
+    }
+    if (pS > 0.f && !low && alpha.v != 0.f) {
+        D3<NP> hs = wi + wo;
+        Dual<NP> inv = 1.0f / dsqrt(ddot(hs, hs));
+        D3<NP> h = hs * inv;
+        Dual<NP> woDotH = ddot(wi, h);
+        Dual<NP> a2 = alpha * alpha;
+        Dual<NP> dd_ = ((h.z * a2 - h.z) * h.z + 1.0f);
+        Dual<NP> Dn = a2 / (dd_ * dd_ * 3.141592653589793f);
+        Dual<NP> G = 1.0f / (1.0f + d_lambda(a2, wi.z) + d_lambda(a2, wo.z));
+        Dual<NP> pw = dpow5(dmax0(1.0f - woDotH));
+        D3<NP> F;
+        F.x = specular.x + (1.0f - specular.x) * pw; F.y = specular.y + (1.0f - specular.y) * pw; F.z = specular.z + (1.0f - specular.z) * pw;
+        Dual<NP> k = Dn * G * 0.25f / wi.z;
+        sv = (F * k) * Li;
+    }
+    Dual<NP> om = 1.0f - metal;
+    color.x = kd.x * om * dv.x + sv.x; color.y = kd.y * om * dv.y + sv.y; color.z = kd.z * om * dv.z + sv.z;
+    dl = dv; sl = sv;
+}
+
+template <int GROUP>
+MR_DEV v3 contract(v3 n, v3 rd, v3 kd, float rough, float metal, v3 dir, v3 Li, v3 gc, v3 gd, v3 gs) {
+    D3<3> c, dl, sl;
+    shade_dual<GROUP>(n, rd, kd, rough, metal, dir, Li, c, dl, sl);
+    float o[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+        o[j] = (gc.x * c.x.d[j] + gc.y * c.y.d[j] + gc.z * c.z.d[j]) + (gd.x * dl.x.d[j] + gd.y * dl.y.d[j] + gd.z * dl.z.d[j]) +
+               (gs.x * sl.x.d[j] + gs.y * sl.y.d[j] + gs.z * sl.z.d[j]);
+    return V3(o[0], o[1], o[2]);
+}
+
+__global__ void __launch_bounds__(MR_BLOCK) k_final_shading_bwd(int N, const float* __restrict__ occ, const float* __restrict__ normal,
+                                                                const float* __restrict__ ray_dir, const float* __restrict__ kd, const float* __restrict__ rm,
+                                                                const float* __restrict__ fdir, const float* __restrict__ fdist, const float* __restrict__ fLi,
+                                                                const float* __restrict__ g_color, const float* __restrict__ g_diff, const float* __restrict__ g_spec,
+                                                                float* __restrict__ g_normal, float* __restrict__ g_kd, float* __restrict__ g_rm, float* __restrict__ g_Li) {
+    const int pi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pi >= N) return;
+    v3 gn = V3(0.f), gk = V3(0.f), gr = V3(0.f), gl = V3(0.f);
+    if (occ[pi] > 0.1f && fdist[pi] > 0.f) {
+        const v3 n = ld3(normal, pi), rd = ld3(ray_dir, pi), k = ld3(kd, pi), dir = ld3(fdir, pi), Li = ld3(fLi, pi);
+        const float rough = rm[2 * (size_t)pi], metal = rm[2 * (size_t)pi + 1];
+        const v3 gc = ld3(g_color, pi), gd = ld3(g_diff, pi), gs = ld3(g_spec, pi);
+        if (g_normal) gn = contract<0>(n, rd, k, rough, metal, dir, Li, gc, gd, gs);
+        if (g_kd) gk = contract<1>(n, rd, k, rough, metal, dir, Li, gc, gd, gs);
+        if (g_rm) gr = contract<2>(n, rd, k, rough, metal, dir, Li, gc, gd, gs);
+        if (g_Li) gl = contract<3>(n, rd, k, rough, metal, dir, Li, gc, gd, gs);
+    }
+    if (g_normal) st3(g_normal, pi, gn);
+    if (g_kd) st3(g_kd, pi, gk);
+    if (g_rm) { g_rm[2 * (size_t)pi] = gr.x; g_rm[2 * (size_t)pi + 1] = gr.y; }
+    if (g_Li) st3(g_Li, pi, gl);
+}
+
+// ---------------------------------------------------------------- material-field backward
+#define MR_LEVELS 16
+struct GridLevelsB { float scale[MR_LEVELS]; uint32_t res[MR_LEVELS]; uint32_t size[MR_LEVELS]; uint32_t offset[MR_LEVELS]; };
+static GridLevelsB host_levels_b() {
+    GridLevelsB L;
+    const float log2_pls = log2f(1.4472692012786865f);
+    uint32_t offset = 0;
+    for (int i = 0; i < MR_LEVELS; i++) {
+        float scale = exp2f(i * log2_pls) * 16 - 1.0f;
+        uint32_t res = (uint32_t)ceilf(scale) + 1;
+        uint64_t dense = (uint64_t)res * res * res;
+        uint32_t params = dense > 0x7fffffffull ? 0x7fffffffu : (uint32_t)dense;
+        params = (params + 7u) / 8u * 8u;
+        if (params > (1u << 19)) params = 1u << 19;
+        L.scale[i] = scale; L.res[i] = res; L.size[i] = params; L.offset[i] = offset;
+        offset += params;
+    }
+    return L;
+}
+MR_DEV uint32_t grid_index_b(uint32_t size, uint32_t res, uint32_t px, uint32_t py, uint32_t pz) {
+    uint32_t stride = 1, index = 0;
+    if (stride <= size) { index += px * stride; stride *= res; }
+    if (stride <= size) { index += py * stride; stride *= res; }
+    if (stride <= size) { index += pz * stride; stride *= res; }
+    if (size < stride) index = (px * 1u) ^ (py * 2654435761u) ^ (pz * 805459861u);
+    return index % size;
+}
+
+struct MatNetB { const __half2* grid; const float *w0, *w1, *w2; float aabb_min[3], aabb_max[3], mn[6], mx[6]; };
+
+__global__ void __launch_bounds__(MR_BLOCK) k_matnet_bwd(MatNetB M, GridLevelsB L, const float* __restrict__ pos, int n, const float* __restrict__ gout,
+                                                         float* __restrict__ g_params, float* __restrict__ g_w0, float* __restrict__ g_w1, float* __restrict__ g_w2) {
+    __shared__ float sw0[1024], sw1[1024], sw2[192];
+    __shared__ float gw0[1024], gw1[1024], gw2[192];
+    for (int i = threadIdx.x; i < 1024; i += blockDim.x) { sw0[i] = M.w0[i]; sw1[i] = M.w1[i]; gw0[i] = 0.f; gw1[i] = 0.f; }
+    for (int i = threadIdx.x; i < 192; i += blockDim.x) { sw2[i] = M.w2[i]; gw2[i] = 0.f; }
+    __syncthreads();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        float x[3];
+#pragma unroll
+        for (int d = 0; d < 3; d++) x[d] = fminf(fmaxf((pos[3 * (size_t)i + d] - M.aabb_min[d]) / (M.aabb_max[d] - M.aabb_min[d]), 0.f), 1.f);
+        // forward recompute
+        float a0[32];
+        for (int lv = 0; lv < MR_LEVELS; lv++) {
+            const float scale = L.scale[lv]; const uint32_t res = L.res[lv], size = L.size[lv];
+            const __half2* g = M.grid + L.offset[lv];
+            float p[3]; uint32_t pg[3];
+#pragma unroll
+            for (int d = 0; d < 3; d++) { float q = fmaf(scale, x[d], 0.5f); float fl = floorf(q); pg[d] = (uint32_t)(int)fl; p[d] = q - fl; }
+            __half r0 = __float2half(0.f), r1 = __float2half(0.f);
+#pragma unroll
+            for (uint32_t idx = 0; idx < 8; idx++) {
+                float w = 1.f; uint32_t pl[3];
+#pragma unroll
+                for (int d = 0; d < 3; d++) { if ((idx & (1u << d)) == 0) { w *= 1 - p[d]; pl[d] = pg[d]; } else { w *= p[d]; pl[d] = pg[d] + 1; } }
+                const __half2 v = g[grid_index_b(size, res, pl[0], pl[1], pl[2])];
+                r0 = __hadd(r0, __float2half(w * __low2float(v))); r1 = __hadd(r1, __float2half(w * __high2float(v)));
+            }
+            a0[2 * lv] = __half2float(r0); a0[2 * lv + 1] = __half2float(r1);
+        }
+        float h1[32], h2[32], z2[6];
+        for (int o = 0; o < 32; o++) { float acc = 0.f; for (int k = 0; k < 32; k++) acc = fmaf(a0[k], sw0[o * 32 + k], acc); h1[o] = fmaxf(acc, 0.f); }
+        for (int o = 0; o < 32; o++) { float acc = 0.f; for (int k = 0; k < 32; k++) acc = fmaf(h1[k], sw1[o * 32 + k], acc); h2[o] = fmaxf(acc, 0.f); }
+        for (int o = 0; o < 6; o++) { float acc = 0.f; for (int k = 0; k < 32; k++) acc = fmaf(h2[k], sw2[o * 32 + k], acc); z2[o] = acc; }
+        // backward
+        float gz2[6];
+        for (int o = 0; o < 6; o++) { float s = 1.0f / (1.0f + expf(-z2[o])); gz2[o] = gout[6 * (size_t)i + o] * (M.mx[o] - M.mn[o]) * s * (1.f - s); }
+        float gh2[32];
+        for (int k = 0; k < 32; k++) { float acc = 0.f; for (int o = 0; o < 6; o++) { acc += gz2[o] * sw2[o * 32 + k]; atomicAdd(&gw2[o * 32 + k], gz2[o] * h2[k]); } gh2[k] = h2[k] > 0.f ? acc : 0.f; }
+        float gh1[32];
+        for (int k = 0; k < 32; k++) { float acc = 0.f; for (int o = 0; o < 32; o++) acc += gh2[o] * sw1[o * 32 + k]; gh1[k] = h1[k] > 0.f ? acc : 0.f; }
+        for (int o = 0; o < 32; o++) if (gh2[o] != 0.f) for (int k = 0; k < 32; k++) atomicAdd(&gw1[o * 32 + k], gh2[o] * h1[k]);
+        float ga0[32];
+        for (int k = 0; k < 32; k++) { float acc = 0.f; for (int o = 0; o < 32; o++) acc += gh1[o] * sw0[o * 32 + k]; ga0[k] = acc; }
+        for (int o = 0; o < 32; o++) if (gh1[o] != 0.f) for (int k = 0; k < 32; k++) atomicAdd(&gw0[o * 32 + k], gh1[o] * a0[k]);
+        if (g_params) {
+            for (int lv = 0; lv < MR_LEVELS; lv++) {
+                const float scale = L.scale[lv]; const uint32_t res = L.res[lv], size = L.size[lv];
+                float p[3]; uint32_t pg[3];
+#pragma unroll
+                for (int d = 0; d < 3; d++) { float q = fmaf(scale, x[d], 0.5f); float fl = floorf(q); pg[d] = (uint32_t)(int)fl; p[d] = q - fl; }
+                const float g0 = ga0[2 * lv], g1 = ga0[2 * lv + 1];
+                if (g0 == 0.f && g1 == 0.f) continue;
+#pragma unroll
+                for (uint32_t idx = 0; idx < 8; idx++) {
+                    float w = 1.f; uint32_t pl[3];
+#pragma unroll
+                    for (int d = 0; d < 3; d++) { if ((idx & (1u << d)) == 0) { w *= 1 - p[d]; pl[d] = pg[d]; } else { w *= p[d]; pl[d] = pg[d] + 1; } }
+                    size_t e = (size_t)L.offset[lv] + grid_index_b(size, res, pl[0], pl[1], pl[2]);
+                    atomicAdd(&g_params[2 * e], w * g0); atomicAdd(&g_params[2 * e + 1], w * g1);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < 1024; k += blockDim.x) { if (g_w0 && gw0[k] != 0.f) atomicAdd(&g_w0[k], gw0[k]); if (g_w1 && gw1[k] != 0.f) atomicAdd(&g_w1[k], gw1[k]); }
+    for (int k = threadIdx.x; k < 192; k += blockDim.x) if (g_w2 && gw2[k] != 0.f) atomicAdd(&g_w2[k], gw2[k]);
+}
+
+}  // namespace mr
+
+using namespace mr;
+
+extern "C" {
+
+int mirres_final_shading_bwd(mirres_ctx_t* ctx, const float* occ, const float* normal, const float* ray_dir, const float* kd,
+                             const float* rough_metal, const float* final_dir, const float* final_dist, const float* final_Li,
+                             const float* g_color, const float* g_diff, const float* g_spec, float* g_normal, float* g_kd,
+                             float* g_rough_metal, float* g_final_Li, void* stream) {
+    if (!ctx || !occ || !normal || !ray_dir || !kd || !rough_metal || !final_dir || !final_dist || !final_Li || !g_color || !g_diff || !g_spec) {
+        set_error("mirres_final_shading_bwd: null"); return MIRRES_E_ARG;
+    }
+    const int N = (int)ctx->N;
+    k_final_shading_bwd<<<grid_for(N, MR_BLOCK), MR_BLOCK, 0, (hipStream_t)stream>>>(N, occ, normal, ray_dir, kd, rough_metal, final_dir, final_dist, final_Li, g_color,
+                                                                                     g_diff, g_spec, g_normal, g_kd, g_rough_metal, g_final_Li);
+    MR_LAUNCH_CHECK("final_shading_bwd");
+    return MIRRES_OK;
+}
+
+int mirres_matnet_bwd(const mirres_matnet_t* m, const float* pos, int n, const float* grad_out, float* g_params_f32, float* g_w0,
+                      float* g_w1, float* g_w2, void* stream) {
+    if (!m || !pos || !grad_out || n < 0) { set_error("mirres_matnet_bwd: bad argument"); return MIRRES_E_ARG; }
+    if (n == 0) return MIRRES_OK;
+    MatNetB M; M.grid = reinterpret_cast<const __half2*>(m->grid_f16); M.w0 = m->w0; M.w1 = m->w1; M.w2 = m->w2;
+    for (int i = 0; i < 3; i++) { M.aabb_min[i] = m->aabb_min[i]; M.aabb_max[i] = m->aabb_max[i]; }
+    for (int i = 0; i < 6; i++) { M.mn[i] = m->out_min[i]; M.mx[i] = m->out_max[i]; }
+    k_matnet_bwd<<<grid_for(n, MR_BLOCK), MR_BLOCK, 0, (hipStream_t)stream>>>(M, host_levels_b(), pos, n, grad_out, g_params_f32, g_w0, g_w1, g_w2);
+    MR_LAUNCH_CHECK("matnet_bwd");
+    return MIRRES_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,555 @@
+// passes.hip — context, environment tables, light tiles and the ReSTIR reservoir passes as wavefront kernels.
+//
+// Every pass that the reference runs as one megakernel with in-line traversal (InitialResampling_, SpatialResampling_,
+// EvaluateFinalSamples_get_vis) is split into   generate (per pixel, emits COMPACTED shadow rays with one atomic per
+// wave) -> trace (bvh_trace.hip, any-hit queue) -> resolve (per pixel, consumes hit bits).  The rays a pixel emits
+// depend only on pass inputs, never on another ray's result, so the split is exact (DESIGN.md §Wavefront split).
+#include "engine.hpp"
+#include "device_math.hpp"
+#include "device_light.hpp"
+#include "device_brdf.hpp"
+
+namespace mr {
+
+int trace_any_queue_counted(const mirres_bvh* bvh, const Ray* rays, const uint32_t* d_count, size_t capacity, int32_t* hit,
+                            unsigned long long* stats, hipStream_t s);
+
+#define MR_BLOCK 256
+
+struct GBufD { const float *occ, *pos, *normal_depth, *brdf, *ray_dir; };
+struct ResD { float* light_data; float* light_pdf; int32_t* M; float* weight; };
+struct ResV { v3 light_data; float light_pdf; int M; float weight; };
+struct Ris { v3 light_data; float inv_pdf, weightSum, M, weight, canonicalWeight; };
+
+MR_DEV Ris empty_ris() { Ris s; s.light_data = V3(0.f); s.inv_pdf = 0.f; s.weightSum = 0.f; s.M = 0.f; s.weight = 0.f; s.canonicalWeight = 0.f; return s; }
+MR_DEV ResV load_res(const ResD& R, size_t i) { ResV r; r.light_data = ld3(R.light_data, i); r.light_pdf = R.light_pdf[i]; r.M = R.M[i]; r.weight = R.weight[i]; return r; }
+MR_DEV void store_zero(const ResD& R, size_t i) { st3(R.light_data, i, V3(0.f)); R.light_pdf[i] = 0.f; R.M[i] = 0; R.weight[i] = 0.f; }
+MR_DEV void store_ris(const ResD& R, size_t i, const Ris& s) {
+    if (isinf(s.weight) || isnan(s.weight)) { store_zero(R, i); return; }
+    st3(R.light_data, i, s.light_data); R.light_pdf[i] = s.inv_pdf; R.M[i] = (int)s.M; R.weight[i] = s.weight;
+}
+MR_DEV void put_ray(Ray* q, uint32_t slot, v3 pos, v3 dir, float vis_near) {
+    v3 o = pos + vis_near * dir;  // origin offset along the RAY direction (VIS_near, e.g. InitialResampling.slang:264-265)
+    float4 a, b;
+    a.x = o.x; a.y = o.y; a.z = o.z; a.w = 0.f;
+    b.x = dir.x; b.y = dir.y; b.z = dir.z; b.w = 1e7f;
+    reinterpret_cast<float4*>(q + slot)[0] = a; reinterpret_cast<float4*>(q + slot)[1] = b;
+}
+MR_DEV EnvD envd(const mirres_env_t& e) { EnvD E; E.tex = e.tex; E.W = e.Wc; E.H = e.Hc; E.pdf = e.pdf; E.cdf = e.cdf; E.mpdf = e.mpdf; E.mcdf = e.mcdf; return E; }
+
+// ---------------------------------------------------------------- environment tables
+// make_sampleable (make_sampleable.slang:34-60): weight = lum(env_le(ngp_dir(dir(h,w)))) * sin(theta)
+__global__ void __launch_bounds__(MR_BLOCK) k_env_weight(const float* __restrict__ tex, int W, int H, float* __restrict__ pdf) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= W * H) return;
+    const float PI = 3.141592653589793f;
+    int h = i / W, w = i % W;
+    float v = (h + .5f) / H;
+    float sin_theta = sinf(PI * v);
+    float ux = (w + .5f) / W;
+    float theta = v * PI, phi = ux * 2 * PI;
+    float cos_theta = cosf(theta), cos_phi = cosf(phi), sin_theta_dir = sinf(theta), sin_phi = sinf(phi);
+    v3 raw = V3(sin_theta_dir * cos_phi, cos_theta, sin_theta_dir * sin_phi);
+    float wv = luminance(env_le(ngp_dir(raw), tex, W, H));
+    pdf[i] = wv * sin_theta;
+}
+// Row scans + Distribution2D (GenerateLightTiles.py:10-24, make_sampleable.slang:62-86). One thread per row, sequential
+// fp32 sums: the table is tiny (256 x 512) and a fixed summation order keeps it reproducible run to run.
+__global__ void __launch_bounds__(64) k_env_rows(int W, int H, float* __restrict__ pdf, float* __restrict__ cdf, float* __restrict__ mpdf) {
+    int y = blockIdx.x * blockDim.x + threadIdx.x;
+    if (y >= H) return;
+    float acc = 0.f;
+    cdf[(size_t)y * (W + 1)] = 0.f;
+    for (int w = 0; w < W; w++) { acc += pdf[(size_t)y * W + w]; cdf[(size_t)y * (W + 1) + w + 1] = acc; }
+    mpdf[y] = acc;
+    const float row_weight = acc;
+    for (int x = 0; x < W; x++) {
+        if (row_weight < 1e-4f) { pdf[(size_t)y * W + x] = 1.0f / W; cdf[(size_t)y * (W + 1) + x] = x / (float)W; }
+        else { pdf[(size_t)y * W + x] /= row_weight; cdf[(size_t)y * (W + 1) + x] /= row_weight; }
+    }
+    cdf[(size_t)y * (W + 1) + W] = 1.f;
+}
+__global__ void k_env_marginal(int H, float* __restrict__ mpdf, float* __restrict__ mcdf) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    float acc = 0.f;
+    mcdf[0] = 0.f;
+    for (int h = 0; h < H; h++) { acc += mpdf[h]; mcdf[h + 1] = acc; }
+    const float total = acc;
+    for (int h = 0; h < H; h++) mpdf[h] = mpdf[h] / total;
+    for (int h = 0; h <= H; h++) mcdf[h] = mcdf[h] / total;
+    mcdf[H] = 1.f;
+}
+
+// createNeighborOffsetTexture (make_sampleable.slang:186-205) — a serial R2 walk, run once by one thread as in the reference
+__global__ void k_neighbor_offsets(int count, float* __restrict__ out) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    const int R = 254;
+    const float phi2 = 1.f / 1.3247179572447f;
+    float u = 0.5f, v = 0.5f;
+    for (uint32_t index = 0; index < (uint32_t)count * 2;) {
+        u += phi2; v += phi2 * phi2;
+        if (u >= 1.f) u -= 1.f;
+        if (v >= 1.f) v -= 1.f;
+        float rSq = (u - 0.5f) * (u - 0.5f) + (v - 0.5f) * (v - 0.5f);
+        if (rSq > 0.25f) continue;
+        out[index++] = (float)(int)((u - 0.5f) * R) / 127;
+        out[index++] = (float)(int)((v - 0.5f) * R) / 127;
+    }
+}
+
+// process_GenerateLightTiles (GenerateLightTiles.slang:16-62): exactly tile_count*tile_size threads (the reference
+// launches 33.5 M threads of which 131 072 work).
+__global__ void __launch_bounds__(MR_BLOCK) k_light_tiles(EnvD E, uint32_t frameIndex, int total, float* __restrict__ light_data,
+                                                          int32_t* __restrict__ light_uv, float* __restrict__ light_pdf) {
+    uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (uint32_t)total) return;
+    uint32_t sg = seed_generator(idx, idx, frameIndex + 1);  // scalar bufferIndex splat to uint2 (:34)
+    float r0 = rnd(sg), r1 = rnd(sg);
+    v3 ld = V3(0.f); int ux = 0, uy = 0; float ip = 0.f;
+    v3 dir; float pdf; v2 luv;
+    if (sample_li(E, r0, r1, dir, pdf, luv)) {
+        v2 o = oct_encode(dir);
+        ld = V3(1.f, o.x, o.y);
+        uv2xy(luv, E.W, E.H, ux, uy);
+        ip = pdf;
+    }
+    st3(light_data, idx, ld);
+    if (light_uv) { light_uv[2 * idx] = ux; light_uv[2 * idx + 1] = uy; }
+    light_pdf[idx] = ip;
+}
+
+// ---------------------------------------------------------------- initial resampling (InitialResampling.slang:151-295)
+__global__ void __launch_bounds__(MR_BLOCK) k_initial_gen(mirres_config_t C, EnvD E, GBufD G, ResD R, const float* __restrict__ tile_data,
+                                                          const float* __restrict__ tile_pdf, uint32_t frameIndex, int fx, int N,
+                                                          Ray* __restrict__ q, uint32_t* __restrict__ q_count, int32_t* __restrict__ slot_out) {
+    const int pi = blockIdx.x * blockDim.x + threadIdx.x;
+    bool want = false; v3 rpos = V3(0.f), rdir = V3(0.f);
+    if (pi < N) {
+        if (G.occ[pi] < 0.1f) store_zero(R, pi);
+        else {
+            const uint32_t x = (uint32_t)(pi % fx), y = (uint32_t)(pi / fx);
+            uint32_t tileSg = seed_generator(x / C.screen_tile_size, y / C.screen_tile_size, frameIndex);
+            uint32_t tileIndex = min((uint32_t)(rnd(tileSg) * C.light_tile_count), (uint32_t)C.light_tile_count - 1);
+            uint32_t tileOffset = tileIndex * C.light_tile_size;
+            uint32_t sg = seed_generator(x, y, frameIndex);
+            uint32_t stride = (C.light_tile_size + C.initial_light_samples - 1) / C.initial_light_samples;
+            uint32_t offset = min((uint32_t)(rnd(sg) * stride), stride - 1);
+            const v3 n = V3(G.normal_depth[4 * (size_t)pi], G.normal_depth[4 * (size_t)pi + 1], G.normal_depth[4 * (size_t)pi + 2]);
+            const rtarget::Ctx ctx = rtarget::make_ctx(n, ld3(G.ray_dir, pi), ld3(G.brdf, pi));
+            const float ratio = (float)C.initial_brdf_samples / (float)(C.initial_light_samples + C.initial_brdf_samples);
+            Ris s = empty_ris();
+            for (uint32_t i = 0; i < (uint32_t)C.initial_light_samples; ++i) {
+                uint32_t index = tileOffset + (offset + i * stride) % C.light_tile_size;
+                v3 ld = ld3(tile_data, index); float lpdf = tile_pdf[index];
+                v3 ldir = oct_decode(V2(ld.y, ld.z));
+                v3 em = env_radiance(E, ldir);
+                float targetPdf = rtarget::target(ctx, em, ldir);
+                float sourcePdf = lerpf(lpdf, rtarget::pdf_brdf(ctx, ldir), ratio);  // res.slang:79-91
+                float w = targetPdf / sourcePdf;                                       // res.slang:93-113
+                s.weightSum += w; s.M += 1.f;
+                if (rnd(sg) * s.weightSum < w) { s.light_data = ld; s.inv_pdf = lpdf; s.weight = targetPdf; }
+            }
+            for (int i = 0; i < C.initial_brdf_samples; ++i) {
+                float xa = rnd(sg), xb = rnd(sg), xc = rnd(sg);
+                v3 ld = V3(0.f); float lpdf = 0.f; v3 dir;
+                if (rtarget::sample_brdf(ctx, xa, xb, xc, dir)) {
+                    lpdf = pdf_li(E, dir);
+                    v2 o = oct_encode(dir);
+                    ld = V3(1.0f, o.x, o.y);
+                }
+                if (ld.x < 0.1f) { s.M += 1.f; continue; }
+                v3 em = env_radiance(E, dir);
+                float targetPdf = rtarget::target(ctx, em, dir);
+                float sourcePdf = lerpf(lpdf, rtarget::pdf_brdf(ctx, dir), ratio);
+                float w = targetPdf / sourcePdf;
+                s.weightSum += w; s.M += 1.f;
+                if (rnd(sg) * s.weightSum < w) { s.light_data = ld; s.inv_pdf = lpdf; s.weight = targetPdf; }
+            }
+            if (s.light_data.x > 0.1f) { want = true; rpos = ld3(G.pos, pi); rdir = oct_decode(V2(s.light_data.y, s.light_data.z)); }
+            // reservoir as if the sample is visible; k_initial_resolve empties it when the shadow ray hits (:269-281)
+            s.weight = s.weight > 0.f ? (s.weightSum / s.M) / s.weight : 0.f;
+            s.M = 1.f;
+            store_ris(R, pi, s);
+        }
+    }
+    uint32_t slot = wave_append(q_count, want);
+    if (want) put_ray(q, slot, rpos, rdir, C.vis_near);
+    if (pi < N) slot_out[pi] = want ? (int32_t)slot : -1;
+}
+__global__ void __launch_bounds__(MR_BLOCK) k_initial_resolve(ResD R, int N, const int32_t* __restrict__ slot, const int32_t* __restrict__ hit) {
+    const int pi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pi >= N) return;
+    int s = slot[pi];
+    if (s >= 0 && hit[s]) { st3(R.light_data, pi, V3(0.f)); R.light_pdf[pi] = 0.f; R.M[pi] = 1; R.weight[pi] = 0.f; }  // createEmpty, then M := 1
+}
+
+// ---------------------------------------------------------------- temporal resampling (TemporalResampling.slang:23-135)
+__global__ void __launch_bounds__(MR_BLOCK) k_temporal(mirres_config_t C, EnvD E, GBufD G, GBufD P, ResD R, ResD PR, const float* __restrict__ motion,
+                                                       uint32_t frameIndex, int fx, int fy, int N) {
+    const int pi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pi >= N) return;
+    if (G.occ[pi] < 0.1f) return;
+    const uint32_t x = (uint32_t)(pi % fx), y = (uint32_t)(pi / fx);
+    uint32_t sg = seed_generator(x, y, frameIndex);
+    float mvx = motion ? motion[2 * (size_t)pi] : 0.f, mvy = motion ? motion[2 * (size_t)pi + 1] : 0.f;
+    float jx = rnd(sg), jy = rnd(sg);
+    int ppx = (int)(((float)x + mvx * (float)(uint32_t)fx) + (jx * 1.f - 0.f));
+    int ppy = (int)(((float)y + mvy * (float)(uint32_t)fy) + (jy * 1.f - 0.f));
+    if (ppx >= fx || ppx < 0 || ppy >= fy || ppy < 0) return;
+    const size_t qi = (size_t)ppy * fx + ppx;
+    if (P.occ[qi] < 0.1f) return;
+    const v3 n = V3(G.normal_depth[4 * (size_t)pi], G.normal_depth[4 * (size_t)pi + 1], G.normal_depth[4 * (size_t)pi + 2]);
+    const float depth = G.normal_depth[4 * (size_t)pi + 3];
+    const v3 pn = V3(P.normal_depth[4 * qi], P.normal_depth[4 * qi + 1], P.normal_depth[4 * qi + 2]);
+    const float pdepth = P.normal_depth[4 * qi + 3];
+    ResV cur = load_res(R, pi), prev = load_res(PR, qi);
+    prev.M = min(prev.M, cur.M * C.max_history);
+    if (!(dot(n, pn) >= 0.5f && fabsf(depth - pdepth) <= 0.1f * depth)) return;  // isValidNeighbor res.slang:63-68
+    const rtarget::Ctx ctx = rtarget::make_ctx(n, ld3(G.ray_dir, pi), ld3(G.brdf, pi));
+    const rtarget::Ctx pctx = rtarget::make_ctx(pn, ld3(P.ray_dir, qi), ld3(P.brdf, qi));
+    Ris s = empty_ris();
+    v3 ldir = oct_decode(V2(cur.light_data.y, cur.light_data.z));
+    float targetPdf = rtarget::target(ctx, env_radiance(E, ldir), ldir);
+    {
+        float w = targetPdf * cur.weight * cur.M;  // res.slang:116-134
+        s.weightSum += w; s.M += cur.M;
+        if (rnd(sg) * s.weightSum < w) { s.light_data = cur.light_data; s.inv_pdf = cur.light_pdf; s.weight = targetPdf; }
+    }
+    v3 pldir = oct_decode(V2(prev.light_data.y, prev.light_data.z));
+    float preTarget = rtarget::target(ctx, env_radiance(E, pldir), pldir);
+    bool usedPrev;
+    {
+        float w = preTarget * prev.weight * prev.M;
+        s.weightSum += w; s.M += prev.M;
+        usedPrev = rnd(sg) * s.weightSum < w;
+        if (usedPrev) { s.light_data = prev.light_data; s.inv_pdf = prev.light_pdf; s.weight = preTarget; }
+    }
+    v3 sdir = oct_decode(V2(s.light_data.y, s.light_data.z));
+    v3 sem = env_radiance(E, sdir);
+    float currentPdf = rtarget::target(ctx, sem, sdir);
+    float prevPdf = rtarget::target(pctx, sem, sdir);
+    float normalization = (usedPrev ? prevPdf : currentPdf) / (cur.M * currentPdf + prev.M * prevPdf);
+    s.weight = s.weight > 0.f ? (s.weightSum * normalization) / s.weight : 0.f;
+    store_ris(R, pi, s);
+}
+
+// ---------------------------------------------------------------- spatial resampling (SpatialResampling.slang:178-322)
+MR_DEV float m_factor(float q0, float q1) { return q0 == 0.f ? 1.f : clampf(powf(fminf(q1 / q0, 1.f), 8.f), 0.f, 1.f); }
+MR_DEV float pairwise_mis(float q0, float q1, float N0, float N1) { return (q1 == 0.f) ? 0.f : (N0 * q0) / (q0 * N0 + q1 * N1); }
+
+// neighbour acceptance exactly in the reference's order of `continue`s (:236-258); returns the pixel index or -1
+MR_DEV int spatial_neighbor(const mirres_config_t& C, const GBufD& G, const ResD& PR, const float* __restrict__ noff, uint32_t startIndex, uint32_t i,
+                            int x, int y, int fx, int fy, v3 n, float depth) {
+    uint32_t ni = (startIndex + i) & (uint32_t)(C.neighbor_offset_count - 1);
+    int nx = x + (int)(noff[2 * ni] * C.gather_radius);
+    int ny = y + (int)(noff[2 * ni + 1] * C.gather_radius);
+    if (!(nx >= 0 && ny >= 0 && nx < fx && ny < fy)) return -1;
+    size_t qi = (size_t)ny * fx + nx;
+    v3 nn = V3(G.normal_depth[4 * qi], G.normal_depth[4 * qi + 1], G.normal_depth[4 * qi + 2]);
+    float ndepth = G.normal_depth[4 * qi + 3];
+    if (!(dot(n, nn) >= 0.5f && fabsf(depth - ndepth) <= 0.1f * depth)) return -1;
+    if (PR.M[qi] == 0) return -1;
+    if (G.occ[qi] < 0.1f) return -1;
+    return (int)qi;
+}
+
+__global__ void __launch_bounds__(MR_BLOCK) k_spatial_gen(mirres_config_t C, GBufD G, ResD PR, const float* __restrict__ noff, uint32_t frameIndex,
+                                                          int fx, int fy, int N, Ray* __restrict__ q, uint32_t* __restrict__ q_count,
+                                                          int32_t* __restrict__ slot_out, uint32_t* __restrict__ mask_out) {
+    const int pi = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t mask = 0, cnt = 0;
+    int nb[8];
+    v3 cpos = V3(0.f), cdir = V3(0.f);
+    if (pi < N && !(G.occ[pi] < 0.1f)) {
+        const int x = pi % fx, y = pi / fx;
+        uint32_t sg = seed_generator((uint32_t)x, (uint32_t)y, frameIndex);
+        const uint32_t startIndex = (uint32_t)(rnd(sg) * C.neighbor_offset_count);
+        const v3 n = V3(G.normal_depth[4 * (size_t)pi], G.normal_depth[4 * (size_t)pi + 1], G.normal_depth[4 * (size_t)pi + 2]);
+        const float depth = G.normal_depth[4 * (size_t)pi + 3];
+        const int k = min(C.neighbor_count, 8);
+        for (int i = 0; i < k; i++) {
+            int qi = spatial_neighbor(C, G, PR, noff, startIndex, (uint32_t)i, x, y, fx, fy, n, depth);
+            nb[i] = qi;
+            if (qi >= 0) { mask |= 1u << i; cnt++; }
+        }
+        if (cnt) { cpos = ld3(G.pos, pi); cdir = oct_decode(V2(PR.light_data[3 * (size_t)pi + 1], PR.light_data[3 * (size_t)pi + 2])); }
+    }
+    uint32_t base = wave_append(q_count, cnt > 0, 2 * cnt);
+    if (cnt) {
+        uint32_t s = base;
+        const int k = min(C.neighbor_count, 8);
+        for (int i = 0; i < k; i++) {
+            if (!(mask & (1u << i))) continue;
+            size_t qi = (size_t)nb[i];
+            v3 ndir = oct_decode(V2(PR.light_data[3 * qi + 1], PR.light_data[3 * qi + 2]));
+            put_ray(q, s, cpos, ndir, C.vis_near);                 // canonical pixel towards the neighbour's light
+            put_ray(q, s + 1, ld3(G.pos, qi), cdir, C.vis_near);   // neighbour towards the canonical light
+            s += 2;
+        }
+    }
+    if (pi < N) { slot_out[pi] = cnt ? (int32_t)base : -1; mask_out[pi] = mask; }
+}
+
+__global__ void __launch_bounds__(MR_BLOCK) k_spatial_resolve(mirres_config_t C, EnvD E, GBufD G, ResD R, ResD PR, const float* __restrict__ noff,
+                                                              uint32_t frameIndex, int fx, int fy, int N, const int32_t* __restrict__ slot,
+                                                              const uint32_t* __restrict__ mask_in, const int32_t* __restrict__ hit) {
+    const int pi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pi >= N) return;
+    if (G.occ[pi] < 0.1f) { store_zero(R, pi); return; }
+    const int x = pi % fx, y = pi / fx;
+    uint32_t sg = seed_generator((uint32_t)x, (uint32_t)y, frameIndex);
+    const v3 n = V3(G.normal_depth[4 * (size_t)pi], G.normal_depth[4 * (size_t)pi + 1], G.normal_depth[4 * (size_t)pi + 2]);
+    const rtarget::Ctx ctx = rtarget::make_ctx(n, ld3(G.ray_dir, pi), ld3(G.brdf, pi));
+    Ris s = empty_ris();
+    const uint32_t startIndex = (uint32_t)(rnd(sg) * C.neighbor_offset_count);
+    ResV cur = load_res(PR, pi);
+    const v3 cdir = oct_decode(V2(cur.light_data.y, cur.light_data.z));
+    const v3 cem = env_radiance(E, cdir);
+    const float curTarget = rtarget::target(ctx, cem, cdir);
+    s.canonicalWeight = 1.f;
+    uint32_t validNeighbors = 1;
+    const uint32_t k = (uint32_t)C.neighbor_count;
+    const uint32_t mask = mask_in[pi];
+    int hs = slot[pi];
+    for (uint32_t i = 0; i < k; ++i) {
+        if (!(mask & (1u << i))) continue;
+        uint32_t ni = (startIndex + i) & (uint32_t)(C.neighbor_offset_count - 1);
+        int nx = x + (int)(noff[2 * ni] * C.gather_radius), ny = y + (int)(noff[2 * ni + 1] * C.gather_radius);
+        size_t qi = (size_t)ny * fx + nx;
+        const v3 nn = V3(G.normal_depth[4 * qi], G.normal_depth[4 * qi + 1], G.normal_depth[4 * qi + 2]);
+        ResV nbr = load_res(PR, qi);
+        const rtarget::Ctx nctx = rtarget::make_ctx(nn, ld3(G.ray_dir, qi), ld3(G.brdf, qi));
+        ++validNeighbors;
+        const v3 ndir = oct_decode(V2(nbr.light_data.y, nbr.light_data.z));
+        const v3 nem = env_radiance(E, ndir);
+        const float canonicalVis = hit[hs] ? 0.f : 1.f, candidateVis = hit[hs + 1] ? 0.f : 1.f;
+        hs += 2;
+        // streamingResampleStepMisUnbiased (res.slang:173-213)
+        float candTarget = rtarget::target(nctx, nem, ndir);
+        float candAtOther = rtarget::target(ctx, nem, ndir);
+        float canonAtOther = rtarget::target(nctx, cem, cdir);
+        candAtOther *= canonicalVis;
+        canonAtOther *= candidateVis;
+        float N0 = (float)((uint32_t)nbr.M * k), N1 = (float)cur.M;
+        float m0 = pairwise_mis(candTarget, candAtOther, N0, N1);
+        float m1 = 1.f - pairwise_mis(canonAtOther, curTarget, N0, N1);
+        float w = candAtOther * nbr.weight * m0;
+        // state.M (+= M_j * min(mFactor..)) is overwritten with M_canonical below (:302), so it is not tracked
+        s.weightSum += w;
+        s.canonicalWeight += m1;
+        if (rnd(sg) * s.weightSum < w) { s.light_data = nbr.light_data; s.inv_pdf = nbr.light_pdf; s.weight = candAtOther; }
+    }
+    {   // streamingResampleFinalizeMis (res.slang:215-232)
+        float w = curTarget * cur.weight * s.canonicalWeight;
+        s.weightSum += w;
+        if (rnd(sg) * s.weightSum < w) { s.light_data = cur.light_data; s.inv_pdf = cur.light_pdf; s.weight = curTarget; }
+    }
+    s.M = (float)cur.M;
+    s.weight = s.weight > 0.f ? (s.weightSum / validNeighbors) / s.weight : 0.f;
+    store_ris(R, pi, s);
+}
+
+// ---------------------------------------------------------------- final-sample visibility + evaluation (EvaluateFinalSamples.slang:84-188)
+__global__ void __launch_bounds__(MR_BLOCK) k_vis_gen(float vis_near, const float* __restrict__ pos, ResD R, int N, Ray* __restrict__ q,
+                                                      uint32_t* __restrict__ q_count, int32_t* __restrict__ slot_out) {
+    const int pi = blockIdx.x * blockDim.x + threadIdx.x;
+    bool want = false; v3 rp = V3(0.f), rd = V3(0.f);
+    if (pi < N) {
+        v3 ld = ld3(R.light_data, pi);
+        if (ld.x > 0.1f) { want = true; rp = ld3(pos, pi); rd = oct_decode(V2(ld.y, ld.z)); }
+    }
+    uint32_t slot = wave_append(q_count, want);
+    if (want) put_ray(q, slot, rp, rd, vis_near);
+    if (pi < N) slot_out[pi] = want ? (int32_t)slot : -1;
+}
+__global__ void __launch_bounds__(MR_BLOCK) k_vis_resolve(int N, const int32_t* __restrict__ slot, const int32_t* __restrict__ hit, float* __restrict__ vis) {
+    const int pi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pi >= N) return;
+    int s = slot[pi];
+    vis[pi] = (s >= 0 && hit[s]) ? 0.0f : 1.0f;
+}
+__global__ void __launch_bounds__(MR_BLOCK) k_eval_final(EnvD E, ResD R, const float* __restrict__ vis, int N, float* __restrict__ fdir,
+                                                         float* __restrict__ fdist, float* __restrict__ fLi) {
+    const int pi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pi >= N) return;
+    ResV cur = load_res(R, pi);
+    v3 od = V3(0.f), Li = V3(0.f); float dist = 0.f;
+    if (cur.light_data.x > 0.1f) {
+        v3 ldir = oct_decode(V2(cur.light_data.y, cur.light_data.z));
+        v3 em = env_radiance(E, ldir);
+        if (vis[pi] > 0.f) { od = ldir; dist = 1e6f; Li = cur.weight * em; }
+    }
+    st3(fdir, pi, od); fdist[pi] = dist; st3(fLi, pi, Li);
+}
+// backward of k_eval_final w.r.t. the environment texels: Li = W * bilinear(env, ngp_dir(ldir))  (EvaluateFinalSamples.slang:129-188 .bwd)
+__global__ void __launch_bounds__(MR_BLOCK) k_eval_final_bwd(EnvD E, ResD R, const float* __restrict__ vis, int N, const float* __restrict__ gLi,
+                                                             float* __restrict__ genv) {
+    const int pi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pi >= N) return;
+    ResV cur = load_res(R, pi);
+    if (!(cur.light_data.x > 0.1f) || !(vis[pi] > 0.f)) return;
+    v3 ldir = oct_decode(V2(cur.light_data.y, cur.light_data.z));
+    int idx[4]; float w[4];
+    if (!env_le_footprint(ngp_dir(ldir), E.W, E.H, idx, w)) return;
+    v3 g = ld3(gLi, pi) * cur.weight;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        atomicAdd(&genv[3 * (size_t)idx[k]], g.x * w[k]); atomicAdd(&genv[3 * (size_t)idx[k] + 1], g.y * w[k]); atomicAdd(&genv[3 * (size_t)idx[k] + 2], g.z * w[k]);
+    }
+}
+
+static GBufD gbufd(const mirres_gbuf_t* g) { GBufD G; G.occ = g->occ; G.pos = g->pos; G.normal_depth = g->normal_depth; G.brdf = g->brdf; G.ray_dir = g->ray_dir; return G; }
+static ResD resd(const mirres_res_t* r) { ResD R; R.light_data = r->light_data; R.light_pdf = r->light_pdf; R.M = r->M; R.weight = r->weight; return R; }
+static EnvD envh(const mirres_env_t* e) { EnvD E; E.tex = e->tex; E.W = e->Wc; E.H = e->Hc; E.pdf = e->pdf; E.cdf = e->cdf; E.mpdf = e->mpdf; E.mcdf = e->mcdf; return E; }
+
+int trace_any(mirres_ctx* ctx, mirres_bvh* bvh, size_t cap, hipStream_t s) {
+    if (ctx->instrument) return trace_any_queue_counted(bvh, ctx->any_rays, &ctx->counters[0], cap, ctx->any_hit, ctx->stats, s);
+    return trace_any_queue(bvh, ctx->any_rays, &ctx->counters[0], cap, ctx->any_hit, ctx->stats, s);
+}
+
+}  // namespace mr
+
+using namespace mr;
+
+extern "C" {
+
+int mirres_ctx_create(mirres_ctx_t** out, int fx, int fy, const mirres_config_t* cfg) {
+    if (!out || fx <= 0 || fy <= 0) { set_error("mirres_ctx_create: bad size"); return MIRRES_E_ARG; }
+    mirres_ctx* c = new mirres_ctx();
+    c->fx = fx; c->fy = fy; c->N = (size_t)fx * fy;
+    if (cfg) c->cfg = *cfg; else mirres_default_config(&c->cfg);
+    if (c->cfg.neighbor_count > 8 || c->cfg.neighbor_count < 0 || (c->cfg.neighbor_offset_count & (c->cfg.neighbor_offset_count - 1))) {
+        set_error("mirres_ctx_create: neighbor_count must be <= 8 and neighbor_offset_count a power of two"); delete c; return MIRRES_E_ARG;
+    }
+    const size_t N = c->N;
+    c->any_cap = N * (size_t)(2 * (c->cfg.neighbor_count > 1 ? c->cfg.neighbor_count : 1));
+    c->cl_cap = N;
+    MR_HIP(hipMalloc(&c->any_rays, sizeof(Ray) * c->any_cap));
+    MR_HIP(hipMalloc(&c->any_hit, sizeof(int32_t) * c->any_cap));
+    MR_HIP(hipMalloc(&c->cl_rays, sizeof(Ray) * c->cl_cap));
+    MR_HIP(hipMalloc(&c->cl_hit, sizeof(HitRec) * c->cl_cap));
+    MR_HIP(hipMalloc(&c->counters, sizeof(uint32_t) * 8));
+    MR_HIP(hipMalloc(&c->stats, sizeof(unsigned long long) * 8));
+    MR_HIP(hipMemset(c->counters, 0, sizeof(uint32_t) * 8));
+    MR_HIP(hipMemset(c->stats, 0, sizeof(unsigned long long) * 8));
+    MR_HIP(hipMalloc(&c->slot_a, sizeof(int32_t) * N));
+    MR_HIP(hipMalloc(&c->mask_a, sizeof(uint32_t) * N));
+    MR_HIP(hipMalloc(&c->slot_c, sizeof(int32_t) * N));
+    MR_HIP(hipMalloc(&c->pend, sizeof(float) * 18 * N));
+    MR_HIP(hipMalloc(&c->noff, sizeof(float) * 2 * (size_t)c->cfg.neighbor_offset_count));
+    k_neighbor_offsets<<<1, 64, 0, 0>>>(c->cfg.neighbor_offset_count, c->noff);
+    MR_HIP(hipDeviceSynchronize());
+    *out = c;
+    return MIRRES_OK;
+}
+
+void mirres_ctx_destroy(mirres_ctx_t* c) {
+    if (!c) return;
+    void* ptrs[] = {c->any_rays, c->any_hit, c->cl_rays, c->cl_hit, c->counters, c->stats, c->slot_a, c->mask_a, c->slot_c, c->pend, c->noff, c->pool};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    delete c;
+}
+
+int mirres_neighbor_offsets(mirres_ctx_t* ctx, float* out, void* stream) {
+    if (!ctx || !out) { set_error("mirres_neighbor_offsets: null"); return MIRRES_E_ARG; }
+    MR_HIP(hipMemcpyAsync(out, ctx->noff, sizeof(float) * 2 * (size_t)ctx->cfg.neighbor_offset_count, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return MIRRES_OK;
+}
+
+int mirres_ctx_stats(mirres_ctx_t* ctx, uint64_t* h_out, int reset) {
+    if (!ctx || !h_out) { set_error("mirres_ctx_stats: null"); return MIRRES_E_ARG; }
+    MR_HIP(hipDeviceSynchronize());
+    MR_HIP(hipMemcpy(h_out, ctx->stats, sizeof(unsigned long long) * 8, hipMemcpyDeviceToHost));
+    if (reset) MR_HIP(hipMemset(ctx->stats, 0, sizeof(unsigned long long) * 8));
+    return MIRRES_OK;
+}
+int mirres_ctx_set_instrument(mirres_ctx_t* ctx, int on) { if (!ctx) return MIRRES_E_ARG; ctx->instrument = on; return MIRRES_OK; }
+
+int mirres_env_make_sampleable(const float* env_tex, int Wc, int Hc, float* pdf, float* cdf, float* mpdf, float* mcdf, void* stream) {
+    if (!env_tex || !pdf || !cdf || !mpdf || !mcdf || Wc <= 0 || Hc <= 0) { set_error("mirres_env_make_sampleable: bad argument"); return MIRRES_E_ARG; }
+    hipStream_t s = (hipStream_t)stream;
+    k_env_weight<<<grid_for((size_t)Wc * Hc, MR_BLOCK), MR_BLOCK, 0, s>>>(env_tex, Wc, Hc, pdf);
+    k_env_rows<<<grid_for(Hc, 64), 64, 0, s>>>(Wc, Hc, pdf, cdf, mpdf);
+    k_env_marginal<<<1, 64, 0, s>>>(Hc, mpdf, mcdf);
+    MR_LAUNCH_CHECK("make_sampleable");
+    return MIRRES_OK;
+}
+
+int mirres_light_tiles(mirres_ctx_t* ctx, const float* env_tex, int Wc, int Hc, const float* pdf, const float* cdf, const float* mpdf,
+                       const float* mcdf, uint32_t frameIndex, float* light_data, int32_t* light_uv, float* light_inv_pdf, void* stream) {
+    if (!ctx || !light_data || !light_inv_pdf) { set_error("mirres_light_tiles: null"); return MIRRES_E_ARG; }
+    EnvD E; E.tex = env_tex; E.W = Wc; E.H = Hc; E.pdf = pdf; E.cdf = cdf; E.mpdf = mpdf; E.mcdf = mcdf;
+    int total = ctx->cfg.light_tile_count * ctx->cfg.light_tile_size;
+    k_light_tiles<<<grid_for(total, MR_BLOCK), MR_BLOCK, 0, (hipStream_t)stream>>>(E, frameIndex, total, light_data, light_uv, light_inv_pdf);
+    MR_LAUNCH_CHECK("light_tiles");
+    return MIRRES_OK;
+}
+
+int mirres_restir_initial(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_env_t* env, const mirres_gbuf_t* g, const mirres_res_t* res,
+                          const float* light_data, const float* light_inv_pdf, uint32_t frameIndex, void* stream) {
+    if (!ctx || !bvh || !env || !g || !res) { set_error("mirres_restir_initial: null"); return MIRRES_E_ARG; }
+    hipStream_t s = (hipStream_t)stream; const int N = (int)ctx->N; const int grd = grid_for(N, MR_BLOCK);
+    MR_HIP(hipMemsetAsync(&ctx->counters[0], 0, sizeof(uint32_t), s));
+    k_initial_gen<<<grd, MR_BLOCK, 0, s>>>(ctx->cfg, envh(env), gbufd(g), resd(res), light_data, light_inv_pdf, frameIndex, ctx->fx, N, ctx->any_rays,
+                                            &ctx->counters[0], ctx->slot_a);
+    int rc = trace_any(ctx, bvh, (size_t)N, s); if (rc) return rc;
+    k_initial_resolve<<<grd, MR_BLOCK, 0, s>>>(resd(res), N, ctx->slot_a, ctx->any_hit);
+    MR_LAUNCH_CHECK("restir_initial");
+    return MIRRES_OK;
+}
+
+int mirres_restir_temporal(mirres_ctx_t* ctx, const mirres_env_t* env, const mirres_gbuf_t* g, const mirres_gbuf_t* prev_g,
+                           const mirres_res_t* res, const mirres_res_t* prev_res, const float* motion, uint32_t frameIndex, void* stream) {
+    if (!ctx || !env || !g || !prev_g || !res || !prev_res) { set_error("mirres_restir_temporal: null"); return MIRRES_E_ARG; }
+    const int N = (int)ctx->N;
+    k_temporal<<<grid_for(N, MR_BLOCK), MR_BLOCK, 0, (hipStream_t)stream>>>(ctx->cfg, envh(env), gbufd(g), gbufd(prev_g), resd(res), resd(prev_res), motion,
+                                                                            frameIndex, ctx->fx, ctx->fy, N);
+    MR_LAUNCH_CHECK("restir_temporal");
+    return MIRRES_OK;
+}
+
+int mirres_restir_spatial(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_env_t* env, const mirres_gbuf_t* g, const mirres_res_t* res,
+                          const mirres_res_t* prev_res, const float* neighbor_offsets, uint32_t frameIndex, void* stream) {
+    if (!ctx || !bvh || !env || !g || !res || !prev_res) { set_error("mirres_restir_spatial: null"); return MIRRES_E_ARG; }
+    hipStream_t s = (hipStream_t)stream; const int N = (int)ctx->N; const int grd = grid_for(N, MR_BLOCK);
+    const float* noff = neighbor_offsets ? neighbor_offsets : ctx->noff;
+    MR_HIP(hipMemsetAsync(&ctx->counters[0], 0, sizeof(uint32_t), s));
+    k_spatial_gen<<<grd, MR_BLOCK, 0, s>>>(ctx->cfg, gbufd(g), resd(prev_res), noff, frameIndex, ctx->fx, ctx->fy, N, ctx->any_rays, &ctx->counters[0],
+                                            ctx->slot_a, ctx->mask_a);
+    int rc = trace_any(ctx, bvh, ctx->any_cap, s); if (rc) return rc;
+    k_spatial_resolve<<<grd, MR_BLOCK, 0, s>>>(ctx->cfg, envh(env), gbufd(g), resd(res), resd(prev_res), noff, frameIndex, ctx->fx, ctx->fy, N, ctx->slot_a,
+                                                ctx->mask_a, ctx->any_hit);
+    MR_LAUNCH_CHECK("restir_spatial");
+    return MIRRES_OK;
+}
+
+int mirres_restir_final_vis(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const float* pos, const mirres_res_t* res, float* vis_map, void* stream) {
+    if (!ctx || !bvh || !pos || !res || !vis_map) { set_error("mirres_restir_final_vis: null"); return MIRRES_E_ARG; }
+    hipStream_t s = (hipStream_t)stream; const int N = (int)ctx->N; const int grd = grid_for(N, MR_BLOCK);
+    MR_HIP(hipMemsetAsync(&ctx->counters[0], 0, sizeof(uint32_t), s));
+    k_vis_gen<<<grd, MR_BLOCK, 0, s>>>(ctx->cfg.vis_near, pos, resd(res), N, ctx->any_rays, &ctx->counters[0], ctx->slot_a);
+    int rc = trace_any(ctx, bvh, (size_t)N, s); if (rc) return rc;
+    k_vis_resolve<<<grd, MR_BLOCK, 0, s>>>(N, ctx->slot_a, ctx->any_hit, vis_map);
+    MR_LAUNCH_CHECK("restir_final_vis");
+    return MIRRES_OK;
+}
+
+int mirres_restir_eval_final(mirres_ctx_t* ctx, const mirres_env_t* env, const mirres_res_t* res, const float* vis_map, float* final_dir,
+                             float* final_dist, float* final_Li, void* stream) {
+    if (!ctx || !env || !res || !vis_map || !final_dir || !final_dist || !final_Li) { set_error("mirres_restir_eval_final: null"); return MIRRES_E_ARG; }
+    const int N = (int)ctx->N;
+    k_eval_final<<<grid_for(N, MR_BLOCK), MR_BLOCK, 0, (hipStream_t)stream>>>(envh(env), resd(res), vis_map, N, final_dir, final_dist, final_Li);
+    MR_LAUNCH_CHECK("restir_eval_final");
+    return MIRRES_OK;
+}
+
+int mirres_restir_eval_final_bwd(mirres_ctx_t* ctx, const mirres_env_t* env, const mirres_res_t* res, const float* vis_map,
+                                 const float* grad_final_Li, float* grad_env, void* stream) {
+    if (!ctx || !env || !res || !vis_map || !grad_final_Li || !grad_env) { set_error("mirres_restir_eval_final_bwd: null"); return MIRRES_E_ARG; }
+    const int N = (int)ctx->N;
+    k_eval_final_bwd<<<grid_for(N, MR_BLOCK), MR_BLOCK, 0, (hipStream_t)stream>>>(envh(env), resd(res), vis_map, N, grad_final_Li, grad_env);
+    MR_LAUNCH_CHECK("restir_eval_final_bwd");
+    return MIRRES_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,216 @@
+// render.hip — the whole frame without returning to Python: run_restir_di_with_pt + restir_di_with_pt
+// (nerf/renderer_restir.py:230-550). The reference issues ~60 launches + 2 torch.where syncs + 9 accumulate kernels per
+// spp from Python; here one C call enqueues the spp loop on a stream, accumulations are fused into the producing kernels,
+// the material net scatters in place (no index tensors), and nothing synchronises with the host.
+#include "engine.hpp"
+#include "device_math.hpp"
+
+namespace mr {
+
+#define MR_BLOCK 256
+
+int launch_final_shading(const mirres_env_t* env, const float* occ, const float* normal, const float* ray_dir, const float* kd, const float* rm,
+                         const float* fdir, const float* fdist, const float* fLi, int N, float* color, float* dl, float* sl, bool acc, hipStream_t s);
+int launch_new_dir(mirres_ctx* ctx, mirres_bvh* bvh, const mirres_path_t* p, uint32_t frameIndex, uint32_t bounce_count, hipStream_t s);
+int launch_bounce(mirres_ctx* ctx, mirres_bvh* bvh, const mirres_env_t* env, const mirres_path_t* p, uint32_t frameIndex, uint32_t bounce_count, float* color,
+                  float* dc, float* sc, float* acc_c, float* acc_d, float* acc_s, hipStream_t s);
+int launch_matnet_scatter(const mirres_matnet_t* m, const float* occ, const float* pos, int n, float* kd, float* rm, int use_scale, const float* scale3,
+                          const float* const_kd, const float* const_rm, hipStream_t s);
+
+// run_restir_di_with_pt :484-486 + restir_di_with_pt :279-287
+__global__ void __launch_bounds__(MR_BLOCK) k_prep(int N, float* __restrict__ occ, const float* __restrict__ ray_dir_in, const float* __restrict__ normal,
+                                                   const float* __restrict__ depth, const float* __restrict__ kd, const float* __restrict__ rm,
+                                                   float* __restrict__ ray_dir, float* __restrict__ nd, float* __restrict__ brdf) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    if (occ[i] <= 0.5f) occ[i] = 0.f;
+    v3 d = ld3(ray_dir_in, i);
+    float l = fmaxf(sqrtf(dot(d, d)), 1e-6f);  // F.normalize(eps=1e-6)
+    st3(ray_dir, i, V3(d.x / l, d.y / l, d.z / l));
+    nd[4 * (size_t)i] = normal[3 * (size_t)i]; nd[4 * (size_t)i + 1] = normal[3 * (size_t)i + 1]; nd[4 * (size_t)i + 2] = normal[3 * (size_t)i + 2];
+    nd[4 * (size_t)i + 3] = depth[i];
+    const float m = rm[2 * (size_t)i + 1], r = rm[2 * (size_t)i];
+    brdf[3 * (size_t)i] = (kd[3 * (size_t)i] * 0.2126f + kd[3 * (size_t)i + 1] * 0.7152f) + kd[3 * (size_t)i + 2] * 0.0722f;
+    brdf[3 * (size_t)i + 1] = (m * 0.2126f + m * 0.7152f) + m * 0.0722f;
+    float a = fminf(fmaxf(r, 0.01f), 1.f);
+    brdf[3 * (size_t)i + 2] = a * a;
+}
+__global__ void __launch_bounds__(MR_BLOCK) k_flip_env(int W, int H, const float* __restrict__ in, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= W * H) return;
+    const int y = i / W, x = i % W;
+    st3(out, i, ld3(in, (size_t)(H - 1 - y) * W + x));
+}
+// average + combined indirect (:507-515)
+__global__ void __launch_bounds__(MR_BLOCK) k_average(size_t n3, float spp, float* t0, float* t1, float* t2, float* t3, float* t4, float* t5, float* comb) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n3) return;
+    t0[i] /= spp; t1[i] /= spp; t2[i] /= spp; t3[i] /= spp; t4[i] /= spp; t5[i] /= spp;
+    comb[i] = t4[i] + t5[i];
+}
+// final composite (:543-549)
+__global__ void __launch_bounds__(MR_BLOCK) k_composite(int N, const float* __restrict__ occ, const float* __restrict__ kd, const float* __restrict__ rm,
+                                                        const float* __restrict__ dd, const float* __restrict__ ds, const float* __restrict__ di,
+                                                        float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const float m = rm[2 * (size_t)i + 1];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float d = kd[3 * (size_t)i + k] * (1.0f - m);
+        float v = d * dd[3 * (size_t)i + k] + ds[3 * (size_t)i + k] + di[3 * (size_t)i + k];
+        if (occ[i] <= 0.1f) v = 1.0f;
+        if (isnan(v)) v = 0.f; else if (isinf(v)) v = v > 0 ? 3.4028234663852886e38f : -3.4028234663852886e38f;  // torch.nan_to_num
+        out[3 * (size_t)i + k] = v;
+    }
+}
+
+struct Pool {
+    float* base; size_t used, cap;
+    float* take(size_t n) { n = (n + 63) & ~(size_t)63; float* p = base + used; used += n; return used <= cap ? p : nullptr; }
+};
+
+static size_t pool_need(size_t N, size_t WH, size_t H, size_t TS) {
+    size_t per_px = 3 + 4 + 3 + 12 + 1 + 3 + 1 + 3 + 18 + 9 + 5 + 10 + 10 + 5 + 6 + 3;
+    return per_px * N + 3 * WH + WH + (WH + H) + H + (H + 1) + 4 * TS + 64 * 64;
+}
+
+}  // namespace mr
+
+using namespace mr;
+
+struct FrameBufs {
+    float *ray_dir, *nd, *brdf;
+    float *r_ld[2], *r_pdf[2], *r_w[2]; int32_t* r_M[2];
+    float *vis, *fdir, *fdist, *fLi;
+    float* tot[6];  // total_color, total_diff, total_spec, total_color_1, total_diff_1, total_spec_1
+    float *c1, *d1, *s1;
+    float *prd, *new_pos, *new_rd, *new_occ, *new_n, *tmp_pos, *tmp_rd, *tmp_occ, *tmp_n, *new_kd, *new_rm;
+    float *tex, *pdf, *cdf, *mpdf, *mcdf, *tile_data, *tile_pdf;
+    float *den_a, *den_b, *comb;
+};
+
+static int carve(mirres_ctx* ctx, int Wc, int Hc, FrameBufs& B) {
+    const size_t N = ctx->N, WH = (size_t)Wc * Hc, TS = (size_t)ctx->cfg.light_tile_count * ctx->cfg.light_tile_size;
+    const size_t need = pool_need(N, WH, (size_t)Hc, TS);
+    if (ctx->pool_floats < need) {
+        if (ctx->pool) { MR_HIP(hipDeviceSynchronize()); MR_HIP(hipFree(ctx->pool)); ctx->pool = nullptr; }
+        MR_HIP(hipMalloc(&ctx->pool, sizeof(float) * need));
+        ctx->pool_floats = need;
+    }
+    Pool P = {ctx->pool, 0, ctx->pool_floats};
+    B.ray_dir = P.take(3 * N); B.nd = P.take(4 * N); B.brdf = P.take(3 * N);
+    for (int k = 0; k < 2; k++) { B.r_ld[k] = P.take(3 * N); B.r_pdf[k] = P.take(N); B.r_w[k] = P.take(N); B.r_M[k] = reinterpret_cast<int32_t*>(P.take(N)); }
+    B.vis = P.take(N); B.fdir = P.take(3 * N); B.fdist = P.take(N); B.fLi = P.take(3 * N);
+    for (int k = 0; k < 6; k++) B.tot[k] = P.take(3 * N);
+    B.c1 = P.take(3 * N); B.d1 = P.take(3 * N); B.s1 = P.take(3 * N);
+    B.prd = P.take(5 * N); B.new_pos = P.take(3 * N); B.new_rd = P.take(3 * N); B.new_occ = P.take(N); B.new_n = P.take(3 * N);
+    B.tmp_pos = P.take(3 * N); B.tmp_rd = P.take(3 * N); B.tmp_occ = P.take(N); B.tmp_n = P.take(3 * N); B.new_kd = P.take(3 * N); B.new_rm = P.take(2 * N);
+    B.tex = P.take(3 * WH); B.pdf = P.take(WH); B.cdf = P.take(WH + Hc); B.mpdf = P.take(Hc); B.mcdf = P.take(Hc + 1);
+    B.tile_data = P.take(3 * TS); B.tile_pdf = P.take(TS);
+    B.den_a = P.take(3 * N); B.den_b = P.take(3 * N); B.comb = B.c1;  // comb reuses c1 after the loop
+    if (!B.den_b) { set_error("mirres_render: internal pool too small"); return MIRRES_E_STATE; }
+    return 0;
+}
+
+static int finish(mirres_ctx* ctx, const mirres_render_args_t* a, float* tot[6], FrameBufs& B, hipStream_t s) {
+    const int N = (int)ctx->N; const size_t n3 = 3 * (size_t)N;
+    const int spp = a->spp;
+    k_average<<<grid_for(n3, MR_BLOCK), MR_BLOCK, 0, s>>>(n3, (float)spp, tot[0], tot[1], tot[2], tot[3], tot[4], tot[5], B.comb);
+    // EAWDenoise_use_phi(_no_di) (Denoising.py:154-251): stepWidth, then stepWidth/2, ...
+    const float* srcs[5] = {tot[1], tot[2], B.comb, tot[4], tot[5]};
+    for (int k = 0; k < 5; k++) {
+        const float* cur = srcs[k];
+        float swf = (float)a->step_width;
+        for (int it = 0; it < a->denoise_iter; it++) {
+            float* dst = (it == a->denoise_iter - 1) ? a->outs[k + 1] : ((it & 1) ? B.den_b : B.den_a);
+            int rc = mirres_eaw(ctx->fx, ctx->fy, (int)swf, a->c_phi, a->n_phi, a->p_phi, a->occ, cur, a->normal, a->pos, dst, s);
+            if (rc) return rc;
+            cur = dst; swf = swf / 2;
+        }
+        if (a->denoise_iter <= 0) MR_HIP(hipMemcpyAsync(a->outs[k + 1], cur, sizeof(float) * n3, hipMemcpyDeviceToDevice, s));
+    }
+    k_composite<<<grid_for(N, MR_BLOCK), MR_BLOCK, 0, s>>>(N, a->occ, a->kd, a->rough_metal, a->outs[1], a->outs[2], a->outs[3], a->outs[0]);
+    MR_LAUNCH_CHECK("render_finish");
+    return 0;
+}
+
+extern "C" {
+
+int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args_t* a, void* stream) {
+    if (!ctx || !bvh || !a || !a->env_map || !a->occ || !a->normal || !a->depth || !a->kd || !a->rough_metal || !a->ray_dir || !a->pos || a->spp <= 0) {
+        set_error("mirres_render: bad argument"); return MIRRES_E_ARG;
+    }
+    for (int k = 0; k < 6; k++) if (!a->outs[k]) { set_error("mirres_render: outs[%d] is null", k); return MIRRES_E_ARG; }
+    if (bvh->T < 2) { set_error("mirres_render: BVH not built"); return MIRRES_E_STATE; }
+    hipStream_t s = (hipStream_t)stream;
+    const int N = (int)ctx->N, fx = ctx->fx; const size_t n3 = 3 * (size_t)N;
+    const int Wc = a->Wc, Hc = a->Hc;
+    FrameBufs B; int rc = carve(ctx, Wc, Hc, B); if (rc) return rc;
+    const bool partial = !(a->spp_begin == 0 && a->spp_end == 0);
+    const int i0 = partial ? a->spp_begin : 0, i1 = partial ? a->spp_end : a->spp;
+    const int grd = grid_for(N, MR_BLOCK);
+
+    k_prep<<<grd, MR_BLOCK, 0, s>>>(N, a->occ, a->ray_dir, a->normal, a->depth, a->kd, a->rough_metal, B.ray_dir, B.nd, B.brdf);
+    k_flip_env<<<grid_for((size_t)Wc * Hc, MR_BLOCK), MR_BLOCK, 0, s>>>(Wc, Hc, a->env_map, B.tex);
+    rc = mirres_env_make_sampleable(B.tex, Wc, Hc, B.pdf, B.cdf, B.mpdf, B.mcdf, s); if (rc) return rc;
+    // zero-initialised state of restir_di_with_pt (:252-302)
+    MR_HIP(hipMemsetAsync(B.r_ld[0], 0, sizeof(float) * (size_t)(B.vis - B.r_ld[0]), s));   // both reservoirs
+    MR_HIP(hipMemsetAsync(B.tot[0], 0, sizeof(float) * (size_t)(B.tex - B.tot[0]), s));      // totals .. new_rm
+    mirres_env_t E = {B.tex, Wc, Hc, B.pdf, B.cdf, B.mpdf, B.mcdf};
+    mirres_gbuf_t G = {a->occ, a->pos, B.nd, B.brdf, B.ray_dir};
+    mirres_res_t R[2] = {{B.r_ld[0], B.r_pdf[0], B.r_M[0], B.r_w[0]}, {B.r_ld[1], B.r_pdf[1], B.r_M[1], B.r_w[1]}};
+    int cur = 0;  // `reservoirs` = R[cur], `prev_reservoirs` = R[cur^1]
+    const uint32_t passes = 20;  // mTotalRISPasses (:242)
+    const int max_bounce = ctx->cfg.max_bounce;
+
+    for (int i = i0; i < i1; i++) {
+        uint32_t pass = 0;
+        const uint32_t base = a->random_offset + passes * (uint32_t)i;
+        rc = mirres_light_tiles(ctx, B.tex, Wc, Hc, B.pdf, B.cdf, B.mpdf, B.mcdf, base + pass, B.tile_data, nullptr, B.tile_pdf, s); if (rc) return rc;
+        pass += 2;
+        rc = mirres_restir_initial(ctx, bvh, &E, &G, &R[cur], B.tile_data, B.tile_pdf, base + pass, s); if (rc) return rc;
+        pass += 1;
+        if (i > 0) {
+            // prev_* G-buffers alias the current ones from the second sample on (:462-465); a rank that starts in the
+            // middle of the sample range (spp sharding) has no history yet and skips the merge but keeps the pass numbering
+            if (i > i0) { rc = mirres_restir_temporal(ctx, &E, &G, &G, &R[cur], &R[cur ^ 1], nullptr, base + pass, s); if (rc) return rc; }
+            pass += 1;
+        }
+        cur ^= 1;  // swap (:358)
+        rc = mirres_restir_spatial(ctx, bvh, &E, &G, &R[cur], &R[cur ^ 1], nullptr, base + pass, s); if (rc) return rc;
+        pass += 1;
+        rc = mirres_restir_final_vis(ctx, bvh, a->pos, &R[cur], B.vis, s); if (rc) return rc;
+        rc = mirres_restir_eval_final(ctx, &E, &R[cur], B.vis, B.fdir, B.fdist, B.fLi, s); if (rc) return rc;
+        rc = launch_final_shading(&E, a->occ, a->normal, B.ray_dir, a->kd, a->rough_metal, B.fdir, B.fdist, B.fLi, N, B.tot[0], B.tot[1], B.tot[2], true, s);
+        if (rc) return rc;
+        mirres_path_t P0 = {a->occ, a->pos, a->normal, B.ray_dir, a->kd, a->rough_metal, B.prd, B.new_pos, B.new_rd, B.new_occ, B.new_n};
+        rc = launch_new_dir(ctx, bvh, &P0, base + pass, 0, s); if (rc) return rc;
+        pass += 5;
+        float *cp = B.new_pos, *crd = B.new_rd, *cocc = B.new_occ, *cn = B.new_n;
+        float *np_ = B.tmp_pos, *nrd = B.tmp_rd, *nocc = B.tmp_occ, *nn = B.tmp_n;
+        for (int b = 1; b <= max_bounce; b++) {
+            rc = launch_matnet_scatter(a->mat, cocc, cp, N, B.new_kd, B.new_rm, a->use_scale, a->scale, a->const_kd, a->const_rm, s); if (rc) return rc;
+            mirres_path_t Pb = {cocc, cp, cn, crd, B.new_kd, B.new_rm, B.prd, np_, nrd, nocc, nn};
+            rc = launch_bounce(ctx, bvh, &E, &Pb, base + pass, (uint32_t)b, B.c1, B.d1, B.s1, B.tot[3], B.tot[4], B.tot[5], s); if (rc) return rc;
+            pass += 5;
+            float* t;
+            t = cp; cp = np_; np_ = t; t = crd; crd = nrd; nrd = t; t = cocc; cocc = nocc; nocc = t; t = cn; cn = nn; nn = t;
+        }
+        cur ^= 1;  // swap back (:460)
+    }
+    if (partial) {
+        for (int k = 0; k < 6; k++) MR_HIP(hipMemcpyAsync(a->outs[k], B.tot[k], sizeof(float) * n3, hipMemcpyDeviceToDevice, s));
+        return MIRRES_OK;
+    }
+    return finish(ctx, a, B.tot, B, s);
+}
+
+int mirres_render_finish(mirres_ctx_t* ctx, const mirres_render_args_t* a, float* sums[6], void* stream) {
+    if (!ctx || !a || !sums) { set_error("mirres_render_finish: null"); return MIRRES_E_ARG; }
+    for (int k = 0; k < 6; k++) if (!a->outs[k] || !sums[k]) { set_error("mirres_render_finish: null buffer %d", k); return MIRRES_E_ARG; }
+    FrameBufs B; int rc = carve(ctx, a->Wc, a->Hc, B); if (rc) return rc;
+    return finish(ctx, a, sums, B, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,131 @@
+"""Mirror of the material-field part of nerf/render_helper.py (reference): MLPTexture3D = hash grid + tiny MLP.
+
+State-dict compatible with the reference: `encoder.params` (flat fp32 [12 599 920]) and `net.net.{0,2,4}.weight`."""
+import ctypes as C
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import lib, check, stream_ptr
+
+GRADIENT_SCALING = 128.0  # render_helper.py:77-80: MLP input-grad hook x128 (=> grid grads x128), encoder input-grad hook /128
+
+
+class _HashGrid(torch.nn.Module):
+    """Stands in for tcnn.Encoding(3, HashGrid 16x2, T=2^19, base 16, scale 1.447): owns the flat fp32 master `params`."""
+    n_output_dims = 32
+
+    def __init__(self, seed=None):
+        super().__init__()
+        n = lib().mirres_matnet_grid_entries() * 2
+        g = torch.Generator(device="cpu")
+        if seed is not None:
+            g.manual_seed(seed)
+        p = (torch.rand(n, generator=g, dtype=torch.float32) * 2 - 1) * 1e-4  # tcnn grid init: U(-1e-4, 1e-4)
+        self.params = torch.nn.Parameter(p.cuda())
+        self._f16 = None
+        self._f16_version = None
+
+    def packed(self):
+        """fp16 copy of the table the kernels read (tcnn computes in fp16); refreshed when `params` changes."""
+        v = self.params._version
+        if self._f16 is None or self._f16_version != v or self._f16.device != self.params.device:
+            if self._f16 is None:
+                self._f16 = torch.empty(self.params.numel(), dtype=torch.int16, device=self.params.device)
+            check(lib().mirres_matnet_pack_grid(self.params.data_ptr(), self._f16.data_ptr(), self.params.numel(), stream_ptr()), "mirres_matnet_pack_grid")
+            self._f16_version = v
+        return self._f16
+
+
+class _MLP(torch.nn.Module):
+    """render_helper.py:28-51: bias-free Linear/ReLU stack with kaiming-uniform init; evaluated by the engine, not by torch."""
+
+    def __init__(self, cfg, loss_scale=1.0):
+        super().__init__()
+        self.loss_scale = loss_scale
+        net = (torch.nn.Linear(cfg['n_input_dims'], cfg['n_neurons'], bias=False), torch.nn.ReLU())
+        for _ in range(cfg['n_hidden_layers'] - 1):
+            net = net + (torch.nn.Linear(cfg['n_neurons'], cfg['n_neurons'], bias=False), torch.nn.ReLU())
+        net = net + (torch.nn.Linear(cfg['n_neurons'], cfg['n_output_dims'], bias=False),)
+        self.net = torch.nn.Sequential(*net).cuda()
+        self.net.apply(self._init_weights)
+
+    @staticmethod
+    def _init_weights(m):
+        if type(m) == torch.nn.Linear:
+            torch.nn.init.kaiming_uniform_(m.weight, nonlinearity='relu')
+
+
+class _MatNetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, owner, pos, params, w0, w1, w2):
+        pos = pos.detach().contiguous().float()
+        n = pos.shape[0]
+        out = torch.empty((n, 6), dtype=torch.float32, device=pos.device)
+        st = owner._struct()
+        check(lib().mirres_matnet_fwd(C.byref(st), pos.data_ptr(), n, out.data_ptr(), None, stream_ptr()), "mirres_matnet_fwd")
+        ctx.owner = owner
+        ctx.save_for_backward(pos)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (pos,) = ctx.saved_tensors
+        owner = ctx.owner
+        grad_out = grad_out.contiguous().float()
+        gp = torch.zeros_like(owner.encoder.params)
+        w = [owner.net.net[i].weight for i in (0, 2, 4)]
+        gw = [torch.zeros_like(t) for t in w]
+        st = owner._struct()
+        check(lib().mirres_matnet_bwd(C.byref(st), pos.data_ptr(), pos.shape[0], grad_out.data_ptr(), gp.data_ptr(), gw[0].data_ptr(), gw[1].data_ptr(),
+                                      gw[2].data_ptr(), stream_ptr()), "mirres_matnet_bwd")
+        # the reference's hooks scale the gradient that reaches the encoder by 128 (render_helper.py:41,78-80)
+        return None, None, gp * GRADIENT_SCALING, gw[0], gw[1], gw[2]
+
+
+class MLPTexture3D(torch.nn.Module):
+    """render_helper.py:53-124."""
+
+    def __init__(self, AABB, channels=3, internal_dims=32, hidden=2, min_max=None, seed=None):
+        super().__init__()
+        if channels != 6 or internal_dims != 32 or hidden != 2:
+            raise ValueError("the engine implements the reference's material field: channels=6, internal_dims=32, hidden=2")
+        self.channels = channels
+        self.internal_dims = internal_dims
+        self.AABB = AABB.cuda()
+        self.AABB = (self.AABB[0:3], self.AABB[3:6])
+        self.min_max = min_max
+        self.encoder = _HashGrid(seed)
+        mlp_cfg = {"n_input_dims": self.encoder.n_output_dims, "n_output_dims": self.channels, "n_hidden_layers": hidden, "n_neurons": self.internal_dims}
+        self.net = _MLP(mlp_cfg, GRADIENT_SCALING)
+
+    def _struct(self):
+        st = _lib.MatNet()
+        self._keep = [self.encoder.packed()] + [self.net.net[i].weight.detach().contiguous() for i in (0, 2, 4)]
+        st.grid_f16 = self._keep[0].data_ptr()
+        st.w0, st.w1, st.w2 = (t.data_ptr() for t in self._keep[1:])
+        lo, hi = self.AABB[0].detach().cpu().tolist(), self.AABB[1].detach().cpu().tolist()
+        mn = self.min_max[0].detach().cpu().tolist(); mx = self.min_max[1].detach().cpu().tolist()
+        st.aabb_min[:] = lo; st.aabb_max[:] = hi; st.out_min[:] = mn; st.out_max[:] = mx
+        return st
+
+    def sample(self, texc):
+        flat = texc.reshape(-1, 3)
+        out = _MatNetFn.apply(self, flat, self.encoder.params, *[self.net.net[i].weight for i in (0, 2, 4)])
+        return out.view(*texc.shape[:-1], self.channels)
+
+    @torch.no_grad()
+    def sample_no_di(self, texc):
+        flat = texc.reshape(-1, 3).contiguous().float()
+        n = flat.shape[0]
+        out = torch.empty((n, 6), dtype=torch.float32, device=flat.device)
+        if n:
+            st = self._struct()
+            check(lib().mirres_matnet_fwd(C.byref(st), flat.data_ptr(), n, out.data_ptr(), None, stream_ptr()), "mirres_matnet_fwd")
+        return out.view(*texc.shape[:-1], self.channels)
+
+    def clamp_(self):
+        pass
+
+    def cleanup(self):
+        pass

@@ -1,0 +1,339 @@
+"""Mirror of nerf/renderer_restir.py (reference): restirbvhWorker, load_m_for_restir, restir_di_with_pt, run_restir_di_with_pt.
+
+Same names, argument order, in-place mutation and return structure as the reference so that NeRFRenderer.render_stage1
+(nerf/renderer.py:975,1113-1123) can call this module unchanged. Two execution paths produce the same numbers:
+  * fused   : one C call (mirres_render) enqueues the whole spp loop — used when no input requires grad;
+  * stepwise: the reference's per-pass Python loop over the same kernels — used under autograd (stage-1 training)."""
+import ctypes as C
+import time
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import lib, check, stream_ptr
+from ._ops import Module, get_ctx, _f32
+from .Denoising import EAWDenoise_use_phi, EAWDenoise_use_phi_no_di
+from .GenerateLightTiles import make_sampleable, GenerateLightTiles
+from . import Resampling
+from .Resampling import (TemporalResampling, EvaluateFinalSamples_di, FinalShading, process_new_dir_for_pt, indirect_one_hit_divided_no_grad)
+
+_FIXED_RANDOM_OFFSET = None
+
+
+def set_random_offset(v):
+    """Pin the per-frame seed the reference draws with np.random.randint(2**20) (renderer_restir.py:245); None restores the draw."""
+    global _FIXED_RANDOM_OFFSET
+    _FIXED_RANDOM_OFFSET = v
+
+
+def safe_l2_normalize(x, dim=None, eps=1e-6):
+    return torch.nn.functional.normalize(x, p=2, dim=dim, eps=eps)
+
+
+class restirbvhWorker:
+    """renderer_restir.py:13-146: owns the LBVH; `.vrt`, `.v_ind`, `.LBVHNode_info`, `.LBVHNode_aabb` are read by callers."""
+
+    def __init__(self, vt, vt_ind):
+        self.vrt = vt
+        self.v_ind = vt_ind
+        self.h = None
+        self._cap = 0
+        self.LBVHNode_info = None
+        self.LBVHNode_aabb = None
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    def _release(self):
+        if self.LBVHNode_info is not None:
+            Resampling._BVH_OWNERS.pop(self.LBVHNode_info.data_ptr(), None)
+        if self.h:
+            lib().mirres_bvh_destroy(self.h)
+            self.h = None
+
+    def _ensure(self, T):
+        if self.h is None or T > self._cap:
+            if self.h:
+                torch.cuda.synchronize()
+                lib().mirres_bvh_destroy(self.h)
+            h = C.c_void_p()
+            check(lib().mirres_bvh_create(C.byref(h), int(T)), "mirres_bvh_create")
+            self.h, self._cap = h, int(T)
+
+    def update_bvh(self):
+        """renderer_restir.py:25-89 -> (LBVHNode_info i32[2T-1,3], LBVHNode_aabb f32[2T-1,6]); no host synchronisation."""
+        vrt = _f32(self.vrt.detach())
+        v_ind = self.v_ind
+        if v_ind.dtype != torch.int32:
+            v_ind = v_ind.to(torch.int32)
+        v_ind = v_ind.contiguous()
+        T = v_ind.shape[0]
+        self._ensure(T)
+        info = torch.empty((2 * T - 1, 3), dtype=torch.int32, device=vrt.device)
+        aabb = torch.empty((2 * T - 1, 6), dtype=torch.float32, device=vrt.device)
+        check(lib().mirres_bvh_build(self.h, vrt.data_ptr(), vrt.shape[0], v_ind.data_ptr(), T, info.data_ptr(), aabb.data_ptr(), None, stream_ptr()),
+              "mirres_bvh_build")
+        self._keep = (vrt, v_ind)
+        return info, aabb
+
+    def update_mesh(self, vt, vt_ind):
+        if self.LBVHNode_info is not None:
+            Resampling._BVH_OWNERS.pop(self.LBVHNode_info.data_ptr(), None)
+        self.vrt = vt
+        self.v_ind = vt_ind
+        self.LBVHNode_info, self.LBVHNode_aabb = self.update_bvh()
+        Resampling._BVH_OWNERS[self.LBVHNode_info.data_ptr()] = self
+
+    def trace(self, rays_o, rays_d, closest=True, t_min=0.0, t_max=1e7):
+        """bvh_hit / bvh_hit_with_normal over a ray batch (helperDi.slang:197-395). Returns dict(hit, t, pos, normal, prim)."""
+        n = rays_o.shape[0]
+        rays = torch.empty((n, 8), dtype=torch.float32, device=rays_o.device)
+        rays[:, 0:3] = rays_o; rays[:, 3] = t_min; rays[:, 4:7] = rays_d; rays[:, 7] = t_max
+        hit = torch.empty(n, dtype=torch.int32, device=rays.device)
+        if not closest:
+            check(lib().mirres_bvh_trace(self.h, rays.data_ptr(), n, 0, hit.data_ptr(), None, None, None, None, None, stream_ptr()), "mirres_bvh_trace")
+            return dict(hit=hit)
+        t = torch.empty(n, dtype=torch.float32, device=rays.device); pos = torch.empty((n, 3), dtype=torch.float32, device=rays.device)
+        nrm = torch.empty_like(pos); prim = torch.empty(n, dtype=torch.int32, device=rays.device)
+        check(lib().mirres_bvh_trace(self.h, rays.data_ptr(), n, 1, hit.data_ptr(), t.data_ptr(), pos.data_ptr(), nrm.data_ptr(), prim.data_ptr(), None, stream_ptr()),
+              "mirres_bvh_trace")
+        return dict(hit=hit, t=t, pos=pos, normal=nrm, prim=prim)
+
+    def InitialResampling_(self, m, pos_map, reservoirs, env_tex, env_width, env_height, framedim_x, framedim_y, frameIndex, occ_map, normal_depth, brdf_map,
+                           ray_dir, pdf_, cdf_, mpdf_, mcdf_, light_data, light_uv, light_inv_pdf):
+        return Resampling.InitialResampling_(m, self.LBVHNode_info, self.LBVHNode_aabb, self.vrt, self.v_ind, pos_map, reservoirs, env_tex, env_width, env_height,
+                                             framedim_x, framedim_y, frameIndex, occ_map, normal_depth, brdf_map, ray_dir, pdf_, cdf_, mpdf_, mcdf_, light_data,
+                                             light_uv, light_inv_pdf)
+
+    def SpatialResampling_(self, m, pos_map, reservoirs, prev_reservoirs, neighborOffsets, env_tex, env_width, env_height, framedim_x, framedim_y, frameIndex,
+                           occ_map, normal_depth, brdf_map, ray_dir):
+        return Resampling.SpatialResampling_(m, self.LBVHNode_info, self.LBVHNode_aabb, self.vrt, self.v_ind, pos_map, reservoirs, prev_reservoirs,
+                                             neighborOffsets, env_tex, env_width, env_height, framedim_x, framedim_y, frameIndex, occ_map, normal_depth, brdf_map,
+                                             ray_dir)
+
+    def EvaluateFinalSamples_get_vis(self, m, pos_map, reservoirs, framedim_x, framedim_y, vis_map):
+        return Resampling.EvaluateFinalSamples_get_vis(m, self.LBVHNode_info, self.LBVHNode_aabb, self.vrt, self.v_ind, pos_map, reservoirs, framedim_x,
+                                                       framedim_y, vis_map)
+
+
+def load_m_for_restir(framedim_x, framedim_y):
+    """renderer_restir.py:148-228 -> the same 17-tuple (8 module handles, light tiles, reservoirs, final samples, neighbour offsets, tile shape)."""
+    ctx = get_ctx(framedim_x, framedim_y)
+    names = ("make_sampleable", "generateLightTiles", "InitialResampling", "TemporalResampling", "SpatialResampling", "EvaluateFinalSamples", "FinalShading",
+             "denoising")
+    mods = tuple(Module(n, ctx) for n in names)
+    light_tile_count, light_tile_size = ctx.cfg.light_tile_count, ctx.cfg.light_tile_size
+    N = int(framedim_x) * int(framedim_y)
+    dev = 'cuda'
+    light_data = torch.zeros((light_tile_count * light_tile_size, 3), dtype=torch.float, device=dev)
+    light_uv = torch.zeros((light_tile_count * light_tile_size, 2), dtype=torch.int, device=dev)
+    light_inv_pdf = torch.zeros((light_tile_count * light_tile_size, 1), dtype=torch.float, device=dev)
+
+    def _res():
+        return (torch.zeros((N, 3), dtype=torch.float, device=dev), torch.zeros((N, 1), dtype=torch.float, device=dev),
+                torch.zeros((N, 1), dtype=torch.int, device=dev), torch.zeros((N, 1), dtype=torch.float, device=dev))
+    reservoirs = _res()
+    final_samples = (torch.zeros((N, 3), dtype=torch.float, device=dev), torch.zeros((N, 1), dtype=torch.float, device=dev),
+                     torch.zeros((N, 3), dtype=torch.float, device=dev))
+    prev_reservoirs = _res()
+    start_time = time.time()
+    neighborOffsets = torch.zeros((ctx.cfg.neighbor_offset_count, 2), dtype=torch.float, device=dev)
+    check(lib().mirres_neighbor_offsets(ctx.h, neighborOffsets.data_ptr(), stream_ptr()), "mirres_neighbor_offsets")
+    print(f"Create neighbor offset time consumed: {time.time() - start_time} s")
+    return mods + (light_data, light_uv, light_inv_pdf, reservoirs, prev_reservoirs, final_samples, neighborOffsets, light_tile_count, light_tile_size)
+
+
+def restir_di_with_pt(use_scale, scale_x, scale_y, scale_z, mlp_mat, bvh_restir_worker, spp, framedim_x, framedim_y, make_sampleable_m, generateLightTiles_m,
+                      InitialResampling_m, TemporalResampling_m, SpatialResampling_m, EvaluateFinalSamples_m, FinalShading_m, light_data, light_uv, light_inv_pdf,
+                      reservoirs, prev_reservoirs, final_samples, neighborOffsets, light_tile_count, light_tile_size, env_map_init, occ_map, pos_map, normal_map,
+                      depth_map, diffuse_map, roughness_specular, ray_dir_map, prev_occ_map, prev_normal_depth, prev_brdf_map, prev_ray_dir, motionVectors, color):
+    """renderer_restir.py:230-471 (stepwise path): the spp loop in Python over the engine's passes; supports autograd through
+    EvaluateFinalSamples_di / FinalShading exactly where the reference does."""
+    mTotalRISPasses = 5 + 15
+    mFrameIndex = 0
+    random_offset = np.random.randint(2**20) if _FIXED_RANDOM_OFFSET is None else int(_FIXED_RANDOM_OFFSET)
+    N = framedim_x * framedim_y
+    dev = 'cuda'
+    z3 = lambda: torch.zeros((N, 3), dtype=torch.float, device=dev)
+    total_color, total_diff_light, total_spec_light, total_indirect_light = z3(), z3(), z3(), z3()
+    total_color_1, color_1, color_diff_1, color_spec_1, total_diff_light_1, total_spec_light_1 = z3(), z3(), z3(), z3(), z3(), z3()
+    prd = torch.zeros((N, 5), dtype=torch.float, device=dev)
+    new_pos_map, new_ray_d, new_normal_map = z3(), z3(), z3()
+    new_occ_map = torch.zeros((N, 1), dtype=torch.float, device=dev)
+    new_diffuse_map = torch.zeros((N, 3), dtype=torch.float, device=dev)
+    new_roughness_specular = torch.zeros((N, 2), dtype=torch.float, device=dev)
+    new_pos_map_temp, new_ray_d_temp, new_normal_map_temp = z3(), z3(), z3()
+    new_occ_map_temp = torch.zeros((N, 1), dtype=torch.float, device=dev)
+
+    normal_depth = torch.cat((normal_map, depth_map), dim=-1).detach()
+    brdf_map = torch.cat((diffuse_map[:, 0:1] * 0.2126 + diffuse_map[:, 1:2] * 0.7152 + diffuse_map[:, 2:3] * 0.0722,
+                          roughness_specular[:, 1:2] * 0.2126 + roughness_specular[:, 1:2] * 0.7152 + roughness_specular[:, 1:2] * 0.0722,
+                          roughness_specular[:, 0:1]), dim=-1).detach()
+    brdf_map[:, 2].clamp_(min=0.01, max=1)
+    brdf_map[:, 2] = brdf_map[:, 2] * brdf_map[:, 2]
+    brdf_map = brdf_map.contiguous()
+    eva_vis_map = torch.ones((N, 1), dtype=torch.float, device=dev)
+    prev_reservoirs = (torch.zeros((N, 3), dtype=torch.float, device=dev), torch.zeros((N, 1), dtype=torch.float, device=dev),
+                       torch.zeros((N, 1), dtype=torch.int, device=dev), torch.zeros((N, 1), dtype=torch.float, device=dev))
+    prev_occ_map = torch.zeros(occ_map.shape, dtype=torch.float, device=dev)
+    prev_normal_depth = torch.zeros((N, 4), dtype=torch.float, device=dev)
+    prev_brdf_map = torch.zeros(brdf_map.shape, dtype=torch.float, device=dev)
+    prev_ray_dir = torch.zeros(ray_dir_map.shape, dtype=torch.float, device=dev)
+
+    env_map = env_map_init.detach()
+    width, height = env_map.shape[1], env_map.shape[0]
+    env_map_init = torch.flip(env_map_init, dims=[0]).reshape(-1, env_map_init.shape[2])
+    debug_out = None
+    env_map = torch.flip(env_map, dims=[0]).reshape(-1, env_map.shape[2]).contiguous()
+    pdf_, cdf_, mpdf_, mcdf_ = make_sampleable(make_sampleable_m, env_map, width, height)
+    ctx = InitialResampling_m.ctx
+    max_bounce = ctx.cfg.max_bounce
+    W = bvh_restir_worker
+    bvh_args = lambda: (W.LBVHNode_info, W.LBVHNode_aabb, W.vrt, W.v_ind)
+
+    for i in range(0, spp):
+        mCurRISPass = 0
+        frameIndex = random_offset + mTotalRISPasses * mFrameIndex + mCurRISPass
+        GenerateLightTiles(generateLightTiles_m, debug_out, env_map, pdf_, cdf_, mpdf_, mcdf_, width, height, frameIndex, light_data, light_uv, light_inv_pdf,
+                           light_tile_count=light_tile_count, light_tile_size=light_tile_size)
+        mCurRISPass += 2
+        frameIndex = random_offset + mTotalRISPasses * mFrameIndex + mCurRISPass
+        W.InitialResampling_(InitialResampling_m, pos_map, reservoirs, env_map, width, height, framedim_x, framedim_y, frameIndex, occ_map, normal_depth, brdf_map,
+                             ray_dir_map, pdf_, cdf_, mpdf_, mcdf_, light_data, light_uv, light_inv_pdf)
+        mCurRISPass += 1
+        frameIndex = random_offset + mTotalRISPasses * mFrameIndex + mCurRISPass
+        if i > 0:
+            TemporalResampling(TemporalResampling_m, reservoirs, prev_reservoirs, env_map, width, height, framedim_x, framedim_y, frameIndex, occ_map, normal_depth,
+                               brdf_map, ray_dir_map, prev_occ_map, prev_normal_depth, prev_brdf_map, prev_ray_dir, motionVectors)
+            mCurRISPass += 1
+        frameIndex = random_offset + mTotalRISPasses * mFrameIndex + mCurRISPass
+        reservoirs, prev_reservoirs = prev_reservoirs, reservoirs
+        W.SpatialResampling_(SpatialResampling_m, pos_map, reservoirs, prev_reservoirs, neighborOffsets, env_map, width, height, framedim_x, framedim_y, frameIndex,
+                             occ_map, normal_depth, brdf_map, ray_dir_map)
+        mCurRISPass += 1
+        W.EvaluateFinalSamples_get_vis(EvaluateFinalSamples_m, pos_map, reservoirs, framedim_x, framedim_y, eva_vis_map)
+        final_Li = EvaluateFinalSamples_di.apply(EvaluateFinalSamples_m, reservoirs[0], reservoirs[1], reservoirs[2], reservoirs[3], env_map_init, width, height,
+                                                 framedim_x, framedim_y, final_samples[0], final_samples[1], eva_vis_map)
+        color, color_diff, color_spec = FinalShading.apply(FinalShading_m, final_samples[0], final_samples[1], final_Li, env_map, width, height, framedim_x,
+                                                           framedim_y, occ_map, normal_map, ray_dir_map, diffuse_map, roughness_specular)
+        frameIndex = random_offset + mTotalRISPasses * mFrameIndex + mCurRISPass
+        process_new_dir_for_pt(FinalShading_m, *bvh_args(), frameIndex, 0, framedim_x, framedim_y, occ_map, pos_map, normal_map.detach(), ray_dir_map, prd,
+                               diffuse_map.detach(), roughness_specular.detach(), new_pos_map, new_ray_d, new_occ_map, new_normal_map)
+        mCurRISPass += 5
+        cur = (new_occ_map, new_pos_map, new_normal_map, new_ray_d)
+        nxt = (new_occ_map_temp, new_pos_map_temp, new_normal_map_temp, new_ray_d_temp)
+        for b in range(1, max_bounce + 1):   # the reference unrolls b = 1, 2 (:396-454)
+            indices = torch.where(cur[0] >= 0.5)
+            kd_ks = mlp_mat.sample_no_di(cur[1][indices[0]])
+            new_diffuse_map[indices[0]] = kd_ks[..., 0:3]
+            new_roughness_specular[indices[0]] = torch.cat((kd_ks[..., 4:5], kd_ks[..., 5:6]), dim=-1)
+            if use_scale:
+                new_diffuse_map[indices[0], 0] = new_diffuse_map[indices[0], 0] * scale_x
+                new_diffuse_map[indices[0], 1] = new_diffuse_map[indices[0], 1] * scale_y
+                new_diffuse_map[indices[0], 2] = new_diffuse_map[indices[0], 2] * scale_z
+                new_diffuse_map = torch.clamp(new_diffuse_map, min=0.0, max=1.0)
+            frameIndex = random_offset + mTotalRISPasses * mFrameIndex + mCurRISPass
+            indirect_one_hit_divided_no_grad(FinalShading_m, *bvh_args(), frameIndex, b, framedim_x, framedim_y, env_map, width, height, pdf_, cdf_, mpdf_, mcdf_,
+                                             cur[0], cur[1], cur[2], cur[3], prd, new_diffuse_map, new_roughness_specular, color_1, color_diff_1, color_spec_1,
+                                             nxt[1], nxt[3], nxt[0], nxt[2])
+            total_color_1 += color_1
+            total_diff_light_1 += color_diff_1
+            total_spec_light_1 += color_spec_1
+            mCurRISPass += 5
+            cur, nxt = nxt, cur
+        mFrameIndex = mFrameIndex + 1
+        reservoirs, prev_reservoirs = prev_reservoirs, reservoirs
+        prev_occ_map, prev_normal_depth, prev_brdf_map, prev_ray_dir = occ_map, normal_depth, brdf_map, ray_dir_map
+        total_color = total_color + color
+        total_diff_light = total_diff_light + color_diff
+        total_spec_light = total_spec_light + color_spec
+    return total_color, total_color_1, total_diff_light, total_spec_light, total_diff_light_1, total_spec_light_1, total_indirect_light, mFrameIndex
+
+
+def _needs_grad(*ts):
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts)
+
+
+def render_fused(ctx, bvh_restir_worker, mlp_mat, use_scale, scale, env_map, occ_map, normal_map, depth_map, diffuse_map, roughness_specular, ray_dir_map, pos_map,
+                 spp, denoise_iter, stepWidth, c_phi, n_phi, p_phi, random_offset, spp_range=None, const_kd=(0.6, 0.6, 0.6), const_rm=(0.5, 0.0)):
+    """One C call for the whole frame (mirres_render). Returns the 6 output buffers [N,3] (raw sums when spp_range is given)."""
+    N = ctx.N
+    a = _lib.RenderArgs()
+    keep = []
+    a.spp, a.random_offset = int(spp), int(random_offset) & 0xffffffff
+    a.use_scale = int(bool(use_scale)); a.scale[:] = [float(s) for s in scale]
+    env = _f32(env_map.detach()); keep.append(env)
+    a.env_map, a.Hc, a.Wc = env.data_ptr(), env.shape[0], env.shape[1]
+    if not occ_map.is_contiguous():
+        raise _lib.MirresError("occ_map is modified in place and must be contiguous")
+    a.occ = occ_map.data_ptr()
+    for name, t in (("normal", normal_map), ("depth", depth_map), ("kd", diffuse_map), ("rough_metal", roughness_specular), ("ray_dir", ray_dir_map), ("pos", pos_map)):
+        t = _f32(t.detach()); keep.append(t); setattr(a, name, t.data_ptr())
+    if mlp_mat is not None:
+        st = mlp_mat._struct(); keep.append(st)
+        a.mat = C.pointer(st)
+    else:
+        a.mat = None
+    a.const_kd[:] = list(const_kd); a.const_rm[:] = list(const_rm)
+    a.denoise_iter, a.step_width, a.c_phi, a.n_phi, a.p_phi = int(denoise_iter), int(stepWidth), float(c_phi), float(n_phi), float(p_phi)
+    outs = [torch.empty((N, 3), dtype=torch.float32, device=env.device) for _ in range(6)]
+    for k in range(6):
+        a.outs[k] = outs[k].data_ptr()
+    if spp_range is not None:
+        a.spp_begin, a.spp_end = int(spp_range[0]), int(spp_range[1])
+    check(lib().mirres_render(ctx.h, bvh_restir_worker.h, C.byref(a), stream_ptr()), "mirres_render")
+    return outs, a, keep
+
+
+def run_restir_di_with_pt(use_scale, scale_x, scale_y, scale_z, mlp_mat, gb_depth, bvh_restir_worker, make_sampleable_m, generateLightTiles_m, InitialResampling_m,
+                          TemporalResampling_m, SpatialResampling_m, EvaluateFinalSamples_m, FinalShading_m, denoising_m, light_data, light_uv, light_inv_pdf,
+                          reservoirs, prev_reservoirs, final_samples, neighborOffsets, light_tile_count, light_tile_size, env_map, occ_map, normal_map, depth_map,
+                          diffuse_map, roughness_specular, ray_dir_map, pos_map, prev_occ_map, prev_normal_depth, prev_brdf_map, prev_ray_dir, framedim_x,
+                          framedim_y, spp, denoise_iter, stepWidth, c_phi_scale=1.0, n_phi_scale=0.1, p_phi_scale=0.1):
+    """renderer_restir.py:473-550. Mutates occ_map in place; returns (final_color, denoised_diffuse, denoised_spec, denoised_indirect,
+    denoised_indirect_diff, denoised_indirect_spec), each f32[N,3]."""
+    if gb_depth is not None:
+        raise NotImplementedError("the bilateral denoiser (--use_bi_de, nerf/renderutils) is outside this engine's hot path (SURVEY §8 f-3)")
+    from .render_helper import MLPTexture3D
+    grad = _needs_grad(env_map, normal_map, diffuse_map, roughness_specular)
+    if not grad and (mlp_mat is None or isinstance(mlp_mat, MLPTexture3D)):
+        random_offset = np.random.randint(2**20) if _FIXED_RANDOM_OFFSET is None else int(_FIXED_RANDOM_OFFSET)
+        outs, _, _ = render_fused(InitialResampling_m.ctx, bvh_restir_worker, mlp_mat, use_scale, (scale_x, scale_y, scale_z), env_map, occ_map, normal_map,
+                                  depth_map, diffuse_map, roughness_specular, ray_dir_map, pos_map, spp, denoise_iter, stepWidth, c_phi_scale, n_phi_scale,
+                                  p_phi_scale, random_offset)
+        return tuple(outs)
+
+    indices = torch.where(occ_map <= 0.5)
+    occ_map[indices[0], :] = 0
+    ray_dir_map = safe_l2_normalize(ray_dir_map, dim=-1).contiguous()
+    motionVectors = None  # all-zero in the reference (:487)
+    color = None
+    diffuse, normal, roughnessSpecular = diffuse_map, normal_map, roughness_specular
+    (total_color, total_color_1, total_diff_light, total_spec_light, total_diff_light_1, total_spec_light_1, total_indirect_light, mFrameIndex) = restir_di_with_pt(
+        use_scale, scale_x, scale_y, scale_z, mlp_mat, bvh_restir_worker, spp, framedim_x, framedim_y, make_sampleable_m, generateLightTiles_m, InitialResampling_m,
+        TemporalResampling_m, SpatialResampling_m, EvaluateFinalSamples_m, FinalShading_m, light_data, light_uv, light_inv_pdf, reservoirs, prev_reservoirs,
+        final_samples, neighborOffsets, light_tile_count, light_tile_size, env_map, occ_map, pos_map, normal, depth_map, diffuse, roughnessSpecular, ray_dir_map,
+        prev_occ_map, prev_normal_depth, prev_brdf_map, prev_ray_dir, motionVectors, color)
+    total_color = total_color / mFrameIndex
+    total_diff_light = total_diff_light / mFrameIndex
+    total_spec_light = total_spec_light / mFrameIndex
+    total_color_1 = total_color_1 / mFrameIndex
+    total_diff_light_1 = total_diff_light_1 / mFrameIndex
+    total_spec_light_1 = total_spec_light_1 / mFrameIndex
+    combined_color_indirect = total_diff_light_1 + total_spec_light_1
+    args = (denoising_m, c_phi_scale, n_phi_scale, p_phi_scale, stepWidth, denoise_iter, framedim_x, framedim_y, occ_map)
+    denoised_diffuse = EAWDenoise_use_phi(*args, total_diff_light, normal, pos_map)
+    denoised_spec = EAWDenoise_use_phi(*args, total_spec_light, normal, pos_map)
+    denoised_indirect = EAWDenoise_use_phi_no_di(*args, combined_color_indirect, normal, pos_map)
+    denoised_indirect_diff = EAWDenoise_use_phi_no_di(*args, total_diff_light_1, normal, pos_map)
+    denoised_indirect_spec = EAWDenoise_use_phi_no_di(*args, total_spec_light_1, normal, pos_map)
+    diffuse = diffuse * (1.0 - roughnessSpecular[..., 1:2])
+    final_color = diffuse * denoised_diffuse + denoised_spec + denoised_indirect
+    indices = torch.where(occ_map <= 0.1)
+    final_color[indices[0], :] = 1.0
+    final_color = torch.nan_to_num(final_color, 0.0)
+    return final_color, denoised_diffuse, denoised_spec, denoised_indirect, denoised_indirect_diff, denoised_indirect_spec
