@@ -64,9 +64,15 @@ int mirres_ctx_create(mirres_ctx_t** out, int fx, int fy, const mirres_config_t*
 void mirres_ctx_destroy(mirres_ctx_t* ctx);
 /* createNeighborOffsetTexture (make_sampleable.slang:186-205) / 127 -> f32[count,2]; ctx keeps a copy.      */
 int mirres_neighbor_offsets(mirres_ctx_t* ctx, float* out, void* stream);
-/* totals since the last reset: u64[8] = rays_any, rays_closest, popped, entered, leaves, overflow, -, - (host; synchronises) */
+/* totals since the last reset (host; synchronises): u64[8] = rays_any, rays_closest, then (popped, entered, leaves) of the any-hit
+ * kernel and (popped, entered, leaves) of the closest-hit kernel — the node counts only advance while instrument bit 0 is set. */
 int mirres_ctx_stats(mirres_ctx_t* ctx, uint64_t* h_out, int reset);
+/* instrument bit 0: traversal kernels count visited nodes into the stats (slower kernels); bit 1: every traversal launch is
+ * bracketed by HIP events on its own stream so that mirres_ctx_trace_time can report per-kernel durations.              */
 int mirres_ctx_set_instrument(mirres_ctx_t* ctx, int on);
+/* sums the event-timed traversal launches since the last call (host; synchronises): ms and launch counts for the any-hit
+ * and the closest-hit kernel.                                                                                         */
+int mirres_ctx_trace_time(mirres_ctx_t* ctx, double* h_ms_any, int* h_n_any, double* h_ms_closest, int* h_n_closest);
 
 /* ------------------------------------------------------------------ environment light */
 /* make_sampleable (GenerateLightTiles.py:4-29 + make_sampleable.slang:34-86). env_tex f32[Hc*Wc,3] is the

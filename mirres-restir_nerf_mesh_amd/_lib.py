@@ -68,6 +68,7 @@ SIGNATURES = {
     "mirres_neighbor_offsets": (C.c_int, [vp, vp, vp]),
     "mirres_ctx_stats": (C.c_int, [vp, C.POINTER(C.c_uint64), C.c_int]),
     "mirres_ctx_set_instrument": (C.c_int, [vp, C.c_int]),
+    "mirres_ctx_trace_time": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "mirres_env_make_sampleable": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
     "mirres_light_tiles": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, u32, vp, vp, vp, vp]),
     "mirres_restir_initial": (C.c_int, [vp, vp, PENV, PG, PRES, vp, vp, u32, vp]),

@@ -37,7 +37,13 @@ class Context:
         out = (C.c_uint64 * 8)()
         check(lib().mirres_ctx_stats(self.h, out, int(reset)), "mirres_ctx_stats")
         v = list(out)
-        return dict(rays_any=v[0], rays_closest=v[1], popped=v[2], entered=v[3], leaves=v[4])
+        return dict(rays_any=v[0], rays_closest=v[1], popped=v[2], entered=v[3], leaves=v[4], cl_popped=v[5], cl_entered=v[6], cl_leaves=v[7])
+
+    def trace_time(self):
+        """(ms_any, launches_any, ms_closest, launches_closest) of the event-timed traversal launches since the last call."""
+        a, c = C.c_double(0), C.c_double(0); na, nc = C.c_int(0), C.c_int(0)
+        check(lib().mirres_ctx_trace_time(self.h, C.byref(a), C.byref(na), C.byref(c), C.byref(nc)), "mirres_ctx_trace_time")
+        return a.value, na.value, c.value, nc.value
 
     def set_instrument(self, on):
         check(lib().mirres_ctx_set_instrument(self.h, int(on)), "mirres_ctx_set_instrument")

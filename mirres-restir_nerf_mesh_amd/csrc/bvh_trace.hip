@@ -201,7 +201,7 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_closest(BvhView B, con
             sp += c[0]; se += c[1]; sl += c[2];
         }
     }
-    if (COUNT && stats) { atomicAdd(&stats[2], sp); atomicAdd(&stats[3], se); atomicAdd(&stats[4], sl); }
+    if (COUNT && stats) { atomicAdd(&stats[5], sp); atomicAdd(&stats[6], se); atomicAdd(&stats[7], sl); }
     if (stats && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[1], (unsigned long long)n);
 }
 

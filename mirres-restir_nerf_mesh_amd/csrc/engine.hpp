@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <vector>
 #include "../../include/mirres.h"
 
 namespace mr {
@@ -63,6 +64,8 @@ struct mirres_ctx {
     uint32_t* counters = nullptr;   // [8] device: any_count, closest_count, scratch...
     unsigned long long* stats = nullptr;  // [8] device totals (see mirres_ctx_stats)
     int instrument = 0;
+    std::vector<hipEvent_t> ev_any, ev_cl;   // start/stop pairs of event-timed traversal launches
+    size_t ev_any_used = 0, ev_cl_used = 0;
     // per-pixel scratch
     int32_t* slot_a = nullptr;      // [N] first any-ray slot of the pixel (or -1)
     uint32_t* mask_a = nullptr;     // [N] per-pass bit mask (spatial: accepted neighbours; bounce: ray kinds)
@@ -84,5 +87,7 @@ int trace_any_queue(const mirres_bvh* bvh, const Ray* rays, const uint32_t* d_co
                     unsigned long long* stats, hipStream_t s);
 int trace_closest_queue(const mirres_bvh* bvh, const Ray* rays, const uint32_t* d_count, size_t capacity, HitRec* out,
                         unsigned long long* stats, hipStream_t s);
+int trace_any(mirres_ctx* ctx, mirres_bvh* bvh, size_t cap, hipStream_t s);       // ctx->any_rays -> ctx->any_hit
+int trace_closest(mirres_ctx* ctx, mirres_bvh* bvh, size_t cap, hipStream_t s);   // ctx->cl_rays  -> ctx->cl_hit
 inline int grid_for(size_t n, int block) { size_t g = (n + block - 1) / block; return (int)(g < 1 ? 1 : g); }
 }  // namespace mr

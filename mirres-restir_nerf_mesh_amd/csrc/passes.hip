@@ -402,9 +402,32 @@ static GBufD gbufd(const mirres_gbuf_t* g) { GBufD G; G.occ = g->occ; G.pos = g-
 static ResD resd(const mirres_res_t* r) { ResD R; R.light_data = r->light_data; R.light_pdf = r->light_pdf; R.M = r->M; R.weight = r->weight; return R; }
 static EnvD envh(const mirres_env_t* e) { EnvD E; E.tex = e->tex; E.W = e->Wc; E.H = e->Hc; E.pdf = e->pdf; E.cdf = e->cdf; E.mpdf = e->mpdf; E.mcdf = e->mcdf; return E; }
 
+int trace_closest_queue_counted(const mirres_bvh* bvh, const Ray* rays, const uint32_t* d_count, size_t capacity, HitRec* out,
+                                unsigned long long* stats, hipStream_t s);
+
+static int ev_pair(std::vector<hipEvent_t>& pool, size_t& used, hipEvent_t** a, hipEvent_t** b) {
+    if (used + 2 > pool.size()) {
+        size_t old = pool.size(); pool.resize(old + 512);
+        for (size_t i = old; i < pool.size(); i++) MR_HIP(hipEventCreate(&pool[i]));
+    }
+    *a = &pool[used]; *b = &pool[used + 1]; used += 2;
+    return 0;
+}
 int trace_any(mirres_ctx* ctx, mirres_bvh* bvh, size_t cap, hipStream_t s) {
-    if (ctx->instrument) return trace_any_queue_counted(bvh, ctx->any_rays, &ctx->counters[0], cap, ctx->any_hit, ctx->stats, s);
-    return trace_any_queue(bvh, ctx->any_rays, &ctx->counters[0], cap, ctx->any_hit, ctx->stats, s);
+    hipEvent_t *e0 = nullptr, *e1 = nullptr;
+    if (ctx->instrument & 2) { int rc = ev_pair(ctx->ev_any, ctx->ev_any_used, &e0, &e1); if (rc) return rc; MR_HIP(hipEventRecord(*e0, s)); }
+    int rc = (ctx->instrument & 1) ? trace_any_queue_counted(bvh, ctx->any_rays, &ctx->counters[0], cap, ctx->any_hit, ctx->stats, s)
+                                   : trace_any_queue(bvh, ctx->any_rays, &ctx->counters[0], cap, ctx->any_hit, ctx->stats, s);
+    if (e1) MR_HIP(hipEventRecord(*e1, s));
+    return rc;
+}
+int trace_closest(mirres_ctx* ctx, mirres_bvh* bvh, size_t cap, hipStream_t s) {
+    hipEvent_t *e0 = nullptr, *e1 = nullptr;
+    if (ctx->instrument & 2) { int rc = ev_pair(ctx->ev_cl, ctx->ev_cl_used, &e0, &e1); if (rc) return rc; MR_HIP(hipEventRecord(*e0, s)); }
+    int rc = (ctx->instrument & 1) ? trace_closest_queue_counted(bvh, ctx->cl_rays, &ctx->counters[1], cap, ctx->cl_hit, ctx->stats, s)
+                                   : trace_closest_queue(bvh, ctx->cl_rays, &ctx->counters[1], cap, ctx->cl_hit, ctx->stats, s);
+    if (e1) MR_HIP(hipEventRecord(*e1, s));
+    return rc;
 }
 
 }  // namespace mr
@@ -447,6 +470,8 @@ void mirres_ctx_destroy(mirres_ctx_t* c) {
     if (!c) return;
     void* ptrs[] = {c->any_rays, c->any_hit, c->cl_rays, c->cl_hit, c->counters, c->stats, c->slot_a, c->mask_a, c->slot_c, c->pend, c->noff, c->pool};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (hipEvent_t e : c->ev_any) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->ev_cl) (void)hipEventDestroy(e);
     delete c;
 }
 
@@ -464,6 +489,17 @@ int mirres_ctx_stats(mirres_ctx_t* ctx, uint64_t* h_out, int reset) {
     return MIRRES_OK;
 }
 int mirres_ctx_set_instrument(mirres_ctx_t* ctx, int on) { if (!ctx) return MIRRES_E_ARG; ctx->instrument = on; return MIRRES_OK; }
+int mirres_ctx_trace_time(mirres_ctx_t* ctx, double* h_ms_any, int* h_n_any, double* h_ms_closest, int* h_n_closest) {
+    if (!ctx) return MIRRES_E_ARG;
+    MR_HIP(hipDeviceSynchronize());
+    double a = 0, c = 0;
+    for (size_t i = 0; i + 1 < ctx->ev_any_used; i += 2) { float ms = 0; MR_HIP(hipEventElapsedTime(&ms, ctx->ev_any[i], ctx->ev_any[i + 1])); a += ms; }
+    for (size_t i = 0; i + 1 < ctx->ev_cl_used; i += 2) { float ms = 0; MR_HIP(hipEventElapsedTime(&ms, ctx->ev_cl[i], ctx->ev_cl[i + 1])); c += ms; }
+    if (h_ms_any) *h_ms_any = a; if (h_n_any) *h_n_any = (int)(ctx->ev_any_used / 2);
+    if (h_ms_closest) *h_ms_closest = c; if (h_n_closest) *h_n_closest = (int)(ctx->ev_cl_used / 2);
+    ctx->ev_any_used = 0; ctx->ev_cl_used = 0;
+    return MIRRES_OK;
+}
 
 int mirres_env_make_sampleable(const float* env_tex, int Wc, int Hc, float* pdf, float* cdf, float* mpdf, float* mcdf, void* stream) {
     if (!env_tex || !pdf || !cdf || !mpdf || !mcdf || Wc <= 0 || Hc <= 0) { set_error("mirres_env_make_sampleable: bad argument"); return MIRRES_E_ARG; }

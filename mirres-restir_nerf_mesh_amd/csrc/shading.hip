@@ -266,8 +266,7 @@ int launch_new_dir(mirres_ctx* ctx, mirres_bvh* bvh, const mirres_path_t* p, uin
     const int N = (int)ctx->N, grd = grid_for(N, MR_BLOCK);
     MR_HIP(hipMemsetAsync(&ctx->counters[1], 0, sizeof(uint32_t), s));
     k_new_dir_gen<<<grd, MR_BLOCK, 0, s>>>(*p, ctx->cfg.max_bounce, ctx->cfg.vis_near, frameIndex, bounce_count, ctx->fx, N, ctx->cl_rays, &ctx->counters[1], ctx->slot_c);
-    int rc = ctx->instrument ? trace_closest_queue_counted(bvh, ctx->cl_rays, &ctx->counters[1], (size_t)N, ctx->cl_hit, ctx->stats, s)
-                             : trace_closest_queue(bvh, ctx->cl_rays, &ctx->counters[1], (size_t)N, ctx->cl_hit, ctx->stats, s);
+    int rc = trace_closest(ctx, bvh, (size_t)N, s);
     if (rc) return rc;
     k_new_dir_resolve<<<grd, MR_BLOCK, 0, s>>>(*p, N, ctx->slot_c, ctx->cl_hit);
     MR_LAUNCH_CHECK("pt_new_dir");
@@ -279,14 +278,8 @@ int launch_bounce(mirres_ctx* ctx, mirres_bvh* bvh, const mirres_env_t* env, con
     MR_HIP(hipMemsetAsync(&ctx->counters[0], 0, 2 * sizeof(uint32_t), s));
     k_bounce_gen<<<grd, MR_BLOCK, 0, s>>>(*p, envh(env), ctx->cfg.max_bounce, ctx->cfg.vis_near, frameIndex, bounce_count, ctx->fx, N, color, dc, sc, ctx->any_rays,
                                            &ctx->counters[0], ctx->cl_rays, &ctx->counters[1], ctx->slot_a, ctx->mask_a, ctx->slot_c, ctx->pend);
-    int rc;
-    if (ctx->instrument) {
-        rc = trace_any_queue_counted(bvh, ctx->any_rays, &ctx->counters[0], 2 * (size_t)N, ctx->any_hit, ctx->stats, s); if (rc) return rc;
-        rc = trace_closest_queue_counted(bvh, ctx->cl_rays, &ctx->counters[1], (size_t)N, ctx->cl_hit, ctx->stats, s); if (rc) return rc;
-    } else {
-        rc = trace_any_queue(bvh, ctx->any_rays, &ctx->counters[0], 2 * (size_t)N, ctx->any_hit, ctx->stats, s); if (rc) return rc;
-        rc = trace_closest_queue(bvh, ctx->cl_rays, &ctx->counters[1], (size_t)N, ctx->cl_hit, ctx->stats, s); if (rc) return rc;
-    }
+    int rc = trace_any(ctx, bvh, 2 * (size_t)N, s); if (rc) return rc;
+    rc = trace_closest(ctx, bvh, (size_t)N, s); if (rc) return rc;
     if (acc_c) k_bounce_resolve<true><<<grd, MR_BLOCK, 0, s>>>(*p, N, ctx->slot_a, ctx->mask_a, ctx->slot_c, ctx->any_hit, ctx->cl_hit, ctx->pend, color, dc, sc, acc_c, acc_d, acc_s);
     else k_bounce_resolve<false><<<grd, MR_BLOCK, 0, s>>>(*p, N, ctx->slot_a, ctx->mask_a, ctx->slot_c, ctx->any_hit, ctx->cl_hit, ctx->pend, color, dc, sc, nullptr, nullptr, nullptr);
     MR_LAUNCH_CHECK("pt_bounce");

@@ -1,0 +1,54 @@
+"""Harness pieces around the hot path (SURVEY §8 a-H): synthetic G-buffer by primary-ray cast through the engine's BVH,
+and the reference's post-processing formulas (sRGB, SSAA down-scale, PSNR) restated for the evaluation driver.
+  linear2srgb : nerf/utils.py:80-106   x<=0.0031308 ? 12.92x : 1.055 (x+1e-6)^(1/2.4) - 0.055
+  PSNR        : nerf/utils.py:611-623  -10 log10(mean((pred-gt)^2))
+"""
+import numpy as np
+import torch
+
+from . import scene
+
+
+def build_gbuffer(worker, H, W, ssaa=1, azimuth_deg=30.0, elevation_deg=30.0, kd=(0.6, 0.6, 0.6), roughness=0.5, metallic=0.0, mlp_mat=None):
+    """Primary visibility from the BVH closest-hit kernel (stands in for nvdiffrast). Returns a dict of [N,*] CUDA tensors at the
+    internal (ssaa-scaled) resolution, in the layout render_stage1 hands to run_restir_di_with_pt (nerf/renderer.py:1083-1123)."""
+    h, w = H * ssaa, W * ssaa
+    eye, rd = scene.camera_rays(h, w, azimuth_deg, elevation_deg)
+    dev = worker.vrt.device
+    rays_d = torch.from_numpy(rd).to(dev)
+    rays_o = torch.from_numpy(eye).to(dev)[None].expand(h * w, 3).contiguous()
+    r = worker.trace(rays_o, rays_d, closest=True)
+    occ = r["hit"].to(torch.float32)[:, None].contiguous()
+    pos = r["pos"]
+    normal = torch.where(occ > 0.5, r["normal"], torch.zeros_like(r["normal"])).contiguous()
+    depth = torch.norm(pos - rays_o, dim=1, keepdim=True).contiguous()
+    N = h * w
+    if mlp_mat is not None:
+        kdks = mlp_mat.sample_no_di(pos)
+        kd_map = kdks[:, 0:3].contiguous()
+        rm = torch.cat((kdks[:, 4:5], kdks[:, 5:6]), dim=-1).contiguous()
+    else:
+        kd_map = torch.tensor(kd, dtype=torch.float32, device=dev)[None].expand(N, 3).contiguous()
+        rm = torch.tensor([roughness, metallic], dtype=torch.float32, device=dev)[None].expand(N, 2).contiguous()
+    return dict(fx=w, fy=h, occ=occ, pos=pos.contiguous(), normal=normal, depth=depth, kd=kd_map, rm=rm, ray_dir=rays_d, eye=eye)
+
+
+def linear2srgb(x):
+    return torch.where(x <= 0.0031308, 12.92 * x, 1.055 * torch.pow(x + 1e-6, 1.0 / 2.4) - 0.055)
+
+
+def postprocess(final_color, occ, H, W, ssaa):
+    """clamp[0,1] -> sRGB -> x alpha -> bilinear SSAA down-scale -> + (1-alpha) * 1  (nerf/renderer.py:1125-1129,1162-1164,1208-1209,1265-1267,1301-1302)."""
+    h, w = H * ssaa, W * ssaa
+    img = linear2srgb(torch.clamp(final_color, 0.0, 1.0)).view(h, w, 3)
+    alpha = (occ.view(h, w, 1) > 0.5).float()
+    img = img * alpha
+    if ssaa > 1:
+        img = torch.nn.functional.interpolate(img.permute(2, 0, 1)[None], size=(H, W), mode="bilinear", align_corners=False, antialias=True)[0].permute(1, 2, 0)
+        alpha = torch.nn.functional.interpolate(alpha.permute(2, 0, 1)[None], size=(H, W), mode="bilinear", align_corners=False, antialias=True)[0].permute(1, 2, 0)
+    return img + (1 - alpha) * 1.0
+
+
+def psnr(pred, gt):
+    mse = torch.mean((pred - gt) ** 2)
+    return float(-10.0 * torch.log10(mse))
