@@ -69,7 +69,7 @@ def make_mesh(subdiv=3, ground_res=16, seed=0, radius=0.55):
     a = np.deg2rad(7.0)
     Rx = np.array([[1, 0, 0], [0, np.cos(a), -np.sin(a)], [0, np.sin(a), np.cos(a)]])
     Rz = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]])
-    gv = gv @ (Rz @ Rx).T * 0.88
+    gv = gv @ (Rz @ Rx).T * 0.8
     idx = np.arange((ground_res + 1) ** 2).reshape(ground_res + 1, ground_res + 1)
     q00, q01, q10, q11 = idx[:-1, :-1].ravel(), idx[:-1, 1:].ravel(), idx[1:, :-1].ravel(), idx[1:, 1:].ravel()
     gf = np.concatenate([np.stack([q00, q01, q11], 1), np.stack([q00, q11, q10], 1)], axis=0) + len(v)

@@ -154,6 +154,18 @@ def make_sampleable(tex_flat, W, H):
     return pdf, cdf, mpdf, mcdf
 
 
+def env_weights(tex_flat, W, H):
+    out = np.zeros(W * H, np.float32)
+    lib().orc_env_weights(_p(_c(tex_flat, np.float32), f32p), W, H, _p(out, f32p))
+    return out
+
+
+def distribution2d(pdf, cdf, W, H):
+    pdf = _c(pdf, np.float32).copy(); cdf = _c(cdf, np.float32).copy()
+    lib().orc_distribution2d(W, H, _p(pdf, f32p), _p(cdf, f32p))
+    return pdf, cdf
+
+
 def neighbor_offsets(count=8192):
     out = np.zeros(2 * count, np.float32)
     lib().orc_neighbor_offsets(count, _p(out, f32p))

@@ -115,6 +115,33 @@ static inline float pdf_li(const Env& E, f3 dir) {
     return (E.pdf[row * E.W + col] * E.mpdf[row] * E.W * E.H) / (2 * PI * PI * sin_theta);
 }
 
+// kernel `make_sampleable` alone (make_sampleable.slang:34-60): un-normalised texel weights
+static inline void env_weights(const float* tex, int W, int H, float* weight) {
+    const float PI = 3.141592653589793f;
+    for (int h = 0; h < H; h++)
+        for (int w = 0; w < W; w++) {
+            float v = (h + .5f) / H;
+            float sin_theta = sinf(PI * v);
+            f2 uv = mk2((w + .5f) / W, v);
+            float theta = uv.y * PI, phi = uv.x * 2 * PI;
+            float cos_theta = cosf(theta), cos_phi = cosf(phi), sin_theta_dir = sinf(theta), sin_phi = sinf(phi);
+            f3 raw = mk3(sin_theta_dir * cos_phi, cos_theta, sin_theta_dir * sin_phi);
+            float wv = luminance(env_le(ngp_dir(raw), tex, W, H));
+            wv *= sin_theta;
+            weight[h * W + w] = wv;
+        }
+}
+// kernel `Distribution2D` alone (make_sampleable.slang:62-86), in place
+static inline void distribution2d(int W, int H, float* pdf, float* cdf) {
+    for (int y = 0; y < H; y++) {
+        float row_weight = cdf[y * (W + 1) + W];
+        for (int x = 0; x < W; x++) {
+            if (row_weight < 1e-4f) { pdf[y * W + x] = 1.0f / W; cdf[y * (W + 1) + x] = x / (float)W; }
+            else { pdf[y * W + x] /= row_weight; cdf[y * (W + 1) + x] /= row_weight; }
+        }
+    }
+}
+
 // make_sampleable: kernels make_sampleable.slang:34-86 + torch glue GenerateLightTiles.py:4-29.
 // Sequential fp32 sums stand in for torch's cumsum/sum (summation order differs by ulps on a GPU).
 static inline void make_sampleable(const float* tex, int W, int H, float* pdf, float* cdf, float* mpdf, float* mcdf) {

@@ -1,0 +1,83 @@
+"""CPU: host-side logic — synthetic scene generator, camera model, sharding arithmetic, post-processing formulas, and the N>1 exchange
+(torch.distributed gloo, world_size 2) of mirres-restir_nerf_mesh_amd/dist.py."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_scene_is_deterministic_and_well_formed(scene_mod):
+    v, t = scene_mod.make_mesh(3, 8)
+    v2, t2 = scene_mod.make_mesh(3, 8)
+    assert np.array_equal(v, v2) and np.array_equal(t, t2)
+    assert v.dtype == np.float32 and t.dtype == np.int32 and t.min() == 0 and t.max() == len(v) - 1
+    assert len(t) == 20 * 4 ** 3 + 2 * 64 and np.abs(v).max() < 1.0                     # inside [-1,1]^3 (--bound 1)
+    tv = v[t]
+    ext = tv.max(1) - tv.min(1)
+    assert ext.min() > 1e-5, "no axis-aligned (zero-thickness) triangle: the reference never enters such boxes (helperDi.slang:165)"
+    vfull, tfull = scene_mod.make_mesh(7, 64)
+    assert len(tfull) == 327680 + 8192
+
+
+def test_camera_model(scene_mod):
+    eye, rd = scene_mod.camera_rays(8, 10, azimuth_deg=30, elevation_deg=30, radius=3.2)
+    assert rd.shape == (80, 3) and abs(np.linalg.norm(eye) - 3.2) < 1e-5
+    c = rd.reshape(8, 10, 3)
+    centre = (c[3, 4] + c[3, 5] + c[4, 4] + c[4, 5]) / 4
+    np.testing.assert_allclose(centre / np.linalg.norm(centre), -eye / np.linalg.norm(eye), atol=1e-6)     # looks at the origin
+    # NeRF-blender convention (nerf/utils.py:408-416): +x right, +y up, camera looks down -z
+    focal = 0.5 * 10 / np.tan(0.5 * 0.6911)
+    assert abs(np.linalg.norm(c[0, 1] - c[0, 0]) - 1 / focal) < 1e-6
+    assert c[0, 0, 2] > c[7, 0, 2]                                                         # image rows go down in world z
+
+
+def test_spp_slices_partition_the_range():
+    from mirres_restir_nerf_mesh_amd.dist import spp_slice
+    for spp in (1, 2, 7, 128, 512):
+        for world in (1, 2, 3, 4, 8):
+            sl = [spp_slice(spp, r, world) for r in range(world)]
+            assert sl[0][0] == 0 and sl[-1][1] == spp
+            assert all(a[1] == b[0] for a, b in zip(sl, sl[1:]))
+            sizes = [e - b for b, e in sl]
+            assert max(sizes) - min(sizes) <= 1 and sum(sizes) == spp
+
+
+def test_postprocess_formulas():
+    import torch
+    from mirres_restir_nerf_mesh_amd import harness
+    x = torch.tensor([0.0, 0.001, 0.0031308, 0.2, 1.0])
+    y = harness.linear2srgb(x)
+    ref = np.where(x.numpy() <= 0.0031308, 12.92 * x.numpy(), 1.055 * (x.numpy() + 1e-6) ** (1 / 2.4) - 0.055)
+    np.testing.assert_allclose(y.numpy(), ref, rtol=1e-6)
+    a = torch.rand(4, 4, 3); b = a + 0.1
+    assert abs(harness.psnr(a, b) - 20.0) < 1e-4                                          # -10 log10(0.01)
+
+
+def _worker(rank, world, port, out):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mirres_restir_nerf_mesh_amd.dist import allreduce_sums, spp_slice
+    g = torch.Generator().manual_seed(100 + rank)
+    sums = [torch.rand(50, 3, generator=g) * (spp_slice(10, rank, world)[1] - spp_slice(10, rank, world)[0]) for _ in range(6)]
+    red = allreduce_sums([s.clone() for s in sums])
+    torch.save(dict(local=sums, red=red), os.path.join(out, "r%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_allreduce_exchange_gloo_world2(tmp_path):
+    """The only data-path collective of the sharded render: one all-reduce(sum) of the six accumulators."""
+    import torch
+    import torch.multiprocessing as mp
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(os.path.join(tmp_path, "r0.pt")); r1 = torch.load(os.path.join(tmp_path, "r1.pt"))
+    for k in range(6):
+        expect = r0["local"][k] + r1["local"][k]
+        assert torch.allclose(r0["red"][k], expect) and torch.allclose(r1["red"][k], expect)
+        assert r0["red"][k].shape == (50, 3)

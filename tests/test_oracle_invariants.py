@@ -1,0 +1,130 @@
+"""CPU: invariants that pin the oracle independently of its own code path: brute-force intersection, LBVH structure,
+Monte-Carlo convergence of the ReSTIR-DI estimator to a direct quadrature of the rendering integral, hash-grid vs dense trilinear."""
+import numpy as np
+import pytest
+
+from util import SmallFrame
+
+
+def _brute(v, t, o, d):
+    """Moller-Trumbore over every triangle with the reference's acceptance rule (no t interval), float64."""
+    v0 = v[t[:, 0]].astype(np.float64); e1 = v[t[:, 1]].astype(np.float64) - v0; e2 = v[t[:, 2]].astype(np.float64) - v0
+    out = []
+    for oi, di in zip(o.astype(np.float64), d.astype(np.float64)):
+        P = np.cross(di, e2); det = (e1 * P).sum(1); ok = np.abs(det) >= 1e-15
+        inv = 1 / np.where(ok, det, 1); T = oi - v0; u = (T * P).sum(1) * inv; Q = np.cross(T, e1); w = (di * Q).sum(1) * inv; tt = (e2 * Q).sum(1) * inv
+        m = ok & (u >= 0) & (u <= 1) & (w >= 0) & (u + w <= 1)
+        out.append((m, tt))
+    return out
+
+
+def test_bvh_structure_and_bruteforce(oracle, scene_mod):
+    v, t = scene_mod.make_mesh(3, 8)
+    info, aabb, srt, h = oracle.bvh_build(v, t)
+    T = len(t)
+    assert np.all(np.diff(srt[:, 0].astype(np.int64)) >= 0) and sorted(srt[:, 1].tolist()) == list(range(T))
+    eq = srt[1:, 0] == srt[:-1, 0]
+    assert np.all(srt[1:, 1][eq] > srt[:-1, 1][eq])                       # stable: ties keep element order
+    L, R = info[:T - 1, 0], info[:T - 1, 1]
+    assert np.array_equal(aabb[:T - 1, :3], np.minimum(aabb[L, :3], aabb[R, :3])) and np.array_equal(aabb[:T - 1, 3:], np.maximum(aabb[L, 3:], aabb[R, 3:]))
+    assert sorted(np.concatenate([L, R]).tolist()) == list(range(1, 2 * T - 1))
+    tv = v[t[info[T - 1:, 2]]]
+    assert np.array_equal(aabb[T - 1:, :3], tv.min(1)) and np.array_equal(aabb[T - 1:, 3:], tv.max(1))
+    eye, rd = scene_mod.camera_rays(24, 24)
+    n = 576
+    o = np.repeat(eye[None], n, 0); d = rd / np.linalg.norm(rd, axis=1, keepdims=True)
+    r = oracle.trace(info, aabb, v, t, oracle.make_rays(o, rd), True, True)
+    br = _brute(v, t, o, d.astype(np.float32))
+    for i, (m, tt) in enumerate(br):
+        if r["hit"][i]:
+            assert m[r["prim"][i]], "BVH hit must be a triangle brute force accepts"       # BVH subset of brute force
+        if m.any() and tt[m].min() > 1e-3:                                                  # all line hits in front: closest t equals the brute-force minimum
+            assert r["hit"][i] and abs(r["t"][i] - tt[m].min()) < 1e-4
+        if not m.any():
+            assert not r["hit"][i]
+    assert r["counters"][:, 3].sum() == 0
+    anyr = oracle.trace(info, aabb, v, t, oracle.make_rays(o, rd), False)
+    assert np.array_equal(anyr["hit"], r["hit"])
+
+
+def test_negative_t_quirk_is_preserved(oracle):
+    """triangle_hit ignores the t interval (helperDi.slang:172-195): a triangle BEHIND the origin whose box contains the origin is a hit."""
+    v = np.array([[-1, -1, 0.3], [1, -1.1, -0.3], [0, 1, 0.1], [5, 5, 5], [6, 5, 5.2], [5, 6, 5.1]], np.float32)
+    t = np.array([[0, 1, 2], [3, 4, 5]], np.int32)
+    info, aabb, _, _ = oracle.bvh_build(v, t)
+    rays = oracle.make_rays(np.array([[0, 0, 0.2]], np.float32), np.array([[0.05, 0.02, 1]], np.float32))
+    r = oracle.trace(info, aabb, v, t, rays, True)
+    assert r["hit"][0] == 1 and r["t"][0] < 0 and r["prim"][0] == 0
+
+
+def test_restir_di_converges_to_quadrature(oracle, scene_mod):
+    """E[color] of the ReSTIR-DI estimator (initial + temporal + spatial + final shading, un-denoised) equals the direct-lighting integral
+    sum_k f(w_k) Le(w_k) V(w_k) dw_k evaluated by brute-force quadrature with the SAME shading function. Foreground mean within 4 %."""
+    F = SmallFrame(oracle, scene_mod, fx=20, fy=16, subdiv=2, ground=4, env_hw=(16, 32), varied=False, rough=0.6)
+    O = oracle
+    N = F.N
+    spp = 192
+    out = O.render(F.fx, F.fy, spp, 777, (F.info, F.aabb), F.vert, F.tri, F.env, F.occ, F.normal, F.depth, F.kd, F.rm, F.ray_dir_raw, F.pos, mat=None, want_avg=True)
+    est = out["avg_direct"]
+    K = 3000
+    k = np.arange(K) + 0.5
+    z = 1 - 2 * k / K; phi = k * np.pi * (3 - np.sqrt(5)); rr = np.sqrt(1 - z * z)
+    dirs = np.stack([rr * np.cos(phi), rr * np.sin(phi), z], 1).astype(np.float32)
+    Le = O.env_le(F.tex, F.Wc, F.Hc, np.stack([-dirs[:, 0], dirs[:, 2], dirs[:, 1]], 1).astype(np.float32))      # env_radiance(L) = env_le(ngp_dir(L))
+    acc = np.zeros((N, 3), np.float64)
+    fg = F.occ > 0.5
+    pos = F.pos[fg]
+    for j in range(K):
+        if Le[j].max() <= 0:
+            continue
+        L = dirs[j]
+        rays = O.make_rays(pos + 0.01 * L, np.repeat(L[None], len(pos), 0))
+        hit = O.trace(F.info, F.aabb, F.vert, F.tri, rays, False)["hit"]
+        vis = np.zeros(N, np.float32); vis[fg] = 1.0 - hit
+        fdir = np.repeat(L[None], N, 0).astype(np.float32); fdist = np.where(vis > 0, 1e6, 0).astype(np.float32)
+        fLi = (Le[j][None] * (4 * np.pi / K) * vis[:, None]).astype(np.float32)
+        c, _, _ = O.final_shading(F.frame, F.normal, F.kd, F.rm, fdir, fdist, fLi)
+        acc[fg] += c[fg]
+    a, b = est[fg].mean(0), acc[fg].mean(0)
+    np.testing.assert_allclose(a, b, rtol=0.04)
+    lum = lambda x: x @ np.array([0.2126, 0.7152, 0.0722])
+    cc = np.corrcoef(lum(est[fg]), lum(acc[fg]))[0, 1]
+    assert cc > 0.9, cc
+
+
+def test_eaw_properties(oracle, scene_mod):
+    F = SmallFrame(oracle, scene_mod, fx=24, fy=20, subdiv=2, ground=4, env_hw=(8, 16))
+    const = np.full((F.N, 3), 0.4, np.float32)
+    out = oracle.eaw(F.fx, F.fy, 2, 2.0, 0.1, 0.001, F.occ, const, F.normal, F.pos)
+    np.testing.assert_allclose(out, 0.4, rtol=1e-6)
+    rng = np.random.default_rng(0)
+    col = rng.random((F.N, 3)).astype(np.float32)
+    out = oracle.eaw(F.fx, F.fy, 1, 2.0, 0.1, 0.001, F.occ, col, F.normal, F.pos)
+    assert np.array_equal(out[F.occ < 0.5], col[F.occ < 0.5])                                  # background copied
+    assert out[F.occ > 0.5].min() >= col.min() - 1e-6 and out[F.occ > 0.5].max() <= col.max() + 1e-6   # convex combination
+
+
+def test_hashgrid_dense_levels_are_trilinear(oracle, scene_mod):
+    total = oracle.hashgrid_layout()[0]
+    rng = np.random.default_rng(5)
+    params = np.zeros(total * 2, np.float32); params[:2 * 17920] = rng.normal(size=2 * 17920).astype(np.float32) * 0.1     # levels 0 and 1
+    keep = oracle.Keep(); mn, mx = scene_mod.material_min_max()
+    z = np.zeros((32, 32), np.float32)
+    mat = oracle.matnet_struct(keep, params, z, z, np.zeros((6, 32), np.float32), (-1, -1, -1), (1, 1, 1), mn, mx)
+    x = rng.random((400, 3)).astype(np.float32)
+    enc = oracle.hashgrid_encode(mat, x).view(np.float16).astype(np.float64)
+    tabs = [(16, 15.0, 0, 4096), (24, 22.156307, 4096, 13824)]
+    p16 = oracle.to_f16_bits(params[:2 * 17920]).view(np.float16).astype(np.float64).reshape(-1, 2)
+    for lv, (res, scale, off, size) in enumerate(tabs):
+        p = x.astype(np.float64) * scale + 0.5
+        i0 = np.floor(p).astype(int); fr = p - i0
+        acc = np.zeros((400, 2))
+        for c in range(8):
+            dx, dy, dz = c & 1, (c >> 1) & 1, (c >> 2) & 1
+            w = (fr[:, 0] if dx else 1 - fr[:, 0]) * (fr[:, 1] if dy else 1 - fr[:, 1]) * (fr[:, 2] if dz else 1 - fr[:, 2])
+            idx = ((i0[:, 0] + dx) + (i0[:, 1] + dy) * res + (i0[:, 2] + dz) * res * res) % size
+            acc += w[:, None] * p16[off + idx]
+        np.testing.assert_allclose(enc[:, 2 * lv:2 * lv + 2], acc, rtol=0, atol=4e-3 * np.abs(acc).max() + 1e-4)
+    assert np.all(enc[:, 4:] == 0)
+    out = oracle.matnet(mat, x * 2 - 1)
+    np.testing.assert_allclose(out, np.tile((mn + mx) / 2, (400, 1)), atol=1e-7)                 # zero weights -> sigmoid(0) = 0.5
