@@ -157,7 +157,8 @@ def main():
         rays_any, rays_cl = st["rays_any"], st["rays_closest"]
         # algorithmic bytes (reference node layout as the accounting basis): per ray 24 (o,d) + 12 (root info) + result,
         # 24 per popped node (aabb) + 24 per entered internal node (two child infos) + 48 per tested leaf (indices + vertices).
-        # popped/entered/leaves are the nodes OUR traversal actually visits (any-hit leaves at the first hit), so this never credits skipped work.
+        # For the any-hit kernel the three counts are what THE PRODUCTION TRAVERSAL itself does (boxes slab-tested, internal nodes fetched, triangles
+        # tested, counted by its own instrumented instantiation: near-first order, early exit) — skipped work is never credited.
         total_rays = rays_any + rays_cl
         bytes_any = 24.0 * st["popped"] + 24.0 * st["entered"] + 48.0 * st["leaves"] + rays_any * (24 + 12 + 4)
         bytes_cl = 24.0 * st["cl_popped"] + 24.0 * st["cl_entered"] + 48.0 * st["cl_leaves"] + rays_cl * (24 + 12 + 28)

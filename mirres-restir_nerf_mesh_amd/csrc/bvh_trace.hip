@@ -27,18 +27,18 @@ namespace mr {
 
 struct Slab { float tn, tf; };
 
-// aabb_hit (helperDi.slang:149-170) split into its closest-independent part.
+// aabb_hit (helperDi.slang:149-170) split into its closest-independent part. The reference computes t0/t1 per axis, swaps them when
+// inv < 0 and folds them with `t0 > t_min ? t0 : t_min` / `t1 < t_max ? t1 : t_max`. Because (b - o) * inv is monotone in b, the swap is
+// exactly min/max of the two products, and the folds are max/min (identical for non-NaN inputs; a +-0 difference cannot change a later
+// comparison) — which maps to v_min/v_max/v_max3/v_min3 instead of compare + 2 cndmask per axis.
 MR_DEV Slab slab(const float* __restrict__ bmin, const float* __restrict__ bmax, const float o[3], const float inv[3], float t_min) {
-    float tn = t_min, tf = INFINITY;
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-        float t0 = (bmin[i] - o[i]) * inv[i];
-        float t1 = (bmax[i] - o[i]) * inv[i];
-        if (inv[i] < 0.0f) { float tmp = t1; t1 = t0; t0 = tmp; }
-        tn = t0 > tn ? t0 : tn;
-        tf = t1 < tf ? t1 : tf;
-    }
-    Slab s; s.tn = tn; s.tf = tf; return s;
+    const float ax = (bmin[0] - o[0]) * inv[0], bx = (bmax[0] - o[0]) * inv[0];
+    const float ay = (bmin[1] - o[1]) * inv[1], by = (bmax[1] - o[1]) * inv[1];
+    const float az = (bmin[2] - o[2]) * inv[2], bz = (bmax[2] - o[2]) * inv[2];
+    Slab s;
+    s.tn = fmaxf(fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz)), t_min);
+    s.tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    return s;
 }
 
 struct TraceOut { bool hit; float t, u, v; int slot; v3 d; };
@@ -205,6 +205,281 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_closest(BvhView B, con
     if (stats && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[1], (unsigned long long)n);
 }
 
+
+// ---------------------------------------------------------------- persistent "while-while" traversal with lane refill
+// PMC on the one-ray-per-thread kernels above: VALU lane utilisation 24 %, 60 % of wave cycles in s_waitcnt — a wave lives as long
+// as its longest ray. Here a wave owns a chunk of the queue (one atomic per MR_CHUNK rays) and, whenever fewer than MR_REFILL lanes
+// are still traversing, idle lanes pull the next rays of the chunk with pure ballot/popcount arithmetic (no atomics). Per-ray
+// arithmetic and visit order are exactly those of traverse<>, so results are bit-identical to the simple kernels.
+#define MR_CHUNK_MAX 1024
+#define MR_REFILL 40
+
+template <bool ANY>
+__global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_persist(BvhView B, const Ray* __restrict__ rays, const uint32_t* __restrict__ d_count,
+                                                                  uint32_t n_fixed, uint32_t* __restrict__ work_head, int32_t* __restrict__ hit_out,
+                                                                  HitRec* __restrict__ rec, float* __restrict__ t_out, float* __restrict__ pos_out,
+                                                                  float* __restrict__ nrm_out, int32_t* __restrict__ prim_out,
+                                                                  unsigned long long* __restrict__ stats) {
+    __shared__ uint2 lds[MR_LDS_STACK * MR_TRACE_BLOCK];
+    uint2* const lds_stack = lds + threadIdx.x;
+    const uint32_t n = d_count ? *d_count : n_fixed;
+    const int lane = lane_id();
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const int NONE = 0x40000000;
+    // chunk size: ~4 chunks per resident wave so that the tail balances, 64..1024 rays (one global atomic per chunk)
+    uint32_t chunk = n / (gridDim.x * (MR_TRACE_BLOCK / 64) * 4);
+    chunk = chunk < 64 ? 64 : (chunk > MR_CHUNK_MAX ? MR_CHUNK_MAX : (chunk & ~63u));
+    uint32_t chunk_next = 0, chunk_end = 0;  // wave-uniform
+    bool exhausted = false;                  // wave-uniform: the global queue has no more chunks
+    bool have = false;
+    // per-lane ray state
+    float o[3], inv[3]; v3 d = V3(0.f), ro = V3(0.f);
+    float t_min = 0.f, closest = 0.f, best_t = 0.f, best_u = 0.f, best_v = 0.f;
+    int cur = NONE, sp = 0, best_slot = -1; uint32_t ridx = 0; bool any_hit = false;
+    uint2 spill[MR_STACK - MR_LDS_STACK];
+    while (true) {
+        // ---- refill idle lanes from the wave's chunk
+        const uint64_t need = __ballot(!have);
+        if (need && !exhausted) {
+            if (chunk_next >= chunk_end) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(work_head, chunk);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (base >= n) exhausted = true;
+                else { chunk_next = base; chunk_end = (base + chunk < n) ? base + chunk : n; }
+            }
+            if (!exhausted) {
+                const uint32_t idx = chunk_next + (uint32_t)__popcll(need & lt_mask);
+                if (!have && idx < chunk_end) {
+                    const float4 a = reinterpret_cast<const float4*>(rays + idx)[0], b = reinterpret_cast<const float4*>(rays + idx)[1];
+                    ridx = idx; ro = V3(a.x, a.y, a.z); t_min = a.w; closest = b.w;
+                    d = normalize(V3(b.x, b.y, b.z));
+                    o[0] = ro.x; o[1] = ro.y; o[2] = ro.z;
+                    { float dd[3] = {d.x, d.y, d.z};
+#pragma unroll
+                      for (int i = 0; i < 3; i++) { float di = dd[i]; if (di == 0.f) di = 0.000001f; inv[i] = 1.0f / di; } }
+                    sp = 0; any_hit = false; best_t = 0.f; best_u = 0.f; best_v = 0.f; best_slot = -1;
+                    Slab s0 = slab(B.root_box, B.root_box + 3, o, inv, t_min);
+                    cur = (s0.tf > s0.tn && closest > s0.tn) ? 0 : NONE;
+                    have = true;
+                }
+                const uint32_t want = (uint32_t)__popcll(need);
+                chunk_next = (chunk_next + want < chunk_end) ? chunk_next + want : chunk_end;
+            }
+        }
+        if (!__ballot(have)) { if (exhausted) break; else continue; }
+        // ---- traverse until too few lanes are busy
+        do {
+            if (have) {
+                bool done = false;
+                if (cur == NONE) {
+                    bool found = false;
+                    while (sp > 0) {
+                        --sp;
+                        uint2 e = (sp < MR_LDS_STACK) ? lds_stack[sp * MR_TRACE_BLOCK] : spill[sp - MR_LDS_STACK];
+                        if (closest > __uint_as_float(e.y)) { cur = (int)e.x; found = true; break; }
+                    }
+                    if (!found) done = true;
+                }
+                if (!done) {
+                    if (cur >= 0) {
+                        const WideNode* __restrict__ nd = B.nodes + cur;
+                        const float4 q0 = reinterpret_cast<const float4*>(nd)[0];
+                        const float4 q1 = reinterpret_cast<const float4*>(nd)[1];
+                        const float4 q2 = reinterpret_cast<const float4*>(nd)[2];
+                        const float4 q3 = reinterpret_cast<const float4*>(nd)[3];
+                        const float lmin[3] = {q0.x, q0.y, q0.z}, lmax[3] = {q0.w, q1.x, q1.y};
+                        const float rmin[3] = {q1.z, q1.w, q2.x}, rmax[3] = {q2.y, q2.z, q2.w};
+                        const int left = __float_as_int(q3.x), right = __float_as_int(q3.y);
+                        Slab sl = slab(lmin, lmax, o, inv, t_min);
+                        Slab sr = slab(rmin, rmax, o, inv, t_min);
+                        if (sl.tf > sl.tn) {
+                            uint2 e; e.x = (uint32_t)left; e.y = __float_as_uint(sl.tn);
+                            if (sp < MR_LDS_STACK) lds_stack[sp * MR_TRACE_BLOCK] = e;
+                            else if (sp < MR_STACK) spill[sp - MR_LDS_STACK] = e;
+                            if (sp < MR_STACK) sp++;
+                        }
+                        cur = (sr.tf > sr.tn && closest > sr.tn) ? right : NONE;
+                    } else {
+                        const int slot = ~cur;
+                        cur = NONE;
+                        const TriRec* __restrict__ tr = B.tris + slot;
+                        const float4 a = reinterpret_cast<const float4*>(tr)[0];
+                        const float4 b = reinterpret_cast<const float4*>(tr)[1];
+                        const float4 c = reinterpret_cast<const float4*>(tr)[2];
+                        const v3 v0 = V3(a.x, a.y, a.z), E1 = V3(a.w, b.x, b.y), E2 = V3(b.z, b.w, c.x);
+                        const v3 P = cross(d, E2);
+                        const float det = dot(E1, P);
+                        if (!(det > -1e-15f && det < 1e-15f)) {
+                            const float invDet = 1 / det;
+                            const v3 Tv = ro - v0;
+                            const float u = dot(Tv, P) * invDet;
+                            if (!(u < 0 || u > 1)) {
+                                const v3 Q = cross(Tv, E1);
+                                const float v = dot(d, Q) * invDet;
+                                if (!(v < 0 || u + v > 1)) {
+                                    any_hit = true;
+                                    if (ANY) done = true;
+                                    else {
+                                        const float t = dot(E2, Q) * invDet;
+                                        closest = fminf(t, closest);
+                                        if (t <= closest) { best_u = u; best_v = v; best_slot = slot; }
+                                        best_t = closest;
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+                if (done) {
+                    have = false;
+                    if (ANY) hit_out[ridx] = any_hit ? 1 : 0;
+                    else {
+                        TraceOut r; r.hit = any_hit; r.t = best_t; r.u = best_u; r.v = best_v; r.slot = best_slot; r.d = d;
+                        v3 p, nn; int pr;
+                        finish_closest(B, r, ro, p, nn, pr);
+                        if (rec) {
+                            float4 o0, o1;
+                            o0.x = p.x; o0.y = p.y; o0.z = p.z; o0.w = __int_as_float(any_hit ? 1 : 0);
+                            o1.x = nn.x; o1.y = nn.y; o1.z = nn.z; o1.w = best_t;
+                            reinterpret_cast<float4*>(rec + ridx)[0] = o0; reinterpret_cast<float4*>(rec + ridx)[1] = o1;
+                        }
+                        if (hit_out) hit_out[ridx] = any_hit ? 1 : 0;
+                        if (t_out) t_out[ridx] = best_t;
+                        if (pos_out) st3(pos_out, ridx, p);
+                        if (nrm_out) st3(nrm_out, ridx, nn);
+                        if (prim_out) prim_out[ridx] = pr;
+                    }
+                }
+            }
+        } while (__popcll(__ballot(have)) >= MR_REFILL || (exhausted && __ballot(have)));
+    }
+    if (stats && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[ANY ? 0 : 1], (unsigned long long)n);
+}
+
+
+// ---------------------------------------------------------------- shadow rays: order-free any-hit traversal
+// For an any-hit query `closest` stays t_max until the first accepted triangle, so (1) the reference's result is the OR over all leaves
+// whose OWN box passes the slab test of "triangle_hit accepts": a leaf's ancestors always pass when the leaf does (their boxes are
+// fmin/fmax unions and (b - o) * inv is monotone in b under IEEE rounding), hence (2) any visiting order and any pruning by ancestor
+// boxes yields the same boolean. This kernel uses that freedom: leaf children are tested at their parent (never pushed), the nearer
+// internal child is descended first, the stack holds bare 4-byte node ids in LDS (16 per lane), and no pop-time re-test is needed.
+#define MR_ANY_LDS 16
+MR_DEV bool tri_accepts(const TriRec* __restrict__ tr, v3 ro, v3 d) {  // triangle_hit (helperDi.slang:172-195) without t
+    const float4 a = reinterpret_cast<const float4*>(tr)[0];
+    const float4 b = reinterpret_cast<const float4*>(tr)[1];
+    const float4 c = reinterpret_cast<const float4*>(tr)[2];
+    const v3 v0 = V3(a.x, a.y, a.z), E1 = V3(a.w, b.x, b.y), E2 = V3(b.z, b.w, c.x);
+    const v3 P = cross(d, E2);
+    const float det = dot(E1, P);
+    if (det > -1e-15f && det < 1e-15f) return false;
+    const float invDet = 1 / det;
+    const v3 Tv = ro - v0;
+    const float u = dot(Tv, P) * invDet;
+    if (u < 0 || u > 1) return false;
+    const v3 Q = cross(Tv, E1);
+    const float v = dot(d, Q) * invDet;
+    if (v < 0 || u + v > 1) return false;
+    return true;
+}
+
+template <bool COUNT>
+__global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any_fast(BvhView B, const Ray* __restrict__ rays, const uint32_t* __restrict__ d_count,
+                                                                   uint32_t n_fixed, uint32_t* __restrict__ work_head, int32_t* __restrict__ hit_out,
+                                                                   unsigned long long* __restrict__ stats) {
+    __shared__ uint32_t lds[MR_ANY_LDS * MR_TRACE_BLOCK];
+    uint32_t* const lds_stack = lds + threadIdx.x;
+    const uint32_t n = d_count ? *d_count : n_fixed;
+    const int lane = lane_id();
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const int NONE = 0x40000000;
+    uint32_t chunk = n / (gridDim.x * (MR_TRACE_BLOCK / 64) * 4);
+    chunk = chunk < 64 ? 64 : (chunk > MR_CHUNK_MAX ? MR_CHUNK_MAX : (chunk & ~63u));
+    uint32_t chunk_next = 0, chunk_end = 0;
+    bool exhausted = false, have = false;
+    float o[3], inv[3]; v3 d = V3(0.f), ro = V3(0.f);
+    float t_min = 0.f, t_max = 0.f;
+    int cur = NONE, sp = 0; uint32_t ridx = 0;
+    uint32_t spill[MR_STACK - MR_ANY_LDS];
+    unsigned long long c_boxes = 0, c_nodes = 0, c_leaves = 0;   // COUNT: boxes slab-tested, internal nodes fetched, triangles tested by THIS kernel
+    while (true) {
+        const uint64_t need = __ballot(!have);
+        if (need && !exhausted) {
+            if (chunk_next >= chunk_end) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(work_head, chunk);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (base >= n) exhausted = true;
+                else { chunk_next = base; chunk_end = (base + chunk < n) ? base + chunk : n; }
+            }
+            if (!exhausted) {
+                const uint32_t idx = chunk_next + (uint32_t)__popcll(need & lt_mask);
+                if (!have && idx < chunk_end) {
+                    const float4 a = reinterpret_cast<const float4*>(rays + idx)[0], b = reinterpret_cast<const float4*>(rays + idx)[1];
+                    ridx = idx; ro = V3(a.x, a.y, a.z); t_min = a.w; t_max = b.w;
+                    d = normalize(V3(b.x, b.y, b.z));
+                    o[0] = ro.x; o[1] = ro.y; o[2] = ro.z;
+                    { float dd[3] = {d.x, d.y, d.z};
+#pragma unroll
+                      for (int i = 0; i < 3; i++) { float di = dd[i]; if (di == 0.f) di = 0.000001f; inv[i] = 1.0f / di; } }
+                    sp = 0;
+                    Slab s0 = slab(B.root_box, B.root_box + 3, o, inv, t_min);
+                    have = true;
+                    if (COUNT) c_boxes++;
+                    if (s0.tf > s0.tn && t_max > s0.tn) cur = 0;
+                    else { hit_out[idx] = 0; have = false; }
+                }
+                const uint32_t want = (uint32_t)__popcll(need);
+                chunk_next = (chunk_next + want < chunk_end) ? chunk_next + want : chunk_end;
+            }
+        }
+        if (!__ballot(have)) { if (exhausted) break; else continue; }
+        do {
+            if (have) {
+                // cur is always an internal node here
+                const WideNode* __restrict__ nd = B.nodes + cur;
+                const float4 q0 = reinterpret_cast<const float4*>(nd)[0];
+                const float4 q1 = reinterpret_cast<const float4*>(nd)[1];
+                const float4 q2 = reinterpret_cast<const float4*>(nd)[2];
+                const float4 q3 = reinterpret_cast<const float4*>(nd)[3];
+                const float lmin[3] = {q0.x, q0.y, q0.z}, lmax[3] = {q0.w, q1.x, q1.y};
+                const float rmin[3] = {q1.z, q1.w, q2.x}, rmax[3] = {q2.y, q2.z, q2.w};
+                const int left = __float_as_int(q3.x), right = __float_as_int(q3.y);
+                const Slab sl = slab(lmin, lmax, o, inv, t_min);
+                const Slab sr = slab(rmin, rmax, o, inv, t_min);
+                bool okL = sl.tf > sl.tn && t_max > sl.tn, okR = sr.tf > sr.tn && t_max > sr.tn;
+                bool hit = false;
+                if (COUNT) { c_nodes++; c_boxes += 2; }
+                if (okL && left < 0) { hit = tri_accepts(B.tris + ~left, ro, d); okL = false; if (COUNT) c_leaves++; }
+                if (!hit && okR && right < 0) { hit = tri_accepts(B.tris + ~right, ro, d); okR = false; if (COUNT) c_leaves++; }
+                bool done = hit;
+                if (!hit) {
+                    if (okL && okR) {
+                        const bool lnear = sl.tn <= sr.tn;
+                        const int far = lnear ? right : left;
+                        cur = lnear ? left : right;
+                        if (sp < MR_ANY_LDS) lds_stack[sp * MR_TRACE_BLOCK] = (uint32_t)far;
+                        else if (sp < MR_STACK) spill[sp - MR_ANY_LDS] = (uint32_t)far;
+                        if (sp < MR_STACK) sp++;
+                    } else if (okL) cur = left;
+                    else if (okR) cur = right;
+                    else if (sp > 0) { --sp; cur = (int)((sp < MR_ANY_LDS) ? lds_stack[sp * MR_TRACE_BLOCK] : spill[sp - MR_ANY_LDS]); }
+                    else done = true;
+                }
+                if (done) { have = false; hit_out[ridx] = hit ? 1 : 0; }
+            }
+        } while (__popcll(__ballot(have)) >= MR_REFILL || (exhausted && __ballot(have)));
+    }
+    if (COUNT && stats) { atomicAdd(&stats[2], c_boxes); atomicAdd(&stats[3], c_nodes); atomicAdd(&stats[4], c_leaves); }
+    if (stats && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[0], (unsigned long long)n);
+}
+
+static int persist_grid(size_t capacity) {
+    size_t want = (capacity + MR_TRACE_BLOCK - 1) / MR_TRACE_BLOCK;
+    size_t cap = 256 * 6;                                       // 6 resident blocks per CU (LDS 24 KB each)
+    return (int)(want < 1 ? 1 : (want > cap ? cap : want));
+}
+
 static int trace_grid(size_t capacity) {
     // persistent-style launch: enough 256-thread blocks to fill 256 CUs several times over, grid-stride beyond
     size_t want = (capacity + MR_TRACE_BLOCK - 1) / MR_TRACE_BLOCK;
@@ -214,20 +489,23 @@ static int trace_grid(size_t capacity) {
 
 int trace_any_queue(const mirres_bvh* bvh, const Ray* rays, const uint32_t* d_count, size_t capacity, int32_t* hit,
                     unsigned long long* stats, hipStream_t s) {
-    k_trace_any<false><<<trace_grid(capacity), MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, d_count, (uint32_t)capacity, hit, nullptr, stats);
+    MR_HIP(hipMemsetAsync(bvh->work, 0, sizeof(uint32_t), s));
+    k_trace_any_fast<false><<<persist_grid(capacity), MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, d_count, (uint32_t)capacity, bvh->work, hit, stats);
     MR_LAUNCH_CHECK("trace_any_queue");
     return 0;
 }
 int trace_closest_queue(const mirres_bvh* bvh, const Ray* rays, const uint32_t* d_count, size_t capacity, HitRec* out,
                         unsigned long long* stats, hipStream_t s) {
-    k_trace_closest<false><<<trace_grid(capacity), MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, d_count, (uint32_t)capacity, out, nullptr, nullptr,
-                                                                            nullptr, nullptr, nullptr, nullptr, stats);
+    MR_HIP(hipMemsetAsync(bvh->work + 1, 0, sizeof(uint32_t), s));
+    k_trace_persist<false><<<persist_grid(capacity), MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, d_count, (uint32_t)capacity, bvh->work + 1, nullptr, out,
+                                                                             nullptr, nullptr, nullptr, nullptr, stats);
     MR_LAUNCH_CHECK("trace_closest_queue");
     return 0;
 }
 int trace_any_queue_counted(const mirres_bvh* bvh, const Ray* rays, const uint32_t* d_count, size_t capacity, int32_t* hit,
                             unsigned long long* stats, hipStream_t s) {
-    k_trace_any<true><<<trace_grid(capacity), MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, d_count, (uint32_t)capacity, hit, nullptr, stats);
+    MR_HIP(hipMemsetAsync(bvh->work, 0, sizeof(uint32_t), s));
+    k_trace_any_fast<true><<<persist_grid(capacity), MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, d_count, (uint32_t)capacity, bvh->work, hit, stats);
     MR_LAUNCH_CHECK("trace_any_queue_counted");
     return 0;
 }
@@ -254,10 +532,17 @@ extern "C" int mirres_bvh_trace(mirres_bvh_t* bvh, const float* rays, int n, int
     if (mode == 0) {
         if (!hit) { set_error("mirres_bvh_trace: any-hit needs hit[]"); return MIRRES_E_ARG; }
         if (counters) k_trace_any<true><<<g, MR_TRACE_BLOCK, 0, s>>>(bvh->view(), r, nullptr, (uint32_t)n, hit, counters, nullptr);
-        else k_trace_any<false><<<g, MR_TRACE_BLOCK, 0, s>>>(bvh->view(), r, nullptr, (uint32_t)n, hit, nullptr, nullptr);
+        else {
+            MR_HIP(hipMemsetAsync(bvh->work + 2, 0, sizeof(uint32_t), s));
+            k_trace_any_fast<false><<<persist_grid((size_t)n), MR_TRACE_BLOCK, 0, s>>>(bvh->view(), r, nullptr, (uint32_t)n, bvh->work + 2, hit, nullptr);
+        }
     } else {
         if (counters) k_trace_closest<true><<<g, MR_TRACE_BLOCK, 0, s>>>(bvh->view(), r, nullptr, (uint32_t)n, nullptr, hit, t, pos, normal, prim, counters, nullptr);
-        else k_trace_closest<false><<<g, MR_TRACE_BLOCK, 0, s>>>(bvh->view(), r, nullptr, (uint32_t)n, nullptr, hit, t, pos, normal, prim, nullptr, nullptr);
+        else {
+            MR_HIP(hipMemsetAsync(bvh->work + 3, 0, sizeof(uint32_t), s));
+            k_trace_persist<false><<<persist_grid((size_t)n), MR_TRACE_BLOCK, 0, s>>>(bvh->view(), r, nullptr, (uint32_t)n, bvh->work + 3, hit, nullptr, t, pos, normal,
+                                                                                    prim, nullptr);
+        }
     }
     MR_LAUNCH_CHECK("mirres_bvh_trace");
     return MIRRES_OK;

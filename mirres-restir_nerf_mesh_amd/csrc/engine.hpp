@@ -50,6 +50,7 @@ struct mirres_bvh {
     mr::WideNode* nodes = nullptr;  // [T-1]
     mr::TriRec* tris = nullptr;     // [T]
     float* root_box = nullptr;      // [6]
+    uint32_t* work = nullptr;       // [4] chunk heads of the persistent traversal kernels
     mr::BvhView view() const { mr::BvhView v; v.nodes = nodes; v.tris = tris; v.root_box = root_box; v.T = T; return v; }
 };
 

@@ -1,0 +1,41 @@
+"""Dev (GPU box): traversal micro-benchmark on shadow-ray-like and bounce-like ray sets from the bench scene."""
+import ctypes as C, sys, os, time
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import mirres_restir_nerf_mesh_amd as M
+from mirres_restir_nerf_mesh_amd import renderer_restir as RR, harness
+from mirres_restir_nerf_mesh_amd._lib import lib, check
+S = M.scene
+res = int(sys.argv[1]) if len(sys.argv) > 1 else 1600
+v, t = S.make_mesh(7, 64)
+W = RR.restirbvhWorker(torch.from_numpy(v).cuda(), torch.from_numpy(t).cuda()); W.update_mesh(W.vrt, W.v_ind)
+g = harness.build_gbuffer(W, res, res, 1)
+fg = g["occ"][:, 0] > 0.5
+pos, nrm = g["pos"][fg], g["normal"][fg]
+gen = torch.Generator(device="cuda").manual_seed(0)
+n = pos.shape[0]
+r = torch.randn((n, 3), device="cuda", generator=gen); r = r / r.norm(dim=1, keepdim=True)
+d = nrm + 0.98 * r; d = d / d.norm(dim=1, keepdim=True)
+o = pos + 0.01 * d
+sets = {"hemisphere": (o, d)}
+perm = torch.randperm(n, device="cuda", generator=gen)
+sets["shuffled"] = (o[perm].contiguous(), d[perm].contiguous())
+for name, (oo, dd) in sets.items():
+    k = oo.shape[0]
+    rays = torch.empty((k, 8), device="cuda"); rays[:, 0:3] = oo; rays[:, 3] = 0; rays[:, 4:7] = dd; rays[:, 7] = 1e7
+    hit = torch.zeros(k, dtype=torch.int32, device="cuda"); tt = torch.zeros(k, device="cuda"); p = torch.zeros((k, 3), device="cuda"); nn = torch.zeros((k, 3), device="cuda")
+    pr = torch.zeros(k, dtype=torch.int32, device="cuda"); cnt = torch.zeros((k, 4), dtype=torch.int32, device="cuda")
+    for mode in (0, 1):
+        check(lib().mirres_bvh_trace(W.h, rays.data_ptr(), k, mode, hit.data_ptr(), tt.data_ptr(), p.data_ptr(), nn.data_ptr(), pr.data_ptr(), cnt.data_ptr(), None), "t")
+        torch.cuda.synchronize()
+        c = cnt.double().sum(0).cpu().numpy()
+        hsum = int(hit.sum())
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        lib().mirres_bvh_trace(W.h, rays.data_ptr(), k, mode, hit.data_ptr(), tt.data_ptr(), p.data_ptr(), nn.data_ptr(), pr.data_ptr(), None, None)
+        e0.record()
+        for _ in range(10):
+            lib().mirres_bvh_trace(W.h, rays.data_ptr(), k, mode, hit.data_ptr(), tt.data_ptr(), p.data_ptr(), nn.data_ptr(), pr.data_ptr(), None, None)
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        by = 24 * c[0] + 24 * c[1] + 48 * c[2] + k * (36 + (4 if mode == 0 else 28))
+        print(f"{name:10s} mode {mode}: n={k} {ms:.3f} ms {k/ms/1e6:.3f} Grays/s  hit {hsum/k:.3f}  boxes/ray {c[0]/k:.1f} nodes/ray {c[1]/k:.1f} leaves/ray {c[2]/k:.2f}  alg {by/ms/1e6:.0f} GB/s  checksum {hsum}")
