@@ -98,4 +98,31 @@ MR_DEV uint32_t wave_append(uint32_t* counter, bool want, uint32_t n = 1) {
     return base + incl - mine;
 }
 
+// Block-level compacted append: ONE global atomic per workgroup (a single queue-head word saturates at ~88 atomics/us on MI355X, and the
+// per-wave version made every ray-generating kernel atomic-bound: 17 k wave atomics = 195 us for a kernel that moves 150 MB).
+// Every thread of the block must call it (two __syncthreads). `n` rays are reserved for lanes with `want`.
+MR_DEV uint32_t block_append(uint32_t* counter, bool want, uint32_t n = 1) {
+    __shared__ uint32_t s_wave[17];
+    uint32_t mine = want ? n : 0u;
+    uint32_t incl = mine;
+    const int lane = lane_id();
+    const int wave = threadIdx.x >> 6, nwaves = (blockDim.x + 63) >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (int w = 0; w < nwaves; w++) { uint32_t t = s_wave[w]; s_wave[w] = tot; tot += t; }
+        s_wave[16] = tot ? atomicAdd(counter, tot) : 0u;
+    }
+    __syncthreads();
+    const uint32_t r = s_wave[16] + s_wave[wave] + incl - mine;
+    __syncthreads();   // s_wave may be reused by a second append in the same kernel
+    return r;
+}
+
 }  // namespace mr

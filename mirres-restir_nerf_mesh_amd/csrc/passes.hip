@@ -15,6 +15,7 @@ int trace_any_queue_counted(const mirres_bvh* bvh, const Ray* rays, const uint32
                             unsigned long long* stats, hipStream_t s);
 
 #define MR_BLOCK 256
+#define MR_GEN_BLOCK 1024   // ray-generating kernels: one queue atomic per 1024 pixels
 
 struct GBufD { const float *occ, *pos, *normal_depth, *brdf, *ray_dir; };
 struct ResD { float* light_data; float* light_pdf; int32_t* M; float* weight; };
@@ -118,9 +119,21 @@ __global__ void __launch_bounds__(MR_BLOCK) k_light_tiles(EnvD E, uint32_t frame
     light_pdf[idx] = ip;
 }
 
+// Per tile sample, the direction and the luminance of its radiance are functions of the sample alone (get_light_info, lightDi.slang:285-298):
+// evaluated once per sample here (131 072 evaluations) instead of once per pixel x candidate in the resampling loop (82 M at 1600^2) — same
+// pure functions of the same inputs, so the values are bit-identical to in-loop evaluation.
+__global__ void __launch_bounds__(MR_BLOCK) k_tile_aux(EnvD E, int total, const float* __restrict__ tile_data, float4* __restrict__ aux) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    v3 ld = ld3(tile_data, idx);
+    v3 ldir = oct_decode(V2(ld.y, ld.z));
+    float4 a; a.x = ldir.x; a.y = ldir.y; a.z = ldir.z; a.w = luminance(env_radiance(E, ldir));
+    aux[idx] = a;
+}
+
 // ---------------------------------------------------------------- initial resampling (InitialResampling.slang:151-295)
-__global__ void __launch_bounds__(MR_BLOCK) k_initial_gen(mirres_config_t C, EnvD E, GBufD G, ResD R, const float* __restrict__ tile_data,
-                                                          const float* __restrict__ tile_pdf, uint32_t frameIndex, int fx, int N,
+__global__ void __launch_bounds__(MR_GEN_BLOCK) k_initial_gen(mirres_config_t C, EnvD E, GBufD G, ResD R, const float* __restrict__ tile_data,
+                                                          const float* __restrict__ tile_pdf, const float4* __restrict__ tile_aux, uint32_t frameIndex, int fx, int N,
                                                           Ray* __restrict__ q, uint32_t* __restrict__ q_count, int32_t* __restrict__ slot_out) {
     const int pi = blockIdx.x * blockDim.x + threadIdx.x;
     bool want = false; v3 rpos = V3(0.f), rdir = V3(0.f);
@@ -141,9 +154,9 @@ __global__ void __launch_bounds__(MR_BLOCK) k_initial_gen(mirres_config_t C, Env
             for (uint32_t i = 0; i < (uint32_t)C.initial_light_samples; ++i) {
                 uint32_t index = tileOffset + (offset + i * stride) % C.light_tile_size;
                 v3 ld = ld3(tile_data, index); float lpdf = tile_pdf[index];
-                v3 ldir = oct_decode(V2(ld.y, ld.z));
-                v3 em = env_radiance(E, ldir);
-                float targetPdf = rtarget::target(ctx, em, ldir);
+                const float4 ax = tile_aux[index];
+                const v3 ldir = V3(ax.x, ax.y, ax.z);
+                float targetPdf = fmaxf(0.f, ax.w * rtarget::eval_brdf(ctx, ldir));   // rtarget::target with the precomputed luminance
                 float sourcePdf = lerpf(lpdf, rtarget::pdf_brdf(ctx, ldir), ratio);  // res.slang:79-91
                 float w = targetPdf / sourcePdf;                                       // res.slang:93-113
                 s.weightSum += w; s.M += 1.f;
@@ -172,7 +185,7 @@ __global__ void __launch_bounds__(MR_BLOCK) k_initial_gen(mirres_config_t C, Env
             store_ris(R, pi, s);
         }
     }
-    uint32_t slot = wave_append(q_count, want);
+    uint32_t slot = block_append(q_count, want);
     if (want) put_ray(q, slot, rpos, rdir, C.vis_near);
     if (pi < N) slot_out[pi] = want ? (int32_t)slot : -1;
 }
@@ -253,7 +266,7 @@ MR_DEV int spatial_neighbor(const mirres_config_t& C, const GBufD& G, const ResD
     return (int)qi;
 }
 
-__global__ void __launch_bounds__(MR_BLOCK) k_spatial_gen(mirres_config_t C, GBufD G, ResD PR, const float* __restrict__ noff, uint32_t frameIndex,
+__global__ void __launch_bounds__(MR_GEN_BLOCK) k_spatial_gen(mirres_config_t C, GBufD G, ResD PR, const float* __restrict__ noff, uint32_t frameIndex,
                                                           int fx, int fy, int N, Ray* __restrict__ q, uint32_t* __restrict__ q_count,
                                                           int32_t* __restrict__ slot_out, uint32_t* __restrict__ mask_out) {
     const int pi = blockIdx.x * blockDim.x + threadIdx.x;
@@ -274,7 +287,7 @@ __global__ void __launch_bounds__(MR_BLOCK) k_spatial_gen(mirres_config_t C, GBu
         }
         if (cnt) { cpos = ld3(G.pos, pi); cdir = oct_decode(V2(PR.light_data[3 * (size_t)pi + 1], PR.light_data[3 * (size_t)pi + 2])); }
     }
-    uint32_t base = wave_append(q_count, cnt > 0, 2 * cnt);
+    uint32_t base = block_append(q_count, cnt > 0, 2 * cnt);
     if (cnt) {
         uint32_t s = base;
         const int k = min(C.neighbor_count, 8);
@@ -350,7 +363,7 @@ __global__ void __launch_bounds__(MR_BLOCK) k_spatial_resolve(mirres_config_t C,
 }
 
 // ---------------------------------------------------------------- final-sample visibility + evaluation (EvaluateFinalSamples.slang:84-188)
-__global__ void __launch_bounds__(MR_BLOCK) k_vis_gen(float vis_near, const float* __restrict__ pos, ResD R, int N, Ray* __restrict__ q,
+__global__ void __launch_bounds__(MR_GEN_BLOCK) k_vis_gen(float vis_near, const float* __restrict__ pos, ResD R, int N, Ray* __restrict__ q,
                                                       uint32_t* __restrict__ q_count, int32_t* __restrict__ slot_out) {
     const int pi = blockIdx.x * blockDim.x + threadIdx.x;
     bool want = false; v3 rp = V3(0.f), rd = V3(0.f);
@@ -358,7 +371,7 @@ __global__ void __launch_bounds__(MR_BLOCK) k_vis_gen(float vis_near, const floa
         v3 ld = ld3(R.light_data, pi);
         if (ld.x > 0.1f) { want = true; rp = ld3(pos, pi); rd = oct_decode(V2(ld.y, ld.z)); }
     }
-    uint32_t slot = wave_append(q_count, want);
+    uint32_t slot = block_append(q_count, want);
     if (want) put_ray(q, slot, rp, rd, vis_near);
     if (pi < N) slot_out[pi] = want ? (int32_t)slot : -1;
 }
@@ -460,6 +473,7 @@ int mirres_ctx_create(mirres_ctx_t** out, int fx, int fy, const mirres_config_t*
     MR_HIP(hipMalloc(&c->slot_c, sizeof(int32_t) * N));
     MR_HIP(hipMalloc(&c->pend, sizeof(float) * 18 * N));
     MR_HIP(hipMalloc(&c->noff, sizeof(float) * 2 * (size_t)c->cfg.neighbor_offset_count));
+    MR_HIP(hipMalloc(&c->tile_aux, sizeof(float) * 4 * (size_t)c->cfg.light_tile_count * c->cfg.light_tile_size));
     k_neighbor_offsets<<<1, 64, 0, 0>>>(c->cfg.neighbor_offset_count, c->noff);
     MR_HIP(hipDeviceSynchronize());
     *out = c;
@@ -468,7 +482,7 @@ int mirres_ctx_create(mirres_ctx_t** out, int fx, int fy, const mirres_config_t*
 
 void mirres_ctx_destroy(mirres_ctx_t* c) {
     if (!c) return;
-    void* ptrs[] = {c->any_rays, c->any_hit, c->cl_rays, c->cl_hit, c->counters, c->stats, c->slot_a, c->mask_a, c->slot_c, c->pend, c->noff, c->pool};
+    void* ptrs[] = {c->any_rays, c->any_hit, c->cl_rays, c->cl_hit, c->counters, c->stats, c->slot_a, c->mask_a, c->slot_c, c->pend, c->noff, c->pool, c->tile_aux};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t e : c->ev_any) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->ev_cl) (void)hipEventDestroy(e);
@@ -526,7 +540,9 @@ int mirres_restir_initial(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_env
     if (!ctx || !bvh || !env || !g || !res) { set_error("mirres_restir_initial: null"); return MIRRES_E_ARG; }
     hipStream_t s = (hipStream_t)stream; const int N = (int)ctx->N; const int grd = grid_for(N, MR_BLOCK);
     MR_HIP(hipMemsetAsync(&ctx->counters[0], 0, sizeof(uint32_t), s));
-    k_initial_gen<<<grd, MR_BLOCK, 0, s>>>(ctx->cfg, envh(env), gbufd(g), resd(res), light_data, light_inv_pdf, frameIndex, ctx->fx, N, ctx->any_rays,
+    const int TS = ctx->cfg.light_tile_count * ctx->cfg.light_tile_size;
+    k_tile_aux<<<grid_for(TS, MR_BLOCK), MR_BLOCK, 0, s>>>(envh(env), TS, light_data, reinterpret_cast<float4*>(ctx->tile_aux));
+    k_initial_gen<<<grid_for(N, MR_GEN_BLOCK), MR_GEN_BLOCK, 0, s>>>(ctx->cfg, envh(env), gbufd(g), resd(res), light_data, light_inv_pdf, reinterpret_cast<const float4*>(ctx->tile_aux), frameIndex, ctx->fx, N, ctx->any_rays,
                                             &ctx->counters[0], ctx->slot_a);
     int rc = trace_any(ctx, bvh, (size_t)N, s); if (rc) return rc;
     k_initial_resolve<<<grd, MR_BLOCK, 0, s>>>(resd(res), N, ctx->slot_a, ctx->any_hit);
@@ -550,7 +566,7 @@ int mirres_restir_spatial(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_env
     hipStream_t s = (hipStream_t)stream; const int N = (int)ctx->N; const int grd = grid_for(N, MR_BLOCK);
     const float* noff = neighbor_offsets ? neighbor_offsets : ctx->noff;
     MR_HIP(hipMemsetAsync(&ctx->counters[0], 0, sizeof(uint32_t), s));
-    k_spatial_gen<<<grd, MR_BLOCK, 0, s>>>(ctx->cfg, gbufd(g), resd(prev_res), noff, frameIndex, ctx->fx, ctx->fy, N, ctx->any_rays, &ctx->counters[0],
+    k_spatial_gen<<<grid_for(N, MR_GEN_BLOCK), MR_GEN_BLOCK, 0, s>>>(ctx->cfg, gbufd(g), resd(prev_res), noff, frameIndex, ctx->fx, ctx->fy, N, ctx->any_rays, &ctx->counters[0],
                                             ctx->slot_a, ctx->mask_a);
     int rc = trace_any(ctx, bvh, ctx->any_cap, s); if (rc) return rc;
     k_spatial_resolve<<<grd, MR_BLOCK, 0, s>>>(ctx->cfg, envh(env), gbufd(g), resd(res), resd(prev_res), noff, frameIndex, ctx->fx, ctx->fy, N, ctx->slot_a,
@@ -563,7 +579,7 @@ int mirres_restir_final_vis(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const float* p
     if (!ctx || !bvh || !pos || !res || !vis_map) { set_error("mirres_restir_final_vis: null"); return MIRRES_E_ARG; }
     hipStream_t s = (hipStream_t)stream; const int N = (int)ctx->N; const int grd = grid_for(N, MR_BLOCK);
     MR_HIP(hipMemsetAsync(&ctx->counters[0], 0, sizeof(uint32_t), s));
-    k_vis_gen<<<grd, MR_BLOCK, 0, s>>>(ctx->cfg.vis_near, pos, resd(res), N, ctx->any_rays, &ctx->counters[0], ctx->slot_a);
+    k_vis_gen<<<grid_for(N, MR_GEN_BLOCK), MR_GEN_BLOCK, 0, s>>>(ctx->cfg.vis_near, pos, resd(res), N, ctx->any_rays, &ctx->counters[0], ctx->slot_a);
     int rc = trace_any(ctx, bvh, (size_t)N, s); if (rc) return rc;
     k_vis_resolve<<<grd, MR_BLOCK, 0, s>>>(N, ctx->slot_a, ctx->any_hit, vis_map);
     MR_LAUNCH_CHECK("restir_final_vis");

@@ -16,6 +16,7 @@ int trace_closest_queue_counted(const mirres_bvh* bvh, const Ray* rays, const ui
                                 unsigned long long* stats, hipStream_t s);
 
 #define MR_BLOCK 256
+#define MR_GEN_BLOCK 1024   // ray-generating kernels: one queue atomic per 1024 pixels
 
 MR_DEV void put_ray(Ray* q, uint32_t slot, v3 pos, v3 dir, float vis_near) {
     v3 o = pos + vis_near * dir;
@@ -89,7 +90,7 @@ MR_DEV void next_bounce_resolve(const mirres_path_t& P, size_t pi, const HitRec*
 }
 
 // ---------------------------------------------------------------- process_new_dir_for_pt (FinalShading.slang:113-265)
-__global__ void __launch_bounds__(MR_BLOCK) k_new_dir_gen(mirres_path_t P, int max_bounce, float vis_near, uint32_t frameIndex, uint32_t bounce_count, int fx,
+__global__ void __launch_bounds__(MR_GEN_BLOCK) k_new_dir_gen(mirres_path_t P, int max_bounce, float vis_near, uint32_t frameIndex, uint32_t bounce_count, int fx,
                                                           int N, Ray* __restrict__ q, uint32_t* __restrict__ q_count, int32_t* __restrict__ slot_out) {
     const int pi = blockIdx.x * blockDim.x + threadIdx.x;
     bool want = false; v3 rp = V3(0.f), rdir = V3(0.f);
@@ -108,7 +109,7 @@ __global__ void __launch_bounds__(MR_BLOCK) k_new_dir_gen(mirres_path_t P, int m
             rp = v.pos;
         }
     }
-    uint32_t slot = wave_append(q_count, want);
+    uint32_t slot = block_append(q_count, want);
     if (want) put_ray(q, slot, rp, rdir, vis_near);
     if (pi < N) slot_out[pi] = want ? (int32_t)slot : -1;
 }
@@ -120,7 +121,7 @@ __global__ void __launch_bounds__(MR_BLOCK) k_new_dir_resolve(mirres_path_t P, i
 }
 
 // ---------------------------------------------------------------- process_path_tracing_divided_no_grad (FinalShading.slang:641-1009)
-__global__ void __launch_bounds__(MR_BLOCK) k_bounce_gen(mirres_path_t P, EnvD E, int max_bounce, float vis_near, uint32_t frameIndex, uint32_t bounce_count,
+__global__ void __launch_bounds__(MR_GEN_BLOCK) k_bounce_gen(mirres_path_t P, EnvD E, int max_bounce, float vis_near, uint32_t frameIndex, uint32_t bounce_count,
                                                          int fx, int N, float* __restrict__ color, float* __restrict__ diff_color, float* __restrict__ spec_color,
                                                          Ray* __restrict__ qa, uint32_t* __restrict__ qa_count, Ray* __restrict__ qc, uint32_t* __restrict__ qc_count,
                                                          int32_t* __restrict__ slot_a, uint32_t* __restrict__ mask_out, int32_t* __restrict__ slot_c,
@@ -216,8 +217,8 @@ __global__ void __launch_bounds__(MR_BLOCK) k_bounce_gen(mirres_path_t P, EnvD E
         st3(color, pi, cv); st3(diff_color, pi, dcv); st3(spec_color, pi, scv);
     }
     const uint32_t na = (mask & 1u) + ((mask >> 1) & 1u);
-    uint32_t base = wave_append(qa_count, na > 0, na);
-    uint32_t cs = wave_append(qc_count, (mask & 4u) != 0);
+    uint32_t base = block_append(qa_count, na > 0, na);
+    uint32_t cs = block_append(qc_count, (mask & 4u) != 0);
     if (mask & 1u) put_ray(qa, base, sp, nee_dir, vis_near);
     if (mask & 2u) put_ray(qa, base + (mask & 1u), sp, bsdf_dir, vis_near);
     if (mask & 4u) put_ray(qc, cs, sp, next_dir, vis_near);
@@ -265,7 +266,7 @@ int launch_final_shading(const mirres_env_t* env, const float* occ, const float*
 int launch_new_dir(mirres_ctx* ctx, mirres_bvh* bvh, const mirres_path_t* p, uint32_t frameIndex, uint32_t bounce_count, hipStream_t s) {
     const int N = (int)ctx->N, grd = grid_for(N, MR_BLOCK);
     MR_HIP(hipMemsetAsync(&ctx->counters[1], 0, sizeof(uint32_t), s));
-    k_new_dir_gen<<<grd, MR_BLOCK, 0, s>>>(*p, ctx->cfg.max_bounce, ctx->cfg.vis_near, frameIndex, bounce_count, ctx->fx, N, ctx->cl_rays, &ctx->counters[1], ctx->slot_c);
+    k_new_dir_gen<<<grid_for(N, MR_GEN_BLOCK), MR_GEN_BLOCK, 0, s>>>(*p, ctx->cfg.max_bounce, ctx->cfg.vis_near, frameIndex, bounce_count, ctx->fx, N, ctx->cl_rays, &ctx->counters[1], ctx->slot_c);
     int rc = trace_closest(ctx, bvh, (size_t)N, s);
     if (rc) return rc;
     k_new_dir_resolve<<<grd, MR_BLOCK, 0, s>>>(*p, N, ctx->slot_c, ctx->cl_hit);
@@ -276,7 +277,7 @@ int launch_bounce(mirres_ctx* ctx, mirres_bvh* bvh, const mirres_env_t* env, con
                   float* dc, float* sc, float* acc_c, float* acc_d, float* acc_s, hipStream_t s) {
     const int N = (int)ctx->N, grd = grid_for(N, MR_BLOCK);
     MR_HIP(hipMemsetAsync(&ctx->counters[0], 0, 2 * sizeof(uint32_t), s));
-    k_bounce_gen<<<grd, MR_BLOCK, 0, s>>>(*p, envh(env), ctx->cfg.max_bounce, ctx->cfg.vis_near, frameIndex, bounce_count, ctx->fx, N, color, dc, sc, ctx->any_rays,
+    k_bounce_gen<<<grid_for(N, MR_GEN_BLOCK), MR_GEN_BLOCK, 0, s>>>(*p, envh(env), ctx->cfg.max_bounce, ctx->cfg.vis_near, frameIndex, bounce_count, ctx->fx, N, color, dc, sc, ctx->any_rays,
                                            &ctx->counters[0], ctx->cl_rays, &ctx->counters[1], ctx->slot_a, ctx->mask_a, ctx->slot_c, ctx->pend);
     int rc = trace_any(ctx, bvh, 2 * (size_t)N, s); if (rc) return rc;
     rc = trace_closest(ctx, bvh, (size_t)N, s); if (rc) return rc;
