@@ -214,6 +214,35 @@ __global__ void __launch_bounds__(256) k_pack(int T, const int32_t* __restrict__
     }
 }
 
+// 4-wide collapse of the LBVH for the shadow-ray kernel: node g's entries are the children of its internal children (a leaf child stays
+// an entry itself). Boxes are copied bit for bit from the refitted LBVH, so every leaf is still guarded by exactly its own box.
+__global__ void __launch_bounds__(256) k_pack4(int T, const int32_t* __restrict__ info, const float* __restrict__ aabb, Node4* __restrict__ nodes4) {
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= T - 1) return;
+    const int LEAF = T - 1;
+    int c[4]; int nc = 0;
+    const int ch[2] = {info[3 * (size_t)g], info[3 * (size_t)g + 1]};
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        if (ch[k] >= LEAF) c[nc++] = ch[k];
+        else { c[nc++] = info[3 * (size_t)ch[k]]; c[nc++] = info[3 * (size_t)ch[k] + 1]; }
+    }
+    Node4 n;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (k < nc) {
+            const float* b = aabb + 6 * (size_t)c[k];
+            n.minx[k] = b[0]; n.miny[k] = b[1]; n.minz[k] = b[2]; n.maxx[k] = b[3]; n.maxy[k] = b[4]; n.maxz[k] = b[5];
+            n.ref[k] = (c[k] >= LEAF) ? ~(c[k] - LEAF) : c[k];
+        } else {
+            n.minx[k] = n.miny[k] = n.minz[k] = 0.f; n.maxx[k] = n.maxy[k] = n.maxz[k] = 0.f;
+            n.ref[k] = 0x7fffffff;
+        }
+        n.pad[k] = 0;
+    }
+    nodes4[g] = n;
+}
+
 __global__ void k_init_extent(uint32_t* extent) {
     int i = threadIdx.x;
     if (i < 3) extent[i] = 0xffffffffu; else if (i < 6) extent[i] = 0u;
@@ -249,6 +278,7 @@ int mirres_bvh_create(mirres_bvh_t** out, int max_tris) {
     MR_HIP(hipMalloc(&b->own_aabb, sizeof(float) * 6 * (2 * T)));
     MR_HIP(hipMalloc(&b->nodes, sizeof(WideNode) * T));
     MR_HIP(hipMalloc(&b->tris, sizeof(TriRec) * T));
+    MR_HIP(hipMalloc(&b->nodes4, sizeof(Node4) * T));
     MR_HIP(hipMalloc(&b->root_box, sizeof(float) * 8));
     MR_HIP(hipMalloc(&b->work, sizeof(uint32_t) * 4));
     size_t tmp = 0;
@@ -262,7 +292,7 @@ int mirres_bvh_create(mirres_bvh_t** out, int max_tris) {
 void mirres_bvh_destroy(mirres_bvh_t* b) {
     if (!b) return;
     void* ptrs[] = {b->ele_aabb, b->extent, b->keys_in, b->keys_out, b->vals_in, b->vals_out, b->parent, b->flags, b->own_info,
-                    b->own_aabb, b->nodes, b->tris, b->root_box, b->sort_tmp, b->work};
+                    b->own_aabb, b->nodes, b->tris, b->root_box, b->sort_tmp, b->work, b->nodes4};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete b;
 }
@@ -284,6 +314,7 @@ int mirres_bvh_build(mirres_bvh_t* b, const float* vert, int V, const int32_t* t
     k_hierarchy<<<grd, blk, 0, s>>>(T, b->keys_out, b->vals_out, b->ele_aabb, info, aabb, b->parent, b->flags, sorted_codes);
     k_refit<<<grd, blk, 0, s>>>(T, info, aabb, b->parent, b->flags);
     k_pack<<<grd, blk, 0, s>>>(T, info, aabb, vert, tri, b->nodes, b->tris, b->root_box);
+    k_pack4<<<grd, blk, 0, s>>>(T, info, aabb, b->nodes4);
     MR_LAUNCH_CHECK("bvh_build");
     return MIRRES_OK;
 }

@@ -18,6 +18,7 @@
 //   * rays come from compacted queues; blocks grid-stride over the queue, count read on device (no host sync).
 #include "engine.hpp"
 #include "device_math.hpp"
+#include <cstdlib>
 
 namespace mr {
 
@@ -474,6 +475,114 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any_fast(BvhView B, co
     if (stats && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[0], (unsigned long long)n);
 }
 
+
+// ---------------------------------------------------------------- shadow rays on the 4-wide collapse (engine.hpp Node4)
+// Same order-free argument as k_trace_any_fast; the hierarchy is the LBVH with every other level removed, so a ray does about half the
+// dependent node fetches (each a full 128-byte line) and the per-visit bookkeeping is amortised over four slab tests.
+template <bool COUNT>
+__global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4(BvhView B, const Ray* __restrict__ rays, const uint32_t* __restrict__ d_count,
+                                                               uint32_t n_fixed, uint32_t* __restrict__ work_head, int32_t* __restrict__ hit_out,
+                                                               unsigned long long* __restrict__ stats) {
+    __shared__ uint32_t lds[MR_ANY_LDS * MR_TRACE_BLOCK];
+    uint32_t* const lds_stack = lds + threadIdx.x;
+    const uint32_t n = d_count ? *d_count : n_fixed;
+    const int lane = lane_id();
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    uint32_t chunk = n / (gridDim.x * (MR_TRACE_BLOCK / 64) * 4);
+    chunk = chunk < 64 ? 64 : (chunk > MR_CHUNK_MAX ? MR_CHUNK_MAX : (chunk & ~63u));
+    uint32_t chunk_next = 0, chunk_end = 0;
+    bool exhausted = false, have = false;
+    float ox = 0, oy = 0, oz = 0, ix = 0, iy = 0, iz = 0; v3 d = V3(0.f), ro = V3(0.f);
+    float t_min = 0.f, t_max = 0.f;
+    int cur = 0, sp = 0; uint32_t ridx = 0;
+    uint32_t spill[MR_STACK - MR_ANY_LDS];
+    unsigned long long c_boxes = 0, c_nodes = 0, c_leaves = 0;
+    while (true) {
+        const uint64_t need = __ballot(!have);
+        if (need && !exhausted) {
+            if (chunk_next >= chunk_end) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(work_head, chunk);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (base >= n) exhausted = true;
+                else { chunk_next = base; chunk_end = (base + chunk < n) ? base + chunk : n; }
+            }
+            if (!exhausted) {
+                const uint32_t idx = chunk_next + (uint32_t)__popcll(need & lt_mask);
+                if (!have && idx < chunk_end) {
+                    const float4 a = reinterpret_cast<const float4*>(rays + idx)[0], b = reinterpret_cast<const float4*>(rays + idx)[1];
+                    ridx = idx; ro = V3(a.x, a.y, a.z); t_min = a.w; t_max = b.w;
+                    d = normalize(V3(b.x, b.y, b.z));
+                    ox = ro.x; oy = ro.y; oz = ro.z;
+                    { float dx = d.x, dy = d.y, dz = d.z;
+                      if (dx == 0.f) dx = 0.000001f; if (dy == 0.f) dy = 0.000001f; if (dz == 0.f) dz = 0.000001f;
+                      ix = 1.0f / dx; iy = 1.0f / dy; iz = 1.0f / dz; }
+                    sp = 0;
+                    const float o3[3] = {ox, oy, oz}, i3[3] = {ix, iy, iz};
+                    Slab s0 = slab(B.root_box, B.root_box + 3, o3, i3, t_min);
+                    if (COUNT) c_boxes++;
+                    if (s0.tf > s0.tn && t_max > s0.tn) { cur = 0; have = true; }
+                    else hit_out[idx] = 0;
+                }
+                const uint32_t want = (uint32_t)__popcll(need);
+                chunk_next = (chunk_next + want < chunk_end) ? chunk_next + want : chunk_end;
+            }
+        }
+        if (!__ballot(have)) { if (exhausted) break; else continue; }
+        do {
+            if (have) {
+                const Node4* __restrict__ nd = B.nodes4 + cur;
+                const float4 mnx = reinterpret_cast<const float4*>(nd)[0], mny = reinterpret_cast<const float4*>(nd)[1], mnz = reinterpret_cast<const float4*>(nd)[2];
+                const float4 mxx = reinterpret_cast<const float4*>(nd)[3], mxy = reinterpret_cast<const float4*>(nd)[4], mxz = reinterpret_cast<const float4*>(nd)[5];
+                const int4 rf = reinterpret_cast<const int4*>(nd)[6];
+                const float bmnx[4] = {mnx.x, mnx.y, mnx.z, mnx.w}, bmny[4] = {mny.x, mny.y, mny.z, mny.w}, bmnz[4] = {mnz.x, mnz.y, mnz.z, mnz.w};
+                const float bmxx[4] = {mxx.x, mxx.y, mxx.z, mxx.w}, bmxy[4] = {mxy.x, mxy.y, mxy.z, mxy.w}, bmxz[4] = {mxz.x, mxz.y, mxz.z, mxz.w};
+                const int ref[4] = {rf.x, rf.y, rf.z, rf.w};
+                if (COUNT) c_nodes++;
+                bool hit = false;
+                int next = -1; float next_tn = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    // the reference's slab test of this child's own box (see slab())
+                    const float ax = (bmnx[k] - ox) * ix, bx = (bmxx[k] - ox) * ix;
+                    const float ay = (bmny[k] - oy) * iy, by = (bmxy[k] - oy) * iy;
+                    const float az = (bmnz[k] - oz) * iz, bz = (bmxz[k] - oz) * iz;
+                    const float tn = fmaxf(fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz)), t_min);
+                    const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+                    const bool ok = ref[k] != 0x7fffffff && tf > tn && t_max > tn;
+                    if (COUNT && ref[k] != 0x7fffffff) c_boxes++;
+                    if (ok && !hit) {
+                        if (ref[k] < 0) { hit = tri_accepts(B.tris + ~ref[k], ro, d); if (COUNT) c_leaves++; }
+                        else if (next < 0) { next = ref[k]; next_tn = tn; }
+                        else {
+                            int far = ref[k];
+                            if (tn < next_tn) { far = next; next = ref[k]; next_tn = tn; }   // keep the nearest for the immediate descent
+                            if (sp < MR_ANY_LDS) lds_stack[sp * MR_TRACE_BLOCK] = (uint32_t)far;
+                            else if (sp < MR_STACK) spill[sp - MR_ANY_LDS] = (uint32_t)far;
+                            if (sp < MR_STACK) sp++;
+                        }
+                    }
+                }
+                bool done = hit;
+                if (!hit) {
+                    if (next >= 0) cur = next;
+                    else if (sp > 0) { --sp; cur = (int)((sp < MR_ANY_LDS) ? lds_stack[sp * MR_TRACE_BLOCK] : spill[sp - MR_ANY_LDS]); }
+                    else done = true;
+                }
+                if (done) { have = false; hit_out[ridx] = hit ? 1 : 0; }
+            }
+        } while (__popcll(__ballot(have)) >= MR_REFILL || (exhausted && __ballot(have)));
+    }
+    if (COUNT && stats) { atomicAdd(&stats[2], c_boxes); atomicAdd(&stats[3], c_nodes); atomicAdd(&stats[4], c_leaves); }
+    if (stats && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[0], (unsigned long long)n);
+}
+
+static int any_mode() {   // MIRRES_ANY=2 selects the binary-tree shadow kernel (A/B experiments); default: 4-wide
+    static int m = -1;
+    if (m < 0) { const char* e = getenv("MIRRES_ANY"); m = (e && e[0] == '2') ? 2 : 4; }
+    return m;
+}
+
 static int persist_grid(size_t capacity) {
     size_t want = (capacity + MR_TRACE_BLOCK - 1) / MR_TRACE_BLOCK;
     size_t cap = 256 * 6;                                       // 6 resident blocks per CU (LDS 24 KB each)
@@ -490,7 +599,8 @@ static int trace_grid(size_t capacity) {
 int trace_any_queue(const mirres_bvh* bvh, const Ray* rays, const uint32_t* d_count, size_t capacity, int32_t* hit,
                     unsigned long long* stats, hipStream_t s) {
     MR_HIP(hipMemsetAsync(bvh->work, 0, sizeof(uint32_t), s));
-    k_trace_any_fast<false><<<persist_grid(capacity), MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, d_count, (uint32_t)capacity, bvh->work, hit, stats);
+    if (any_mode() == 4) k_trace_any4<false><<<persist_grid(capacity), MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, d_count, (uint32_t)capacity, bvh->work, hit, stats);
+    else k_trace_any_fast<false><<<persist_grid(capacity), MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, d_count, (uint32_t)capacity, bvh->work, hit, stats);
     MR_LAUNCH_CHECK("trace_any_queue");
     return 0;
 }
@@ -505,7 +615,8 @@ int trace_closest_queue(const mirres_bvh* bvh, const Ray* rays, const uint32_t* 
 int trace_any_queue_counted(const mirres_bvh* bvh, const Ray* rays, const uint32_t* d_count, size_t capacity, int32_t* hit,
                             unsigned long long* stats, hipStream_t s) {
     MR_HIP(hipMemsetAsync(bvh->work, 0, sizeof(uint32_t), s));
-    k_trace_any_fast<true><<<persist_grid(capacity), MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, d_count, (uint32_t)capacity, bvh->work, hit, stats);
+    if (any_mode() == 4) k_trace_any4<true><<<persist_grid(capacity), MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, d_count, (uint32_t)capacity, bvh->work, hit, stats);
+    else k_trace_any_fast<true><<<persist_grid(capacity), MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, d_count, (uint32_t)capacity, bvh->work, hit, stats);
     MR_LAUNCH_CHECK("trace_any_queue_counted");
     return 0;
 }
@@ -534,7 +645,8 @@ extern "C" int mirres_bvh_trace(mirres_bvh_t* bvh, const float* rays, int n, int
         if (counters) k_trace_any<true><<<g, MR_TRACE_BLOCK, 0, s>>>(bvh->view(), r, nullptr, (uint32_t)n, hit, counters, nullptr);
         else {
             MR_HIP(hipMemsetAsync(bvh->work + 2, 0, sizeof(uint32_t), s));
-            k_trace_any_fast<false><<<persist_grid((size_t)n), MR_TRACE_BLOCK, 0, s>>>(bvh->view(), r, nullptr, (uint32_t)n, bvh->work + 2, hit, nullptr);
+            if (any_mode() == 4) k_trace_any4<false><<<persist_grid((size_t)n), MR_TRACE_BLOCK, 0, s>>>(bvh->view(), r, nullptr, (uint32_t)n, bvh->work + 2, hit, nullptr);
+            else k_trace_any_fast<false><<<persist_grid((size_t)n), MR_TRACE_BLOCK, 0, s>>>(bvh->view(), r, nullptr, (uint32_t)n, bvh->work + 2, hit, nullptr);
         }
     } else {
         if (counters) k_trace_closest<true><<<g, MR_TRACE_BLOCK, 0, s>>>(bvh->view(), r, nullptr, (uint32_t)n, nullptr, hit, t, pos, normal, prim, counters, nullptr);

@@ -16,6 +16,13 @@ struct __attribute__((aligned(64))) WideNode {
     int32_t left, right;  // >=0 internal node index, <0 : ~leaf_slot
     int32_t pad[2];
 };
+// 4-wide node for shadow rays (any-hit may use any hierarchy over the same leaf boxes — bvh_trace.hip): the LBVH node's grandchildren
+// (or children when a child is a leaf), boxes copied verbatim, SoA so that the four slab tests vectorise. One 128-byte line per visit.
+struct __attribute__((aligned(128))) Node4 {
+    float minx[4], miny[4], minz[4], maxx[4], maxy[4], maxz[4];
+    int32_t ref[4];   // >=0 internal LBVH node id, <0 ~leaf slot, 0x7fffffff = unused entry
+    int32_t pad[4];
+};
 struct __attribute__((aligned(16))) TriRec {  // 48 B
     float v0[3], e1[3], e2[3];
     int32_t prim;
@@ -31,6 +38,7 @@ struct __attribute__((aligned(16))) HitRec {  // 32 B closest-hit record
 
 struct BvhView {
     const WideNode* nodes; const TriRec* tris; const float* root_box;  // root_box -> aabb[0..5] of node 0
+    const Node4* nodes4;
     int T;
 };
 
@@ -49,9 +57,10 @@ struct mirres_bvh {
     // traversal layout
     mr::WideNode* nodes = nullptr;  // [T-1]
     mr::TriRec* tris = nullptr;     // [T]
+    mr::Node4* nodes4 = nullptr;    // [T-1] indexed by LBVH node id (only the nodes reachable from the root by 2-level steps are used)
     float* root_box = nullptr;      // [6]
     uint32_t* work = nullptr;       // [4] chunk heads of the persistent traversal kernels
-    mr::BvhView view() const { mr::BvhView v; v.nodes = nodes; v.tris = tris; v.root_box = root_box; v.T = T; return v; }
+    mr::BvhView view() const { mr::BvhView v; v.nodes = nodes; v.tris = tris; v.root_box = root_box; v.T = T; v.nodes4 = nodes4; return v; }
 };
 
 struct mirres_ctx {
