@@ -585,7 +585,8 @@ static int any_mode() {   // MIRRES_ANY=2 selects the binary-tree shadow kernel 
 
 static int persist_grid(size_t capacity) {
     size_t want = (capacity + MR_TRACE_BLOCK - 1) / MR_TRACE_BLOCK;
-    size_t cap = 256 * 6;                                       // 6 resident blocks per CU (LDS 24 KB each)
+    size_t cap = 256 * 6;                                       // 6 resident blocks per CU: measured faster than 8 (forcing <= 64 VGPRs spills and thrashes
+                                                                // the L1; PMC shows the kernels bound by TCP line lookups of divergent 16-B gathers, not by latency hiding)
     return (int)(want < 1 ? 1 : (want > cap ? cap : want));
 }
 

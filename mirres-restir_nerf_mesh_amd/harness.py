@@ -52,3 +52,61 @@ def postprocess(final_color, occ, H, W, ssaa):
 def psnr(pred, gt):
     mse = torch.mean((pred - gt) ** 2)
     return float(-10.0 * torch.log10(mse))
+
+
+def read_hdr(path):
+    """Radiance RGBE (.hdr) reader -> float32 [H,W,3] RGB, for `--envmap_path` relighting (the reference uses cv2.imread(..., IMREAD_ANYDEPTH),
+    nerf/network.py:136). Supports flat and new-style RLE scanlines."""
+    with open(path, "rb") as f:
+        data = f.read()
+    pos = 0
+    if not data.startswith(b"#?"):
+        raise ValueError("not a Radiance HDR file")
+    while True:
+        end = data.index(b"\n", pos)
+        line = data[pos:end]
+        pos = end + 1
+        if line == b"":
+            break
+    end = data.index(b"\n", pos)
+    dims = data[pos:end].split()
+    pos = end + 1
+    if len(dims) != 4 or dims[0] != b"-Y" or dims[2] != b"+X":
+        raise ValueError("unsupported orientation %r" % dims)
+    H, W = int(dims[1]), int(dims[3])
+    buf = np.frombuffer(data, dtype=np.uint8, offset=pos)
+    rgbe = np.zeros((H, W, 4), np.uint8)
+    p = 0
+    for y in range(H):
+        if W >= 8 and W < 32768 and buf[p] == 2 and buf[p + 1] == 2 and (int(buf[p + 2]) << 8 | int(buf[p + 3])) == W:
+            p += 4
+            for c in range(4):
+                x = 0
+                while x < W:
+                    n = int(buf[p]); p += 1
+                    if n > 128:
+                        n -= 128
+                        rgbe[y, x:x + n, c] = buf[p]; p += 1
+                    else:
+                        rgbe[y, x:x + n, c] = buf[p:p + n]; p += n
+                    x += n
+        else:
+            rgbe[y] = buf[p:p + 4 * W].reshape(W, 4); p += 4 * W
+    e = rgbe[..., 3].astype(np.int32)
+    scale = np.where(e > 0, np.ldexp(1.0, e - 136), 0.0).astype(np.float32)
+    return np.ascontiguousarray(rgbe[..., :3].astype(np.float32) * scale[..., None])
+
+
+def write_hdr(path, img):
+    """Flat (non-RLE) Radiance RGBE writer, used by the tests to make fixtures."""
+    img = np.asarray(img, np.float32)
+    H, W, _ = img.shape
+    m = img.max(axis=2)
+    mant, ex = np.frexp(m)
+    sc = np.where(m > 1e-32, mant * 256.0 / np.maximum(m, 1e-32), 0.0)
+    rgbe = np.zeros((H, W, 4), np.uint8)
+    rgbe[..., :3] = np.clip(img * sc[..., None], 0, 255).astype(np.uint8)
+    rgbe[..., 3] = np.where(m > 1e-32, ex + 128, 0).astype(np.uint8)
+    with open(path, "wb") as f:
+        f.write(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n" % (H, W))
+        f.write(rgbe.tobytes())

@@ -81,3 +81,17 @@ def test_allreduce_exchange_gloo_world2(tmp_path):
         expect = r0["local"][k] + r1["local"][k]
         assert torch.allclose(r0["red"][k], expect) and torch.allclose(r1["red"][k], expect)
         assert r0["red"][k].shape == (50, 3)
+
+
+def test_rgbe_roundtrip(tmp_path):
+    from mirres_restir_nerf_mesh_amd import harness
+    rng = np.random.default_rng(0)
+    img = (rng.random((6, 10, 3)) * np.array([0.01, 1.0, 300.0])).astype(np.float32)
+    img[0, 0] = 0
+    p = str(tmp_path / "e.hdr")
+    harness.write_hdr(p, img)
+    back = harness.read_hdr(p)
+    assert back.shape == img.shape and back.dtype == np.float32
+    m = img.max(axis=2, keepdims=True)
+    assert np.all(np.abs(back - img) <= m / 128.0 + 1e-9)      # 8-bit mantissa shared by the texel
+    assert np.all(back[0, 0] == 0)
