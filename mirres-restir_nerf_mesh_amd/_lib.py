@@ -86,6 +86,7 @@ SIGNATURES = {
     "mirres_matnet_grid_entries": (C.c_int, []),
     "mirres_matnet_pack_grid": (C.c_int, [vp, vp, C.c_int64, vp]),
     "mirres_matnet_fwd": (C.c_int, [PMAT, vp, C.c_int, vp, vp, vp]),
+    "mirres_matnet_mlp": (C.c_int, [PMAT, vp, C.c_int, vp, vp]),
     "mirres_matnet_scatter": (C.c_int, [PMAT, vp, vp, C.c_int, vp, vp, C.c_int, C.POINTER(C.c_float), vp]),
     "mirres_matnet_bwd": (C.c_int, [PMAT, vp, C.c_int, vp, vp, vp, vp, vp, vp]),
     "mirres_render": (C.c_int, [vp, vp, PARGS, vp]),

@@ -146,6 +146,152 @@ __global__ void __launch_bounds__(MR_BLOCK) k_matnet_scatter(MatNetD M, GridLeve
     }
 }
 
+
+// ---------------------------------------------------------------- MFMA-tiled MLP (the one dense contraction of the path)
+// 64 points per wave, v_mfma_f32_32x32x16_f16: M = 32 points, N = 32 neurons, K = 16 features per instruction.
+// fp32-accurate on the f16 matrix pipe: every fp32 operand is split x = xh + xl (two fp16 numbers, |x - xh - xl| <= 2^-22 |x|) and the
+// product is evaluated as xh*wh + xh*wl + xl*wh with fp32 accumulation inside the MFMA (f16 x f16 products are exact in fp32); the layer-0
+// inputs are fp16 already (hash-grid features), so layer 0 needs two terms. Result: the reference's fp32 torch.nn.Linear stack to ~1e-6,
+// at 32 MFMAs per 64 points instead of 2 240 VALU FMAs per point.
+// LDS staging: feature rows padded to 40 halfs and hidden rows to 36 floats so that the 16-byte fragment reads of 32 consecutive points
+// fall on distinct bank groups (MI355X guide, LDS section: b128 reads are served in 16-lane groups over 64 banks).
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+#define MR_FROW 40
+#define MR_HROW 36
+
+MR_DEV void split8(const float* __restrict__ x, half8_t& hi, half8_t& lo) {
+#pragma unroll
+    for (int t = 0; t < 8; t++) { _Float16 h = (_Float16)x[t]; hi[t] = h; lo[t] = (_Float16)(x[t] - (float)h); }
+}
+MR_DEV int mfma_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+// Register-resident layer chaining: the product is computed transposed, C[neuron][point] = W[neuron][k] * X^T[k][point], so the accumulator
+// a lane holds after layer l (point = lane & 31, neurons (r&3) + 8(r>>2) + 4(lane>>5)) IS the B-operand fragment of layer l+1 — an MFMA is a
+// dot product over k, so any assignment of k to (lane>>5, slot) is valid as long as the A fragment (weights) uses the same one. Activations
+// never leave registers between layers: ReLU + hi/lo split on the accumulator, no LDS transpose.
+// MODE 0: features given (enc_in fp16 [n,32]) -> out6[n,6];  MODE 1: positions of the compacted pixel list -> scatter kd / (rough, metal)
+template <int MODE>
+__global__ void __launch_bounds__(MR_BLOCK) k_mlp_mfma(MatNetD M, GridLevels L, const uint16_t* __restrict__ enc_in, const float* __restrict__ pos,
+                                                       const int32_t* __restrict__ index, const uint32_t* __restrict__ d_count, int n_fixed,
+                                                       float* __restrict__ out6, float* __restrict__ kd, float* __restrict__ rm, int use_scale,
+                                                       float sx, float sy, float sz) {
+    __shared__ __attribute__((aligned(16))) _Float16 sF[MODE == 1 ? MR_BLOCK * MR_FROW : 8];
+    const int n = d_count ? (int)*d_count : n_fixed;
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int j = lane & 31, half = lane >> 5;
+    // A fragments (weights): lane (neuron j, half) holds W[j][k(kk, half, t)], with k() matching what the B fragment of that layer carries
+    half8_t wh[3][2], wl[3][2];
+#pragma unroll
+    for (int l = 0; l < 3; l++) {
+        const float* W = l == 0 ? M.w0 : (l == 1 ? M.w1 : M.w2);
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++) {
+            float w8[8];
+#pragma unroll
+            for (int t = 0; t < 8; t++) {
+                const int k = (l == 0) ? (kk * 16 + half * 8 + t) : mfma_row(kk * 8 + t, lane);
+                w8[t] = (l == 2 && j >= 6) ? 0.f : W[j * 32 + k];
+            }
+            split8(w8, wh[l][kk], wl[l][kk]);
+        }
+    }
+    for (int base = blockIdx.x * MR_BLOCK; base < n; base += gridDim.x * MR_BLOCK) {
+        int pix = 0;
+        if (MODE == 1) {
+            const int p = base + threadIdx.x;
+            __half enc[32];
+            const bool valid = p < n;
+            if (valid) { pix = index[p]; float x[3]; normalise_pos(M, pos, pix, x); encode_point(L, M.grid, x, enc); }
+            __half* fRow = reinterpret_cast<__half*>(sF) + (size_t)threadIdx.x * MR_FROW;
+#pragma unroll
+            for (int q = 0; q < 32; q++) fRow[q] = valid ? enc[q] : __float2half(0.f);
+            __syncthreads();
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; mt++) {
+            const int prow = wave * 64 + mt * 32 + j;      // the point this lane carries in the B operand / accumulator column
+            const int p = base + prow;
+            // ---- layer 0: B = fp16 features of point p, k = kk*16 + half*8 + t
+            half8_t f[2];
+#pragma unroll
+            for (int kk = 0; kk < 2; kk++) {
+                if (MODE == 0) {
+                    if (p < n) f[kk] = *reinterpret_cast<const half8_t*>(enc_in + 32 * (size_t)p + kk * 16 + half * 8);
+                    else {
+#pragma unroll
+                        for (int t = 0; t < 8; t++) f[kk][t] = (_Float16)0.f;
+                    }
+                } else f[kk] = *reinterpret_cast<const half8_t*>(sF + (size_t)prow * MR_FROW + kk * 16 + half * 8);
+            }
+            f32x16_t acc;
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[r] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 2; kk++) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[0][kk], f[kk], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[0][kk], f[kk], acc, 0, 0, 0);
+            }
+            // ---- layers 1, 2: ReLU + hi/lo split of the accumulator = next B operand
+#pragma unroll
+            for (int l = 1; l < 3; l++) {
+                half8_t xh[2], xl[2];
+#pragma unroll
+                for (int kk = 0; kk < 2; kk++) {
+                    float x8[8];
+#pragma unroll
+                    for (int t = 0; t < 8; t++) x8[t] = fmaxf(acc[kk * 8 + t], 0.f);
+                    split8(x8, xh[kk], xl[kk]);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[r] = 0.f;
+#pragma unroll
+                for (int kk = 0; kk < 2; kk++) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[l][kk], xh[kk], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[l][kk], xh[kk], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[l][kk], xl[kk], acc, 0, 0, 0);
+                }
+            }
+            // ---- epilogue: rows 0..5 are the outputs: lanes 0-31 hold rows 0-3 (regs 0-3), lanes 32-63 rows 4,5 (regs 0,1)
+            if (p < n) {
+                const int nrow = half == 0 ? 4 : 2;
+                float o[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int ch = r + 4 * half;
+                    const int c2 = ch < 6 ? ch : 5;
+                    float sg = 1.0f / (1.0f + expf(-acc[r]));
+                    o[r] = sg * (M.mx[c2] - M.mn[c2]) + M.mn[c2];
+                }
+                if (MODE == 0) {
+                    for (int r = 0; r < nrow; r++) out6[6 * (size_t)p + r + 4 * half] = o[r];
+                } else {
+                    const int px = __shfl(pix, (mt * 32 + j), 64) ;   // pixel id lives in the thread that encoded the point (same wave, lane mt*32+j)
+                    if (half == 0) {
+                        float a0 = o[0], a1 = o[1], a2 = o[2];
+                        if (use_scale) { a0 = fminf(fmaxf(a0 * sx, 0.f), 1.f); a1 = fminf(fmaxf(a1 * sy, 0.f), 1.f); a2 = fminf(fmaxf(a2 * sz, 0.f), 1.f); }
+                        kd[3 * (size_t)px] = a0; kd[3 * (size_t)px + 1] = a1; kd[3 * (size_t)px + 2] = a2;
+                    } else { rm[2 * (size_t)px] = o[0]; rm[2 * (size_t)px + 1] = o[1]; }
+                }
+            } else if (MODE == 1) { (void)__shfl(pix, (mt * 32 + j), 64); }
+        }
+        if (MODE == 1) __syncthreads();
+    }
+}
+
+// compacted list of pixels whose vertex needs a material lookup (occ >= 0.5): replaces torch.where (renderer_restir.py:398)
+__global__ void __launch_bounds__(1024) k_active_list(const float* __restrict__ occ, int n, int32_t* __restrict__ index, uint32_t* __restrict__ count,
+                                                      float* __restrict__ kd, int clamp_all) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool want = i < n && occ[i] >= 0.5f;
+    const uint32_t slot = block_append(count, want);
+    if (want) index[slot] = i;
+    if (clamp_all && i < n) {  // torch.clamp(new_diffuse_map, 0, 1) over the whole map when use_scale (:408); active pixels are clamped by the MLP kernel
+#pragma unroll
+        for (int k = 0; k < 3; k++) kd[3 * (size_t)i + k] = fminf(fmaxf(kd[3 * (size_t)i + k], 0.f), 1.f);
+    }
+}
+
 __global__ void __launch_bounds__(MR_BLOCK) k_pack_grid(const float* __restrict__ in, uint16_t* __restrict__ out, int64_t n) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -157,6 +303,17 @@ static MatNetD matd(const mirres_matnet_t* m) {
     for (int i = 0; i < 3; i++) { M.aabb_min[i] = m->aabb_min[i]; M.aabb_max[i] = m->aabb_max[i]; }
     for (int i = 0; i < 6; i++) { M.mn[i] = m->out_min[i]; M.mx[i] = m->out_max[i]; }
     return M;
+}
+
+int launch_matnet_scatter_mfma(const mirres_matnet_t* m, const float* occ, const float* pos, int n, float* kd, float* rm, int use_scale, const float* scale3,
+                               int32_t* index, uint32_t* count, hipStream_t s) {
+    float sx = scale3 ? scale3[0] : 1.f, sy = scale3 ? scale3[1] : 1.f, sz = scale3 ? scale3[2] : 1.f;
+    MR_HIP(hipMemsetAsync(count, 0, sizeof(uint32_t), s));
+    k_active_list<<<grid_for(n, 1024), 1024, 0, s>>>(occ, n, index, count, kd, use_scale);
+    int g = grid_for(n, MR_BLOCK); if (g > 256 * 8) g = 256 * 8;
+    k_mlp_mfma<1><<<g, MR_BLOCK, 0, s>>>(matd(m), host_levels(nullptr), nullptr, pos, index, count, 0, nullptr, kd, rm, use_scale, sx, sy, sz);
+    MR_LAUNCH_CHECK("matnet_scatter_mfma");
+    return 0;
 }
 
 int launch_matnet_scatter(const mirres_matnet_t* m, const float* occ, const float* pos, int n, float* kd, float* rm, int use_scale, const float* scale3,
@@ -191,6 +348,15 @@ int mirres_matnet_fwd(const mirres_matnet_t* m, const float* pos, int n, float* 
     if (n == 0) return MIRRES_OK;
     k_matnet_fwd<<<grid_for(n, MR_BLOCK), MR_BLOCK, 0, (hipStream_t)stream>>>(matd(m), host_levels(nullptr), pos, n, out, enc_out);
     MR_LAUNCH_CHECK("matnet_fwd");
+    return MIRRES_OK;
+}
+
+int mirres_matnet_mlp(const mirres_matnet_t* m, const uint16_t* enc, int n, float* out, void* stream) {
+    if (!m || !enc || !out || n < 0) { set_error("mirres_matnet_mlp: bad argument"); return MIRRES_E_ARG; }
+    if (n == 0) return MIRRES_OK;
+    int g = grid_for(n, MR_BLOCK); if (g > 256 * 8) g = 256 * 8;
+    k_mlp_mfma<0><<<g, MR_BLOCK, 0, (hipStream_t)stream>>>(matd(m), host_levels(nullptr), enc, nullptr, nullptr, nullptr, n, out, nullptr, nullptr, 0, 1.f, 1.f, 1.f);
+    MR_LAUNCH_CHECK("matnet_mlp");
     return MIRRES_OK;
 }
 

@@ -16,6 +16,8 @@ int launch_bounce(mirres_ctx* ctx, mirres_bvh* bvh, const mirres_env_t* env, con
                   float* dc, float* sc, float* acc_c, float* acc_d, float* acc_s, hipStream_t s);
 int launch_matnet_scatter(const mirres_matnet_t* m, const float* occ, const float* pos, int n, float* kd, float* rm, int use_scale, const float* scale3,
                           const float* const_kd, const float* const_rm, hipStream_t s);
+int launch_matnet_scatter_mfma(const mirres_matnet_t* m, const float* occ, const float* pos, int n, float* kd, float* rm, int use_scale, const float* scale3,
+                               int32_t* index, uint32_t* count, hipStream_t s);
 
 // run_restir_di_with_pt :484-486 + restir_di_with_pt :279-287
 __global__ void __launch_bounds__(MR_BLOCK) k_prep(int N, float* __restrict__ occ, const float* __restrict__ ray_dir_in, const float* __restrict__ normal,
@@ -190,7 +192,10 @@ int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args
         float *cp = B.new_pos, *crd = B.new_rd, *cocc = B.new_occ, *cn = B.new_n;
         float *np_ = B.tmp_pos, *nrd = B.tmp_rd, *nocc = B.tmp_occ, *nn = B.tmp_n;
         for (int b = 1; b <= max_bounce; b++) {
-            rc = launch_matnet_scatter(a->mat, cocc, cp, N, B.new_kd, B.new_rm, a->use_scale, a->scale, a->const_kd, a->const_rm, s); if (rc) return rc;
+            // material lookup at the new vertices: compacted pixel list -> hash-grid gather -> MFMA MLP -> scatter (slot_c is free between passes)
+            if (a->mat) rc = launch_matnet_scatter_mfma(a->mat, cocc, cp, N, B.new_kd, B.new_rm, a->use_scale, a->scale, ctx->slot_c, &ctx->counters[2], s);
+            else rc = launch_matnet_scatter(nullptr, cocc, cp, N, B.new_kd, B.new_rm, a->use_scale, a->scale, a->const_kd, a->const_rm, s);
+            if (rc) return rc;
             mirres_path_t Pb = {cocc, cp, cn, crd, B.new_kd, B.new_rm, B.prd, np_, nrd, nocc, nn};
             rc = launch_bounce(ctx, bvh, &E, &Pb, base + pass, (uint32_t)b, B.c1, B.d1, B.s1, B.tot[3], B.tot[4], B.tot[5], s); if (rc) return rc;
             pass += 5;

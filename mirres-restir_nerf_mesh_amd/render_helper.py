@@ -124,6 +124,30 @@ class MLPTexture3D(torch.nn.Module):
             check(lib().mirres_matnet_fwd(C.byref(st), flat.data_ptr(), n, out.data_ptr(), None, stream_ptr()), "mirres_matnet_fwd")
         return out.view(*texc.shape[:-1], self.channels)
 
+    @torch.no_grad()
+    def mlp_on_encoding(self, enc_fp16):
+        """`self.net.forward(p_enc)` + sigmoid/range (render_helper.py:100-104) on precomputed fp16 encodings [n,32]: the MFMA-tiled kernel."""
+        enc = enc_fp16.contiguous()
+        assert enc.dtype in (torch.float16, torch.int16) and enc.shape[-1] == 32
+        n = enc.shape[0]
+        out = torch.empty((n, 6), dtype=torch.float32, device=enc.device)
+        if n:
+            st = self._struct()
+            check(lib().mirres_matnet_mlp(C.byref(st), enc.data_ptr(), n, out.data_ptr(), stream_ptr()), "mirres_matnet_mlp")
+        return out
+
+    @torch.no_grad()
+    def encode(self, texc):
+        """`self.encoder(_texc)` (render_helper.py:97): fp16 hash-grid features [n,32] of world-space positions."""
+        flat = texc.reshape(-1, 3).contiguous().float()
+        n = flat.shape[0]
+        out = torch.empty((n, 6), dtype=torch.float32, device=flat.device)
+        enc = torch.empty((n, 32), dtype=torch.float16, device=flat.device)
+        if n:
+            st = self._struct()
+            check(lib().mirres_matnet_fwd(C.byref(st), flat.data_ptr(), n, out.data_ptr(), enc.data_ptr(), stream_ptr()), "mirres_matnet_fwd")
+        return enc
+
     def clamp_(self):
         pass
 

@@ -46,3 +46,27 @@ def test_matnet_forward(oracle, scene_mod):
                 acc += wgt[:, None] * tab.reshape(4096, 2)[idx]
     got = ref_enc[100:400, :2].view(np.float16).astype(np.float64)
     np.testing.assert_allclose(got, acc, rtol=0, atol=3e-3 * np.abs(acc).max() + 1e-4)
+
+
+def test_mfma_mlp_matches_fp32_chain(oracle, scene_mod):
+    """The MFMA-tiled MLP (f16 matrix pipe, hi/lo operand split) reproduces the fp32 fmaf-chain MLP (oracle and the per-lane kernel) to ~1e-6."""
+    import torch
+    from mirres_restir_nerf_mesh_amd.render_helper import MLPTexture3D
+    mn, mx = scene_mod.material_min_max(me_max=0.7)
+    mlp = MLPTexture3D(torch.tensor([-1, -1, -1, 1, 1, 1], dtype=torch.float32), channels=6, min_max=(torch.from_numpy(mn).cuda(), torch.from_numpy(mx).cuda()), seed=9)
+    with torch.no_grad():
+        mlp.encoder.params.mul_(3e3)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for n in (1, 63, 64, 257, 5000, 70001):        # ragged tails of the 64-point MFMA tiles / 256-point blocks
+        pts = torch.rand((n, 3), device="cuda", generator=g) * 2 - 1
+        ref = mlp.sample_no_di(pts)                 # per-lane fp32 kernel (itself checked against the oracle above)
+        enc = mlp.encode(pts)
+        got = mlp.mlp_on_encoding(enc)
+        assert got.shape == (n, 6)
+        torch.testing.assert_close(got, ref, rtol=0, atol=3e-6)
+    keep = oracle.Keep()
+    w = [mlp.net.net[i].weight.detach().cpu().numpy() for i in (0, 2, 4)]
+    om = oracle.matnet_struct(keep, mlp.encoder.params.detach().cpu().numpy(), w[0], w[1], w[2], (-1, -1, -1), (1, 1, 1), mn, mx)
+    pts = torch.rand((4096, 3), device="cuda", generator=g) * 2 - 1
+    np.testing.assert_allclose(mlp.mlp_on_encoding(mlp.encode(pts)).cpu().numpy(), oracle.matnet(om, pts.cpu().numpy()), rtol=0, atol=4e-6)
+    assert mlp.mlp_on_encoding(torch.empty((0, 32), dtype=torch.float16, device="cuda")).shape == (0, 6)

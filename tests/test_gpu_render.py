@@ -107,6 +107,6 @@ def test_spp_slices_compose(oracle, scene_mod):
     assert all(float(e.abs().sum()) == 0 for e in empty)
     # statistically equivalent: slice sums add up to the same mean radiance as the single-GPU run (within Monte-Carlo noise)
     tot = (s01[1] + s13[1]) / 3
-    ref = sums[1] / 3
+    ref = sums[1]          # mirres_render_finish averaged the sums in place
     fg = torch.from_numpy(F.occ > 0.5).cuda()
     assert abs(float(tot[fg].mean()) - float(ref[fg].mean())) < 0.15 * float(ref[fg].mean()) + 1e-3
