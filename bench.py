@@ -86,11 +86,17 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if args.gpus > 1 and world == 1:
         raise SystemExit("launch N>1 with torch.distributed.run (one process per GPU)")
+    ndev = torch.cuda.device_count()
+    local = local % max(1, ndev)          # (only differs from LOCAL_RANK when ranks are forced onto fewer GPUs for a dry run with gloo)
     torch.cuda.set_device(local)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        backend = os.environ.get("MIRRES_DIST_BACKEND", "nccl")      # "nccl" is RCCL on ROCm; "gloo" only for single-GPU dry runs of the N>1 path
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     import mirres_restir_nerf_mesh_amd as M
     from mirres_restir_nerf_mesh_amd import renderer_restir as RR, harness, dist as MD
     from mirres_restir_nerf_mesh_amd._ops import get_ctx

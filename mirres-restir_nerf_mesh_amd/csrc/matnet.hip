@@ -171,34 +171,41 @@ MR_DEV int mfma_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 *
 // dot product over k, so any assignment of k to (lane>>5, slot) is valid as long as the A fragment (weights) uses the same one. Activations
 // never leave registers between layers: ReLU + hi/lo split on the accumulator, no LDS transpose.
 // MODE 0: features given (enc_in fp16 [n,32]) -> out6[n,6];  MODE 1: positions of the compacted pixel list -> scatter kd / (rough, metal)
-template <int MODE>
+// NT = 32-point tiles per wave, processed in lock-step so that NT independent accumulator chains keep the matrix pipe busy while the
+// previous MFMA of the same chain drains (a dependent 32x32x16 MFMA cannot issue back-to-back).
+MR_DEV float relu1(float x) { float r; asm volatile("v_max_f32 %0, %1, 0" : "=v"(r) : "v"(x)); return r; }  // plain v_max (hipcc adds a canonicalising max to fmaxf)
+
+template <int MODE, int NT>
 __global__ void __launch_bounds__(MR_BLOCK) k_mlp_mfma(MatNetD M, GridLevels L, const uint16_t* __restrict__ enc_in, const float* __restrict__ pos,
                                                        const int32_t* __restrict__ index, const uint32_t* __restrict__ d_count, int n_fixed,
                                                        float* __restrict__ out6, float* __restrict__ kd, float* __restrict__ rm, int use_scale,
                                                        float sx, float sy, float sz) {
+    constexpr int PTS = (MR_BLOCK / 64) * NT * 32;   // points per block iteration
     __shared__ __attribute__((aligned(16))) _Float16 sF[MODE == 1 ? MR_BLOCK * MR_FROW : 8];
+    __shared__ float sW[2240];
     const int n = d_count ? (int)*d_count : n_fixed;
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     const int j = lane & 31, half = lane >> 5;
+    for (int i = threadIdx.x; i < 2240; i += MR_BLOCK) sW[i] = i < 1024 ? M.w0[i] : (i < 2048 ? M.w1[i - 1024] : M.w2[i - 2048]);   // coalesced
+    __syncthreads();
     // A fragments (weights): lane (neuron j, half) holds W[j][k(kk, half, t)], with k() matching what the B fragment of that layer carries
     half8_t wh[3][2], wl[3][2];
 #pragma unroll
     for (int l = 0; l < 3; l++) {
-        const float* W = l == 0 ? M.w0 : (l == 1 ? M.w1 : M.w2);
 #pragma unroll
         for (int kk = 0; kk < 2; kk++) {
             float w8[8];
 #pragma unroll
             for (int t = 0; t < 8; t++) {
                 const int k = (l == 0) ? (kk * 16 + half * 8 + t) : mfma_row(kk * 8 + t, lane);
-                w8[t] = (l == 2 && j >= 6) ? 0.f : W[j * 32 + k];
+                w8[t] = (l == 2 && j >= 6) ? 0.f : sW[l * 1024 + j * 32 + k];
             }
             split8(w8, wh[l][kk], wl[l][kk]);
         }
     }
-    for (int base = blockIdx.x * MR_BLOCK; base < n; base += gridDim.x * MR_BLOCK) {
+    for (int base = blockIdx.x * PTS; base < n; base += gridDim.x * PTS) {
         int pix = 0;
-        if (MODE == 1) {
+        if (MODE == 1) {   // NT == 2: one point per thread
             const int p = base + threadIdx.x;
             __half enc[32];
             const bool valid = p < n;
@@ -208,72 +215,83 @@ __global__ void __launch_bounds__(MR_BLOCK) k_mlp_mfma(MatNetD M, GridLevels L, 
             for (int q = 0; q < 32; q++) fRow[q] = valid ? enc[q] : __float2half(0.f);
             __syncthreads();
         }
+        int prow[NT], p[NT];
+        f32x16_t acc[NT];
+        half8_t f[NT][2];
 #pragma unroll
-        for (int mt = 0; mt < 2; mt++) {
-            const int prow = wave * 64 + mt * 32 + j;      // the point this lane carries in the B operand / accumulator column
-            const int p = base + prow;
-            // ---- layer 0: B = fp16 features of point p, k = kk*16 + half*8 + t
-            half8_t f[2];
+        for (int mt = 0; mt < NT; mt++) {
+            prow[mt] = wave * NT * 32 + mt * 32 + j;       // the point this lane carries in the B operand / accumulator column
+            p[mt] = base + prow[mt];
 #pragma unroll
             for (int kk = 0; kk < 2; kk++) {
                 if (MODE == 0) {
-                    if (p < n) f[kk] = *reinterpret_cast<const half8_t*>(enc_in + 32 * (size_t)p + kk * 16 + half * 8);
+                    if (p[mt] < n) f[mt][kk] = *reinterpret_cast<const half8_t*>(enc_in + 32 * (size_t)p[mt] + kk * 16 + half * 8);
                     else {
 #pragma unroll
-                        for (int t = 0; t < 8; t++) f[kk][t] = (_Float16)0.f;
+                        for (int t = 0; t < 8; t++) f[mt][kk][t] = (_Float16)0.f;
                     }
-                } else f[kk] = *reinterpret_cast<const half8_t*>(sF + (size_t)prow * MR_FROW + kk * 16 + half * 8);
+                } else f[mt][kk] = *reinterpret_cast<const half8_t*>(sF + (size_t)prow[mt] * MR_FROW + kk * 16 + half * 8);
             }
-            f32x16_t acc;
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc[r] = 0.f;
+            for (int r = 0; r < 16; r++) acc[mt][r] = 0.f;
+        }
+        // ---- layer 0: B = fp16 features (exact), two weight terms
 #pragma unroll
-            for (int kk = 0; kk < 2; kk++) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[0][kk], f[kk], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[0][kk], f[kk], acc, 0, 0, 0);
-            }
-            // ---- layers 1, 2: ReLU + hi/lo split of the accumulator = next B operand
+        for (int kk = 0; kk < 2; kk++) {
 #pragma unroll
-            for (int l = 1; l < 3; l++) {
-                half8_t xh[2], xl[2];
+            for (int mt = 0; mt < NT; mt++) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[0][kk], f[mt][kk], acc[mt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < NT; mt++) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[0][kk], f[mt][kk], acc[mt], 0, 0, 0);
+        }
+        // ---- layers 1, 2: ReLU + hi/lo split of the accumulator = next B operand
+#pragma unroll
+        for (int l = 1; l < 3; l++) {
+            half8_t xh[NT][2], xl[NT][2];
+#pragma unroll
+            for (int mt = 0; mt < NT; mt++) {
 #pragma unroll
                 for (int kk = 0; kk < 2; kk++) {
                     float x8[8];
 #pragma unroll
-                    for (int t = 0; t < 8; t++) x8[t] = fmaxf(acc[kk * 8 + t], 0.f);
-                    split8(x8, xh[kk], xl[kk]);
+                    for (int t = 0; t < 8; t++) x8[t] = relu1(acc[mt][kk * 8 + t]);
+                    split8(x8, xh[mt][kk], xl[mt][kk]);
                 }
 #pragma unroll
-                for (int r = 0; r < 16; r++) acc[r] = 0.f;
-#pragma unroll
-                for (int kk = 0; kk < 2; kk++) {
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[l][kk], xh[kk], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[l][kk], xh[kk], acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[l][kk], xl[kk], acc, 0, 0, 0);
-                }
+                for (int r = 0; r < 16; r++) acc[mt][r] = 0.f;
             }
-            // ---- epilogue: rows 0..5 are the outputs: lanes 0-31 hold rows 0-3 (regs 0-3), lanes 32-63 rows 4,5 (regs 0,1)
-            if (p < n) {
+#pragma unroll
+            for (int kk = 0; kk < 2; kk++) {
+#pragma unroll
+                for (int mt = 0; mt < NT; mt++) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[l][kk], xh[mt][kk], acc[mt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < NT; mt++) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[l][kk], xh[mt][kk], acc[mt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < NT; mt++) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[l][kk], xl[mt][kk], acc[mt], 0, 0, 0);
+            }
+        }
+        // ---- epilogue: rows 0..5 are the outputs: lanes 0-31 hold rows 0-3 (regs 0-3), lanes 32-63 rows 4,5 (regs 0,1)
+#pragma unroll
+        for (int mt = 0; mt < NT; mt++) {
+            int px = 0;
+            if (MODE == 1) px = __shfl(pix, mt * 32 + j, 64);   // pixel id lives in the thread that encoded the point (same wave, lane mt*32+j)
+            if (p[mt] < n) {
                 const int nrow = half == 0 ? 4 : 2;
                 float o[4];
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const int ch = r + 4 * half;
                     const int c2 = ch < 6 ? ch : 5;
-                    float sg = 1.0f / (1.0f + expf(-acc[r]));
+                    float sg = 1.0f / (1.0f + expf(-acc[mt][r]));
                     o[r] = sg * (M.mx[c2] - M.mn[c2]) + M.mn[c2];
                 }
                 if (MODE == 0) {
-                    for (int r = 0; r < nrow; r++) out6[6 * (size_t)p + r + 4 * half] = o[r];
-                } else {
-                    const int px = __shfl(pix, (mt * 32 + j), 64) ;   // pixel id lives in the thread that encoded the point (same wave, lane mt*32+j)
-                    if (half == 0) {
-                        float a0 = o[0], a1 = o[1], a2 = o[2];
-                        if (use_scale) { a0 = fminf(fmaxf(a0 * sx, 0.f), 1.f); a1 = fminf(fmaxf(a1 * sy, 0.f), 1.f); a2 = fminf(fmaxf(a2 * sz, 0.f), 1.f); }
-                        kd[3 * (size_t)px] = a0; kd[3 * (size_t)px + 1] = a1; kd[3 * (size_t)px + 2] = a2;
-                    } else { rm[2 * (size_t)px] = o[0]; rm[2 * (size_t)px + 1] = o[1]; }
-                }
-            } else if (MODE == 1) { (void)__shfl(pix, (mt * 32 + j), 64); }
+                    for (int r = 0; r < nrow; r++) out6[6 * (size_t)p[mt] + r + 4 * half] = o[r];
+                } else if (half == 0) {
+                    float a0 = o[0], a1 = o[1], a2 = o[2];
+                    if (use_scale) { a0 = fminf(fmaxf(a0 * sx, 0.f), 1.f); a1 = fminf(fmaxf(a1 * sy, 0.f), 1.f); a2 = fminf(fmaxf(a2 * sz, 0.f), 1.f); }
+                    kd[3 * (size_t)px] = a0; kd[3 * (size_t)px + 1] = a1; kd[3 * (size_t)px + 2] = a2;
+                } else { rm[2 * (size_t)px] = o[0]; rm[2 * (size_t)px + 1] = o[1]; }
+            }
         }
         if (MODE == 1) __syncthreads();
     }
@@ -311,7 +329,7 @@ int launch_matnet_scatter_mfma(const mirres_matnet_t* m, const float* occ, const
     MR_HIP(hipMemsetAsync(count, 0, sizeof(uint32_t), s));
     k_active_list<<<grid_for(n, 1024), 1024, 0, s>>>(occ, n, index, count, kd, use_scale);
     int g = grid_for(n, MR_BLOCK); if (g > 256 * 8) g = 256 * 8;
-    k_mlp_mfma<1><<<g, MR_BLOCK, 0, s>>>(matd(m), host_levels(nullptr), nullptr, pos, index, count, 0, nullptr, kd, rm, use_scale, sx, sy, sz);
+    k_mlp_mfma<1, 2><<<g, MR_BLOCK, 0, s>>>(matd(m), host_levels(nullptr), nullptr, pos, index, count, 0, nullptr, kd, rm, use_scale, sx, sy, sz);
     MR_LAUNCH_CHECK("matnet_scatter_mfma");
     return 0;
 }
@@ -354,8 +372,8 @@ int mirres_matnet_fwd(const mirres_matnet_t* m, const float* pos, int n, float* 
 int mirres_matnet_mlp(const mirres_matnet_t* m, const uint16_t* enc, int n, float* out, void* stream) {
     if (!m || !enc || !out || n < 0) { set_error("mirres_matnet_mlp: bad argument"); return MIRRES_E_ARG; }
     if (n == 0) return MIRRES_OK;
-    int g = grid_for(n, MR_BLOCK); if (g > 256 * 8) g = 256 * 8;
-    k_mlp_mfma<0><<<g, MR_BLOCK, 0, (hipStream_t)stream>>>(matd(m), host_levels(nullptr), enc, nullptr, nullptr, nullptr, n, out, nullptr, nullptr, 0, 1.f, 1.f, 1.f);
+    int g = grid_for(n, 256); if (g > 256 * 8) g = 256 * 8;      // 2 tiles (64 points) per wave
+    k_mlp_mfma<0, 2><<<g, MR_BLOCK, 0, (hipStream_t)stream>>>(matd(m), host_levels(nullptr), enc, nullptr, nullptr, nullptr, n, out, nullptr, nullptr, 0, 1.f, 1.f, 1.f);
     MR_LAUNCH_CHECK("matnet_mlp");
     return MIRRES_OK;
 }

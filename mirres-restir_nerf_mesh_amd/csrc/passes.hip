@@ -17,6 +17,16 @@ int trace_any_queue_counted(const mirres_bvh* bvh, const Ray* rays, const uint32
 #define MR_BLOCK 256
 #define MR_GEN_BLOCK 1024   // ray-generating kernels: one queue atomic per 1024 pixels
 
+// 2-D tile -> pixel mapping for the kernels that gather from neighbouring pixels (spatial pass: +-30 px): a square tile of threads touches a
+// (T+60)^2 window instead of the (blockDim+60) x 61 strip a row-major block touches, which is what the L1/L2 hit rate of the gathers follows.
+MR_DEV int tile_pixel(int fx, int fy, int tw, int N) {
+    const int tiles_x = (fx + tw - 1) / tw;
+    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const int x = tx * tw + (int)(threadIdx.x % tw), y = ty * tw + (int)(threadIdx.x / tw);
+    return (x < fx && y < fy) ? y * fx + x : N;   // N = "no pixel"
+}
+static int tile_grid(int fx, int fy, int tw) { return ((fx + tw - 1) / tw) * ((fy + tw - 1) / tw); }
+
 struct GBufD { const float *occ, *pos, *normal_depth, *brdf, *ray_dir; };
 struct ResD { float* light_data; float* light_pdf; int32_t* M; float* weight; };
 struct ResV { v3 light_data; float light_pdf; int M; float weight; };
@@ -269,7 +279,7 @@ MR_DEV int spatial_neighbor(const mirres_config_t& C, const GBufD& G, const ResD
 __global__ void __launch_bounds__(MR_GEN_BLOCK) k_spatial_gen(mirres_config_t C, GBufD G, ResD PR, const float* __restrict__ noff, uint32_t frameIndex,
                                                           int fx, int fy, int N, Ray* __restrict__ q, uint32_t* __restrict__ q_count,
                                                           int32_t* __restrict__ slot_out, uint32_t* __restrict__ mask_out) {
-    const int pi = blockIdx.x * blockDim.x + threadIdx.x;
+    const int pi = tile_pixel(fx, fy, 32, N);
     uint32_t mask = 0, cnt = 0;
     int nb[8];
     v3 cpos = V3(0.f), cdir = V3(0.f);
@@ -306,7 +316,7 @@ __global__ void __launch_bounds__(MR_GEN_BLOCK) k_spatial_gen(mirres_config_t C,
 __global__ void __launch_bounds__(MR_BLOCK) k_spatial_resolve(mirres_config_t C, EnvD E, GBufD G, ResD R, ResD PR, const float* __restrict__ noff,
                                                               uint32_t frameIndex, int fx, int fy, int N, const int32_t* __restrict__ slot,
                                                               const uint32_t* __restrict__ mask_in, const int32_t* __restrict__ hit) {
-    const int pi = blockIdx.x * blockDim.x + threadIdx.x;
+    const int pi = tile_pixel(fx, fy, 16, N);
     if (pi >= N) return;
     if (G.occ[pi] < 0.1f) { store_zero(R, pi); return; }
     const int x = pi % fx, y = pi / fx;
@@ -566,10 +576,10 @@ int mirres_restir_spatial(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_env
     hipStream_t s = (hipStream_t)stream; const int N = (int)ctx->N; const int grd = grid_for(N, MR_BLOCK);
     const float* noff = neighbor_offsets ? neighbor_offsets : ctx->noff;
     MR_HIP(hipMemsetAsync(&ctx->counters[0], 0, sizeof(uint32_t), s));
-    k_spatial_gen<<<grid_for(N, MR_GEN_BLOCK), MR_GEN_BLOCK, 0, s>>>(ctx->cfg, gbufd(g), resd(prev_res), noff, frameIndex, ctx->fx, ctx->fy, N, ctx->any_rays, &ctx->counters[0],
+    k_spatial_gen<<<tile_grid(ctx->fx, ctx->fy, 32), MR_GEN_BLOCK, 0, s>>>(ctx->cfg, gbufd(g), resd(prev_res), noff, frameIndex, ctx->fx, ctx->fy, N, ctx->any_rays, &ctx->counters[0],
                                             ctx->slot_a, ctx->mask_a);
     int rc = trace_any(ctx, bvh, ctx->any_cap, s); if (rc) return rc;
-    k_spatial_resolve<<<grd, MR_BLOCK, 0, s>>>(ctx->cfg, envh(env), gbufd(g), resd(res), resd(prev_res), noff, frameIndex, ctx->fx, ctx->fy, N, ctx->slot_a,
+    k_spatial_resolve<<<tile_grid(ctx->fx, ctx->fy, 16), MR_BLOCK, 0, s>>>(ctx->cfg, envh(env), gbufd(g), resd(res), resd(prev_res), noff, frameIndex, ctx->fx, ctx->fy, N, ctx->slot_a,
                                                 ctx->mask_a, ctx->any_hit);
     MR_LAUNCH_CHECK("restir_spatial");
     return MIRRES_OK;

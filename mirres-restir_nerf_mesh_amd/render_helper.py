@@ -104,8 +104,10 @@ class MLPTexture3D(torch.nn.Module):
         self._keep = [self.encoder.packed()] + [self.net.net[i].weight.detach().contiguous() for i in (0, 2, 4)]
         st.grid_f16 = self._keep[0].data_ptr()
         st.w0, st.w1, st.w2 = (t.data_ptr() for t in self._keep[1:])
-        lo, hi = self.AABB[0].detach().cpu().tolist(), self.AABB[1].detach().cpu().tolist()
-        mn = self.min_max[0].detach().cpu().tolist(); mx = self.min_max[1].detach().cpu().tolist()
+        if getattr(self, "_host_consts", None) is None:   # constants of the module: read back once (a .cpu() per call would sync the stream)
+            self._host_consts = (self.AABB[0].detach().cpu().tolist(), self.AABB[1].detach().cpu().tolist(),
+                                 self.min_max[0].detach().cpu().tolist(), self.min_max[1].detach().cpu().tolist())
+        lo, hi, mn, mx = self._host_consts
         st.aabb_min[:] = lo; st.aabb_max[:] = hi; st.out_min[:] = mn; st.out_max[:] = mx
         return st
 

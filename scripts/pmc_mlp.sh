@@ -1,6 +1,10 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 python3 scripts/dev_mlp_bench.py 2>&1 | tail -2
+rm -rf gpurun_out/pk; mkdir -p gpurun_out/pk
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pk -o k -- python3 scripts/dev_mlp_bench.py > gpurun_out/pk/log 2>&1
+grep -E 'k_mlp_mfma|k_matnet_fwd' gpurun_out/pk/k_kernel_stats.csv | cut -c1-60,200-330
+rm -rf gpurun_out/pk
 rm -rf gpurun_out/pm; mkdir -p gpurun_out/pm
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE SQ_INSTS_MFMA --output-format csv -d gpurun_out/pm -o p -- python3 scripts/dev_mlp_bench.py > gpurun_out/pm/log 2>&1
 python3 - <<'PY'
