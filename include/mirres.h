@@ -55,6 +55,8 @@ int mirres_bvh_build(mirres_bvh_t* bvh, const float* vert, int V, const int32_t*
 /* bvh_hit / bvh_hit_with_normal (utils/helperDi.slang:197-274, 313-395) over a batch of rays.
  * rays f32[n,8] = (ox,oy,oz,t_min, dx,dy,dz,t_max). mode 0: any-hit (early exit; only `hit` is written),
  * mode 1: closest by exhaustion in the reference's traversal order (hit,t,pos,normal,prim written; NULL skips).
+ * mode 2: closest, same outputs bit for bit, via the front-to-back 4-wide fast path + reference-order recomputation of the rays whose
+ *         result could depend on the visiting order (t <= 0 hits, exact ties); may grow an internal n-entry buffer on first use.
  * counters u32[n,4] (popped, entered-internal, leaves-tested, stack-overflow) may be NULL.                   */
 int mirres_bvh_trace(mirres_bvh_t* bvh, const float* rays, int n, int mode, int32_t* hit, float* t, float* pos, float* normal,
                      int32_t* prim, uint32_t* counters, void* stream);

@@ -280,7 +280,7 @@ int mirres_bvh_create(mirres_bvh_t** out, int max_tris) {
     MR_HIP(hipMalloc(&b->tris, sizeof(TriRec) * T));
     MR_HIP(hipMalloc(&b->nodes4, sizeof(Node4) * T));
     MR_HIP(hipMalloc(&b->root_box, sizeof(float) * 8));
-    MR_HIP(hipMalloc(&b->work, sizeof(uint32_t) * 4));
+    MR_HIP(hipMalloc(&b->work, sizeof(uint32_t) * 8));
     size_t tmp = 0;
     MR_HIP(rocprim::radix_sort_pairs(nullptr, tmp, b->keys_in, b->keys_out, b->vals_in, b->vals_out, T, 0, 32, 0));
     b->sort_tmp_bytes = tmp;
@@ -292,7 +292,7 @@ int mirres_bvh_create(mirres_bvh_t** out, int max_tris) {
 void mirres_bvh_destroy(mirres_bvh_t* b) {
     if (!b) return;
     void* ptrs[] = {b->ele_aabb, b->extent, b->keys_in, b->keys_out, b->vals_in, b->vals_out, b->parent, b->flags, b->own_info,
-                    b->own_aabb, b->nodes, b->tris, b->root_box, b->sort_tmp, b->work, b->nodes4};
+                    b->own_aabb, b->nodes, b->tris, b->root_box, b->sort_tmp, b->work, b->nodes4, b->redo};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete b;
 }

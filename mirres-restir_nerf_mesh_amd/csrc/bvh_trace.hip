@@ -220,7 +220,7 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_persist(BvhView B, con
                                                                   uint32_t n_fixed, uint32_t* __restrict__ work_head, int32_t* __restrict__ hit_out,
                                                                   HitRec* __restrict__ rec, float* __restrict__ t_out, float* __restrict__ pos_out,
                                                                   float* __restrict__ nrm_out, int32_t* __restrict__ prim_out,
-                                                                  unsigned long long* __restrict__ stats) {
+                                                                  unsigned long long* __restrict__ stats, const uint32_t* __restrict__ redo = nullptr) {
     __shared__ uint2 lds[MR_LDS_STACK * MR_TRACE_BLOCK];
     uint2* const lds_stack = lds + threadIdx.x;
     const uint32_t n = d_count ? *d_count : n_fixed;
@@ -252,8 +252,9 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_persist(BvhView B, con
             if (!exhausted) {
                 const uint32_t idx = chunk_next + (uint32_t)__popcll(need & lt_mask);
                 if (!have && idx < chunk_end) {
-                    const float4 a = reinterpret_cast<const float4*>(rays + idx)[0], b = reinterpret_cast<const float4*>(rays + idx)[1];
-                    ridx = idx; ro = V3(a.x, a.y, a.z); t_min = a.w; closest = b.w;
+                    const uint32_t rid = redo ? redo[idx] : idx;   // redo: the few rays the ordered fast path hands back (see k_trace_closest4)
+                    const float4 a = reinterpret_cast<const float4*>(rays + rid)[0], b = reinterpret_cast<const float4*>(rays + rid)[1];
+                    ridx = rid; ro = V3(a.x, a.y, a.z); t_min = a.w; closest = b.w;
                     d = normalize(V3(b.x, b.y, b.z));
                     o[0] = ro.x; o[1] = ro.y; o[2] = ro.z;
                     { float dd[3] = {d.x, d.y, d.z};
@@ -577,6 +578,213 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4(BvhView B, const 
     if (stats && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[0], (unsigned long long)n);
 }
 
+
+// ---------------------------------------------------------------- closest hit: ordered 4-wide fast path + exact fallback
+// The reference's closest-hit result depends on its (unordered, right-first) visiting order only in two situations:
+//   (a) a triangle is accepted with t <= 0 (triangle_hit ignores the t interval, helperDi.slang:172-195): `closest` drops to <= t_min and the
+//       rest of the search is culled, so WHICH behind-the-origin triangle is found first matters;
+//   (b) two different triangles are accepted with exactly the same t (the later one in visiting order provides prim / normal).
+// Otherwise every traversal that culls with `closest > tn` finds the same minimum: the minimum triangle's boxes all contain its hit point,
+// so their entry distance tn <= t_min_hit <= closest and they are never culled (DESIGN.md §Traversal exactness). This kernel therefore walks
+// the 4-wide collapse front to back (far more culling than the reference order), watches for (a) and (b), and appends the few affected rays
+// to a redo list that k_trace_persist<false> (reference order) then recomputes. The final output is bit-identical to the reference order.
+template <bool COUNT>
+__global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_closest4(BvhView B, const Ray* __restrict__ rays, const uint32_t* __restrict__ d_count,
+                                                                   uint32_t n_fixed, uint32_t* __restrict__ work_head, HitRec* __restrict__ rec,
+                                                                   int32_t* __restrict__ hit_out, float* __restrict__ t_out, float* __restrict__ pos_out,
+                                                                   float* __restrict__ nrm_out, int32_t* __restrict__ prim_out,
+                                                                   uint32_t* __restrict__ redo, uint32_t* __restrict__ redo_count,
+                                                                   unsigned long long* __restrict__ stats) {
+    __shared__ uint2 lds[MR_LDS_STACK * MR_TRACE_BLOCK];
+    uint2* const lds_stack = lds + threadIdx.x;
+    const uint32_t n = d_count ? *d_count : n_fixed;
+    const int lane = lane_id();
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    uint32_t chunk = n / (gridDim.x * (MR_TRACE_BLOCK / 64) * 4);
+    chunk = chunk < 64 ? 64 : (chunk > MR_CHUNK_MAX ? MR_CHUNK_MAX : (chunk & ~63u));
+    uint32_t chunk_next = 0, chunk_end = 0;
+    bool exhausted = false, have = false;
+    float ox = 0, oy = 0, oz = 0, ix = 0, iy = 0, iz = 0; v3 d = V3(0.f), ro = V3(0.f);
+    float t_min = 0.f, closest = 0.f, best_u = 0.f, best_v = 0.f;
+    int cur = -1, sp = 0, best_slot = -1; uint32_t ridx = 0; bool any_hit = false, need_redo = false;
+    uint2 spill[MR_STACK - MR_LDS_STACK];
+    unsigned long long c_boxes = 0, c_nodes = 0, c_leaves = 0;
+    while (true) {
+        const uint64_t need = __ballot(!have);
+        if (need && !exhausted) {
+            if (chunk_next >= chunk_end) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(work_head, chunk);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (base >= n) exhausted = true;
+                else { chunk_next = base; chunk_end = (base + chunk < n) ? base + chunk : n; }
+            }
+            if (!exhausted) {
+                const uint32_t idx = chunk_next + (uint32_t)__popcll(need & lt_mask);
+                if (!have && idx < chunk_end) {
+                    const float4 a = reinterpret_cast<const float4*>(rays + idx)[0], b = reinterpret_cast<const float4*>(rays + idx)[1];
+                    ridx = idx; ro = V3(a.x, a.y, a.z); t_min = a.w; closest = b.w;
+                    d = normalize(V3(b.x, b.y, b.z));
+                    ox = ro.x; oy = ro.y; oz = ro.z;
+                    { float dx = d.x, dy = d.y, dz = d.z;
+                      if (dx == 0.f) dx = 0.000001f; if (dy == 0.f) dy = 0.000001f; if (dz == 0.f) dz = 0.000001f;
+                      ix = 1.0f / dx; iy = 1.0f / dy; iz = 1.0f / dz; }
+                    sp = 0; any_hit = false; need_redo = false; best_u = 0.f; best_v = 0.f; best_slot = -1;
+                    const float o3[3] = {ox, oy, oz}, i3[3] = {ix, iy, iz};
+                    Slab s0 = slab(B.root_box, B.root_box + 3, o3, i3, t_min);
+                    if (COUNT) c_boxes++;
+                    cur = (s0.tf > s0.tn && closest > s0.tn) ? 0 : -1;
+                    have = true;
+                }
+                const uint32_t want = (uint32_t)__popcll(need);
+                chunk_next = (chunk_next + want < chunk_end) ? chunk_next + want : chunk_end;
+            }
+        }
+        if (!__ballot(have)) { if (exhausted) break; else continue; }
+        do {
+            if (have) {
+                bool done = false;
+                if (cur < 0) {   // pop the nearest deferred node that still beats `closest`
+                    bool found = false;
+                    while (sp > 0) {
+                        --sp;
+                        uint2 e = (sp < MR_LDS_STACK) ? lds_stack[sp * MR_TRACE_BLOCK] : spill[sp - MR_LDS_STACK];
+                        if (closest > __uint_as_float(e.y)) { cur = (int)e.x; found = true; break; }
+                    }
+                    if (!found) done = true;
+                }
+                if (!done) {
+                    const Node4* __restrict__ nd = B.nodes4 + cur;
+                    const float4 mnx = reinterpret_cast<const float4*>(nd)[0], mny = reinterpret_cast<const float4*>(nd)[1], mnz = reinterpret_cast<const float4*>(nd)[2];
+                    const float4 mxx = reinterpret_cast<const float4*>(nd)[3], mxy = reinterpret_cast<const float4*>(nd)[4], mxz = reinterpret_cast<const float4*>(nd)[5];
+                    const int4 rf = reinterpret_cast<const int4*>(nd)[6];
+                    const float bmnx[4] = {mnx.x, mnx.y, mnx.z, mnx.w}, bmny[4] = {mny.x, mny.y, mny.z, mny.w}, bmnz[4] = {mnz.x, mnz.y, mnz.z, mnz.w};
+                    const float bmxx[4] = {mxx.x, mxx.y, mxx.z, mxx.w}, bmxy[4] = {mxy.x, mxy.y, mxy.z, mxy.w}, bmxz[4] = {mxz.x, mxz.y, mxz.z, mxz.w};
+                    const int ref[4] = {rf.x, rf.y, rf.z, rf.w};
+                    if (COUNT) c_nodes++;
+                    float ctn[4]; bool cok[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const float ax = (bmnx[k] - ox) * ix, bx = (bmxx[k] - ox) * ix;
+                        const float ay = (bmny[k] - oy) * iy, by = (bmxy[k] - oy) * iy;
+                        const float az = (bmnz[k] - oz) * iz, bz = (bmxz[k] - oz) * iz;
+                        ctn[k] = fmaxf(fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz)), t_min);
+                        const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+                        cok[k] = ref[k] != 0x7fffffff && tf > ctn[k];
+                        if (COUNT && ref[k] != 0x7fffffff) c_boxes++;
+                    }
+                    // leaves first (they can only shrink `closest`), then internal children front to back
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        if (cok[k] && ref[k] < 0 && closest > ctn[k]) {
+                            if (COUNT) c_leaves++;
+                            const int slot = ~ref[k];
+                            const TriRec* __restrict__ tr = B.tris + slot;
+                            const float4 a = reinterpret_cast<const float4*>(tr)[0];
+                            const float4 b = reinterpret_cast<const float4*>(tr)[1];
+                            const float4 c = reinterpret_cast<const float4*>(tr)[2];
+                            const v3 v0 = V3(a.x, a.y, a.z), E1 = V3(a.w, b.x, b.y), E2 = V3(b.z, b.w, c.x);
+                            const v3 P = cross(d, E2);
+                            const float det = dot(E1, P);
+                            if (!(det > -1e-15f && det < 1e-15f)) {
+                                const float invDet = 1 / det;
+                                const v3 Tv = ro - v0;
+                                const float u = dot(Tv, P) * invDet;
+                                if (!(u < 0 || u > 1)) {
+                                    const v3 Q = cross(Tv, E1);
+                                    const float v = dot(d, Q) * invDet;
+                                    if (!(v < 0 || u + v > 1)) {
+                                        const float t = dot(E2, Q) * invDet;
+                                        any_hit = true;
+                                        if (!(t > 0.f)) need_redo = true;                                               // case (a) (also NaN)
+                                        if (t <= closest) {
+                                            if (t == closest && best_slot >= 0 && best_slot != slot) need_redo = true;    // case (b)
+                                            closest = t; best_u = u; best_v = v; best_slot = slot;
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                    }
+                    // internal children that still beat `closest`: nearest becomes `cur`, the others are pushed far -> near
+                    int nref[4]; float ntn[4]; int nn = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        if (cok[k] && ref[k] >= 0 && closest > ctn[k]) {
+                            int r = ref[k]; float tn = ctn[k];
+                            // insertion into descending-tn order (n <= 4)
+#pragma unroll
+                            for (int q = 0; q < 4; q++) {
+                                if (q < nn && ntn[q] < tn) { const int tr_ = nref[q]; const float tt_ = ntn[q]; nref[q] = r; ntn[q] = tn; r = tr_; tn = tt_; }
+                            }
+                            nref[nn] = r; ntn[nn] = tn; nn++;
+                        }
+                    }
+                    cur = -1;
+                    if (nn > 0) {
+                        cur = nref[nn - 1];
+#pragma unroll
+                        for (int q = 0; q < 3; q++) {
+                            if (q < nn - 1) {
+                                uint2 e; e.x = (uint32_t)nref[q]; e.y = __float_as_uint(ntn[q]);
+                                if (sp < MR_LDS_STACK) lds_stack[sp * MR_TRACE_BLOCK] = e;
+                                else if (sp < MR_STACK) spill[sp - MR_LDS_STACK] = e;
+                                if (sp < MR_STACK) sp++; else need_redo = true;
+                            }
+                        }
+                    }
+                }
+                if (done) {
+                    have = false;
+                    if (need_redo) redo[atomicAdd(redo_count, 1u)] = ridx;
+                    TraceOut r; r.hit = any_hit; r.t = any_hit ? closest : 0.f; r.u = best_u; r.v = best_v; r.slot = best_slot; r.d = d;
+                    v3 p, nn_; int pr;
+                    finish_closest(B, r, ro, p, nn_, pr);
+                    if (rec) {
+                        float4 o0, o1;
+                        o0.x = p.x; o0.y = p.y; o0.z = p.z; o0.w = __int_as_float(any_hit ? 1 : 0);
+                        o1.x = nn_.x; o1.y = nn_.y; o1.z = nn_.z; o1.w = r.t;
+                        reinterpret_cast<float4*>(rec + ridx)[0] = o0; reinterpret_cast<float4*>(rec + ridx)[1] = o1;
+                    }
+                    if (hit_out) hit_out[ridx] = any_hit ? 1 : 0;
+                    if (t_out) t_out[ridx] = r.t;
+                    if (pos_out) st3(pos_out, ridx, p);
+                    if (nrm_out) st3(nrm_out, ridx, nn_);
+                    if (prim_out) prim_out[ridx] = pr;
+                }
+            }
+        } while (__popcll(__ballot(have)) >= MR_REFILL || (exhausted && __ballot(have)));
+    }
+    if (COUNT && stats) { atomicAdd(&stats[5], c_boxes); atomicAdd(&stats[6], c_nodes); atomicAdd(&stats[7], c_leaves); }
+    if (stats && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[1], (unsigned long long)n);
+}
+
+static int persist_grid(size_t capacity);
+static int ensure_redo(mirres_bvh* bvh, size_t capacity) {
+    if (bvh->redo_cap >= capacity) return 0;
+    if (bvh->redo) { MR_HIP(hipDeviceSynchronize()); MR_HIP(hipFree(bvh->redo)); bvh->redo = nullptr; }
+    MR_HIP(hipMalloc(&bvh->redo, sizeof(uint32_t) * capacity));
+    bvh->redo_cap = capacity;
+    return 0;
+}
+// ordered fast path + reference-order recomputation of the handed-back rays (see k_trace_closest4)
+template <bool COUNT>
+static int closest_fast(mirres_bvh* bvh, const Ray* rays, const uint32_t* d_count, size_t capacity, HitRec* rec, int32_t* hit, float* t, float* pos,
+                        float* nrm, int32_t* prim, unsigned long long* stats, hipStream_t s) {
+    int rc = ensure_redo(bvh, capacity); if (rc) return rc;
+    MR_HIP(hipMemsetAsync(bvh->work + 4, 0, 3 * sizeof(uint32_t), s));   // [4] fast head, [5] redo count, [6] redo head
+    k_trace_closest4<COUNT><<<persist_grid(capacity), MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, d_count, (uint32_t)capacity, bvh->work + 4, rec, hit, t, pos, nrm, prim,
+                                                                               bvh->redo, bvh->work + 5, stats);
+    k_trace_persist<false><<<256, MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, bvh->work + 5, 0u, bvh->work + 6, hit, rec, t, pos, nrm, prim, nullptr, bvh->redo);
+    MR_LAUNCH_CHECK("closest_fast");
+    return 0;
+}
+
+static int closest_mode() {   // MIRRES_CLOSEST=4: ordered 4-wide fast path + redo in the frame loop (pays off only when most rays hit)
+    static int m = -1;
+    if (m < 0) { const char* e = getenv("MIRRES_CLOSEST"); m = (e && e[0] == '4') ? 4 : 2; }
+    return m;
+}
 static int any_mode() {   // MIRRES_ANY=2 selects the binary-tree shadow kernel (A/B experiments); default: 4-wide
     static int m = -1;
     if (m < 0) { const char* e = getenv("MIRRES_ANY"); m = (e && e[0] == '2') ? 2 : 4; }
@@ -607,6 +815,7 @@ int trace_any_queue(const mirres_bvh* bvh, const Ray* rays, const uint32_t* d_co
 }
 int trace_closest_queue(const mirres_bvh* bvh, const Ray* rays, const uint32_t* d_count, size_t capacity, HitRec* out,
                         unsigned long long* stats, hipStream_t s) {
+    if (closest_mode() == 4) return closest_fast<false>(const_cast<mirres_bvh*>(bvh), rays, d_count, capacity, out, nullptr, nullptr, nullptr, nullptr, nullptr, stats, s);
     MR_HIP(hipMemsetAsync(bvh->work + 1, 0, sizeof(uint32_t), s));
     k_trace_persist<false><<<persist_grid(capacity), MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, d_count, (uint32_t)capacity, bvh->work + 1, nullptr, out,
                                                                              nullptr, nullptr, nullptr, nullptr, stats);
@@ -623,6 +832,7 @@ int trace_any_queue_counted(const mirres_bvh* bvh, const Ray* rays, const uint32
 }
 int trace_closest_queue_counted(const mirres_bvh* bvh, const Ray* rays, const uint32_t* d_count, size_t capacity, HitRec* out,
                                 unsigned long long* stats, hipStream_t s) {
+    if (closest_mode() == 4) return closest_fast<true>(const_cast<mirres_bvh*>(bvh), rays, d_count, capacity, out, nullptr, nullptr, nullptr, nullptr, nullptr, stats, s);
     k_trace_closest<true><<<trace_grid(capacity), MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, d_count, (uint32_t)capacity, out, nullptr, nullptr,
                                                                            nullptr, nullptr, nullptr, nullptr, stats);
     MR_LAUNCH_CHECK("trace_closest_queue_counted");
@@ -635,12 +845,13 @@ using namespace mr;
 
 extern "C" int mirres_bvh_trace(mirres_bvh_t* bvh, const float* rays, int n, int mode, int32_t* hit, float* t, float* pos, float* normal,
                                 int32_t* prim, uint32_t* counters, void* stream) {
-    if (!bvh || !rays || n < 0 || (mode != 0 && mode != 1)) { set_error("mirres_bvh_trace: bad argument"); return MIRRES_E_ARG; }
+    if (!bvh || !rays || n < 0 || (mode != 0 && mode != 1 && mode != 2)) { set_error("mirres_bvh_trace: bad argument"); return MIRRES_E_ARG; }
     if (bvh->T < 2) { set_error("mirres_bvh_trace: BVH not built"); return MIRRES_E_STATE; }
     if (n == 0) return MIRRES_OK;
     hipStream_t s = (hipStream_t)stream;
     const Ray* r = reinterpret_cast<const Ray*>(rays);
     const int g = trace_grid((size_t)n);
+    if (mode == 2) return closest_fast<false>(bvh, r, nullptr, (size_t)n, nullptr, hit, t, pos, normal, prim, nullptr, s);
     if (mode == 0) {
         if (!hit) { set_error("mirres_bvh_trace: any-hit needs hit[]"); return MIRRES_E_ARG; }
         if (counters) k_trace_any<true><<<g, MR_TRACE_BLOCK, 0, s>>>(bvh->view(), r, nullptr, (uint32_t)n, hit, counters, nullptr);

@@ -59,7 +59,8 @@ struct mirres_bvh {
     mr::TriRec* tris = nullptr;     // [T]
     mr::Node4* nodes4 = nullptr;    // [T-1] indexed by LBVH node id (only the nodes reachable from the root by 2-level steps are used)
     float* root_box = nullptr;      // [6]
-    uint32_t* work = nullptr;       // [4] chunk heads of the persistent traversal kernels
+    uint32_t* work = nullptr;       // [8] chunk heads of the persistent traversal kernels, [5] = redo count
+    uint32_t* redo = nullptr; size_t redo_cap = 0;   // ray ids handed back by the ordered closest-hit fast path
     mr::BvhView view() const { mr::BvhView v; v.nodes = nodes; v.tris = tris; v.root_box = root_box; v.T = T; v.nodes4 = nodes4; return v; }
 };
 

@@ -25,8 +25,8 @@ for name, (oo, dd) in sets.items():
     rays = torch.empty((k, 8), device="cuda"); rays[:, 0:3] = oo; rays[:, 3] = 0; rays[:, 4:7] = dd; rays[:, 7] = 1e7
     hit = torch.zeros(k, dtype=torch.int32, device="cuda"); tt = torch.zeros(k, device="cuda"); p = torch.zeros((k, 3), device="cuda"); nn = torch.zeros((k, 3), device="cuda")
     pr = torch.zeros(k, dtype=torch.int32, device="cuda"); cnt = torch.zeros((k, 4), dtype=torch.int32, device="cuda")
-    for mode in (0, 1):
-        check(lib().mirres_bvh_trace(W.h, rays.data_ptr(), k, mode, hit.data_ptr(), tt.data_ptr(), p.data_ptr(), nn.data_ptr(), pr.data_ptr(), cnt.data_ptr(), None), "t")
+    for mode in (0, 1, 2):
+        check(lib().mirres_bvh_trace(W.h, rays.data_ptr(), k, mode, hit.data_ptr(), tt.data_ptr(), p.data_ptr(), nn.data_ptr(), pr.data_ptr(), cnt.data_ptr() if mode < 2 else None, None), "t")
         torch.cuda.synchronize()
         c = cnt.double().sum(0).cpu().numpy()
         hsum = int(hit.sum())

@@ -81,6 +81,16 @@ def test_trace_bit_exact(torch_cuda, oracle, scene_mod, subdiv, ground, hw):
         assert np.array_equal(_bits(pos.cpu().numpy()), _bits(ref["pos"])), name
         assert np.array_equal(_bits(nrm.cpu().numpy()), _bits(ref["normal"])), name
         assert np.array_equal(cnt.cpu().numpy()[:, :3].astype(np.uint32), ref["counters"][:, :3]), name   # same nodes visited
+        # mode 2: front-to-back 4-wide fast path + reference-order redo of order-dependent rays -> still bit-exact
+        h2 = torch.zeros(k, dtype=torch.int32, device="cuda"); t2 = torch.zeros(k, device="cuda"); p2 = torch.zeros((k, 3), device="cuda")
+        n2 = torch.zeros((k, 3), device="cuda"); pr2 = torch.zeros(k, dtype=torch.int32, device="cuda")
+        check(lib().mirres_bvh_trace(w.h, dr.data_ptr(), k, 2, h2.data_ptr(), t2.data_ptr(), p2.data_ptr(), n2.data_ptr(), pr2.data_ptr(), None, None), name)
+        torch.cuda.synchronize()
+        assert np.array_equal(h2.cpu().numpy(), ref["hit"]), name + " fast"
+        assert np.array_equal(pr2.cpu().numpy(), ref["prim"]), name + " fast"
+        assert np.array_equal(_bits(t2.cpu().numpy()), _bits(ref["t"])), name + " fast"
+        assert np.array_equal(_bits(p2.cpu().numpy()), _bits(ref["pos"])), name + " fast"
+        assert np.array_equal(_bits(n2.cpu().numpy()), _bits(ref["normal"])), name + " fast"
         hit0 = torch.zeros(k, dtype=torch.int32, device="cuda")
         check(lib().mirres_bvh_trace(w.h, dr.data_ptr(), k, 0, hit0.data_ptr(), None, None, None, None, None, None), name)
         assert np.array_equal(hit0.cpu().numpy(), ref["hit"]), name + " any-hit"
