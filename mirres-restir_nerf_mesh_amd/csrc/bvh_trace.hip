@@ -480,11 +480,21 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any_fast(BvhView B, co
 // ---------------------------------------------------------------- shadow rays on the 4-wide collapse (engine.hpp Node4)
 // Same order-free argument as k_trace_any_fast; the hierarchy is the LBVH with every other level removed, so a ray does about half the
 // dependent node fetches (each a full 128-byte line) and the per-visit bookkeeping is amortised over four slab tests.
-template <bool COUNT>
+// TOPN > 0: the first levels of the 4-wide tree (BvhView::top4, built breadth-first by k_top4, child references inside the top carry
+// MR_TOPBIT | local index) are copied into LDS once per persistent workgroup and served from there — every ray walks them, and the PMC
+// profile shows the kernel bound by vector-L1 line lookups of divergent node fetches, which LDS reads do not consume.
+#define MR_TOPBIT 0x20000000
+template <bool COUNT, int TOPN>
 __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4(BvhView B, const Ray* __restrict__ rays, const uint32_t* __restrict__ d_count,
                                                                uint32_t n_fixed, uint32_t* __restrict__ work_head, int32_t* __restrict__ hit_out,
                                                                unsigned long long* __restrict__ stats) {
     __shared__ uint32_t lds[MR_ANY_LDS * MR_TRACE_BLOCK];
+    __shared__ __attribute__((aligned(16))) float4 s_top[TOPN > 0 ? TOPN * 8 : 1];
+    if (TOPN > 0) {
+        const float4* src = reinterpret_cast<const float4*>(B.top4);
+        for (int i = threadIdx.x; i < TOPN * 8; i += MR_TRACE_BLOCK) s_top[i] = src[i];
+        __syncthreads();
+    }
     uint32_t* const lds_stack = lds + threadIdx.x;
     const uint32_t n = d_count ? *d_count : n_fixed;
     const int lane = lane_id();
@@ -522,7 +532,7 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4(BvhView B, const 
                     const float o3[3] = {ox, oy, oz}, i3[3] = {ix, iy, iz};
                     Slab s0 = slab(B.root_box, B.root_box + 3, o3, i3, t_min);
                     if (COUNT) c_boxes++;
-                    if (s0.tf > s0.tn && t_max > s0.tn) { cur = 0; have = true; }
+                    if (s0.tf > s0.tn && t_max > s0.tn) { cur = TOPN > 0 ? MR_TOPBIT : 0; have = true; }
                     else hit_out[idx] = 0;
                 }
                 const uint32_t want = (uint32_t)__popcll(need);
@@ -532,14 +542,22 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4(BvhView B, const 
         if (!__ballot(have)) { if (exhausted) break; else continue; }
         do {
             if (have) {
-                const Node4* __restrict__ nd = B.nodes4 + cur;
-                const float4 mnx = reinterpret_cast<const float4*>(nd)[0], mny = reinterpret_cast<const float4*>(nd)[1], mnz = reinterpret_cast<const float4*>(nd)[2];
-                const float4 mxx = reinterpret_cast<const float4*>(nd)[3], mxy = reinterpret_cast<const float4*>(nd)[4], mxz = reinterpret_cast<const float4*>(nd)[5];
-                const int4 rf = reinterpret_cast<const int4*>(nd)[6];
+                float4 mnx, mny, mnz, mxx, mxy, mxz; int4 rf;
+                if (TOPN > 0 && (cur & MR_TOPBIT)) {
+                    const float4* nd = s_top + (size_t)(cur & 0xffff) * 8;
+                    mnx = nd[0]; mny = nd[1]; mnz = nd[2]; mxx = nd[3]; mxy = nd[4]; mxz = nd[5];
+                    const float4 r4 = nd[TOPN > 85 ? 7 : 6];   // pad[] carries the references for the 341-entry prefix (k_top4)
+                    rf.x = __float_as_int(r4.x); rf.y = __float_as_int(r4.y); rf.z = __float_as_int(r4.z); rf.w = __float_as_int(r4.w);
+                } else {
+                    const Node4* __restrict__ nd = B.nodes4 + cur;
+                    mnx = reinterpret_cast<const float4*>(nd)[0]; mny = reinterpret_cast<const float4*>(nd)[1]; mnz = reinterpret_cast<const float4*>(nd)[2];
+                    mxx = reinterpret_cast<const float4*>(nd)[3]; mxy = reinterpret_cast<const float4*>(nd)[4]; mxz = reinterpret_cast<const float4*>(nd)[5];
+                    rf = reinterpret_cast<const int4*>(nd)[6];
+                    if (COUNT) c_nodes++;    // only global fetches are charged
+                }
                 const float bmnx[4] = {mnx.x, mnx.y, mnx.z, mnx.w}, bmny[4] = {mny.x, mny.y, mny.z, mny.w}, bmnz[4] = {mnz.x, mnz.y, mnz.z, mnz.w};
                 const float bmxx[4] = {mxx.x, mxx.y, mxx.z, mxx.w}, bmxy[4] = {mxy.x, mxy.y, mxy.z, mxy.w}, bmxz[4] = {mxz.x, mxz.y, mxz.z, mxz.w};
                 const int ref[4] = {rf.x, rf.y, rf.z, rf.w};
-                if (COUNT) c_nodes++;
                 bool hit = false;
                 int next = -1; float next_tn = 0.f;
 #pragma unroll
@@ -780,6 +798,19 @@ static int closest_fast(mirres_bvh* bvh, const Ray* rays, const uint32_t* d_coun
     return 0;
 }
 
+static int top_mode() {   // MIRRES_TOP=0 disables / 85 / 341 selects how many 4-wide nodes are served from LDS (A/B experiments)
+    static int m = -1;
+    if (m < 0) { const char* e = getenv("MIRRES_TOP"); m = e ? atoi(e) : 85; if (m != 0 && m != 85 && m != 341) m = 85; }
+    return m;
+}
+template <bool COUNT>
+static void launch_any4(const mirres_bvh* bvh, int grid, const Ray* rays, const uint32_t* d_count, uint32_t cap, uint32_t* head, int32_t* hit,
+                        unsigned long long* stats, hipStream_t s) {
+    const int top = (bvh->T - 1 >= 341 * 4) ? top_mode() : 0;   // small trees: not worth it (and the top would not be full)
+    if (top == 85) k_trace_any4<COUNT, 85><<<grid, MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, d_count, cap, head, hit, stats);
+    else if (top == 341) k_trace_any4<COUNT, 341><<<grid, MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, d_count, cap, head, hit, stats);
+    else k_trace_any4<COUNT, 0><<<grid, MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, d_count, cap, head, hit, stats);
+}
 static int closest_mode() {   // MIRRES_CLOSEST=4: ordered 4-wide fast path + redo in the frame loop (pays off only when most rays hit)
     static int m = -1;
     if (m < 0) { const char* e = getenv("MIRRES_CLOSEST"); m = (e && e[0] == '4') ? 4 : 2; }
@@ -808,7 +839,7 @@ static int trace_grid(size_t capacity) {
 int trace_any_queue(const mirres_bvh* bvh, const Ray* rays, const uint32_t* d_count, size_t capacity, int32_t* hit,
                     unsigned long long* stats, hipStream_t s) {
     MR_HIP(hipMemsetAsync(bvh->work, 0, sizeof(uint32_t), s));
-    if (any_mode() == 4) k_trace_any4<false><<<persist_grid(capacity), MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, d_count, (uint32_t)capacity, bvh->work, hit, stats);
+    if (any_mode() == 4) launch_any4<false>(bvh, persist_grid(capacity), rays, d_count, (uint32_t)capacity, bvh->work, hit, stats, s);
     else k_trace_any_fast<false><<<persist_grid(capacity), MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, d_count, (uint32_t)capacity, bvh->work, hit, stats);
     MR_LAUNCH_CHECK("trace_any_queue");
     return 0;
@@ -825,7 +856,7 @@ int trace_closest_queue(const mirres_bvh* bvh, const Ray* rays, const uint32_t* 
 int trace_any_queue_counted(const mirres_bvh* bvh, const Ray* rays, const uint32_t* d_count, size_t capacity, int32_t* hit,
                             unsigned long long* stats, hipStream_t s) {
     MR_HIP(hipMemsetAsync(bvh->work, 0, sizeof(uint32_t), s));
-    if (any_mode() == 4) k_trace_any4<true><<<persist_grid(capacity), MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, d_count, (uint32_t)capacity, bvh->work, hit, stats);
+    if (any_mode() == 4) launch_any4<true>(bvh, persist_grid(capacity), rays, d_count, (uint32_t)capacity, bvh->work, hit, stats, s);
     else k_trace_any_fast<true><<<persist_grid(capacity), MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, d_count, (uint32_t)capacity, bvh->work, hit, stats);
     MR_LAUNCH_CHECK("trace_any_queue_counted");
     return 0;
@@ -857,7 +888,7 @@ extern "C" int mirres_bvh_trace(mirres_bvh_t* bvh, const float* rays, int n, int
         if (counters) k_trace_any<true><<<g, MR_TRACE_BLOCK, 0, s>>>(bvh->view(), r, nullptr, (uint32_t)n, hit, counters, nullptr);
         else {
             MR_HIP(hipMemsetAsync(bvh->work + 2, 0, sizeof(uint32_t), s));
-            if (any_mode() == 4) k_trace_any4<false><<<persist_grid((size_t)n), MR_TRACE_BLOCK, 0, s>>>(bvh->view(), r, nullptr, (uint32_t)n, bvh->work + 2, hit, nullptr);
+            if (any_mode() == 4) launch_any4<false>(bvh, persist_grid((size_t)n), r, nullptr, (uint32_t)n, bvh->work + 2, hit, nullptr, s);
             else k_trace_any_fast<false><<<persist_grid((size_t)n), MR_TRACE_BLOCK, 0, s>>>(bvh->view(), r, nullptr, (uint32_t)n, bvh->work + 2, hit, nullptr);
         }
     } else {

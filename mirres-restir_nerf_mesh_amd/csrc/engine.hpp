@@ -39,6 +39,7 @@ struct __attribute__((aligned(16))) HitRec {  // 32 B closest-hit record
 struct BvhView {
     const WideNode* nodes; const TriRec* tris; const float* root_box;  // root_box -> aabb[0..5] of node 0
     const Node4* nodes4;
+    const Node4* top4;     // breadth-first copy of the first levels of nodes4 (341 entries), children inside it referenced as MR_TOPBIT | index
     int T;
 };
 
@@ -57,11 +58,12 @@ struct mirres_bvh {
     // traversal layout
     mr::WideNode* nodes = nullptr;  // [T-1]
     mr::TriRec* tris = nullptr;     // [T]
+    mr::Node4* top4 = nullptr;      // [341]
     mr::Node4* nodes4 = nullptr;    // [T-1] indexed by LBVH node id (only the nodes reachable from the root by 2-level steps are used)
     float* root_box = nullptr;      // [6]
     uint32_t* work = nullptr;       // [8] chunk heads of the persistent traversal kernels, [5] = redo count
     uint32_t* redo = nullptr; size_t redo_cap = 0;   // ray ids handed back by the ordered closest-hit fast path
-    mr::BvhView view() const { mr::BvhView v; v.nodes = nodes; v.tris = tris; v.root_box = root_box; v.T = T; v.nodes4 = nodes4; return v; }
+    mr::BvhView view() const { mr::BvhView v; v.nodes = nodes; v.tris = tris; v.root_box = root_box; v.T = T; v.nodes4 = nodes4; v.top4 = top4; return v; }
 };
 
 struct mirres_ctx {
