@@ -17,7 +17,9 @@ MR_DEV Basis basis(v3 N) { Basis b; b.B = perp_stark(N); b.T = cross(b.B, N); b.
 MR_DEV v3 to_local(const Basis& b, v3 w) { return V3(dot(b.B, w), dot(b.T, w), dot(b.N, w)); }
 MR_DEV v3 to_global(const Basis& b, v3 w) { return b.B * w.x + b.T * w.y + b.N * w.z; }
 
-MR_DEV float pow5(float c) { return powf(fmaxf(1 - c, 0), 5); }  // evalFresnelSchlick's pow(max(1-c,0),5)
+// evalFresnelSchlick's pow(max(1-c,0),5) as three multiplications: within 2 ulp of powf (itself not bit-identical between ocml and glibc),
+// ~40 VALU instructions cheaper per BRDF evaluation (33 evaluations per pixel in the initial pass).
+MR_DEV float pow5(float c) { const float x = fmaxf(1 - c, 0); const float x2 = x * x; return x2 * x2 * x; }
 MR_DEV float schlick(float f0, float f90, float c) { return f0 + (f90 - f0) * pow5(c); }
 MR_DEV v3 schlick3(v3 f0, float f90, float c) { float p = pow5(c); return V3(f0.x + (f90 - f0.x) * p, f0.y + (f90 - f0.y) * p, f0.z + (f90 - f0.z) * p); }
 MR_DEV float lambda_ggx(float a2, float c) {  // brdf.slang:34-40
