@@ -110,3 +110,40 @@ def test_spp_slices_compose(oracle, scene_mod):
     ref = sums[1]          # mirres_render_finish averaged the sums in place
     fg = torch.from_numpy(F.occ > 0.5).cuda()
     assert abs(float(tot[fg].mean()) - float(ref[fg].mean())) < 0.15 * float(ref[fg].mean()) + 1e-3
+
+
+def test_stage1_training_step_backward(oracle, scene_mod):
+    """BASELINE config 3 in miniature: kd / (roughness, metallic) from the material field (requires grad), learnable env map, stepwise
+    run_restir_di_with_pt under autograd, image loss, backward. Gradients reach the hash grid, the MLP weights and the env map through
+    FinalShading / EvaluateFinalSamples_di / EAWDenoise_run exactly where the reference's do (Resampling.py, Denoising.py)."""
+    F, W, mods, RR, torch = _setup(oracle, scene_mod, fx=40, fy=32)
+    from mirres_restir_nerf_mesh_amd.render_helper import MLPTexture3D
+    mn, mx = scene_mod.material_min_max(me_max=0.3)
+    mlp = MLPTexture3D(torch.tensor([-1, -1, -1, 1, 1, 1], dtype=torch.float32), channels=6, min_max=(torch.from_numpy(mn).cuda(), torch.from_numpy(mx).cuda()), seed=11)
+    with torch.no_grad():
+        mlp.encoder.params.mul_(2e3)
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    N = F.N; z = lambda *s: torch.zeros(s, device="cuda")
+    env = cu(F.env).requires_grad_(True)
+    kdks = mlp.sample(cu(F.pos))                                   # nerf/renderer.py:1017-1022
+    kd = kdks[:, 0:3].contiguous(); rm = torch.cat((kdks[:, 4:5], kdks[:, 5:6]), dim=-1).contiguous()
+    normal = cu(F.normal).requires_grad_(True)
+    RR.set_random_offset(777)
+    out = RR.run_restir_di_with_pt(False, 1.0, 1.0, 1.0, mlp, None, W, *mods[:8], *mods[8:17], env, cu(F.occ[:, None].copy()), normal, cu(F.depth[:, None]), kd, rm,
+                                   cu(F.ray_dir_raw), cu(F.pos), z(N, 1), z(N, 4), z(N, 3), z(N, 3), F.fx, F.fy, 2, 2, 2, 2.0, 0.1, 0.001)
+    RR.set_random_offset(None)
+    target = torch.full((N, 3), 0.5, device="cuda")
+    fg = cu(F.occ > 0.5)
+    loss = (out[0][fg] - target[fg]).abs().mean() + 0.1 * (out[1][fg].mean() + out[2][fg].mean())
+    loss.backward()
+    for name, g in (("env", env.grad), ("grid", mlp.encoder.params.grad), ("w0", mlp.net.net[0].weight.grad), ("w2", mlp.net.net[4].weight.grad), ("normal", normal.grad)):
+        assert g is not None and torch.isfinite(g).all() and float(g.abs().sum()) > 0, name
+    # one optimiser step changes the loss in the right direction for a small enough step (first-order sanity of the whole chain)
+    with torch.no_grad():
+        env_new = (env - 1e-1 * env.grad / (env.grad.abs().max() + 1e-12)).clamp_(min=0.01)
+    RR.set_random_offset(777)
+    out2 = RR.run_restir_di_with_pt(False, 1.0, 1.0, 1.0, mlp, None, W, *mods[:8], *mods[8:17], env_new, cu(F.occ[:, None].copy()), normal.detach(), cu(F.depth[:, None]),
+                                    kd.detach(), rm.detach(), cu(F.ray_dir_raw), cu(F.pos), z(N, 1), z(N, 4), z(N, 3), z(N, 3), F.fx, F.fy, 2, 2, 2, 2.0, 0.1, 0.001)
+    RR.set_random_offset(None)
+    loss2 = (out2[0][fg] - target[fg]).abs().mean() + 0.1 * (out2[1][fg].mean() + out2[2][fg].mean())
+    assert float(loss2) < float(loss) + 1e-4
