@@ -280,6 +280,115 @@ __global__ void __launch_bounds__(256) k_top4(int T, const Node4* __restrict__ n
     }
 }
 
+
+// ---- compressed 4-wide layout for shadow rays (engine.hpp Node4q / LeafRec)
+// step 2^(E-127) per axis: the smallest power of two (E >= 67) for which the decode expression of q = 255 still reaches the node's max corner
+MR_DEV float q_step(uint32_t E) { return __uint_as_float(E << 23); }
+MR_DEV float q_decode(uint32_t q, float step, float org) { return fmaf((float)q, step, org); }   // q*step is exact => one rounding, same value as mul+add
+__global__ void __launch_bounds__(256) k_pack4q(int T, const int32_t* __restrict__ info, const float* __restrict__ aabb, const float* __restrict__ vert,
+                                                const int32_t* __restrict__ tri, Node4q* __restrict__ nodes4q, LeafRec* __restrict__ leaves) {
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= T) return;
+    const int LEAF = T - 1;
+    {
+        const int prim = info[3 * ((size_t)LEAF + g) + 2];
+        const int32_t* ti = tri + 3 * (size_t)prim;
+        v3 a = ld3(vert, ti[0]), b = ld3(vert, ti[1]), c = ld3(vert, ti[2]);
+        v3 e1 = b - a, e2 = c - a;
+        const float* bx = aabb + 6 * ((size_t)LEAF + g);
+        LeafRec r;
+        r.v0[0] = a.x; r.v0[1] = a.y; r.v0[2] = a.z; r.e1[0] = e1.x; r.e1[1] = e1.y; r.e1[2] = e1.z; r.e2[0] = e2.x; r.e2[1] = e2.y; r.e2[2] = e2.z;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { r.lo[k] = bx[k]; r.hi[k] = bx[3 + k]; }
+        r.prim = prim;
+        leaves[g] = r;
+    }
+    if (g >= T - 1) return;
+    // children: start from the node's two LBVH children and keep opening the internal entry with the largest surface area until there are
+    // four (the usual wide-BVH collapse; any hierarchy over the same leaves gives the same any-hit bit). Entries stay LBVH node ids.
+    int c[4]; int nc = 2;
+    c[0] = info[3 * (size_t)g]; c[1] = info[3 * (size_t)g + 1];
+    for (int round = 0; round < 2; round++) {
+        int pick = -1; float best = -1.f;
+        for (int k = 0; k < nc; k++) {
+            if (c[k] >= LEAF) continue;
+            const float* b = aabb + 6 * (size_t)c[k];
+            const float dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2];
+            const float area = dx * dy + dy * dz + dz * dx;
+            if (area > best) { best = area; pick = k; }
+        }
+        if (pick < 0) break;
+        const int open = c[pick];
+        c[pick] = info[3 * (size_t)open]; c[nc++] = info[3 * (size_t)open + 1];
+    }
+    float cb[4][6];
+    for (int k = 0; k < nc; k++) for (int a = 0; a < 6; a++) cb[k][a] = aabb[6 * (size_t)c[k] + a];
+    Node4q n;
+    n.exps = 0; n.pad[0] = n.pad[1] = 0;
+    for (int a = 0; a < 3; a++) {
+        float lo = cb[0][a], hi = cb[0][3 + a];
+        for (int k = 1; k < nc; k++) { lo = fminf(lo, cb[k][a]); hi = fmaxf(hi, cb[k][3 + a]); }
+        const float r = (hi - lo) / 255.0f;
+        uint32_t E = ((__float_as_uint(r) >> 23) & 0xffu);
+        if (E < 67u) E = 67u;
+        if (E > 254u) E = 254u;
+        while (E < 254u && q_decode(255u, q_step(E), lo) < hi) E++;
+        const float st = q_step(E);
+        uint32_t wlo = 0, whi = 0;
+        for (int k = 0; k < 4; k++) {
+            uint32_t ql = 255u, qh = 0u;   // unused entry (never tested: ref = 0x7fffffff)
+            if (k < nc) {
+                const float fl = fminf(fmaxf(floorf((cb[k][a] - lo) / st), 0.f), 255.f);
+                const float fh = fminf(fmaxf(ceilf((cb[k][3 + a] - lo) / st), 0.f), 255.f);
+                ql = (uint32_t)fl; qh = (uint32_t)fh;
+                while (ql > 0u && q_decode(ql, st, lo) > cb[k][a]) ql--;                 // outward: decoded min <= exact min (q = 0 decodes to lo itself)
+                while (ql < 255u && q_decode(ql + 1u, st, lo) <= cb[k][a]) ql++;         // and as tight as the grid allows
+                while (qh < 255u && q_decode(qh, st, lo) < cb[k][3 + a]) qh++;           // decoded max >= exact max (q = 255 reaches hi by the choice of E)
+                while (qh > 0u && q_decode(qh - 1u, st, lo) >= cb[k][3 + a]) qh--;
+            }
+            wlo |= ql << (8 * k); whi |= qh << (8 * k);
+        }
+        n.org[a] = lo; n.exps |= E << (8 * a); n.qlo[a] = wlo; n.qhi[a] = whi;
+    }
+    for (int k = 0; k < 4; k++) n.ref[k] = (k < nc) ? ((c[k] >= LEAF) ? ~(c[k] - LEAF) : c[k]) : 0x7fffffff;
+    nodes4q[g] = n;
+}
+
+// Breadth-first prefix (TOPN = 85: levels 0..3, 341: levels 0..4) of the compressed 4-wide tree for the LDS-resident part of the shadow-ray
+// kernel; references to children inside the prefix become MR_TOPBIT | index. Same heap layout as k_top4.
+__global__ void __launch_bounds__(256) k_top4q(int T, const Node4q* __restrict__ nodes4q, Node4q* __restrict__ top, int TOPN) {
+    __shared__ int s_id[341];
+    const int t = threadIdx.x;
+    if (t == 0) s_id[0] = 0;
+    __syncthreads();
+    const int levels = TOPN == 85 ? 3 : 4;    // expansions needed to fill the prefix
+    int first = 0, cnt = 1;
+    for (int lvl = 0; lvl < levels; lvl++) {
+        for (int e = first + t; e < first + cnt; e += 256) {
+            const int id = s_id[e];
+            for (int k = 0; k < 4; k++) {
+                int r = id >= 0 ? nodes4q[id].ref[k] : 0x7fffffff;
+                s_id[4 * e + 1 + k] = (r >= 0 && r != 0x7fffffff) ? r : -1;
+            }
+        }
+        first += cnt; cnt *= 4;
+        __syncthreads();
+    }
+    for (int e = t; e < TOPN; e += 256) {
+        const int id = s_id[e];
+        Node4q n;
+        if (id >= 0) n = nodes4q[id];
+        else { n.org[0] = n.org[1] = n.org[2] = 0.f; n.exps = 0x434343u; for (int a = 0; a < 3; a++) { n.qlo[a] = 0xffffffffu; n.qhi[a] = 0u; } n.pad[0] = n.pad[1] = 0;
+               for (int k = 0; k < 4; k++) n.ref[k] = 0x7fffffff; }
+        for (int k = 0; k < 4; k++) {
+            const int cslot = 4 * e + 1 + k;
+            const bool internal = id >= 0 && n.ref[k] >= 0 && n.ref[k] != 0x7fffffff;
+            if (internal && cslot < TOPN) n.ref[k] = 0x20000000 | cslot;
+        }
+        top[e] = n;
+    }
+}
+
 __global__ void k_init_extent(uint32_t* extent) {
     int i = threadIdx.x;
     if (i < 3) extent[i] = 0xffffffffu; else if (i < 6) extent[i] = 0u;
@@ -317,8 +426,12 @@ int mirres_bvh_create(mirres_bvh_t** out, int max_tris) {
     MR_HIP(hipMalloc(&b->tris, sizeof(TriRec) * T));
     MR_HIP(hipMalloc(&b->nodes4, sizeof(Node4) * T));
     MR_HIP(hipMalloc(&b->top4, sizeof(Node4) * 341));
+    MR_HIP(hipMalloc(&b->nodes4q, sizeof(Node4q) * T));
+    MR_HIP(hipMalloc(&b->leaves, sizeof(LeafRec) * T));
+    MR_HIP(hipMalloc(&b->top85q, sizeof(Node4q) * 85));
+    MR_HIP(hipMalloc(&b->top341q, sizeof(Node4q) * 341));
     MR_HIP(hipMalloc(&b->root_box, sizeof(float) * 8));
-    MR_HIP(hipMalloc(&b->work, sizeof(uint32_t) * 8));
+    MR_HIP(hipMalloc(&b->work, sizeof(uint32_t) * 8 * MR_WSET));
     size_t tmp = 0;
     MR_HIP(rocprim::radix_sort_pairs(nullptr, tmp, b->keys_in, b->keys_out, b->vals_in, b->vals_out, T, 0, 32, 0));
     b->sort_tmp_bytes = tmp;
@@ -330,7 +443,7 @@ int mirres_bvh_create(mirres_bvh_t** out, int max_tris) {
 void mirres_bvh_destroy(mirres_bvh_t* b) {
     if (!b) return;
     void* ptrs[] = {b->ele_aabb, b->extent, b->keys_in, b->keys_out, b->vals_in, b->vals_out, b->parent, b->flags, b->own_info,
-                    b->own_aabb, b->nodes, b->tris, b->root_box, b->sort_tmp, b->work, b->nodes4, b->redo, b->top4};
+                    b->own_aabb, b->nodes, b->tris, b->root_box, b->sort_tmp, b->work, b->nodes4, b->redo, b->top4, b->nodes4q, b->leaves, b->top85q, b->top341q};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete b;
 }
@@ -354,6 +467,8 @@ int mirres_bvh_build(mirres_bvh_t* b, const float* vert, int V, const int32_t* t
     k_pack<<<grd, blk, 0, s>>>(T, info, aabb, vert, tri, b->nodes, b->tris, b->root_box);
     k_pack4<<<grd, blk, 0, s>>>(T, info, aabb, b->nodes4);
     if (T - 1 >= 341 * 4) k_top4<<<1, 256, 0, s>>>(T, b->nodes4, b->top4);
+    k_pack4q<<<grd, blk, 0, s>>>(T, info, aabb, vert, tri, b->nodes4q, b->leaves);
+    if (T - 1 >= 341 * 4) { k_top4q<<<1, 256, 0, s>>>(T, b->nodes4q, b->top85q, 85); k_top4q<<<1, 256, 0, s>>>(T, b->nodes4q, b->top341q, 341); }
     MR_LAUNCH_CHECK("bvh_build");
     return MIRRES_OK;
 }

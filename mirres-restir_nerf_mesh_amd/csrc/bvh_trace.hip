@@ -214,6 +214,22 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_closest(BvhView B, con
 // arithmetic and visit order are exactly those of traverse<>, so results are bit-identical to the simple kernels.
 #define MR_CHUNK_MAX 1024
 #define MR_REFILL 40
+// Work distribution. A single queue-head word serialises at ~88 returning atomics/us on MI355X: with 64-ray chunks a 2.3 M-ray launch needs
+// 36 k of them = 0.41 ms — the whole kernel. The ray queue is therefore cut into MR_NQ contiguous sub-queues with their own head words
+// (128 B apart: different L2 channels); a wave starts on sub-queue (wave id mod MR_NQ), takes chunks from it and moves to the next one when
+// it runs dry (each sub-queue is probed at most once after it emptied, so a wave stops after MR_NQ failed probes).
+MR_DEV bool grab_chunk(uint32_t* __restrict__ heads, uint32_t n, uint32_t per, uint32_t chunk, uint32_t& q, uint32_t& fails, uint32_t& c_next, uint32_t& c_end, int lane) {
+    while (fails < MR_NQ) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(heads + q * MR_QSTRIDE, chunk);
+        base = __builtin_amdgcn_readfirstlane(base);
+        const uint32_t qb = q * per;
+        const uint32_t qe = (qb + per < n) ? qb + per : n;
+        if (qb < n && base < qe - qb) { c_next = qb + base; c_end = (c_next + chunk < qe) ? c_next + chunk : qe; return true; }
+        q = (q + 1 == MR_NQ) ? 0 : q + 1; fails++;
+    }
+    return false;
+}
 
 template <bool ANY>
 __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_persist(BvhView B, const Ray* __restrict__ rays, const uint32_t* __restrict__ d_count,
@@ -230,6 +246,8 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_persist(BvhView B, con
     // chunk size: ~4 chunks per resident wave so that the tail balances, 64..1024 rays (one global atomic per chunk)
     uint32_t chunk = n / (gridDim.x * (MR_TRACE_BLOCK / 64) * 4);
     chunk = chunk < 64 ? 64 : (chunk > MR_CHUNK_MAX ? MR_CHUNK_MAX : (chunk & ~63u));
+    const uint32_t q_per = (((n + MR_NQ - 1) / MR_NQ) + 63u) & ~63u;                                  // rays per sub-queue
+    uint32_t q_cur = (blockIdx.x * (MR_TRACE_BLOCK / 64) + (threadIdx.x >> 6)) % MR_NQ, q_fail = 0;   // wave-uniform
     uint32_t chunk_next = 0, chunk_end = 0;  // wave-uniform
     bool exhausted = false;                  // wave-uniform: the global queue has no more chunks
     bool have = false;
@@ -242,13 +260,7 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_persist(BvhView B, con
         // ---- refill idle lanes from the wave's chunk
         const uint64_t need = __ballot(!have);
         if (need && !exhausted) {
-            if (chunk_next >= chunk_end) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(work_head, chunk);
-                base = __builtin_amdgcn_readfirstlane(base);
-                if (base >= n) exhausted = true;
-                else { chunk_next = base; chunk_end = (base + chunk < n) ? base + chunk : n; }
-            }
+            if (chunk_next >= chunk_end) exhausted = !grab_chunk(work_head, n, q_per, chunk, q_cur, q_fail, chunk_next, chunk_end, lane);
             if (!exhausted) {
                 const uint32_t idx = chunk_next + (uint32_t)__popcll(need & lt_mask);
                 if (!have && idx < chunk_end) {
@@ -397,6 +409,8 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any_fast(BvhView B, co
     const int NONE = 0x40000000;
     uint32_t chunk = n / (gridDim.x * (MR_TRACE_BLOCK / 64) * 4);
     chunk = chunk < 64 ? 64 : (chunk > MR_CHUNK_MAX ? MR_CHUNK_MAX : (chunk & ~63u));
+    const uint32_t q_per = (((n + MR_NQ - 1) / MR_NQ) + 63u) & ~63u;                                  // rays per sub-queue
+    uint32_t q_cur = (blockIdx.x * (MR_TRACE_BLOCK / 64) + (threadIdx.x >> 6)) % MR_NQ, q_fail = 0;   // wave-uniform
     uint32_t chunk_next = 0, chunk_end = 0;
     bool exhausted = false, have = false;
     float o[3], inv[3]; v3 d = V3(0.f), ro = V3(0.f);
@@ -407,13 +421,7 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any_fast(BvhView B, co
     while (true) {
         const uint64_t need = __ballot(!have);
         if (need && !exhausted) {
-            if (chunk_next >= chunk_end) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(work_head, chunk);
-                base = __builtin_amdgcn_readfirstlane(base);
-                if (base >= n) exhausted = true;
-                else { chunk_next = base; chunk_end = (base + chunk < n) ? base + chunk : n; }
-            }
+            if (chunk_next >= chunk_end) exhausted = !grab_chunk(work_head, n, q_per, chunk, q_cur, q_fail, chunk_next, chunk_end, lane);
             if (!exhausted) {
                 const uint32_t idx = chunk_next + (uint32_t)__popcll(need & lt_mask);
                 if (!have && idx < chunk_end) {
@@ -501,6 +509,8 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4(BvhView B, const 
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     uint32_t chunk = n / (gridDim.x * (MR_TRACE_BLOCK / 64) * 4);
     chunk = chunk < 64 ? 64 : (chunk > MR_CHUNK_MAX ? MR_CHUNK_MAX : (chunk & ~63u));
+    const uint32_t q_per = (((n + MR_NQ - 1) / MR_NQ) + 63u) & ~63u;                                  // rays per sub-queue
+    uint32_t q_cur = (blockIdx.x * (MR_TRACE_BLOCK / 64) + (threadIdx.x >> 6)) % MR_NQ, q_fail = 0;   // wave-uniform
     uint32_t chunk_next = 0, chunk_end = 0;
     bool exhausted = false, have = false;
     float ox = 0, oy = 0, oz = 0, ix = 0, iy = 0, iz = 0; v3 d = V3(0.f), ro = V3(0.f);
@@ -511,13 +521,7 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4(BvhView B, const 
     while (true) {
         const uint64_t need = __ballot(!have);
         if (need && !exhausted) {
-            if (chunk_next >= chunk_end) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(work_head, chunk);
-                base = __builtin_amdgcn_readfirstlane(base);
-                if (base >= n) exhausted = true;
-                else { chunk_next = base; chunk_end = (base + chunk < n) ? base + chunk : n; }
-            }
+            if (chunk_next >= chunk_end) exhausted = !grab_chunk(work_head, n, q_per, chunk, q_cur, q_fail, chunk_next, chunk_end, lane);
             if (!exhausted) {
                 const uint32_t idx = chunk_next + (uint32_t)__popcll(need & lt_mask);
                 if (!have && idx < chunk_end) {
@@ -597,6 +601,152 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4(BvhView B, const 
 }
 
 
+// ---------------------------------------------------------------- shadow rays on the COMPRESSED 4-wide collapse (engine.hpp Node4q / LeafRec)
+// The any-hit bit is the OR over leaves whose own box passes the slab test (above); interior boxes only steer the search and may be any
+// supersets. Node4q stores them as 8-bit outward-rounded offsets (64 B per visit = 4 dwordx4 gathers instead of 8 — the kernel is bound by
+// vector-L1 lookups of divergent gathers); (b' - o) * inv is monotone in b', so a decoded box passes whenever the exact one does and no
+// leaf the reference visits is missed. A leaf that passes the conservative test is re-tested against its exact LBVH box (LeafRec) before
+// the triangle test, so the set of triangles tested — and therefore the result — is the reference's, bit for bit.
+MR_DEV bool tri_accepts_regs(float4 a, float4 b, float4 c, v3 ro, v3 d) {
+    const v3 v0 = V3(a.x, a.y, a.z), E1 = V3(a.w, b.x, b.y), E2 = V3(b.z, b.w, c.x);
+    const v3 P = cross(d, E2);
+    const float det = dot(E1, P);
+    if (det > -1e-15f && det < 1e-15f) return false;
+    const float invDet = 1 / det;
+    const v3 Tv = ro - v0;
+    const float u = dot(Tv, P) * invDet;
+    if (u < 0 || u > 1) return false;
+    const v3 Q = cross(Tv, E1);
+    const float v = dot(d, Q) * invDet;
+    if (v < 0 || u + v > 1) return false;
+    return true;
+}
+template <bool COUNT, int TOPN>
+__global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const Ray* __restrict__ rays, const uint32_t* __restrict__ d_count,
+                                                               uint32_t n_fixed, uint32_t* __restrict__ work_head, int32_t* __restrict__ hit_out,
+                                                               unsigned long long* __restrict__ stats) {
+    __shared__ uint32_t lds[MR_ANY_LDS * MR_TRACE_BLOCK];
+    __shared__ __attribute__((aligned(16))) uint4 s_top[TOPN > 0 ? TOPN * 4 : 1];
+    if (TOPN > 0) {
+        const uint4* src = reinterpret_cast<const uint4*>(TOPN > 85 ? B.top341q : B.top85q);
+        for (int i = threadIdx.x; i < TOPN * 4; i += MR_TRACE_BLOCK) s_top[i] = src[i];
+        __syncthreads();
+    }
+    uint32_t* const lds_stack = lds + threadIdx.x;
+    const uint32_t n = d_count ? *d_count : n_fixed;
+    const int lane = lane_id();
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    uint32_t chunk = n / (gridDim.x * (MR_TRACE_BLOCK / 64) * 4);
+    chunk = chunk < 64 ? 64 : (chunk > MR_CHUNK_MAX ? MR_CHUNK_MAX : (chunk & ~63u));
+    const uint32_t q_per = (((n + MR_NQ - 1) / MR_NQ) + 63u) & ~63u;                                  // rays per sub-queue
+    uint32_t q_cur = (blockIdx.x * (MR_TRACE_BLOCK / 64) + (threadIdx.x >> 6)) % MR_NQ, q_fail = 0;   // wave-uniform
+    uint32_t chunk_next = 0, chunk_end = 0;
+    bool exhausted = false, have = false;
+    float ox = 0, oy = 0, oz = 0, ix = 0, iy = 0, iz = 0; v3 d = V3(0.f), ro = V3(0.f);
+    float t_min = 0.f, t_max = 0.f;
+    int cur = 0, sp = 0; uint32_t ridx = 0;
+    uint32_t spill[MR_STACK - MR_ANY_LDS];
+    unsigned long long c_boxes = 0, c_nodes = 0, c_leaves = 0;
+    while (true) {
+        const uint64_t need = __ballot(!have);
+        if (need && !exhausted) {
+            if (chunk_next >= chunk_end) exhausted = !grab_chunk(work_head, n, q_per, chunk, q_cur, q_fail, chunk_next, chunk_end, lane);
+            if (!exhausted) {
+                const uint32_t idx = chunk_next + (uint32_t)__popcll(need & lt_mask);
+                if (!have && idx < chunk_end) {
+                    const float4 a = reinterpret_cast<const float4*>(rays + idx)[0], b = reinterpret_cast<const float4*>(rays + idx)[1];
+                    ridx = idx; ro = V3(a.x, a.y, a.z); t_min = a.w; t_max = b.w;
+                    d = normalize(V3(b.x, b.y, b.z));
+                    ox = ro.x; oy = ro.y; oz = ro.z;
+                    { float dx = d.x, dy = d.y, dz = d.z;
+                      if (dx == 0.f) dx = 0.000001f; if (dy == 0.f) dy = 0.000001f; if (dz == 0.f) dz = 0.000001f;
+                      ix = 1.0f / dx; iy = 1.0f / dy; iz = 1.0f / dz; }
+                    sp = 0;
+                    const float o3[3] = {ox, oy, oz}, i3[3] = {ix, iy, iz};
+                    Slab s0 = slab(B.root_box, B.root_box + 3, o3, i3, t_min);
+                    if (COUNT) c_boxes++;
+                    if (s0.tf > s0.tn && t_max > s0.tn) { cur = TOPN > 0 ? MR_TOPBIT : 0; have = true; }
+                    else hit_out[idx] = 0;
+                }
+                const uint32_t want = (uint32_t)__popcll(need);
+                chunk_next = (chunk_next + want < chunk_end) ? chunk_next + want : chunk_end;
+            }
+        }
+        if (!__ballot(have)) { if (exhausted) break; else continue; }
+        do {
+            if (have) {
+                // one 64-byte record per iteration — a Node4q or a LeafRec — fetched before the type is looked at, so that a wave pays ONE memory
+                // round trip per iteration however its lanes split between nodes and leaves (the slowest lane sets the wave's pace)
+                uint4 h0, h1, h2, rf;
+                const bool leaf = cur < 0;
+                if (TOPN > 0 && !leaf && (cur & MR_TOPBIT)) {
+                    const uint4* nd = s_top + (size_t)(cur & 0xffff) * 4;
+                    h0 = nd[0]; h1 = nd[1]; h2 = nd[2]; rf = nd[3];
+                } else {
+                    const uint4* __restrict__ nd = leaf ? reinterpret_cast<const uint4*>(B.leaves + ~cur) : reinterpret_cast<const uint4*>(B.nodes4q + cur);
+                    h0 = nd[0]; h1 = nd[1]; h2 = nd[2]; rf = nd[3];
+                    if (COUNT && !leaf) c_nodes++;    // only global fetches are charged
+                }
+                bool hit = false;
+                int next = 0x7fffffff; float next_tn = 0.f;
+                if (leaf) {
+                    // the reference visits a leaf iff its OWN box passes: re-test with the exact box kept beside the triangle
+                    const float4 l0 = make_float4(__uint_as_float(h0.x), __uint_as_float(h0.y), __uint_as_float(h0.z), __uint_as_float(h0.w));
+                    const float4 l1 = make_float4(__uint_as_float(h1.x), __uint_as_float(h1.y), __uint_as_float(h1.z), __uint_as_float(h1.w));
+                    const float4 l2 = make_float4(__uint_as_float(h2.x), __uint_as_float(h2.y), __uint_as_float(h2.z), __uint_as_float(h2.w));
+                    const float4 l3 = make_float4(__uint_as_float(rf.x), __uint_as_float(rf.y), __uint_as_float(rf.z), __uint_as_float(rf.w));
+                    const float ex0 = (l2.y - ox) * ix, ex1 = (l3.x - ox) * ix;
+                    const float ey0 = (l2.z - oy) * iy, ey1 = (l3.y - oy) * iy;
+                    const float ez0 = (l2.w - oz) * iz, ez1 = (l3.z - oz) * iz;
+                    const float etn = fmaxf(fmaxf(fmaxf(fminf(ex0, ex1), fminf(ey0, ey1)), fminf(ez0, ez1)), t_min);
+                    const float etf = fminf(fminf(fmaxf(ex0, ex1), fmaxf(ey0, ey1)), fmaxf(ez0, ez1));
+                    if (COUNT) c_boxes++;
+                    if (etf > etn && t_max > etn) { hit = tri_accepts_regs(l0, l1, l2, ro, d); if (COUNT) c_leaves++; }
+                } else {
+                    const float gx = __uint_as_float(h0.x), gy = __uint_as_float(h0.y), gz = __uint_as_float(h0.z);
+                    const float sx = __uint_as_float((h0.w & 0xffu) << 23), sy = __uint_as_float((h0.w & 0xff00u) << 15), sz = __uint_as_float((h0.w & 0xff0000u) << 7);
+                    const uint32_t qlx = h1.x, qly = h1.y, qlz = h1.z, qhx = h1.w, qhy = h2.x, qhz = h2.y;
+                    const int ref[4] = {(int)rf.x, (int)rf.y, (int)rf.z, (int)rf.w};
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        // conservative box: decode (exactly the expression k_pack4q rounded against), then the reference's slab test
+                        const float lx = fmaf((float)((qlx >> (8 * k)) & 0xffu), sx, gx), hx = fmaf((float)((qhx >> (8 * k)) & 0xffu), sx, gx);
+                        const float ly = fmaf((float)((qly >> (8 * k)) & 0xffu), sy, gy), hy = fmaf((float)((qhy >> (8 * k)) & 0xffu), sy, gy);
+                        const float lz = fmaf((float)((qlz >> (8 * k)) & 0xffu), sz, gz), hz = fmaf((float)((qhz >> (8 * k)) & 0xffu), sz, gz);
+                        const float ax = (lx - ox) * ix, bx = (hx - ox) * ix;
+                        const float ay = (ly - oy) * iy, by = (hy - oy) * iy;
+                        const float az = (lz - oz) * iz, bz = (hz - oz) * iz;
+                        const float tn = fmaxf(fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz)), t_min);
+                        const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+                        const bool ok = ref[k] != 0x7fffffff && tf > tn && t_max > tn;
+                        if (COUNT && ref[k] != 0x7fffffff) c_boxes++;
+                        if (ok) {
+                            if (next == 0x7fffffff) { next = ref[k]; next_tn = tn; }
+                            else {
+                                int far = ref[k];
+                                if (tn < next_tn) { far = next; next = ref[k]; next_tn = tn; }   // keep the nearest (node or leaf) for the immediate descent
+                                if (sp < MR_ANY_LDS) lds_stack[sp * MR_TRACE_BLOCK] = (uint32_t)far;
+                                else if (sp < MR_STACK) spill[sp - MR_ANY_LDS] = (uint32_t)far;
+                                if (sp < MR_STACK) sp++;
+                            }
+                        }
+                    }
+                }
+                bool done = hit;
+                if (!hit) {
+                    if (next != 0x7fffffff) cur = next;
+                    else if (sp > 0) { --sp; cur = (int)((sp < MR_ANY_LDS) ? lds_stack[sp * MR_TRACE_BLOCK] : spill[sp - MR_ANY_LDS]); }
+                    else done = true;
+                }
+                if (done) { have = false; hit_out[ridx] = hit ? 1 : 0; }
+            }
+        } while (__popcll(__ballot(have)) >= MR_REFILL || (exhausted && __ballot(have)));
+    }
+    if (COUNT && stats) { atomicAdd(&stats[2], c_boxes); atomicAdd(&stats[3], c_nodes); atomicAdd(&stats[4], c_leaves); }
+    if (stats && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[0], (unsigned long long)n);
+}
+
+
 // ---------------------------------------------------------------- closest hit: ordered 4-wide fast path + exact fallback
 // The reference's closest-hit result depends on its (unordered, right-first) visiting order only in two situations:
 //   (a) a triangle is accepted with t <= 0 (triangle_hit ignores the t interval, helperDi.slang:172-195): `closest` drops to <= t_min and the
@@ -620,6 +770,8 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_closest4(BvhView B, co
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     uint32_t chunk = n / (gridDim.x * (MR_TRACE_BLOCK / 64) * 4);
     chunk = chunk < 64 ? 64 : (chunk > MR_CHUNK_MAX ? MR_CHUNK_MAX : (chunk & ~63u));
+    const uint32_t q_per = (((n + MR_NQ - 1) / MR_NQ) + 63u) & ~63u;                                  // rays per sub-queue
+    uint32_t q_cur = (blockIdx.x * (MR_TRACE_BLOCK / 64) + (threadIdx.x >> 6)) % MR_NQ, q_fail = 0;   // wave-uniform
     uint32_t chunk_next = 0, chunk_end = 0;
     bool exhausted = false, have = false;
     float ox = 0, oy = 0, oz = 0, ix = 0, iy = 0, iz = 0; v3 d = V3(0.f), ro = V3(0.f);
@@ -630,13 +782,7 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_closest4(BvhView B, co
     while (true) {
         const uint64_t need = __ballot(!have);
         if (need && !exhausted) {
-            if (chunk_next >= chunk_end) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(work_head, chunk);
-                base = __builtin_amdgcn_readfirstlane(base);
-                if (base >= n) exhausted = true;
-                else { chunk_next = base; chunk_end = (base + chunk < n) ? base + chunk : n; }
-            }
+            if (chunk_next >= chunk_end) exhausted = !grab_chunk(work_head, n, q_per, chunk, q_cur, q_fail, chunk_next, chunk_end, lane);
             if (!exhausted) {
                 const uint32_t idx = chunk_next + (uint32_t)__popcll(need & lt_mask);
                 if (!have && idx < chunk_end) {
@@ -790,10 +936,10 @@ template <bool COUNT>
 static int closest_fast(mirres_bvh* bvh, const Ray* rays, const uint32_t* d_count, size_t capacity, HitRec* rec, int32_t* hit, float* t, float* pos,
                         float* nrm, int32_t* prim, unsigned long long* stats, hipStream_t s) {
     int rc = ensure_redo(bvh, capacity); if (rc) return rc;
-    MR_HIP(hipMemsetAsync(bvh->work + 4, 0, 3 * sizeof(uint32_t), s));   // [4] fast head, [5] redo count, [6] redo head
-    k_trace_closest4<COUNT><<<persist_grid(capacity), MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, d_count, (uint32_t)capacity, bvh->work + 4, rec, hit, t, pos, nrm, prim,
-                                                                               bvh->redo, bvh->work + 5, stats);
-    k_trace_persist<false><<<256, MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, bvh->work + 5, 0u, bvh->work + 6, hit, rec, t, pos, nrm, prim, nullptr, bvh->redo);
+    MR_HIP(hipMemsetAsync(bvh->work + 4 * MR_WSET, 0, 3 * MR_WSET * sizeof(uint32_t), s));   // set 4 fast heads, set 5 [0] redo count, set 6 redo heads
+    k_trace_closest4<COUNT><<<persist_grid(capacity), MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, d_count, (uint32_t)capacity, bvh->work + 4 * MR_WSET, rec, hit, t, pos, nrm, prim,
+                                                                               bvh->redo, bvh->work + 5 * MR_WSET, stats);
+    k_trace_persist<false><<<256, MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, bvh->work + 5 * MR_WSET, 0u, bvh->work + 6 * MR_WSET, hit, rec, t, pos, nrm, prim, nullptr, bvh->redo);
     MR_LAUNCH_CHECK("closest_fast");
     return 0;
 }
@@ -811,14 +957,24 @@ static void launch_any4(const mirres_bvh* bvh, int grid, const Ray* rays, const 
     else if (top == 341) k_trace_any4<COUNT, 341><<<grid, MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, d_count, cap, head, hit, stats);
     else k_trace_any4<COUNT, 0><<<grid, MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, d_count, cap, head, hit, stats);
 }
+template <bool COUNT>
+static void launch_any4q(const mirres_bvh* bvh, int grid, const Ray* rays, const uint32_t* d_count, uint32_t cap, uint32_t* head, int32_t* hit,
+                         unsigned long long* stats, hipStream_t s) {
+    static int topq = -1;
+    if (topq < 0) { const char* e = getenv("MIRRES_TOPQ"); topq = e ? atoi(e) : 85; if (topq != 0 && topq != 85 && topq != 341) topq = 85; }
+    const int top = (bvh->T - 1 >= 341 * 4) ? topq : 0;
+    if (top == 85) k_trace_any4q<COUNT, 85><<<grid, MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, d_count, cap, head, hit, stats);
+    else if (top == 341) k_trace_any4q<COUNT, 341><<<grid, MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, d_count, cap, head, hit, stats);
+    else k_trace_any4q<COUNT, 0><<<grid, MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, d_count, cap, head, hit, stats);
+}
 static int closest_mode() {   // MIRRES_CLOSEST=4: ordered 4-wide fast path + redo in the frame loop (pays off only when most rays hit)
     static int m = -1;
     if (m < 0) { const char* e = getenv("MIRRES_CLOSEST"); m = (e && e[0] == '4') ? 4 : 2; }
     return m;
 }
-static int any_mode() {   // MIRRES_ANY=2 selects the binary-tree shadow kernel (A/B experiments); default: 4-wide
+static int any_mode() {   // shadow-ray kernel: default 8 = compressed 4-wide (Node4q); MIRRES_ANY=4 plain 4-wide, =2 binary (A/B experiments)
     static int m = -1;
-    if (m < 0) { const char* e = getenv("MIRRES_ANY"); m = (e && e[0] == '2') ? 2 : 4; }
+    if (m < 0) { const char* e = getenv("MIRRES_ANY"); m = (e && e[0] == '2') ? 2 : ((e && e[0] == '4') ? 4 : 8); }
     return m;
 }
 
@@ -838,8 +994,9 @@ static int trace_grid(size_t capacity) {
 
 int trace_any_queue(const mirres_bvh* bvh, const Ray* rays, const uint32_t* d_count, size_t capacity, int32_t* hit,
                     unsigned long long* stats, hipStream_t s) {
-    MR_HIP(hipMemsetAsync(bvh->work, 0, sizeof(uint32_t), s));
-    if (any_mode() == 4) launch_any4<false>(bvh, persist_grid(capacity), rays, d_count, (uint32_t)capacity, bvh->work, hit, stats, s);
+    MR_HIP(hipMemsetAsync(bvh->work, 0, MR_WSET * sizeof(uint32_t), s));
+    if (any_mode() == 8) launch_any4q<false>(bvh, persist_grid(capacity), rays, d_count, (uint32_t)capacity, bvh->work, hit, stats, s);
+    else if (any_mode() == 4) launch_any4<false>(bvh, persist_grid(capacity), rays, d_count, (uint32_t)capacity, bvh->work, hit, stats, s);
     else k_trace_any_fast<false><<<persist_grid(capacity), MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, d_count, (uint32_t)capacity, bvh->work, hit, stats);
     MR_LAUNCH_CHECK("trace_any_queue");
     return 0;
@@ -847,16 +1004,17 @@ int trace_any_queue(const mirres_bvh* bvh, const Ray* rays, const uint32_t* d_co
 int trace_closest_queue(const mirres_bvh* bvh, const Ray* rays, const uint32_t* d_count, size_t capacity, HitRec* out,
                         unsigned long long* stats, hipStream_t s) {
     if (closest_mode() == 4) return closest_fast<false>(const_cast<mirres_bvh*>(bvh), rays, d_count, capacity, out, nullptr, nullptr, nullptr, nullptr, nullptr, stats, s);
-    MR_HIP(hipMemsetAsync(bvh->work + 1, 0, sizeof(uint32_t), s));
-    k_trace_persist<false><<<persist_grid(capacity), MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, d_count, (uint32_t)capacity, bvh->work + 1, nullptr, out,
+    MR_HIP(hipMemsetAsync(bvh->work + 1 * MR_WSET, 0, MR_WSET * sizeof(uint32_t), s));
+    k_trace_persist<false><<<persist_grid(capacity), MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, d_count, (uint32_t)capacity, bvh->work + 1 * MR_WSET, nullptr, out,
                                                                              nullptr, nullptr, nullptr, nullptr, stats);
     MR_LAUNCH_CHECK("trace_closest_queue");
     return 0;
 }
 int trace_any_queue_counted(const mirres_bvh* bvh, const Ray* rays, const uint32_t* d_count, size_t capacity, int32_t* hit,
                             unsigned long long* stats, hipStream_t s) {
-    MR_HIP(hipMemsetAsync(bvh->work, 0, sizeof(uint32_t), s));
-    if (any_mode() == 4) launch_any4<true>(bvh, persist_grid(capacity), rays, d_count, (uint32_t)capacity, bvh->work, hit, stats, s);
+    MR_HIP(hipMemsetAsync(bvh->work, 0, MR_WSET * sizeof(uint32_t), s));
+    if (any_mode() == 8) launch_any4q<true>(bvh, persist_grid(capacity), rays, d_count, (uint32_t)capacity, bvh->work, hit, stats, s);
+    else if (any_mode() == 4) launch_any4<true>(bvh, persist_grid(capacity), rays, d_count, (uint32_t)capacity, bvh->work, hit, stats, s);
     else k_trace_any_fast<true><<<persist_grid(capacity), MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, d_count, (uint32_t)capacity, bvh->work, hit, stats);
     MR_LAUNCH_CHECK("trace_any_queue_counted");
     return 0;
@@ -887,15 +1045,16 @@ extern "C" int mirres_bvh_trace(mirres_bvh_t* bvh, const float* rays, int n, int
         if (!hit) { set_error("mirres_bvh_trace: any-hit needs hit[]"); return MIRRES_E_ARG; }
         if (counters) k_trace_any<true><<<g, MR_TRACE_BLOCK, 0, s>>>(bvh->view(), r, nullptr, (uint32_t)n, hit, counters, nullptr);
         else {
-            MR_HIP(hipMemsetAsync(bvh->work + 2, 0, sizeof(uint32_t), s));
-            if (any_mode() == 4) launch_any4<false>(bvh, persist_grid((size_t)n), r, nullptr, (uint32_t)n, bvh->work + 2, hit, nullptr, s);
-            else k_trace_any_fast<false><<<persist_grid((size_t)n), MR_TRACE_BLOCK, 0, s>>>(bvh->view(), r, nullptr, (uint32_t)n, bvh->work + 2, hit, nullptr);
+            MR_HIP(hipMemsetAsync(bvh->work + 2 * MR_WSET, 0, MR_WSET * sizeof(uint32_t), s));
+            if (any_mode() == 8) launch_any4q<false>(bvh, persist_grid((size_t)n), r, nullptr, (uint32_t)n, bvh->work + 2 * MR_WSET, hit, nullptr, s);
+            else if (any_mode() == 4) launch_any4<false>(bvh, persist_grid((size_t)n), r, nullptr, (uint32_t)n, bvh->work + 2 * MR_WSET, hit, nullptr, s);
+            else k_trace_any_fast<false><<<persist_grid((size_t)n), MR_TRACE_BLOCK, 0, s>>>(bvh->view(), r, nullptr, (uint32_t)n, bvh->work + 2 * MR_WSET, hit, nullptr);
         }
     } else {
         if (counters) k_trace_closest<true><<<g, MR_TRACE_BLOCK, 0, s>>>(bvh->view(), r, nullptr, (uint32_t)n, nullptr, hit, t, pos, normal, prim, counters, nullptr);
         else {
-            MR_HIP(hipMemsetAsync(bvh->work + 3, 0, sizeof(uint32_t), s));
-            k_trace_persist<false><<<persist_grid((size_t)n), MR_TRACE_BLOCK, 0, s>>>(bvh->view(), r, nullptr, (uint32_t)n, bvh->work + 3, hit, nullptr, t, pos, normal,
+            MR_HIP(hipMemsetAsync(bvh->work + 3 * MR_WSET, 0, MR_WSET * sizeof(uint32_t), s));
+            k_trace_persist<false><<<persist_grid((size_t)n), MR_TRACE_BLOCK, 0, s>>>(bvh->view(), r, nullptr, (uint32_t)n, bvh->work + 3 * MR_WSET, hit, nullptr, t, pos, normal,
                                                                                     prim, nullptr);
         }
     }

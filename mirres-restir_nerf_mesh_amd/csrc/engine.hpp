@@ -5,6 +5,11 @@
 #include <vector>
 #include "../../include/mirres.h"
 
+// persistent-traversal work queue: MR_NQ sub-queue heads, one per 128-byte line (bvh_trace.hip grab_chunk); mirres_bvh::work holds 8 such sets
+#define MR_NQ 32
+#define MR_QSTRIDE 32
+#define MR_WSET (MR_NQ * MR_QSTRIDE)
+
 namespace mr {
 
 // ---- traversal layout (DESIGN.md §BVH layout). One 64-byte record per INTERNAL node holding both children's
@@ -23,6 +28,21 @@ struct __attribute__((aligned(128))) Node4 {
     int32_t ref[4];   // >=0 internal LBVH node id, <0 ~leaf slot, 0x7fffffff = unused entry
     int32_t pad[4];
 };
+// Compressed 4-wide node (64 B = half a line, 4 dwordx4 loads instead of 8): child boxes as 8-bit offsets from the node's own min corner in
+// power-of-two steps, rounded OUTWARD against the exact decode expression fmaf(q, 2^e, origin) the kernel evaluates, so every decoded box
+// contains the LBVH box it stands for. Only used by the shadow-ray kernel, whose result depends on the leaves' own boxes alone
+// (bvh_trace.hip): leaves that pass the conservative test are re-tested against their exact box, stored with the triangle in LeafRec.
+struct __attribute__((aligned(64))) Node4q {
+    float org[3]; uint32_t exps;          // biased exponents of the x/y/z step in bytes 0..2
+    uint32_t qlo[3], qhi[3];              // byte k of qlo[a] / qhi[a] = child k's min / max along axis a
+    uint32_t pad[2];
+    int32_t ref[4];                       // as Node4::ref
+};
+struct __attribute__((aligned(64))) LeafRec {  // 64 B: triangle (v0, e1, e2) + the leaf's exact LBVH box + primitive id
+    float v0[3], e1[3], e2[3];
+    float lo[3], hi[3];
+    int32_t prim;
+};
 struct __attribute__((aligned(16))) TriRec {  // 48 B
     float v0[3], e1[3], e2[3];
     int32_t prim;
@@ -39,6 +59,7 @@ struct __attribute__((aligned(16))) HitRec {  // 32 B closest-hit record
 struct BvhView {
     const WideNode* nodes; const TriRec* tris; const float* root_box;  // root_box -> aabb[0..5] of node 0
     const Node4* nodes4;
+    const Node4q* nodes4q; const LeafRec* leaves; const Node4q* top85q; const Node4q* top341q;   // compressed shadow-ray layout
     const Node4* top4;     // breadth-first copy of the first levels of nodes4 (341 entries), children inside it referenced as MR_TOPBIT | index
     int T;
 };
@@ -60,10 +81,13 @@ struct mirres_bvh {
     mr::TriRec* tris = nullptr;     // [T]
     mr::Node4* top4 = nullptr;      // [341]
     mr::Node4* nodes4 = nullptr;    // [T-1] indexed by LBVH node id (only the nodes reachable from the root by 2-level steps are used)
+    mr::Node4q* nodes4q = nullptr;  // [T-1] compressed 4-wide nodes (shadow rays)
+    mr::LeafRec* leaves = nullptr;  // [T]
+    mr::Node4q* top85q = nullptr, *top341q = nullptr;   // [85], [341] breadth-first prefixes of nodes4q, children inside tagged MR_TOPBIT
     float* root_box = nullptr;      // [6]
-    uint32_t* work = nullptr;       // [8] chunk heads of the persistent traversal kernels, [5] = redo count
+    uint32_t* work = nullptr;       // [8 * MR_WSET] head sets of the persistent traversal kernels, set 5 word 0 = redo count
     uint32_t* redo = nullptr; size_t redo_cap = 0;   // ray ids handed back by the ordered closest-hit fast path
-    mr::BvhView view() const { mr::BvhView v; v.nodes = nodes; v.tris = tris; v.root_box = root_box; v.T = T; v.nodes4 = nodes4; v.top4 = top4; return v; }
+    mr::BvhView view() const { mr::BvhView v; v.nodes = nodes; v.tris = tris; v.root_box = root_box; v.T = T; v.nodes4 = nodes4; v.top4 = top4; v.nodes4q = nodes4q; v.leaves = leaves; v.top85q = top85q; v.top341q = top341q; return v; }
 };
 
 struct mirres_ctx {
