@@ -175,6 +175,7 @@ def main():
                 "launch_ms": round(ms_launch, 4), "launches": n_any, "rays_per_launch": round(rays_any / max(1, n_any)),
                 "bytes_per_ray": round(bytes_any / max(1, rays_any), 1), "grays_per_s": round(rays_any / (ms_any * 1e-3) / 1e9, 3) if ms_any > 0 else 0.0,
                 "closest_launch_ms": round(ms_cl / max(1, n_cl), 4), "closest_achieved": round(bytes_cl / (ms_cl * 1e-3) / 1e9, 2) if ms_cl > 0 else 0.0, "rays_per_pixel_sample": round(total_rays / (float(N) * prof_spp), 3),
+                "per_ray": {"any": [round(st[k] / max(1, rays_any), 2) for k in ("popped", "entered", "leaves")], "closest": [round(st[k] / max(1, rays_cl), 2) for k in ("cl_popped", "cl_entered", "cl_leaves")]},
                 "traversal_share_of_step": round((ms_any + ms_cl) / prof_spp * args.spp / (dt / args.steps * 1e3) * (world if world > 1 else 1), 3)}
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):

@@ -632,6 +632,7 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const
         for (int i = threadIdx.x; i < TOPN * 4; i += MR_TRACE_BLOCK) s_top[i] = src[i];
         __syncthreads();
     }
+    if (B.dbg && (threadIdx.x & 63) == 0) B.dbg[2 * (blockIdx.x * (MR_TRACE_BLOCK / 64) + (threadIdx.x >> 6))] = wall_clock64();
     uint32_t* const lds_stack = lds + threadIdx.x;
     const uint32_t n = d_count ? *d_count : n_fixed;
     const int lane = lane_id();
@@ -742,6 +743,7 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const
             }
         } while (__popcll(__ballot(have)) >= MR_REFILL || (exhausted && __ballot(have)));
     }
+    if (B.dbg && (threadIdx.x & 63) == 0) B.dbg[2 * (blockIdx.x * (MR_TRACE_BLOCK / 64) + (threadIdx.x >> 6)) + 1] = wall_clock64();
     if (COUNT && stats) { atomicAdd(&stats[2], c_boxes); atomicAdd(&stats[3], c_nodes); atomicAdd(&stats[4], c_leaves); }
     if (stats && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[0], (unsigned long long)n);
 }
@@ -1059,5 +1061,14 @@ extern "C" int mirres_bvh_trace(mirres_bvh_t* bvh, const float* rays, int n, int
         }
     }
     MR_LAUNCH_CHECK("mirres_bvh_trace");
+    return MIRRES_OK;
+}
+
+// development aid (not part of include/mirres.h): enable != 0 allocates the per-wave timestamp buffer read by k_trace_any4q; out (host, 2*16384 u64) receives it
+extern "C" int mirres_debug_wave_times(mirres_bvh_t* bvh, unsigned long long* out, int enable) {
+    if (!bvh) return MIRRES_E_ARG;
+    if (enable && !bvh->dbg) { MR_HIP(hipMalloc(&bvh->dbg, sizeof(unsigned long long) * 2 * 16384)); MR_HIP(hipMemset(bvh->dbg, 0, sizeof(unsigned long long) * 2 * 16384)); }
+    if (out && bvh->dbg) { MR_HIP(hipDeviceSynchronize()); MR_HIP(hipMemcpy(out, bvh->dbg, sizeof(unsigned long long) * 2 * 16384, hipMemcpyDeviceToHost)); }
+    if (!enable && bvh->dbg) { MR_HIP(hipFree(bvh->dbg)); bvh->dbg = nullptr; }
     return MIRRES_OK;
 }

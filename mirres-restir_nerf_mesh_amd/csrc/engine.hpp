@@ -62,6 +62,7 @@ struct BvhView {
     const Node4q* nodes4q; const LeafRec* leaves; const Node4q* top85q; const Node4q* top341q;   // compressed shadow-ray layout
     const Node4* top4;     // breadth-first copy of the first levels of nodes4 (341 entries), children inside it referenced as MR_TOPBIT | index
     int T;
+    unsigned long long* dbg;   // optional [2 * waves]: wall-clock start / end of every traversal wave (mirres_debug_wave_times)
 };
 
 }  // namespace mr
@@ -86,8 +87,9 @@ struct mirres_bvh {
     mr::Node4q* top85q = nullptr, *top341q = nullptr;   // [85], [341] breadth-first prefixes of nodes4q, children inside tagged MR_TOPBIT
     float* root_box = nullptr;      // [6]
     uint32_t* work = nullptr;       // [8 * MR_WSET] head sets of the persistent traversal kernels, set 5 word 0 = redo count
+    unsigned long long* dbg = nullptr;   // see BvhView::dbg
     uint32_t* redo = nullptr; size_t redo_cap = 0;   // ray ids handed back by the ordered closest-hit fast path
-    mr::BvhView view() const { mr::BvhView v; v.nodes = nodes; v.tris = tris; v.root_box = root_box; v.T = T; v.nodes4 = nodes4; v.top4 = top4; v.nodes4q = nodes4q; v.leaves = leaves; v.top85q = top85q; v.top341q = top341q; return v; }
+    mr::BvhView view() const { mr::BvhView v; v.nodes = nodes; v.tris = tris; v.root_box = root_box; v.T = T; v.nodes4 = nodes4; v.top4 = top4; v.nodes4q = nodes4q; v.leaves = leaves; v.top85q = top85q; v.top341q = top341q; v.dbg = dbg; return v; }
 };
 
 struct mirres_ctx {
@@ -112,6 +114,8 @@ struct mirres_ctx {
     float* tile_aux = nullptr;      // [tiles,4] per tile sample: light direction xyz + luminance of its radiance
     // frame buffers of the fused loop (mirres_render)
     float* pool = nullptr; size_t pool_floats = 0;
+    // K-sample batch of the path-tracing stages (mirres_render): queues + per-slot state for K * N sample slots
+    char* ptb = nullptr; size_t ptb_bytes = 0;
 };
 
 namespace mr {
@@ -127,5 +131,16 @@ int trace_closest_queue(const mirres_bvh* bvh, const Ray* rays, const uint32_t* 
                         unsigned long long* stats, hipStream_t s);
 int trace_any(mirres_ctx* ctx, mirres_bvh* bvh, size_t cap, hipStream_t s);       // ctx->any_rays -> ctx->any_hit
 int trace_closest(mirres_ctx* ctx, mirres_bvh* bvh, size_t cap, hipStream_t s);   // ctx->cl_rays  -> ctx->cl_hit
+// queues and per-slot scratch of the path-tracing stages: the context's own (one sample per pixel — the stepwise ABI) or a K-sample batch
+// (mirres_render): slot v = k * N + pixel holds sample k of the batch, so one launch carries K samples' rays.
+struct PtQueues {
+    Ray* any_rays; int32_t* any_hit; Ray* cl_rays; HitRec* cl_hit;
+    uint32_t* counters;                 // [0] shadow rays, [1] continuation rays, [2] material-net list
+    int32_t* slot_a; uint32_t* mask_a; int32_t* slot_c; float* pend;
+    int N, NV;                          // pixels, sample slots (K * N)
+    int first_sample_is_zero;           // sample 0 of the frame has one pass fewer before the path-tracing stages (no temporal pass)
+};
+int trace_any_q(mirres_ctx* ctx, mirres_bvh* bvh, const Ray* rays, const uint32_t* count, size_t cap, int32_t* hit, hipStream_t s);
+int trace_closest_q(mirres_ctx* ctx, mirres_bvh* bvh, const Ray* rays, const uint32_t* count, size_t cap, HitRec* out, hipStream_t s);
 inline int grid_for(size_t n, int block) { size_t g = (n + block - 1) / block; return (int)(g < 1 ? 1 : g); }
 }  // namespace mr

@@ -436,22 +436,24 @@ static int ev_pair(std::vector<hipEvent_t>& pool, size_t& used, hipEvent_t** a, 
     *a = &pool[used]; *b = &pool[used + 1]; used += 2;
     return 0;
 }
-int trace_any(mirres_ctx* ctx, mirres_bvh* bvh, size_t cap, hipStream_t s) {
+int trace_any_q(mirres_ctx* ctx, mirres_bvh* bvh, const Ray* rays, const uint32_t* count, size_t cap, int32_t* hit, hipStream_t s) {
     hipEvent_t *e0 = nullptr, *e1 = nullptr;
     if (ctx->instrument & 2) { int rc = ev_pair(ctx->ev_any, ctx->ev_any_used, &e0, &e1); if (rc) return rc; MR_HIP(hipEventRecord(*e0, s)); }
-    int rc = (ctx->instrument & 1) ? trace_any_queue_counted(bvh, ctx->any_rays, &ctx->counters[0], cap, ctx->any_hit, ctx->stats, s)
-                                   : trace_any_queue(bvh, ctx->any_rays, &ctx->counters[0], cap, ctx->any_hit, ctx->stats, s);
+    int rc = (ctx->instrument & 1) ? trace_any_queue_counted(bvh, rays, count, cap, hit, ctx->stats, s)
+                                   : trace_any_queue(bvh, rays, count, cap, hit, ctx->stats, s);
     if (e1) MR_HIP(hipEventRecord(*e1, s));
     return rc;
 }
-int trace_closest(mirres_ctx* ctx, mirres_bvh* bvh, size_t cap, hipStream_t s) {
+int trace_closest_q(mirres_ctx* ctx, mirres_bvh* bvh, const Ray* rays, const uint32_t* count, size_t cap, HitRec* out, hipStream_t s) {
     hipEvent_t *e0 = nullptr, *e1 = nullptr;
     if (ctx->instrument & 2) { int rc = ev_pair(ctx->ev_cl, ctx->ev_cl_used, &e0, &e1); if (rc) return rc; MR_HIP(hipEventRecord(*e0, s)); }
-    int rc = (ctx->instrument & 1) ? trace_closest_queue_counted(bvh, ctx->cl_rays, &ctx->counters[1], cap, ctx->cl_hit, ctx->stats, s)
-                                   : trace_closest_queue(bvh, ctx->cl_rays, &ctx->counters[1], cap, ctx->cl_hit, ctx->stats, s);
+    int rc = (ctx->instrument & 1) ? trace_closest_queue_counted(bvh, rays, count, cap, out, ctx->stats, s)
+                                   : trace_closest_queue(bvh, rays, count, cap, out, ctx->stats, s);
     if (e1) MR_HIP(hipEventRecord(*e1, s));
     return rc;
 }
+int trace_any(mirres_ctx* ctx, mirres_bvh* bvh, size_t cap, hipStream_t s) { return trace_any_q(ctx, bvh, ctx->any_rays, &ctx->counters[0], cap, ctx->any_hit, s); }
+int trace_closest(mirres_ctx* ctx, mirres_bvh* bvh, size_t cap, hipStream_t s) { return trace_closest_q(ctx, bvh, ctx->cl_rays, &ctx->counters[1], cap, ctx->cl_hit, s); }
 
 }  // namespace mr
 
@@ -492,7 +494,7 @@ int mirres_ctx_create(mirres_ctx_t** out, int fx, int fy, const mirres_config_t*
 
 void mirres_ctx_destroy(mirres_ctx_t* c) {
     if (!c) return;
-    void* ptrs[] = {c->any_rays, c->any_hit, c->cl_rays, c->cl_hit, c->counters, c->stats, c->slot_a, c->mask_a, c->slot_c, c->pend, c->noff, c->pool, c->tile_aux};
+    void* ptrs[] = {c->any_rays, c->any_hit, c->cl_rays, c->cl_hit, c->counters, c->stats, c->slot_a, c->mask_a, c->slot_c, c->pend, c->noff, c->pool, c->tile_aux, c->ptb};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t e : c->ev_any) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->ev_cl) (void)hipEventDestroy(e);

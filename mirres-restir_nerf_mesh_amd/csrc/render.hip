@@ -11,9 +11,9 @@ namespace mr {
 
 int launch_final_shading(const mirres_env_t* env, const float* occ, const float* normal, const float* ray_dir, const float* kd, const float* rm,
                          const float* fdir, const float* fdist, const float* fLi, int N, float* color, float* dl, float* sl, bool acc, hipStream_t s);
-int launch_new_dir(mirres_ctx* ctx, mirres_bvh* bvh, const mirres_path_t* p, uint32_t frameIndex, uint32_t bounce_count, hipStream_t s);
+int launch_new_dir(mirres_ctx* ctx, mirres_bvh* bvh, const mirres_path_t* p, uint32_t frameIndex, uint32_t bounce_count, hipStream_t s, const PtQueues* q);
 int launch_bounce(mirres_ctx* ctx, mirres_bvh* bvh, const mirres_env_t* env, const mirres_path_t* p, uint32_t frameIndex, uint32_t bounce_count, float* color,
-                  float* dc, float* sc, float* acc_c, float* acc_d, float* acc_s, hipStream_t s);
+                  float* dc, float* sc, float* acc_c, float* acc_d, float* acc_s, hipStream_t s, const PtQueues* q);
 int launch_matnet_scatter(const mirres_matnet_t* m, const float* occ, const float* pos, int n, float* kd, float* rm, int use_scale, const float* scale3,
                           const float* const_kd, const float* const_rm, hipStream_t s);
 int launch_matnet_scatter_mfma(const mirres_matnet_t* m, const float* occ, const float* pos, int n, float* kd, float* rm, int use_scale, const float* scale3,
@@ -67,6 +67,22 @@ __global__ void __launch_bounds__(MR_BLOCK) k_composite(int N, const float* __re
     }
 }
 
+// Adds a batch's indirect light to the frame totals in the order a sample-by-sample loop would: sample k ascending, bounce ascending
+// (renderer_restir.py:420-422, 450-452), so the sums are bit-identical to the unbatched loop. cb = [bounce][colour, diffuse, specular][NV * 3].
+__global__ void __launch_bounds__(MR_BLOCK) k_pt_reduce(int N, int K, int nb, const float* __restrict__ cb, float* __restrict__ t3, float* __restrict__ t4, float* __restrict__ t5) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t n3 = 3 * (size_t)N;
+    if (i >= n3) return;
+    const size_t nv3 = n3 * (size_t)K;
+    float a = t3[i], b = t4[i], c = t5[i];
+    for (int k = 0; k < K; k++)
+        for (int bo = 0; bo < nb; bo++) {
+            const float* base = cb + (size_t)bo * 3 * nv3 + (size_t)k * n3 + i;
+            a += base[0]; b += base[nv3]; c += base[2 * nv3];
+        }
+    t3[i] = a; t4[i] = b; t5[i] = c;
+}
+
 struct Pool {
     float* base; size_t used, cap;
     float* take(size_t n) { n = (n + 63) & ~(size_t)63; float* p = base + used; used += n; return used <= cap ? p : nullptr; }
@@ -112,6 +128,47 @@ static int carve(mirres_ctx* ctx, int Wc, int Hc, FrameBufs& B) {
     B.tile_data = P.take(3 * TS); B.tile_pdf = P.take(TS);
     B.den_a = P.take(3 * N); B.den_b = P.take(3 * N); B.comb = B.c1;  // comb reuses c1 after the loop
     if (!B.den_b) { set_error("mirres_render: internal pool too small"); return MIRRES_E_STATE; }
+    return 0;
+}
+
+// K-sample batch of the path-tracing stages: queues + per-slot path state for K * N sample slots, one allocation kept in the context
+struct PtBatch {
+    int K; PtQueues q;
+    float *prd, *pos[2], *rd[2], *occ[2], *n[2], *kd, *rm;
+    float* cb;      // [max_bounce][3][K * N * 3] per-bounce colour / diffuse / specular of every slot
+};
+static int pt_batch_size() {   // MIRRES_PT_BATCH = samples per path-tracing launch (default 16; 1 = sample by sample)
+    const char* e = getenv("MIRRES_PT_BATCH");   // read per frame (tests switch it)
+    int k = e ? atoi(e) : 16; if (k < 1) k = 1; if (k > 64) k = 64;
+    return k;
+}
+static int carve_batch(mirres_ctx* ctx, int N, int K, int max_bounce, PtBatch& PB) {
+    if (K < 1) K = 1;
+    while ((size_t)K * (size_t)N > 0x30000000ull && K > 1) K--;   // slot indices are 32-bit
+    const size_t NV = (size_t)K * (size_t)N;
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const int nb = max_bounce > 0 ? max_bounce : 1;
+    size_t need = al(sizeof(Ray) * 2 * NV) + al(4 * 2 * NV) + al(sizeof(Ray) * NV) + al(sizeof(HitRec) * NV) + al(64) + 3 * al(4 * NV) + al(4 * 18 * NV)
+                + al(4 * 5 * NV) + 2 * (3 * al(4 * 3 * NV) + al(4 * NV)) + al(4 * 3 * NV) + al(4 * 2 * NV) + al(4 * 9 * NV * (size_t)nb);
+    if (ctx->ptb_bytes < need) {
+        if (ctx->ptb) { MR_HIP(hipDeviceSynchronize()); MR_HIP(hipFree(ctx->ptb)); ctx->ptb = nullptr; ctx->ptb_bytes = 0; }
+        MR_HIP(hipMalloc(&ctx->ptb, need));
+        MR_HIP(hipMemset(ctx->ptb, 0, need));   // slots that never receive a vertex are read (and ignored) by the bounce kernels
+        ctx->ptb_bytes = need;
+    }
+    char* p = ctx->ptb;
+    auto take = [&](size_t b) { char* r = p; p += al(b); return r; };
+    PB.K = K;
+    PB.q.any_rays = (Ray*)take(sizeof(Ray) * 2 * NV); PB.q.any_hit = (int32_t*)take(4 * 2 * NV);
+    PB.q.cl_rays = (Ray*)take(sizeof(Ray) * NV); PB.q.cl_hit = (HitRec*)take(sizeof(HitRec) * NV);
+    PB.q.counters = (uint32_t*)take(64);
+    PB.q.slot_a = (int32_t*)take(4 * NV); PB.q.mask_a = (uint32_t*)take(4 * NV); PB.q.slot_c = (int32_t*)take(4 * NV);
+    PB.q.pend = (float*)take(4 * 18 * NV);
+    PB.q.N = N; PB.q.NV = (int)NV; PB.q.first_sample_is_zero = 0;
+    PB.prd = (float*)take(4 * 5 * NV);
+    for (int k = 0; k < 2; k++) { PB.pos[k] = (float*)take(4 * 3 * NV); PB.rd[k] = (float*)take(4 * 3 * NV); PB.n[k] = (float*)take(4 * 3 * NV); PB.occ[k] = (float*)take(4 * NV); }
+    PB.kd = (float*)take(4 * 3 * NV); PB.rm = (float*)take(4 * 2 * NV);
+    PB.cb = (float*)take(4 * 9 * NV * (size_t)nb);
     return 0;
 }
 
@@ -166,43 +223,55 @@ int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args
     const uint32_t passes = 20;  // mTotalRISPasses (:242)
     const int max_bounce = ctx->cfg.max_bounce;
 
-    for (int i = i0; i < i1; i++) {
-        uint32_t pass = 0;
-        const uint32_t base = a->random_offset + passes * (uint32_t)i;
-        rc = mirres_light_tiles(ctx, B.tex, Wc, Hc, B.pdf, B.cdf, B.mpdf, B.mcdf, base + pass, B.tile_data, nullptr, B.tile_pdf, s); if (rc) return rc;
-        pass += 2;
-        rc = mirres_restir_initial(ctx, bvh, &E, &G, &R[cur], B.tile_data, B.tile_pdf, base + pass, s); if (rc) return rc;
-        pass += 1;
-        if (i > 0) {
-            // prev_* G-buffers alias the current ones from the second sample on (:462-465); a rank that starts in the
-            // middle of the sample range (spp sharding) has no history yet and skips the merge but keeps the pass numbering
-            if (i > i0) { rc = mirres_restir_temporal(ctx, &E, &G, &G, &R[cur], &R[cur ^ 1], nullptr, base + pass, s); if (rc) return rc; }
+    // ---- K-sample batches. The ReSTIR stages of a sample need the previous sample's reservoirs (temporal reuse) and run one sample at a
+    // time; the path-tracing stages depend only on the G-buffer and the sample's RNG stream, so the K samples of a batch go through them
+    // together: K * N slots per launch. A traversal launch has a tail as long as its slowest rays (~0.1 ms) during which most CUs idle —
+    // a third of a 2.3 M-ray launch, a small fraction of a K-times larger one.
+    const int Kmax = pt_batch_size();
+    PtBatch PB; rc = carve_batch(ctx, N, Kmax < (i1 - i0) ? Kmax : (i1 - i0), max_bounce, PB); if (rc) return rc;
+    for (int ib = i0; ib < i1; ib += PB.K) {
+        const int kk = (i1 - ib < PB.K) ? (i1 - ib) : PB.K;
+        for (int i = ib; i < ib + kk; i++) {
+            uint32_t pass = 0;
+            const uint32_t base = a->random_offset + passes * (uint32_t)i;
+            rc = mirres_light_tiles(ctx, B.tex, Wc, Hc, B.pdf, B.cdf, B.mpdf, B.mcdf, base + pass, B.tile_data, nullptr, B.tile_pdf, s); if (rc) return rc;
+            pass += 2;
+            rc = mirres_restir_initial(ctx, bvh, &E, &G, &R[cur], B.tile_data, B.tile_pdf, base + pass, s); if (rc) return rc;
             pass += 1;
-        }
-        cur ^= 1;  // swap (:358)
-        rc = mirres_restir_spatial(ctx, bvh, &E, &G, &R[cur], &R[cur ^ 1], nullptr, base + pass, s); if (rc) return rc;
-        pass += 1;
-        rc = mirres_restir_final_vis(ctx, bvh, a->pos, &R[cur], B.vis, s); if (rc) return rc;
-        rc = mirres_restir_eval_final(ctx, &E, &R[cur], B.vis, B.fdir, B.fdist, B.fLi, s); if (rc) return rc;
-        rc = launch_final_shading(&E, a->occ, a->normal, B.ray_dir, a->kd, a->rough_metal, B.fdir, B.fdist, B.fLi, N, B.tot[0], B.tot[1], B.tot[2], true, s);
-        if (rc) return rc;
-        mirres_path_t P0 = {a->occ, a->pos, a->normal, B.ray_dir, a->kd, a->rough_metal, B.prd, B.new_pos, B.new_rd, B.new_occ, B.new_n};
-        rc = launch_new_dir(ctx, bvh, &P0, base + pass, 0, s); if (rc) return rc;
-        pass += 5;
-        float *cp = B.new_pos, *crd = B.new_rd, *cocc = B.new_occ, *cn = B.new_n;
-        float *np_ = B.tmp_pos, *nrd = B.tmp_rd, *nocc = B.tmp_occ, *nn = B.tmp_n;
-        for (int b = 1; b <= max_bounce; b++) {
-            // material lookup at the new vertices: compacted pixel list -> hash-grid gather -> MFMA MLP -> scatter (slot_c is free between passes)
-            if (a->mat) rc = launch_matnet_scatter_mfma(a->mat, cocc, cp, N, B.new_kd, B.new_rm, a->use_scale, a->scale, ctx->slot_c, &ctx->counters[2], s);
-            else rc = launch_matnet_scatter(nullptr, cocc, cp, N, B.new_kd, B.new_rm, a->use_scale, a->scale, a->const_kd, a->const_rm, s);
+            if (i > 0) {
+                // prev_* G-buffers alias the current ones from the second sample on (:462-465); a rank that starts in the
+                // middle of the sample range (spp sharding) has no history yet and skips the merge but keeps the pass numbering
+                if (i > i0) { rc = mirres_restir_temporal(ctx, &E, &G, &G, &R[cur], &R[cur ^ 1], nullptr, base + pass, s); if (rc) return rc; }
+                pass += 1;
+            }
+            cur ^= 1;  // swap (:358)
+            rc = mirres_restir_spatial(ctx, bvh, &E, &G, &R[cur], &R[cur ^ 1], nullptr, base + pass, s); if (rc) return rc;
+            pass += 1;
+            rc = mirres_restir_final_vis(ctx, bvh, a->pos, &R[cur], B.vis, s); if (rc) return rc;
+            rc = mirres_restir_eval_final(ctx, &E, &R[cur], B.vis, B.fdir, B.fdist, B.fLi, s); if (rc) return rc;
+            rc = launch_final_shading(&E, a->occ, a->normal, B.ray_dir, a->kd, a->rough_metal, B.fdir, B.fdist, B.fLi, N, B.tot[0], B.tot[1], B.tot[2], true, s);
             if (rc) return rc;
-            mirres_path_t Pb = {cocc, cp, cn, crd, B.new_kd, B.new_rm, B.prd, np_, nrd, nocc, nn};
-            rc = launch_bounce(ctx, bvh, &E, &Pb, base + pass, (uint32_t)b, B.c1, B.d1, B.s1, B.tot[3], B.tot[4], B.tot[5], s); if (rc) return rc;
-            pass += 5;
-            float* t;
-            t = cp; cp = np_; np_ = t; t = crd; crd = nrd; nrd = t; t = cocc; cocc = nocc; nocc = t; t = cn; cn = nn; nn = t;
+            cur ^= 1;  // swap back (:460)
         }
-        cur ^= 1;  // swap back (:460)
+        // ---- path-tracing stages of samples ib .. ib+kk-1 (new direction, then max_bounce indirect vertices)
+        PtQueues Q = PB.q; Q.NV = kk * N; Q.first_sample_is_zero = (ib == 0);
+        uint32_t fi = a->random_offset + passes * (uint32_t)ib + 5;   // pass number of new_dir for a sample with a temporal pass before it
+        mirres_path_t P0 = {a->occ, a->pos, a->normal, B.ray_dir, a->kd, a->rough_metal, PB.prd, PB.pos[0], PB.rd[0], PB.occ[0], PB.n[0]};
+        rc = launch_new_dir(ctx, bvh, &P0, fi, 0, s, &Q); if (rc) return rc;
+        fi += 5;
+        int src = 0;
+        for (int b = 1; b <= max_bounce; b++) {
+            // material lookup at the new vertices: compacted slot list -> hash-grid gather -> MFMA MLP -> scatter (slot_c is free between passes)
+            if (a->mat) rc = launch_matnet_scatter_mfma(a->mat, PB.occ[src], PB.pos[src], Q.NV, PB.kd, PB.rm, a->use_scale, a->scale, Q.slot_c, &Q.counters[2], s);
+            else rc = launch_matnet_scatter(nullptr, PB.occ[src], PB.pos[src], Q.NV, PB.kd, PB.rm, a->use_scale, a->scale, a->const_kd, a->const_rm, s);
+            if (rc) return rc;
+            mirres_path_t Pb = {PB.occ[src], PB.pos[src], PB.n[src], PB.rd[src], PB.kd, PB.rm, PB.prd, PB.pos[src ^ 1], PB.rd[src ^ 1], PB.occ[src ^ 1], PB.n[src ^ 1]};
+            float* cb = PB.cb + (size_t)(b - 1) * 9 * (size_t)Q.NV;
+            rc = launch_bounce(ctx, bvh, &E, &Pb, fi, (uint32_t)b, cb, cb + 3 * (size_t)Q.NV, cb + 6 * (size_t)Q.NV, nullptr, nullptr, nullptr, s, &Q); if (rc) return rc;
+            fi += 5;
+            src ^= 1;
+        }
+        if (max_bounce > 0) k_pt_reduce<<<grid_for(n3, MR_BLOCK), MR_BLOCK, 0, s>>>(N, kk, max_bounce, PB.cb, B.tot[3], B.tot[4], B.tot[5]);
     }
     if (partial) {
         for (int k = 0; k < 6; k++) MR_HIP(hipMemcpyAsync(a->outs[k], B.tot[k], sizeof(float) * n3, hipMemcpyDeviceToDevice, s));

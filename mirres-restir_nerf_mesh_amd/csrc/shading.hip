@@ -90,28 +90,35 @@ MR_DEV void next_bounce_resolve(const mirres_path_t& P, size_t pi, const HitRec*
 }
 
 // ---------------------------------------------------------------- process_new_dir_for_pt (FinalShading.slang:113-265)
+// Sample slots: thread v = k * N + pixel works on sample k of a K-sample batch (NV = K * N; K = 1 for the stepwise ABI). The vertex inputs of
+// new_dir are the G-buffer (one per pixel, shared by the K samples); the outputs and everything in the bounce kernels are per slot. The RNG
+// stream of a slot is the one its sample would get in a sample-by-sample loop: frameIndex + 20 * k (mTotalRISPasses), minus one for the
+// frame's very first sample, which has no temporal pass before it (renderer_restir.py:341-356).
+MR_DEV uint32_t slot_frame(uint32_t frameIndex, int k, int first_is_zero) { return frameIndex + 20u * (uint32_t)k - ((first_is_zero && k == 0) ? 1u : 0u); }
 __global__ void __launch_bounds__(MR_GEN_BLOCK) k_new_dir_gen(mirres_path_t P, int max_bounce, float vis_near, uint32_t frameIndex, uint32_t bounce_count, int fx,
-                                                          int N, Ray* __restrict__ q, uint32_t* __restrict__ q_count, int32_t* __restrict__ slot_out) {
-    const int pi = blockIdx.x * blockDim.x + threadIdx.x;
+                                                          int N, int NV, int first_is_zero, Ray* __restrict__ q, uint32_t* __restrict__ q_count, int32_t* __restrict__ slot_out) {
+    const int v_ = blockIdx.x * blockDim.x + threadIdx.x;
     bool want = false; v3 rp = V3(0.f), rdir = V3(0.f);
-    if (pi < N) {
-        v3 thr = V3(P.prd[5 * (size_t)pi], P.prd[5 * (size_t)pi + 1], P.prd[5 * (size_t)pi + 2]);
-        float is_stop = P.prd[5 * (size_t)pi + 4];
-        P.new_occ[pi] = 0.f; P.prd[5 * (size_t)pi + 4] = 1.f;
-        if (bounce_count == 0) { thr = V3(1.0f); is_stop = 0.f; P.prd[5 * (size_t)pi] = 1.f; P.prd[5 * (size_t)pi + 1] = 1.f; P.prd[5 * (size_t)pi + 2] = 1.f; P.prd[5 * (size_t)pi + 3] = 0.f; }
+    if (v_ < NV) {
+        const int k = v_ / N, pi = v_ - k * N;
+        const size_t sv = (size_t)v_;
+        v3 thr = V3(P.prd[5 * sv], P.prd[5 * sv + 1], P.prd[5 * sv + 2]);
+        float is_stop = P.prd[5 * sv + 4];
+        P.new_occ[sv] = 0.f; P.prd[5 * sv + 4] = 1.f;
+        if (bounce_count == 0) { thr = V3(1.0f); is_stop = 0.f; P.prd[5 * sv] = 1.f; P.prd[5 * sv + 1] = 1.f; P.prd[5 * sv + 2] = 1.f; P.prd[5 * sv + 3] = 0.f; }
         if (!(is_stop > 0.f) && P.occ[pi] > 0.1f) {
             Vertex v = load_vertex(P, pi);
-            uint32_t sg = seed_generator((uint32_t)(pi % fx), (uint32_t)(pi / fx), frameIndex);
+            uint32_t sg = seed_generator((uint32_t)(pi % fx), (uint32_t)(pi / fx), slot_frame(frameIndex, k, first_is_zero));
             shade::Lobes L = shade::lobes(v.diffuse, v.rough, v.metallic, v.rd, v.n);
             shade::Frame fr = shade::create_frame(v.n);
             v3 wi = shade::to_local(fr, -v.rd);
-            want = next_bounce_gen(P, pi, max_bounce, bounce_count, fr, L, wi, v.diffuse * (1.0f - v.metallic), thr, sg, rdir);
+            want = next_bounce_gen(P, sv, max_bounce, bounce_count, fr, L, wi, v.diffuse * (1.0f - v.metallic), thr, sg, rdir);
             rp = v.pos;
         }
     }
     uint32_t slot = block_append(q_count, want);
     if (want) put_ray(q, slot, rp, rdir, vis_near);
-    if (pi < N) slot_out[pi] = want ? (int32_t)slot : -1;
+    if (v_ < NV) slot_out[v_] = want ? (int32_t)slot : -1;
 }
 __global__ void __launch_bounds__(MR_BLOCK) k_new_dir_resolve(mirres_path_t P, int N, const int32_t* __restrict__ slot, const HitRec* __restrict__ rec) {
     const int pi = blockIdx.x * blockDim.x + threadIdx.x;
@@ -122,14 +129,15 @@ __global__ void __launch_bounds__(MR_BLOCK) k_new_dir_resolve(mirres_path_t P, i
 
 // ---------------------------------------------------------------- process_path_tracing_divided_no_grad (FinalShading.slang:641-1009)
 __global__ void __launch_bounds__(MR_GEN_BLOCK) k_bounce_gen(mirres_path_t P, EnvD E, int max_bounce, float vis_near, uint32_t frameIndex, uint32_t bounce_count,
-                                                         int fx, int N, float* __restrict__ color, float* __restrict__ diff_color, float* __restrict__ spec_color,
+                                                         int fx, int N, int NV, int first_is_zero, float* __restrict__ color, float* __restrict__ diff_color, float* __restrict__ spec_color,
                                                          Ray* __restrict__ qa, uint32_t* __restrict__ qa_count, Ray* __restrict__ qc, uint32_t* __restrict__ qc_count,
                                                          int32_t* __restrict__ slot_a, uint32_t* __restrict__ mask_out, int32_t* __restrict__ slot_c,
                                                          float* __restrict__ pend) {
-    const int pi = blockIdx.x * blockDim.x + threadIdx.x;
+    const int pi = blockIdx.x * blockDim.x + threadIdx.x;   // sample slot (all vertex data of a bounce is per slot)
     uint32_t mask = 0;  // bit0 NEE shadow ray, bit1 BSDF shadow ray, bit2 continuation ray
     v3 sp = V3(0.f), nee_dir = V3(0.f), bsdf_dir = V3(0.f), next_dir = V3(0.f);
-    if (pi < N) {
+    if (pi < NV) {
+        const int k_ = pi / N, px = pi - k_ * N;
         v3 thr = V3(P.prd[5 * (size_t)pi], P.prd[5 * (size_t)pi + 1], P.prd[5 * (size_t)pi + 2]);
         float specularBounce = P.prd[5 * (size_t)pi + 3];
         float is_stop = P.prd[5 * (size_t)pi + 4];
@@ -139,7 +147,7 @@ __global__ void __launch_bounds__(MR_GEN_BLOCK) k_bounce_gen(mirres_path_t P, En
         if (!(is_stop > 0.f)) {
             Vertex v = load_vertex(P, pi);
             sp = v.pos;
-            uint32_t sg = seed_generator((uint32_t)(pi % fx), (uint32_t)(pi / fx), frameIndex);
+            uint32_t sg = seed_generator((uint32_t)(px % fx), (uint32_t)(px / fx), slot_frame(frameIndex, k_, first_is_zero));
             if (P.occ[pi] > 0.1f) {
                 shade::Lobes L = shade::lobes(v.diffuse, v.rough, v.metallic, v.rd, v.n);
                 float lightPdf = 0.0f, scatteringPdf = 0.0f;
@@ -222,7 +230,7 @@ __global__ void __launch_bounds__(MR_GEN_BLOCK) k_bounce_gen(mirres_path_t P, En
     if (mask & 1u) put_ray(qa, base, sp, nee_dir, vis_near);
     if (mask & 2u) put_ray(qa, base + (mask & 1u), sp, bsdf_dir, vis_near);
     if (mask & 4u) put_ray(qc, cs, sp, next_dir, vis_near);
-    if (pi < N) { slot_a[pi] = na ? (int32_t)base : -1; mask_out[pi] = mask; slot_c[pi] = (mask & 4u) ? (int32_t)cs : -1; }
+    if (pi < NV) { slot_a[pi] = na ? (int32_t)base : -1; mask_out[pi] = mask; slot_c[pi] = (mask & 4u) ? (int32_t)cs : -1; }
 }
 
 template <bool ACC>
@@ -263,26 +271,34 @@ int launch_final_shading(const mirres_env_t* env, const float* occ, const float*
     MR_LAUNCH_CHECK("final_shading");
     return 0;
 }
-int launch_new_dir(mirres_ctx* ctx, mirres_bvh* bvh, const mirres_path_t* p, uint32_t frameIndex, uint32_t bounce_count, hipStream_t s) {
-    const int N = (int)ctx->N, grd = grid_for(N, MR_BLOCK);
-    MR_HIP(hipMemsetAsync(&ctx->counters[1], 0, sizeof(uint32_t), s));
-    k_new_dir_gen<<<grid_for(N, MR_GEN_BLOCK), MR_GEN_BLOCK, 0, s>>>(*p, ctx->cfg.max_bounce, ctx->cfg.vis_near, frameIndex, bounce_count, ctx->fx, N, ctx->cl_rays, &ctx->counters[1], ctx->slot_c);
-    int rc = trace_closest(ctx, bvh, (size_t)N, s);
+static PtQueues ctx_queues(mirres_ctx* ctx) {
+    PtQueues q; q.any_rays = ctx->any_rays; q.any_hit = ctx->any_hit; q.cl_rays = ctx->cl_rays; q.cl_hit = ctx->cl_hit; q.counters = ctx->counters;
+    q.slot_a = ctx->slot_a; q.mask_a = ctx->mask_a; q.slot_c = ctx->slot_c; q.pend = ctx->pend; q.N = (int)ctx->N; q.NV = (int)ctx->N; q.first_sample_is_zero = 0;
+    return q;
+}
+int launch_new_dir(mirres_ctx* ctx, mirres_bvh* bvh, const mirres_path_t* p, uint32_t frameIndex, uint32_t bounce_count, hipStream_t s, const PtQueues* qq) {
+    const PtQueues Q = qq ? *qq : ctx_queues(ctx);
+    const int NV = Q.NV, grd = grid_for(NV, MR_BLOCK);
+    MR_HIP(hipMemsetAsync(&Q.counters[1], 0, sizeof(uint32_t), s));
+    k_new_dir_gen<<<grid_for(NV, MR_GEN_BLOCK), MR_GEN_BLOCK, 0, s>>>(*p, ctx->cfg.max_bounce, ctx->cfg.vis_near, frameIndex, bounce_count, ctx->fx, Q.N, NV, Q.first_sample_is_zero,
+                                                                       Q.cl_rays, &Q.counters[1], Q.slot_c);
+    int rc = trace_closest_q(ctx, bvh, Q.cl_rays, &Q.counters[1], (size_t)NV, Q.cl_hit, s);
     if (rc) return rc;
-    k_new_dir_resolve<<<grd, MR_BLOCK, 0, s>>>(*p, N, ctx->slot_c, ctx->cl_hit);
+    k_new_dir_resolve<<<grd, MR_BLOCK, 0, s>>>(*p, NV, Q.slot_c, Q.cl_hit);
     MR_LAUNCH_CHECK("pt_new_dir");
     return 0;
 }
 int launch_bounce(mirres_ctx* ctx, mirres_bvh* bvh, const mirres_env_t* env, const mirres_path_t* p, uint32_t frameIndex, uint32_t bounce_count, float* color,
-                  float* dc, float* sc, float* acc_c, float* acc_d, float* acc_s, hipStream_t s) {
-    const int N = (int)ctx->N, grd = grid_for(N, MR_BLOCK);
-    MR_HIP(hipMemsetAsync(&ctx->counters[0], 0, 2 * sizeof(uint32_t), s));
-    k_bounce_gen<<<grid_for(N, MR_GEN_BLOCK), MR_GEN_BLOCK, 0, s>>>(*p, envh(env), ctx->cfg.max_bounce, ctx->cfg.vis_near, frameIndex, bounce_count, ctx->fx, N, color, dc, sc, ctx->any_rays,
-                                           &ctx->counters[0], ctx->cl_rays, &ctx->counters[1], ctx->slot_a, ctx->mask_a, ctx->slot_c, ctx->pend);
-    int rc = trace_any(ctx, bvh, 2 * (size_t)N, s); if (rc) return rc;
-    rc = trace_closest(ctx, bvh, (size_t)N, s); if (rc) return rc;
-    if (acc_c) k_bounce_resolve<true><<<grd, MR_BLOCK, 0, s>>>(*p, N, ctx->slot_a, ctx->mask_a, ctx->slot_c, ctx->any_hit, ctx->cl_hit, ctx->pend, color, dc, sc, acc_c, acc_d, acc_s);
-    else k_bounce_resolve<false><<<grd, MR_BLOCK, 0, s>>>(*p, N, ctx->slot_a, ctx->mask_a, ctx->slot_c, ctx->any_hit, ctx->cl_hit, ctx->pend, color, dc, sc, nullptr, nullptr, nullptr);
+                  float* dc, float* sc, float* acc_c, float* acc_d, float* acc_s, hipStream_t s, const PtQueues* qq) {
+    const PtQueues Q = qq ? *qq : ctx_queues(ctx);
+    const int NV = Q.NV, grd = grid_for(NV, MR_BLOCK);
+    MR_HIP(hipMemsetAsync(&Q.counters[0], 0, 2 * sizeof(uint32_t), s));
+    k_bounce_gen<<<grid_for(NV, MR_GEN_BLOCK), MR_GEN_BLOCK, 0, s>>>(*p, envh(env), ctx->cfg.max_bounce, ctx->cfg.vis_near, frameIndex, bounce_count, ctx->fx, Q.N, NV, Q.first_sample_is_zero,
+                                                                      color, dc, sc, Q.any_rays, &Q.counters[0], Q.cl_rays, &Q.counters[1], Q.slot_a, Q.mask_a, Q.slot_c, Q.pend);
+    int rc = trace_any_q(ctx, bvh, Q.any_rays, &Q.counters[0], 2 * (size_t)NV, Q.any_hit, s); if (rc) return rc;
+    rc = trace_closest_q(ctx, bvh, Q.cl_rays, &Q.counters[1], (size_t)NV, Q.cl_hit, s); if (rc) return rc;
+    if (acc_c) k_bounce_resolve<true><<<grd, MR_BLOCK, 0, s>>>(*p, NV, Q.slot_a, Q.mask_a, Q.slot_c, Q.any_hit, Q.cl_hit, Q.pend, color, dc, sc, acc_c, acc_d, acc_s);
+    else k_bounce_resolve<false><<<grd, MR_BLOCK, 0, s>>>(*p, NV, Q.slot_a, Q.mask_a, Q.slot_c, Q.any_hit, Q.cl_hit, Q.pend, color, dc, sc, nullptr, nullptr, nullptr);
     MR_LAUNCH_CHECK("pt_bounce");
     return 0;
 }
@@ -305,13 +321,13 @@ int mirres_final_shading(mirres_ctx_t* ctx, const mirres_env_t* env, const float
 
 int mirres_pt_new_dir(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_path_t* p, uint32_t frameIndex, uint32_t bounce_count, void* stream) {
     if (!ctx || !bvh || !p) { set_error("mirres_pt_new_dir: null"); return MIRRES_E_ARG; }
-    return launch_new_dir(ctx, bvh, p, frameIndex, bounce_count, (hipStream_t)stream);
+    return launch_new_dir(ctx, bvh, p, frameIndex, bounce_count, (hipStream_t)stream, nullptr);
 }
 
 int mirres_pt_bounce(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_env_t* env, const mirres_path_t* p, uint32_t frameIndex,
                      uint32_t bounce_count, float* color, float* diff_color, float* spec_color, void* stream) {
     if (!ctx || !bvh || !env || !p || !color || !diff_color || !spec_color) { set_error("mirres_pt_bounce: null"); return MIRRES_E_ARG; }
-    return launch_bounce(ctx, bvh, env, p, frameIndex, bounce_count, color, diff_color, spec_color, nullptr, nullptr, nullptr, (hipStream_t)stream);
+    return launch_bounce(ctx, bvh, env, p, frameIndex, bounce_count, color, diff_color, spec_color, nullptr, nullptr, nullptr, (hipStream_t)stream, nullptr);
 }
 
 }  // extern "C"
