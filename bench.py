@@ -155,27 +155,35 @@ def main():
         def frame(n):
             occ = g["occ"].clone()
             RR.render_fused(ctx, W, mlp, False, (1, 1, 1), env, occ, g["normal"], g["depth"], g["kd"], g["rm"], g["ray_dir"], g["pos"], n, 2, 2, 2.0, 0.1, 0.001, 12345)
-        # (a) node-visit counts of exactly these rays from the instrumented kernel variant (deterministic; untimed)
-        ctx.set_instrument(1); ctx.stats(reset=True); frame(prof_spp); st = ctx.stats(reset=True)
+        # (a) visit counts of exactly these rays (deterministic; untimed): the reference traversal's own counts ("the reference node
+        #     layout as the accounting basis regardless of the build's internal layout", counts of bvh_hit's order on the same ray set) and the
+        #     production kernel's (64-byte records it fetches from global memory)
+        ctx.set_instrument(5); ctx.stats(reset=True); frame(prof_spp); st = ctx.stats(reset=True)
+        ctx.set_instrument(1); ctx.stats(reset=True); frame(prof_spp); own = ctx.stats(reset=True)
         # (b) event-timed launches of the production kernels on the same rays
         ctx.set_instrument(2); ctx.trace_time(); frame(prof_spp); ms_any, n_any, ms_cl, n_cl = ctx.trace_time()
         ctx.set_instrument(0)
         rays_any, rays_cl = st["rays_any"], st["rays_closest"]
-        # algorithmic bytes (reference node layout as the accounting basis): per ray 24 (o,d) + 12 (root info) + result,
-        # 24 per popped node (aabb) + 24 per entered internal node (two child infos) + 48 per tested leaf (indices + vertices).
-        # For the any-hit kernel the three counts are what THE PRODUCTION TRAVERSAL itself does (boxes slab-tested, internal nodes fetched, triangles
-        # tested, counted by its own instrumented instantiation: near-first order, early exit) — skipped work is never credited.
+        # algorithmic bytes: per ray 24 (o,d) + 12 (root info) + result, 24 per popped node (aabb) + 24 per entered internal node
+        # (two child infos) + 48 per tested leaf (indices + vertices), with the reference traversal's counts.
         total_rays = rays_any + rays_cl
         bytes_any = 24.0 * st["popped"] + 24.0 * st["entered"] + 48.0 * st["leaves"] + rays_any * (24 + 12 + 4)
         bytes_cl = 24.0 * st["cl_popped"] + 24.0 * st["cl_entered"] + 48.0 * st["cl_leaves"] + rays_cl * (24 + 12 + 28)
+        own_bytes_any = 64.0 * own["entered"] + rays_any * (32 + 4)      # compressed 64-byte node / leaf records + the 32-byte ray + result
         ms_launch = ms_any / max(1, n_any)
         achieved = bytes_any / (ms_any * 1e-3) / 1e9 if ms_any > 0 else 0.0
-        roof = {"bound": "hbm", "kernel": "k_trace_any (shadow-ray BVH traversal)", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
+        own_achieved = own_bytes_any / (ms_any * 1e-3) / 1e9 if ms_any > 0 else 0.0
+        roof = {"bound": "hbm", "kernel": "k_trace_any4q (shadow-ray BVH traversal)", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 5), "traffic": None,
                 "launch_ms": round(ms_launch, 4), "launches": n_any, "rays_per_launch": round(rays_any / max(1, n_any)),
                 "bytes_per_ray": round(bytes_any / max(1, rays_any), 1), "grays_per_s": round(rays_any / (ms_any * 1e-3) / 1e9, 3) if ms_any > 0 else 0.0,
+                "own_bytes_per_ray": round(own_bytes_any / max(1, rays_any), 1), "own_achieved": round(own_achieved, 2), "own_frac": round(own_achieved / 8000.0, 5),
+                "note": "achieved = SURVEY 8d algorithmic bytes (reference layout, reference traversal's visit counts on the same rays) / event-timed duration; "
+                        "it exceeds the HBM peak because the production kernel stops at the first occluder, walks a 4-wide tree near-first and fetches 64-byte compressed "
+                        "records (own_*: the bytes it actually requests), and the 43 MB layout is cache resident (traffic = HBM bytes from PMC); the kernel is VALU-issue bound",
                 "closest_launch_ms": round(ms_cl / max(1, n_cl), 4), "closest_achieved": round(bytes_cl / (ms_cl * 1e-3) / 1e9, 2) if ms_cl > 0 else 0.0, "rays_per_pixel_sample": round(total_rays / (float(N) * prof_spp), 3),
-                "per_ray": {"any": [round(st[k] / max(1, rays_any), 2) for k in ("popped", "entered", "leaves")], "closest": [round(st[k] / max(1, rays_cl), 2) for k in ("cl_popped", "cl_entered", "cl_leaves")]},
+                "per_ray": {"any_reference": [round(st[k] / max(1, rays_any), 2) for k in ("popped", "entered", "leaves")], "any_production": [round(own[k] / max(1, rays_any), 2) for k in ("popped", "entered", "leaves")],
+                            "closest": [round(st[k] / max(1, rays_cl), 2) for k in ("cl_popped", "cl_entered", "cl_leaves")]},
                 "traversal_share_of_step": round((ms_any + ms_cl) / prof_spp * args.spp / (dt / args.steps * 1e3) * (world if world > 1 else 1), 3)}
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):

@@ -70,7 +70,9 @@ int mirres_neighbor_offsets(mirres_ctx_t* ctx, float* out, void* stream);
  * kernel and (popped, entered, leaves) of the closest-hit kernel — the node counts only advance while instrument bit 0 is set. */
 int mirres_ctx_stats(mirres_ctx_t* ctx, uint64_t* h_out, int reset);
 /* instrument bit 0: traversal kernels count visited nodes into the stats (slower kernels); bit 1: every traversal launch is
- * bracketed by HIP events on its own stream so that mirres_ctx_trace_time can report per-kernel durations.              */
+ * bracketed by HIP events on its own stream so that mirres_ctx_trace_time can report per-kernel durations; bit 2 (with bit 0):
+ * shadow rays are counted by the reference-order traversal (bvh_hit's own visits, helperDi.slang:197-274) instead of the
+ * production kernel's. Instrumented frames run on one stream.                                                           */
 int mirres_ctx_set_instrument(mirres_ctx_t* ctx, int on);
 /* sums the event-timed traversal launches since the last call (host; synchronises): ms and launch counts for the any-hit
  * and the closest-hit kernel.                                                                                         */

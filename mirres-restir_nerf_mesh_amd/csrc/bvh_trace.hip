@@ -686,7 +686,7 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const
                 } else {
                     const uint4* __restrict__ nd = leaf ? reinterpret_cast<const uint4*>(B.leaves + ~cur) : reinterpret_cast<const uint4*>(B.nodes4q + cur);
                     h0 = nd[0]; h1 = nd[1]; h2 = nd[2]; rf = nd[3];
-                    if (COUNT && !leaf) c_nodes++;    // only global fetches are charged
+                    if (COUNT) c_nodes++;    // 64-byte records fetched from global memory (nodes served from LDS are not charged)
                 }
                 bool hit = false;
                 int next = 0x7fffffff; float next_tn = 0.f;
@@ -995,25 +995,32 @@ static int trace_grid(size_t capacity) {
 }
 
 int trace_any_queue(const mirres_bvh* bvh, const Ray* rays, const uint32_t* d_count, size_t capacity, int32_t* hit,
-                    unsigned long long* stats, hipStream_t s) {
-    MR_HIP(hipMemsetAsync(bvh->work, 0, MR_WSET * sizeof(uint32_t), s));
-    if (any_mode() == 8) launch_any4q<false>(bvh, persist_grid(capacity), rays, d_count, (uint32_t)capacity, bvh->work, hit, stats, s);
-    else if (any_mode() == 4) launch_any4<false>(bvh, persist_grid(capacity), rays, d_count, (uint32_t)capacity, bvh->work, hit, stats, s);
-    else k_trace_any_fast<false><<<persist_grid(capacity), MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, d_count, (uint32_t)capacity, bvh->work, hit, stats);
+                    unsigned long long* stats, hipStream_t s, int lane) {
+    uint32_t* const heads = bvh->work + (lane ? 7 : 0) * MR_WSET;   // launches that may overlap on two streams use different head sets
+    MR_HIP(hipMemsetAsync(heads, 0, MR_WSET * sizeof(uint32_t), s));
+    if (any_mode() == 8) launch_any4q<false>(bvh, persist_grid(capacity), rays, d_count, (uint32_t)capacity, heads, hit, stats, s);
+    else if (any_mode() == 4) launch_any4<false>(bvh, persist_grid(capacity), rays, d_count, (uint32_t)capacity, heads, hit, stats, s);
+    else k_trace_any_fast<false><<<persist_grid(capacity), MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, d_count, (uint32_t)capacity, heads, hit, stats);
     MR_LAUNCH_CHECK("trace_any_queue");
     return 0;
 }
 int trace_closest_queue(const mirres_bvh* bvh, const Ray* rays, const uint32_t* d_count, size_t capacity, HitRec* out,
-                        unsigned long long* stats, hipStream_t s) {
+                        unsigned long long* stats, hipStream_t s, int lane) {
     if (closest_mode() == 4) return closest_fast<false>(const_cast<mirres_bvh*>(bvh), rays, d_count, capacity, out, nullptr, nullptr, nullptr, nullptr, nullptr, stats, s);
-    MR_HIP(hipMemsetAsync(bvh->work + 1 * MR_WSET, 0, MR_WSET * sizeof(uint32_t), s));
-    k_trace_persist<false><<<persist_grid(capacity), MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, d_count, (uint32_t)capacity, bvh->work + 1 * MR_WSET, nullptr, out,
+    uint32_t* const heads = bvh->work + (lane ? 8 : 1) * MR_WSET;
+    MR_HIP(hipMemsetAsync(heads, 0, MR_WSET * sizeof(uint32_t), s));
+    k_trace_persist<false><<<persist_grid(capacity), MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, d_count, (uint32_t)capacity, heads, nullptr, out,
                                                                              nullptr, nullptr, nullptr, nullptr, stats);
     MR_LAUNCH_CHECK("trace_closest_queue");
     return 0;
 }
 int trace_any_queue_counted(const mirres_bvh* bvh, const Ray* rays, const uint32_t* d_count, size_t capacity, int32_t* hit,
-                            unsigned long long* stats, hipStream_t s) {
+                            unsigned long long* stats, hipStream_t s, int reference_order) {
+    if (reference_order) {   // visit counts of the reference's own traversal (bvh_hit order, no early exit) on the same rays — SURVEY §8d's accounting basis
+        k_trace_any<true><<<trace_grid(capacity), MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, d_count, (uint32_t)capacity, hit, nullptr, stats);
+        MR_LAUNCH_CHECK("trace_any_queue_counted(ref)");
+        return 0;
+    }
     MR_HIP(hipMemsetAsync(bvh->work, 0, MR_WSET * sizeof(uint32_t), s));
     if (any_mode() == 8) launch_any4q<true>(bvh, persist_grid(capacity), rays, d_count, (uint32_t)capacity, bvh->work, hit, stats, s);
     else if (any_mode() == 4) launch_any4<true>(bvh, persist_grid(capacity), rays, d_count, (uint32_t)capacity, bvh->work, hit, stats, s);

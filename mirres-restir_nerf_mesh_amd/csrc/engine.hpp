@@ -86,7 +86,7 @@ struct mirres_bvh {
     mr::LeafRec* leaves = nullptr;  // [T]
     mr::Node4q* top85q = nullptr, *top341q = nullptr;   // [85], [341] breadth-first prefixes of nodes4q, children inside tagged MR_TOPBIT
     float* root_box = nullptr;      // [6]
-    uint32_t* work = nullptr;       // [8 * MR_WSET] head sets of the persistent traversal kernels, set 5 word 0 = redo count
+    uint32_t* work = nullptr;       // [10 * MR_WSET] head sets of the persistent traversal kernels (0/1 frame loop, 2/3 API, 4-6 ordered closest + redo, 7/8 second stream)
     unsigned long long* dbg = nullptr;   // see BvhView::dbg
     uint32_t* redo = nullptr; size_t redo_cap = 0;   // ray ids handed back by the ordered closest-hit fast path
     mr::BvhView view() const { mr::BvhView v; v.nodes = nodes; v.tris = tris; v.root_box = root_box; v.T = T; v.nodes4 = nodes4; v.top4 = top4; v.nodes4q = nodes4q; v.leaves = leaves; v.top85q = top85q; v.top341q = top341q; v.dbg = dbg; return v; }
@@ -116,6 +116,7 @@ struct mirres_ctx {
     float* pool = nullptr; size_t pool_floats = 0;
     // K-sample batch of the path-tracing stages (mirres_render): queues + per-slot state for K * N sample slots
     char* ptb = nullptr; size_t ptb_bytes = 0;
+    hipStream_t aux_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // second stream of mirres_render (path-tracing stages)
 };
 
 namespace mr {
@@ -126,9 +127,9 @@ int check_hip(hipError_t e, const char* what);
 
 // queue tracing (bvh_trace.hip). count is read on the device; capacity bounds the grid-stride loop.
 int trace_any_queue(const mirres_bvh* bvh, const Ray* rays, const uint32_t* d_count, size_t capacity, int32_t* hit,
-                    unsigned long long* stats, hipStream_t s);
+                    unsigned long long* stats, hipStream_t s, int lane = 0);
 int trace_closest_queue(const mirres_bvh* bvh, const Ray* rays, const uint32_t* d_count, size_t capacity, HitRec* out,
-                        unsigned long long* stats, hipStream_t s);
+                        unsigned long long* stats, hipStream_t s, int lane = 0);
 int trace_any(mirres_ctx* ctx, mirres_bvh* bvh, size_t cap, hipStream_t s);       // ctx->any_rays -> ctx->any_hit
 int trace_closest(mirres_ctx* ctx, mirres_bvh* bvh, size_t cap, hipStream_t s);   // ctx->cl_rays  -> ctx->cl_hit
 // queues and per-slot scratch of the path-tracing stages: the context's own (one sample per pixel — the stepwise ABI) or a K-sample batch
@@ -138,9 +139,10 @@ struct PtQueues {
     uint32_t* counters;                 // [0] shadow rays, [1] continuation rays, [2] material-net list
     int32_t* slot_a; uint32_t* mask_a; int32_t* slot_c; float* pend;
     int N, NV;                          // pixels, sample slots (K * N)
+    int lane;                           // 1: launched on the context's second stream (own traversal head sets)
     int first_sample_is_zero;           // sample 0 of the frame has one pass fewer before the path-tracing stages (no temporal pass)
 };
-int trace_any_q(mirres_ctx* ctx, mirres_bvh* bvh, const Ray* rays, const uint32_t* count, size_t cap, int32_t* hit, hipStream_t s);
-int trace_closest_q(mirres_ctx* ctx, mirres_bvh* bvh, const Ray* rays, const uint32_t* count, size_t cap, HitRec* out, hipStream_t s);
+int trace_any_q(mirres_ctx* ctx, mirres_bvh* bvh, const Ray* rays, const uint32_t* count, size_t cap, int32_t* hit, hipStream_t s, int lane = 0);
+int trace_closest_q(mirres_ctx* ctx, mirres_bvh* bvh, const Ray* rays, const uint32_t* count, size_t cap, HitRec* out, hipStream_t s, int lane = 0);
 inline int grid_for(size_t n, int block) { size_t g = (n + block - 1) / block; return (int)(g < 1 ? 1 : g); }
 }  // namespace mr

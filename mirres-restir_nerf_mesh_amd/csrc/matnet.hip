@@ -173,7 +173,7 @@ MR_DEV int mfma_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 *
 // MODE 0: features given (enc_in fp16 [n,32]) -> out6[n,6];  MODE 1: positions of the compacted pixel list -> scatter kd / (rough, metal)
 // NT = 32-point tiles per wave, processed in lock-step so that NT independent accumulator chains keep the matrix pipe busy while the
 // previous MFMA of the same chain drains (a dependent 32x32x16 MFMA cannot issue back-to-back).
-MR_DEV float relu1(float x) { float r; asm volatile("v_max_f32 %0, %1, 0" : "=v"(r) : "v"(x)); return r; }  // plain v_max (hipcc adds a canonicalising max to fmaxf)
+MR_DEV float relu1(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, __builtin_huge_valf()); }  // one v_med3 (fmaxf costs an extra canonicalising max); no inline asm: the MFMA->VALU hazard tracking must see the read
 
 template <int MODE, int NT>
 __global__ void __launch_bounds__(MR_BLOCK) k_mlp_mfma(MatNetD M, GridLevels L, const uint16_t* __restrict__ enc_in, const float* __restrict__ pos,

@@ -12,7 +12,7 @@
 namespace mr {
 
 int trace_any_queue_counted(const mirres_bvh* bvh, const Ray* rays, const uint32_t* d_count, size_t capacity, int32_t* hit,
-                            unsigned long long* stats, hipStream_t s);
+                            unsigned long long* stats, hipStream_t s, int reference_order);
 
 #define MR_BLOCK 256
 #define MR_GEN_BLOCK 1024   // ray-generating kernels: one queue atomic per 1024 pixels
@@ -436,19 +436,19 @@ static int ev_pair(std::vector<hipEvent_t>& pool, size_t& used, hipEvent_t** a, 
     *a = &pool[used]; *b = &pool[used + 1]; used += 2;
     return 0;
 }
-int trace_any_q(mirres_ctx* ctx, mirres_bvh* bvh, const Ray* rays, const uint32_t* count, size_t cap, int32_t* hit, hipStream_t s) {
+int trace_any_q(mirres_ctx* ctx, mirres_bvh* bvh, const Ray* rays, const uint32_t* count, size_t cap, int32_t* hit, hipStream_t s, int lane) {
     hipEvent_t *e0 = nullptr, *e1 = nullptr;
     if (ctx->instrument & 2) { int rc = ev_pair(ctx->ev_any, ctx->ev_any_used, &e0, &e1); if (rc) return rc; MR_HIP(hipEventRecord(*e0, s)); }
-    int rc = (ctx->instrument & 1) ? trace_any_queue_counted(bvh, rays, count, cap, hit, ctx->stats, s)
-                                   : trace_any_queue(bvh, rays, count, cap, hit, ctx->stats, s);
+    int rc = (ctx->instrument & 1) ? trace_any_queue_counted(bvh, rays, count, cap, hit, ctx->stats, s, (ctx->instrument & 4) != 0)
+                                   : trace_any_queue(bvh, rays, count, cap, hit, ctx->stats, s, lane);
     if (e1) MR_HIP(hipEventRecord(*e1, s));
     return rc;
 }
-int trace_closest_q(mirres_ctx* ctx, mirres_bvh* bvh, const Ray* rays, const uint32_t* count, size_t cap, HitRec* out, hipStream_t s) {
+int trace_closest_q(mirres_ctx* ctx, mirres_bvh* bvh, const Ray* rays, const uint32_t* count, size_t cap, HitRec* out, hipStream_t s, int lane) {
     hipEvent_t *e0 = nullptr, *e1 = nullptr;
     if (ctx->instrument & 2) { int rc = ev_pair(ctx->ev_cl, ctx->ev_cl_used, &e0, &e1); if (rc) return rc; MR_HIP(hipEventRecord(*e0, s)); }
     int rc = (ctx->instrument & 1) ? trace_closest_queue_counted(bvh, rays, count, cap, out, ctx->stats, s)
-                                   : trace_closest_queue(bvh, rays, count, cap, out, ctx->stats, s);
+                                   : trace_closest_queue(bvh, rays, count, cap, out, ctx->stats, s, lane);
     if (e1) MR_HIP(hipEventRecord(*e1, s));
     return rc;
 }
@@ -498,6 +498,9 @@ void mirres_ctx_destroy(mirres_ctx_t* c) {
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t e : c->ev_any) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->ev_cl) (void)hipEventDestroy(e);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     delete c;
 }
 

@@ -2,6 +2,8 @@
 // (nerf/renderer_restir.py:230-550). The reference issues ~60 launches + 2 torch.where syncs + 9 accumulate kernels per
 // spp from Python; here one C call enqueues the spp loop on a stream, accumulations are fused into the producing kernels,
 // the material net scatters in place (no index tensors), and nothing synchronises with the host.
+#include <cstdio>
+#include <cstdlib>
 #include "engine.hpp"
 #include "device_math.hpp"
 
@@ -83,6 +85,13 @@ __global__ void __launch_bounds__(MR_BLOCK) k_pt_reduce(int N, int K, int nb, co
     t3[i] = a; t4[i] = b; t5[i] = c;
 }
 
+// development aid: order-independent checksum of a buffer (MIRRES_DBG_SUM=1 prints one line per ReSTIR stage and sample to stderr)
+__global__ void __launch_bounds__(MR_BLOCK) k_checksum(const uint32_t* __restrict__ p, size_t n, unsigned long long* out) {
+    unsigned long long acc = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) acc += (unsigned long long)p[i] * (unsigned long long)((i % 1021) + 1);
+    atomicAdd(out, acc);
+}
+
 struct Pool {
     float* base; size_t used, cap;
     float* take(size_t n) { n = (n + 63) & ~(size_t)63; float* p = base + used; used += n; return used <= cap ? p : nullptr; }
@@ -142,6 +151,7 @@ static int pt_batch_size() {   // MIRRES_PT_BATCH = samples per path-tracing lau
     int k = e ? atoi(e) : 16; if (k < 1) k = 1; if (k > 64) k = 64;
     return k;
 }
+static bool use_two_streams() { const char* e = getenv("MIRRES_STREAMS"); return !(e && e[0] == '1'); }   // MIRRES_STREAMS=1: everything on the caller's stream
 static int carve_batch(mirres_ctx* ctx, int N, int K, int max_bounce, PtBatch& PB) {
     if (K < 1) K = 1;
     while ((size_t)K * (size_t)N > 0x30000000ull && K > 1) K--;   // slot indices are 32-bit
@@ -164,7 +174,7 @@ static int carve_batch(mirres_ctx* ctx, int N, int K, int max_bounce, PtBatch& P
     PB.q.counters = (uint32_t*)take(64);
     PB.q.slot_a = (int32_t*)take(4 * NV); PB.q.mask_a = (uint32_t*)take(4 * NV); PB.q.slot_c = (int32_t*)take(4 * NV);
     PB.q.pend = (float*)take(4 * 18 * NV);
-    PB.q.N = N; PB.q.NV = (int)NV; PB.q.first_sample_is_zero = 0;
+    PB.q.N = N; PB.q.NV = (int)NV; PB.q.first_sample_is_zero = 0; PB.q.lane = 0;
     PB.prd = (float*)take(4 * 5 * NV);
     for (int k = 0; k < 2; k++) { PB.pos[k] = (float*)take(4 * 3 * NV); PB.rd[k] = (float*)take(4 * 3 * NV); PB.n[k] = (float*)take(4 * 3 * NV); PB.occ[k] = (float*)take(4 * NV); }
     PB.kd = (float*)take(4 * 3 * NV); PB.rm = (float*)take(4 * 2 * NV);
@@ -229,6 +239,24 @@ int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args
     // a third of a 2.3 M-ray launch, a small fraction of a K-times larger one.
     const int Kmax = pt_batch_size();
     PtBatch PB; rc = carve_batch(ctx, N, Kmax < (i1 - i0) ? Kmax : (i1 - i0), max_bounce, PB); if (rc) return rc;
+    // The two branches share only read-only inputs (G-buffer, environment tables, BVH) and write different totals (0..2 / 3..5), so the
+    // path-tracing batches go to a second stream: their large launches fill the CUs the small per-sample ReSTIR launches leave idle, and the
+    // launch gaps of one stream are covered by the other. Instrumented frames (counters / per-launch event timing) stay on one stream.
+    hipStream_t sp = s;
+    const bool two_streams = use_two_streams() && ctx->instrument == 0;
+    if (two_streams) {
+        if (!ctx->aux_stream) {
+            MR_HIP(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+            MR_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming)); MR_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+        }
+        sp = ctx->aux_stream;
+        MR_HIP(hipEventRecord(ctx->ev_fork, s)); MR_HIP(hipStreamWaitEvent(sp, ctx->ev_fork, 0));
+        PB.q.lane = 1;
+    }
+    const bool dbg_sum = getenv("MIRRES_DBG_SUM") != nullptr;
+    unsigned long long* d_sums = nullptr; int n_sums = 0;
+    if (dbg_sum) { MR_HIP(hipMalloc(&d_sums, 8 * 4096)); MR_HIP(hipMemsetAsync(d_sums, 0, 8 * 4096, s)); }
+    auto csum = [&](const void* p, size_t words) { if (dbg_sum && n_sums < 4096) k_checksum<<<1024, MR_BLOCK, 0, s>>>((const uint32_t*)p, words, d_sums + n_sums++); };
     for (int ib = i0; ib < i1; ib += PB.K) {
         const int kk = (i1 - ib < PB.K) ? (i1 - ib) : PB.K;
         for (int i = ib; i < ib + kk; i++) {
@@ -237,6 +265,7 @@ int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args
             rc = mirres_light_tiles(ctx, B.tex, Wc, Hc, B.pdf, B.cdf, B.mpdf, B.mcdf, base + pass, B.tile_data, nullptr, B.tile_pdf, s); if (rc) return rc;
             pass += 2;
             rc = mirres_restir_initial(ctx, bvh, &E, &G, &R[cur], B.tile_data, B.tile_pdf, base + pass, s); if (rc) return rc;
+            csum(R[cur].light_data, 3 * (size_t)N); csum(R[cur].weight, (size_t)N);
             pass += 1;
             if (i > 0) {
                 // prev_* G-buffers alias the current ones from the second sample on (:462-465); a rank that starts in the
@@ -247,31 +276,40 @@ int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args
             cur ^= 1;  // swap (:358)
             rc = mirres_restir_spatial(ctx, bvh, &E, &G, &R[cur], &R[cur ^ 1], nullptr, base + pass, s); if (rc) return rc;
             pass += 1;
+            csum(R[cur].light_data, 3 * (size_t)N); csum(R[cur].weight, (size_t)N);
             rc = mirres_restir_final_vis(ctx, bvh, a->pos, &R[cur], B.vis, s); if (rc) return rc;
+            csum(B.vis, (size_t)N);
             rc = mirres_restir_eval_final(ctx, &E, &R[cur], B.vis, B.fdir, B.fdist, B.fLi, s); if (rc) return rc;
             rc = launch_final_shading(&E, a->occ, a->normal, B.ray_dir, a->kd, a->rough_metal, B.fdir, B.fdist, B.fLi, N, B.tot[0], B.tot[1], B.tot[2], true, s);
             if (rc) return rc;
+            csum(B.fLi, 3 * (size_t)N); csum(B.tot[1], 3 * (size_t)N);
             cur ^= 1;  // swap back (:460)
         }
         // ---- path-tracing stages of samples ib .. ib+kk-1 (new direction, then max_bounce indirect vertices)
         PtQueues Q = PB.q; Q.NV = kk * N; Q.first_sample_is_zero = (ib == 0);
         uint32_t fi = a->random_offset + passes * (uint32_t)ib + 5;   // pass number of new_dir for a sample with a temporal pass before it
         mirres_path_t P0 = {a->occ, a->pos, a->normal, B.ray_dir, a->kd, a->rough_metal, PB.prd, PB.pos[0], PB.rd[0], PB.occ[0], PB.n[0]};
-        rc = launch_new_dir(ctx, bvh, &P0, fi, 0, s, &Q); if (rc) return rc;
+        rc = launch_new_dir(ctx, bvh, &P0, fi, 0, sp, &Q); if (rc) return rc;
         fi += 5;
         int src = 0;
         for (int b = 1; b <= max_bounce; b++) {
             // material lookup at the new vertices: compacted slot list -> hash-grid gather -> MFMA MLP -> scatter (slot_c is free between passes)
-            if (a->mat) rc = launch_matnet_scatter_mfma(a->mat, PB.occ[src], PB.pos[src], Q.NV, PB.kd, PB.rm, a->use_scale, a->scale, Q.slot_c, &Q.counters[2], s);
-            else rc = launch_matnet_scatter(nullptr, PB.occ[src], PB.pos[src], Q.NV, PB.kd, PB.rm, a->use_scale, a->scale, a->const_kd, a->const_rm, s);
+            if (a->mat && !(getenv("MIRRES_MATNET") && getenv("MIRRES_MATNET")[0] == 'v')) rc = launch_matnet_scatter_mfma(a->mat, PB.occ[src], PB.pos[src], Q.NV, PB.kd, PB.rm, a->use_scale, a->scale, Q.slot_c, &Q.counters[2], sp);
+            else rc = launch_matnet_scatter(a->mat, PB.occ[src], PB.pos[src], Q.NV, PB.kd, PB.rm, a->use_scale, a->scale, a->const_kd, a->const_rm, sp);
             if (rc) return rc;
             mirres_path_t Pb = {PB.occ[src], PB.pos[src], PB.n[src], PB.rd[src], PB.kd, PB.rm, PB.prd, PB.pos[src ^ 1], PB.rd[src ^ 1], PB.occ[src ^ 1], PB.n[src ^ 1]};
             float* cb = PB.cb + (size_t)(b - 1) * 9 * (size_t)Q.NV;
-            rc = launch_bounce(ctx, bvh, &E, &Pb, fi, (uint32_t)b, cb, cb + 3 * (size_t)Q.NV, cb + 6 * (size_t)Q.NV, nullptr, nullptr, nullptr, s, &Q); if (rc) return rc;
+            rc = launch_bounce(ctx, bvh, &E, &Pb, fi, (uint32_t)b, cb, cb + 3 * (size_t)Q.NV, cb + 6 * (size_t)Q.NV, nullptr, nullptr, nullptr, sp, &Q); if (rc) return rc;
             fi += 5;
             src ^= 1;
         }
-        if (max_bounce > 0) k_pt_reduce<<<grid_for(n3, MR_BLOCK), MR_BLOCK, 0, s>>>(N, kk, max_bounce, PB.cb, B.tot[3], B.tot[4], B.tot[5]);
+        if (max_bounce > 0) k_pt_reduce<<<grid_for(n3, MR_BLOCK), MR_BLOCK, 0, sp>>>(N, kk, max_bounce, PB.cb, B.tot[3], B.tot[4], B.tot[5]);
+    }
+    if (two_streams) { MR_HIP(hipEventRecord(ctx->ev_join, sp)); MR_HIP(hipStreamWaitEvent(s, ctx->ev_join, 0)); }
+    if (dbg_sum) {
+        std::vector<unsigned long long> h(n_sums);
+        MR_HIP(hipStreamSynchronize(s)); MR_HIP(hipMemcpy(h.data(), d_sums, 8 * (size_t)n_sums, hipMemcpyDeviceToHost)); (void)hipFree(d_sums);
+        for (int k = 0; k < n_sums; k++) fprintf(stderr, "[sum %d] %016llx\n", k, h[k]);
     }
     if (partial) {
         for (int k = 0; k < 6; k++) MR_HIP(hipMemcpyAsync(a->outs[k], B.tot[k], sizeof(float) * n3, hipMemcpyDeviceToDevice, s));

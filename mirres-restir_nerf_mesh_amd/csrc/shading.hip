@@ -11,7 +11,7 @@
 namespace mr {
 
 int trace_any_queue_counted(const mirres_bvh* bvh, const Ray* rays, const uint32_t* d_count, size_t capacity, int32_t* hit,
-                            unsigned long long* stats, hipStream_t s);
+                            unsigned long long* stats, hipStream_t s, int reference_order);
 int trace_closest_queue_counted(const mirres_bvh* bvh, const Ray* rays, const uint32_t* d_count, size_t capacity, HitRec* out,
                                 unsigned long long* stats, hipStream_t s);
 
@@ -273,7 +273,7 @@ int launch_final_shading(const mirres_env_t* env, const float* occ, const float*
 }
 static PtQueues ctx_queues(mirres_ctx* ctx) {
     PtQueues q; q.any_rays = ctx->any_rays; q.any_hit = ctx->any_hit; q.cl_rays = ctx->cl_rays; q.cl_hit = ctx->cl_hit; q.counters = ctx->counters;
-    q.slot_a = ctx->slot_a; q.mask_a = ctx->mask_a; q.slot_c = ctx->slot_c; q.pend = ctx->pend; q.N = (int)ctx->N; q.NV = (int)ctx->N; q.first_sample_is_zero = 0;
+    q.slot_a = ctx->slot_a; q.mask_a = ctx->mask_a; q.slot_c = ctx->slot_c; q.pend = ctx->pend; q.N = (int)ctx->N; q.NV = (int)ctx->N; q.first_sample_is_zero = 0; q.lane = 0;
     return q;
 }
 int launch_new_dir(mirres_ctx* ctx, mirres_bvh* bvh, const mirres_path_t* p, uint32_t frameIndex, uint32_t bounce_count, hipStream_t s, const PtQueues* qq) {
@@ -282,7 +282,7 @@ int launch_new_dir(mirres_ctx* ctx, mirres_bvh* bvh, const mirres_path_t* p, uin
     MR_HIP(hipMemsetAsync(&Q.counters[1], 0, sizeof(uint32_t), s));
     k_new_dir_gen<<<grid_for(NV, MR_GEN_BLOCK), MR_GEN_BLOCK, 0, s>>>(*p, ctx->cfg.max_bounce, ctx->cfg.vis_near, frameIndex, bounce_count, ctx->fx, Q.N, NV, Q.first_sample_is_zero,
                                                                        Q.cl_rays, &Q.counters[1], Q.slot_c);
-    int rc = trace_closest_q(ctx, bvh, Q.cl_rays, &Q.counters[1], (size_t)NV, Q.cl_hit, s);
+    int rc = trace_closest_q(ctx, bvh, Q.cl_rays, &Q.counters[1], (size_t)NV, Q.cl_hit, s, Q.lane);
     if (rc) return rc;
     k_new_dir_resolve<<<grd, MR_BLOCK, 0, s>>>(*p, NV, Q.slot_c, Q.cl_hit);
     MR_LAUNCH_CHECK("pt_new_dir");
@@ -295,8 +295,8 @@ int launch_bounce(mirres_ctx* ctx, mirres_bvh* bvh, const mirres_env_t* env, con
     MR_HIP(hipMemsetAsync(&Q.counters[0], 0, 2 * sizeof(uint32_t), s));
     k_bounce_gen<<<grid_for(NV, MR_GEN_BLOCK), MR_GEN_BLOCK, 0, s>>>(*p, envh(env), ctx->cfg.max_bounce, ctx->cfg.vis_near, frameIndex, bounce_count, ctx->fx, Q.N, NV, Q.first_sample_is_zero,
                                                                       color, dc, sc, Q.any_rays, &Q.counters[0], Q.cl_rays, &Q.counters[1], Q.slot_a, Q.mask_a, Q.slot_c, Q.pend);
-    int rc = trace_any_q(ctx, bvh, Q.any_rays, &Q.counters[0], 2 * (size_t)NV, Q.any_hit, s); if (rc) return rc;
-    rc = trace_closest_q(ctx, bvh, Q.cl_rays, &Q.counters[1], (size_t)NV, Q.cl_hit, s); if (rc) return rc;
+    int rc = trace_any_q(ctx, bvh, Q.any_rays, &Q.counters[0], 2 * (size_t)NV, Q.any_hit, s, Q.lane); if (rc) return rc;
+    rc = trace_closest_q(ctx, bvh, Q.cl_rays, &Q.counters[1], (size_t)NV, Q.cl_hit, s, Q.lane); if (rc) return rc;
     if (acc_c) k_bounce_resolve<true><<<grd, MR_BLOCK, 0, s>>>(*p, NV, Q.slot_a, Q.mask_a, Q.slot_c, Q.any_hit, Q.cl_hit, Q.pend, color, dc, sc, acc_c, acc_d, acc_s);
     else k_bounce_resolve<false><<<grd, MR_BLOCK, 0, s>>>(*p, NV, Q.slot_a, Q.mask_a, Q.slot_c, Q.any_hit, Q.cl_hit, Q.pend, color, dc, sc, nullptr, nullptr, nullptr);
     MR_LAUNCH_CHECK("pt_bounce");

@@ -1,0 +1,31 @@
+"""Dev (GPU box): stress the two-stream frame loop for schedule-dependent results: N frames on two streams against one single-stream frame."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import numpy as np, torch
+import mirres_restir_nerf_mesh_amd as M
+from mirres_restir_nerf_mesh_amd import renderer_restir as RR, harness
+from mirres_restir_nerf_mesh_amd._ops import get_ctx
+from mirres_restir_nerf_mesh_amd.render_helper import MLPTexture3D
+S = M.scene
+v, t = S.make_mesh(7, 64)
+W = RR.restirbvhWorker(torch.from_numpy(v).cuda(), torch.from_numpy(t).cuda()); W.update_mesh(W.vrt, W.v_ind)
+g = harness.build_gbuffer(W, 800, 800, 2)
+env = torch.from_numpy(S.make_env(256, 512)).cuda()
+ctx = get_ctx(g["fx"], g["fy"])
+mn, mx = S.material_min_max()
+mlp = MLPTexture3D(torch.tensor([-1, -1, -1, 1, 1, 1], dtype=torch.float32), channels=6, min_max=(torch.from_numpy(mn).cuda(), torch.from_numpy(mx).cuda()), seed=3)
+with torch.no_grad(): mlp.encoder.params.mul_(1e3)
+SPP = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+REPS = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+def frame(K, st):
+    os.environ["MIRRES_PT_BATCH"] = str(K); os.environ["MIRRES_STREAMS"] = str(st)
+    outs, _, _ = RR.render_fused(ctx, W, mlp, False, (1, 1, 1), env, g["occ"].clone(), g["normal"], g["depth"], g["kd"], g["rm"], g["ray_dir"], g["pos"], SPP, 2, 2, 2.0, 0.1, 0.001, 777)
+    torch.cuda.synchronize()
+    return [o.clone() for o in outs]
+ref = frame(1, 1)
+bad = 0
+for rep in range(REPS):
+    got = frame((1, 4, 16)[rep % 3], 2)
+    mm = [int((a != b).any(dim=1).sum()) for a, b in zip(ref, got)]
+    if any(mm): bad += 1; print("rep", rep, "mismatch", mm, flush=True)
+print("frames with a mismatch:", bad, "of", REPS)

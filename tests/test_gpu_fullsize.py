@@ -90,3 +90,29 @@ def test_frame_properties_at_full_size(big, scene_mod):
     assert abs(float(outs3[0][~bgm].mean()) - float(fc[~bgm].mean())) < 0.02 * float(fc[~bgm].mean()) + 1e-3
     st = ctx.stats(reset=True)
     assert st["rays_any"] > 0 and st["rays_closest"] > 0
+
+
+def test_schedule_does_not_change_the_frame_at_full_size(big, scene_mod, monkeypatch):
+    """The frame loop's scheduling choices — K samples of the path-tracing stages per launch, those stages on a second stream — must not
+    change a single bit of any output: 1600 x 1600, 6 samples, K = 1 on one stream against K = 4 (ragged last batch) on two streams."""
+    v, t, W, RR, harness, torch = big
+    from mirres_restir_nerf_mesh_amd._ops import get_ctx
+    g = harness.build_gbuffer(W, 800, 800, 2)
+    env = torch.from_numpy(scene_mod.make_env(256, 512)).cuda()
+    ctx = get_ctx(g["fx"], g["fy"])
+    from mirres_restir_nerf_mesh_amd.render_helper import MLPTexture3D
+    mn, mx = scene_mod.material_min_max()
+    mlp = MLPTexture3D(torch.tensor([-1, -1, -1, 1, 1, 1], dtype=torch.float32), channels=6, min_max=(torch.from_numpy(mn).cuda(), torch.from_numpy(mx).cuda()), seed=3)
+    with torch.no_grad():
+        mlp.encoder.params.mul_(1e3)
+    def frame():
+        outs, _, _ = RR.render_fused(ctx, W, mlp, False, (1, 1, 1), env, g["occ"].clone(), g["normal"], g["depth"], g["kd"], g["rm"], g["ray_dir"], g["pos"], 6, 2, 2, 2.0, 0.1, 0.001, 777)
+        torch.cuda.synchronize()
+        return [o.clone() for o in outs]
+    monkeypatch.setenv("MIRRES_PT_BATCH", "1"); monkeypatch.setenv("MIRRES_STREAMS", "1")
+    ref = frame()
+    monkeypatch.setenv("MIRRES_PT_BATCH", "4"); monkeypatch.setenv("MIRRES_STREAMS", "2")
+    for rep in range(3):
+        got = frame()
+        for a, b in zip(ref, got):
+            assert torch.equal(a, b)
