@@ -116,7 +116,8 @@ struct mirres_ctx {
     float* pool = nullptr; size_t pool_floats = 0;
     // K-sample batch of the path-tracing stages (mirres_render): queues + per-slot state for K * N sample slots
     char* ptb = nullptr; size_t ptb_bytes = 0;
-    hipStream_t aux_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // second stream of mirres_render (path-tracing stages)
+    hipStream_t aux_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    std::vector<hipEvent_t> ev_sync; // cross-stream hand-offs of the batch pipeline   // second stream of mirres_render (path-tracing stages)
 };
 
 namespace mr {
@@ -142,6 +143,10 @@ struct PtQueues {
     int lane;                           // 1: launched on the context's second stream (own traversal head sets)
     int first_sample_is_zero;           // sample 0 of the frame has one pass fewer before the path-tracing stages (no temporal pass)
 };
+int launch_initial_batch(mirres_ctx* ctx, mirres_bvh* bvh, const mirres_env_t* env, const mirres_gbuf_t* g, const mirres_res_t* res, float* tile_data,
+                         float* tile_pdf, float* tile_aux, uint32_t frame0, int K, const PtQueues* q, hipStream_t s);
+int launch_final_batch(mirres_ctx* ctx, mirres_bvh* bvh, const mirres_env_t* env, const float* occ, const float* pos, const float* normal, const float* ray_dir,
+                       const float* kd, const float* rm, const mirres_res_t* res, int K, const PtQueues* q, float* color, float* diff, float* spec, hipStream_t s);
 int trace_any_q(mirres_ctx* ctx, mirres_bvh* bvh, const Ray* rays, const uint32_t* count, size_t cap, int32_t* hit, hipStream_t s, int lane = 0);
 int trace_closest_q(mirres_ctx* ctx, mirres_bvh* bvh, const Ray* rays, const uint32_t* count, size_t cap, HitRec* out, hipStream_t s, int lane = 0);
 inline int grid_for(size_t n, int block) { size_t g = (n + block - 1) / block; return (int)(g < 1 ? 1 : g); }

@@ -110,11 +110,13 @@ __global__ void k_neighbor_offsets(int count, float* __restrict__ out) {
 
 // process_GenerateLightTiles (GenerateLightTiles.slang:16-62): exactly tile_count*tile_size threads (the reference
 // launches 33.5 M threads of which 131 072 work).
-__global__ void __launch_bounds__(MR_BLOCK) k_light_tiles(EnvD E, uint32_t frameIndex, int total, float* __restrict__ light_data,
+// `total` = K * per: sample k of a K-sample batch (mirres_render) fills tiles [k * per, (k + 1) * per) with the stream of frameIndex + 20 k.
+__global__ void __launch_bounds__(MR_BLOCK) k_light_tiles(EnvD E, uint32_t frameIndex, int total, int per, float* __restrict__ light_data,
                                                           int32_t* __restrict__ light_uv, float* __restrict__ light_pdf) {
     uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (uint32_t)total) return;
-    uint32_t sg = seed_generator(idx, idx, frameIndex + 1);  // scalar bufferIndex splat to uint2 (:34)
+    const uint32_t ks = idx / (uint32_t)per, li = idx - ks * (uint32_t)per;
+    uint32_t sg = seed_generator(li, li, frameIndex + 20u * ks + 1);  // scalar bufferIndex splat to uint2 (:34)
     float r0 = rnd(sg), r1 = rnd(sg);
     v3 ld = V3(0.f); int ux = 0, uy = 0; float ip = 0.f;
     v3 dir; float pdf; v2 luv;
@@ -143,12 +145,17 @@ __global__ void __launch_bounds__(MR_BLOCK) k_tile_aux(EnvD E, int total, const 
 
 // ---------------------------------------------------------------- initial resampling (InitialResampling.slang:151-295)
 __global__ void __launch_bounds__(MR_GEN_BLOCK) k_initial_gen(mirres_config_t C, EnvD E, GBufD G, ResD R, const float* __restrict__ tile_data,
-                                                          const float* __restrict__ tile_pdf, const float4* __restrict__ tile_aux, uint32_t frameIndex, int fx, int N,
-                                                          Ray* __restrict__ q, uint32_t* __restrict__ q_count, int32_t* __restrict__ slot_out) {
-    const int pi = blockIdx.x * blockDim.x + threadIdx.x;
+                                                          const float* __restrict__ tile_pdf, const float4* __restrict__ tile_aux, uint32_t frameIndex0, int fx, int N,
+                                                          int NV, int TS, Ray* __restrict__ q, uint32_t* __restrict__ q_count, int32_t* __restrict__ slot_out) {
+    // slot sv = k * N + pixel: sample k of a K-sample batch (NV = K * N; K = 1 for the stepwise ABI) — reservoir at sv, G-buffer at the pixel,
+    // light tiles of sample k at k * TS, RNG stream frameIndex0 + 20 k
+    const int sv = blockIdx.x * blockDim.x + threadIdx.x;
     bool want = false; v3 rpos = V3(0.f), rdir = V3(0.f);
-    if (pi < N) {
-        if (G.occ[pi] < 0.1f) store_zero(R, pi);
+    if (sv < NV) {
+        const int ks = sv / N, pi = sv - ks * N;
+        const uint32_t frameIndex = frameIndex0 + 20u * (uint32_t)ks;
+        tile_data += 3 * (size_t)ks * TS; tile_pdf += (size_t)ks * TS; tile_aux += (size_t)ks * TS;
+        if (G.occ[pi] < 0.1f) store_zero(R, sv);
         else {
             const uint32_t x = (uint32_t)(pi % fx), y = (uint32_t)(pi / fx);
             uint32_t tileSg = seed_generator(x / C.screen_tile_size, y / C.screen_tile_size, frameIndex);
@@ -192,12 +199,12 @@ __global__ void __launch_bounds__(MR_GEN_BLOCK) k_initial_gen(mirres_config_t C,
             // reservoir as if the sample is visible; k_initial_resolve empties it when the shadow ray hits (:269-281)
             s.weight = s.weight > 0.f ? (s.weightSum / s.M) / s.weight : 0.f;
             s.M = 1.f;
-            store_ris(R, pi, s);
+            store_ris(R, sv, s);
         }
     }
     uint32_t slot = block_append(q_count, want);
     if (want) put_ray(q, slot, rpos, rdir, C.vis_near);
-    if (pi < N) slot_out[pi] = want ? (int32_t)slot : -1;
+    if (sv < NV) slot_out[sv] = want ? (int32_t)slot : -1;
 }
 __global__ void __launch_bounds__(MR_BLOCK) k_initial_resolve(ResD R, int N, const int32_t* __restrict__ slot, const int32_t* __restrict__ hit) {
     const int pi = blockIdx.x * blockDim.x + threadIdx.x;
@@ -373,17 +380,58 @@ __global__ void __launch_bounds__(MR_BLOCK) k_spatial_resolve(mirres_config_t C,
 }
 
 // ---------------------------------------------------------------- final-sample visibility + evaluation (EvaluateFinalSamples.slang:84-188)
-__global__ void __launch_bounds__(MR_GEN_BLOCK) k_vis_gen(float vis_near, const float* __restrict__ pos, ResD R, int N, Ray* __restrict__ q,
+__global__ void __launch_bounds__(MR_GEN_BLOCK) k_vis_gen(float vis_near, const float* __restrict__ pos, ResD R, int N, int NV, Ray* __restrict__ q,
                                                       uint32_t* __restrict__ q_count, int32_t* __restrict__ slot_out) {
-    const int pi = blockIdx.x * blockDim.x + threadIdx.x;
+    const int sv = blockIdx.x * blockDim.x + threadIdx.x;   // slot k * N + pixel (reservoir per slot, position per pixel)
     bool want = false; v3 rp = V3(0.f), rd = V3(0.f);
-    if (pi < N) {
-        v3 ld = ld3(R.light_data, pi);
-        if (ld.x > 0.1f) { want = true; rp = ld3(pos, pi); rd = oct_decode(V2(ld.y, ld.z)); }
+    if (sv < NV) {
+        v3 ld = ld3(R.light_data, sv);
+        if (ld.x > 0.1f) { want = true; rp = ld3(pos, sv % N); rd = oct_decode(V2(ld.y, ld.z)); }
     }
     uint32_t slot = block_append(q_count, want);
     if (want) put_ray(q, slot, rp, rd, vis_near);
-    if (pi < N) slot_out[pi] = want ? (int32_t)slot : -1;
+    if (sv < NV) slot_out[sv] = want ? (int32_t)slot : -1;
+}
+// Final visibility + EvaluateFinalSamples + FinalShading of the K samples of a batch, one thread per pixel, samples in ascending order: the three
+// per-sample kernels (k_vis_resolve, k_eval_final, k_final_shading<ACC>) back to back on registers — same arithmetic, same summation order.
+__global__ void __launch_bounds__(MR_BLOCK) k_final_direct(EnvD E, const float* __restrict__ occ, const float* __restrict__ normal, const float* __restrict__ ray_dir,
+                                                           const float* __restrict__ kd, const float* __restrict__ rm, ResD R, const int32_t* __restrict__ slot,
+                                                           const int32_t* __restrict__ hit, int N, int K, float* __restrict__ color, float* __restrict__ diff_light,
+                                                           float* __restrict__ spec_light) {
+    const int pi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pi >= N) return;
+    const v3 n = ld3(normal, pi), rd = ld3(ray_dir, pi), diffuse = ld3(kd, pi);
+    const float rough = rm[2 * (size_t)pi], metallic = rm[2 * (size_t)pi + 1];
+    const bool fg = occ[pi] > 0.1f;
+    v3 ac = ld3(color, pi), ad = ld3(diff_light, pi), as = ld3(spec_light, pi);
+    const v3 bg = fg ? V3(0.f) : env_le(ngp_dir(rd), E.tex, E.W, E.H);
+    for (int k = 0; k < K; k++) {
+        const size_t sv = (size_t)k * N + pi;
+        v3 c = V3(0.f), ldiff = V3(0.f), lspec = V3(0.f);
+        if (fg) {
+            const int sl = slot[sv];
+            const float vis = (sl >= 0 && hit[sl]) ? 0.0f : 1.0f;                       // k_vis_resolve
+            const v3 ld = ld3(R.light_data, sv);
+            v3 dir = V3(0.f), Li = V3(0.f); float dist = 0.f;
+            if (ld.x > 0.1f) {                                                           // k_eval_final
+                const v3 ldir = oct_decode(V2(ld.y, ld.z));
+                const v3 em = env_radiance(E, ldir);
+                if (vis > 0.f) { dir = ldir; dist = 1e6f; Li = R.weight[sv] * em; }
+            }
+            v3 dv = V3(0.f), sv3 = V3(0.f);                                              // k_final_shading
+            if (dist > 0.f) {
+                shade::Frame fr = shade::create_frame(n);
+                v3 wi = shade::to_local(fr, -rd), wo = shade::to_local(fr, dir);
+                shade::Lobes L = shade::lobes(diffuse, rough, metallic, rd, n);
+                if (L.pD > 0.f) dv = shade::diffuse_light(wi, wo) * Li;
+                if (L.pS > 0.f) sv3 = shade::specular_eval(wi, wo, L.specular, L.alpha) * Li;
+            }
+            c = diffuse * (1.0f - metallic) * dv + sv3;
+            ldiff = dv; lspec = sv3;
+        } else c = bg;
+        ac = ac + c; ad = ad + ldiff; as = as + lspec;
+    }
+    st3(color, pi, ac); st3(diff_light, pi, ad); st3(spec_light, pi, as);
 }
 __global__ void __launch_bounds__(MR_BLOCK) k_vis_resolve(int N, const int32_t* __restrict__ slot, const int32_t* __restrict__ hit, float* __restrict__ vis) {
     const int pi = blockIdx.x * blockDim.x + threadIdx.x;
@@ -455,6 +503,34 @@ int trace_closest_q(mirres_ctx* ctx, mirres_bvh* bvh, const Ray* rays, const uin
 int trace_any(mirres_ctx* ctx, mirres_bvh* bvh, size_t cap, hipStream_t s) { return trace_any_q(ctx, bvh, ctx->any_rays, &ctx->counters[0], cap, ctx->any_hit, s); }
 int trace_closest(mirres_ctx* ctx, mirres_bvh* bvh, size_t cap, hipStream_t s) { return trace_closest_q(ctx, bvh, ctx->cl_rays, &ctx->counters[1], cap, ctx->cl_hit, s); }
 
+// ---- K-sample batches of the history-free ReSTIR stages (mirres_render). Initial resampling needs nothing from earlier samples, and the final
+// visibility / evaluation / shading of a sample feeds only the frame totals, so K samples go through each of them in one set of launches
+// (K * N slots, like the path-tracing stages); only temporal + spatial reuse stay sample by sample.
+int launch_initial_batch(mirres_ctx* ctx, mirres_bvh* bvh, const mirres_env_t* env, const mirres_gbuf_t* g, const mirres_res_t* res, float* tile_data,
+                         float* tile_pdf, float* tile_aux, uint32_t frame0, int K, const PtQueues* q, hipStream_t s) {
+    const int N = (int)ctx->N, NV = K * N;
+    const int TS = ctx->cfg.light_tile_count * ctx->cfg.light_tile_size;
+    MR_HIP(hipMemsetAsync(&q->counters[0], 0, sizeof(uint32_t), s));
+    k_light_tiles<<<grid_for((size_t)K * TS, MR_BLOCK), MR_BLOCK, 0, s>>>(envh(env), frame0, K * TS, TS, tile_data, nullptr, tile_pdf);       // pass 0 (+1 inside)
+    k_tile_aux<<<grid_for((size_t)K * TS, MR_BLOCK), MR_BLOCK, 0, s>>>(envh(env), K * TS, tile_data, reinterpret_cast<float4*>(tile_aux));
+    k_initial_gen<<<grid_for(NV, MR_GEN_BLOCK), MR_GEN_BLOCK, 0, s>>>(ctx->cfg, envh(env), gbufd(g), resd(res), tile_data, tile_pdf, reinterpret_cast<const float4*>(tile_aux),
+                                                                       frame0 + 2, ctx->fx, N, NV, TS, q->any_rays, &q->counters[0], q->slot_a);       // pass 2
+    int rc = trace_any_q(ctx, bvh, q->any_rays, &q->counters[0], (size_t)NV, q->any_hit, s, q->lane); if (rc) return rc;
+    k_initial_resolve<<<grid_for(NV, MR_BLOCK), MR_BLOCK, 0, s>>>(resd(res), NV, q->slot_a, q->any_hit);
+    MR_LAUNCH_CHECK("initial_batch");
+    return 0;
+}
+int launch_final_batch(mirres_ctx* ctx, mirres_bvh* bvh, const mirres_env_t* env, const float* occ, const float* pos, const float* normal, const float* ray_dir,
+                       const float* kd, const float* rm, const mirres_res_t* res, int K, const PtQueues* q, float* color, float* diff, float* spec, hipStream_t s) {
+    const int N = (int)ctx->N, NV = K * N;
+    MR_HIP(hipMemsetAsync(&q->counters[0], 0, sizeof(uint32_t), s));
+    k_vis_gen<<<grid_for(NV, MR_GEN_BLOCK), MR_GEN_BLOCK, 0, s>>>(ctx->cfg.vis_near, pos, resd(res), N, NV, q->any_rays, &q->counters[0], q->slot_a);
+    int rc = trace_any_q(ctx, bvh, q->any_rays, &q->counters[0], (size_t)NV, q->any_hit, s, q->lane); if (rc) return rc;
+    k_final_direct<<<grid_for(N, MR_BLOCK), MR_BLOCK, 0, s>>>(envh(env), occ, normal, ray_dir, kd, rm, resd(res), q->slot_a, q->any_hit, N, K, color, diff, spec);
+    MR_LAUNCH_CHECK("final_batch");
+    return 0;
+}
+
 }  // namespace mr
 
 using namespace mr;
@@ -498,6 +574,7 @@ void mirres_ctx_destroy(mirres_ctx_t* c) {
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (hipEvent_t e : c->ev_any) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->ev_cl) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->ev_sync) (void)hipEventDestroy(e);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
@@ -545,7 +622,7 @@ int mirres_light_tiles(mirres_ctx_t* ctx, const float* env_tex, int Wc, int Hc, 
     if (!ctx || !light_data || !light_inv_pdf) { set_error("mirres_light_tiles: null"); return MIRRES_E_ARG; }
     EnvD E; E.tex = env_tex; E.W = Wc; E.H = Hc; E.pdf = pdf; E.cdf = cdf; E.mpdf = mpdf; E.mcdf = mcdf;
     int total = ctx->cfg.light_tile_count * ctx->cfg.light_tile_size;
-    k_light_tiles<<<grid_for(total, MR_BLOCK), MR_BLOCK, 0, (hipStream_t)stream>>>(E, frameIndex, total, light_data, light_uv, light_inv_pdf);
+    k_light_tiles<<<grid_for(total, MR_BLOCK), MR_BLOCK, 0, (hipStream_t)stream>>>(E, frameIndex, total, total, light_data, light_uv, light_inv_pdf);
     MR_LAUNCH_CHECK("light_tiles");
     return MIRRES_OK;
 }
@@ -557,7 +634,7 @@ int mirres_restir_initial(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_env
     MR_HIP(hipMemsetAsync(&ctx->counters[0], 0, sizeof(uint32_t), s));
     const int TS = ctx->cfg.light_tile_count * ctx->cfg.light_tile_size;
     k_tile_aux<<<grid_for(TS, MR_BLOCK), MR_BLOCK, 0, s>>>(envh(env), TS, light_data, reinterpret_cast<float4*>(ctx->tile_aux));
-    k_initial_gen<<<grid_for(N, MR_GEN_BLOCK), MR_GEN_BLOCK, 0, s>>>(ctx->cfg, envh(env), gbufd(g), resd(res), light_data, light_inv_pdf, reinterpret_cast<const float4*>(ctx->tile_aux), frameIndex, ctx->fx, N, ctx->any_rays,
+    k_initial_gen<<<grid_for(N, MR_GEN_BLOCK), MR_GEN_BLOCK, 0, s>>>(ctx->cfg, envh(env), gbufd(g), resd(res), light_data, light_inv_pdf, reinterpret_cast<const float4*>(ctx->tile_aux), frameIndex, ctx->fx, N, N, TS, ctx->any_rays,
                                             &ctx->counters[0], ctx->slot_a);
     int rc = trace_any(ctx, bvh, (size_t)N, s); if (rc) return rc;
     k_initial_resolve<<<grd, MR_BLOCK, 0, s>>>(resd(res), N, ctx->slot_a, ctx->any_hit);
@@ -594,7 +671,7 @@ int mirres_restir_final_vis(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const float* p
     if (!ctx || !bvh || !pos || !res || !vis_map) { set_error("mirres_restir_final_vis: null"); return MIRRES_E_ARG; }
     hipStream_t s = (hipStream_t)stream; const int N = (int)ctx->N; const int grd = grid_for(N, MR_BLOCK);
     MR_HIP(hipMemsetAsync(&ctx->counters[0], 0, sizeof(uint32_t), s));
-    k_vis_gen<<<grid_for(N, MR_GEN_BLOCK), MR_GEN_BLOCK, 0, s>>>(ctx->cfg.vis_near, pos, resd(res), N, ctx->any_rays, &ctx->counters[0], ctx->slot_a);
+    k_vis_gen<<<grid_for(N, MR_GEN_BLOCK), MR_GEN_BLOCK, 0, s>>>(ctx->cfg.vis_near, pos, resd(res), N, N, ctx->any_rays, &ctx->counters[0], ctx->slot_a);
     int rc = trace_any(ctx, bvh, (size_t)N, s); if (rc) return rc;
     k_vis_resolve<<<grd, MR_BLOCK, 0, s>>>(N, ctx->slot_a, ctx->any_hit, vis_map);
     MR_LAUNCH_CHECK("restir_final_vis");

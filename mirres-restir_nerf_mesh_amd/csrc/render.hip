@@ -145,21 +145,28 @@ struct PtBatch {
     int K; PtQueues q;
     float *prd, *pos[2], *rd[2], *occ[2], *n[2], *kd, *rm;
     float* cb;      // [max_bounce][3][K * N * 3] per-bounce colour / diffuse / specular of every slot
+    // history-free ReSTIR stages: two sets (batch parity) of K initial / temporal reservoirs and K spatial-output reservoirs, light tiles of K samples
+    mirres_res_t rinit[2], rspat[2];
+    float *tile_data, *tile_pdf, *tile_aux;
 };
+static mirres_res_t res_slot(const mirres_res_t& r, int k, size_t N) {
+    mirres_res_t o; o.light_data = r.light_data + 3 * (size_t)k * N; o.light_pdf = r.light_pdf + (size_t)k * N; o.M = r.M + (size_t)k * N; o.weight = r.weight + (size_t)k * N; return o;
+}
 static int pt_batch_size() {   // MIRRES_PT_BATCH = samples per path-tracing launch (default 16; 1 = sample by sample)
     const char* e = getenv("MIRRES_PT_BATCH");   // read per frame (tests switch it)
     int k = e ? atoi(e) : 16; if (k < 1) k = 1; if (k > 64) k = 64;
     return k;
 }
 static bool use_two_streams() { const char* e = getenv("MIRRES_STREAMS"); return !(e && e[0] == '1'); }   // MIRRES_STREAMS=1: everything on the caller's stream
-static int carve_batch(mirres_ctx* ctx, int N, int K, int max_bounce, PtBatch& PB) {
+static int carve_batch(mirres_ctx* ctx, int N, int K, int max_bounce, size_t TS, PtBatch& PB) {
     if (K < 1) K = 1;
     while ((size_t)K * (size_t)N > 0x30000000ull && K > 1) K--;   // slot indices are 32-bit
     const size_t NV = (size_t)K * (size_t)N;
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const int nb = max_bounce > 0 ? max_bounce : 1;
     size_t need = al(sizeof(Ray) * 2 * NV) + al(4 * 2 * NV) + al(sizeof(Ray) * NV) + al(sizeof(HitRec) * NV) + al(64) + 3 * al(4 * NV) + al(4 * 18 * NV)
-                + al(4 * 5 * NV) + 2 * (3 * al(4 * 3 * NV) + al(4 * NV)) + al(4 * 3 * NV) + al(4 * 2 * NV) + al(4 * 9 * NV * (size_t)nb);
+                + al(4 * 5 * NV) + 2 * (3 * al(4 * 3 * NV) + al(4 * NV)) + al(4 * 3 * NV) + al(4 * 2 * NV) + al(4 * 9 * NV * (size_t)nb)
+                + 4 * (al(4 * 3 * NV) + 3 * al(4 * NV)) + al(4 * 3 * (size_t)K * TS) + al(4 * (size_t)K * TS) + al(16 * (size_t)K * TS);
     if (ctx->ptb_bytes < need) {
         if (ctx->ptb) { MR_HIP(hipDeviceSynchronize()); MR_HIP(hipFree(ctx->ptb)); ctx->ptb = nullptr; ctx->ptb_bytes = 0; }
         MR_HIP(hipMalloc(&ctx->ptb, need));
@@ -179,6 +186,11 @@ static int carve_batch(mirres_ctx* ctx, int N, int K, int max_bounce, PtBatch& P
     for (int k = 0; k < 2; k++) { PB.pos[k] = (float*)take(4 * 3 * NV); PB.rd[k] = (float*)take(4 * 3 * NV); PB.n[k] = (float*)take(4 * 3 * NV); PB.occ[k] = (float*)take(4 * NV); }
     PB.kd = (float*)take(4 * 3 * NV); PB.rm = (float*)take(4 * 2 * NV);
     PB.cb = (float*)take(4 * 9 * NV * (size_t)nb);
+    for (int k = 0; k < 4; k++) {
+        mirres_res_t& r = (k < 2) ? PB.rinit[k] : PB.rspat[k - 2];
+        r.light_data = (float*)take(4 * 3 * NV); r.light_pdf = (float*)take(4 * NV); r.M = (int32_t*)take(4 * NV); r.weight = (float*)take(4 * NV);
+    }
+    PB.tile_data = (float*)take(4 * 3 * (size_t)K * TS); PB.tile_pdf = (float*)take(4 * (size_t)K * TS); PB.tile_aux = (float*)take(16 * (size_t)K * TS);
     return 0;
 }
 
@@ -228,8 +240,6 @@ int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args
     MR_HIP(hipMemsetAsync(B.tot[0], 0, sizeof(float) * (size_t)(B.tex - B.tot[0]), s));      // totals .. new_rm
     mirres_env_t E = {B.tex, Wc, Hc, B.pdf, B.cdf, B.mpdf, B.mcdf};
     mirres_gbuf_t G = {a->occ, a->pos, B.nd, B.brdf, B.ray_dir};
-    mirres_res_t R[2] = {{B.r_ld[0], B.r_pdf[0], B.r_M[0], B.r_w[0]}, {B.r_ld[1], B.r_pdf[1], B.r_M[1], B.r_w[1]}};
-    int cur = 0;  // `reservoirs` = R[cur], `prev_reservoirs` = R[cur^1]
     const uint32_t passes = 20;  // mTotalRISPasses (:242)
     const int max_bounce = ctx->cfg.max_bounce;
 
@@ -237,79 +247,111 @@ int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args
     // time; the path-tracing stages depend only on the G-buffer and the sample's RNG stream, so the K samples of a batch go through them
     // together: K * N slots per launch. A traversal launch has a tail as long as its slowest rays (~0.1 ms) during which most CUs idle —
     // a third of a 2.3 M-ray launch, a small fraction of a K-times larger one.
+    if (i1 > i0) {   // an empty slice of the sample range (spp sharding with more ranks than samples) leaves the zeroed totals
     const int Kmax = pt_batch_size();
-    PtBatch PB; rc = carve_batch(ctx, N, Kmax < (i1 - i0) ? Kmax : (i1 - i0), max_bounce, PB); if (rc) return rc;
-    // The two branches share only read-only inputs (G-buffer, environment tables, BVH) and write different totals (0..2 / 3..5), so the
-    // path-tracing batches go to a second stream: their large launches fill the CUs the small per-sample ReSTIR launches leave idle, and the
-    // launch gaps of one stream are covered by the other. Instrumented frames (counters / per-launch event timing) stay on one stream.
+    const size_t TS = (size_t)ctx->cfg.light_tile_count * ctx->cfg.light_tile_size;
+    PtBatch PB; rc = carve_batch(ctx, N, Kmax < (i1 - i0) ? Kmax : (i1 - i0), max_bounce, TS, PB); if (rc) return rc;
+    // ---- schedule. Per batch b of K samples:
+    //   I(b)  initial resampling of the K samples (light tiles, candidates, shadow rays)              bulk stream, K * N slots per launch
+    //   C(b)  temporal + spatial reuse, one sample after the other (needs the previous sample)        caller's stream, N pixels per launch
+    //   F(b)  final visibility + evaluation + shading of the K samples -> totals 0..2                 bulk stream
+    //   PT(b) new direction + max_bounce indirect vertices of the K samples -> totals 3..5            bulk stream
+    // The branches share only read-only inputs (G-buffer, environment tables, BVH). The bulk stream's large launches fill the CUs the small
+    // sample-by-sample launches of the chain leave idle (a 2.3 M-ray traversal launch idles a third of the chip in its tail), and the launch
+    // gaps of one stream are covered by the other. Reservoir sets alternate with the batch parity; hand-offs are events:
+    //   bulk:   wait C(b-1) | F(b-1) | I(b+1) | signal | PT(b)            chain:  wait signal(b-1) | C(b) | signal
+    // Instrumented frames (counters / per-launch event timing) and MIRRES_STREAMS=1 run the same sequence on one stream.
     hipStream_t sp = s;
     const bool two_streams = use_two_streams() && ctx->instrument == 0;
+    const int nbatch = (i1 - i0 + PB.K - 1) / PB.K;
     if (two_streams) {
         if (!ctx->aux_stream) {
             MR_HIP(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
             MR_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming)); MR_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
         }
+        while ((int)ctx->ev_sync.size() < 2 * (nbatch + 1)) { hipEvent_t e; MR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ctx->ev_sync.push_back(e); }
         sp = ctx->aux_stream;
         MR_HIP(hipEventRecord(ctx->ev_fork, s)); MR_HIP(hipStreamWaitEvent(sp, ctx->ev_fork, 0));
         PB.q.lane = 1;
     }
+    auto ev_bulk = [&](int b) { return ctx->ev_sync[2 * (b + 1)]; };       // bulk stream reached "I(b+1) done" in iteration b (b = -1: I(0))
+    auto ev_chain = [&](int b) { return ctx->ev_sync[2 * (b + 1) + 1]; };  // chain C(b) done
+    auto batch_k = [&](int b) { const int ib = i0 + b * PB.K; return (i1 - ib < PB.K) ? (i1 - ib) : PB.K; };
+    auto initial = [&](int b) -> int {
+        const int ib = i0 + b * PB.K;
+        PtQueues Q = PB.q; Q.NV = batch_k(b) * N;
+        return launch_initial_batch(ctx, bvh, &E, &G, &PB.rinit[b & 1], PB.tile_data, PB.tile_pdf, PB.tile_aux, a->random_offset + passes * (uint32_t)ib, batch_k(b), &Q, sp);
+    };
     const bool dbg_sum = getenv("MIRRES_DBG_SUM") != nullptr;
     unsigned long long* d_sums = nullptr; int n_sums = 0;
     if (dbg_sum) { MR_HIP(hipMalloc(&d_sums, 8 * 4096)); MR_HIP(hipMemsetAsync(d_sums, 0, 8 * 4096, s)); }
     auto csum = [&](const void* p, size_t words) { if (dbg_sum && n_sums < 4096) k_checksum<<<1024, MR_BLOCK, 0, s>>>((const uint32_t*)p, words, d_sums + n_sums++); };
-    for (int ib = i0; ib < i1; ib += PB.K) {
-        const int kk = (i1 - ib < PB.K) ? (i1 - ib) : PB.K;
-        for (int i = ib; i < ib + kk; i++) {
-            uint32_t pass = 0;
+    rc = initial(0); if (rc) return rc;
+    if (two_streams) MR_HIP(hipEventRecord(ev_bulk(-1), sp));
+    for (int b = 0; b < nbatch; b++) {
+        const int ib = i0 + b * PB.K, kk = batch_k(b);
+        // ---- bulk stream: F(b-1), I(b+1)
+        if (b > 0) {
+            if (two_streams) MR_HIP(hipStreamWaitEvent(sp, ev_chain(b - 1), 0));
+            PtQueues Q = PB.q; Q.NV = batch_k(b - 1) * N;
+            rc = launch_final_batch(ctx, bvh, &E, a->occ, a->pos, a->normal, B.ray_dir, a->kd, a->rough_metal, &PB.rspat[(b - 1) & 1], batch_k(b - 1), &Q, B.tot[0], B.tot[1], B.tot[2], sp);
+            if (rc) return rc;
+        }
+        if (b + 1 < nbatch) { rc = initial(b + 1); if (rc) return rc; }
+        if (two_streams) MR_HIP(hipEventRecord(ev_bulk(b), sp));
+        // ---- chain: temporal + spatial reuse of samples ib .. ib+kk-1
+        if (two_streams) MR_HIP(hipStreamWaitEvent(s, ev_bulk(b - 1), 0));
+        for (int k = 0; k < kk; k++) {
+            const int i = ib + k;
             const uint32_t base = a->random_offset + passes * (uint32_t)i;
-            rc = mirres_light_tiles(ctx, B.tex, Wc, Hc, B.pdf, B.cdf, B.mpdf, B.mcdf, base + pass, B.tile_data, nullptr, B.tile_pdf, s); if (rc) return rc;
-            pass += 2;
-            rc = mirres_restir_initial(ctx, bvh, &E, &G, &R[cur], B.tile_data, B.tile_pdf, base + pass, s); if (rc) return rc;
-            csum(R[cur].light_data, 3 * (size_t)N); csum(R[cur].weight, (size_t)N);
-            pass += 1;
+            uint32_t pass = 3;
+            mirres_res_t rt = res_slot(PB.rinit[b & 1], k, (size_t)N), rs = res_slot(PB.rspat[b & 1], k, (size_t)N);
+            csum(rt.light_data, 3 * (size_t)N); csum(rt.weight, (size_t)N);
             if (i > 0) {
-                // prev_* G-buffers alias the current ones from the second sample on (:462-465); a rank that starts in the
-                // middle of the sample range (spp sharding) has no history yet and skips the merge but keeps the pass numbering
-                if (i > i0) { rc = mirres_restir_temporal(ctx, &E, &G, &G, &R[cur], &R[cur ^ 1], nullptr, base + pass, s); if (rc) return rc; }
+                // prev_* G-buffers alias the current ones from the second sample on (:462-465); a rank that starts in the middle of the sample
+                // range (spp sharding) has no history yet and skips the merge but keeps the pass numbering
+                if (i > i0) {
+                    mirres_res_t rp = (k > 0) ? res_slot(PB.rspat[b & 1], k - 1, (size_t)N) : res_slot(PB.rspat[(b - 1) & 1], PB.K - 1, (size_t)N);
+                    rc = mirres_restir_temporal(ctx, &E, &G, &G, &rt, &rp, nullptr, base + pass, s); if (rc) return rc;
+                }
                 pass += 1;
             }
-            cur ^= 1;  // swap (:358)
-            rc = mirres_restir_spatial(ctx, bvh, &E, &G, &R[cur], &R[cur ^ 1], nullptr, base + pass, s); if (rc) return rc;
-            pass += 1;
-            csum(R[cur].light_data, 3 * (size_t)N); csum(R[cur].weight, (size_t)N);
-            rc = mirres_restir_final_vis(ctx, bvh, a->pos, &R[cur], B.vis, s); if (rc) return rc;
-            csum(B.vis, (size_t)N);
-            rc = mirres_restir_eval_final(ctx, &E, &R[cur], B.vis, B.fdir, B.fdist, B.fLi, s); if (rc) return rc;
-            rc = launch_final_shading(&E, a->occ, a->normal, B.ray_dir, a->kd, a->rough_metal, B.fdir, B.fdist, B.fLi, N, B.tot[0], B.tot[1], B.tot[2], true, s);
-            if (rc) return rc;
-            csum(B.fLi, 3 * (size_t)N); csum(B.tot[1], 3 * (size_t)N);
-            cur ^= 1;  // swap back (:460)
+            rc = mirres_restir_spatial(ctx, bvh, &E, &G, &rs, &rt, nullptr, base + pass, s); if (rc) return rc;
+            csum(rs.light_data, 3 * (size_t)N); csum(rs.weight, (size_t)N);
         }
-        // ---- path-tracing stages of samples ib .. ib+kk-1 (new direction, then max_bounce indirect vertices)
+        if (two_streams) MR_HIP(hipEventRecord(ev_chain(b), s));
+        // ---- bulk stream: path-tracing stages of samples ib .. ib+kk-1 (new direction, then max_bounce indirect vertices)
         PtQueues Q = PB.q; Q.NV = kk * N; Q.first_sample_is_zero = (ib == 0);
         uint32_t fi = a->random_offset + passes * (uint32_t)ib + 5;   // pass number of new_dir for a sample with a temporal pass before it
         mirres_path_t P0 = {a->occ, a->pos, a->normal, B.ray_dir, a->kd, a->rough_metal, PB.prd, PB.pos[0], PB.rd[0], PB.occ[0], PB.n[0]};
         rc = launch_new_dir(ctx, bvh, &P0, fi, 0, sp, &Q); if (rc) return rc;
         fi += 5;
         int src = 0;
-        for (int b = 1; b <= max_bounce; b++) {
+        for (int bo = 1; bo <= max_bounce; bo++) {
             // material lookup at the new vertices: compacted slot list -> hash-grid gather -> MFMA MLP -> scatter (slot_c is free between passes)
             if (a->mat && !(getenv("MIRRES_MATNET") && getenv("MIRRES_MATNET")[0] == 'v')) rc = launch_matnet_scatter_mfma(a->mat, PB.occ[src], PB.pos[src], Q.NV, PB.kd, PB.rm, a->use_scale, a->scale, Q.slot_c, &Q.counters[2], sp);
             else rc = launch_matnet_scatter(a->mat, PB.occ[src], PB.pos[src], Q.NV, PB.kd, PB.rm, a->use_scale, a->scale, a->const_kd, a->const_rm, sp);
             if (rc) return rc;
             mirres_path_t Pb = {PB.occ[src], PB.pos[src], PB.n[src], PB.rd[src], PB.kd, PB.rm, PB.prd, PB.pos[src ^ 1], PB.rd[src ^ 1], PB.occ[src ^ 1], PB.n[src ^ 1]};
-            float* cb = PB.cb + (size_t)(b - 1) * 9 * (size_t)Q.NV;
-            rc = launch_bounce(ctx, bvh, &E, &Pb, fi, (uint32_t)b, cb, cb + 3 * (size_t)Q.NV, cb + 6 * (size_t)Q.NV, nullptr, nullptr, nullptr, sp, &Q); if (rc) return rc;
+            float* cb = PB.cb + (size_t)(bo - 1) * 9 * (size_t)Q.NV;
+            rc = launch_bounce(ctx, bvh, &E, &Pb, fi, (uint32_t)bo, cb, cb + 3 * (size_t)Q.NV, cb + 6 * (size_t)Q.NV, nullptr, nullptr, nullptr, sp, &Q); if (rc) return rc;
             fi += 5;
             src ^= 1;
         }
         if (max_bounce > 0) k_pt_reduce<<<grid_for(n3, MR_BLOCK), MR_BLOCK, 0, sp>>>(N, kk, max_bounce, PB.cb, B.tot[3], B.tot[4], B.tot[5]);
+    }
+    {   // F(last)
+        if (two_streams) MR_HIP(hipStreamWaitEvent(sp, ev_chain(nbatch - 1), 0));
+        PtQueues Q = PB.q; Q.NV = batch_k(nbatch - 1) * N;
+        rc = launch_final_batch(ctx, bvh, &E, a->occ, a->pos, a->normal, B.ray_dir, a->kd, a->rough_metal, &PB.rspat[(nbatch - 1) & 1], batch_k(nbatch - 1), &Q, B.tot[0], B.tot[1], B.tot[2], sp);
+        if (rc) return rc;
     }
     if (two_streams) { MR_HIP(hipEventRecord(ctx->ev_join, sp)); MR_HIP(hipStreamWaitEvent(s, ctx->ev_join, 0)); }
     if (dbg_sum) {
         std::vector<unsigned long long> h(n_sums);
         MR_HIP(hipStreamSynchronize(s)); MR_HIP(hipMemcpy(h.data(), d_sums, 8 * (size_t)n_sums, hipMemcpyDeviceToHost)); (void)hipFree(d_sums);
         for (int k = 0; k < n_sums; k++) fprintf(stderr, "[sum %d] %016llx\n", k, h[k]);
+    }
     }
     if (partial) {
         for (int k = 0; k < 6; k++) MR_HIP(hipMemcpyAsync(a->outs[k], B.tot[k], sizeof(float) * n3, hipMemcpyDeviceToDevice, s));
