@@ -27,17 +27,45 @@ MR_DEV int tile_pixel(int fx, int fy, int tw, int N) {
 }
 static int tile_grid(int fx, int fy, int tw) { return ((fx + tw - 1) / tw) * ((fy + tw - 1) / tw); }
 
-struct GBufD { const float *occ, *pos, *normal_depth, *brdf, *ray_dir; };
-struct ResD { float* light_data; float* light_pdf; int32_t* M; float* weight; };
+// G-buffer / reservoir views. The ABI layout is the reference's SoA (one array per field). mirres_render's internal buffers use packed records so
+// that a neighbour gather touches one or two cache lines instead of seven:  GBufD::rec = 64 B per pixel {n.xyz depth | ray_dir.xyz occ | brdf.xyz 0 |
+// pos.xyz 0};  ResD::rec = 32 B per slot {light_data.xyz inv_pdf | M(int bits) weight 0 0}. Same values, same arithmetic — only the addresses differ.
+struct GBufD { const float *occ, *pos, *normal_depth, *brdf, *ray_dir; const float4* rec; };
+struct ResD { float* light_data; float* light_pdf; int32_t* M; float* weight; float4* rec; };
+struct GPix { v3 n; float depth; v3 rd; float occ; v3 brdf; };
+MR_DEV GPix load_gpix(const GBufD& G, size_t i) {   // normal+depth, ray_dir, occ, brdf of one pixel
+    GPix p;
+    if (G.rec) {
+        const float4 a = G.rec[4 * i], b = G.rec[4 * i + 1], c = G.rec[4 * i + 2];
+        p.n = V3(a.x, a.y, a.z); p.depth = a.w; p.rd = V3(b.x, b.y, b.z); p.occ = b.w; p.brdf = V3(c.x, c.y, c.z);
+    } else {
+        p.n = V3(G.normal_depth[4 * i], G.normal_depth[4 * i + 1], G.normal_depth[4 * i + 2]); p.depth = G.normal_depth[4 * i + 3];
+        p.rd = ld3(G.ray_dir, i); p.occ = G.occ[i]; p.brdf = ld3(G.brdf, i);
+    }
+    return p;
+}
+MR_DEV v3 load_gpos(const GBufD& G, size_t i) { if (G.rec) { const float4 d = G.rec[4 * i + 3]; return V3(d.x, d.y, d.z); } return ld3(G.pos, i); }
 struct ResV { v3 light_data; float light_pdf; int M; float weight; };
 struct Ris { v3 light_data; float inv_pdf, weightSum, M, weight, canonicalWeight; };
 
 MR_DEV Ris empty_ris() { Ris s; s.light_data = V3(0.f); s.inv_pdf = 0.f; s.weightSum = 0.f; s.M = 0.f; s.weight = 0.f; s.canonicalWeight = 0.f; return s; }
-MR_DEV ResV load_res(const ResD& R, size_t i) { ResV r; r.light_data = ld3(R.light_data, i); r.light_pdf = R.light_pdf[i]; r.M = R.M[i]; r.weight = R.weight[i]; return r; }
-MR_DEV void store_zero(const ResD& R, size_t i) { st3(R.light_data, i, V3(0.f)); R.light_pdf[i] = 0.f; R.M[i] = 0; R.weight[i] = 0.f; }
+MR_DEV ResV load_res(const ResD& R, size_t i) {
+    ResV r;
+    if (R.rec) { const float4 a = R.rec[2 * i], b = R.rec[2 * i + 1]; r.light_data = V3(a.x, a.y, a.z); r.light_pdf = a.w; r.M = __float_as_int(b.x); r.weight = b.y; }
+    else { r.light_data = ld3(R.light_data, i); r.light_pdf = R.light_pdf[i]; r.M = R.M[i]; r.weight = R.weight[i]; }
+    return r;
+}
+MR_DEV void store_res(const ResD& R, size_t i, v3 ld, float ipdf, int M, float w) {
+    if (R.rec) { float4 a, b; a.x = ld.x; a.y = ld.y; a.z = ld.z; a.w = ipdf; b.x = __int_as_float(M); b.y = w; b.z = 0.f; b.w = 0.f; R.rec[2 * i] = a; R.rec[2 * i + 1] = b; }
+    else { st3(R.light_data, i, ld); R.light_pdf[i] = ipdf; R.M[i] = M; R.weight[i] = w; }
+}
+MR_DEV v3 res_light(const ResD& R, size_t i) { if (R.rec) { const float4 a = R.rec[2 * i]; return V3(a.x, a.y, a.z); } return ld3(R.light_data, i); }
+MR_DEV int res_M(const ResD& R, size_t i) { return R.rec ? __float_as_int(R.rec[2 * i + 1].x) : R.M[i]; }
+MR_DEV float res_weight(const ResD& R, size_t i) { return R.rec ? R.rec[2 * i + 1].y : R.weight[i]; }
+MR_DEV void store_zero(const ResD& R, size_t i) { store_res(R, i, V3(0.f), 0.f, 0, 0.f); }
 MR_DEV void store_ris(const ResD& R, size_t i, const Ris& s) {
     if (isinf(s.weight) || isnan(s.weight)) { store_zero(R, i); return; }
-    st3(R.light_data, i, s.light_data); R.light_pdf[i] = s.inv_pdf; R.M[i] = (int)s.M; R.weight[i] = s.weight;
+    store_res(R, i, s.light_data, s.inv_pdf, (int)s.M, s.weight);
 }
 MR_DEV void put_ray(Ray* q, uint32_t slot, v3 pos, v3 dir, float vis_near) {
     v3 o = pos + vis_near * dir;  // origin offset along the RAY direction (VIS_near, e.g. InitialResampling.slang:264-265)
@@ -155,7 +183,8 @@ __global__ void __launch_bounds__(MR_GEN_BLOCK) k_initial_gen(mirres_config_t C,
         const int ks = sv / N, pi = sv - ks * N;
         const uint32_t frameIndex = frameIndex0 + 20u * (uint32_t)ks;
         tile_data += 3 * (size_t)ks * TS; tile_pdf += (size_t)ks * TS; tile_aux += (size_t)ks * TS;
-        if (G.occ[pi] < 0.1f) store_zero(R, sv);
+        const GPix gp = load_gpix(G, pi);
+        if (gp.occ < 0.1f) store_zero(R, sv);
         else {
             const uint32_t x = (uint32_t)(pi % fx), y = (uint32_t)(pi / fx);
             uint32_t tileSg = seed_generator(x / C.screen_tile_size, y / C.screen_tile_size, frameIndex);
@@ -164,8 +193,8 @@ __global__ void __launch_bounds__(MR_GEN_BLOCK) k_initial_gen(mirres_config_t C,
             uint32_t sg = seed_generator(x, y, frameIndex);
             uint32_t stride = (C.light_tile_size + C.initial_light_samples - 1) / C.initial_light_samples;
             uint32_t offset = min((uint32_t)(rnd(sg) * stride), stride - 1);
-            const v3 n = V3(G.normal_depth[4 * (size_t)pi], G.normal_depth[4 * (size_t)pi + 1], G.normal_depth[4 * (size_t)pi + 2]);
-            const rtarget::Ctx ctx = rtarget::make_ctx(n, ld3(G.ray_dir, pi), ld3(G.brdf, pi));
+            const v3 n = gp.n;
+            const rtarget::Ctx ctx = rtarget::make_ctx(n, gp.rd, gp.brdf);
             const float ratio = (float)C.initial_brdf_samples / (float)(C.initial_light_samples + C.initial_brdf_samples);
             Ris s = empty_ris();
             for (uint32_t i = 0; i < (uint32_t)C.initial_light_samples; ++i) {
@@ -195,7 +224,7 @@ __global__ void __launch_bounds__(MR_GEN_BLOCK) k_initial_gen(mirres_config_t C,
                 s.weightSum += w; s.M += 1.f;
                 if (rnd(sg) * s.weightSum < w) { s.light_data = ld; s.inv_pdf = lpdf; s.weight = targetPdf; }
             }
-            if (s.light_data.x > 0.1f) { want = true; rpos = ld3(G.pos, pi); rdir = oct_decode(V2(s.light_data.y, s.light_data.z)); }
+            if (s.light_data.x > 0.1f) { want = true; rpos = load_gpos(G, pi); rdir = oct_decode(V2(s.light_data.y, s.light_data.z)); }
             // reservoir as if the sample is visible; k_initial_resolve empties it when the shadow ray hits (:269-281)
             s.weight = s.weight > 0.f ? (s.weightSum / s.M) / s.weight : 0.f;
             s.M = 1.f;
@@ -210,7 +239,7 @@ __global__ void __launch_bounds__(MR_BLOCK) k_initial_resolve(ResD R, int N, con
     const int pi = blockIdx.x * blockDim.x + threadIdx.x;
     if (pi >= N) return;
     int s = slot[pi];
-    if (s >= 0 && hit[s]) { st3(R.light_data, pi, V3(0.f)); R.light_pdf[pi] = 0.f; R.M[pi] = 1; R.weight[pi] = 0.f; }  // createEmpty, then M := 1
+    if (s >= 0 && hit[s]) store_res(R, pi, V3(0.f), 0.f, 1, 0.f);  // createEmpty, then M := 1
 }
 
 // ---------------------------------------------------------------- temporal resampling (TemporalResampling.slang:23-135)
@@ -218,7 +247,8 @@ __global__ void __launch_bounds__(MR_BLOCK) k_temporal(mirres_config_t C, EnvD E
                                                        uint32_t frameIndex, int fx, int fy, int N) {
     const int pi = blockIdx.x * blockDim.x + threadIdx.x;
     if (pi >= N) return;
-    if (G.occ[pi] < 0.1f) return;
+    const GPix gc = load_gpix(G, pi);
+    if (gc.occ < 0.1f) return;
     const uint32_t x = (uint32_t)(pi % fx), y = (uint32_t)(pi / fx);
     uint32_t sg = seed_generator(x, y, frameIndex);
     float mvx = motion ? motion[2 * (size_t)pi] : 0.f, mvy = motion ? motion[2 * (size_t)pi + 1] : 0.f;
@@ -227,16 +257,15 @@ __global__ void __launch_bounds__(MR_BLOCK) k_temporal(mirres_config_t C, EnvD E
     int ppy = (int)(((float)y + mvy * (float)(uint32_t)fy) + (jy * 1.f - 0.f));
     if (ppx >= fx || ppx < 0 || ppy >= fy || ppy < 0) return;
     const size_t qi = (size_t)ppy * fx + ppx;
-    if (P.occ[qi] < 0.1f) return;
-    const v3 n = V3(G.normal_depth[4 * (size_t)pi], G.normal_depth[4 * (size_t)pi + 1], G.normal_depth[4 * (size_t)pi + 2]);
-    const float depth = G.normal_depth[4 * (size_t)pi + 3];
-    const v3 pn = V3(P.normal_depth[4 * qi], P.normal_depth[4 * qi + 1], P.normal_depth[4 * qi + 2]);
-    const float pdepth = P.normal_depth[4 * qi + 3];
+    const GPix gq = load_gpix(P, qi);
+    if (gq.occ < 0.1f) return;
+    const v3 n = gc.n; const float depth = gc.depth;
+    const v3 pn = gq.n; const float pdepth = gq.depth;
     ResV cur = load_res(R, pi), prev = load_res(PR, qi);
     prev.M = min(prev.M, cur.M * C.max_history);
     if (!(dot(n, pn) >= 0.5f && fabsf(depth - pdepth) <= 0.1f * depth)) return;  // isValidNeighbor res.slang:63-68
-    const rtarget::Ctx ctx = rtarget::make_ctx(n, ld3(G.ray_dir, pi), ld3(G.brdf, pi));
-    const rtarget::Ctx pctx = rtarget::make_ctx(pn, ld3(P.ray_dir, qi), ld3(P.brdf, qi));
+    const rtarget::Ctx ctx = rtarget::make_ctx(n, gc.rd, gc.brdf);
+    const rtarget::Ctx pctx = rtarget::make_ctx(pn, gq.rd, gq.brdf);
     Ris s = empty_ris();
     v3 ldir = oct_decode(V2(cur.light_data.y, cur.light_data.z));
     float targetPdf = rtarget::target(ctx, env_radiance(E, ldir), ldir);
@@ -267,69 +296,86 @@ __global__ void __launch_bounds__(MR_BLOCK) k_temporal(mirres_config_t C, EnvD E
 MR_DEV float m_factor(float q0, float q1) { return q0 == 0.f ? 1.f : clampf(powf(fminf(q1 / q0, 1.f), 8.f), 0.f, 1.f); }
 MR_DEV float pairwise_mis(float q0, float q1, float N0, float N1) { return (q1 == 0.f) ? 0.f : (N0 * q0) / (q0 * N0 + q1 * N1); }
 
-// neighbour acceptance exactly in the reference's order of `continue`s (:236-258); returns the pixel index or -1
-MR_DEV int spatial_neighbor(const mirres_config_t& C, const GBufD& G, const ResD& PR, const float* __restrict__ noff, uint32_t startIndex, uint32_t i,
-                            int x, int y, int fx, int fy, v3 n, float depth) {
-    uint32_t ni = (startIndex + i) & (uint32_t)(C.neighbor_offset_count - 1);
-    int nx = x + (int)(noff[2 * ni] * C.gather_radius);
-    int ny = y + (int)(noff[2 * ni + 1] * C.gather_radius);
-    if (!(nx >= 0 && ny >= 0 && nx < fx && ny < fy)) return -1;
-    size_t qi = (size_t)ny * fx + nx;
-    v3 nn = V3(G.normal_depth[4 * qi], G.normal_depth[4 * qi + 1], G.normal_depth[4 * qi + 2]);
-    float ndepth = G.normal_depth[4 * qi + 3];
-    if (!(dot(n, nn) >= 0.5f && fabsf(depth - ndepth) <= 0.1f * depth)) return -1;
-    if (PR.M[qi] == 0) return -1;
-    if (G.occ[qi] < 0.1f) return -1;
-    return (int)qi;
-}
-
+// neighbour acceptance in the reference's order of `continue`s (:236-258): in bounds -> normal / depth similar -> neighbour reservoir M != 0 ->
+// neighbour is foreground. The loads of all candidate neighbours are issued before any test is looked at (a runtime loop with early-outs made
+// each of the ~15 gathers of a pixel wait for the previous one: the kernel spent its time on dependent L2 round trips); the tests are unchanged.
+template <int MR_MAX_NB>   // 5 (the reference's neighbour count) or 8: bounds the unrolled gathers, i.e. the registers held
 __global__ void __launch_bounds__(MR_GEN_BLOCK) k_spatial_gen(mirres_config_t C, GBufD G, ResD PR, const float* __restrict__ noff, uint32_t frameIndex,
                                                           int fx, int fy, int N, Ray* __restrict__ q, uint32_t* __restrict__ q_count,
                                                           int32_t* __restrict__ slot_out, uint32_t* __restrict__ mask_out) {
     const int pi = tile_pixel(fx, fy, 32, N);
     uint32_t mask = 0, cnt = 0;
-    int nb[8];
+    int nb[MR_MAX_NB];
     v3 cpos = V3(0.f), cdir = V3(0.f);
-    if (pi < N && !(G.occ[pi] < 0.1f)) {
+    const int k = min(C.neighbor_count, MR_MAX_NB);
+    GPix gc; gc.occ = 0.f;
+    if (pi < N) gc = load_gpix(G, pi);
+    if (pi < N && !(gc.occ < 0.1f)) {
         const int x = pi % fx, y = pi / fx;
         uint32_t sg = seed_generator((uint32_t)x, (uint32_t)y, frameIndex);
         const uint32_t startIndex = (uint32_t)(rnd(sg) * C.neighbor_offset_count);
-        const v3 n = V3(G.normal_depth[4 * (size_t)pi], G.normal_depth[4 * (size_t)pi + 1], G.normal_depth[4 * (size_t)pi + 2]);
-        const float depth = G.normal_depth[4 * (size_t)pi + 3];
-        const int k = min(C.neighbor_count, 8);
-        for (int i = 0; i < k; i++) {
-            int qi = spatial_neighbor(C, G, PR, noff, startIndex, (uint32_t)i, x, y, fx, fy, n, depth);
-            nb[i] = qi;
-            if (qi >= 0) { mask |= 1u << i; cnt++; }
+        const v3 n = gc.n; const float depth = gc.depth;
+        float4 nd[MR_MAX_NB]; float nocc[MR_MAX_NB]; int nM[MR_MAX_NB];
+#pragma unroll
+        for (int i = 0; i < MR_MAX_NB; i++) {
+            nb[i] = -1;
+            if (i < k) {
+                const uint32_t ni = (startIndex + (uint32_t)i) & (uint32_t)(C.neighbor_offset_count - 1);
+                const int nx = x + (int)(noff[2 * ni] * C.gather_radius), ny = y + (int)(noff[2 * ni + 1] * C.gather_radius);
+                if (nx >= 0 && ny >= 0 && nx < fx && ny < fy) nb[i] = ny * fx + nx;
+            }
         }
-        if (cnt) { cpos = ld3(G.pos, pi); cdir = oct_decode(V2(PR.light_data[3 * (size_t)pi + 1], PR.light_data[3 * (size_t)pi + 2])); }
+#pragma unroll
+        for (int i = 0; i < MR_MAX_NB; i++) {
+            if (nb[i] >= 0) {
+                const size_t qi = (size_t)nb[i];
+                if (G.rec) { nd[i] = G.rec[4 * qi]; nocc[i] = G.rec[4 * qi + 1].w; }
+                else { nd[i] = reinterpret_cast<const float4*>(G.normal_depth)[qi]; nocc[i] = G.occ[qi]; }
+                nM[i] = res_M(PR, qi);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MR_MAX_NB; i++) {
+            bool ok = nb[i] >= 0;
+            if (ok) {
+                const v3 nn = V3(nd[i].x, nd[i].y, nd[i].z);
+                ok = dot(n, nn) >= 0.5f && fabsf(depth - nd[i].w) <= 0.1f * depth;   // isValidNeighbor (res.slang:63-68)
+                ok = ok && nM[i] != 0 && !(nocc[i] < 0.1f);
+            }
+            if (ok) { mask |= 1u << i; cnt++; } else nb[i] = -1;
+        }
+        if (cnt) { cpos = load_gpos(G, pi); const v3 cl = res_light(PR, pi); cdir = oct_decode(V2(cl.y, cl.z)); }
     }
     uint32_t base = block_append(q_count, cnt > 0, 2 * cnt);
     if (cnt) {
+        v3 nl[MR_MAX_NB], np[MR_MAX_NB];
+#pragma unroll
+        for (int i = 0; i < MR_MAX_NB; i++) if (mask & (1u << i)) { nl[i] = res_light(PR, (size_t)nb[i]); np[i] = load_gpos(G, (size_t)nb[i]); }
         uint32_t s = base;
-        const int k = min(C.neighbor_count, 8);
-        for (int i = 0; i < k; i++) {
+#pragma unroll
+        for (int i = 0; i < MR_MAX_NB; i++) {
             if (!(mask & (1u << i))) continue;
-            size_t qi = (size_t)nb[i];
-            v3 ndir = oct_decode(V2(PR.light_data[3 * qi + 1], PR.light_data[3 * qi + 2]));
-            put_ray(q, s, cpos, ndir, C.vis_near);                 // canonical pixel towards the neighbour's light
-            put_ray(q, s + 1, ld3(G.pos, qi), cdir, C.vis_near);   // neighbour towards the canonical light
+            const v3 ndir = oct_decode(V2(nl[i].y, nl[i].z));
+            put_ray(q, s, cpos, ndir, C.vis_near);        // canonical pixel towards the neighbour's light
+            put_ray(q, s + 1, np[i], cdir, C.vis_near);   // neighbour towards the canonical light
             s += 2;
         }
     }
     if (pi < N) { slot_out[pi] = cnt ? (int32_t)base : -1; mask_out[pi] = mask; }
 }
 
+template <int MR_MAX_NB>
 __global__ void __launch_bounds__(MR_BLOCK) k_spatial_resolve(mirres_config_t C, EnvD E, GBufD G, ResD R, ResD PR, const float* __restrict__ noff,
                                                               uint32_t frameIndex, int fx, int fy, int N, const int32_t* __restrict__ slot,
                                                               const uint32_t* __restrict__ mask_in, const int32_t* __restrict__ hit) {
     const int pi = tile_pixel(fx, fy, 16, N);
     if (pi >= N) return;
-    if (G.occ[pi] < 0.1f) { store_zero(R, pi); return; }
+    const GPix gc = load_gpix(G, pi);
+    if (gc.occ < 0.1f) { store_zero(R, pi); return; }
     const int x = pi % fx, y = pi / fx;
     uint32_t sg = seed_generator((uint32_t)x, (uint32_t)y, frameIndex);
-    const v3 n = V3(G.normal_depth[4 * (size_t)pi], G.normal_depth[4 * (size_t)pi + 1], G.normal_depth[4 * (size_t)pi + 2]);
-    const rtarget::Ctx ctx = rtarget::make_ctx(n, ld3(G.ray_dir, pi), ld3(G.brdf, pi));
+    const v3 n = gc.n;
+    const rtarget::Ctx ctx = rtarget::make_ctx(n, gc.rd, gc.brdf);
     Ris s = empty_ris();
     const uint32_t startIndex = (uint32_t)(rnd(sg) * C.neighbor_offset_count);
     ResV cur = load_res(PR, pi);
@@ -341,14 +387,23 @@ __global__ void __launch_bounds__(MR_BLOCK) k_spatial_resolve(mirres_config_t C,
     const uint32_t k = (uint32_t)C.neighbor_count;
     const uint32_t mask = mask_in[pi];
     int hs = slot[pi];
-    for (uint32_t i = 0; i < k; ++i) {
-        if (!(mask & (1u << i))) continue;
-        uint32_t ni = (startIndex + i) & (uint32_t)(C.neighbor_offset_count - 1);
-        int nx = x + (int)(noff[2 * ni] * C.gather_radius), ny = y + (int)(noff[2 * ni + 1] * C.gather_radius);
-        size_t qi = (size_t)ny * fx + nx;
-        const v3 nn = V3(G.normal_depth[4 * qi], G.normal_depth[4 * qi + 1], G.normal_depth[4 * qi + 2]);
-        ResV nbr = load_res(PR, qi);
-        const rtarget::Ctx nctx = rtarget::make_ctx(nn, ld3(G.ray_dir, qi), ld3(G.brdf, qi));
+    // the accepted neighbours' pixel data and reservoirs are fetched up front (independent gathers in flight together), then merged in order
+    GPix gnb[MR_MAX_NB]; ResV rnb[MR_MAX_NB];
+#pragma unroll
+    for (int i = 0; i < MR_MAX_NB; i++) {
+        if ((uint32_t)i < k && (mask & (1u << i))) {
+            const uint32_t ni = (startIndex + (uint32_t)i) & (uint32_t)(C.neighbor_offset_count - 1);
+            const int nx = x + (int)(noff[2 * ni] * C.gather_radius), ny = y + (int)(noff[2 * ni + 1] * C.gather_radius);
+            const size_t qi = (size_t)ny * fx + nx;
+            gnb[i] = load_gpix(G, qi); rnb[i] = load_res(PR, qi);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MR_MAX_NB; i++) {
+        if (!((uint32_t)i < k && (mask & (1u << i)))) continue;
+        const v3 nn = gnb[i].n;
+        const ResV nbr = rnb[i];
+        const rtarget::Ctx nctx = rtarget::make_ctx(nn, gnb[i].rd, gnb[i].brdf);
         ++validNeighbors;
         const v3 ndir = oct_decode(V2(nbr.light_data.y, nbr.light_data.z));
         const v3 nem = env_radiance(E, ndir);
@@ -385,7 +440,7 @@ __global__ void __launch_bounds__(MR_GEN_BLOCK) k_vis_gen(float vis_near, const 
     const int sv = blockIdx.x * blockDim.x + threadIdx.x;   // slot k * N + pixel (reservoir per slot, position per pixel)
     bool want = false; v3 rp = V3(0.f), rd = V3(0.f);
     if (sv < NV) {
-        v3 ld = ld3(R.light_data, sv);
+        v3 ld = res_light(R, sv);
         if (ld.x > 0.1f) { want = true; rp = ld3(pos, sv % N); rd = oct_decode(V2(ld.y, ld.z)); }
     }
     uint32_t slot = block_append(q_count, want);
@@ -411,12 +466,12 @@ __global__ void __launch_bounds__(MR_BLOCK) k_final_direct(EnvD E, const float* 
         if (fg) {
             const int sl = slot[sv];
             const float vis = (sl >= 0 && hit[sl]) ? 0.0f : 1.0f;                       // k_vis_resolve
-            const v3 ld = ld3(R.light_data, sv);
+            const v3 ld = res_light(R, sv);
             v3 dir = V3(0.f), Li = V3(0.f); float dist = 0.f;
             if (ld.x > 0.1f) {                                                           // k_eval_final
                 const v3 ldir = oct_decode(V2(ld.y, ld.z));
                 const v3 em = env_radiance(E, ldir);
-                if (vis > 0.f) { dir = ldir; dist = 1e6f; Li = R.weight[sv] * em; }
+                if (vis > 0.f) { dir = ldir; dist = 1e6f; Li = res_weight(R, sv) * em; }
             }
             v3 dv = V3(0.f), sv3 = V3(0.f);                                              // k_final_shading
             if (dist > 0.f) {
@@ -469,8 +524,13 @@ __global__ void __launch_bounds__(MR_BLOCK) k_eval_final_bwd(EnvD E, ResD R, con
     }
 }
 
-static GBufD gbufd(const mirres_gbuf_t* g) { GBufD G; G.occ = g->occ; G.pos = g->pos; G.normal_depth = g->normal_depth; G.brdf = g->brdf; G.ray_dir = g->ray_dir; return G; }
-static ResD resd(const mirres_res_t* r) { ResD R; R.light_data = r->light_data; R.light_pdf = r->light_pdf; R.M = r->M; R.weight = r->weight; return R; }
+// internal convention (mirres_render only; the ABI entry points never see it): light_pdf == NULL -> `light_data` points to packed reservoir records
+static GBufD gbufd(const mirres_gbuf_t* g) { GBufD G; G.occ = g->occ; G.pos = g->pos; G.normal_depth = g->normal_depth; G.brdf = g->brdf; G.ray_dir = g->ray_dir; G.rec = nullptr; return G; }
+static ResD resd(const mirres_res_t* r) {
+    ResD R; R.light_data = r->light_data; R.light_pdf = r->light_pdf; R.M = r->M; R.weight = r->weight; R.rec = nullptr;
+    if (!r->light_pdf) { R.rec = reinterpret_cast<float4*>(r->light_data); R.light_data = nullptr; }
+    return R;
+}
 static EnvD envh(const mirres_env_t* e) { EnvD E; E.tex = e->tex; E.W = e->Wc; E.H = e->Hc; E.pdf = e->pdf; E.cdf = e->cdf; E.mpdf = e->mpdf; E.mcdf = e->mcdf; return E; }
 
 int trace_closest_queue_counted(const mirres_bvh* bvh, const Ray* rays, const uint32_t* d_count, size_t capacity, HitRec* out,
@@ -658,11 +718,18 @@ int mirres_restir_spatial(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_env
     hipStream_t s = (hipStream_t)stream; const int N = (int)ctx->N; const int grd = grid_for(N, MR_BLOCK);
     const float* noff = neighbor_offsets ? neighbor_offsets : ctx->noff;
     MR_HIP(hipMemsetAsync(&ctx->counters[0], 0, sizeof(uint32_t), s));
-    k_spatial_gen<<<tile_grid(ctx->fx, ctx->fy, 32), MR_GEN_BLOCK, 0, s>>>(ctx->cfg, gbufd(g), resd(prev_res), noff, frameIndex, ctx->fx, ctx->fy, N, ctx->any_rays, &ctx->counters[0],
-                                            ctx->slot_a, ctx->mask_a);
+    const bool nb5 = ctx->cfg.neighbor_count <= 5;
+    if (nb5) k_spatial_gen<5><<<tile_grid(ctx->fx, ctx->fy, 32), MR_GEN_BLOCK, 0, s>>>(ctx->cfg, gbufd(g), resd(prev_res), noff, frameIndex, ctx->fx, ctx->fy, N, ctx->any_rays, &ctx->counters[0],
+                                                                                   ctx->slot_a, ctx->mask_a);
+    else k_spatial_gen<8><<<tile_grid(ctx->fx, ctx->fy, 32), MR_GEN_BLOCK, 0, s>>>(ctx->cfg, gbufd(g), resd(prev_res), noff, frameIndex, ctx->fx, ctx->fy, N, ctx->any_rays, &ctx->counters[0],
+                                                                               ctx->slot_a, ctx->mask_a);
     int rc = trace_any(ctx, bvh, ctx->any_cap, s); if (rc) return rc;
-    k_spatial_resolve<<<tile_grid(ctx->fx, ctx->fy, 16), MR_BLOCK, 0, s>>>(ctx->cfg, envh(env), gbufd(g), resd(res), resd(prev_res), noff, frameIndex, ctx->fx, ctx->fy, N, ctx->slot_a,
-                                                ctx->mask_a, ctx->any_hit);
+    GBufD gr = gbufd(g);
+    if (ctx->grec) gr.rec = reinterpret_cast<const float4*>(ctx->grec);   // mirres_render: same values, one 64-byte record per neighbour instead of three arrays
+    if (nb5) k_spatial_resolve<5><<<tile_grid(ctx->fx, ctx->fy, 16), MR_BLOCK, 0, s>>>(ctx->cfg, envh(env), gr, resd(res), resd(prev_res), noff, frameIndex, ctx->fx, ctx->fy, N,
+                                                                                   ctx->slot_a, ctx->mask_a, ctx->any_hit);
+    else k_spatial_resolve<8><<<tile_grid(ctx->fx, ctx->fy, 16), MR_BLOCK, 0, s>>>(ctx->cfg, envh(env), gr, resd(res), resd(prev_res), noff, frameIndex, ctx->fx, ctx->fy, N,
+                                                                               ctx->slot_a, ctx->mask_a, ctx->any_hit);
     MR_LAUNCH_CHECK("restir_spatial");
     return MIRRES_OK;
 }

@@ -24,7 +24,8 @@ int launch_matnet_scatter_mfma(const mirres_matnet_t* m, const float* occ, const
 // run_restir_di_with_pt :484-486 + restir_di_with_pt :279-287
 __global__ void __launch_bounds__(MR_BLOCK) k_prep(int N, float* __restrict__ occ, const float* __restrict__ ray_dir_in, const float* __restrict__ normal,
                                                    const float* __restrict__ depth, const float* __restrict__ kd, const float* __restrict__ rm,
-                                                   float* __restrict__ ray_dir, float* __restrict__ nd, float* __restrict__ brdf) {
+                                                   float* __restrict__ ray_dir, float* __restrict__ nd, float* __restrict__ brdf, const float* __restrict__ pos,
+                                                   float4* __restrict__ grec) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     if (occ[i] <= 0.5f) occ[i] = 0.f;
@@ -38,6 +39,13 @@ __global__ void __launch_bounds__(MR_BLOCK) k_prep(int N, float* __restrict__ oc
     brdf[3 * (size_t)i + 1] = (m * 0.2126f + m * 0.7152f) + m * 0.0722f;
     float a = fminf(fmaxf(r, 0.01f), 1.f);
     brdf[3 * (size_t)i + 2] = a * a;
+    // the same values as one 64-byte record per pixel for the neighbour gathers of the reuse passes (passes.hip GBufD::rec)
+    float4 r0, r1, r2, r3;
+    r0.x = nd[4 * (size_t)i]; r0.y = nd[4 * (size_t)i + 1]; r0.z = nd[4 * (size_t)i + 2]; r0.w = nd[4 * (size_t)i + 3];
+    r1.x = ray_dir[3 * (size_t)i]; r1.y = ray_dir[3 * (size_t)i + 1]; r1.z = ray_dir[3 * (size_t)i + 2]; r1.w = occ[i];
+    r2.x = brdf[3 * (size_t)i]; r2.y = brdf[3 * (size_t)i + 1]; r2.z = brdf[3 * (size_t)i + 2]; r2.w = 0.f;
+    r3.x = pos[3 * (size_t)i]; r3.y = pos[3 * (size_t)i + 1]; r3.z = pos[3 * (size_t)i + 2]; r3.w = 0.f;
+    grec[4 * (size_t)i] = r0; grec[4 * (size_t)i + 1] = r1; grec[4 * (size_t)i + 2] = r2; grec[4 * (size_t)i + 3] = r3;
 }
 __global__ void __launch_bounds__(MR_BLOCK) k_flip_env(int W, int H, const float* __restrict__ in, float* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -98,7 +106,7 @@ struct Pool {
 };
 
 static size_t pool_need(size_t N, size_t WH, size_t H, size_t TS) {
-    size_t per_px = 3 + 4 + 3 + 12 + 1 + 3 + 1 + 3 + 18 + 9 + 5 + 10 + 10 + 5 + 6 + 3;
+    size_t per_px = 3 + 4 + 3 + 12 + 1 + 3 + 1 + 3 + 18 + 9 + 5 + 10 + 10 + 5 + 6 + 3 + 16 + 1;
     return per_px * N + 3 * WH + WH + (WH + H) + H + (H + 1) + 4 * TS + 64 * 64;
 }
 
@@ -107,7 +115,7 @@ static size_t pool_need(size_t N, size_t WH, size_t H, size_t TS) {
 using namespace mr;
 
 struct FrameBufs {
-    float *ray_dir, *nd, *brdf;
+    float *ray_dir, *nd, *brdf, *grec;
     float *r_ld[2], *r_pdf[2], *r_w[2]; int32_t* r_M[2];
     float *vis, *fdir, *fdist, *fLi;
     float* tot[6];  // total_color, total_diff, total_spec, total_color_1, total_diff_1, total_spec_1
@@ -136,7 +144,8 @@ static int carve(mirres_ctx* ctx, int Wc, int Hc, FrameBufs& B) {
     B.tex = P.take(3 * WH); B.pdf = P.take(WH); B.cdf = P.take(WH + Hc); B.mpdf = P.take(Hc); B.mcdf = P.take(Hc + 1);
     B.tile_data = P.take(3 * TS); B.tile_pdf = P.take(TS);
     B.den_a = P.take(3 * N); B.den_b = P.take(3 * N); B.comb = B.c1;  // comb reuses c1 after the loop
-    if (!B.den_b) { set_error("mirres_render: internal pool too small"); return MIRRES_E_STATE; }
+    B.grec = P.take(16 * N);
+    if (!B.den_b || !B.grec) { set_error("mirres_render: internal pool too small"); return MIRRES_E_STATE; }
     return 0;
 }
 
@@ -149,8 +158,8 @@ struct PtBatch {
     mirres_res_t rinit[2], rspat[2];
     float *tile_data, *tile_pdf, *tile_aux;
 };
-static mirres_res_t res_slot(const mirres_res_t& r, int k, size_t N) {
-    mirres_res_t o; o.light_data = r.light_data + 3 * (size_t)k * N; o.light_pdf = r.light_pdf + (size_t)k * N; o.M = r.M + (size_t)k * N; o.weight = r.weight + (size_t)k * N; return o;
+static mirres_res_t res_slot(const mirres_res_t& r, int k, size_t N) {   // packed 32-byte records (passes.hip resd(): light_pdf == NULL)
+    mirres_res_t o; o.light_data = r.light_data + 8 * (size_t)k * N; o.light_pdf = nullptr; o.M = nullptr; o.weight = nullptr; return o;
 }
 static int pt_batch_size() {   // MIRRES_PT_BATCH = samples per path-tracing launch (default 16; 1 = sample by sample)
     const char* e = getenv("MIRRES_PT_BATCH");   // read per frame (tests switch it)
@@ -166,7 +175,7 @@ static int carve_batch(mirres_ctx* ctx, int N, int K, int max_bounce, size_t TS,
     const int nb = max_bounce > 0 ? max_bounce : 1;
     size_t need = al(sizeof(Ray) * 2 * NV) + al(4 * 2 * NV) + al(sizeof(Ray) * NV) + al(sizeof(HitRec) * NV) + al(64) + 3 * al(4 * NV) + al(4 * 18 * NV)
                 + al(4 * 5 * NV) + 2 * (3 * al(4 * 3 * NV) + al(4 * NV)) + al(4 * 3 * NV) + al(4 * 2 * NV) + al(4 * 9 * NV * (size_t)nb)
-                + 4 * (al(4 * 3 * NV) + 3 * al(4 * NV)) + al(4 * 3 * (size_t)K * TS) + al(4 * (size_t)K * TS) + al(16 * (size_t)K * TS);
+                + 4 * al(4 * 8 * NV) + al(4 * 3 * (size_t)K * TS) + al(4 * (size_t)K * TS) + al(16 * (size_t)K * TS);
     if (ctx->ptb_bytes < need) {
         if (ctx->ptb) { MR_HIP(hipDeviceSynchronize()); MR_HIP(hipFree(ctx->ptb)); ctx->ptb = nullptr; ctx->ptb_bytes = 0; }
         MR_HIP(hipMalloc(&ctx->ptb, need));
@@ -188,7 +197,7 @@ static int carve_batch(mirres_ctx* ctx, int N, int K, int max_bounce, size_t TS,
     PB.cb = (float*)take(4 * 9 * NV * (size_t)nb);
     for (int k = 0; k < 4; k++) {
         mirres_res_t& r = (k < 2) ? PB.rinit[k] : PB.rspat[k - 2];
-        r.light_data = (float*)take(4 * 3 * NV); r.light_pdf = (float*)take(4 * NV); r.M = (int32_t*)take(4 * NV); r.weight = (float*)take(4 * NV);
+        r.light_data = (float*)take(4 * 8 * NV); r.light_pdf = nullptr; r.M = nullptr; r.weight = nullptr;
     }
     PB.tile_data = (float*)take(4 * 3 * (size_t)K * TS); PB.tile_pdf = (float*)take(4 * (size_t)K * TS); PB.tile_aux = (float*)take(16 * (size_t)K * TS);
     return 0;
@@ -232,7 +241,7 @@ int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args
     const int i0 = partial ? a->spp_begin : 0, i1 = partial ? a->spp_end : a->spp;
     const int grd = grid_for(N, MR_BLOCK);
 
-    k_prep<<<grd, MR_BLOCK, 0, s>>>(N, a->occ, a->ray_dir, a->normal, a->depth, a->kd, a->rough_metal, B.ray_dir, B.nd, B.brdf);
+    k_prep<<<grd, MR_BLOCK, 0, s>>>(N, a->occ, a->ray_dir, a->normal, a->depth, a->kd, a->rough_metal, B.ray_dir, B.nd, B.brdf, a->pos, reinterpret_cast<float4*>(B.grec));
     k_flip_env<<<grid_for((size_t)Wc * Hc, MR_BLOCK), MR_BLOCK, 0, s>>>(Wc, Hc, a->env_map, B.tex);
     rc = mirres_env_make_sampleable(B.tex, Wc, Hc, B.pdf, B.cdf, B.mpdf, B.mcdf, s); if (rc) return rc;
     // zero-initialised state of restir_di_with_pt (:252-302)
@@ -240,6 +249,8 @@ int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args
     MR_HIP(hipMemsetAsync(B.tot[0], 0, sizeof(float) * (size_t)(B.tex - B.tot[0]), s));      // totals .. new_rm
     mirres_env_t E = {B.tex, Wc, Hc, B.pdf, B.cdf, B.mpdf, B.mcdf};
     mirres_gbuf_t G = {a->occ, a->pos, B.nd, B.brdf, B.ray_dir};
+    struct GrecGuard { mirres_ctx* c; ~GrecGuard() { c->grec = nullptr; } } grec_guard{ctx};
+    ctx->grec = B.grec;   // packed copy for the neighbour gathers of the spatial merge; cleared when this call returns (the launches captured the pointer)
     const uint32_t passes = 20;  // mTotalRISPasses (:242)
     const int max_bounce = ctx->cfg.max_bounce;
 
@@ -306,7 +317,7 @@ int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args
             const uint32_t base = a->random_offset + passes * (uint32_t)i;
             uint32_t pass = 3;
             mirres_res_t rt = res_slot(PB.rinit[b & 1], k, (size_t)N), rs = res_slot(PB.rspat[b & 1], k, (size_t)N);
-            csum(rt.light_data, 3 * (size_t)N); csum(rt.weight, (size_t)N);
+            csum(rt.light_data, 8 * (size_t)N);
             if (i > 0) {
                 // prev_* G-buffers alias the current ones from the second sample on (:462-465); a rank that starts in the middle of the sample
                 // range (spp sharding) has no history yet and skips the merge but keeps the pass numbering
@@ -317,7 +328,7 @@ int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args
                 pass += 1;
             }
             rc = mirres_restir_spatial(ctx, bvh, &E, &G, &rs, &rt, nullptr, base + pass, s); if (rc) return rc;
-            csum(rs.light_data, 3 * (size_t)N); csum(rs.weight, (size_t)N);
+            csum(rs.light_data, 8 * (size_t)N);
         }
         if (two_streams) MR_HIP(hipEventRecord(ev_chain(b), s));
         // ---- bulk stream: path-tracing stages of samples ib .. ib+kk-1 (new direction, then max_bounce indirect vertices)
