@@ -7,8 +7,8 @@ python3 bench.py > gpurun_out/out/${R}_bench_default.json 2> gpurun_out/out/${R}
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pf/kt -o kt -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/pf/kt/log 2>&1
 grep '^{' gpurun_out/pf/kt/log | tail -1 > gpurun_out/out/${R}_bench_under_rocprof.json
 cp gpurun_out/pf/kt/kt_kernel_stats.csv gpurun_out/out/${R}_kernel_stats.csv
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pf/fetch -o f -- python3 bench.py --spp 4 --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > gpurun_out/pf/fetch/log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pf/write -o w -- python3 bench.py --spp 4 --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > gpurun_out/pf/write/log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pf/fetch -o f -- python3 bench.py --spp 8 --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > gpurun_out/pf/fetch/log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pf/write -o w -- python3 bench.py --spp 8 --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > gpurun_out/pf/write/log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pf/mlp -o m -- python3 scripts/dev_mlp_bench.py > gpurun_out/pf/mlp/log 2>&1
 cp gpurun_out/pf/mlp/m_kernel_stats.csv gpurun_out/out/${R}_mlp_kernel_stats.csv
 grep -E '^(mlp_mfma|valu)' gpurun_out/pf/mlp/log > gpurun_out/out/${R}_mlp_bench.txt
@@ -30,9 +30,9 @@ def pick(d, key):
     for k, v in d.items():
         if key in k: return v
     return {'avg_KB': 0.0, 'launches': 0}
-f = pick(out['FETCH_SIZE'], 'k_trace_any4<false'); w = pick(out['WRITE_SIZE'], 'k_trace_any4<false')
-json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --spp 4 --steps 1 --warmup 0 --no-cpu-baseline --no-roofline",
-           "kernel": "mr::k_trace_any4<false, 85>", "launches_sampled": f['launches'], "FETCH_SIZE_KB_avg": f['avg_KB'], "WRITE_SIZE_KB_avg": w['avg_KB'],
+f = pick(out['FETCH_SIZE'], 'k_trace_any4q<false'); w = pick(out['WRITE_SIZE'], 'k_trace_any4q<false')
+json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --spp 8 --steps 1 --warmup 0 --no-cpu-baseline --no-roofline",
+           "kernel": "mr::k_trace_any4q<false, 85>", "launches_sampled": f['launches'], "FETCH_SIZE_KB_avg": f['avg_KB'], "WRITE_SIZE_KB_avg": w['avg_KB'],
            "correction": "gfx950: FETCH_SIZE reports 1/2 of the bytes of 16-B/lane loads (MI355X_MICROARCH.md, HBM section) -> doubled; WRITE_SIZE as reported; the guide calibrates the factor on streaming reads, so for the traversal's dwordx4 gathers it is an extrapolation",
            "k_trace_any_hbm_bytes_per_launch": round((2 * f['avg_KB'] + w['avg_KB']) * 1024)}, open('gpurun_out/out/pmc_traffic.json', 'w'), indent=1)
 print(open('gpurun_out/out/pmc_traffic.json').read())
