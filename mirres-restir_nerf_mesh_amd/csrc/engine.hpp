@@ -129,7 +129,7 @@ int check_hip(hipError_t e, const char* what);
 
 // queue tracing (bvh_trace.hip). count is read on the device; capacity bounds the grid-stride loop.
 int trace_any_queue(const mirres_bvh* bvh, const Ray* rays, const uint32_t* d_count, size_t capacity, int32_t* hit,
-                    unsigned long long* stats, hipStream_t s, int lane = 0);
+                    unsigned long long* stats, hipStream_t s, int lane = 0, int timed = 0);
 int trace_closest_queue(const mirres_bvh* bvh, const Ray* rays, const uint32_t* d_count, size_t capacity, HitRec* out,
                         unsigned long long* stats, hipStream_t s, int lane = 0);
 int trace_any(mirres_ctx* ctx, mirres_bvh* bvh, size_t cap, hipStream_t s);       // ctx->any_rays -> ctx->any_hit

@@ -548,7 +548,7 @@ int trace_any_q(mirres_ctx* ctx, mirres_bvh* bvh, const Ray* rays, const uint32_
     hipEvent_t *e0 = nullptr, *e1 = nullptr;
     if (ctx->instrument & 2) { int rc = ev_pair(ctx->ev_any, ctx->ev_any_used, &e0, &e1); if (rc) return rc; MR_HIP(hipEventRecord(*e0, s)); }
     int rc = (ctx->instrument & 1) ? trace_any_queue_counted(bvh, rays, count, cap, hit, ctx->stats, s, (ctx->instrument & 4) != 0)
-                                   : trace_any_queue(bvh, rays, count, cap, hit, ctx->stats, s, lane);
+                                   : trace_any_queue(bvh, rays, count, cap, hit, ctx->stats, s, lane, (ctx->instrument & 2) != 0);
     if (e1) MR_HIP(hipEventRecord(*e1, s));
     return rc;
 }

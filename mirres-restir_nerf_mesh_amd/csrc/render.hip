@@ -261,7 +261,11 @@ int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args
     if (i1 > i0) {   // an empty slice of the sample range (spp sharding with more ranks than samples) leaves the zeroed totals
     const int Kmax = pt_batch_size();
     const size_t TS = (size_t)ctx->cfg.light_tile_count * ctx->cfg.light_tile_size;
-    PtBatch PB; rc = carve_batch(ctx, N, Kmax < (i1 - i0) ? Kmax : (i1 - i0), max_bounce, TS, PB); if (rc) return rc;
+    // K: the configured batch size, but at least ~4 batches per frame so that the chain of batch b overlaps the bulk work of its neighbours
+    // (a rank of an 8-GPU run renders 16 of 128 samples: K = 4)
+    int Kuse = Kmax;
+    { const int n = i1 - i0; if (n < 4 * Kuse) Kuse = (n + 3) / 4; if (Kuse < 4) Kuse = 4; if (Kuse > Kmax) Kuse = Kmax; if (Kuse > n) Kuse = n; }
+    PtBatch PB; rc = carve_batch(ctx, N, Kuse, max_bounce, TS, PB); if (rc) return rc;
     // ---- schedule. Per batch b of K samples:
     //   I(b)  initial resampling of the K samples (light tiles, candidates, shadow rays)              bulk stream, K * N slots per launch
     //   C(b)  temporal + spatial reuse, one sample after the other (needs the previous sample)        caller's stream, N pixels per launch
