@@ -243,44 +243,6 @@ __global__ void __launch_bounds__(256) k_pack4(int T, const int32_t* __restrict_
     nodes4[g] = n;
 }
 
-// Breadth-first copy of the top of the 4-wide tree for the LDS-resident part of the shadow-ray kernel. Entry 0 = root; entries [0,85) are
-// complete levels 0..3 in BFS order, [85,341) level 4, so a kernel may stage the first 85 or all 341. References to children that live
-// inside the staged prefix become MR_TOPBIT | index at build time for BOTH prefix sizes: a child of a level-3 node (index >= 85) is tagged
-// only in the `deep` copy of its parent's refs, kept in pad[]; the kernel picks refs or pad by its TOPN.
-__global__ void __launch_bounds__(256) k_top4(int T, const Node4* __restrict__ nodes4, Node4* __restrict__ top) {
-    __shared__ int s_id[341];     // global node id of each top entry, -1 = hole (a shallower leaf / unused entry above it)
-    const int t = threadIdx.x;
-    if (t == 0) s_id[0] = 0;
-    __syncthreads();
-    // levels are laid out as full 4-ary levels: entry e's k-th child sits at 4e + 1 + k
-    for (int lvl = 0; lvl < 4; lvl++) {
-        const int first = lvl == 0 ? 0 : (lvl == 1 ? 1 : (lvl == 2 ? 5 : 21)), cnt = lvl == 0 ? 1 : (lvl == 1 ? 4 : (lvl == 2 ? 16 : 64));
-        for (int e = first + t; e < first + cnt; e += 256) {
-            const int id = s_id[e];
-            for (int k = 0; k < 4; k++) {
-                int r = id >= 0 ? nodes4[id].ref[k] : 0x7fffffff;
-                s_id[4 * e + 1 + k] = (r >= 0 && r != 0x7fffffff) ? r : -1;
-            }
-        }
-        __syncthreads();
-    }
-    for (int e = t; e < 341; e += 256) {
-        const int id = s_id[e];
-        Node4 n;
-        if (id >= 0) n = nodes4[id];
-        else { for (int k = 0; k < 4; k++) { n.minx[k] = n.miny[k] = n.minz[k] = n.maxx[k] = n.maxy[k] = n.maxz[k] = 0.f; n.ref[k] = 0x7fffffff; } }
-        for (int k = 0; k < 4; k++) {
-            const int c = 4 * e + 1 + k;                       // BFS slot of child k
-            const bool internal = id >= 0 && n.ref[k] >= 0 && n.ref[k] != 0x7fffffff;
-            n.pad[k] = n.ref[k];                               // pad[] = references for a 341-entry prefix, ref[] = for an 85-entry prefix
-            if (internal && c < 341) n.pad[k] = 0x20000000 | c;
-            if (internal && c < 85) n.ref[k] = 0x20000000 | c;
-        }
-        top[e] = n;
-    }
-}
-
-
 // ---- compressed 4-wide layout for shadow rays (engine.hpp Node4q / LeafRec)
 // step 2^(E-127) per axis: the smallest power of two (E >= 67) for which the decode expression of q = 255 still reaches the node's max corner
 MR_DEV float q_step(uint32_t E) { return __uint_as_float(E << 23); }
@@ -355,7 +317,7 @@ __global__ void __launch_bounds__(256) k_pack4q(int T, const int32_t* __restrict
 }
 
 // Breadth-first prefix (TOPN = 85: levels 0..3, 341: levels 0..4) of the compressed 4-wide tree for the LDS-resident part of the shadow-ray
-// kernel; references to children inside the prefix become MR_TOPBIT | index. Same heap layout as k_top4.
+// kernel; references to children inside the prefix become MR_TOPBIT | index. Heap layout: entry e's k-th child sits at 4e + 1 + k.
 __global__ void __launch_bounds__(256) k_top4q(int T, const Node4q* __restrict__ nodes4q, Node4q* __restrict__ top, int TOPN) {
     __shared__ int s_id[341];
     const int t = threadIdx.x;
@@ -425,7 +387,6 @@ int mirres_bvh_create(mirres_bvh_t** out, int max_tris) {
     MR_HIP(hipMalloc(&b->nodes, sizeof(WideNode) * T));
     MR_HIP(hipMalloc(&b->tris, sizeof(TriRec) * T));
     MR_HIP(hipMalloc(&b->nodes4, sizeof(Node4) * T));
-    MR_HIP(hipMalloc(&b->top4, sizeof(Node4) * 341));
     MR_HIP(hipMalloc(&b->nodes4q, sizeof(Node4q) * T));
     MR_HIP(hipMalloc(&b->leaves, sizeof(LeafRec) * T));
     MR_HIP(hipMalloc(&b->top85q, sizeof(Node4q) * 85));
@@ -443,7 +404,7 @@ int mirres_bvh_create(mirres_bvh_t** out, int max_tris) {
 void mirres_bvh_destroy(mirres_bvh_t* b) {
     if (!b) return;
     void* ptrs[] = {b->ele_aabb, b->extent, b->keys_in, b->keys_out, b->vals_in, b->vals_out, b->parent, b->flags, b->own_info,
-                    b->own_aabb, b->nodes, b->tris, b->root_box, b->sort_tmp, b->work, b->nodes4, b->redo, b->top4, b->nodes4q, b->leaves, b->top85q, b->top341q};
+                    b->own_aabb, b->nodes, b->tris, b->root_box, b->sort_tmp, b->work, b->nodes4, b->redo, b->nodes4q, b->leaves, b->top85q, b->top341q};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete b;
 }
@@ -466,7 +427,6 @@ int mirres_bvh_build(mirres_bvh_t* b, const float* vert, int V, const int32_t* t
     k_refit<<<grd, blk, 0, s>>>(T, info, aabb, b->parent, b->flags);
     k_pack<<<grd, blk, 0, s>>>(T, info, aabb, vert, tri, b->nodes, b->tris, b->root_box);
     k_pack4<<<grd, blk, 0, s>>>(T, info, aabb, b->nodes4);
-    if (T - 1 >= 341 * 4) k_top4<<<1, 256, 0, s>>>(T, b->nodes4, b->top4);
     k_pack4q<<<grd, blk, 0, s>>>(T, info, aabb, vert, tri, b->nodes4q, b->leaves);
     if (T - 1 >= 341 * 4) { k_top4q<<<1, 256, 0, s>>>(T, b->nodes4q, b->top85q, 85); k_top4q<<<1, 256, 0, s>>>(T, b->nodes4q, b->top341q, 341); }
     MR_LAUNCH_CHECK("bvh_build");

@@ -376,231 +376,9 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_persist(BvhView B, con
 // For an any-hit query `closest` stays t_max until the first accepted triangle, so (1) the reference's result is the OR over all leaves
 // whose OWN box passes the slab test of "triangle_hit accepts": a leaf's ancestors always pass when the leaf does (their boxes are
 // fmin/fmax unions and (b - o) * inv is monotone in b under IEEE rounding), hence (2) any visiting order and any pruning by ancestor
-// boxes yields the same boolean. This kernel uses that freedom: leaf children are tested at their parent (never pushed), the nearer
-// internal child is descended first, the stack holds bare 4-byte node ids in LDS (16 per lane), and no pop-time re-test is needed.
+// boxes yields the same boolean. The stack holds bare 4-byte references in LDS (16 per lane, scratch beyond); no pop-time re-test is needed.
 #define MR_ANY_LDS 16
-MR_DEV bool tri_accepts(const TriRec* __restrict__ tr, v3 ro, v3 d) {  // triangle_hit (helperDi.slang:172-195) without t
-    const float4 a = reinterpret_cast<const float4*>(tr)[0];
-    const float4 b = reinterpret_cast<const float4*>(tr)[1];
-    const float4 c = reinterpret_cast<const float4*>(tr)[2];
-    const v3 v0 = V3(a.x, a.y, a.z), E1 = V3(a.w, b.x, b.y), E2 = V3(b.z, b.w, c.x);
-    const v3 P = cross(d, E2);
-    const float det = dot(E1, P);
-    if (det > -1e-15f && det < 1e-15f) return false;
-    const float invDet = 1 / det;
-    const v3 Tv = ro - v0;
-    const float u = dot(Tv, P) * invDet;
-    if (u < 0 || u > 1) return false;
-    const v3 Q = cross(Tv, E1);
-    const float v = dot(d, Q) * invDet;
-    if (v < 0 || u + v > 1) return false;
-    return true;
-}
-
-template <bool COUNT>
-__global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any_fast(BvhView B, const Ray* __restrict__ rays, const uint32_t* __restrict__ d_count,
-                                                                   uint32_t n_fixed, uint32_t* __restrict__ work_head, int32_t* __restrict__ hit_out,
-                                                                   unsigned long long* __restrict__ stats) {
-    __shared__ uint32_t lds[MR_ANY_LDS * MR_TRACE_BLOCK];
-    uint32_t* const lds_stack = lds + threadIdx.x;
-    const uint32_t n = d_count ? *d_count : n_fixed;
-    const int lane = lane_id();
-    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    const int NONE = 0x40000000;
-    uint32_t chunk = n / (gridDim.x * (MR_TRACE_BLOCK / 64) * 4);
-    chunk = chunk < 64 ? 64 : (chunk > MR_CHUNK_MAX ? MR_CHUNK_MAX : (chunk & ~63u));
-    const uint32_t q_per = (((n + MR_NQ - 1) / MR_NQ) + 63u) & ~63u;                                  // rays per sub-queue
-    uint32_t q_cur = (blockIdx.x * (MR_TRACE_BLOCK / 64) + (threadIdx.x >> 6)) % MR_NQ, q_fail = 0;   // wave-uniform
-    uint32_t chunk_next = 0, chunk_end = 0;
-    bool exhausted = false, have = false;
-    float o[3], inv[3]; v3 d = V3(0.f), ro = V3(0.f);
-    float t_min = 0.f, t_max = 0.f;
-    int cur = NONE, sp = 0; uint32_t ridx = 0;
-    uint32_t spill[MR_STACK - MR_ANY_LDS];
-    unsigned long long c_boxes = 0, c_nodes = 0, c_leaves = 0;   // COUNT: boxes slab-tested, internal nodes fetched, triangles tested by THIS kernel
-    while (true) {
-        const uint64_t need = __ballot(!have);
-        if (need && !exhausted) {
-            if (chunk_next >= chunk_end) exhausted = !grab_chunk(work_head, n, q_per, chunk, q_cur, q_fail, chunk_next, chunk_end, lane);
-            if (!exhausted) {
-                const uint32_t idx = chunk_next + (uint32_t)__popcll(need & lt_mask);
-                if (!have && idx < chunk_end) {
-                    const float4 a = reinterpret_cast<const float4*>(rays + idx)[0], b = reinterpret_cast<const float4*>(rays + idx)[1];
-                    ridx = idx; ro = V3(a.x, a.y, a.z); t_min = a.w; t_max = b.w;
-                    d = normalize(V3(b.x, b.y, b.z));
-                    o[0] = ro.x; o[1] = ro.y; o[2] = ro.z;
-                    { float dd[3] = {d.x, d.y, d.z};
-#pragma unroll
-                      for (int i = 0; i < 3; i++) { float di = dd[i]; if (di == 0.f) di = 0.000001f; inv[i] = 1.0f / di; } }
-                    sp = 0;
-                    Slab s0 = slab(B.root_box, B.root_box + 3, o, inv, t_min);
-                    have = true;
-                    if (COUNT) c_boxes++;
-                    if (s0.tf > s0.tn && t_max > s0.tn) cur = 0;
-                    else { hit_out[idx] = 0; have = false; }
-                }
-                const uint32_t want = (uint32_t)__popcll(need);
-                chunk_next = (chunk_next + want < chunk_end) ? chunk_next + want : chunk_end;
-            }
-        }
-        if (!__ballot(have)) { if (exhausted) break; else continue; }
-        do {
-            if (have) {
-                // cur is always an internal node here
-                const WideNode* __restrict__ nd = B.nodes + cur;
-                const float4 q0 = reinterpret_cast<const float4*>(nd)[0];
-                const float4 q1 = reinterpret_cast<const float4*>(nd)[1];
-                const float4 q2 = reinterpret_cast<const float4*>(nd)[2];
-                const float4 q3 = reinterpret_cast<const float4*>(nd)[3];
-                const float lmin[3] = {q0.x, q0.y, q0.z}, lmax[3] = {q0.w, q1.x, q1.y};
-                const float rmin[3] = {q1.z, q1.w, q2.x}, rmax[3] = {q2.y, q2.z, q2.w};
-                const int left = __float_as_int(q3.x), right = __float_as_int(q3.y);
-                const Slab sl = slab(lmin, lmax, o, inv, t_min);
-                const Slab sr = slab(rmin, rmax, o, inv, t_min);
-                bool okL = sl.tf > sl.tn && t_max > sl.tn, okR = sr.tf > sr.tn && t_max > sr.tn;
-                bool hit = false;
-                if (COUNT) { c_nodes++; c_boxes += 2; }
-                if (okL && left < 0) { hit = tri_accepts(B.tris + ~left, ro, d); okL = false; if (COUNT) c_leaves++; }
-                if (!hit && okR && right < 0) { hit = tri_accepts(B.tris + ~right, ro, d); okR = false; if (COUNT) c_leaves++; }
-                bool done = hit;
-                if (!hit) {
-                    if (okL && okR) {
-                        const bool lnear = sl.tn <= sr.tn;
-                        const int far = lnear ? right : left;
-                        cur = lnear ? left : right;
-                        if (sp < MR_ANY_LDS) lds_stack[sp * MR_TRACE_BLOCK] = (uint32_t)far;
-                        else if (sp < MR_STACK) spill[sp - MR_ANY_LDS] = (uint32_t)far;
-                        if (sp < MR_STACK) sp++;
-                    } else if (okL) cur = left;
-                    else if (okR) cur = right;
-                    else if (sp > 0) { --sp; cur = (int)((sp < MR_ANY_LDS) ? lds_stack[sp * MR_TRACE_BLOCK] : spill[sp - MR_ANY_LDS]); }
-                    else done = true;
-                }
-                if (done) { have = false; hit_out[ridx] = hit ? 1 : 0; }
-            }
-        } while (__popcll(__ballot(have)) >= MR_REFILL || (exhausted && __ballot(have)));
-    }
-    if (COUNT && stats) { atomicAdd(&stats[2], c_boxes); atomicAdd(&stats[3], c_nodes); atomicAdd(&stats[4], c_leaves); }
-    if (stats && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[0], (unsigned long long)n);
-}
-
-
-// ---------------------------------------------------------------- shadow rays on the 4-wide collapse (engine.hpp Node4)
-// Same order-free argument as k_trace_any_fast; the hierarchy is the LBVH with every other level removed, so a ray does about half the
-// dependent node fetches (each a full 128-byte line) and the per-visit bookkeeping is amortised over four slab tests.
-// TOPN > 0: the first levels of the 4-wide tree (BvhView::top4, built breadth-first by k_top4, child references inside the top carry
-// MR_TOPBIT | local index) are copied into LDS once per persistent workgroup and served from there — every ray walks them, and the PMC
-// profile shows the kernel bound by vector-L1 line lookups of divergent node fetches, which LDS reads do not consume.
 #define MR_TOPBIT 0x20000000
-template <bool COUNT, int TOPN>
-__global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4(BvhView B, const Ray* __restrict__ rays, const uint32_t* __restrict__ d_count,
-                                                               uint32_t n_fixed, uint32_t* __restrict__ work_head, int32_t* __restrict__ hit_out,
-                                                               unsigned long long* __restrict__ stats) {
-    __shared__ uint32_t lds[MR_ANY_LDS * MR_TRACE_BLOCK];
-    __shared__ __attribute__((aligned(16))) float4 s_top[TOPN > 0 ? TOPN * 8 : 1];
-    if (TOPN > 0) {
-        const float4* src = reinterpret_cast<const float4*>(B.top4);
-        for (int i = threadIdx.x; i < TOPN * 8; i += MR_TRACE_BLOCK) s_top[i] = src[i];
-        __syncthreads();
-    }
-    uint32_t* const lds_stack = lds + threadIdx.x;
-    const uint32_t n = d_count ? *d_count : n_fixed;
-    const int lane = lane_id();
-    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    uint32_t chunk = n / (gridDim.x * (MR_TRACE_BLOCK / 64) * 4);
-    chunk = chunk < 64 ? 64 : (chunk > MR_CHUNK_MAX ? MR_CHUNK_MAX : (chunk & ~63u));
-    const uint32_t q_per = (((n + MR_NQ - 1) / MR_NQ) + 63u) & ~63u;                                  // rays per sub-queue
-    uint32_t q_cur = (blockIdx.x * (MR_TRACE_BLOCK / 64) + (threadIdx.x >> 6)) % MR_NQ, q_fail = 0;   // wave-uniform
-    uint32_t chunk_next = 0, chunk_end = 0;
-    bool exhausted = false, have = false;
-    float ox = 0, oy = 0, oz = 0, ix = 0, iy = 0, iz = 0; v3 d = V3(0.f), ro = V3(0.f);
-    float t_min = 0.f, t_max = 0.f;
-    int cur = 0, sp = 0; uint32_t ridx = 0;
-    uint32_t spill[MR_STACK - MR_ANY_LDS];
-    unsigned long long c_boxes = 0, c_nodes = 0, c_leaves = 0;
-    while (true) {
-        const uint64_t need = __ballot(!have);
-        if (need && !exhausted) {
-            if (chunk_next >= chunk_end) exhausted = !grab_chunk(work_head, n, q_per, chunk, q_cur, q_fail, chunk_next, chunk_end, lane);
-            if (!exhausted) {
-                const uint32_t idx = chunk_next + (uint32_t)__popcll(need & lt_mask);
-                if (!have && idx < chunk_end) {
-                    const float4 a = reinterpret_cast<const float4*>(rays + idx)[0], b = reinterpret_cast<const float4*>(rays + idx)[1];
-                    ridx = idx; ro = V3(a.x, a.y, a.z); t_min = a.w; t_max = b.w;
-                    d = normalize(V3(b.x, b.y, b.z));
-                    ox = ro.x; oy = ro.y; oz = ro.z;
-                    { float dx = d.x, dy = d.y, dz = d.z;
-                      if (dx == 0.f) dx = 0.000001f; if (dy == 0.f) dy = 0.000001f; if (dz == 0.f) dz = 0.000001f;
-                      ix = 1.0f / dx; iy = 1.0f / dy; iz = 1.0f / dz; }
-                    sp = 0;
-                    const float o3[3] = {ox, oy, oz}, i3[3] = {ix, iy, iz};
-                    Slab s0 = slab(B.root_box, B.root_box + 3, o3, i3, t_min);
-                    if (COUNT) c_boxes++;
-                    if (s0.tf > s0.tn && t_max > s0.tn) { cur = TOPN > 0 ? MR_TOPBIT : 0; have = true; }
-                    else hit_out[idx] = 0;
-                }
-                const uint32_t want = (uint32_t)__popcll(need);
-                chunk_next = (chunk_next + want < chunk_end) ? chunk_next + want : chunk_end;
-            }
-        }
-        if (!__ballot(have)) { if (exhausted) break; else continue; }
-        do {
-            if (have) {
-                float4 mnx, mny, mnz, mxx, mxy, mxz; int4 rf;
-                if (TOPN > 0 && (cur & MR_TOPBIT)) {
-                    const float4* nd = s_top + (size_t)(cur & 0xffff) * 8;
-                    mnx = nd[0]; mny = nd[1]; mnz = nd[2]; mxx = nd[3]; mxy = nd[4]; mxz = nd[5];
-                    const float4 r4 = nd[TOPN > 85 ? 7 : 6];   // pad[] carries the references for the 341-entry prefix (k_top4)
-                    rf.x = __float_as_int(r4.x); rf.y = __float_as_int(r4.y); rf.z = __float_as_int(r4.z); rf.w = __float_as_int(r4.w);
-                } else {
-                    const Node4* __restrict__ nd = B.nodes4 + cur;
-                    mnx = reinterpret_cast<const float4*>(nd)[0]; mny = reinterpret_cast<const float4*>(nd)[1]; mnz = reinterpret_cast<const float4*>(nd)[2];
-                    mxx = reinterpret_cast<const float4*>(nd)[3]; mxy = reinterpret_cast<const float4*>(nd)[4]; mxz = reinterpret_cast<const float4*>(nd)[5];
-                    rf = reinterpret_cast<const int4*>(nd)[6];
-                    if (COUNT) c_nodes++;    // only global fetches are charged
-                }
-                const float bmnx[4] = {mnx.x, mnx.y, mnx.z, mnx.w}, bmny[4] = {mny.x, mny.y, mny.z, mny.w}, bmnz[4] = {mnz.x, mnz.y, mnz.z, mnz.w};
-                const float bmxx[4] = {mxx.x, mxx.y, mxx.z, mxx.w}, bmxy[4] = {mxy.x, mxy.y, mxy.z, mxy.w}, bmxz[4] = {mxz.x, mxz.y, mxz.z, mxz.w};
-                const int ref[4] = {rf.x, rf.y, rf.z, rf.w};
-                bool hit = false;
-                int next = -1; float next_tn = 0.f;
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    // the reference's slab test of this child's own box (see slab())
-                    const float ax = (bmnx[k] - ox) * ix, bx = (bmxx[k] - ox) * ix;
-                    const float ay = (bmny[k] - oy) * iy, by = (bmxy[k] - oy) * iy;
-                    const float az = (bmnz[k] - oz) * iz, bz = (bmxz[k] - oz) * iz;
-                    const float tn = fmaxf(fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz)), t_min);
-                    const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
-                    const bool ok = ref[k] != 0x7fffffff && tf > tn && t_max > tn;
-                    if (COUNT && ref[k] != 0x7fffffff) c_boxes++;
-                    if (ok && !hit) {
-                        if (ref[k] < 0) { hit = tri_accepts(B.tris + ~ref[k], ro, d); if (COUNT) c_leaves++; }
-                        else if (next < 0) { next = ref[k]; next_tn = tn; }
-                        else {
-                            int far = ref[k];
-                            if (tn < next_tn) { far = next; next = ref[k]; next_tn = tn; }   // keep the nearest for the immediate descent
-                            if (sp < MR_ANY_LDS) lds_stack[sp * MR_TRACE_BLOCK] = (uint32_t)far;
-                            else if (sp < MR_STACK) spill[sp - MR_ANY_LDS] = (uint32_t)far;
-                            if (sp < MR_STACK) sp++;
-                        }
-                    }
-                }
-                bool done = hit;
-                if (!hit) {
-                    if (next >= 0) cur = next;
-                    else if (sp > 0) { --sp; cur = (int)((sp < MR_ANY_LDS) ? lds_stack[sp * MR_TRACE_BLOCK] : spill[sp - MR_ANY_LDS]); }
-                    else done = true;
-                }
-                if (done) { have = false; hit_out[ridx] = hit ? 1 : 0; }
-            }
-        } while (__popcll(__ballot(have)) >= MR_REFILL || (exhausted && __ballot(have)));
-    }
-    if (COUNT && stats) { atomicAdd(&stats[2], c_boxes); atomicAdd(&stats[3], c_nodes); atomicAdd(&stats[4], c_leaves); }
-    if (stats && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[0], (unsigned long long)n);
-}
-
-
 // ---------------------------------------------------------------- shadow rays on the COMPRESSED 4-wide collapse (engine.hpp Node4q / LeafRec)
 // The any-hit bit is the OR over leaves whose own box passes the slab test (above); interior boxes only steer the search and may be any
 // supersets. Node4q stores them as 8-bit outward-rounded offsets (64 B per visit = 4 dwordx4 gathers instead of 8 — the kernel is bound by
@@ -947,19 +725,6 @@ static int closest_fast(mirres_bvh* bvh, const Ray* rays, const uint32_t* d_coun
     return 0;
 }
 
-static int top_mode() {   // MIRRES_TOP=0 disables / 85 / 341 selects how many 4-wide nodes are served from LDS (A/B experiments)
-    static int m = -1;
-    if (m < 0) { const char* e = getenv("MIRRES_TOP"); m = e ? atoi(e) : 85; if (m != 0 && m != 85 && m != 341) m = 85; }
-    return m;
-}
-template <bool COUNT>
-static void launch_any4(const mirres_bvh* bvh, int grid, const Ray* rays, const uint32_t* d_count, uint32_t cap, uint32_t* head, int32_t* hit,
-                        unsigned long long* stats, hipStream_t s) {
-    const int top = (bvh->T - 1 >= 341 * 4) ? top_mode() : 0;   // small trees: not worth it (and the top would not be full)
-    if (top == 85) k_trace_any4<COUNT, 85><<<grid, MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, d_count, cap, head, hit, stats);
-    else if (top == 341) k_trace_any4<COUNT, 341><<<grid, MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, d_count, cap, head, hit, stats);
-    else k_trace_any4<COUNT, 0><<<grid, MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, d_count, cap, head, hit, stats);
-}
 static int g_timed_tag = 0;   // set by trace_any_queue for event-timed launches (mirres_ctx_set_instrument bit 1)
 template <bool COUNT>
 static void launch_any4q(const mirres_bvh* bvh, int grid, const Ray* rays, const uint32_t* d_count, uint32_t cap, uint32_t* head, int32_t* hit,
@@ -977,12 +742,6 @@ static int closest_mode() {   // MIRRES_CLOSEST=4: ordered 4-wide fast path + re
     if (m < 0) { const char* e = getenv("MIRRES_CLOSEST"); m = (e && e[0] == '4') ? 4 : 2; }
     return m;
 }
-static int any_mode() {   // shadow-ray kernel: default 8 = compressed 4-wide (Node4q); MIRRES_ANY=4 plain 4-wide, =2 binary (A/B experiments)
-    static int m = -1;
-    if (m < 0) { const char* e = getenv("MIRRES_ANY"); m = (e && e[0] == '2') ? 2 : ((e && e[0] == '4') ? 4 : 8); }
-    return m;
-}
-
 static int persist_grid(size_t capacity) {
     size_t want = (capacity + MR_TRACE_BLOCK - 1) / MR_TRACE_BLOCK;
     size_t cap = 256 * 6;                                       // 6 resident blocks per CU: measured faster than 8 (forcing <= 64 VGPRs spills and thrashes
@@ -1002,9 +761,7 @@ int trace_any_queue(const mirres_bvh* bvh, const Ray* rays, const uint32_t* d_co
     g_timed_tag = timed;
     uint32_t* const heads = bvh->work + (lane ? 7 : 0) * MR_WSET;   // launches that may overlap on two streams use different head sets
     MR_HIP(hipMemsetAsync(heads, 0, MR_WSET * sizeof(uint32_t), s));
-    if (any_mode() == 8) launch_any4q<false>(bvh, persist_grid(capacity), rays, d_count, (uint32_t)capacity, heads, hit, stats, s);
-    else if (any_mode() == 4) launch_any4<false>(bvh, persist_grid(capacity), rays, d_count, (uint32_t)capacity, heads, hit, stats, s);
-    else k_trace_any_fast<false><<<persist_grid(capacity), MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, d_count, (uint32_t)capacity, heads, hit, stats);
+    launch_any4q<false>(bvh, persist_grid(capacity), rays, d_count, (uint32_t)capacity, heads, hit, stats, s);
     MR_LAUNCH_CHECK("trace_any_queue");
     return 0;
 }
@@ -1026,9 +783,7 @@ int trace_any_queue_counted(const mirres_bvh* bvh, const Ray* rays, const uint32
         return 0;
     }
     MR_HIP(hipMemsetAsync(bvh->work, 0, MR_WSET * sizeof(uint32_t), s));
-    if (any_mode() == 8) launch_any4q<true>(bvh, persist_grid(capacity), rays, d_count, (uint32_t)capacity, bvh->work, hit, stats, s);
-    else if (any_mode() == 4) launch_any4<true>(bvh, persist_grid(capacity), rays, d_count, (uint32_t)capacity, bvh->work, hit, stats, s);
-    else k_trace_any_fast<true><<<persist_grid(capacity), MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, d_count, (uint32_t)capacity, bvh->work, hit, stats);
+    launch_any4q<true>(bvh, persist_grid(capacity), rays, d_count, (uint32_t)capacity, bvh->work, hit, stats, s);
     MR_LAUNCH_CHECK("trace_any_queue_counted");
     return 0;
 }
@@ -1059,9 +814,7 @@ extern "C" int mirres_bvh_trace(mirres_bvh_t* bvh, const float* rays, int n, int
         if (counters) k_trace_any<true><<<g, MR_TRACE_BLOCK, 0, s>>>(bvh->view(), r, nullptr, (uint32_t)n, hit, counters, nullptr);
         else {
             MR_HIP(hipMemsetAsync(bvh->work + 2 * MR_WSET, 0, MR_WSET * sizeof(uint32_t), s));
-            if (any_mode() == 8) launch_any4q<false>(bvh, persist_grid((size_t)n), r, nullptr, (uint32_t)n, bvh->work + 2 * MR_WSET, hit, nullptr, s);
-            else if (any_mode() == 4) launch_any4<false>(bvh, persist_grid((size_t)n), r, nullptr, (uint32_t)n, bvh->work + 2 * MR_WSET, hit, nullptr, s);
-            else k_trace_any_fast<false><<<persist_grid((size_t)n), MR_TRACE_BLOCK, 0, s>>>(bvh->view(), r, nullptr, (uint32_t)n, bvh->work + 2 * MR_WSET, hit, nullptr);
+            launch_any4q<false>(bvh, persist_grid((size_t)n), r, nullptr, (uint32_t)n, bvh->work + 2 * MR_WSET, hit, nullptr, s);
         }
     } else {
         if (counters) k_trace_closest<true><<<g, MR_TRACE_BLOCK, 0, s>>>(bvh->view(), r, nullptr, (uint32_t)n, nullptr, hit, t, pos, normal, prim, counters, nullptr);

@@ -60,7 +60,6 @@ struct BvhView {
     const WideNode* nodes; const TriRec* tris; const float* root_box;  // root_box -> aabb[0..5] of node 0
     const Node4* nodes4;
     const Node4q* nodes4q; const LeafRec* leaves; const Node4q* top85q; const Node4q* top341q;   // compressed shadow-ray layout
-    const Node4* top4;     // breadth-first copy of the first levels of nodes4 (341 entries), children inside it referenced as MR_TOPBIT | index
     int T;
     unsigned long long* dbg;   // optional [2 * waves]: wall-clock start / end of every traversal wave (mirres_debug_wave_times)
 };
@@ -80,7 +79,6 @@ struct mirres_bvh {
     // traversal layout
     mr::WideNode* nodes = nullptr;  // [T-1]
     mr::TriRec* tris = nullptr;     // [T]
-    mr::Node4* top4 = nullptr;      // [341]
     mr::Node4* nodes4 = nullptr;    // [T-1] indexed by LBVH node id (only the nodes reachable from the root by 2-level steps are used)
     mr::Node4q* nodes4q = nullptr;  // [T-1] compressed 4-wide nodes (shadow rays)
     mr::LeafRec* leaves = nullptr;  // [T]
@@ -89,7 +87,7 @@ struct mirres_bvh {
     uint32_t* work = nullptr;       // [10 * MR_WSET] head sets of the persistent traversal kernels (0/1 frame loop, 2/3 API, 4-6 ordered closest + redo, 7/8 second stream)
     unsigned long long* dbg = nullptr;   // see BvhView::dbg
     uint32_t* redo = nullptr; size_t redo_cap = 0;   // ray ids handed back by the ordered closest-hit fast path
-    mr::BvhView view() const { mr::BvhView v; v.nodes = nodes; v.tris = tris; v.root_box = root_box; v.T = T; v.nodes4 = nodes4; v.top4 = top4; v.nodes4q = nodes4q; v.leaves = leaves; v.top85q = top85q; v.top341q = top341q; v.dbg = dbg; return v; }
+    mr::BvhView view() const { mr::BvhView v; v.nodes = nodes; v.tris = tris; v.root_box = root_box; v.T = T; v.nodes4 = nodes4; v.nodes4q = nodes4q; v.leaves = leaves; v.top85q = top85q; v.top341q = top341q; v.dbg = dbg; return v; }
 };
 
 struct mirres_ctx {
