@@ -35,6 +35,7 @@ def parse():
     p.add_argument("--spp", type=int, default=128)
     p.add_argument("--bounces", type=int, default=2, help="indirect bounces (MAX_Bounce, FinalShading.slang:7) -> 3 path vertices")
     p.add_argument("--subdiv", type=int, default=7, help="icosphere subdivisions (7 -> 327 680 + 8 192 ground triangles)")
+    p.add_argument("--shard", choices=("strips", "spp"), default="spp", help="N > 1: exact row strips with halo exchange, or spp slices + all-reduce")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-roofline", action="store_true")
     p.add_argument("--const-material", action="store_true", help="constant material instead of the hash-grid + MLP field")
@@ -125,6 +126,8 @@ def main():
 
     def step():
         W.update_mesh(W.vrt, W.v_ind)                                   # LBVH rebuilt every frame (nerf/renderer.py:975)
+        if world > 1 and args.shard == "strips":      # exact: row strips + per-sample halo exchange + all-gather of the raw sums (dist.py)
+            return MD.render_strips(ctx, W, mlp, env, g, args.spp, 12345, rank, world, max_bounce=args.bounces)
         return MD.render_sharded(ctx, W, mlp, env, g, args.spp, 12345, rank, world)
 
     def barrier():
@@ -204,7 +207,7 @@ def main():
                 "config": {"workload": "BASELINE configs[1]: TensoIR-lego-shaped synthetic mesh (T=%d), %dx%d output, ssaa %d (internal %dx%d), %d spp, "
                                        "%d indirect bounces + ReSTIR (initial/temporal/spatial), LBVH rebuild per frame, %s, EAW denoise"
                                        % (len(t), args.res, args.res, args.ssaa, fx, fy, args.spp, args.bounces, "constant material" if args.const_material else "hash-grid+MLP material field"),
-                           "internal_pixels": N, "spp": args.spp, "triangles": int(len(t)), "parallelism": "spp-sharded x%d + all-reduce" % world if world > 1 else "single GPU",
+                           "internal_pixels": N, "spp": args.spp, "triangles": int(len(t)), "parallelism": ("%s x%d" % ("row strips + halo exchange + all-gather" if args.shard == "strips" else "spp-sharded + all-reduce", world)) if world > 1 else "single GPU",
                            "output_pixel_msamples_per_s": round(args.res * args.res * args.spp * args.steps / dt / 1e6, 3),
                            "finite": bool(torch.isfinite(fc).all().item()), "mean_radiance": round(float(fc[g["occ"][:, 0] > 0.5].mean().item()), 5)},
                 "roofline": roof, "cpu_baseline": cpu}

@@ -170,7 +170,16 @@ typedef struct mirres_render_args {
     float* outs[6];                   /* final_color, den_diffuse, den_spec, den_indirect, den_indirect_diff, den_indirect_spec */
     int spp_begin, spp_end;           /* multi-GPU spp sharding: render samples [spp_begin, spp_end) and skip the
                                          average/denoise/composite (raw sums are left in outs[0..5]); 0,0 = all  */
-    int y_begin, y_end;               /* reserved for strip sharding                                            */
+    /* Multi-GPU strip sharding (exact: bit-identical to one GPU for the rows a rank owns). The context is created for the rank's
+     * LOCAL frame = its own rows plus up to 30 halo rows (the spatial gather radius) on either side; all per-pixel inputs cover the
+     * local frame. strip_full_fy = height of the whole frame (0 = no strip sharding), strip_y_off = global row of local row 0,
+     * [own_y0, own_y1) = the local rows this rank owns. Halo rows are only read (G-buffer, reservoirs); `halo` is called once per
+     * sample, on the host while the frame is being enqueued, between temporal and spatial reuse: it must enqueue — on the same
+     * stream — the exchange that fills the halo rows of `records` (packed reservoirs, f32[local pixels, 8]) with the neighbouring
+     * ranks' own rows and sends this rank's border rows. Like a spp slice, a strip leaves raw sums in outs[0..5].                */
+    int strip_full_fy, strip_y_off, own_y0, own_y1;
+    int (*halo)(void* user, float* records, int sample, void* stream);
+    void* halo_user;
 } mirres_render_args_t;
 int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args_t* a, void* stream);
 /* second half of run_restir_di_with_pt (:507-549) on already-summed accumulators (after an all-reduce).         */

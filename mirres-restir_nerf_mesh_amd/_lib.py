@@ -50,7 +50,11 @@ class RenderArgs(C.Structure):
                 ("occ", vp), ("normal", vp), ("depth", vp), ("kd", vp), ("rough_metal", vp), ("ray_dir", vp), ("pos", vp),
                 ("mat", C.POINTER(MatNet)), ("const_kd", C.c_float * 3), ("const_rm", C.c_float * 2),
                 ("denoise_iter", C.c_int), ("step_width", C.c_int), ("c_phi", C.c_float), ("n_phi", C.c_float), ("p_phi", C.c_float),
-                ("outs", vp * 6), ("spp_begin", C.c_int), ("spp_end", C.c_int), ("y_begin", C.c_int), ("y_end", C.c_int)]
+                ("outs", vp * 6), ("spp_begin", C.c_int), ("spp_end", C.c_int),
+                ("strip_full_fy", C.c_int), ("strip_y_off", C.c_int), ("own_y0", C.c_int), ("own_y1", C.c_int), ("halo", vp), ("halo_user", vp)]
+
+
+HALO_FN = C.CFUNCTYPE(C.c_int, vp, vp, C.c_int, vp)   # int halo(void* user, float* records, int sample, void* stream)
 
 
 # every symbol include/mirres.h declares: name -> (restype, argtypes)

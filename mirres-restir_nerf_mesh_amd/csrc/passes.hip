@@ -174,7 +174,7 @@ __global__ void __launch_bounds__(MR_BLOCK) k_tile_aux(EnvD E, int total, const 
 // ---------------------------------------------------------------- initial resampling (InitialResampling.slang:151-295)
 __global__ void __launch_bounds__(MR_GEN_BLOCK) k_initial_gen(mirres_config_t C, EnvD E, GBufD G, ResD R, const float* __restrict__ tile_data,
                                                           const float* __restrict__ tile_pdf, const float4* __restrict__ tile_aux, uint32_t frameIndex0, int fx, int N,
-                                                          int NV, int TS, Ray* __restrict__ q, uint32_t* __restrict__ q_count, int32_t* __restrict__ slot_out) {
+                                                          int NV, int TS, int y_off, Ray* __restrict__ q, uint32_t* __restrict__ q_count, int32_t* __restrict__ slot_out) {
     // slot sv = k * N + pixel: sample k of a K-sample batch (NV = K * N; K = 1 for the stepwise ABI) — reservoir at sv, G-buffer at the pixel,
     // light tiles of sample k at k * TS, RNG stream frameIndex0 + 20 k
     const int sv = blockIdx.x * blockDim.x + threadIdx.x;
@@ -186,7 +186,7 @@ __global__ void __launch_bounds__(MR_GEN_BLOCK) k_initial_gen(mirres_config_t C,
         const GPix gp = load_gpix(G, pi);
         if (gp.occ < 0.1f) store_zero(R, sv);
         else {
-            const uint32_t x = (uint32_t)(pi % fx), y = (uint32_t)(pi / fx);
+            const uint32_t x = (uint32_t)(pi % fx), y = (uint32_t)(pi / fx + y_off);   // global pixel coordinates seed the streams (strip sharding: y_off)
             uint32_t tileSg = seed_generator(x / C.screen_tile_size, y / C.screen_tile_size, frameIndex);
             uint32_t tileIndex = min((uint32_t)(rnd(tileSg) * C.light_tile_count), (uint32_t)C.light_tile_count - 1);
             uint32_t tileOffset = tileIndex * C.light_tile_size;
@@ -244,13 +244,13 @@ __global__ void __launch_bounds__(MR_BLOCK) k_initial_resolve(ResD R, int N, con
 
 // ---------------------------------------------------------------- temporal resampling (TemporalResampling.slang:23-135)
 __global__ void __launch_bounds__(MR_BLOCK) k_temporal(mirres_config_t C, EnvD E, GBufD G, GBufD P, ResD R, ResD PR, const float* __restrict__ motion,
-                                                       uint32_t frameIndex, int fx, int fy, int N) {
+                                                       uint32_t frameIndex, int fx, int fy, int N, int y_off) {
     const int pi = blockIdx.x * blockDim.x + threadIdx.x;
     if (pi >= N) return;
     const GPix gc = load_gpix(G, pi);
     if (gc.occ < 0.1f) return;
     const uint32_t x = (uint32_t)(pi % fx), y = (uint32_t)(pi / fx);
-    uint32_t sg = seed_generator(x, y, frameIndex);
+    uint32_t sg = seed_generator(x, y + (uint32_t)y_off, frameIndex);
     float mvx = motion ? motion[2 * (size_t)pi] : 0.f, mvy = motion ? motion[2 * (size_t)pi + 1] : 0.f;
     float jx = rnd(sg), jy = rnd(sg);
     int ppx = (int)(((float)x + mvx * (float)(uint32_t)fx) + (jx * 1.f - 0.f));
@@ -301,18 +301,20 @@ MR_DEV float pairwise_mis(float q0, float q1, float N0, float N1) { return (q1 =
 // each of the ~15 gathers of a pixel wait for the previous one: the kernel spent its time on dependent L2 round trips); the tests are unchanged.
 template <int MR_MAX_NB>   // 5 (the reference's neighbour count) or 8: bounds the unrolled gathers, i.e. the registers held
 __global__ void __launch_bounds__(MR_GEN_BLOCK) k_spatial_gen(mirres_config_t C, GBufD G, ResD PR, const float* __restrict__ noff, uint32_t frameIndex,
-                                                          int fx, int fy, int N, Ray* __restrict__ q, uint32_t* __restrict__ q_count,
-                                                          int32_t* __restrict__ slot_out, uint32_t* __restrict__ mask_out) {
+                                                          int fx, int fy, int N, int y_off, const float* __restrict__ occ_own, Ray* __restrict__ q,
+                                                          uint32_t* __restrict__ q_count, int32_t* __restrict__ slot_out, uint32_t* __restrict__ mask_out) {
+    // strip sharding: y_off = global row of local row 0 (seeds), occ_own = occupancy with the halo rows zeroed (which pixels this rank merges);
+    // neighbours are tested against the true G-buffer, halo rows included
     const int pi = tile_pixel(fx, fy, 32, N);
     uint32_t mask = 0, cnt = 0;
     int nb[MR_MAX_NB];
     v3 cpos = V3(0.f), cdir = V3(0.f);
     const int k = min(C.neighbor_count, MR_MAX_NB);
     GPix gc; gc.occ = 0.f;
-    if (pi < N) gc = load_gpix(G, pi);
+    if (pi < N) { gc = load_gpix(G, pi); if (occ_own) gc.occ = occ_own[pi]; }
     if (pi < N && !(gc.occ < 0.1f)) {
         const int x = pi % fx, y = pi / fx;
-        uint32_t sg = seed_generator((uint32_t)x, (uint32_t)y, frameIndex);
+        uint32_t sg = seed_generator((uint32_t)x, (uint32_t)(y + y_off), frameIndex);
         const uint32_t startIndex = (uint32_t)(rnd(sg) * C.neighbor_offset_count);
         const v3 n = gc.n; const float depth = gc.depth;
         float4 nd[MR_MAX_NB]; float nocc[MR_MAX_NB]; int nM[MR_MAX_NB];
@@ -366,14 +368,14 @@ __global__ void __launch_bounds__(MR_GEN_BLOCK) k_spatial_gen(mirres_config_t C,
 
 template <int MR_MAX_NB>
 __global__ void __launch_bounds__(MR_BLOCK) k_spatial_resolve(mirres_config_t C, EnvD E, GBufD G, ResD R, ResD PR, const float* __restrict__ noff,
-                                                              uint32_t frameIndex, int fx, int fy, int N, const int32_t* __restrict__ slot,
-                                                              const uint32_t* __restrict__ mask_in, const int32_t* __restrict__ hit) {
+                                                              uint32_t frameIndex, int fx, int fy, int N, int y_off, const float* __restrict__ occ_own,
+                                                              const int32_t* __restrict__ slot, const uint32_t* __restrict__ mask_in, const int32_t* __restrict__ hit) {
     const int pi = tile_pixel(fx, fy, 16, N);
     if (pi >= N) return;
     const GPix gc = load_gpix(G, pi);
-    if (gc.occ < 0.1f) { store_zero(R, pi); return; }
+    if ((occ_own ? occ_own[pi] : gc.occ) < 0.1f) { store_zero(R, pi); return; }
     const int x = pi % fx, y = pi / fx;
-    uint32_t sg = seed_generator((uint32_t)x, (uint32_t)y, frameIndex);
+    uint32_t sg = seed_generator((uint32_t)x, (uint32_t)(y + y_off), frameIndex);
     const v3 n = gc.n;
     const rtarget::Ctx ctx = rtarget::make_ctx(n, gc.rd, gc.brdf);
     Ris s = empty_ris();
@@ -574,7 +576,7 @@ int launch_initial_batch(mirres_ctx* ctx, mirres_bvh* bvh, const mirres_env_t* e
     k_light_tiles<<<grid_for((size_t)K * TS, MR_BLOCK), MR_BLOCK, 0, s>>>(envh(env), frame0, K * TS, TS, tile_data, nullptr, tile_pdf);       // pass 0 (+1 inside)
     k_tile_aux<<<grid_for((size_t)K * TS, MR_BLOCK), MR_BLOCK, 0, s>>>(envh(env), K * TS, tile_data, reinterpret_cast<float4*>(tile_aux));
     k_initial_gen<<<grid_for(NV, MR_GEN_BLOCK), MR_GEN_BLOCK, 0, s>>>(ctx->cfg, envh(env), gbufd(g), resd(res), tile_data, tile_pdf, reinterpret_cast<const float4*>(tile_aux),
-                                                                       frame0 + 2, ctx->fx, N, NV, TS, q->any_rays, &q->counters[0], q->slot_a);       // pass 2
+                                                                       frame0 + 2, ctx->fx, N, NV, TS, ctx->y_off, q->any_rays, &q->counters[0], q->slot_a);       // pass 2
     int rc = trace_any_q(ctx, bvh, q->any_rays, &q->counters[0], (size_t)NV, q->any_hit, s, q->lane); if (rc) return rc;
     k_initial_resolve<<<grid_for(NV, MR_BLOCK), MR_BLOCK, 0, s>>>(resd(res), NV, q->slot_a, q->any_hit);
     MR_LAUNCH_CHECK("initial_batch");
@@ -694,7 +696,7 @@ int mirres_restir_initial(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_env
     MR_HIP(hipMemsetAsync(&ctx->counters[0], 0, sizeof(uint32_t), s));
     const int TS = ctx->cfg.light_tile_count * ctx->cfg.light_tile_size;
     k_tile_aux<<<grid_for(TS, MR_BLOCK), MR_BLOCK, 0, s>>>(envh(env), TS, light_data, reinterpret_cast<float4*>(ctx->tile_aux));
-    k_initial_gen<<<grid_for(N, MR_GEN_BLOCK), MR_GEN_BLOCK, 0, s>>>(ctx->cfg, envh(env), gbufd(g), resd(res), light_data, light_inv_pdf, reinterpret_cast<const float4*>(ctx->tile_aux), frameIndex, ctx->fx, N, N, TS, ctx->any_rays,
+    k_initial_gen<<<grid_for(N, MR_GEN_BLOCK), MR_GEN_BLOCK, 0, s>>>(ctx->cfg, envh(env), gbufd(g), resd(res), light_data, light_inv_pdf, reinterpret_cast<const float4*>(ctx->tile_aux), frameIndex, ctx->fx, N, N, TS, 0, ctx->any_rays,
                                             &ctx->counters[0], ctx->slot_a);
     int rc = trace_any(ctx, bvh, (size_t)N, s); if (rc) return rc;
     k_initial_resolve<<<grd, MR_BLOCK, 0, s>>>(resd(res), N, ctx->slot_a, ctx->any_hit);
@@ -707,7 +709,7 @@ int mirres_restir_temporal(mirres_ctx_t* ctx, const mirres_env_t* env, const mir
     if (!ctx || !env || !g || !prev_g || !res || !prev_res) { set_error("mirres_restir_temporal: null"); return MIRRES_E_ARG; }
     const int N = (int)ctx->N;
     k_temporal<<<grid_for(N, MR_BLOCK), MR_BLOCK, 0, (hipStream_t)stream>>>(ctx->cfg, envh(env), gbufd(g), gbufd(prev_g), resd(res), resd(prev_res), motion,
-                                                                            frameIndex, ctx->fx, ctx->fy, N);
+                                                                            frameIndex, ctx->fx, ctx->fy, N, ctx->y_off);
     MR_LAUNCH_CHECK("restir_temporal");
     return MIRRES_OK;
 }
@@ -719,16 +721,16 @@ int mirres_restir_spatial(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_env
     const float* noff = neighbor_offsets ? neighbor_offsets : ctx->noff;
     MR_HIP(hipMemsetAsync(&ctx->counters[0], 0, sizeof(uint32_t), s));
     const bool nb5 = ctx->cfg.neighbor_count <= 5;
-    if (nb5) k_spatial_gen<5><<<tile_grid(ctx->fx, ctx->fy, 32), MR_GEN_BLOCK, 0, s>>>(ctx->cfg, gbufd(g), resd(prev_res), noff, frameIndex, ctx->fx, ctx->fy, N, ctx->any_rays, &ctx->counters[0],
+    if (nb5) k_spatial_gen<5><<<tile_grid(ctx->fx, ctx->fy, 32), MR_GEN_BLOCK, 0, s>>>(ctx->cfg, gbufd(g), resd(prev_res), noff, frameIndex, ctx->fx, ctx->fy, N, ctx->y_off, ctx->occ_own, ctx->any_rays, &ctx->counters[0],
                                                                                    ctx->slot_a, ctx->mask_a);
-    else k_spatial_gen<8><<<tile_grid(ctx->fx, ctx->fy, 32), MR_GEN_BLOCK, 0, s>>>(ctx->cfg, gbufd(g), resd(prev_res), noff, frameIndex, ctx->fx, ctx->fy, N, ctx->any_rays, &ctx->counters[0],
+    else k_spatial_gen<8><<<tile_grid(ctx->fx, ctx->fy, 32), MR_GEN_BLOCK, 0, s>>>(ctx->cfg, gbufd(g), resd(prev_res), noff, frameIndex, ctx->fx, ctx->fy, N, ctx->y_off, ctx->occ_own, ctx->any_rays, &ctx->counters[0],
                                                                                ctx->slot_a, ctx->mask_a);
     int rc = trace_any(ctx, bvh, ctx->any_cap, s); if (rc) return rc;
     GBufD gr = gbufd(g);
     if (ctx->grec) gr.rec = reinterpret_cast<const float4*>(ctx->grec);   // mirres_render: same values, one 64-byte record per neighbour instead of three arrays
-    if (nb5) k_spatial_resolve<5><<<tile_grid(ctx->fx, ctx->fy, 16), MR_BLOCK, 0, s>>>(ctx->cfg, envh(env), gr, resd(res), resd(prev_res), noff, frameIndex, ctx->fx, ctx->fy, N,
+    if (nb5) k_spatial_resolve<5><<<tile_grid(ctx->fx, ctx->fy, 16), MR_BLOCK, 0, s>>>(ctx->cfg, envh(env), gr, resd(res), resd(prev_res), noff, frameIndex, ctx->fx, ctx->fy, N, ctx->y_off, ctx->occ_own,
                                                                                    ctx->slot_a, ctx->mask_a, ctx->any_hit);
-    else k_spatial_resolve<8><<<tile_grid(ctx->fx, ctx->fy, 16), MR_BLOCK, 0, s>>>(ctx->cfg, envh(env), gr, resd(res), resd(prev_res), noff, frameIndex, ctx->fx, ctx->fy, N,
+    else k_spatial_resolve<8><<<tile_grid(ctx->fx, ctx->fy, 16), MR_BLOCK, 0, s>>>(ctx->cfg, envh(env), gr, resd(res), resd(prev_res), noff, frameIndex, ctx->fx, ctx->fy, N, ctx->y_off, ctx->occ_own,
                                                                                ctx->slot_a, ctx->mask_a, ctx->any_hit);
     MR_LAUNCH_CHECK("restir_spatial");
     return MIRRES_OK;

@@ -53,6 +53,13 @@ __global__ void __launch_bounds__(MR_BLOCK) k_flip_env(int W, int H, const float
     const int y = i / W, x = i % W;
     st3(out, i, ld3(in, (size_t)(H - 1 - y) * W + x));
 }
+// strip sharding: occupancy with the halo rows zeroed — the stages that only feed this rank's own pixels skip the halo rows like background
+__global__ void __launch_bounds__(MR_BLOCK) k_own_occ(int N, int fx, int own_y0, int own_y1, const float* __restrict__ occ, float* __restrict__ occ_own) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int y = i / fx;
+    occ_own[i] = (y >= own_y0 && y < own_y1) ? occ[i] : 0.f;
+}
 // average + combined indirect (:507-515)
 __global__ void __launch_bounds__(MR_BLOCK) k_average(size_t n3, float spp, float* t0, float* t1, float* t2, float* t3, float* t4, float* t5, float* comb) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -115,7 +122,7 @@ static size_t pool_need(size_t N, size_t WH, size_t H, size_t TS) {
 using namespace mr;
 
 struct FrameBufs {
-    float *ray_dir, *nd, *brdf, *grec;
+    float *ray_dir, *nd, *brdf, *grec, *occ_own;
     float *r_ld[2], *r_pdf[2], *r_w[2]; int32_t* r_M[2];
     float *vis, *fdir, *fdist, *fLi;
     float* tot[6];  // total_color, total_diff, total_spec, total_color_1, total_diff_1, total_spec_1
@@ -144,8 +151,8 @@ static int carve(mirres_ctx* ctx, int Wc, int Hc, FrameBufs& B) {
     B.tex = P.take(3 * WH); B.pdf = P.take(WH); B.cdf = P.take(WH + Hc); B.mpdf = P.take(Hc); B.mcdf = P.take(Hc + 1);
     B.tile_data = P.take(3 * TS); B.tile_pdf = P.take(TS);
     B.den_a = P.take(3 * N); B.den_b = P.take(3 * N); B.comb = B.c1;  // comb reuses c1 after the loop
-    B.grec = P.take(16 * N);
-    if (!B.den_b || !B.grec) { set_error("mirres_render: internal pool too small"); return MIRRES_E_STATE; }
+    B.grec = P.take(16 * N); B.occ_own = P.take(N);
+    if (!B.den_b || !B.grec || !B.occ_own) { set_error("mirres_render: internal pool too small"); return MIRRES_E_STATE; }
     return 0;
 }
 
@@ -237,8 +244,19 @@ int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args
     const int N = (int)ctx->N, fx = ctx->fx; const size_t n3 = 3 * (size_t)N;
     const int Wc = a->Wc, Hc = a->Hc;
     FrameBufs B; int rc = carve(ctx, Wc, Hc, B); if (rc) return rc;
-    const bool partial = !(a->spp_begin == 0 && a->spp_end == 0);
-    const int i0 = partial ? a->spp_begin : 0, i1 = partial ? a->spp_end : a->spp;
+    const bool strip = a->strip_full_fy > 0;
+    if (strip && !(a->own_y0 >= 0 && a->own_y0 < a->own_y1 && a->own_y1 <= ctx->fy && a->strip_y_off >= 0 && a->strip_y_off + ctx->fy <= a->strip_full_fy)) {
+        set_error("mirres_render: strip rows [%d,%d) of a %d-row local frame at global row %d of %d", a->own_y0, a->own_y1, ctx->fy, a->strip_y_off, a->strip_full_fy);
+        return MIRRES_E_ARG;
+    }
+    if (strip) {   // the halo must cover the spatial gather radius wherever the image continues beyond the own rows
+        const int r = (int)ctx->cfg.gather_radius;
+        const int above = a->strip_y_off + a->own_y0, below = a->strip_full_fy - (a->strip_y_off + a->own_y1);
+        if (a->own_y0 < (above < r ? above : r) || ctx->fy - a->own_y1 < (below < r ? below : r)) { set_error("mirres_render: strip halo narrower than the gather radius %d", r); return MIRRES_E_ARG; }
+    }
+    const bool partial = strip || !(a->spp_begin == 0 && a->spp_end == 0);
+    const bool sliced = !(a->spp_begin == 0 && a->spp_end == 0);
+    const int i0 = sliced ? a->spp_begin : 0, i1 = sliced ? a->spp_end : a->spp;
     const int grd = grid_for(N, MR_BLOCK);
 
     k_prep<<<grd, MR_BLOCK, 0, s>>>(N, a->occ, a->ray_dir, a->normal, a->depth, a->kd, a->rough_metal, B.ray_dir, B.nd, B.brdf, a->pos, reinterpret_cast<float4*>(B.grec));
@@ -248,7 +266,15 @@ int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args
     MR_HIP(hipMemsetAsync(B.r_ld[0], 0, sizeof(float) * (size_t)(B.vis - B.r_ld[0]), s));   // both reservoirs
     MR_HIP(hipMemsetAsync(B.tot[0], 0, sizeof(float) * (size_t)(B.tex - B.tot[0]), s));      // totals .. new_rm
     mirres_env_t E = {B.tex, Wc, Hc, B.pdf, B.cdf, B.mpdf, B.mcdf};
-    mirres_gbuf_t G = {a->occ, a->pos, B.nd, B.brdf, B.ray_dir};
+    // strip sharding: `occ` (halo rows zeroed) selects the pixels this rank computes; the spatial pass tests neighbours against the true G-buffer
+    const float* occ = a->occ;
+    struct StripGuard { mirres_ctx* c; ~StripGuard() { c->y_off = 0; c->full_fy = 0; c->occ_own = nullptr; } } strip_guard{ctx};
+    if (strip) {
+        k_own_occ<<<grd, MR_BLOCK, 0, s>>>(N, fx, a->own_y0, a->own_y1, a->occ, B.occ_own);
+        occ = B.occ_own; ctx->y_off = a->strip_y_off; ctx->full_fy = a->strip_full_fy; ctx->occ_own = B.occ_own;
+    }
+    mirres_gbuf_t G = {occ, a->pos, B.nd, B.brdf, B.ray_dir};          // own-pixel stages (initial, temporal)
+    mirres_gbuf_t Gt = {a->occ, a->pos, B.nd, B.brdf, B.ray_dir};      // spatial reuse: neighbours in the halo rows are real pixels
     struct GrecGuard { mirres_ctx* c; ~GrecGuard() { c->grec = nullptr; } } grec_guard{ctx};
     ctx->grec = B.grec;   // packed copy for the neighbour gathers of the spatial merge; cleared when this call returns (the launches captured the pointer)
     const uint32_t passes = 20;  // mTotalRISPasses (:242)
@@ -309,7 +335,7 @@ int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args
         if (b > 0) {
             if (two_streams) MR_HIP(hipStreamWaitEvent(sp, ev_chain(b - 1), 0));
             PtQueues Q = PB.q; Q.NV = batch_k(b - 1) * N;
-            rc = launch_final_batch(ctx, bvh, &E, a->occ, a->pos, a->normal, B.ray_dir, a->kd, a->rough_metal, &PB.rspat[(b - 1) & 1], batch_k(b - 1), &Q, B.tot[0], B.tot[1], B.tot[2], sp);
+            rc = launch_final_batch(ctx, bvh, &E, occ, a->pos, a->normal, B.ray_dir, a->kd, a->rough_metal, &PB.rspat[(b - 1) & 1], batch_k(b - 1), &Q, B.tot[0], B.tot[1], B.tot[2], sp);
             if (rc) return rc;
         }
         if (b + 1 < nbatch) { rc = initial(b + 1); if (rc) return rc; }
@@ -331,14 +357,17 @@ int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args
                 }
                 pass += 1;
             }
-            rc = mirres_restir_spatial(ctx, bvh, &E, &G, &rs, &rt, nullptr, base + pass, s); if (rc) return rc;
+            if (a->halo) {   // strip sharding: the neighbouring ranks' border rows of the temporal output -> this rank's halo rows (and vice versa)
+                if (a->halo(a->halo_user, rt.light_data, i, (void*)s)) { set_error("mirres_render: halo exchange callback failed at sample %d", i); return MIRRES_E_STATE; }
+            }
+            rc = mirres_restir_spatial(ctx, bvh, &E, &Gt, &rs, &rt, nullptr, base + pass, s); if (rc) return rc;
             csum(rs.light_data, 8 * (size_t)N);
         }
         if (two_streams) MR_HIP(hipEventRecord(ev_chain(b), s));
         // ---- bulk stream: path-tracing stages of samples ib .. ib+kk-1 (new direction, then max_bounce indirect vertices)
         PtQueues Q = PB.q; Q.NV = kk * N; Q.first_sample_is_zero = (ib == 0);
         uint32_t fi = a->random_offset + passes * (uint32_t)ib + 5;   // pass number of new_dir for a sample with a temporal pass before it
-        mirres_path_t P0 = {a->occ, a->pos, a->normal, B.ray_dir, a->kd, a->rough_metal, PB.prd, PB.pos[0], PB.rd[0], PB.occ[0], PB.n[0]};
+        mirres_path_t P0 = {occ, a->pos, a->normal, B.ray_dir, a->kd, a->rough_metal, PB.prd, PB.pos[0], PB.rd[0], PB.occ[0], PB.n[0]};
         rc = launch_new_dir(ctx, bvh, &P0, fi, 0, sp, &Q); if (rc) return rc;
         fi += 5;
         int src = 0;
@@ -358,7 +387,7 @@ int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args
     {   // F(last)
         if (two_streams) MR_HIP(hipStreamWaitEvent(sp, ev_chain(nbatch - 1), 0));
         PtQueues Q = PB.q; Q.NV = batch_k(nbatch - 1) * N;
-        rc = launch_final_batch(ctx, bvh, &E, a->occ, a->pos, a->normal, B.ray_dir, a->kd, a->rough_metal, &PB.rspat[(nbatch - 1) & 1], batch_k(nbatch - 1), &Q, B.tot[0], B.tot[1], B.tot[2], sp);
+        rc = launch_final_batch(ctx, bvh, &E, occ, a->pos, a->normal, B.ray_dir, a->kd, a->rough_metal, &PB.rspat[(nbatch - 1) & 1], batch_k(nbatch - 1), &Q, B.tot[0], B.tot[1], B.tot[2], sp);
         if (rc) return rc;
     }
     if (two_streams) { MR_HIP(hipEventRecord(ctx->ev_join, sp)); MR_HIP(hipStreamWaitEvent(s, ctx->ev_join, 0)); }

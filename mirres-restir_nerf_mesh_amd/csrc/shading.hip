@@ -96,7 +96,7 @@ MR_DEV void next_bounce_resolve(const mirres_path_t& P, size_t pi, const HitRec*
 // frame's very first sample, which has no temporal pass before it (renderer_restir.py:341-356).
 MR_DEV uint32_t slot_frame(uint32_t frameIndex, int k, int first_is_zero) { return frameIndex + 20u * (uint32_t)k - ((first_is_zero && k == 0) ? 1u : 0u); }
 __global__ void __launch_bounds__(MR_GEN_BLOCK) k_new_dir_gen(mirres_path_t P, int max_bounce, float vis_near, uint32_t frameIndex, uint32_t bounce_count, int fx,
-                                                          int N, int NV, int first_is_zero, Ray* __restrict__ q, uint32_t* __restrict__ q_count, int32_t* __restrict__ slot_out) {
+                                                          int N, int NV, int first_is_zero, int y_off, Ray* __restrict__ q, uint32_t* __restrict__ q_count, int32_t* __restrict__ slot_out) {
     const int v_ = blockIdx.x * blockDim.x + threadIdx.x;
     bool want = false; v3 rp = V3(0.f), rdir = V3(0.f);
     if (v_ < NV) {
@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(MR_GEN_BLOCK) k_new_dir_gen(mirres_path_t P, i
         if (bounce_count == 0) { thr = V3(1.0f); is_stop = 0.f; P.prd[5 * sv] = 1.f; P.prd[5 * sv + 1] = 1.f; P.prd[5 * sv + 2] = 1.f; P.prd[5 * sv + 3] = 0.f; }
         if (!(is_stop > 0.f) && P.occ[pi] > 0.1f) {
             Vertex v = load_vertex(P, pi);
-            uint32_t sg = seed_generator((uint32_t)(pi % fx), (uint32_t)(pi / fx), slot_frame(frameIndex, k, first_is_zero));
+            uint32_t sg = seed_generator((uint32_t)(pi % fx), (uint32_t)(pi / fx + y_off), slot_frame(frameIndex, k, first_is_zero));
             shade::Lobes L = shade::lobes(v.diffuse, v.rough, v.metallic, v.rd, v.n);
             shade::Frame fr = shade::create_frame(v.n);
             v3 wi = shade::to_local(fr, -v.rd);
@@ -129,7 +129,7 @@ __global__ void __launch_bounds__(MR_BLOCK) k_new_dir_resolve(mirres_path_t P, i
 
 // ---------------------------------------------------------------- process_path_tracing_divided_no_grad (FinalShading.slang:641-1009)
 __global__ void __launch_bounds__(MR_GEN_BLOCK) k_bounce_gen(mirres_path_t P, EnvD E, int max_bounce, float vis_near, uint32_t frameIndex, uint32_t bounce_count,
-                                                         int fx, int N, int NV, int first_is_zero, float* __restrict__ color, float* __restrict__ diff_color, float* __restrict__ spec_color,
+                                                         int fx, int N, int NV, int first_is_zero, int y_off, float* __restrict__ color, float* __restrict__ diff_color, float* __restrict__ spec_color,
                                                          Ray* __restrict__ qa, uint32_t* __restrict__ qa_count, Ray* __restrict__ qc, uint32_t* __restrict__ qc_count,
                                                          int32_t* __restrict__ slot_a, uint32_t* __restrict__ mask_out, int32_t* __restrict__ slot_c,
                                                          float* __restrict__ pend) {
@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(MR_GEN_BLOCK) k_bounce_gen(mirres_path_t P, En
         if (!(is_stop > 0.f)) {
             Vertex v = load_vertex(P, pi);
             sp = v.pos;
-            uint32_t sg = seed_generator((uint32_t)(px % fx), (uint32_t)(px / fx), slot_frame(frameIndex, k_, first_is_zero));
+            uint32_t sg = seed_generator((uint32_t)(px % fx), (uint32_t)(px / fx + y_off), slot_frame(frameIndex, k_, first_is_zero));
             if (P.occ[pi] > 0.1f) {
                 shade::Lobes L = shade::lobes(v.diffuse, v.rough, v.metallic, v.rd, v.n);
                 float lightPdf = 0.0f, scatteringPdf = 0.0f;
@@ -280,7 +280,7 @@ int launch_new_dir(mirres_ctx* ctx, mirres_bvh* bvh, const mirres_path_t* p, uin
     const PtQueues Q = qq ? *qq : ctx_queues(ctx);
     const int NV = Q.NV, grd = grid_for(NV, MR_BLOCK);
     MR_HIP(hipMemsetAsync(&Q.counters[1], 0, sizeof(uint32_t), s));
-    k_new_dir_gen<<<grid_for(NV, MR_GEN_BLOCK), MR_GEN_BLOCK, 0, s>>>(*p, ctx->cfg.max_bounce, ctx->cfg.vis_near, frameIndex, bounce_count, ctx->fx, Q.N, NV, Q.first_sample_is_zero,
+    k_new_dir_gen<<<grid_for(NV, MR_GEN_BLOCK), MR_GEN_BLOCK, 0, s>>>(*p, ctx->cfg.max_bounce, ctx->cfg.vis_near, frameIndex, bounce_count, ctx->fx, Q.N, NV, Q.first_sample_is_zero, ctx->y_off,
                                                                        Q.cl_rays, &Q.counters[1], Q.slot_c);
     int rc = trace_closest_q(ctx, bvh, Q.cl_rays, &Q.counters[1], (size_t)NV, Q.cl_hit, s, Q.lane);
     if (rc) return rc;
@@ -293,7 +293,7 @@ int launch_bounce(mirres_ctx* ctx, mirres_bvh* bvh, const mirres_env_t* env, con
     const PtQueues Q = qq ? *qq : ctx_queues(ctx);
     const int NV = Q.NV, grd = grid_for(NV, MR_BLOCK);
     MR_HIP(hipMemsetAsync(&Q.counters[0], 0, 2 * sizeof(uint32_t), s));
-    k_bounce_gen<<<grid_for(NV, MR_GEN_BLOCK), MR_GEN_BLOCK, 0, s>>>(*p, envh(env), ctx->cfg.max_bounce, ctx->cfg.vis_near, frameIndex, bounce_count, ctx->fx, Q.N, NV, Q.first_sample_is_zero,
+    k_bounce_gen<<<grid_for(NV, MR_GEN_BLOCK), MR_GEN_BLOCK, 0, s>>>(*p, envh(env), ctx->cfg.max_bounce, ctx->cfg.vis_near, frameIndex, bounce_count, ctx->fx, Q.N, NV, Q.first_sample_is_zero, ctx->y_off,
                                                                       color, dc, sc, Q.any_rays, &Q.counters[0], Q.cl_rays, &Q.counters[1], Q.slot_a, Q.mask_a, Q.slot_c, Q.pend);
     int rc = trace_any_q(ctx, bvh, Q.any_rays, &Q.counters[0], 2 * (size_t)NV, Q.any_hit, s, Q.lane); if (rc) return rc;
     rc = trace_closest_q(ctx, bvh, Q.cl_rays, &Q.counters[1], (size_t)NV, Q.cl_hit, s, Q.lane); if (rc) return rc;

@@ -3,7 +3,14 @@
 Scheme used here: the spp range of the frame is split into contiguous slices, one per rank (disjoint frame-index ranges, so every rank
 draws the samples a single GPU would have drawn for those indices); mesh/BVH/env/material are replicated. The ONLY data-path exchange is
 one all-reduce(sum) of the six [N,3] accumulators after the loop, followed by the (cheap, replicated) average + EAW + composite.
-Temporal reuse restarts at the first sample of a slice, i.e. the result is statistically equivalent, not bit-identical, to 1 GPU."""
+Temporal reuse restarts at the first sample of a slice, i.e. the result is statistically equivalent, not bit-identical, to 1 GPU.
+
+Exact scheme (`render_strips`, SURVEY §8e primary): the frame is cut into horizontal strips, one per rank. Everything on the path is per pixel
+except the spatial reuse pass, which reads the pre-spatial reservoirs and the G-buffer of neighbours within 30 px: a rank's LOCAL frame is
+its own rows plus 30 halo rows on either side (static G-buffer halo), and once per sample — between temporal and spatial reuse — the ranks
+swap the border rows of their packed reservoirs (30 rows x fx x 32 B per direction: 1.5 MB at 1600 px, point to point with the two
+neighbours). RNG streams are seeded with global pixel coordinates, so the rows a rank owns are bit-identical to the single-GPU frame; the six
+raw sums are all-gathered by rows and the (cheap) average + EAW + composite runs replicated on the whole frame."""
 import ctypes as C
 
 import torch
@@ -54,3 +61,147 @@ def render_sharded(ctx, worker, mlp_mat, env_map, g, spp, random_offset, rank, w
     arr = (C.c_void_p * 6)(*[s.data_ptr() for s in sums])
     check(lib().mirres_render_finish(ctx.h, C.byref(a), arr, stream_ptr()), "mirres_render_finish")
     return outs
+
+
+# ------------------------------------------------------------------------------------------------ exact strip sharding
+HALO_ROWS = 30   # = mirres_config_t.gather_radius (SpatialResampling.slang:33-39)
+
+
+def strip_rows(fy, rank, world, halo=HALO_ROWS):
+    """Rows of `rank`'s strip of an fy-row frame: (y0, y1, lo, hi) = own rows [y0, y1) and local frame rows [lo, hi) (own + halo, clipped).
+    Strips differ by at most one row; every strip must be at least `halo` rows high so that a halo never reaches beyond the adjacent rank."""
+    base, rem = divmod(int(fy), int(world))
+    if base < halo and world > 1:
+        raise ValueError("strip sharding needs at least %d rows per rank (fy=%d, world=%d)" % (halo, fy, world))
+    y0 = rank * base + min(rank, rem)
+    y1 = y0 + base + (1 if rank < rem else 0)
+    return y0, y1, max(0, y0 - halo), min(int(fy), y1 + halo)
+
+
+class _DevMem:
+    """Aliases raw device memory as a torch tensor (through __cuda_array_interface__), for the buffers libmirres hands to callbacks."""
+    def __init__(self, ptr, shape):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
+
+
+def device_view(ptr, shape):
+    return torch.as_tensor(_DevMem(ptr, shape), device="cuda")
+
+
+def halo_plan(fy, fx, rank, world, halo=HALO_ROWS):
+    """What the per-sample exchange moves, in LOCAL row numbers of `rank`'s frame: a list of (peer, send_rows, recv_rows) with row ranges
+    [a, b). The rank above receives our first own rows (its bottom halo) and sends its last own rows (our top halo); same below."""
+    y0, y1, lo, hi = strip_rows(fy, rank, world, halo)
+    plan = []
+    if rank > 0:
+        top = y0 - lo                                             # our top halo = the upper neighbour's last `top` own rows
+        py0, py1, plo, phi = strip_rows(fy, rank - 1, world, halo)
+        plan.append((rank - 1, (y0 - lo, y0 - lo + (phi - py1)), (0, top)))
+    if rank < world - 1:
+        bot = hi - y1
+        py0, py1, plo, phi = strip_rows(fy, rank + 1, world, halo)
+        plan.append((rank + 1, (y1 - lo - (py0 - plo), y1 - lo), (y1 - lo, y1 - lo + bot)))
+    return plan
+
+
+def exchange_halos(records, plan, group=None):
+    """One exchange step on `records` ([local rows, fx, 8] packed reservoirs, a view of the engine's buffer). NCCL/RCCL: batched
+    point-to-point ops enqueued on the current stream. gloo (CPU tests, or GPU tensors staged through the host): blocking."""
+    import torch.distributed as dist
+    if not plan:
+        return
+    if dist.get_backend(group) == "nccl":
+        ops, keep = [], []
+        for peer, (sa, sb), (ra, rb) in plan:
+            ops.append(dist.P2POp(dist.isend, records[sa:sb], peer, group))
+            ops.append(dist.P2POp(dist.irecv, records[ra:rb], peer, group))
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        return
+    reqs, staged = [], []
+    for peer, (sa, sb), (ra, rb) in plan:
+        out = records[sa:sb].detach().to("cpu").contiguous()
+        buf = torch.empty((rb - ra,) + tuple(records.shape[1:]), dtype=records.dtype)
+        reqs.append(dist.isend(out, peer, group)); reqs.append(dist.irecv(buf, peer, group))
+        staged.append((ra, rb, buf, out))
+    for r in reqs:
+        r.wait()
+    for ra, rb, buf, _ in staged:
+        records[ra:rb].copy_(buf)
+
+
+def gather_rows(own, fy, fx, world, group=None):
+    """All-gather of row strips: `own` = list of [own rows * fx, C] tensors of this rank -> list of [fy * fx, C] tensors on every rank."""
+    import torch.distributed as dist
+    base, rem = divmod(int(fy), int(world))
+    rows = [base + (1 if r < rem else 0) for r in range(world)]
+    mx = max(rows)
+    out = []
+    for t in own:
+        c = t.shape[1]
+        pad = torch.zeros((mx * fx, c), dtype=t.dtype, device=t.device)
+        pad[:t.shape[0]] = t
+        parts = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(parts, pad, group=group)
+        out.append(torch.cat([parts[r][:rows[r] * fx] for r in range(world)], dim=0))
+    return out
+
+
+def render_strips(ctx_full, worker, mlp_mat, env_map, g, spp, random_offset, rank, world, denoise_iter=2, step_width=2, c_phi=2.0, n_phi=0.1, p_phi=0.001,
+                  use_scale=False, scale=(1.0, 1.0, 1.0), group=None, max_bounce=None):
+    """Exact multi-GPU frame: this rank renders its strip (all spp) with per-sample halo exchange, the raw sums are all-gathered by rows and
+    finished on every rank. `g` is the full-frame G-buffer dict (harness.build_gbuffer); `ctx_full` a context of the full frame (finish only)."""
+    from . import _lib
+    from ._lib import lib, check, stream_ptr
+    from ._ops import get_ctx
+    from .renderer_restir import render_fused
+    fx, fy = int(g["fx"]), int(g["fy"])
+    if world == 1:
+        outs, _, _ = render_fused(ctx_full, worker, mlp_mat, use_scale, scale, env_map, g["occ"].clone(), g["normal"], g["depth"], g["kd"], g["rm"], g["ray_dir"],
+                                  g["pos"], spp, denoise_iter, step_width, c_phi, n_phi, p_phi, random_offset)
+        return outs
+    y0, y1, lo, hi = strip_rows(fy, rank, world)
+    sl = slice(lo * fx, hi * fx)
+    loc = {k: g[k][sl].contiguous() for k in ("occ", "normal", "depth", "kd", "rm", "ray_dir", "pos")}
+    ctx_loc = get_ctx(fx, hi - lo, max_bounce)
+    plan = halo_plan(fy, fx, rank, world)
+    n_loc = (hi - lo) * fx
+
+    def _halo(user, records, sample, stream):
+        try:
+            exchange_halos(device_view(records, (hi - lo, fx, 8)), plan, group)
+            return 0
+        except Exception as e:      # surfaced by mirres_render as MIRRES_E_STATE
+            import sys
+            print("[mirres] halo exchange failed:", e, file=sys.stderr)
+            return 1
+    cb = _lib.HALO_FN(_halo)
+    sums, a, keep = render_fused(ctx_loc, worker, mlp_mat, use_scale, scale, env_map, loc["occ"], loc["normal"], loc["depth"], loc["kd"], loc["rm"], loc["ray_dir"],
+                                 loc["pos"], spp, denoise_iter, step_width, c_phi, n_phi, p_phi, random_offset, strip=(fy, lo, y0 - lo, y1 - lo), halo=cb)
+    own = [s_[(y0 - lo) * fx:(y1 - lo) * fx].contiguous() for s_ in sums]
+    full = gather_rows(own, fy, fx, world, group)
+    # replicated finish on the whole frame (average, EAW, composite)
+    _, af, keepf = _finish_args(ctx_full, env_map, g, spp, denoise_iter, step_width, c_phi, n_phi, p_phi)
+    outs = [torch.empty_like(s_) for s_ in full]
+    for k in range(6):
+        af.outs[k] = outs[k].data_ptr()
+    arr = (C.c_void_p * 6)(*[s_.data_ptr() for s_ in full])
+    check(lib().mirres_render_finish(ctx_full.h, C.byref(af), arr, stream_ptr()), "mirres_render_finish")
+    return outs
+
+
+def _finish_args(ctx, env_map, g, spp, denoise_iter, step_width, c_phi, n_phi, p_phi):
+    """RenderArgs for mirres_render_finish on the full frame (only the G-buffer, spp and the denoiser parameters are read)."""
+    from . import _lib
+    a = _lib.RenderArgs()
+    keep = []
+    a.spp = int(spp)
+    env = env_map.detach().contiguous().float(); keep.append(env)
+    a.env_map, a.Hc, a.Wc = env.data_ptr(), env.shape[0], env.shape[1]
+    occ = g["occ"].clone(); keep.append(occ)
+    occ[occ <= 0.5] = 0          # what mirres_render leaves in occ (renderer_restir.py:484-485)
+    a.occ = occ.data_ptr()
+    for name, key in (("normal", "normal"), ("depth", "depth"), ("kd", "kd"), ("rough_metal", "rm"), ("ray_dir", "ray_dir"), ("pos", "pos")):
+        t = g[key].detach().contiguous().float(); keep.append(t); setattr(a, name, t.data_ptr())
+    a.denoise_iter, a.step_width, a.c_phi, a.n_phi, a.p_phi = int(denoise_iter), int(step_width), float(c_phi), float(n_phi), float(p_phi)
+    return None, a, keep

@@ -1,0 +1,38 @@
+"""Dev (GPU box): what one rank of an 8-GPU run does per frame under the two sharding schemes (no communication): a 200-row strip with
+halos at 128 spp, against the full frame at 16 spp."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import numpy as np, torch
+import mirres_restir_nerf_mesh_amd as M
+from mirres_restir_nerf_mesh_amd import renderer_restir as RR, harness, dist as D, _lib
+from mirres_restir_nerf_mesh_amd._ops import get_ctx
+from mirres_restir_nerf_mesh_amd.render_helper import MLPTexture3D
+S = M.scene
+v, t = S.make_mesh(7, 64)
+W = RR.restirbvhWorker(torch.from_numpy(v).cuda(), torch.from_numpy(t).cuda()); W.update_mesh(W.vrt, W.v_ind)
+g = harness.build_gbuffer(W, 800, 800, 2)
+env = torch.from_numpy(S.make_env(256, 512)).cuda()
+fx, fy = g["fx"], g["fy"]
+mn, mx = S.material_min_max()
+mlp = MLPTexture3D(torch.tensor([-1, -1, -1, 1, 1, 1], dtype=torch.float32), channels=6, min_max=(torch.from_numpy(mn).cuda(), torch.from_numpy(mx).cuda()), seed=3)
+def timed(fn, n=3):
+    fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): fn()
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
+world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+for rank in (0, world // 2):
+    y0, y1, lo, hi = D.strip_rows(fy, rank, world)
+    loc = {k: g[k][lo * fx:hi * fx].contiguous() for k in ("occ", "normal", "depth", "kd", "rm", "ray_dir", "pos")}
+    ctx = get_ctx(fx, hi - lo)
+    cb = _lib.HALO_FN(lambda u, r, s, st: 0)
+    def strip():
+        W.update_mesh(W.vrt, W.v_ind)
+        RR.render_fused(ctx, W, mlp, False, (1, 1, 1), env, loc["occ"].clone(), loc["normal"], loc["depth"], loc["kd"], loc["rm"], loc["ray_dir"], loc["pos"], 128, 2, 2, 2.0, 0.1, 0.001, 1,
+                        strip=(fy, lo, y0 - lo, y1 - lo), halo=cb)
+    print("strip rank %d/%d rows [%d,%d) local %d rows: %.1f ms/frame" % (rank, world, y0, y1, hi - lo, timed(strip)))
+ctxf = get_ctx(fx, fy)
+b, e = D.spp_slice(128, 0, world)
+def sl():
+    W.update_mesh(W.vrt, W.v_ind)
+    RR.render_fused(ctxf, W, mlp, False, (1, 1, 1), env, g["occ"].clone(), g["normal"], g["depth"], g["kd"], g["rm"], g["ray_dir"], g["pos"], 128, 2, 2, 2.0, 0.1, 0.001, 1, spp_range=(b, e))
+print("spp slice [%d,%d) full frame: %.1f ms/frame" % (b, e, timed(sl)))

@@ -83,6 +83,62 @@ def test_allreduce_exchange_gloo_world2(tmp_path):
         assert r0["red"][k].shape == (50, 3)
 
 
+def test_strip_partition_and_halo_plan():
+    """Strip sharding host logic: strips tile the frame, halos are 30 rows clipped at the image border, and the exchange plan of adjacent
+    ranks is symmetric (what rank r sends to r+1 is exactly what r+1 expects in its top halo)."""
+    from mirres_restir_nerf_mesh_amd import dist as D
+    for fy, world in ((1600, 8), (1600, 3), (96, 2), (1601, 4)):
+        rows = [D.strip_rows(fy, r, world) for r in range(world)]
+        assert rows[0][0] == 0 and rows[-1][1] == fy and all(a[1] == b[0] for a, b in zip(rows, rows[1:]))
+        for r, (y0, y1, lo, hi) in enumerate(rows):
+            assert lo == max(0, y0 - 30) and hi == min(fy, y1 + 30)
+            for peer, (sa, sb), (ra, rb) in D.halo_plan(fy, 8, r, world):
+                # the rows we send are our own rows; the rows we receive are halo rows; global rows match the peer's view
+                assert y0 - lo <= sa < sb <= y1 - lo and (rb <= y0 - lo or ra >= y1 - lo)
+                back = [p for p in D.halo_plan(fy, 8, peer, world) if p[0] == r][0]
+                plo = rows[peer][2]
+                assert (lo + sa, lo + sb) == (plo + back[2][0], plo + back[2][1])      # our send range == the peer's receive range, in global rows
+                assert (lo + ra, lo + rb) == (plo + back[1][0], plo + back[1][1])
+    with pytest.raises(ValueError):
+        D.strip_rows(100, 0, 8)                                                            # 12 rows per rank < 30-row halo
+
+
+def _strip_worker(rank, world, port, out):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mirres_restir_nerf_mesh_amd import dist as D
+    fy, fx = 100, 6
+    y0, y1, lo, hi = D.strip_rows(fy, rank, world)
+    # "global truth": record value = global row * 1000 + column * 10 + field; a rank starts with only its own rows filled in
+    gy = torch.arange(fy, dtype=torch.float32)[:, None, None] * 1000 + torch.arange(fx, dtype=torch.float32)[None, :, None] * 10 + torch.arange(8, dtype=torch.float32)[None, None, :]
+    rec = torch.full((hi - lo, fx, 8), -1.0)
+    rec[y0 - lo:y1 - lo] = gy[y0:y1]
+    D.exchange_halos(rec, D.halo_plan(fy, fx, rank, world))
+    own = [gy[y0:y1, :, :3].reshape(-1, 3).clone() * (k + 1) for k in range(6)]
+    full = D.gather_rows(own, fy, fx, world)
+    torch.save(dict(rec=rec, lo=lo, hi=hi, full=full), os.path.join(out, "s%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_strip_exchange_and_gather_gloo_world2(tmp_path):
+    """The two data-path exchanges of the exact multi-GPU scheme on CPU tensors: after one halo exchange every rank's local frame (own +
+    halo rows) equals the global records, and the row all-gather reassembles the full-frame sums on every rank."""
+    import torch
+    import torch.multiprocessing as mp
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_strip_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    fy, fx = 100, 6
+    gy = torch.arange(fy, dtype=torch.float32)[:, None, None] * 1000 + torch.arange(fx, dtype=torch.float32)[None, :, None] * 10 + torch.arange(8, dtype=torch.float32)[None, None, :]
+    for r in range(2):
+        d = torch.load(os.path.join(tmp_path, "s%d.pt" % r))
+        assert torch.equal(d["rec"], gy[d["lo"]:d["hi"]])
+        for k in range(6):
+            assert torch.equal(d["full"][k], gy[:, :, :3].reshape(-1, 3) * (k + 1))
+
+
 def test_rgbe_roundtrip(tmp_path):
     from mirres_restir_nerf_mesh_amd import harness
     rng = np.random.default_rng(0)
