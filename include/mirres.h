@@ -137,6 +137,15 @@ int mirres_eaw(int fx, int fy, int step_width, float c_phi, float n_phi, float p
 int mirres_eaw_bwd(int fx, int fy, int step_width, float c_phi, float n_phi, float p_phi, const float* occ, const float* color,
                    const float* normal, const float* pos, const float* grad_out, float* g_color, float* g_normal, float* g_pos, void* stream);
 
+/* bilateral_denoiser (nerf/renderutils/ops.py:173-211; c_src/denoising.cu:14-130): the alternative denoiser of run_restir_di_with_pt
+ * (--use_bi_de, renderer_restir.py:529-541). sigma = max(2 * factor, 1e-4); window radius 2 ceil(2.5 sigma) + 1. col f32[N,3],
+ * nrm f32[N,3] (normalised inside: safe_normalize, ops.py:168), zdz f32[N,2] = (z, |dz|); out f32[N,4] = (sum w col, max(sum w, 1e-4)) —
+ * the caller divides (ops.py:198). scratch f32[N,8] is overwritten.                                                              */
+int mirres_bilateral(int fx, int fy, float sigma, const float* col, const float* nrm, const float* zdz, float* scratch, float* out4, void* stream);
+/* _bilateral_denoiser_func.backward (ops.py:181-185): col_grad f32[N,3] from grad_out f32[N,4] (its 4th channel carries no gradient to col). */
+int mirres_bilateral_bwd(int fx, int fy, float sigma, const float* nrm, const float* zdz, const float* grad_out4, float* scratch, float* col_grad,
+                         void* stream);
+
 /* ------------------------------------------------------------------ material field (MLPTexture3D, render_helper.py:53-124) */
 typedef struct mirres_matnet {
     const uint16_t* grid_f16; /* fp16 hash-grid table, 6 299 960 x 2 entries (tcnn layout)                      */
@@ -168,6 +177,7 @@ typedef struct mirres_render_args {
     float const_kd[3], const_rm[2];
     int denoise_iter, step_width; float c_phi, n_phi, p_phi;
     float* outs[6];                   /* final_color, den_diffuse, den_spec, den_indirect, den_indirect_diff, den_indirect_spec */
+    const float* gb_depth;            /* f32[N,2] (z, |dz|) or NULL: non-NULL selects the bilateral denoiser with factor 2 (:529-541) instead of EAW */
     int spp_begin, spp_end;           /* multi-GPU spp sharding: render samples [spp_begin, spp_end) and skip the
                                          average/denoise/composite (raw sums are left in outs[0..5]); 0,0 = all  */
     /* Multi-GPU strip sharding (exact: bit-identical to one GPU for the rows a rank owns). The context is created for the rank's

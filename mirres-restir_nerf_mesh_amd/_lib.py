@@ -50,7 +50,7 @@ class RenderArgs(C.Structure):
                 ("occ", vp), ("normal", vp), ("depth", vp), ("kd", vp), ("rough_metal", vp), ("ray_dir", vp), ("pos", vp),
                 ("mat", C.POINTER(MatNet)), ("const_kd", C.c_float * 3), ("const_rm", C.c_float * 2),
                 ("denoise_iter", C.c_int), ("step_width", C.c_int), ("c_phi", C.c_float), ("n_phi", C.c_float), ("p_phi", C.c_float),
-                ("outs", vp * 6), ("spp_begin", C.c_int), ("spp_end", C.c_int),
+                ("outs", vp * 6), ("gb_depth", vp), ("spp_begin", C.c_int), ("spp_end", C.c_int),
                 ("strip_full_fy", C.c_int), ("strip_y_off", C.c_int), ("own_y0", C.c_int), ("own_y1", C.c_int), ("halo", vp), ("halo_user", vp)]
 
 
@@ -86,6 +86,8 @@ SIGNATURES = {
     "mirres_pt_new_dir": (C.c_int, [vp, vp, PPATH, u32, u32, vp]),
     "mirres_pt_bounce": (C.c_int, [vp, vp, PENV, PPATH, u32, u32, vp, vp, vp, vp]),
     "mirres_eaw": (C.c_int, [C.c_int, C.c_int, C.c_int, f32, f32, f32, vp, vp, vp, vp, vp, vp]),
+    "mirres_bilateral": (C.c_int, [C.c_int, C.c_int, C.c_float, vp, vp, vp, vp, vp, vp]),
+    "mirres_bilateral_bwd": (C.c_int, [C.c_int, C.c_int, C.c_float, vp, vp, vp, vp, vp, vp]),
     "mirres_eaw_bwd": (C.c_int, [C.c_int, C.c_int, C.c_int, f32, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "mirres_matnet_grid_entries": (C.c_int, []),
     "mirres_matnet_pack_grid": (C.c_int, [vp, vp, C.c_int64, vp]),

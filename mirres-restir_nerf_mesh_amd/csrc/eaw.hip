@@ -102,9 +102,80 @@ __global__ void __launch_bounds__(MR_BLOCK) k_eaw_bwd(int fx, int fy, int step, 
     if (gp) atomic_add3(gp, pi, g_p0);
 }
 
+
+// ---------------------------------------------------------------- bilateral denoiser (nerf/renderutils: ops.py:173-211, c_src/denoising.cu:14-130)
+// The alternative denoiser of run_restir_di_with_pt (--use_bi_de, renderer_restir.py:529-541). Per pixel, over a (2r+1)^2 window with
+// r = 2 ceil(2.5 sigma) + 1 (sigma = 4 -> 43 x 43 taps): w = exp(-d^2 / 2 sigma^2) * clamp(n_t . n_c, 1e-4, 1)^128 * exp(-|z_t - z_c| / max(dz_c d, 1e-4));
+// out = (sum w col, max(sum w, 1e-4)). The backward is the transposed gather (the depth term's denominator uses the TAP's dz, denoising.cu:113).
+// Inputs are read from one packed 32-byte record per pixel {col.xyz n.x | n.yz z dz} built by k_bilateral_pack (the normal is normalised
+// there: safe_normalize, ops.py:168-169), so a tap is two 16-byte loads that neighbouring pixels share through L1.
+#define MR_BIL_EPS 0.0001f
+__global__ void __launch_bounds__(MR_BLOCK) k_bilateral_pack(size_t n, const float* __restrict__ col, const float* __restrict__ nrm, const float* __restrict__ zdz,
+                                                             float4* __restrict__ rec) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    v3 nn = ld3(nrm, i);
+    const float len = sqrtf(fmaxf(dot(nn, nn), 1e-20f));
+    nn = V3(nn.x / len, nn.y / len, nn.z / len);
+    float4 a, b;
+    a.x = col ? col[3 * i] : 0.f; a.y = col ? col[3 * i + 1] : 0.f; a.z = col ? col[3 * i + 2] : 0.f; a.w = nn.x;
+    b.x = nn.y; b.y = nn.z; b.z = zdz[2 * i]; b.w = zdz[2 * i + 1];
+    rec[2 * i] = a; rec[2 * i + 1] = b;
+}
+// MODE 0: forward, out4 = (sum w col, max(sum w, 1e-4)); MODE 1: forward divided, out3 = sum w col / max(sum w, 1e-4) (the fused frame loop);
+// MODE 2: backward, out3 = sum w' grad_out4[tap].xyz
+template <int MODE>
+__global__ void __launch_bounds__(MR_BLOCK) k_bilateral(int fx, int fy, float sigma, const float4* __restrict__ rec, const float* __restrict__ grad_out4,
+                                                        float* __restrict__ out) {
+    // 16 x 16 pixel tiles: the 58 x 58 tap window of a workgroup stays in L1 / L2
+    const int tiles_x = (fx + 15) >> 4;
+    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const int x = tx * 16 + (int)(threadIdx.x & 15), y = ty * 16 + (int)(threadIdx.x >> 4);
+    if (x >= fx || y >= fy) return;
+    const size_t pi = (size_t)y * fx + x;
+    const float4 ca = rec[2 * pi], cb = rec[2 * pi + 1];
+    const v3 c_nrm = V3(ca.w, cb.x, cb.y);
+    const float c_z = cb.z, c_dz = cb.w;
+    const float variance = sigma * sigma;
+    const int rad = 2 * (int)ceilf(sigma * 2.5f) + 1;
+    float accum_w = 0.f; v3 acc = V3(0.f);
+    for (int dy = -rad; dy <= rad; ++dy) {
+        const int yy = y + dy;
+        if (yy < 0 || yy >= fy) continue;
+        for (int dx = -rad; dx <= rad; ++dx) {
+            const int xx = x + dx;
+            if (xx < 0 || xx >= fx) continue;
+            const size_t qi = (size_t)yy * fx + xx;
+            const float4 ta = rec[2 * qi], tb = rec[2 * qi + 1];
+            const v3 t_nrm = V3(ta.w, tb.x, tb.y);
+            const float dist_sqr = (float)(dx * dx + dy * dy);
+            const float dist = sqrtf(dist_sqr);
+            const float w_xy = expf(-dist_sqr / (2.0f * variance));
+            const float w_normal = powf(fminf(fmaxf(dot(t_nrm, c_nrm), MR_BIL_EPS), 1.0f), 128.0f);
+            const float w_depth = expf(-(fabsf(tb.z - c_z) / fmaxf((MODE == 2 ? tb.w : c_dz) * dist, MR_BIL_EPS)));
+            const float w = w_xy * w_normal * w_depth;
+            if (MODE == 2) acc = acc + V3(grad_out4[4 * qi], grad_out4[4 * qi + 1], grad_out4[4 * qi + 2]) * w;
+            else { acc = acc + V3(ta.x, ta.y, ta.z) * w; accum_w += w; }
+        }
+    }
+    if (MODE == 0) { out[4 * pi] = acc.x; out[4 * pi + 1] = acc.y; out[4 * pi + 2] = acc.z; out[4 * pi + 3] = fmaxf(accum_w, MR_BIL_EPS); }
+    else if (MODE == 1) { const float d = fmaxf(accum_w, MR_BIL_EPS); out[3 * pi] = acc.x / d; out[3 * pi + 1] = acc.y / d; out[3 * pi + 2] = acc.z / d; }
+    else { out[3 * pi] = acc.x; out[3 * pi + 1] = acc.y; out[3 * pi + 2] = acc.z; }
+}
+
 }  // namespace mr
 
 using namespace mr;
+
+namespace mr {
+int launch_bilateral_divided(int fx, int fy, float sigma, const float* col, const float* nrm, const float* zdz, float* scratch, float* out3, hipStream_t s) {
+    const size_t n = (size_t)fx * fy;
+    k_bilateral_pack<<<grid_for(n, MR_BLOCK), MR_BLOCK, 0, s>>>(n, col, nrm, zdz, reinterpret_cast<float4*>(scratch));
+    k_bilateral<1><<<((fx + 15) / 16) * ((fy + 15) / 16), MR_BLOCK, 0, s>>>(fx, fy, sigma, reinterpret_cast<const float4*>(scratch), nullptr, out3);
+    MR_LAUNCH_CHECK("bilateral_divided");
+    return 0;
+}
+}  // namespace mr
 
 extern "C" {
 
@@ -125,4 +196,23 @@ int mirres_eaw_bwd(int fx, int fy, int step_width, float c_phi, float n_phi, flo
     return MIRRES_OK;
 }
 
+
+/* bilateral_denoiser_fwd / _bwd (nerf/renderutils/ops.py:173-188, c_src/denoising.cu). col f32[N,3], nrm f32[N,3] (normalised here), zdz f32[N,2],
+ * out f32[N,4] = (sum w col, max(sum w, 1e-4)); scratch f32[N,8] holds the packed taps.                                                    */
+int mirres_bilateral(int fx, int fy, float sigma, const float* col, const float* nrm, const float* zdz, float* scratch, float* out4, void* stream) {
+    if (fx <= 0 || fy <= 0 || !(sigma > 0.f) || !col || !nrm || !zdz || !scratch || !out4) { set_error("mirres_bilateral: bad argument"); return MIRRES_E_ARG; }
+    const size_t n = (size_t)fx * fy; hipStream_t s = (hipStream_t)stream;
+    k_bilateral_pack<<<grid_for(n, MR_BLOCK), MR_BLOCK, 0, s>>>(n, col, nrm, zdz, reinterpret_cast<float4*>(scratch));
+    k_bilateral<0><<<((fx + 15) / 16) * ((fy + 15) / 16), MR_BLOCK, 0, s>>>(fx, fy, sigma, reinterpret_cast<const float4*>(scratch), nullptr, out4);
+    MR_LAUNCH_CHECK("bilateral");
+    return MIRRES_OK;
+}
+int mirres_bilateral_bwd(int fx, int fy, float sigma, const float* nrm, const float* zdz, const float* grad_out4, float* scratch, float* col_grad, void* stream) {
+    if (fx <= 0 || fy <= 0 || !(sigma > 0.f) || !nrm || !zdz || !grad_out4 || !scratch || !col_grad) { set_error("mirres_bilateral_bwd: bad argument"); return MIRRES_E_ARG; }
+    const size_t n = (size_t)fx * fy; hipStream_t s = (hipStream_t)stream;
+    k_bilateral_pack<<<grid_for(n, MR_BLOCK), MR_BLOCK, 0, s>>>(n, nullptr, nrm, zdz, reinterpret_cast<float4*>(scratch));
+    k_bilateral<2><<<((fx + 15) / 16) * ((fy + 15) / 16), MR_BLOCK, 0, s>>>(fx, fy, sigma, reinterpret_cast<const float4*>(scratch), grad_out4, col_grad);
+    MR_LAUNCH_CHECK("bilateral_bwd");
+    return MIRRES_OK;
+}
 }  // extern "C"

@@ -16,6 +16,7 @@ int launch_final_shading(const mirres_env_t* env, const float* occ, const float*
 int launch_new_dir(mirres_ctx* ctx, mirres_bvh* bvh, const mirres_path_t* p, uint32_t frameIndex, uint32_t bounce_count, hipStream_t s, const PtQueues* q);
 int launch_bounce(mirres_ctx* ctx, mirres_bvh* bvh, const mirres_env_t* env, const mirres_path_t* p, uint32_t frameIndex, uint32_t bounce_count, float* color,
                   float* dc, float* sc, float* acc_c, float* acc_d, float* acc_s, hipStream_t s, const PtQueues* q);
+int launch_bilateral_divided(int fx, int fy, float sigma, const float* col, const float* nrm, const float* zdz, float* scratch, float* out3, hipStream_t s);
 int launch_matnet_scatter(const mirres_matnet_t* m, const float* occ, const float* pos, int n, float* kd, float* rm, int use_scale, const float* scale3,
                           const float* const_kd, const float* const_rm, hipStream_t s);
 int launch_matnet_scatter_mfma(const mirres_matnet_t* m, const float* occ, const float* pos, int n, float* kd, float* rm, int use_scale, const float* scale3,
@@ -214,8 +215,14 @@ static int finish(mirres_ctx* ctx, const mirres_render_args_t* a, float* tot[6],
     const int N = (int)ctx->N; const size_t n3 = 3 * (size_t)N;
     const int spp = a->spp;
     k_average<<<grid_for(n3, MR_BLOCK), MR_BLOCK, 0, s>>>(n3, (float)spp, tot[0], tot[1], tot[2], tot[3], tot[4], tot[5], B.comb);
-    // EAWDenoise_use_phi(_no_di) (Denoising.py:154-251): stepWidth, then stepWidth/2, ...
     const float* srcs[5] = {tot[1], tot[2], B.comb, tot[4], tot[5]};
+    if (a->gb_depth) {
+        // bilateral_denoiser(_no_di) with factor 2 (renderer_restir.py:529-541): sigma = max(2 * factor, 1e-4); the packed tap records live in
+        // the (now idle) packed G-buffer area of the pool (16 floats per pixel >= the 8 needed)
+        const float sigma = fmaxf(2.0f * 2.0f, 0.0001f);
+        for (int k = 0; k < 5; k++) { int rc = launch_bilateral_divided(ctx->fx, ctx->fy, sigma, srcs[k], a->normal, a->gb_depth, B.grec, a->outs[k + 1], s); if (rc) return rc; }
+    } else {
+    // EAWDenoise_use_phi(_no_di) (Denoising.py:154-251): stepWidth, then stepWidth/2, ...
     for (int k = 0; k < 5; k++) {
         const float* cur = srcs[k];
         float swf = (float)a->step_width;
@@ -226,6 +233,7 @@ static int finish(mirres_ctx* ctx, const mirres_render_args_t* a, float* tot[6],
             cur = dst; swf = swf / 2;
         }
         if (a->denoise_iter <= 0) MR_HIP(hipMemcpyAsync(a->outs[k + 1], cur, sizeof(float) * n3, hipMemcpyDeviceToDevice, s));
+    }
     }
     k_composite<<<grid_for(N, MR_BLOCK), MR_BLOCK, 0, s>>>(N, a->occ, a->kd, a->rough_metal, a->outs[1], a->outs[2], a->outs[3], a->outs[0]);
     MR_LAUNCH_CHECK("render_finish");

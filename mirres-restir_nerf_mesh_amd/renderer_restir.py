@@ -14,6 +14,7 @@ from . import _lib
 from ._lib import lib, check, stream_ptr
 from ._ops import Module, get_ctx, _f32
 from .Denoising import EAWDenoise_use_phi, EAWDenoise_use_phi_no_di
+from .renderutils.ops import bilateral_denoiser, bilateral_denoiser_no_di   # renderer_restir.py:11
 from .GenerateLightTiles import make_sampleable, GenerateLightTiles
 from . import Resampling
 from .Resampling import (TemporalResampling, EvaluateFinalSamples_di, FinalShading, process_new_dir_for_pt, indirect_one_hit_divided_no_grad)
@@ -260,7 +261,7 @@ def _needs_grad(*ts):
 
 def render_fused(ctx, bvh_restir_worker, mlp_mat, use_scale, scale, env_map, occ_map, normal_map, depth_map, diffuse_map, roughness_specular, ray_dir_map, pos_map,
                  spp, denoise_iter, stepWidth, c_phi, n_phi, p_phi, random_offset, spp_range=None, const_kd=(0.6, 0.6, 0.6), const_rm=(0.5, 0.0),
-                 strip=None, halo=None):
+                 strip=None, halo=None, gb_depth=None):
     """One C call for the whole frame (mirres_render). Returns the 6 output buffers [N,3] (raw sums when spp_range or strip is given).
     strip = (full_fy, y_off, own_y0, own_y1): `ctx` and all per-pixel inputs describe a rank's LOCAL frame (own rows + halo rows, dist.py);
     halo = a _lib.HALO_FN called once per sample to exchange the halo rows of the packed reservoirs."""
@@ -286,6 +287,8 @@ def render_fused(ctx, bvh_restir_worker, mlp_mat, use_scale, scale, env_map, occ
     outs = [torch.empty((N, 3), dtype=torch.float32, device=env.device) for _ in range(6)]
     for k in range(6):
         a.outs[k] = outs[k].data_ptr()
+    if gb_depth is not None:      # bilateral denoiser instead of EAW (--use_bi_de)
+        gd = _f32(gb_depth.detach()); keep.append(gd); a.gb_depth = gd.data_ptr()
     if spp_range is not None:
         a.spp_begin, a.spp_end = int(spp_range[0]), int(spp_range[1])
     if strip is not None:
@@ -304,15 +307,13 @@ def run_restir_di_with_pt(use_scale, scale_x, scale_y, scale_z, mlp_mat, gb_dept
                           framedim_y, spp, denoise_iter, stepWidth, c_phi_scale=1.0, n_phi_scale=0.1, p_phi_scale=0.1):
     """renderer_restir.py:473-550. Mutates occ_map in place; returns (final_color, denoised_diffuse, denoised_spec, denoised_indirect,
     denoised_indirect_diff, denoised_indirect_spec), each f32[N,3]."""
-    if gb_depth is not None:
-        raise NotImplementedError("the bilateral denoiser (--use_bi_de, nerf/renderutils) is outside this engine's hot path (SURVEY §8 f-3)")
     from .render_helper import MLPTexture3D
     grad = _needs_grad(env_map, normal_map, diffuse_map, roughness_specular)
     if not grad and (mlp_mat is None or isinstance(mlp_mat, MLPTexture3D)):
         random_offset = np.random.randint(2**20) if _FIXED_RANDOM_OFFSET is None else int(_FIXED_RANDOM_OFFSET)
         outs, _, _ = render_fused(InitialResampling_m.ctx, bvh_restir_worker, mlp_mat, use_scale, (scale_x, scale_y, scale_z), env_map, occ_map, normal_map,
                                   depth_map, diffuse_map, roughness_specular, ray_dir_map, pos_map, spp, denoise_iter, stepWidth, c_phi_scale, n_phi_scale,
-                                  p_phi_scale, random_offset)
+                                  p_phi_scale, random_offset, gb_depth=gb_depth)
         return tuple(outs)
 
     indices = torch.where(occ_map <= 0.5)
@@ -333,12 +334,21 @@ def run_restir_di_with_pt(use_scale, scale_x, scale_y, scale_z, mlp_mat, gb_dept
     total_diff_light_1 = total_diff_light_1 / mFrameIndex
     total_spec_light_1 = total_spec_light_1 / mFrameIndex
     combined_color_indirect = total_diff_light_1 + total_spec_light_1
-    args = (denoising_m, c_phi_scale, n_phi_scale, p_phi_scale, stepWidth, denoise_iter, framedim_x, framedim_y, occ_map)
-    denoised_diffuse = EAWDenoise_use_phi(*args, total_diff_light, normal, pos_map)
-    denoised_spec = EAWDenoise_use_phi(*args, total_spec_light, normal, pos_map)
-    denoised_indirect = EAWDenoise_use_phi_no_di(*args, combined_color_indirect, normal, pos_map)
-    denoised_indirect_diff = EAWDenoise_use_phi_no_di(*args, total_diff_light_1, normal, pos_map)
-    denoised_indirect_spec = EAWDenoise_use_phi_no_di(*args, total_spec_light_1, normal, pos_map)
+    if gb_depth is None:
+        args = (denoising_m, c_phi_scale, n_phi_scale, p_phi_scale, stepWidth, denoise_iter, framedim_x, framedim_y, occ_map)
+        denoised_diffuse = EAWDenoise_use_phi(*args, total_diff_light, normal, pos_map)
+        denoised_spec = EAWDenoise_use_phi(*args, total_spec_light, normal, pos_map)
+        denoised_indirect = EAWDenoise_use_phi_no_di(*args, combined_color_indirect, normal, pos_map)
+        denoised_indirect_diff = EAWDenoise_use_phi_no_di(*args, total_diff_light_1, normal, pos_map)
+        denoised_indirect_spec = EAWDenoise_use_phi_no_di(*args, total_spec_light_1, normal, pos_map)
+    else:   # --use_bi_de (:529-541)
+        factor = 2.0
+        cat = lambda c: torch.cat((c, normal, gb_depth), dim=-1)
+        denoised_diffuse = bilateral_denoiser(framedim_y, framedim_x, cat(total_diff_light), factor)
+        denoised_spec = bilateral_denoiser(framedim_y, framedim_x, cat(total_spec_light), factor)
+        denoised_indirect = bilateral_denoiser_no_di(framedim_y, framedim_x, cat(combined_color_indirect), factor)
+        denoised_indirect_diff = bilateral_denoiser_no_di(framedim_y, framedim_x, cat(total_diff_light_1), factor)
+        denoised_indirect_spec = bilateral_denoiser_no_di(framedim_y, framedim_x, cat(total_spec_light_1), factor)
     diffuse = diffuse * (1.0 - roughnessSpecular[..., 1:2])
     final_color = diffuse * denoised_diffuse + denoised_spec + denoised_indirect
     indices = torch.where(occ_map <= 0.1)

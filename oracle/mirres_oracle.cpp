@@ -142,6 +142,44 @@ void orc_eaw(int fx, int fy, int stepWidth, float c_phi, float n_phi, float p_ph
         for (int x = 0; x < fx; x++) eaw_pixel(fx, fy, stepWidth, c_phi, n_phi, p_phi, occ, color, normal, pos, out, x, y);
 }
 
+// ---- bilateral denoiser (nerf/renderutils/ops.py:164-211 + c_src/denoising.cu:14-130), the --use_bi_de branch of run_restir_di_with_pt
+// (renderer_restir.py:529-541). mode 0: out4 = (sum w col, max(sum w, 1e-4)); mode 1: col_grad3 = sum w' grad4.xyz (transposed depth term).
+void orc_bilateral(int fx, int fy, float sigma, const float* col, const float* nrm_in, const float* zdz, const float* grad4, int mode, float* out) {
+    const size_t n = (size_t)fx * fy;
+    std::vector<float> nrm(3 * n);
+    for (size_t i = 0; i < n; i++) {                        // safe_normalize (ops.py:164-169)
+        float x = nrm_in[3 * i], y = nrm_in[3 * i + 1], z = nrm_in[3 * i + 2];
+        float len = std::sqrt(std::max((x * x + y * y) + z * z, 1e-20f));
+        nrm[3 * i] = x / len; nrm[3 * i + 1] = y / len; nrm[3 * i + 2] = z / len;
+    }
+    const float variance = sigma * sigma;
+    const int rad = 2 * (int)std::ceil(sigma * 2.5f) + 1;
+#pragma omp parallel for
+    for (int y = 0; y < fy; y++)
+        for (int x = 0; x < fx; x++) {
+            const size_t pi = (size_t)y * fx + x;
+            const float cz = zdz[2 * pi], cdz = zdz[2 * pi + 1];
+            float aw = 0.f, ax = 0.f, ay = 0.f, az = 0.f;
+            for (int dy = -rad; dy <= rad; ++dy)
+                for (int dx = -rad; dx <= rad; ++dx) {
+                    const int yy = y + dy, xx = x + dx;
+                    if (yy < 0 || xx < 0 || yy >= fy || xx >= fx) continue;
+                    const size_t qi = (size_t)yy * fx + xx;
+                    const float dist_sqr = (float)(dx * dx + dy * dy), dist = std::sqrt(dist_sqr);
+                    const float w_xy = std::exp(-dist_sqr / (2.0f * variance));
+                    const float nd = (nrm[3 * qi] * nrm[3 * pi] + nrm[3 * qi + 1] * nrm[3 * pi + 1]) + nrm[3 * qi + 2] * nrm[3 * pi + 2];
+                    const float w_normal = std::pow(std::min(std::max(nd, 0.0001f), 1.0f), 128.0f);
+                    const float den = std::max((mode == 1 ? zdz[2 * qi + 1] : cdz) * dist, 0.0001f);
+                    const float w_depth = std::exp(-(std::fabs(zdz[2 * qi] - cz) / den));
+                    const float w = w_xy * w_normal * w_depth;
+                    if (mode == 1) { ax += grad4[4 * qi] * w; ay += grad4[4 * qi + 1] * w; az += grad4[4 * qi + 2] * w; }
+                    else { ax += col[3 * qi] * w; ay += col[3 * qi + 1] * w; az += col[3 * qi + 2] * w; aw += w; }
+                }
+            if (mode == 1) { out[3 * pi] = ax; out[3 * pi + 1] = ay; out[3 * pi + 2] = az; }
+            else { out[4 * pi] = ax; out[4 * pi + 1] = ay; out[4 * pi + 2] = az; out[4 * pi + 3] = std::max(aw, 0.0001f); }
+        }
+}
+
 // ---- material field
 struct OrcMatNet {
     const uint16_t* params_f16;  // [total_entries*2] fp16 bits

@@ -279,6 +279,19 @@ def eaw(fx, fy, step, c_phi, n_phi, p_phi, occ, color, normal, pos):
     return out
 
 
+def bilateral(fx, fy, sigma, col, nrm, zdz, grad4=None):
+    """grad4 None: forward -> f32[N,4] (sum w col, max(sum w, 1e-4)); else backward -> col_grad f32[N,3]."""
+    n = fx * fy
+    nrm = _c(nrm, np.float32); zdz = _c(zdz, np.float32)
+    if grad4 is None:
+        out = np.zeros((n, 4), np.float32)
+        lib().orc_bilateral(fx, fy, C.c_float(sigma), _p(_c(col, np.float32), f32p), _p(nrm, f32p), _p(zdz, f32p), None, 0, _p(out, f32p))
+    else:
+        out = np.zeros((n, 3), np.float32)
+        lib().orc_bilateral(fx, fy, C.c_float(sigma), None, _p(nrm, f32p), _p(zdz, f32p), _p(_c(grad4, np.float32), f32p), 1, _p(out, f32p))
+    return out
+
+
 # ------------------------------------------------------------------ material field
 def hashgrid_layout():
     off = np.zeros(17, np.uint32); res = np.zeros(16, np.uint32); sc = np.zeros(16, np.float32)

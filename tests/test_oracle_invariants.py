@@ -128,3 +128,25 @@ def test_hashgrid_dense_levels_are_trilinear(oracle, scene_mod):
     assert np.all(enc[:, 4:] == 0)
     out = oracle.matnet(mat, x * 2 - 1)
     np.testing.assert_allclose(out, np.tile((mn + mx) / 2, (400, 1)), atol=1e-7)                 # zero weights -> sigmoid(0) = 0.5
+
+
+def test_bilateral_denoiser_properties(oracle):
+    """nerf/renderutils bilateral denoiser (the --use_bi_de branch of run_restir_di_with_pt): a normalised filter keeps a constant image,
+    the fourth channel is the clamped weight sum, and the backward kernel is the exact adjoint of the forward in the colour
+    (<bwd(g), c> == <g, fwd(c)>: the depth term's denominator is transposed, c_src/denoising.cu:113)."""
+    rng = np.random.default_rng(5)
+    fx, fy, sigma = 20, 14, 1.0
+    n = fx * fy
+    nrm = rng.normal(size=(n, 3)).astype(np.float32); nrm[:, 2] += 3.0
+    zdz = np.stack([1.0 + 0.05 * rng.random(n), 0.01 + 0.02 * rng.random(n)], axis=1).astype(np.float32)
+    const = np.tile(np.array([[0.3, 0.6, 0.9]], np.float32), (n, 1))
+    o = oracle.bilateral(fx, fy, sigma, const, nrm, zdz)
+    assert o.shape == (n, 4) and np.all(o[:, 3] >= 1e-4)
+    np.testing.assert_allclose(o[:, :3] / o[:, 3:4], const, rtol=2e-6)
+    c = rng.random((n, 3)).astype(np.float32); g = rng.normal(size=(n, 4)).astype(np.float32)
+    f = oracle.bilateral(fx, fy, sigma, c, nrm, zdz)
+    b = oracle.bilateral(fx, fy, sigma, None, nrm, zdz, grad4=g)
+    lhs = float((b.astype(np.float64) * c).sum()); rhs = float((g[:, :3].astype(np.float64) * f[:, :3]).sum())
+    assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(rhs))
+    # the centre tap has weight 1, so an isolated bright pixel keeps at least its own contribution
+    assert np.all(f[:, 3] >= 0.999)          # (n.n)^128 of a unit normal is 1 up to fp32 rounding
