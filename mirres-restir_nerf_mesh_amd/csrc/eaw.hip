@@ -168,6 +168,86 @@ __global__ void __launch_bounds__(MR_BLOCK) k_bilateral(int fx, int fy, float si
 using namespace mr;
 
 namespace mr {
+// The five buffers the frame loop denoises share normal / depth guides, i.e. the weights: one pass over the window accumulates all of them.
+// Taps are read from one packed 80-byte record per pixel {n.xyz z | dz c0 | c1 c2.x | c2.yz c3.xy | c3.z c4} (5 x 16-byte loads instead of
+// 16 scalar ones), and the terms that depend only on the tap offset — dist = sqrt(dx^2 + dy^2) and exp(-d^2 / 2 sigma^2) — come from an LDS
+// table filled once per workgroup with the very expressions of the per-tap code (same bits). out_k = sum w col_k / max(sum w, 1e-4).
+struct Bil5 { const float* col[5]; float* out[5]; };
+__global__ void __launch_bounds__(MR_BLOCK) k_bilateral_pack5(size_t n, const float* __restrict__ nrm, const float* __restrict__ zdz, Bil5 P, float4* __restrict__ rec) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    v3 nn = ld3(nrm, i);
+    const float len = sqrtf(fmaxf(dot(nn, nn), 1e-20f));
+    v3 c[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) c[k] = ld3(P.col[k], i);
+    float4 r[5];
+    r[0].x = nn.x / len; r[0].y = nn.y / len; r[0].z = nn.z / len; r[0].w = zdz[2 * i];
+    r[1].x = zdz[2 * i + 1]; r[1].y = c[0].x; r[1].z = c[0].y; r[1].w = c[0].z;
+    r[2].x = c[1].x; r[2].y = c[1].y; r[2].z = c[1].z; r[2].w = c[2].x;
+    r[3].x = c[2].y; r[3].y = c[2].z; r[3].z = c[3].x; r[3].w = c[3].y;
+    r[4].x = c[3].z; r[4].y = c[4].x; r[4].z = c[4].y; r[4].w = c[4].z;
+#pragma unroll
+    for (int k = 0; k < 5; k++) rec[5 * i + k] = r[k];
+}
+#define MR_BIL_MAXRAD 21     // sigma = 4 (factor 2, renderer_restir.py:530); larger windows fall back to the per-buffer kernel
+__global__ void __launch_bounds__(MR_BLOCK) k_bilateral5(int fx, int fy, float sigma, const float4* __restrict__ rec, Bil5 P) {
+    __shared__ float s_wxy[(2 * MR_BIL_MAXRAD + 1) * (2 * MR_BIL_MAXRAD + 1)], s_dist[(2 * MR_BIL_MAXRAD + 1) * (2 * MR_BIL_MAXRAD + 1)];
+    const float variance = sigma * sigma;
+    const int rad = 2 * (int)ceilf(sigma * 2.5f) + 1, wdt = 2 * rad + 1;
+    for (int i = threadIdx.x; i < wdt * wdt; i += MR_BLOCK) {
+        const int dy = i / wdt - rad, dx = i % wdt - rad;
+        const float dist_sqr = (float)(dx * dx + dy * dy);
+        s_dist[i] = sqrtf(dist_sqr);
+        s_wxy[i] = expf(-dist_sqr / (2.0f * variance));
+    }
+    __syncthreads();
+    const int tiles_x = (fx + 15) >> 4;
+    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const int x = tx * 16 + (int)(threadIdx.x & 15), y = ty * 16 + (int)(threadIdx.x >> 4);
+    if (x >= fx || y >= fy) return;
+    const size_t pi = (size_t)y * fx + x;
+    const float4 ca = rec[5 * pi];
+    const v3 c_nrm = V3(ca.x, ca.y, ca.z);
+    const float c_z = ca.w, c_dz = rec[5 * pi + 1].x;
+    float accum_w = 0.f; v3 acc[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) acc[k] = V3(0.f);
+    for (int dy = -rad; dy <= rad; ++dy) {
+        const int yy = y + dy;
+        if (yy < 0 || yy >= fy) continue;
+        for (int dx = -rad; dx <= rad; ++dx) {
+            const int xx = x + dx;
+            if (xx < 0 || xx >= fx) continue;
+            const float4* __restrict__ t = rec + 5 * ((size_t)yy * fx + xx);
+            const float4 t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3], t4 = t[4];
+            const int li = (dy + rad) * wdt + (dx + rad);
+            const float w_normal = powf(fminf(fmaxf(dot(V3(t0.x, t0.y, t0.z), c_nrm), MR_BIL_EPS), 1.0f), 128.0f);
+            const float w_depth = expf(-(fabsf(t0.w - c_z) / fmaxf(c_dz * s_dist[li], MR_BIL_EPS)));
+            const float w = s_wxy[li] * w_normal * w_depth;
+            acc[0] = acc[0] + V3(t1.y, t1.z, t1.w) * w; acc[1] = acc[1] + V3(t2.x, t2.y, t2.z) * w; acc[2] = acc[2] + V3(t2.w, t3.x, t3.y) * w;
+            acc[3] = acc[3] + V3(t3.z, t3.w, t4.x) * w; acc[4] = acc[4] + V3(t4.y, t4.z, t4.w) * w;
+            accum_w += w;
+        }
+    }
+    const float d = fmaxf(accum_w, MR_BIL_EPS);
+#pragma unroll
+    for (int k = 0; k < 5; k++) { P.out[k][3 * pi] = acc[k].x / d; P.out[k][3 * pi + 1] = acc[k].y / d; P.out[k][3 * pi + 2] = acc[k].z / d; }
+}
+int launch_bilateral_divided(int fx, int fy, float sigma, const float* col, const float* nrm, const float* zdz, float* scratch, float* out3, hipStream_t s);
+// scratch: f32[N, 20]
+int launch_bilateral5(int fx, int fy, float sigma, const float* const col[5], const float* nrm, const float* zdz, float* scratch, float* const out[5], hipStream_t s) {
+    const size_t n = (size_t)fx * fy;
+    if (2 * (int)ceilf(sigma * 2.5f) + 1 > MR_BIL_MAXRAD) {
+        for (int k = 0; k < 5; k++) { int rc = launch_bilateral_divided(fx, fy, sigma, col[k], nrm, zdz, scratch, out[k], s); if (rc) return rc; }
+        return 0;
+    }
+    Bil5 P; for (int k = 0; k < 5; k++) { P.col[k] = col[k]; P.out[k] = out[k]; }
+    k_bilateral_pack5<<<grid_for(n, MR_BLOCK), MR_BLOCK, 0, s>>>(n, nrm, zdz, P, reinterpret_cast<float4*>(scratch));
+    k_bilateral5<<<((fx + 15) / 16) * ((fy + 15) / 16), MR_BLOCK, 0, s>>>(fx, fy, sigma, reinterpret_cast<const float4*>(scratch), P);
+    MR_LAUNCH_CHECK("bilateral5");
+    return 0;
+}
 int launch_bilateral_divided(int fx, int fy, float sigma, const float* col, const float* nrm, const float* zdz, float* scratch, float* out3, hipStream_t s) {
     const size_t n = (size_t)fx * fy;
     k_bilateral_pack<<<grid_for(n, MR_BLOCK), MR_BLOCK, 0, s>>>(n, col, nrm, zdz, reinterpret_cast<float4*>(scratch));

@@ -16,7 +16,7 @@ int launch_final_shading(const mirres_env_t* env, const float* occ, const float*
 int launch_new_dir(mirres_ctx* ctx, mirres_bvh* bvh, const mirres_path_t* p, uint32_t frameIndex, uint32_t bounce_count, hipStream_t s, const PtQueues* q);
 int launch_bounce(mirres_ctx* ctx, mirres_bvh* bvh, const mirres_env_t* env, const mirres_path_t* p, uint32_t frameIndex, uint32_t bounce_count, float* color,
                   float* dc, float* sc, float* acc_c, float* acc_d, float* acc_s, hipStream_t s, const PtQueues* q);
-int launch_bilateral_divided(int fx, int fy, float sigma, const float* col, const float* nrm, const float* zdz, float* scratch, float* out3, hipStream_t s);
+int launch_bilateral5(int fx, int fy, float sigma, const float* const col[5], const float* nrm, const float* zdz, float* scratch, float* const out[5], hipStream_t s);
 int launch_matnet_scatter(const mirres_matnet_t* m, const float* occ, const float* pos, int n, float* kd, float* rm, int use_scale, const float* scale3,
                           const float* const_kd, const float* const_rm, hipStream_t s);
 int launch_matnet_scatter_mfma(const mirres_matnet_t* m, const float* occ, const float* pos, int n, float* kd, float* rm, int use_scale, const float* scale3,
@@ -114,7 +114,7 @@ struct Pool {
 };
 
 static size_t pool_need(size_t N, size_t WH, size_t H, size_t TS) {
-    size_t per_px = 3 + 4 + 3 + 12 + 1 + 3 + 1 + 3 + 18 + 9 + 5 + 10 + 10 + 5 + 6 + 3 + 16 + 1;
+    size_t per_px = 3 + 4 + 3 + 12 + 1 + 3 + 1 + 3 + 18 + 9 + 5 + 10 + 10 + 5 + 6 + 3 + 16 + 1 + 20;
     return per_px * N + 3 * WH + WH + (WH + H) + H + (H + 1) + 4 * TS + 64 * 64;
 }
 
@@ -123,7 +123,7 @@ static size_t pool_need(size_t N, size_t WH, size_t H, size_t TS) {
 using namespace mr;
 
 struct FrameBufs {
-    float *ray_dir, *nd, *brdf, *grec, *occ_own;
+    float *ray_dir, *nd, *brdf, *grec, *occ_own, *bil;
     float *r_ld[2], *r_pdf[2], *r_w[2]; int32_t* r_M[2];
     float *vis, *fdir, *fdist, *fLi;
     float* tot[6];  // total_color, total_diff, total_spec, total_color_1, total_diff_1, total_spec_1
@@ -152,8 +152,8 @@ static int carve(mirres_ctx* ctx, int Wc, int Hc, FrameBufs& B) {
     B.tex = P.take(3 * WH); B.pdf = P.take(WH); B.cdf = P.take(WH + Hc); B.mpdf = P.take(Hc); B.mcdf = P.take(Hc + 1);
     B.tile_data = P.take(3 * TS); B.tile_pdf = P.take(TS);
     B.den_a = P.take(3 * N); B.den_b = P.take(3 * N); B.comb = B.c1;  // comb reuses c1 after the loop
-    B.grec = P.take(16 * N); B.occ_own = P.take(N);
-    if (!B.den_b || !B.grec || !B.occ_own) { set_error("mirres_render: internal pool too small"); return MIRRES_E_STATE; }
+    B.grec = P.take(16 * N); B.occ_own = P.take(N); B.bil = P.take(20 * N);   // bil: packed taps of the bilateral finish
+    if (!B.den_b || !B.grec || !B.occ_own || !B.bil) { set_error("mirres_render: internal pool too small"); return MIRRES_E_STATE; }
     return 0;
 }
 
@@ -220,7 +220,8 @@ static int finish(mirres_ctx* ctx, const mirres_render_args_t* a, float* tot[6],
         // bilateral_denoiser(_no_di) with factor 2 (renderer_restir.py:529-541): sigma = max(2 * factor, 1e-4); the packed tap records live in
         // the (now idle) packed G-buffer area of the pool (16 floats per pixel >= the 8 needed)
         const float sigma = fmaxf(2.0f * 2.0f, 0.0001f);
-        for (int k = 0; k < 5; k++) { int rc = launch_bilateral_divided(ctx->fx, ctx->fy, sigma, srcs[k], a->normal, a->gb_depth, B.grec, a->outs[k + 1], s); if (rc) return rc; }
+        float* const dsts[5] = {a->outs[1], a->outs[2], a->outs[3], a->outs[4], a->outs[5]};
+        int rc = launch_bilateral5(ctx->fx, ctx->fy, sigma, srcs, a->normal, a->gb_depth, B.bil, dsts, s); if (rc) return rc;   // one pass: the five buffers share the weights
     } else {
     // EAWDenoise_use_phi(_no_di) (Denoising.py:154-251): stepWidth, then stepWidth/2, ...
     for (int k = 0; k < 5; k++) {
