@@ -177,6 +177,8 @@ typedef struct mirres_render_args {
     float const_kd[3], const_rm[2];
     int denoise_iter, step_width; float c_phi, n_phi, p_phi;
     float* outs[6];                   /* final_color, den_diffuse, den_spec, den_indirect, den_indirect_diff, den_indirect_spec */
+    float* tape;                      /* f32[samples, N, 8] or NULL: per sample and pixel the final (spatially merged) reservoir and its visibility
+                                         {light_data.xyz inv_pdf | M weight vis 0}, what mirres_render_bwd differentiates through        */
     const float* gb_depth;            /* f32[N,2] (z, |dz|) or NULL: non-NULL selects the bilateral denoiser with factor 2 (:529-541) instead of EAW */
     int spp_begin, spp_end;           /* multi-GPU spp sharding: render samples [spp_begin, spp_end) and skip the
                                          average/denoise/composite (raw sums are left in outs[0..5]); 0,0 = all  */
@@ -192,6 +194,13 @@ typedef struct mirres_render_args {
     void* halo_user;
 } mirres_render_args_t;
 int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args_t* a, void* stream);
+/* Backward of the frame's DIRECT lighting sums w.r.t. what the reference differentiates (EvaluateFinalSamples_di.backward +
+ * FinalShading.backward summed over the samples, Resampling.py:116-214): from the cotangents of the three direct sums (total colour,
+ * diffuse light, specular light — f32[N,3] each) and the tape of the forward call (`samples` samples), gradients w.r.t. normal [N,3],
+ * kd [N,3], (roughness, metallic) [N,2] (overwritten) and the environment texels f32[Hc*Wc,3] in the caller's (unflipped) layout
+ * (accumulated). The indirect sums carry no gradient (process_path_tracing_divided_no_grad). `a` = the forward call's arguments.       */
+int mirres_render_bwd(mirres_ctx_t* ctx, const mirres_render_args_t* a, int samples, const float* g_color, const float* g_diff,
+                      const float* g_spec, float* g_normal, float* g_kd, float* g_rough_metal, float* g_env, void* stream);
 /* second half of run_restir_di_with_pt (:507-549) on already-summed accumulators (after an all-reduce).         */
 int mirres_render_finish(mirres_ctx_t* ctx, const mirres_render_args_t* a, float* sums[6], void* stream);
 

@@ -50,7 +50,7 @@ class RenderArgs(C.Structure):
                 ("occ", vp), ("normal", vp), ("depth", vp), ("kd", vp), ("rough_metal", vp), ("ray_dir", vp), ("pos", vp),
                 ("mat", C.POINTER(MatNet)), ("const_kd", C.c_float * 3), ("const_rm", C.c_float * 2),
                 ("denoise_iter", C.c_int), ("step_width", C.c_int), ("c_phi", C.c_float), ("n_phi", C.c_float), ("p_phi", C.c_float),
-                ("outs", vp * 6), ("gb_depth", vp), ("spp_begin", C.c_int), ("spp_end", C.c_int),
+                ("outs", vp * 6), ("tape", vp), ("gb_depth", vp), ("spp_begin", C.c_int), ("spp_end", C.c_int),
                 ("strip_full_fy", C.c_int), ("strip_y_off", C.c_int), ("own_y0", C.c_int), ("own_y1", C.c_int), ("halo", vp), ("halo_user", vp)]
 
 
@@ -96,6 +96,7 @@ SIGNATURES = {
     "mirres_matnet_scatter": (C.c_int, [PMAT, vp, vp, C.c_int, vp, vp, C.c_int, C.POINTER(C.c_float), vp]),
     "mirres_matnet_bwd": (C.c_int, [PMAT, vp, C.c_int, vp, vp, vp, vp, vp, vp]),
     "mirres_render": (C.c_int, [vp, vp, PARGS, vp]),
+    "mirres_render_bwd": (C.c_int, [vp, PARGS, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]),
     "mirres_render_finish": (C.c_int, [vp, PARGS, C.POINTER(vp), vp]),
 }
 

@@ -7,6 +7,7 @@
 //     into the fp32 master table (tcnn accumulates its grid gradient the same way).
 #include "engine.hpp"
 #include "device_math.hpp"
+#include "device_light.hpp"
 #include <hip/hip_fp16.h>
 #include <cmath>
 
@@ -158,6 +159,61 @@ __global__ void __launch_bounds__(MR_BLOCK) k_final_shading_bwd(int N, const flo
     if (g_kd) st3(g_kd, pi, gk);
     if (g_rm) { g_rm[2 * (size_t)pi] = gr.x; g_rm[2 * (size_t)pi + 1] = gr.y; }
     if (g_Li) st3(g_Li, pi, gl);
+}
+
+// ---------------------------------------------------------------- fused backward of the frame's direct-lighting sums (mirres_render_bwd)
+// total = sum over samples s of FinalShading(normal, kd, rm, Li_s) with Li_s = W_s * env(dir_s) * [visible_s] (EvaluateFinalSamples_di): one thread
+// per pixel walks the tape of the forward call, re-forms each sample's (dir, Li) exactly as the forward did, contracts the dual-number
+// Jacobian of the shading with the cotangents of the three sums (the same code as k_final_shading_bwd) and scatters d/dLi into the four
+// environment texels of the bilinear lookup (k_eval_final_bwd). tex is the flipped map the forward sampled; g_env is in the caller's layout.
+__global__ void __launch_bounds__(MR_BLOCK) k_direct_bwd(EnvD E, int N, int S, const float* __restrict__ occ, const float* __restrict__ normal,
+                                                         const float* __restrict__ ray_dir_raw, const float* __restrict__ kd, const float* __restrict__ rm,
+                                                         const float4* __restrict__ tape, const float* __restrict__ g_color, const float* __restrict__ g_diff,
+                                                         const float* __restrict__ g_spec, float* __restrict__ g_normal, float* __restrict__ g_kd,
+                                                         float* __restrict__ g_rm, float* __restrict__ g_env) {
+    const int pi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pi >= N) return;
+    v3 gn = V3(0.f), gk = V3(0.f), gr = V3(0.f);
+    if (occ[pi] > 0.1f) {
+        const v3 n = ld3(normal, pi), k = ld3(kd, pi);
+        v3 rd = ld3(ray_dir_raw, pi);
+        { const float l = fmaxf(sqrtf(dot(rd, rd)), 1e-6f); rd = V3(rd.x / l, rd.y / l, rd.z / l); }   // the forward's k_prep (F.normalize, eps 1e-6)
+        const float rough = rm[2 * (size_t)pi], metal = rm[2 * (size_t)pi + 1];
+        const v3 gc = ld3(g_color, pi), gd = ld3(g_diff, pi), gs = ld3(g_spec, pi);
+        for (int s = 0; s < S; s++) {
+            const float4 a = tape[2 * ((size_t)s * N + pi)], b = tape[2 * ((size_t)s * N + pi) + 1];
+            if (!(a.x > 0.1f) || !(b.z > 0.f)) continue;                  // empty reservoir or occluded: Li = 0, dist = 0 -> no contribution
+            const v3 dir = oct_decode(V2(a.y, a.z));
+            const v3 Li = b.y * env_radiance(E, dir);
+            gn = gn + contract<0>(n, rd, k, rough, metal, dir, Li, gc, gd, gs);
+            gk = gk + contract<1>(n, rd, k, rough, metal, dir, Li, gc, gd, gs);
+            gr = gr + contract<2>(n, rd, k, rough, metal, dir, Li, gc, gd, gs);
+            if (g_env) {
+                const v3 gl = contract<3>(n, rd, k, rough, metal, dir, Li, gc, gd, gs) * b.y;    // d/d env = W * d/dLi
+                int idx[4]; float w[4];
+                if (env_le_footprint(ngp_dir(dir), E.W, E.H, idx, w)) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const int ty = idx[q] / E.W, tx = idx[q] - ty * E.W;
+                        float* dst = g_env + 3 * ((size_t)(E.H - 1 - ty) * E.W + tx);                // tex row ty = caller's row H-1-ty (k_flip_env)
+                        atomicAdd(dst, gl.x * w[q]); atomicAdd(dst + 1, gl.y * w[q]); atomicAdd(dst + 2, gl.z * w[q]);
+                    }
+                }
+            }
+        }
+    }
+    if (g_normal) st3(g_normal, pi, gn);
+    if (g_kd) st3(g_kd, pi, gk);
+    if (g_rm) { g_rm[2 * (size_t)pi] = gr.x; g_rm[2 * (size_t)pi + 1] = gr.y; }
+}
+int launch_direct_bwd(const float* tex, int Wc, int Hc, int N, int S, const float* occ, const float* normal, const float* ray_dir_raw, const float* kd, const float* rm,
+                      const float* tape, const float* g_color, const float* g_diff, const float* g_spec, float* g_normal, float* g_kd, float* g_rm, float* g_env,
+                      hipStream_t s) {
+    EnvD E; E.tex = tex; E.W = Wc; E.H = Hc; E.pdf = nullptr; E.cdf = nullptr; E.mpdf = nullptr; E.mcdf = nullptr;
+    k_direct_bwd<<<grid_for(N, MR_BLOCK), MR_BLOCK, 0, s>>>(E, N, S, occ, normal, ray_dir_raw, kd, rm, reinterpret_cast<const float4*>(tape), g_color, g_diff, g_spec,
+                                                            g_normal, g_kd, g_rm, g_env);
+    MR_LAUNCH_CHECK("direct_bwd");
+    return 0;
 }
 
 // ---------------------------------------------------------------- material-field backward

@@ -147,7 +147,7 @@ struct PtQueues {
 int launch_initial_batch(mirres_ctx* ctx, mirres_bvh* bvh, const mirres_env_t* env, const mirres_gbuf_t* g, const mirres_res_t* res, float* tile_data,
                          float* tile_pdf, float* tile_aux, uint32_t frame0, int K, const PtQueues* q, hipStream_t s);
 int launch_final_batch(mirres_ctx* ctx, mirres_bvh* bvh, const mirres_env_t* env, const float* occ, const float* pos, const float* normal, const float* ray_dir,
-                       const float* kd, const float* rm, const mirres_res_t* res, int K, const PtQueues* q, float* color, float* diff, float* spec, hipStream_t s);
+                       const float* kd, const float* rm, const mirres_res_t* res, int K, const PtQueues* q, float* color, float* diff, float* spec, float* tape, hipStream_t s);
 int trace_any_q(mirres_ctx* ctx, mirres_bvh* bvh, const Ray* rays, const uint32_t* count, size_t cap, int32_t* hit, hipStream_t s, int lane = 0);
 int trace_closest_q(mirres_ctx* ctx, mirres_bvh* bvh, const Ray* rays, const uint32_t* count, size_t cap, HitRec* out, hipStream_t s, int lane = 0);
 inline int grid_for(size_t n, int block) { size_t g = (n + block - 1) / block; return (int)(g < 1 ? 1 : g); }

@@ -454,7 +454,7 @@ __global__ void __launch_bounds__(MR_GEN_BLOCK) k_vis_gen(float vis_near, const 
 __global__ void __launch_bounds__(MR_BLOCK) k_final_direct(EnvD E, const float* __restrict__ occ, const float* __restrict__ normal, const float* __restrict__ ray_dir,
                                                            const float* __restrict__ kd, const float* __restrict__ rm, ResD R, const int32_t* __restrict__ slot,
                                                            const int32_t* __restrict__ hit, int N, int K, float* __restrict__ color, float* __restrict__ diff_light,
-                                                           float* __restrict__ spec_light) {
+                                                           float* __restrict__ spec_light, float4* __restrict__ tape) {
     const int pi = blockIdx.x * blockDim.x + threadIdx.x;
     if (pi >= N) return;
     const v3 n = ld3(normal, pi), rd = ld3(ray_dir, pi), diffuse = ld3(kd, pi);
@@ -465,6 +465,13 @@ __global__ void __launch_bounds__(MR_BLOCK) k_final_direct(EnvD E, const float* 
     for (int k = 0; k < K; k++) {
         const size_t sv = (size_t)k * N + pi;
         v3 c = V3(0.f), ldiff = V3(0.f), lspec = V3(0.f);
+        if (tape) {   // what the backward needs of this sample: the merged reservoir and its visibility (mirres_render_bwd)
+            const ResV rv = load_res(R, sv);
+            const int sl0 = slot[sv];
+            float4 a, b; a.x = rv.light_data.x; a.y = rv.light_data.y; a.z = rv.light_data.z; a.w = rv.light_pdf;
+            b.x = __int_as_float(rv.M); b.y = rv.weight; b.z = (sl0 >= 0 && hit[sl0]) ? 0.0f : 1.0f; b.w = 0.f;
+            tape[2 * sv] = a; tape[2 * sv + 1] = b;
+        }
         if (fg) {
             const int sl = slot[sv];
             const float vis = (sl >= 0 && hit[sl]) ? 0.0f : 1.0f;                       // k_vis_resolve
@@ -583,12 +590,12 @@ int launch_initial_batch(mirres_ctx* ctx, mirres_bvh* bvh, const mirres_env_t* e
     return 0;
 }
 int launch_final_batch(mirres_ctx* ctx, mirres_bvh* bvh, const mirres_env_t* env, const float* occ, const float* pos, const float* normal, const float* ray_dir,
-                       const float* kd, const float* rm, const mirres_res_t* res, int K, const PtQueues* q, float* color, float* diff, float* spec, hipStream_t s) {
+                       const float* kd, const float* rm, const mirres_res_t* res, int K, const PtQueues* q, float* color, float* diff, float* spec, float* tape, hipStream_t s) {
     const int N = (int)ctx->N, NV = K * N;
     MR_HIP(hipMemsetAsync(&q->counters[0], 0, sizeof(uint32_t), s));
     k_vis_gen<<<grid_for(NV, MR_GEN_BLOCK), MR_GEN_BLOCK, 0, s>>>(ctx->cfg.vis_near, pos, resd(res), N, NV, q->any_rays, &q->counters[0], q->slot_a);
     int rc = trace_any_q(ctx, bvh, q->any_rays, &q->counters[0], (size_t)NV, q->any_hit, s, q->lane); if (rc) return rc;
-    k_final_direct<<<grid_for(N, MR_BLOCK), MR_BLOCK, 0, s>>>(envh(env), occ, normal, ray_dir, kd, rm, resd(res), q->slot_a, q->any_hit, N, K, color, diff, spec);
+    k_final_direct<<<grid_for(N, MR_BLOCK), MR_BLOCK, 0, s>>>(envh(env), occ, normal, ray_dir, kd, rm, resd(res), q->slot_a, q->any_hit, N, K, color, diff, spec, reinterpret_cast<float4*>(tape));
     MR_LAUNCH_CHECK("final_batch");
     return 0;
 }

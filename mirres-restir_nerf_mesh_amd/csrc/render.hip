@@ -16,6 +16,9 @@ int launch_final_shading(const mirres_env_t* env, const float* occ, const float*
 int launch_new_dir(mirres_ctx* ctx, mirres_bvh* bvh, const mirres_path_t* p, uint32_t frameIndex, uint32_t bounce_count, hipStream_t s, const PtQueues* q);
 int launch_bounce(mirres_ctx* ctx, mirres_bvh* bvh, const mirres_env_t* env, const mirres_path_t* p, uint32_t frameIndex, uint32_t bounce_count, float* color,
                   float* dc, float* sc, float* acc_c, float* acc_d, float* acc_s, hipStream_t s, const PtQueues* q);
+int launch_direct_bwd(const float* tex, int Wc, int Hc, int N, int S, const float* occ, const float* normal, const float* ray_dir_raw, const float* kd, const float* rm,
+                      const float* tape, const float* g_color, const float* g_diff, const float* g_spec, float* g_normal, float* g_kd, float* g_rm, float* g_env,
+                      hipStream_t s);
 int launch_bilateral5(int fx, int fy, float sigma, const float* const col[5], const float* nrm, const float* zdz, float* scratch, float* const out[5], hipStream_t s);
 int launch_matnet_scatter(const mirres_matnet_t* m, const float* occ, const float* pos, int n, float* kd, float* rm, int use_scale, const float* scale3,
                           const float* const_kd, const float* const_rm, hipStream_t s);
@@ -344,7 +347,8 @@ int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args
         if (b > 0) {
             if (two_streams) MR_HIP(hipStreamWaitEvent(sp, ev_chain(b - 1), 0));
             PtQueues Q = PB.q; Q.NV = batch_k(b - 1) * N;
-            rc = launch_final_batch(ctx, bvh, &E, occ, a->pos, a->normal, B.ray_dir, a->kd, a->rough_metal, &PB.rspat[(b - 1) & 1], batch_k(b - 1), &Q, B.tot[0], B.tot[1], B.tot[2], sp);
+            rc = launch_final_batch(ctx, bvh, &E, occ, a->pos, a->normal, B.ray_dir, a->kd, a->rough_metal, &PB.rspat[(b - 1) & 1], batch_k(b - 1), &Q, B.tot[0], B.tot[1], B.tot[2],
+                                    a->tape ? a->tape + 8 * (size_t)N * (size_t)((b - 1) * PB.K) : nullptr, sp);
             if (rc) return rc;
         }
         if (b + 1 < nbatch) { rc = initial(b + 1); if (rc) return rc; }
@@ -396,7 +400,8 @@ int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args
     {   // F(last)
         if (two_streams) MR_HIP(hipStreamWaitEvent(sp, ev_chain(nbatch - 1), 0));
         PtQueues Q = PB.q; Q.NV = batch_k(nbatch - 1) * N;
-        rc = launch_final_batch(ctx, bvh, &E, occ, a->pos, a->normal, B.ray_dir, a->kd, a->rough_metal, &PB.rspat[(nbatch - 1) & 1], batch_k(nbatch - 1), &Q, B.tot[0], B.tot[1], B.tot[2], sp);
+        rc = launch_final_batch(ctx, bvh, &E, occ, a->pos, a->normal, B.ray_dir, a->kd, a->rough_metal, &PB.rspat[(nbatch - 1) & 1], batch_k(nbatch - 1), &Q, B.tot[0], B.tot[1], B.tot[2],
+                                a->tape ? a->tape + 8 * (size_t)N * (size_t)((nbatch - 1) * PB.K) : nullptr, sp);
         if (rc) return rc;
     }
     if (two_streams) { MR_HIP(hipEventRecord(ctx->ev_join, sp)); MR_HIP(hipStreamWaitEvent(s, ctx->ev_join, 0)); }
@@ -411,6 +416,18 @@ int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args
         return MIRRES_OK;
     }
     return finish(ctx, a, B.tot, B, s);
+}
+
+int mirres_render_bwd(mirres_ctx_t* ctx, const mirres_render_args_t* a, int samples, const float* g_color, const float* g_diff, const float* g_spec,
+                      float* g_normal, float* g_kd, float* g_rough_metal, float* g_env, void* stream) {
+    if (!ctx || !a || !a->tape || samples <= 0 || !g_color || !g_diff || !g_spec || !a->env_map || !a->occ || !a->normal || !a->kd || !a->rough_metal || !a->ray_dir) {
+        set_error("mirres_render_bwd: bad argument (the forward call must have recorded a tape)"); return MIRRES_E_ARG;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    FrameBufs B; int rc = carve(ctx, a->Wc, a->Hc, B); if (rc) return rc;
+    k_flip_env<<<grid_for((size_t)a->Wc * a->Hc, MR_BLOCK), MR_BLOCK, 0, s>>>(a->Wc, a->Hc, a->env_map, B.tex);   // the map the forward sampled
+    return launch_direct_bwd(B.tex, a->Wc, a->Hc, (int)ctx->N, samples, a->occ, a->normal, a->ray_dir, a->kd, a->rough_metal, a->tape, g_color, g_diff, g_spec,
+                             g_normal, g_kd, g_rough_metal, g_env, s);
 }
 
 int mirres_render_finish(mirres_ctx_t* ctx, const mirres_render_args_t* a, float* sums[6], void* stream) {

@@ -261,7 +261,7 @@ def _needs_grad(*ts):
 
 def render_fused(ctx, bvh_restir_worker, mlp_mat, use_scale, scale, env_map, occ_map, normal_map, depth_map, diffuse_map, roughness_specular, ray_dir_map, pos_map,
                  spp, denoise_iter, stepWidth, c_phi, n_phi, p_phi, random_offset, spp_range=None, const_kd=(0.6, 0.6, 0.6), const_rm=(0.5, 0.0),
-                 strip=None, halo=None, gb_depth=None):
+                 strip=None, halo=None, gb_depth=None, tape=None):
     """One C call for the whole frame (mirres_render). Returns the 6 output buffers [N,3] (raw sums when spp_range or strip is given).
     strip = (full_fy, y_off, own_y0, own_y1): `ctx` and all per-pixel inputs describe a rank's LOCAL frame (own rows + halo rows, dist.py);
     halo = a _lib.HALO_FN called once per sample to exchange the halo rows of the packed reservoirs."""
@@ -274,7 +274,7 @@ def render_fused(ctx, bvh_restir_worker, mlp_mat, use_scale, scale, env_map, occ
     a.env_map, a.Hc, a.Wc = env.data_ptr(), env.shape[0], env.shape[1]
     if not occ_map.is_contiguous():
         raise _lib.MirresError("occ_map is modified in place and must be contiguous")
-    a.occ = occ_map.data_ptr()
+    a.occ = occ_map.data_ptr(); keep.append(occ_map)     # thresholded in place; mirres_render_bwd / mirres_render_finish read it again
     for name, t in (("normal", normal_map), ("depth", depth_map), ("kd", diffuse_map), ("rough_metal", roughness_specular), ("ray_dir", ray_dir_map), ("pos", pos_map)):
         t = _f32(t.detach()); keep.append(t); setattr(a, name, t.data_ptr())
     if mlp_mat is not None:
@@ -287,6 +287,8 @@ def render_fused(ctx, bvh_restir_worker, mlp_mat, use_scale, scale, env_map, occ
     outs = [torch.empty((N, 3), dtype=torch.float32, device=env.device) for _ in range(6)]
     for k in range(6):
         a.outs[k] = outs[k].data_ptr()
+    if tape is not None:          # per-sample record for mirres_render_bwd (training)
+        keep.append(tape); a.tape = tape.data_ptr()
     if gb_depth is not None:      # bilateral denoiser instead of EAW (--use_bi_de)
         gd = _f32(gb_depth.detach()); keep.append(gd); a.gb_depth = gd.data_ptr()
     if spp_range is not None:
@@ -298,6 +300,44 @@ def render_fused(ctx, bvh_restir_worker, mlp_mat, use_scale, scale, env_map, occ
             a.halo = C.cast(halo, C.c_void_p)
     check(lib().mirres_render(ctx.h, bvh_restir_worker.h, C.byref(a), stream_ptr()), "mirres_render")
     return outs, a, keep
+
+
+class _FusedLoop(torch.autograd.Function):
+    """The spp loop of restir_di_with_pt as ONE forward call (mirres_render, batched + two streams) that records a per-sample tape, and ONE backward
+    call (mirres_render_bwd) for what the reference differentiates on this path: EvaluateFinalSamples_di + FinalShading of every sample
+    (Resampling.py:116-214) — gradients w.r.t. env_map, normal, kd, (roughness, metallic). The indirect sums carry no gradient
+    (process_path_tracing_divided_no_grad). Returns the six raw sums of the loop."""
+    @staticmethod
+    def forward(ctx, env_map, normal_map, diffuse_map, roughness_specular, rctx, worker, mlp_mat, use_scale, scale, occ_map, depth_map, ray_dir_map, pos_map, spp,
+                random_offset):
+        N = rctx.N
+        tape = torch.empty((int(spp) * N, 8), dtype=torch.float32, device=env_map.device)
+        sums, a, keep = render_fused(rctx, worker, mlp_mat, use_scale, scale, env_map, occ_map, normal_map, depth_map, diffuse_map, roughness_specular, ray_dir_map,
+                                     pos_map, spp, 0, 1, 1.0, 1.0, 1.0, random_offset, spp_range=(0, int(spp)), tape=tape)
+        ctx.a, ctx.keep, ctx.rctx, ctx.spp, ctx.env_shape = a, keep, rctx, int(spp), tuple(env_map.shape)
+        ctx.mark_non_differentiable(sums[3], sums[4], sums[5])
+        return tuple(sums)
+
+    @staticmethod
+    def backward(ctx, g_color, g_diff, g_spec, *unused):
+        N = ctx.rctx.N
+        dev = g_color.device
+        z3 = lambda g: _f32(g) if g is not None else torch.zeros((N, 3), dtype=torch.float32, device=dev)
+        gc, gd, gs = z3(g_color), z3(g_diff), z3(g_spec)
+        need_env, need_n, need_kd, need_rm = ctx.needs_input_grad[0:4]
+        g_env = torch.zeros(ctx.env_shape, dtype=torch.float32, device=dev) if need_env else None
+        g_n = torch.empty((N, 3), dtype=torch.float32, device=dev) if need_n else None
+        g_kd = torch.empty((N, 3), dtype=torch.float32, device=dev) if need_kd else None
+        g_rm = torch.empty((N, 2), dtype=torch.float32, device=dev) if need_rm else None
+        p = lambda t: t.data_ptr() if t is not None else None
+        check(lib().mirres_render_bwd(ctx.rctx.h, C.byref(ctx.a), ctx.spp, gc.data_ptr(), gd.data_ptr(), gs.data_ptr(), p(g_n), p(g_kd), p(g_rm), p(g_env), stream_ptr()),
+              "mirres_render_bwd")
+        return (g_env, g_n, g_kd, g_rm) + (None,) * 11
+
+
+def _fused_training():
+    import os
+    return os.environ.get("MIRRES_TRAIN_FUSED", "1") != "0"
 
 
 def run_restir_di_with_pt(use_scale, scale_x, scale_y, scale_z, mlp_mat, gb_depth, bvh_restir_worker, make_sampleable_m, generateLightTiles_m, InitialResampling_m,
@@ -316,13 +356,21 @@ def run_restir_di_with_pt(use_scale, scale_x, scale_y, scale_z, mlp_mat, gb_dept
                                   p_phi_scale, random_offset, gb_depth=gb_depth)
         return tuple(outs)
 
-    indices = torch.where(occ_map <= 0.5)
-    occ_map[indices[0], :] = 0
-    ray_dir_map = safe_l2_normalize(ray_dir_map, dim=-1).contiguous()
-    motionVectors = None  # all-zero in the reference (:487)
-    color = None
     diffuse, normal, roughnessSpecular = diffuse_map, normal_map, roughness_specular
-    (total_color, total_color_1, total_diff_light, total_spec_light, total_diff_light_1, total_spec_light_1, total_indirect_light, mFrameIndex) = restir_di_with_pt(
+    if _fused_training() and (mlp_mat is None or isinstance(mlp_mat, MLPTexture3D)) and occ_map.is_contiguous():
+        # training: the same loop as ONE batched forward + ONE backward call (MIRRES_TRAIN_FUSED=0 selects the reference-shaped sample-by-sample loop below)
+        random_offset = np.random.randint(2**20) if _FIXED_RANDOM_OFFSET is None else int(_FIXED_RANDOM_OFFSET)
+        (total_color, total_diff_light, total_spec_light, total_color_1, total_diff_light_1, total_spec_light_1) = _FusedLoop.apply(
+            env_map, normal_map, diffuse_map, roughness_specular, InitialResampling_m.ctx, bvh_restir_worker, mlp_mat, use_scale, (scale_x, scale_y, scale_z), occ_map,
+            depth_map, ray_dir_map, pos_map, spp, random_offset)
+        mFrameIndex = spp
+    else:
+      indices = torch.where(occ_map <= 0.5)
+      occ_map[indices[0], :] = 0
+      ray_dir_map = safe_l2_normalize(ray_dir_map, dim=-1).contiguous()
+      motionVectors = None  # all-zero in the reference (:487)
+      color = None
+      (total_color, total_color_1, total_diff_light, total_spec_light, total_diff_light_1, total_spec_light_1, total_indirect_light, mFrameIndex) = restir_di_with_pt(
         use_scale, scale_x, scale_y, scale_z, mlp_mat, bvh_restir_worker, spp, framedim_x, framedim_y, make_sampleable_m, generateLightTiles_m, InitialResampling_m,
         TemporalResampling_m, SpatialResampling_m, EvaluateFinalSamples_m, FinalShading_m, light_data, light_uv, light_inv_pdf, reservoirs, prev_reservoirs,
         final_samples, neighborOffsets, light_tile_count, light_tile_size, env_map, occ_map, pos_map, normal, depth_map, diffuse, roughnessSpecular, ray_dir_map,

@@ -42,10 +42,11 @@ def test_one_spp_frame_matches_oracle(oracle, scene_mod):
     assert np.array_equal(got[0][F.occ < 0.5], np.ones_like(got[0][F.occ < 0.5]))    # background := 1 (:546-547)
 
 
-def test_fused_equals_stepwise(oracle, scene_mod):
+def test_fused_equals_stepwise(oracle, scene_mod, monkeypatch):
     """The one-call fused loop and the reference-shaped Python loop run the same kernels; the only difference is that the stepwise path
     prepares ray_dir / brdf_map with torch ops (F.normalize rounds differently from the fused prep kernel by an ulp), so results agree to
     fp32 rounding on >= 99 % of the values (an ulp can still flip a discrete choice in a rare pixel)."""
+    monkeypatch.setenv("MIRRES_TRAIN_FUSED", "0")     # the autograd path below must be the reference-shaped sample-by-sample loop
     F, W, mods, RR, torch = _setup(oracle, scene_mod)
     from mirres_restir_nerf_mesh_amd.render_helper import MLPTexture3D
     mn, mx = scene_mod.material_min_max()
@@ -257,3 +258,34 @@ def test_two_rank_strip_render_equals_single_gpu(tmp_path):
     for k in range(6):
         assert torch.equal(r0["outs"][k], r0["ref"][k]), "rank 0 buffer %d" % k
         assert torch.equal(r1["outs"][k], r0["ref"][k]), "rank 1 buffer %d" % k
+
+
+def test_fused_training_gradients_match_the_stepwise_loop(oracle, scene_mod, monkeypatch):
+    """Training path: the batched forward + single backward call (_FusedLoop: mirres_render with a tape, mirres_render_bwd) against the
+    reference-shaped loop of per-sample autograd Functions (FinalShading / EvaluateFinalSamples_di), same random offset. The forward agrees
+    like test_fused_equals_stepwise; gradients w.r.t. env map, normal, kd and (roughness, metallic) agree to fp32 summation order (atomics
+    into the env texels) up to the rare pixel whose discrete choice flips on the F.normalize ulp."""
+    F, W, mods, RR, torch = _setup(oracle, scene_mod)
+    from mirres_restir_nerf_mesh_amd.render_helper import MLPTexture3D
+    mn, mx = scene_mod.material_min_max()
+    mlp = MLPTexture3D(torch.tensor([-1, -1, -1, 1, 1, 1], dtype=torch.float32), channels=6, min_max=(torch.from_numpy(mn).cuda(), torch.from_numpy(mx).cuda()), seed=3)
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    N = F.N; z = lambda *s: torch.zeros(s, device="cuda")
+    wgt = torch.rand((N, 3), generator=torch.Generator().manual_seed(1)).cuda()
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("MIRRES_TRAIN_FUSED", mode)
+        RR.set_random_offset(4242)
+        env = cu(F.env).requires_grad_(True); nrm = cu(F.normal).requires_grad_(True); kd = cu(F.kd).requires_grad_(True); rm = cu(F.rm).requires_grad_(True)
+        out = RR.run_restir_di_with_pt(False, 1.0, 1.0, 1.0, mlp, None, W, *mods[:8], *mods[8:17], env, cu(F.occ[:, None].copy()), nrm, cu(F.depth[:, None]), kd, rm,
+                                       cu(F.ray_dir_raw), cu(F.pos), z(N, 1), z(N, 4), z(N, 3), z(N, 3), F.fx, F.fy, 3, 2, 2, 2.0, 0.1, 0.001)
+        loss = (out[0] * wgt).sum() + 0.5 * (out[1] * wgt).sum() + 0.25 * out[2].sum()
+        loss.backward()
+        res[mode] = dict(out=[o.detach().cpu().numpy() for o in out], g=[t.grad.cpu().numpy() for t in (env, nrm, kd, rm)])
+    for a, b in zip(res["0"]["out"], res["1"]["out"]):
+        assert np.isclose(a, b, rtol=1e-4, atol=1e-6).mean() >= 0.99
+    for name, a, b in zip(("env", "normal", "kd", "rm"), res["0"]["g"], res["1"]["g"]):
+        assert np.isfinite(b).all() and np.abs(b).sum() > 0, name
+        cos = float((a * b).sum() / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
+        rel = float(np.linalg.norm(a - b) / (np.linalg.norm(a) + 1e-30))
+        assert cos > 0.999 and rel < 0.05, "%s: cos %.6f rel %.4f" % (name, cos, rel)
