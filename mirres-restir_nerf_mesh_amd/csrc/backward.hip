@@ -246,20 +246,37 @@ MR_DEV uint32_t grid_index_b(uint32_t size, uint32_t res, uint32_t px, uint32_t 
 
 struct MatNetB { const __half2* grid; const float *w0, *w1, *w2; float aabb_min[3], aabb_max[3], mn[6], mx[6]; };
 
+// Weight gradients are outer-product sums over the points (gW1[o][k] = sum_p gh2_p[o] * h1_p[k], ...). The first version added every
+// product to LDS with an atomic — 2 240 LDS atomics per point onto 2 240 addresses shared by the whole workgroup, 15 of the kernel's 17.6 ms.
+// Now each wave stages its 64 points' two factor vectors in LDS and every lane accumulates a fixed set of matrix entries in registers over
+// all the tiles its wave processes (lane l owns entries l, l + 64, ...: the k index is l % 32 for all of them, so one factor is read once per
+// point); one LDS reduction over the four waves and one global atomic per entry per workgroup at the end.
+#define MR_BW_WAVES (MR_BLOCK / 64)
+#define MR_BW_LD 33     // padded row of the staged [64][32] factors
 __global__ void __launch_bounds__(MR_BLOCK) k_matnet_bwd(MatNetB M, GridLevelsB L, const float* __restrict__ pos, int n, const float* __restrict__ gout,
                                                          float* __restrict__ g_params, float* __restrict__ g_w0, float* __restrict__ g_w1, float* __restrict__ g_w2) {
     __shared__ float sw0[1024], sw1[1024], sw2[192];
-    __shared__ float gw0[1024], gw1[1024], gw2[192];
-    for (int i = threadIdx.x; i < 1024; i += blockDim.x) { sw0[i] = M.w0[i]; sw1[i] = M.w1[i]; gw0[i] = 0.f; gw1[i] = 0.f; }
-    for (int i = threadIdx.x; i < 192; i += blockDim.x) { sw2[i] = M.w2[i]; gw2[i] = 0.f; }
+    __shared__ float sU[MR_BW_WAVES][64 * MR_BW_LD], sV[MR_BW_WAVES][64 * MR_BW_LD];
+    for (int i = threadIdx.x; i < 1024; i += blockDim.x) { sw0[i] = M.w0[i]; sw1[i] = M.w1[i]; }
+    for (int i = threadIdx.x; i < 192; i += blockDim.x) sw2[i] = M.w2[i];
     __syncthreads();
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) {
-        float x[3];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* const U = sU[wave]; float* const V = sV[wave];
+    float acc0[16], acc1[16], acc2[3];
 #pragma unroll
-        for (int d = 0; d < 3; d++) x[d] = fminf(fmaxf((pos[3 * (size_t)i + d] - M.aabb_min[d]) / (M.aabb_max[d] - M.aabb_min[d]), 0.f), 1.f);
+    for (int j = 0; j < 16; j++) { acc0[j] = 0.f; acc1[j] = 0.f; }
+    acc2[0] = acc2[1] = acc2[2] = 0.f;
+    const int tiles = (n + 63) / 64;
+    for (int tile = blockIdx.x * MR_BW_WAVES + wave; tile < tiles; tile += gridDim.x * MR_BW_WAVES) {
+        const int i = tile * 64 + lane;
+        const bool live = i < n;
+        float a0[32], h1[32], h2[32], gz2[6], gh2[32], gh1[32], ga0[32];
+        float x[3] = {0.f, 0.f, 0.f};
+        if (live) {
+#pragma unroll
+            for (int d = 0; d < 3; d++) x[d] = fminf(fmaxf((pos[3 * (size_t)i + d] - M.aabb_min[d]) / (M.aabb_max[d] - M.aabb_min[d]), 0.f), 1.f);
+        }
         // forward recompute
-        float a0[32];
         for (int lv = 0; lv < MR_LEVELS; lv++) {
             const float scale = L.scale[lv]; const uint32_t res = L.res[lv], size = L.size[lv];
             const __half2* g = M.grid + L.offset[lv];
@@ -277,22 +294,51 @@ __global__ void __launch_bounds__(MR_BLOCK) k_matnet_bwd(MatNetB M, GridLevelsB 
             }
             a0[2 * lv] = __half2float(r0); a0[2 * lv + 1] = __half2float(r1);
         }
-        float h1[32], h2[32], z2[6];
+        float z2[6];
         for (int o = 0; o < 32; o++) { float acc = 0.f; for (int k = 0; k < 32; k++) acc = fmaf(a0[k], sw0[o * 32 + k], acc); h1[o] = fmaxf(acc, 0.f); }
         for (int o = 0; o < 32; o++) { float acc = 0.f; for (int k = 0; k < 32; k++) acc = fmaf(h1[k], sw1[o * 32 + k], acc); h2[o] = fmaxf(acc, 0.f); }
         for (int o = 0; o < 6; o++) { float acc = 0.f; for (int k = 0; k < 32; k++) acc = fmaf(h2[k], sw2[o * 32 + k], acc); z2[o] = acc; }
-        // backward
-        float gz2[6];
-        for (int o = 0; o < 6; o++) { float s = 1.0f / (1.0f + expf(-z2[o])); gz2[o] = gout[6 * (size_t)i + o] * (M.mx[o] - M.mn[o]) * s * (1.f - s); }
-        float gh2[32];
-        for (int k = 0; k < 32; k++) { float acc = 0.f; for (int o = 0; o < 6; o++) { acc += gz2[o] * sw2[o * 32 + k]; atomicAdd(&gw2[o * 32 + k], gz2[o] * h2[k]); } gh2[k] = h2[k] > 0.f ? acc : 0.f; }
-        float gh1[32];
+        // backward through the MLP (a dead lane carries zeros)
+        for (int o = 0; o < 6; o++) { float sg = 1.0f / (1.0f + expf(-z2[o])); gz2[o] = live ? gout[6 * (size_t)i + o] * (M.mx[o] - M.mn[o]) * sg * (1.f - sg) : 0.f; }
+        for (int k = 0; k < 32; k++) { float acc = 0.f; for (int o = 0; o < 6; o++) acc += gz2[o] * sw2[o * 32 + k]; gh2[k] = h2[k] > 0.f ? acc : 0.f; }
         for (int k = 0; k < 32; k++) { float acc = 0.f; for (int o = 0; o < 32; o++) acc += gh2[o] * sw1[o * 32 + k]; gh1[k] = h1[k] > 0.f ? acc : 0.f; }
-        for (int o = 0; o < 32; o++) if (gh2[o] != 0.f) for (int k = 0; k < 32; k++) atomicAdd(&gw1[o * 32 + k], gh2[o] * h1[k]);
-        float ga0[32];
         for (int k = 0; k < 32; k++) { float acc = 0.f; for (int o = 0; o < 32; o++) acc += gh1[o] * sw0[o * 32 + k]; ga0[k] = acc; }
-        for (int o = 0; o < 32; o++) if (gh1[o] != 0.f) for (int k = 0; k < 32; k++) atomicAdd(&gw0[o * 32 + k], gh1[o] * a0[k]);
-        if (g_params) {
+        // weight gradients: three staged outer-product sums over the wave's 64 points (wave-synchronous: a wave owns its U / V)
+        {   // gW2[o][k] += gz2[o] * h2[k]   (6 x 32 = 192 entries: lane owns e = lane + 64 j, j < 3)
+            for (int o = 0; o < 6; o++) U[lane * MR_BW_LD + o] = gz2[o];
+            for (int k = 0; k < 32; k++) V[lane * MR_BW_LD + k] = h2[k];
+            __builtin_amdgcn_wave_barrier();
+            for (int p = 0; p < 64; p++) {
+                const float vk = V[p * MR_BW_LD + (lane & 31)];
+#pragma unroll
+                for (int j = 0; j < 3; j++) acc2[j] = fmaf(U[p * MR_BW_LD + (lane >> 5) + 2 * j], vk, acc2[j]);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        {   // gW1[o][k] += gh2[o] * h1[k]
+            for (int o = 0; o < 32; o++) U[lane * MR_BW_LD + o] = gh2[o];
+            for (int k = 0; k < 32; k++) V[lane * MR_BW_LD + k] = h1[k];
+            __builtin_amdgcn_wave_barrier();
+            for (int p = 0; p < 64; p++) {
+                const float vk = V[p * MR_BW_LD + (lane & 31)];
+#pragma unroll
+                for (int j = 0; j < 16; j++) acc1[j] = fmaf(U[p * MR_BW_LD + (lane >> 5) + 2 * j], vk, acc1[j]);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        {   // gW0[o][k] += gh1[o] * a0[k]
+            for (int o = 0; o < 32; o++) U[lane * MR_BW_LD + o] = gh1[o];
+            for (int k = 0; k < 32; k++) V[lane * MR_BW_LD + k] = a0[k];
+            __builtin_amdgcn_wave_barrier();
+            for (int p = 0; p < 64; p++) {
+                const float vk = V[p * MR_BW_LD + (lane & 31)];
+#pragma unroll
+                for (int j = 0; j < 16; j++) acc0[j] = fmaf(U[p * MR_BW_LD + (lane >> 5) + 2 * j], vk, acc0[j]);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        // hash-grid gradient: fp32 atomics into the master-precision gradient table (tcnn accumulates its grid gradient the same way)
+        if (g_params && live) {
             for (int lv = 0; lv < MR_LEVELS; lv++) {
                 const float scale = L.scale[lv]; const uint32_t res = L.res[lv], size = L.size[lv];
                 float p[3]; uint32_t pg[3];
@@ -311,9 +357,18 @@ __global__ void __launch_bounds__(MR_BLOCK) k_matnet_bwd(MatNetB M, GridLevelsB 
             }
         }
     }
+    // reduce the four waves' register accumulators through LDS (entry e = lane + 64 j  <->  [o = e / 32][k = e % 32]), one global atomic per entry
     __syncthreads();
-    for (int k = threadIdx.x; k < 1024; k += blockDim.x) { if (g_w0 && gw0[k] != 0.f) atomicAdd(&g_w0[k], gw0[k]); if (g_w1 && gw1[k] != 0.f) atomicAdd(&g_w1[k], gw1[k]); }
-    for (int k = threadIdx.x; k < 192; k += blockDim.x) if (g_w2 && gw2[k] != 0.f) atomicAdd(&g_w2[k], gw2[k]);
+    float* red = &sU[0][0];            // 2 240 floats needed, 4 * 64 * 33 available
+    for (int i = threadIdx.x; i < 2240; i += blockDim.x) red[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; j++) { atomicAdd(&red[lane + 64 * j], acc0[j]); atomicAdd(&red[1024 + lane + 64 * j], acc1[j]); }
+#pragma unroll
+    for (int j = 0; j < 3; j++) atomicAdd(&red[2048 + lane + 64 * j], acc2[j]);
+    __syncthreads();
+    for (int k = threadIdx.x; k < 1024; k += blockDim.x) { if (g_w0 && red[k] != 0.f) atomicAdd(&g_w0[k], red[k]); if (g_w1 && red[1024 + k] != 0.f) atomicAdd(&g_w1[k], red[1024 + k]); }
+    for (int k = threadIdx.x; k < 192; k += blockDim.x) if (g_w2 && red[2048 + k] != 0.f) atomicAdd(&g_w2[k], red[2048 + k]);
 }
 
 }  // namespace mr
@@ -343,7 +398,8 @@ int mirres_matnet_bwd(const mirres_matnet_t* m, const float* pos, int n, const f
     MatNetB M; M.grid = reinterpret_cast<const __half2*>(m->grid_f16); M.w0 = m->w0; M.w1 = m->w1; M.w2 = m->w2;
     for (int i = 0; i < 3; i++) { M.aabb_min[i] = m->aabb_min[i]; M.aabb_max[i] = m->aabb_max[i]; }
     for (int i = 0; i < 6; i++) { M.mn[i] = m->out_min[i]; M.mx[i] = m->out_max[i]; }
-    k_matnet_bwd<<<grid_for(n, MR_BLOCK), MR_BLOCK, 0, (hipStream_t)stream>>>(M, host_levels_b(), pos, n, grad_out, g_params_f32, g_w0, g_w1, g_w2);
+    int grd = grid_for(n, MR_BLOCK); if (grd > 256 * 4) grd = 256 * 4;      // workgroups loop over point tiles and keep the weight gradients in registers
+    k_matnet_bwd<<<grd, MR_BLOCK, 0, (hipStream_t)stream>>>(M, host_levels_b(), pos, n, grad_out, g_params_f32, g_w0, g_w1, g_w2);
     MR_LAUNCH_CHECK("matnet_bwd");
     return MIRRES_OK;
 }
