@@ -45,27 +45,33 @@ MR_DEV GPix load_gpix(const GBufD& G, size_t i) {   // normal+depth, ray_dir, oc
     return p;
 }
 MR_DEV v3 load_gpos(const GBufD& G, size_t i) { if (G.rec) { const float4 d = G.rec[4 * i + 3]; return V3(d.x, d.y, d.z); } return ld3(G.pos, i); }
-struct ResV { v3 light_data; float light_pdf; int M; float weight; };
-struct Ris { v3 light_data; float inv_pdf, weightSum, M, weight, canonicalWeight; };
+// vcode (packed records only): what is already known about the visibility of the stored light sample FROM THIS PIXEL — 0 unknown, 1 visible,
+// 2 occluded. The shadow ray that the final-visibility stage would trace for a sample is bit-identical (same origin, direction, offset) to one
+// an earlier stage traced for it — the initial candidate's ray, or the spatial pass's "canonical pixel towards the neighbour's light" ray —
+// so that stage's answer is carried along with the sample (through the temporal merge only when history comes from the same pixel) and the
+// final stage traces only what is still unknown: one shadow ray in five disappears, results unchanged by construction.
+struct ResV { v3 light_data; float light_pdf; int M; float weight; int vcode; };
+struct Ris { v3 light_data; float inv_pdf, weightSum, M, weight, canonicalWeight; int vcode; };
 
-MR_DEV Ris empty_ris() { Ris s; s.light_data = V3(0.f); s.inv_pdf = 0.f; s.weightSum = 0.f; s.M = 0.f; s.weight = 0.f; s.canonicalWeight = 0.f; return s; }
+MR_DEV Ris empty_ris() { Ris s; s.light_data = V3(0.f); s.inv_pdf = 0.f; s.weightSum = 0.f; s.M = 0.f; s.weight = 0.f; s.canonicalWeight = 0.f; s.vcode = 0; return s; }
 MR_DEV ResV load_res(const ResD& R, size_t i) {
     ResV r;
-    if (R.rec) { const float4 a = R.rec[2 * i], b = R.rec[2 * i + 1]; r.light_data = V3(a.x, a.y, a.z); r.light_pdf = a.w; r.M = __float_as_int(b.x); r.weight = b.y; }
-    else { r.light_data = ld3(R.light_data, i); r.light_pdf = R.light_pdf[i]; r.M = R.M[i]; r.weight = R.weight[i]; }
+    if (R.rec) { const float4 a = R.rec[2 * i], b = R.rec[2 * i + 1]; r.light_data = V3(a.x, a.y, a.z); r.light_pdf = a.w; r.M = __float_as_int(b.x); r.weight = b.y; r.vcode = __float_as_int(b.z); }
+    else { r.light_data = ld3(R.light_data, i); r.light_pdf = R.light_pdf[i]; r.M = R.M[i]; r.weight = R.weight[i]; r.vcode = 0; }
     return r;
 }
-MR_DEV void store_res(const ResD& R, size_t i, v3 ld, float ipdf, int M, float w) {
-    if (R.rec) { float4 a, b; a.x = ld.x; a.y = ld.y; a.z = ld.z; a.w = ipdf; b.x = __int_as_float(M); b.y = w; b.z = 0.f; b.w = 0.f; R.rec[2 * i] = a; R.rec[2 * i + 1] = b; }
+MR_DEV void store_res(const ResD& R, size_t i, v3 ld, float ipdf, int M, float w, int vcode = 0) {
+    if (R.rec) { float4 a, b; a.x = ld.x; a.y = ld.y; a.z = ld.z; a.w = ipdf; b.x = __int_as_float(M); b.y = w; b.z = __int_as_float(vcode); b.w = 0.f; R.rec[2 * i] = a; R.rec[2 * i + 1] = b; }
     else { st3(R.light_data, i, ld); R.light_pdf[i] = ipdf; R.M[i] = M; R.weight[i] = w; }
 }
 MR_DEV v3 res_light(const ResD& R, size_t i) { if (R.rec) { const float4 a = R.rec[2 * i]; return V3(a.x, a.y, a.z); } return ld3(R.light_data, i); }
 MR_DEV int res_M(const ResD& R, size_t i) { return R.rec ? __float_as_int(R.rec[2 * i + 1].x) : R.M[i]; }
 MR_DEV float res_weight(const ResD& R, size_t i) { return R.rec ? R.rec[2 * i + 1].y : R.weight[i]; }
+MR_DEV int res_vcode(const ResD& R, size_t i) { return R.rec ? __float_as_int(R.rec[2 * i + 1].z) : 0; }
 MR_DEV void store_zero(const ResD& R, size_t i) { store_res(R, i, V3(0.f), 0.f, 0, 0.f); }
 MR_DEV void store_ris(const ResD& R, size_t i, const Ris& s) {
     if (isinf(s.weight) || isnan(s.weight)) { store_zero(R, i); return; }
-    store_res(R, i, s.light_data, s.inv_pdf, (int)s.M, s.weight);
+    store_res(R, i, s.light_data, s.inv_pdf, (int)s.M, s.weight, s.vcode);
 }
 MR_DEV void put_ray(Ray* q, uint32_t slot, v3 pos, v3 dir, float vis_near) {
     v3 o = pos + vis_near * dir;  // origin offset along the RAY direction (VIS_near, e.g. InitialResampling.slang:264-265)
@@ -240,6 +246,7 @@ __global__ void __launch_bounds__(MR_BLOCK) k_initial_resolve(ResD R, int N, con
     if (pi >= N) return;
     int s = slot[pi];
     if (s >= 0 && hit[s]) store_res(R, pi, V3(0.f), 0.f, 1, 0.f);  // createEmpty, then M := 1
+    else if (s >= 0 && R.rec) R.rec[2 * (size_t)pi + 1].z = __int_as_float(1);   // the candidate's shadow ray came back free: visible from this pixel
 }
 
 // ---------------------------------------------------------------- temporal resampling (TemporalResampling.slang:23-135)
@@ -272,7 +279,7 @@ __global__ void __launch_bounds__(MR_BLOCK) k_temporal(mirres_config_t C, EnvD E
     {
         float w = targetPdf * cur.weight * cur.M;  // res.slang:116-134
         s.weightSum += w; s.M += cur.M;
-        if (rnd(sg) * s.weightSum < w) { s.light_data = cur.light_data; s.inv_pdf = cur.light_pdf; s.weight = targetPdf; }
+        if (rnd(sg) * s.weightSum < w) { s.light_data = cur.light_data; s.inv_pdf = cur.light_pdf; s.weight = targetPdf; s.vcode = cur.vcode; }
     }
     v3 pldir = oct_decode(V2(prev.light_data.y, prev.light_data.z));
     float preTarget = rtarget::target(ctx, env_radiance(E, pldir), pldir);
@@ -281,7 +288,7 @@ __global__ void __launch_bounds__(MR_BLOCK) k_temporal(mirres_config_t C, EnvD E
         float w = preTarget * prev.weight * prev.M;
         s.weightSum += w; s.M += prev.M;
         usedPrev = rnd(sg) * s.weightSum < w;
-        if (usedPrev) { s.light_data = prev.light_data; s.inv_pdf = prev.light_pdf; s.weight = preTarget; }
+        if (usedPrev) { s.light_data = prev.light_data; s.inv_pdf = prev.light_pdf; s.weight = preTarget; s.vcode = (qi == (size_t)pi) ? prev.vcode : 0; }
     }
     v3 sdir = oct_decode(V2(s.light_data.y, s.light_data.z));
     v3 sem = env_radiance(E, sdir);
@@ -424,12 +431,12 @@ __global__ void __launch_bounds__(MR_BLOCK) k_spatial_resolve(mirres_config_t C,
         // state.M (+= M_j * min(mFactor..)) is overwritten with M_canonical below (:302), so it is not tracked
         s.weightSum += w;
         s.canonicalWeight += m1;
-        if (rnd(sg) * s.weightSum < w) { s.light_data = nbr.light_data; s.inv_pdf = nbr.light_pdf; s.weight = candAtOther; }
+        if (rnd(sg) * s.weightSum < w) { s.light_data = nbr.light_data; s.inv_pdf = nbr.light_pdf; s.weight = candAtOther; s.vcode = canonicalVis > 0.f ? 1 : 2; }
     }
     {   // streamingResampleFinalizeMis (res.slang:215-232)
         float w = curTarget * cur.weight * s.canonicalWeight;
         s.weightSum += w;
-        if (rnd(sg) * s.weightSum < w) { s.light_data = cur.light_data; s.inv_pdf = cur.light_pdf; s.weight = curTarget; }
+        if (rnd(sg) * s.weightSum < w) { s.light_data = cur.light_data; s.inv_pdf = cur.light_pdf; s.weight = curTarget; s.vcode = cur.vcode; }
     }
     s.M = (float)cur.M;
     s.weight = s.weight > 0.f ? (s.weightSum / validNeighbors) / s.weight : 0.f;
@@ -443,7 +450,7 @@ __global__ void __launch_bounds__(MR_GEN_BLOCK) k_vis_gen(float vis_near, const 
     bool want = false; v3 rp = V3(0.f), rd = V3(0.f);
     if (sv < NV) {
         v3 ld = res_light(R, sv);
-        if (ld.x > 0.1f) { want = true; rp = ld3(pos, sv % N); rd = oct_decode(V2(ld.y, ld.z)); }
+        if (ld.x > 0.1f && res_vcode(R, sv) == 0) { want = true; rp = ld3(pos, sv % N); rd = oct_decode(V2(ld.y, ld.z)); }
     }
     uint32_t slot = block_append(q_count, want);
     if (want) put_ray(q, slot, rp, rd, vis_near);
@@ -469,12 +476,12 @@ __global__ void __launch_bounds__(MR_BLOCK) k_final_direct(EnvD E, const float* 
             const ResV rv = load_res(R, sv);
             const int sl0 = slot[sv];
             float4 a, b; a.x = rv.light_data.x; a.y = rv.light_data.y; a.z = rv.light_data.z; a.w = rv.light_pdf;
-            b.x = __int_as_float(rv.M); b.y = rv.weight; b.z = (sl0 >= 0 && hit[sl0]) ? 0.0f : 1.0f; b.w = 0.f;
+            b.x = __int_as_float(rv.M); b.y = rv.weight; b.z = rv.vcode ? (rv.vcode == 1 ? 1.0f : 0.0f) : ((sl0 >= 0 && hit[sl0]) ? 0.0f : 1.0f); b.w = 0.f;
             tape[2 * sv] = a; tape[2 * sv + 1] = b;
         }
         if (fg) {
-            const int sl = slot[sv];
-            const float vis = (sl >= 0 && hit[sl]) ? 0.0f : 1.0f;                       // k_vis_resolve
+            const int sl = slot[sv], vc = res_vcode(R, sv);
+            const float vis = vc ? (vc == 1 ? 1.0f : 0.0f) : ((sl >= 0 && hit[sl]) ? 0.0f : 1.0f);   // k_vis_resolve, or the earlier stage's answer for the same ray
             const v3 ld = res_light(R, sv);
             v3 dir = V3(0.f), Li = V3(0.f); float dist = 0.f;
             if (ld.x > 0.1f) {                                                           // k_eval_final

@@ -3,6 +3,7 @@
 // spp from Python; here one C call enqueues the spp loop on a stream, accumulations are fused into the producing kernels,
 // the material net scatters in place (no index tensors), and nothing synchronises with the host.
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include "engine.hpp"
 #include "device_math.hpp"
