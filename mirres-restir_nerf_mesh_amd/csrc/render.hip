@@ -91,7 +91,8 @@ __global__ void __launch_bounds__(MR_BLOCK) k_composite(int N, const float* __re
 
 // Adds a batch's indirect light to the frame totals in the order a sample-by-sample loop would: sample k ascending, bounce ascending
 // (renderer_restir.py:420-422, 450-452), so the sums are bit-identical to the unbatched loop. cb = [bounce][colour, diffuse, specular][NV * 3].
-__global__ void __launch_bounds__(MR_BLOCK) k_pt_reduce(int N, int K, int nb, const float* __restrict__ cb, float* __restrict__ t3, float* __restrict__ t4, float* __restrict__ t5) {
+__global__ void __launch_bounds__(MR_BLOCK) k_pt_reduce(int N, int K, int nb, const float* __restrict__ cb, const uint32_t* __restrict__ maskb, float* __restrict__ t3,
+                                                        float* __restrict__ t4, float* __restrict__ t5) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t n3 = 3 * (size_t)N;
     if (i >= n3) return;
@@ -99,6 +100,9 @@ __global__ void __launch_bounds__(MR_BLOCK) k_pt_reduce(int N, int K, int nb, co
     float a = t3[i], b = t4[i], c = t5[i];
     for (int k = 0; k < K; k++)
         for (int bo = 0; bo < nb; bo++) {
+            // colours exist only where the bounce had something to add (mask bits 0/1: NEE / BSDF contributions, bit 4: environment pick-up);
+            // elsewhere the slot's contribution is zero and x + 0 == x
+            if (!(maskb[(size_t)bo * (nv3 / 3) + (size_t)k * N + i / 3] & 19u)) continue;
             const float* base = cb + (size_t)bo * 3 * nv3 + (size_t)k * n3 + i;
             a += base[0]; b += base[nv3]; c += base[2 * nv3];
         }
@@ -166,6 +170,7 @@ struct PtBatch {
     int K; PtQueues q;
     float *prd, *pos[2], *rd[2], *occ[2], *n[2], *kd, *rm;
     float* cb;      // [max_bounce][3][K * N * 3] per-bounce colour / diffuse / specular of every slot
+    uint32_t* maskb; // [max_bounce][K * N] per-bounce ray/colour masks (k_bounce_gen)
     // history-free ReSTIR stages: two sets (batch parity) of K initial / temporal reservoirs and K spatial-output reservoirs, light tiles of K samples
     mirres_res_t rinit[2], rspat[2];
     float *tile_data, *tile_pdf, *tile_aux;
@@ -186,7 +191,7 @@ static int carve_batch(mirres_ctx* ctx, int N, int K, int max_bounce, size_t TS,
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const int nb = max_bounce > 0 ? max_bounce : 1;
     size_t need = al(sizeof(Ray) * 2 * NV) + al(4 * 2 * NV) + al(sizeof(Ray) * NV) + al(sizeof(HitRec) * NV) + al(64) + 3 * al(4 * NV) + al(4 * 18 * NV)
-                + al(4 * 5 * NV) + 2 * (3 * al(4 * 3 * NV) + al(4 * NV)) + al(4 * 3 * NV) + al(4 * 2 * NV) + al(4 * 9 * NV * (size_t)nb)
+                + al(4 * 5 * NV) + 2 * (3 * al(4 * 3 * NV) + al(4 * NV)) + al(4 * 3 * NV) + al(4 * 2 * NV) + al(4 * 9 * NV * (size_t)nb) + al(4 * NV * (size_t)nb)
                 + 4 * al(4 * 8 * NV) + al(4 * 3 * (size_t)K * TS) + al(4 * (size_t)K * TS) + al(16 * (size_t)K * TS);
     if (ctx->ptb_bytes < need) {
         if (ctx->ptb) { MR_HIP(hipDeviceSynchronize()); MR_HIP(hipFree(ctx->ptb)); ctx->ptb = nullptr; ctx->ptb_bytes = 0; }
@@ -207,6 +212,7 @@ static int carve_batch(mirres_ctx* ctx, int N, int K, int max_bounce, size_t TS,
     for (int k = 0; k < 2; k++) { PB.pos[k] = (float*)take(4 * 3 * NV); PB.rd[k] = (float*)take(4 * 3 * NV); PB.n[k] = (float*)take(4 * 3 * NV); PB.occ[k] = (float*)take(4 * NV); }
     PB.kd = (float*)take(4 * 3 * NV); PB.rm = (float*)take(4 * 2 * NV);
     PB.cb = (float*)take(4 * 9 * NV * (size_t)nb);
+    PB.maskb = (uint32_t*)take(4 * NV * (size_t)nb);
     for (int k = 0; k < 4; k++) {
         mirres_res_t& r = (k < 2) ? PB.rinit[k] : PB.rspat[k - 2];
         r.light_data = (float*)take(4 * 8 * NV); r.light_pdf = nullptr; r.M = nullptr; r.weight = nullptr;
@@ -392,11 +398,12 @@ int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args
             if (rc) return rc;
             mirres_path_t Pb = {PB.occ[src], PB.pos[src], PB.n[src], PB.rd[src], PB.kd, PB.rm, PB.prd, PB.pos[src ^ 1], PB.rd[src ^ 1], PB.occ[src ^ 1], PB.n[src ^ 1]};
             float* cb = PB.cb + (size_t)(bo - 1) * 9 * (size_t)Q.NV;
+            Q.mask_a = PB.maskb + (size_t)(bo - 1) * (size_t)Q.NV;      // kept per bounce for k_pt_reduce
             rc = launch_bounce(ctx, bvh, &E, &Pb, fi, (uint32_t)bo, cb, cb + 3 * (size_t)Q.NV, cb + 6 * (size_t)Q.NV, nullptr, nullptr, nullptr, sp, &Q); if (rc) return rc;
             fi += 5;
             src ^= 1;
         }
-        if (max_bounce > 0) k_pt_reduce<<<grid_for(n3, MR_BLOCK), MR_BLOCK, 0, sp>>>(N, kk, max_bounce, PB.cb, B.tot[3], B.tot[4], B.tot[5]);
+        if (max_bounce > 0) k_pt_reduce<<<grid_for(n3, MR_BLOCK), MR_BLOCK, 0, sp>>>(N, kk, max_bounce, PB.cb, PB.maskb, B.tot[3], B.tot[4], B.tot[5]);
     }
     {   // F(last)
         if (two_streams) MR_HIP(hipStreamWaitEvent(sp, ev_chain(nbatch - 1), 0));

@@ -129,7 +129,7 @@ __global__ void __launch_bounds__(MR_BLOCK) k_new_dir_resolve(mirres_path_t P, i
 
 // ---------------------------------------------------------------- process_path_tracing_divided_no_grad (FinalShading.slang:641-1009)
 __global__ void __launch_bounds__(MR_GEN_BLOCK) k_bounce_gen(mirres_path_t P, EnvD E, int max_bounce, float vis_near, uint32_t frameIndex, uint32_t bounce_count,
-                                                         int fx, int N, int NV, int first_is_zero, int y_off, float* __restrict__ color, float* __restrict__ diff_color, float* __restrict__ spec_color,
+                                                         int fx, int N, int NV, int first_is_zero, int y_off, int sparse, float* __restrict__ color, float* __restrict__ diff_color, float* __restrict__ spec_color,
                                                          Ray* __restrict__ qa, uint32_t* __restrict__ qa_count, Ray* __restrict__ qc, uint32_t* __restrict__ qc_count,
                                                          int32_t* __restrict__ slot_a, uint32_t* __restrict__ mask_out, int32_t* __restrict__ slot_c,
                                                          float* __restrict__ pend) {
@@ -222,7 +222,11 @@ __global__ void __launch_bounds__(MR_GEN_BLOCK) k_bounce_gen(mirres_path_t P, En
                 P.prd[5 * (size_t)pi + 4] = 1.f;
             }
         }
-        st3(color, pi, cv); st3(diff_color, pi, dcv); st3(spec_color, pi, scv);
+        // sparse (mirres_render's batches): most slots of a bounce are dead paths, so the three colours are written only where there is something
+        // to say — an environment pick-up (bit 4 of the mask) — and k_bounce_resolve / k_pt_reduce read them only where bits 0, 1 or 4 are set
+        const bool has_c = !is_black(cv) || !is_black(dcv) || !is_black(scv);
+        if (has_c) mask |= 16u;
+        if (!sparse || has_c) { st3(color, pi, cv); st3(diff_color, pi, dcv); st3(spec_color, pi, scv); }
     }
     const uint32_t na = (mask & 1u) + ((mask >> 1) & 1u);
     uint32_t base = block_append(qa_count, na > 0, na);
@@ -237,11 +241,12 @@ template <bool ACC>
 __global__ void __launch_bounds__(MR_BLOCK) k_bounce_resolve(mirres_path_t P, int N, const int32_t* __restrict__ slot_a, const uint32_t* __restrict__ mask_in,
                                                              const int32_t* __restrict__ slot_c, const int32_t* __restrict__ hit, const HitRec* __restrict__ rec,
                                                              const float* __restrict__ pend, float* __restrict__ color, float* __restrict__ diff_color,
-                                                             float* __restrict__ spec_color, float* __restrict__ acc_c, float* __restrict__ acc_d, float* __restrict__ acc_s) {
+                                                             float* __restrict__ spec_color, float* __restrict__ acc_c, float* __restrict__ acc_d, float* __restrict__ acc_s, int sparse) {
     const int pi = blockIdx.x * blockDim.x + threadIdx.x;
     if (pi >= N) return;
     const uint32_t mask = mask_in[pi];
-    v3 cv = ld3(color, pi), dcv = ld3(diff_color, pi), scv = ld3(spec_color, pi);
+    v3 cv = V3(0.f), dcv = V3(0.f), scv = V3(0.f);
+    if (!sparse || (mask & 16u)) { cv = ld3(color, pi); dcv = ld3(diff_color, pi); scv = ld3(spec_color, pi); }
     if (mask & 3u) {
         const float* pd = pend + 18 * (size_t)pi;
         int s = slot_a[pi];
@@ -293,12 +298,12 @@ int launch_bounce(mirres_ctx* ctx, mirres_bvh* bvh, const mirres_env_t* env, con
     const PtQueues Q = qq ? *qq : ctx_queues(ctx);
     const int NV = Q.NV, grd = grid_for(NV, MR_BLOCK);
     MR_HIP(hipMemsetAsync(&Q.counters[0], 0, 2 * sizeof(uint32_t), s));
-    k_bounce_gen<<<grid_for(NV, MR_GEN_BLOCK), MR_GEN_BLOCK, 0, s>>>(*p, envh(env), ctx->cfg.max_bounce, ctx->cfg.vis_near, frameIndex, bounce_count, ctx->fx, Q.N, NV, Q.first_sample_is_zero, ctx->y_off,
+    k_bounce_gen<<<grid_for(NV, MR_GEN_BLOCK), MR_GEN_BLOCK, 0, s>>>(*p, envh(env), ctx->cfg.max_bounce, ctx->cfg.vis_near, frameIndex, bounce_count, ctx->fx, Q.N, NV, Q.first_sample_is_zero, ctx->y_off, qq ? 1 : 0,
                                                                       color, dc, sc, Q.any_rays, &Q.counters[0], Q.cl_rays, &Q.counters[1], Q.slot_a, Q.mask_a, Q.slot_c, Q.pend);
     int rc = trace_any_q(ctx, bvh, Q.any_rays, &Q.counters[0], 2 * (size_t)NV, Q.any_hit, s, Q.lane); if (rc) return rc;
     rc = trace_closest_q(ctx, bvh, Q.cl_rays, &Q.counters[1], (size_t)NV, Q.cl_hit, s, Q.lane); if (rc) return rc;
-    if (acc_c) k_bounce_resolve<true><<<grd, MR_BLOCK, 0, s>>>(*p, NV, Q.slot_a, Q.mask_a, Q.slot_c, Q.any_hit, Q.cl_hit, Q.pend, color, dc, sc, acc_c, acc_d, acc_s);
-    else k_bounce_resolve<false><<<grd, MR_BLOCK, 0, s>>>(*p, NV, Q.slot_a, Q.mask_a, Q.slot_c, Q.any_hit, Q.cl_hit, Q.pend, color, dc, sc, nullptr, nullptr, nullptr);
+    if (acc_c) k_bounce_resolve<true><<<grd, MR_BLOCK, 0, s>>>(*p, NV, Q.slot_a, Q.mask_a, Q.slot_c, Q.any_hit, Q.cl_hit, Q.pend, color, dc, sc, acc_c, acc_d, acc_s, qq ? 1 : 0);
+    else k_bounce_resolve<false><<<grd, MR_BLOCK, 0, s>>>(*p, NV, Q.slot_a, Q.mask_a, Q.slot_c, Q.any_hit, Q.cl_hit, Q.pend, color, dc, sc, nullptr, nullptr, nullptr, qq ? 1 : 0);
     MR_LAUNCH_CHECK("pt_bounce");
     return 0;
 }
