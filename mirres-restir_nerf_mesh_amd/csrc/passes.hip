@@ -339,7 +339,13 @@ __global__ void __launch_bounds__(MR_GEN_BLOCK) k_spatial_gen(mirres_config_t C,
             if (nb[i] >= 0) {
                 const size_t qi = (size_t)nb[i];
                 if (G.rec) { nd[i] = G.rec[4 * qi]; nocc[i] = G.rec[4 * qi + 1].w; }
-                else { nd[i] = reinterpret_cast<const float4*>(G.normal_depth)[qi]; nocc[i] = G.occ[qi]; }
+                else {
+                    nd[i] = reinterpret_cast<const float4*>(G.normal_depth)[qi];
+                    // packed reservoirs exist only inside mirres_render, where the input reservoirs were written by this frame's initial /
+                    // temporal passes over this very G-buffer: M != 0 there already means "foreground" (background pixels store M = 0), so the
+                    // occupancy gather — one of the three cache lines a candidate neighbour costs — is redundant
+                    nocc[i] = PR.rec ? 1.0f : G.occ[qi];
+                }
                 nM[i] = res_M(PR, qi);
             }
         }
