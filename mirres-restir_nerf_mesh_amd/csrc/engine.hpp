@@ -80,6 +80,13 @@ struct mirres_bvh {
     mr::WideNode* nodes = nullptr;  // [T-1]
     mr::TriRec* tris = nullptr;     // [T]
     mr::Node4* nodes4 = nullptr;    // [T-1] indexed by LBVH node id (only the nodes reachable from the root by 2-level steps are used)
+    // PLOC tree for the shadow-ray hierarchy (bvh_build.hip): any hierarchy over the same leaf boxes gives the same any-hit bit, so the shadow rays
+    // get a higher-quality tree than the LBVH the closest-hit kernel must walk in the reference's order
+    int32_t* pl_info = nullptr; float* pl_aabb = nullptr;               // [2T-1,3], [2T-1,6] in the LBVH arrays' convention (leaves copied)
+    int32_t* pl_cid[2] = {nullptr, nullptr}; float* pl_box[2] = {nullptr, nullptr};   // cluster ids / boxes, ping-pong
+    int32_t* pl_nn = nullptr; unsigned long long* pl_flag = nullptr; unsigned long long* pl_scan = nullptr;
+    int32_t* pl_state = nullptr;    // [4]: n (clusters), next node id, scratch
+    void* pl_tmp = nullptr; size_t pl_tmp_bytes = 0;
     mr::Node4q* nodes4q = nullptr;  // [T-1] compressed 4-wide nodes (shadow rays)
     mr::LeafRec* leaves = nullptr;  // [T]
     mr::Node4q* top85q = nullptr, *top341q = nullptr;   // [85], [341] breadth-first prefixes of nodes4q, children inside tagged MR_TOPBIT
