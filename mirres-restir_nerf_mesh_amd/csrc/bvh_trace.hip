@@ -544,6 +544,10 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_closest4(BvhView B, co
                                                                    float* __restrict__ nrm_out, int32_t* __restrict__ prim_out,
                                                                    uint32_t* __restrict__ redo, uint32_t* __restrict__ redo_count,
                                                                    unsigned long long* __restrict__ stats) {
+    // Same machinery as k_trace_any4q: compressed 4-wide nodes (conservative boxes only steer and cull: a culled subtree's entry distance is
+    // <= the exact one, so nothing that could beat `closest` is skipped), leaves re-tested against their exact box, ONE 64-byte record per
+    // lane and iteration fetched before its type is known, results written after the loop. Children are visited front to back and the stack
+    // keeps (reference, entry distance) so that deferred subtrees are re-tested against the then-current `closest`.
     __shared__ uint2 lds[MR_LDS_STACK * MR_TRACE_BLOCK];
     uint2* const lds_stack = lds + threadIdx.x;
     const uint32_t n = d_count ? *d_count : n_fixed;
@@ -554,10 +558,11 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_closest4(BvhView B, co
     const uint32_t q_per = (((n + MR_NQ - 1) / MR_NQ) + 63u) & ~63u;                                  // rays per sub-queue
     uint32_t q_cur = (blockIdx.x * (MR_TRACE_BLOCK / 64) + (threadIdx.x >> 6)) % MR_NQ, q_fail = 0;   // wave-uniform
     uint32_t chunk_next = 0, chunk_end = 0;
-    bool exhausted = false, have = false;
+    bool exhausted = false, have = false, fin = false;
     float ox = 0, oy = 0, oz = 0, ix = 0, iy = 0, iz = 0; v3 d = V3(0.f), ro = V3(0.f);
     float t_min = 0.f, closest = 0.f, best_u = 0.f, best_v = 0.f;
-    int cur = -1, sp = 0, best_slot = -1; uint32_t ridx = 0; bool any_hit = false, need_redo = false;
+    const int NONE = 0x7fffffff;
+    int cur = NONE, sp = 0, best_slot = -1; uint32_t ridx = 0; bool any_hit = false, need_redo = false;
     uint2 spill[MR_STACK - MR_LDS_STACK];
     unsigned long long c_boxes = 0, c_nodes = 0, c_leaves = 0;
     while (true) {
@@ -578,7 +583,7 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_closest4(BvhView B, co
                     const float o3[3] = {ox, oy, oz}, i3[3] = {ix, iy, iz};
                     Slab s0 = slab(B.root_box, B.root_box + 3, o3, i3, t_min);
                     if (COUNT) c_boxes++;
-                    cur = (s0.tf > s0.tn && closest > s0.tn) ? 0 : -1;
+                    cur = (s0.tf > s0.tn && closest > s0.tn) ? 0 : NONE;
                     have = true;
                 }
                 const uint32_t want = (uint32_t)__popcll(need);
@@ -589,46 +594,40 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_closest4(BvhView B, co
         do {
             if (have) {
                 bool done = false;
-                if (cur < 0) {   // pop the nearest deferred node that still beats `closest`
+                if (cur == NONE) {   // pop the nearest deferred subtree that still beats `closest`
                     bool found = false;
                     while (sp > 0) {
                         --sp;
-                        uint2 e = (sp < MR_LDS_STACK) ? lds_stack[sp * MR_TRACE_BLOCK] : spill[sp - MR_LDS_STACK];
-                        if (closest > __uint_as_float(e.y)) { cur = (int)e.x; found = true; break; }
+                        const uint2 e = (sp < MR_LDS_STACK) ? lds_stack[sp * MR_TRACE_BLOCK] : spill[sp - MR_LDS_STACK];
+                        const float etn = __uint_as_float(e.y);
+                        if (closest > etn) { cur = (int)e.x; found = true; break; }
+                        if (closest == etn && any_hit) need_redo = true;   // culled on equality: a tie the reference's order could resolve differently
                     }
                     if (!found) done = true;
                 }
                 if (!done) {
-                    const Node4* __restrict__ nd = B.nodes4 + cur;
-                    const float4 mnx = reinterpret_cast<const float4*>(nd)[0], mny = reinterpret_cast<const float4*>(nd)[1], mnz = reinterpret_cast<const float4*>(nd)[2];
-                    const float4 mxx = reinterpret_cast<const float4*>(nd)[3], mxy = reinterpret_cast<const float4*>(nd)[4], mxz = reinterpret_cast<const float4*>(nd)[5];
-                    const int4 rf = reinterpret_cast<const int4*>(nd)[6];
-                    const float bmnx[4] = {mnx.x, mnx.y, mnx.z, mnx.w}, bmny[4] = {mny.x, mny.y, mny.z, mny.w}, bmnz[4] = {mnz.x, mnz.y, mnz.z, mnz.w};
-                    const float bmxx[4] = {mxx.x, mxx.y, mxx.z, mxx.w}, bmxy[4] = {mxy.x, mxy.y, mxy.z, mxy.w}, bmxz[4] = {mxz.x, mxz.y, mxz.z, mxz.w};
-                    const int ref[4] = {rf.x, rf.y, rf.z, rf.w};
+                    const bool leaf = cur < 0;
+                    const uint4* __restrict__ nd = leaf ? reinterpret_cast<const uint4*>(B.leaves + ~cur) : reinterpret_cast<const uint4*>(B.nodes4q + cur);
+                    const uint4 h0 = nd[0], h1 = nd[1], h2 = nd[2], rf = nd[3];
                     if (COUNT) c_nodes++;
-                    float ctn[4]; bool cok[4];
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const float ax = (bmnx[k] - ox) * ix, bx = (bmxx[k] - ox) * ix;
-                        const float ay = (bmny[k] - oy) * iy, by = (bmxy[k] - oy) * iy;
-                        const float az = (bmnz[k] - oz) * iz, bz = (bmxz[k] - oz) * iz;
-                        ctn[k] = fmaxf(fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz)), t_min);
-                        const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
-                        cok[k] = ref[k] != 0x7fffffff && tf > ctn[k];
-                        if (COUNT && ref[k] != 0x7fffffff) c_boxes++;
-                    }
-                    // leaves first (they can only shrink `closest`), then internal children front to back
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        if (cok[k] && ref[k] < 0 && closest > ctn[k]) {
+                    if (leaf) {
+                        const int slot = ~cur;
+                        cur = NONE;
+                        const float4 l0 = make_float4(__uint_as_float(h0.x), __uint_as_float(h0.y), __uint_as_float(h0.z), __uint_as_float(h0.w));
+                        const float4 l1 = make_float4(__uint_as_float(h1.x), __uint_as_float(h1.y), __uint_as_float(h1.z), __uint_as_float(h1.w));
+                        const float4 l2 = make_float4(__uint_as_float(h2.x), __uint_as_float(h2.y), __uint_as_float(h2.z), __uint_as_float(h2.w));
+                        const float4 l3 = make_float4(__uint_as_float(rf.x), __uint_as_float(rf.y), __uint_as_float(rf.z), __uint_as_float(rf.w));
+                        // the reference tests a leaf iff its OWN box passes against the current `closest`
+                        const float ex0 = (l2.y - ox) * ix, ex1 = (l3.x - ox) * ix;
+                        const float ey0 = (l2.z - oy) * iy, ey1 = (l3.y - oy) * iy;
+                        const float ez0 = (l2.w - oz) * iz, ez1 = (l3.z - oz) * iz;
+                        const float etn = fmaxf(fmaxf(fmaxf(fminf(ex0, ex1), fminf(ey0, ey1)), fminf(ez0, ez1)), t_min);
+                        const float etf = fminf(fminf(fmaxf(ex0, ex1), fmaxf(ey0, ey1)), fmaxf(ez0, ez1));
+                        if (COUNT) c_boxes++;
+                        if (etf > etn && closest == etn && any_hit) need_redo = true;
+                        if (etf > etn && closest > etn) {
                             if (COUNT) c_leaves++;
-                            const int slot = ~ref[k];
-                            const TriRec* __restrict__ tr = B.tris + slot;
-                            const float4 a = reinterpret_cast<const float4*>(tr)[0];
-                            const float4 b = reinterpret_cast<const float4*>(tr)[1];
-                            const float4 c = reinterpret_cast<const float4*>(tr)[2];
-                            const v3 v0 = V3(a.x, a.y, a.z), E1 = V3(a.w, b.x, b.y), E2 = V3(b.z, b.w, c.x);
+                            const v3 v0 = V3(l0.x, l0.y, l0.z), E1 = V3(l0.w, l1.x, l1.y), E2 = V3(l1.z, l1.w, l2.x);
                             const v3 P = cross(d, E2);
                             const float det = dot(E1, P);
                             if (!(det > -1e-15f && det < 1e-15f)) {
@@ -650,55 +649,69 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_closest4(BvhView B, co
                                 }
                             }
                         }
-                    }
-                    // internal children that still beat `closest`: nearest becomes `cur`, the others are pushed far -> near
-                    int nref[4]; float ntn[4]; int nn = 0;
+                    } else {
+                        const float gx = __uint_as_float(h0.x), gy = __uint_as_float(h0.y), gz = __uint_as_float(h0.z);
+                        const float sx = __uint_as_float((h0.w & 0xffu) << 23), sy = __uint_as_float((h0.w & 0xff00u) << 15), sz = __uint_as_float((h0.w & 0xff0000u) << 7);
+                        const uint32_t qlx = h1.x, qly = h1.y, qlz = h1.z, qhx = h1.w, qhy = h2.x, qhz = h2.y;
+                        const int ref[4] = {(int)rf.x, (int)rf.y, (int)rf.z, (int)rf.w};
+                        // children that may still hold something nearer, kept in descending entry distance (n <= 4)
+                        int nref[4]; float ntn[4]; int nn = 0;
 #pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        if (cok[k] && ref[k] >= 0 && closest > ctn[k]) {
-                            int r = ref[k]; float tn = ctn[k];
-                            // insertion into descending-tn order (n <= 4)
+                        for (int k = 0; k < 4; k++) {
+                            const float lx = fmaf((float)((qlx >> (8 * k)) & 0xffu), sx, gx), hx = fmaf((float)((qhx >> (8 * k)) & 0xffu), sx, gx);
+                            const float ly = fmaf((float)((qly >> (8 * k)) & 0xffu), sy, gy), hy = fmaf((float)((qhy >> (8 * k)) & 0xffu), sy, gy);
+                            const float lz = fmaf((float)((qlz >> (8 * k)) & 0xffu), sz, gz), hz = fmaf((float)((qhz >> (8 * k)) & 0xffu), sz, gz);
+                            const float ax = (lx - ox) * ix, bx = (hx - ox) * ix;
+                            const float ay = (ly - oy) * iy, by = (hy - oy) * iy;
+                            const float az = (lz - oz) * iz, bz = (hz - oz) * iz;
+                            float tn = fmaxf(fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz)), t_min);
+                            const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+                            if (COUNT && ref[k] != NONE) c_boxes++;
+                            if (ref[k] != NONE && tf > tn && closest > tn) {
+                                int r = ref[k];
 #pragma unroll
-                            for (int q = 0; q < 4; q++) {
-                                if (q < nn && ntn[q] < tn) { const int tr_ = nref[q]; const float tt_ = ntn[q]; nref[q] = r; ntn[q] = tn; r = tr_; tn = tt_; }
+                                for (int q = 0; q < 4; q++) {
+                                    if (q < nn && ntn[q] < tn) { const int tr_ = nref[q]; const float tt_ = ntn[q]; nref[q] = r; ntn[q] = tn; r = tr_; tn = tt_; }
+                                }
+                                nref[nn] = r; ntn[nn] = tn; nn++;
                             }
-                            nref[nn] = r; ntn[nn] = tn; nn++;
                         }
-                    }
-                    cur = -1;
-                    if (nn > 0) {
-                        cur = nref[nn - 1];
+                        cur = NONE;
+                        if (nn > 0) {
+                            cur = nref[nn - 1];
 #pragma unroll
-                        for (int q = 0; q < 3; q++) {
-                            if (q < nn - 1) {
-                                uint2 e; e.x = (uint32_t)nref[q]; e.y = __float_as_uint(ntn[q]);
-                                if (sp < MR_LDS_STACK) lds_stack[sp * MR_TRACE_BLOCK] = e;
-                                else if (sp < MR_STACK) spill[sp - MR_LDS_STACK] = e;
-                                if (sp < MR_STACK) sp++; else need_redo = true;
+                            for (int q = 0; q < 3; q++) {
+                                if (q < nn - 1) {
+                                    uint2 e; e.x = (uint32_t)nref[q]; e.y = __float_as_uint(ntn[q]);
+                                    if (sp < MR_LDS_STACK) lds_stack[sp * MR_TRACE_BLOCK] = e;
+                                    else if (sp < MR_STACK) spill[sp - MR_LDS_STACK] = e;
+                                    if (sp < MR_STACK) sp++; else need_redo = true;
+                                }
                             }
                         }
                     }
                 }
-                if (done) {
-                    have = false;
-                    if (need_redo) redo[atomicAdd(redo_count, 1u)] = ridx;
-                    TraceOut r; r.hit = any_hit; r.t = any_hit ? closest : 0.f; r.u = best_u; r.v = best_v; r.slot = best_slot; r.d = d;
-                    v3 p, nn_; int pr;
-                    finish_closest(B, r, ro, p, nn_, pr);
-                    if (rec) {
-                        float4 o0, o1;
-                        o0.x = p.x; o0.y = p.y; o0.z = p.z; o0.w = __int_as_float(any_hit ? 1 : 0);
-                        o1.x = nn_.x; o1.y = nn_.y; o1.z = nn_.z; o1.w = r.t;
-                        reinterpret_cast<float4*>(rec + ridx)[0] = o0; reinterpret_cast<float4*>(rec + ridx)[1] = o1;
-                    }
-                    if (hit_out) hit_out[ridx] = any_hit ? 1 : 0;
-                    if (t_out) t_out[ridx] = r.t;
-                    if (pos_out) st3(pos_out, ridx, p);
-                    if (nrm_out) st3(nrm_out, ridx, nn_);
-                    if (prim_out) prim_out[ridx] = pr;
-                }
+                if (done) { have = false; fin = true; }
             }
         } while (__popcll(__ballot(have)) >= MR_REFILL || (exhausted && __ballot(have)));
+        if (fin) {   // results of the rays that finished in this stretch, written by all of them together
+            fin = false;
+            if (need_redo) redo[atomicAdd(redo_count, 1u)] = ridx;
+            TraceOut r; r.hit = any_hit; r.t = any_hit ? closest : 0.f; r.u = best_u; r.v = best_v; r.slot = best_slot; r.d = d;
+            v3 p, nn_; int pr;
+            finish_closest(B, r, ro, p, nn_, pr);
+            if (rec) {
+                float4 o0, o1;
+                o0.x = p.x; o0.y = p.y; o0.z = p.z; o0.w = __int_as_float(any_hit ? 1 : 0);
+                o1.x = nn_.x; o1.y = nn_.y; o1.z = nn_.z; o1.w = r.t;
+                reinterpret_cast<float4*>(rec + ridx)[0] = o0; reinterpret_cast<float4*>(rec + ridx)[1] = o1;
+            }
+            if (hit_out) hit_out[ridx] = any_hit ? 1 : 0;
+            if (t_out) t_out[ridx] = r.t;
+            if (pos_out) st3(pos_out, ridx, p);
+            if (nrm_out) st3(nrm_out, ridx, nn_);
+            if (prim_out) prim_out[ridx] = pr;
+        }
     }
     if (COUNT && stats) { atomicAdd(&stats[5], c_boxes); atomicAdd(&stats[6], c_nodes); atomicAdd(&stats[7], c_leaves); }
     if (stats && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[1], (unsigned long long)n);
@@ -737,15 +750,15 @@ static void launch_any4q(const mirres_bvh* bvh, int grid, const Ray* rays, const
     else if (top == 341) k_trace_any4q<COUNT, 341><<<grid, MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, d_count, cap, head, hit, stats);
     else k_trace_any4q<COUNT, 0><<<grid, MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, d_count, cap, head, hit, stats);
 }
-static int closest_mode() {   // MIRRES_CLOSEST=4: ordered 4-wide fast path + redo in the frame loop (pays off only when most rays hit)
+static int closest_mode() {   // 4 (default): ordered compressed 4-wide fast path + reference-order redo of the flagged rays; MIRRES_CLOSEST=2: reference order for all
     static int m = -1;
-    if (m < 0) { const char* e = getenv("MIRRES_CLOSEST"); m = (e && e[0] == '4') ? 4 : 2; }
+    if (m < 0) { const char* e = getenv("MIRRES_CLOSEST"); m = (e && e[0] == '2') ? 2 : 4; }
     return m;
 }
 static int persist_grid(size_t capacity) {
     size_t want = (capacity + MR_TRACE_BLOCK - 1) / MR_TRACE_BLOCK;
-    size_t cap = 256 * 6;                                       // 6 resident blocks per CU: measured faster than 8 (forcing <= 64 VGPRs spills and thrashes
-                                                                // the L1; PMC shows the kernels bound by TCP line lookups of divergent 16-B gathers, not by latency hiding)
+    size_t cap = 256 * 6;                                       // 6 resident blocks per CU: measured faster than 8 (forcing <= 64 VGPRs spills; the kernels are
+                                                                // VALU-issue bound while CUs hold waves — DESIGN.md §5 — so more occupancy buys nothing)
     return (int)(want < 1 ? 1 : (want > cap ? cap : want));
 }
 
