@@ -214,35 +214,6 @@ __global__ void __launch_bounds__(256) k_pack(int T, const int32_t* __restrict__
     }
 }
 
-// 4-wide collapse of the LBVH for the shadow-ray kernel: node g's entries are the children of its internal children (a leaf child stays
-// an entry itself). Boxes are copied bit for bit from the refitted LBVH, so every leaf is still guarded by exactly its own box.
-__global__ void __launch_bounds__(256) k_pack4(int T, const int32_t* __restrict__ info, const float* __restrict__ aabb, Node4* __restrict__ nodes4) {
-    int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= T - 1) return;
-    const int LEAF = T - 1;
-    int c[4]; int nc = 0;
-    const int ch[2] = {info[3 * (size_t)g], info[3 * (size_t)g + 1]};
-#pragma unroll
-    for (int k = 0; k < 2; k++) {
-        if (ch[k] >= LEAF) c[nc++] = ch[k];
-        else { c[nc++] = info[3 * (size_t)ch[k]]; c[nc++] = info[3 * (size_t)ch[k] + 1]; }
-    }
-    Node4 n;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        if (k < nc) {
-            const float* b = aabb + 6 * (size_t)c[k];
-            n.minx[k] = b[0]; n.miny[k] = b[1]; n.minz[k] = b[2]; n.maxx[k] = b[3]; n.maxy[k] = b[4]; n.maxz[k] = b[5];
-            n.ref[k] = (c[k] >= LEAF) ? ~(c[k] - LEAF) : c[k];
-        } else {
-            n.minx[k] = n.miny[k] = n.minz[k] = 0.f; n.maxx[k] = n.maxy[k] = n.maxz[k] = 0.f;
-            n.ref[k] = 0x7fffffff;
-        }
-        n.pad[k] = 0;
-    }
-    nodes4[g] = n;
-}
-
 // ---------------------------------------------------------------- PLOC: a higher-quality binary tree over the same leaves, for shadow rays only
 // Parallel locally-ordered clustering (Meister & Bittner 2018) over the Morton-sorted leaves: every cluster looks R positions left and right
 // for the partner that minimises the surface area of the merged box; mutual nearest neighbours merge; the cluster array is compacted; repeat.
@@ -512,7 +483,6 @@ int mirres_bvh_create(mirres_bvh_t** out, int max_tris) {
     MR_HIP(hipMalloc(&b->own_aabb, sizeof(float) * 6 * (2 * T)));
     MR_HIP(hipMalloc(&b->nodes, sizeof(WideNode) * T));
     MR_HIP(hipMalloc(&b->tris, sizeof(TriRec) * T));
-    MR_HIP(hipMalloc(&b->nodes4, sizeof(Node4) * T));
     MR_HIP(hipMalloc(&b->nodes4q, sizeof(Node4q) * T));
     MR_HIP(hipMalloc(&b->leaves, sizeof(LeafRec) * T));
     MR_HIP(hipMalloc(&b->top85q, sizeof(Node4q) * 85));
@@ -530,7 +500,7 @@ int mirres_bvh_create(mirres_bvh_t** out, int max_tris) {
 void mirres_bvh_destroy(mirres_bvh_t* b) {
     if (!b) return;
     void* ptrs[] = {b->ele_aabb, b->extent, b->keys_in, b->keys_out, b->vals_in, b->vals_out, b->parent, b->flags, b->own_info,
-                    b->own_aabb, b->nodes, b->tris, b->root_box, b->sort_tmp, b->work, b->nodes4, b->redo, b->nodes4q, b->leaves, b->top85q, b->top341q, b->pl_info, b->pl_aabb, b->pl_cid[0], b->pl_cid[1], b->pl_box[0], b->pl_box[1],
+                    b->own_aabb, b->nodes, b->tris, b->root_box, b->sort_tmp, b->work, b->redo, b->nodes4q, b->leaves, b->top85q, b->top341q, b->pl_info, b->pl_aabb, b->pl_cid[0], b->pl_cid[1], b->pl_box[0], b->pl_box[1],
                     b->pl_nn, b->pl_flag, b->pl_scan, b->pl_state, b->pl_tmp};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete b;
@@ -553,7 +523,6 @@ int mirres_bvh_build(mirres_bvh_t* b, const float* vert, int V, const int32_t* t
     k_hierarchy<<<grd, blk, 0, s>>>(T, b->keys_out, b->vals_out, b->ele_aabb, info, aabb, b->parent, b->flags, sorted_codes);
     k_refit<<<grd, blk, 0, s>>>(T, info, aabb, b->parent, b->flags);
     k_pack<<<grd, blk, 0, s>>>(T, info, aabb, vert, tri, b->nodes, b->tris, b->root_box);
-    k_pack4<<<grd, blk, 0, s>>>(T, info, aabb, b->nodes4);
     const int32_t* hinfo = info; const float* haabb = aabb;          // the hierarchy the shadow-ray layout is collapsed from
     if (use_ploc() && T >= 64) {
         { int rc = ploc_alloc(b); if (rc) return rc; }

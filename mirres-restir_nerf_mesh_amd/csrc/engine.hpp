@@ -21,13 +21,6 @@ struct __attribute__((aligned(64))) WideNode {
     int32_t left, right;  // >=0 internal node index, <0 : ~leaf_slot
     int32_t pad[2];
 };
-// 4-wide node for shadow rays (any-hit may use any hierarchy over the same leaf boxes — bvh_trace.hip): the LBVH node's grandchildren
-// (or children when a child is a leaf), boxes copied verbatim, SoA so that the four slab tests vectorise. One 128-byte line per visit.
-struct __attribute__((aligned(128))) Node4 {
-    float minx[4], miny[4], minz[4], maxx[4], maxy[4], maxz[4];
-    int32_t ref[4];   // >=0 internal LBVH node id, <0 ~leaf slot, 0x7fffffff = unused entry
-    int32_t pad[4];
-};
 // Compressed 4-wide node (64 B = half a line, 4 dwordx4 loads instead of 8): child boxes as 8-bit offsets from the node's own min corner in
 // power-of-two steps, rounded OUTWARD against the exact decode expression fmaf(q, 2^e, origin) the kernel evaluates, so every decoded box
 // contains the LBVH box it stands for. Only used by the shadow-ray kernel, whose result depends on the leaves' own boxes alone
@@ -36,7 +29,7 @@ struct __attribute__((aligned(64))) Node4q {
     float org[3]; uint32_t exps;          // biased exponents of the x/y/z step in bytes 0..2
     uint32_t qlo[3], qhi[3];              // byte k of qlo[a] / qhi[a] = child k's min / max along axis a
     uint32_t pad[2];
-    int32_t ref[4];                       // as Node4::ref
+    int32_t ref[4];                       // >=0 node id, <0 ~leaf slot, 0x7fffffff = unused entry; inside an LDS-staged prefix: MR_TOPBIT | index
 };
 struct __attribute__((aligned(64))) LeafRec {  // 64 B: triangle (v0, e1, e2) + the leaf's exact LBVH box + primitive id
     float v0[3], e1[3], e2[3];
@@ -58,7 +51,6 @@ struct __attribute__((aligned(16))) HitRec {  // 32 B closest-hit record
 
 struct BvhView {
     const WideNode* nodes; const TriRec* tris; const float* root_box;  // root_box -> aabb[0..5] of node 0
-    const Node4* nodes4;
     const Node4q* nodes4q; const LeafRec* leaves; const Node4q* top85q; const Node4q* top341q;   // compressed shadow-ray layout
     int T;
     unsigned long long* dbg;   // optional [2 * waves]: wall-clock start / end of every traversal wave (mirres_debug_wave_times)
@@ -79,7 +71,6 @@ struct mirres_bvh {
     // traversal layout
     mr::WideNode* nodes = nullptr;  // [T-1]
     mr::TriRec* tris = nullptr;     // [T]
-    mr::Node4* nodes4 = nullptr;    // [T-1] indexed by LBVH node id (only the nodes reachable from the root by 2-level steps are used)
     // PLOC tree for the shadow-ray hierarchy (bvh_build.hip): any hierarchy over the same leaf boxes gives the same any-hit bit, so the shadow rays
     // get a higher-quality tree than the LBVH the closest-hit kernel must walk in the reference's order
     int32_t* pl_info = nullptr; float* pl_aabb = nullptr;               // [2T-1,3], [2T-1,6] in the LBVH arrays' convention (leaves copied)
@@ -94,7 +85,7 @@ struct mirres_bvh {
     uint32_t* work = nullptr;       // [10 * MR_WSET] head sets of the persistent traversal kernels (0/1 frame loop, 2/3 API, 4-6 ordered closest + redo, 7/8 second stream)
     unsigned long long* dbg = nullptr;   // see BvhView::dbg
     uint32_t* redo = nullptr; size_t redo_cap = 0;   // ray ids handed back by the ordered closest-hit fast path
-    mr::BvhView view() const { mr::BvhView v; v.nodes = nodes; v.tris = tris; v.root_box = root_box; v.T = T; v.nodes4 = nodes4; v.nodes4q = nodes4q; v.leaves = leaves; v.top85q = top85q; v.top341q = top341q; v.dbg = dbg; return v; }
+    mr::BvhView view() const { mr::BvhView v; v.nodes = nodes; v.tris = tris; v.root_box = root_box; v.T = T; v.nodes4q = nodes4q; v.leaves = leaves; v.top85q = top85q; v.top341q = top341q; v.dbg = dbg; return v; }
 };
 
 struct mirres_ctx {
