@@ -146,6 +146,16 @@ int mirres_bilateral(int fx, int fy, float sigma, const float* col, const float*
 int mirres_bilateral_bwd(int fx, int fy, float sigma, const float* nrm, const float* zdz, const float* grad_out4, float* scratch, float* col_grad,
                          void* stream);
 
+/* prepare_shading_normal (nerf/renderutils/ops.py:100-163; c_src/normal.cu): the shading normal render_stage1 hands to the path
+ * (nerf/renderer.py:1013). All inputs f32[n,3] (broadcast inputs expanded by the caller); out f32[n,3]. The backward writes the six input
+ * gradients (any may be NULL).                                                                                                   */
+int mirres_prepare_shading_normal(long long n, const float* pos, const float* view_pos, const float* perturbed_nrm, const float* smooth_nrm,
+                                  const float* smooth_tng, const float* geom_nrm, int two_sided_shading, int opengl, float* out, void* stream);
+int mirres_prepare_shading_normal_bwd(long long n, const float* pos, const float* view_pos, const float* perturbed_nrm, const float* smooth_nrm,
+                                      const float* smooth_tng, const float* geom_nrm, int two_sided_shading, int opengl, const float* dout,
+                                      float* g_pos, float* g_view_pos, float* g_perturbed_nrm, float* g_smooth_nrm, float* g_smooth_tng,
+                                      float* g_geom_nrm, void* stream);
+
 /* ------------------------------------------------------------------ material field (MLPTexture3D, render_helper.py:53-124) */
 typedef struct mirres_matnet {
     const uint16_t* grid_f16; /* fp16 hash-grid table, 6 299 960 x 2 entries (tcnn layout)                      */

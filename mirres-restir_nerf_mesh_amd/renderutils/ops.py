@@ -51,3 +51,41 @@ def bilateral_denoiser(h, w, input, factor=1.0):
 def bilateral_denoiser_no_di(h, w, input, factor=1.0):
     """The same filter without autograd bookkeeping (ops.py:201-211)."""
     return bilateral_denoiser(h, w, input, factor)
+
+
+# ---------------------------------------------------------------------------------------------- prepare_shading_normal (ops.py:100-163)
+class _prepare_shading_normal_func(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pos, view_pos, perturbed_nrm, smooth_nrm, smooth_tng, geom_nrm, two_sided_shading, opengl):
+        shape = torch.broadcast_shapes(pos.shape, view_pos.shape, perturbed_nrm.shape, smooth_nrm.shape, smooth_tng.shape, geom_nrm.shape)
+        ins = [_f32c(t.detach().expand(shape)) for t in (pos, view_pos, perturbed_nrm, smooth_nrm, smooth_tng, geom_nrm)]
+        n = ins[0].numel() // 3
+        out = torch.empty(shape, dtype=torch.float32, device=ins[0].device)
+        check(lib().mirres_prepare_shading_normal(n, *[t.data_ptr() for t in ins], int(bool(two_sided_shading)), int(bool(opengl)), out.data_ptr(), stream_ptr()),
+              "mirres_prepare_shading_normal")
+        ctx.save_for_backward(*ins)
+        ctx.flags = (int(bool(two_sided_shading)), int(bool(opengl)))
+        ctx.in_shapes = [tuple(t.shape) for t in (pos, view_pos, perturbed_nrm, smooth_nrm, smooth_tng, geom_nrm)]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        ins = ctx.saved_tensors
+        n = ins[0].numel() // 3
+        g = [torch.empty_like(ins[0]) if need else None for need in ctx.needs_input_grad[:6]]
+        p = lambda t: t.data_ptr() if t is not None else None
+        check(lib().mirres_prepare_shading_normal_bwd(n, *[t.data_ptr() for t in ins], ctx.flags[0], ctx.flags[1], _f32c(dout.expand(ins[0].shape)).data_ptr(),
+                                                      *[p(t) for t in g], stream_ptr()), "mirres_prepare_shading_normal_bwd")
+        # inputs that were broadcast (view_pos [1,1,1,3], the default perturbed normal) get their gradient summed back to their own shape
+        return tuple(t.sum_to_size(s) if t is not None else None for t, s in zip(g, ctx.in_shapes)) + (None, None)
+
+
+def prepare_shading_normal(pos, view_pos, perturbed_nrm, smooth_nrm, smooth_tng, geom_nrm, two_sided_shading=True, opengl=True, use_python=False):
+    """ops.py:128-163: final shading normal (tangent-space perturbation, two-sided flip, bending of back-facing normals). `use_python` is accepted
+    for signature compatibility; there is one implementation (the HIP kernels)."""
+    if perturbed_nrm is None:
+        perturbed_nrm = torch.tensor([0, 0, 1], dtype=torch.float32, device=pos.device, requires_grad=False)[None, None, None, ...]
+    out = _prepare_shading_normal_func.apply(pos, view_pos, perturbed_nrm, smooth_nrm, smooth_tng, geom_nrm, two_sided_shading, opengl)
+    if torch.is_anomaly_enabled():
+        assert torch.all(torch.isfinite(out)), "Output of prepare_shading_normal contains inf or NaN"
+    return out

@@ -279,6 +279,25 @@ def eaw(fx, fy, step, c_phi, n_phi, p_phi, occ, color, normal, pos):
     return out
 
 
+def prepare_shading_normal(pos, view_pos, perturbed_nrm, smooth_nrm, smooth_tng, geom_nrm, two_sided_shading=True, opengl=True):
+    """nerf/renderutils: bsdf_prepare_shading_normal (ops.py:84-121) == c_src/normal.cu forward, restated in numpy float32 (test infrastructure).
+    safeNormalize = v / |v| (0 for the zero vector, vec3f.h:87-91); bend threshold 0.1 (normal.cu:12)."""
+    f = np.float32
+    def nz(v):
+        l = np.sqrt(((v[..., 0] * v[..., 0] + v[..., 1] * v[..., 1]) + v[..., 2] * v[..., 2]).astype(f))[..., None]
+        return np.where(l > 0, v / np.where(l > 0, l, f(1)), f(0)).astype(f)
+    dot = lambda a, b: ((a[..., 0] * b[..., 0] + a[..., 1] * b[..., 1]) + a[..., 2] * b[..., 2]).astype(f)[..., None]
+    pos, view_pos, p, sn, st, gn = (np.asarray(a, f) for a in (pos, view_pos, perturbed_nrm, smooth_nrm, smooth_tng, geom_nrm))
+    nrm, tng, view = nz(sn), nz(st), nz((view_pos - pos).astype(f))
+    bit = nz(np.cross(tng, nrm).astype(f))
+    sgn = f(-1.0 if opengl else 1.0)
+    sh = nz((tng * p[..., 0:1] + bit * (sgn * p[..., 1:2]) + nrm * np.maximum(p[..., 2:3], f(0))).astype(f))
+    flip = (dot(view, gn) < 0) if two_sided_shading else np.zeros(dot(view, gn).shape, bool)
+    sh2, gn2 = np.where(flip, -sh, sh), np.where(flip, -gn, gn)
+    t = np.clip(dot(view, sh2) / f(0.1), f(0), f(1)).astype(f)
+    return (gn2 * (f(1) - t) + sh2 * t).astype(f)
+
+
 def bilateral(fx, fy, sigma, col, nrm, zdz, grad4=None):
     """grad4 None: forward -> f32[N,4] (sum w col, max(sum w, 1e-4)); else backward -> col_grad f32[N,3]."""
     n = fx * fy

@@ -80,3 +80,44 @@ def test_use_bi_de_branch_of_the_frame(oracle, scene_mod):
     assert torch.isfinite(env.grad).all() and float(env.grad.abs().sum()) > 0
     frac = (np.abs(out2[1].detach().cpu().numpy() - outs[1].cpu().numpy()).max(axis=1) <= 1e-3).mean()
     assert frac >= 0.99
+
+
+def test_prepare_shading_normal_forward_and_backward(oracle):
+    """nerf/renderutils.prepare_shading_normal on HIP: forward against the numpy restatement (incl. zero vectors, both flags, broadcast view
+    position and default perturbation), backward against torch autograd of the same formula in float64."""
+    import torch
+    from mirres_restir_nerf_mesh_amd.renderutils.ops import prepare_shading_normal
+    rng = np.random.default_rng(2)
+    shape = (1, 12, 17, 3)
+    mk = lambda: rng.normal(size=shape).astype(np.float32)
+    pos, sn, st, gn, pn = mk(), mk(), mk(), mk(), mk()
+    pn[..., 2] = np.abs(pn[..., 2]); pn[0, 0, :4, 2] = -0.3                  # some negative z (clamped), mostly tangent-space normals
+    sn[0, 1, 0] = 0; st[0, 1, 1] = 0                                          # zero-length inputs -> safeNormalize returns 0
+    view = np.array([0.5, -2.0, 3.0], np.float32).reshape(1, 1, 1, 3)
+    cu = lambda a: torch.from_numpy(a).cuda()
+    for two_sided in (True, False):
+        for opengl in (True, False):
+            ref = oracle.prepare_shading_normal(pos, view, pn, sn, st, gn, two_sided, opengl)
+            got = prepare_shading_normal(cu(pos), cu(view), cu(pn), cu(sn), cu(st), cu(gn), two_sided, opengl).cpu().numpy()
+            np.testing.assert_allclose(got, ref, rtol=2e-6, atol=2e-7)
+    ref0 = oracle.prepare_shading_normal(pos, view, np.array([0, 0, 1], np.float32).reshape(1, 1, 1, 3), sn, st, gn)
+    np.testing.assert_allclose(prepare_shading_normal(cu(pos), cu(view), None, cu(sn), cu(st), cu(gn)).cpu().numpy(), ref0, rtol=2e-6, atol=2e-7)
+    # backward: float64 torch autograd of the same formula (away from the zero-length rows, where the derivative is defined as 0)
+    def formula(pos, view, p, sn, st, gn, two_sided, opengl):
+        nz = lambda v: v / v.norm(dim=-1, keepdim=True)
+        nrm, tng, vv = nz(sn), nz(st), nz(view - pos)
+        bit = nz(torch.cross(tng, nrm, dim=-1))
+        sh = nz(tng * p[..., 0:1] + bit * ((-1.0 if opengl else 1.0) * p[..., 1:2]) + nrm * p[..., 2:3].clamp(min=0))
+        flip = ((vv * gn).sum(-1, keepdim=True) < 0) & two_sided
+        sh2, gn2 = torch.where(flip, -sh, sh), torch.where(flip, -gn, gn)
+        t = ((vv * sh2).sum(-1, keepdim=True) / 0.1).clamp(0, 1)
+        return gn2 * (1 - t) + sh2 * t
+    sl = (slice(None), slice(2, None))
+    w = rng.normal(size=(1, 10, 17, 3)).astype(np.float32)
+    ins32 = [cu(a[sl] if a.shape[1] > 1 else a).requires_grad_(True) for a in (pos, view, pn, sn, st, gn)]
+    out = prepare_shading_normal(*ins32, True, True)
+    (out * cu(w)).sum().backward()
+    ins64 = [torch.from_numpy((a[sl] if a.shape[1] > 1 else a).astype(np.float64)).requires_grad_(True) for a in (pos, view, pn, sn, st, gn)]
+    (formula(*ins64, True, True) * torch.from_numpy(w.astype(np.float64))).sum().backward()
+    for name, a, b in zip(("pos", "view_pos", "perturbed", "smooth_nrm", "smooth_tng", "geom_nrm"), ins32, ins64):
+        np.testing.assert_allclose(a.grad.cpu().numpy(), b.grad.numpy(), rtol=2e-3, atol=2e-4, err_msg=name)

@@ -150,3 +150,25 @@ def test_bilateral_denoiser_properties(oracle):
     assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(rhs))
     # the centre tap has weight 1, so an isolated bright pixel keeps at least its own contribution
     assert np.all(f[:, 3] >= 0.999)          # (n.n)^128 of a unit normal is 1 up to fp32 rounding
+
+
+def test_prepare_shading_normal_known_cases(oracle):
+    """nerf/renderutils.prepare_shading_normal (numpy restatement): unperturbed front-facing normal is returned unchanged, a back-facing
+    geometric normal flips both normals when two-sided, and a grazing smooth normal is bent towards the geometric one (threshold 0.1)."""
+    f = np.float32
+    pos = np.zeros((1, 3), f); view = np.array([[0, 0, 5]], f)
+    up = np.array([[0, 0, 2]], f); tng = np.array([[3, 0, 0]], f); p0 = np.array([[0, 0, 1]], f)
+    out = oracle.prepare_shading_normal(pos, view, p0, up, tng, np.array([[0, 0, 1]], f))
+    np.testing.assert_allclose(out, [[0, 0, 1]], atol=1e-7)
+    out = oracle.prepare_shading_normal(pos, view, p0, -up, tng, np.array([[0, 0, -1]], f), two_sided_shading=True)
+    np.testing.assert_allclose(out, [[0, 0, 1]], atol=1e-7)                                  # flipped to face the viewer
+    out1 = oracle.prepare_shading_normal(pos, view, p0, -up, tng, np.array([[0, 0, -1]], f), two_sided_shading=False)
+    np.testing.assert_allclose(out1, [[0, 0, -1]], atol=1e-7)                                # one-sided: t = 0 -> the geometric normal
+    graz = np.array([[1, 0, 0.05]], f)                                                       # smooth normal almost perpendicular to the view
+    out2 = oracle.prepare_shading_normal(pos, view, p0, graz, np.array([[0, 1, 0]], f), np.array([[0, 0, 1]], f))
+    n = graz / np.linalg.norm(graz); t = (n[0, 2] / 0.1)
+    np.testing.assert_allclose(out2, np.array([[0, 0, 1]], f) * (1 - t) + n * t, rtol=1e-5, atol=1e-6)
+    # tangent-space perturbation: x picks the tangent, y the bitangent (sign by convention)
+    o_gl = oracle.prepare_shading_normal(pos, view, np.array([[0, 1, 1]], f), up, tng, np.array([[0, 0, 1]], f), opengl=True)
+    o_dx = oracle.prepare_shading_normal(pos, view, np.array([[0, 1, 1]], f), up, tng, np.array([[0, 0, 1]], f), opengl=False)
+    assert o_gl[0, 1] * o_dx[0, 1] < 0 and abs(o_gl[0, 2] - o_dx[0, 2]) < 1e-6
