@@ -20,8 +20,11 @@ def timed(fn, n=3):
     for _ in range(n): fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
 world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-for rank in (0, world // 2):
-    y0, y1, lo, hi = D.strip_rows(fy, rank, world)
+balanced = len(sys.argv) > 2
+bounds = D.strip_bounds(fy, world, g["occ"] if balanced else None, fx)
+print("bounds", bounds)
+for rank in range(world):
+    y0, y1, lo, hi = D.strip_rows(fy, rank, world, bounds=bounds)
     loc = {k: g[k][lo * fx:hi * fx].contiguous() for k in ("occ", "normal", "depth", "kd", "rm", "ray_dir", "pos")}
     ctx = get_ctx(fx, hi - lo)
     cb = _lib.HALO_FN(lambda u, r, s, st: 0)

@@ -99,6 +99,17 @@ def test_strip_partition_and_halo_plan():
                 plo = rows[peer][2]
                 assert (lo + sa, lo + sb) == (plo + back[2][0], plo + back[2][1])      # our send range == the peer's receive range, in global rows
                 assert (lo + ra, lo + rb) == (plo + back[1][0], plo + back[1][1])
+    # cost-balanced heights: a frame whose lower half is foreground gets taller strips at the top; every strip keeps the halo's minimum height
+    import torch
+    fy, fx = 400, 10
+    occ = torch.zeros(fy, fx); occ[200:] = 1
+    b = D.strip_bounds(fy, 4, occ.reshape(-1, 1), fx)
+    assert b[0] == 0 and b[-1] == fy and all(y1 - y0 >= 30 for y0, y1 in zip(b, b[1:]))
+    assert b[1] - b[0] > b[4] - b[3]                                                      # cheap rows -> taller strip
+    cost = 0.2 * fx + 0.8 * occ.sum(1)
+    per = [float(cost[y0:y1].sum()) for y0, y1 in zip(b, b[1:])]
+    assert max(per) < 1.35 * min(per)
+    assert D.strip_bounds(fy, 4) == [0, 100, 200, 300, 400]
     with pytest.raises(ValueError):
         D.strip_rows(100, 0, 8)                                                            # 12 rows per rank < 30-row halo
 
