@@ -15,11 +15,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-fgpu-rdc" if False else "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-but-set-variable",
          "-I", os.path.join(HERE, "..", "..", "include")]
 
-# No packed-fp32 VALU code (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32, formed by the SLP vectoriser) in kernels that may share a SIMD with the
-# MFMA material-net kernel when mirres_render runs its two streams: on the MI355X boxes of this pool such waves occasionally got wrong results
+# No packed-fp32 VALU code (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32, formed by the SLP vectoriser) anywhere in the library: kernels may share
+# a SIMD with the MFMA material-net kernel when mirres_render runs its two streams, and on the MI355X boxes of this pool such waves occasionally got wrong results
 # for one 16-lane pass while another wave's v_mfma was in flight (found by tests/test_gpu_fullsize.py::test_schedule_does_not_change_the_frame;
 # bisected to exactly this: no MFMA -> clean, no v_pk_* in the neighbour kernels -> clean). DESIGN.md §Two streams.
-PER_FILE = {f: ["-fno-slp-vectorize"] for f in ("passes.hip", "shading.hip", "bvh_trace.hip", "bvh_build.hip", "eaw.hip", "render.hip", "backward.hip", "normal.hip")}
+PER_FILE = {f: ["-fno-slp-vectorize"] for f in ("passes.hip", "shading.hip", "bvh_trace.hip", "bvh_build.hip", "eaw.hip", "render.hip", "backward.hip", "normal.hip", "matnet.hip")}
 
 
 def _newer(a, deps):
