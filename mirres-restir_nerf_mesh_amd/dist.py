@@ -231,3 +231,30 @@ def _finish_args(ctx, env_map, g, spp, denoise_iter, step_width, c_phi, n_phi, p
         t = g[key].detach().contiguous().float(); keep.append(t); setattr(a, name, t.data_ptr())
     a.denoise_iter, a.step_width, a.c_phi, a.n_phi, a.p_phi = int(denoise_iter), int(step_width), float(c_phi), float(n_phi), float(p_phi)
     return None, a, keep
+
+
+# ------------------------------------------------------------------------------------------------ training: gradient exchange
+def allreduce_gradients(tensors, group=None, average=True):
+    """Stage-1 data parallelism (BASELINE configs[4]: 'grads all-reduced over xGMI'): every rank renders its own views / strips and
+    the parameter gradients — hash grid (50 MB fp32), MLP, environment map, vertex offsets — are summed as ONE flat bucket (RCCL rings are bound
+    by the per-link bandwidth of xGMI, so one large collective instead of one per tensor). `tensors` = parameters (their .grad is used; missing
+    grads count as zero) or plain gradient tensors; updated in place."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    grads = []
+    for t in tensors:
+        g = t.grad if isinstance(t, torch.nn.Parameter) or (t.requires_grad and t.grad is not None) else t
+        if g is None:
+            t.grad = torch.zeros_like(t); g = t.grad
+        grads.append(g)
+    if not grads:
+        return
+    flat = torch.cat([g.reshape(-1).to(torch.float32) for g in grads])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    if average:
+        flat /= dist.get_world_size(group)
+    o = 0
+    for g in grads:
+        n = g.numel()
+        g.copy_(flat[o:o + n].view_as(g)); o += n

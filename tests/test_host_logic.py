@@ -150,6 +150,34 @@ def test_strip_exchange_and_gather_gloo_world2(tmp_path):
             assert torch.equal(d["full"][k], gy[:, :, :3].reshape(-1, 3) * (k + 1))
 
 
+def _grad_worker(rank, world, port, out):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mirres_restir_nerf_mesh_amd.dist import allreduce_gradients
+    torch.manual_seed(0)
+    w = torch.nn.Parameter(torch.zeros(7, 3)); e = torch.nn.Parameter(torch.zeros(4, 5, 3)); unused = torch.nn.Parameter(torch.zeros(2))
+    w.grad = torch.full((7, 3), float(rank + 1)); e.grad = torch.arange(60, dtype=torch.float32).reshape(4, 5, 3) * (rank + 1)
+    allreduce_gradients([w, e, unused])
+    torch.save(dict(w=w.grad, e=e.grad, u=unused.grad), os.path.join(out, "g%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_gloo_world2(tmp_path):
+    """Training exchange: parameter gradients averaged over ranks as one flat bucket; a parameter without a gradient on some rank counts as zero."""
+    import torch
+    import torch.multiprocessing as mp
+    port = 35500 + (os.getpid() % 2000)
+    mp.spawn(_grad_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        d = torch.load(os.path.join(tmp_path, "g%d.pt" % r))
+        assert torch.allclose(d["w"], torch.full((7, 3), 1.5))
+        assert torch.allclose(d["e"], torch.arange(60, dtype=torch.float32).reshape(4, 5, 3) * 1.5)
+        assert torch.equal(d["u"], torch.zeros(2))
+
+
 def test_rgbe_roundtrip(tmp_path):
     from mirres_restir_nerf_mesh_amd import harness
     rng = np.random.default_rng(0)
