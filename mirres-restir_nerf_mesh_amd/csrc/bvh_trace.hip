@@ -485,20 +485,22 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const
                 } else {
                     const float gx = __uint_as_float(h0.x), gy = __uint_as_float(h0.y), gz = __uint_as_float(h0.z);
                     const float sx = __uint_as_float((h0.w & 0xffu) << 23), sy = __uint_as_float((h0.w & 0xff00u) << 15), sz = __uint_as_float((h0.w & 0xff0000u) << 7);
-                    const uint32_t qlx = h1.x, qly = h1.y, qlz = h1.z, qhx = h1.w, qhy = h2.x, qhz = h2.y;
+                    const uint32_t nqx = ix >= 0.f ? h1.x : h1.w, fqx = ix >= 0.f ? h1.w : h1.x;
+                    const uint32_t nqy = iy >= 0.f ? h1.y : h2.x, fqy = iy >= 0.f ? h2.x : h1.y;
+                    const uint32_t nqz = iz >= 0.f ? h1.z : h2.y, fqz = iz >= 0.f ? h2.y : h1.z;
                     const int ref[4] = {(int)rf.x, (int)rf.y, (int)rf.z, (int)rf.w};
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
                         // conservative box: decode (exactly the expression k_pack4q rounded against), then the reference's slab test
-                        const float lx = fmaf((float)((qlx >> (8 * k)) & 0xffu), sx, gx), hx = fmaf((float)((qhx >> (8 * k)) & 0xffu), sx, gx);
-                        const float ly = fmaf((float)((qly >> (8 * k)) & 0xffu), sy, gy), hy = fmaf((float)((qhy >> (8 * k)) & 0xffu), sy, gy);
-                        const float lz = fmaf((float)((qlz >> (8 * k)) & 0xffu), sz, gz), hz = fmaf((float)((qhz >> (8 * k)) & 0xffu), sz, gz);
-                        const float ax = (lx - ox) * ix, bx = (hx - ox) * ix;
-                        const float ay = (ly - oy) * iy, by = (hy - oy) * iy;
-                        const float az = (lz - oz) * iz, bz = (hz - oz) * iz;
-                        const float tn = fmaxf(fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz)), t_min);
-                        const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
-                        const bool ok = ref[k] != 0x7fffffff && tf > tn && t_max > tn;
+                        // near / far plane of each axis picked by the sign of the direction (nqx = the byte word holding the planes the ray meets first):
+                        // (near - o) * inv <= (far - o) * inv exactly as min / max of the two products would give; an unused entry has lo = 255 > hi = 0
+                        // on every axis, hence tn > tf and it fails by itself
+                        const float nx = (fmaf((float)((nqx >> (8 * k)) & 0xffu), sx, gx) - ox) * ix, fx_ = (fmaf((float)((fqx >> (8 * k)) & 0xffu), sx, gx) - ox) * ix;
+                        const float ny = (fmaf((float)((nqy >> (8 * k)) & 0xffu), sy, gy) - oy) * iy, fy_ = (fmaf((float)((fqy >> (8 * k)) & 0xffu), sy, gy) - oy) * iy;
+                        const float nz = (fmaf((float)((nqz >> (8 * k)) & 0xffu), sz, gz) - oz) * iz, fz_ = (fmaf((float)((fqz >> (8 * k)) & 0xffu), sz, gz) - oz) * iz;
+                        const float tn = fmaxf(fmaxf(fmaxf(nx, ny), nz), t_min);
+                        const float tf = fminf(fminf(fx_, fy_), fz_);
+                        const bool ok = tf > tn && t_max > tn;
                         if (COUNT && ref[k] != 0x7fffffff) c_boxes++;
                         if (ok) {
                             if (next == 0x7fffffff) { next = ref[k]; next_tn = tn; }
@@ -652,22 +654,21 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_closest4(BvhView B, co
                     } else {
                         const float gx = __uint_as_float(h0.x), gy = __uint_as_float(h0.y), gz = __uint_as_float(h0.z);
                         const float sx = __uint_as_float((h0.w & 0xffu) << 23), sy = __uint_as_float((h0.w & 0xff00u) << 15), sz = __uint_as_float((h0.w & 0xff0000u) << 7);
-                        const uint32_t qlx = h1.x, qly = h1.y, qlz = h1.z, qhx = h1.w, qhy = h2.x, qhz = h2.y;
+                        const uint32_t nqx = ix >= 0.f ? h1.x : h1.w, fqx = ix >= 0.f ? h1.w : h1.x;
+                        const uint32_t nqy = iy >= 0.f ? h1.y : h2.x, fqy = iy >= 0.f ? h2.x : h1.y;
+                        const uint32_t nqz = iz >= 0.f ? h1.z : h2.y, fqz = iz >= 0.f ? h2.y : h1.z;
                         const int ref[4] = {(int)rf.x, (int)rf.y, (int)rf.z, (int)rf.w};
                         // children that may still hold something nearer, kept in descending entry distance (n <= 4)
                         int nref[4]; float ntn[4]; int nn = 0;
 #pragma unroll
                         for (int k = 0; k < 4; k++) {
-                            const float lx = fmaf((float)((qlx >> (8 * k)) & 0xffu), sx, gx), hx = fmaf((float)((qhx >> (8 * k)) & 0xffu), sx, gx);
-                            const float ly = fmaf((float)((qly >> (8 * k)) & 0xffu), sy, gy), hy = fmaf((float)((qhy >> (8 * k)) & 0xffu), sy, gy);
-                            const float lz = fmaf((float)((qlz >> (8 * k)) & 0xffu), sz, gz), hz = fmaf((float)((qhz >> (8 * k)) & 0xffu), sz, gz);
-                            const float ax = (lx - ox) * ix, bx = (hx - ox) * ix;
-                            const float ay = (ly - oy) * iy, by = (hy - oy) * iy;
-                            const float az = (lz - oz) * iz, bz = (hz - oz) * iz;
-                            float tn = fmaxf(fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz)), t_min);
-                            const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+                            const float nx = (fmaf((float)((nqx >> (8 * k)) & 0xffu), sx, gx) - ox) * ix, fx_ = (fmaf((float)((fqx >> (8 * k)) & 0xffu), sx, gx) - ox) * ix;
+                            const float ny = (fmaf((float)((nqy >> (8 * k)) & 0xffu), sy, gy) - oy) * iy, fy_ = (fmaf((float)((fqy >> (8 * k)) & 0xffu), sy, gy) - oy) * iy;
+                            const float nz = (fmaf((float)((nqz >> (8 * k)) & 0xffu), sz, gz) - oz) * iz, fz_ = (fmaf((float)((fqz >> (8 * k)) & 0xffu), sz, gz) - oz) * iz;
+                            float tn = fmaxf(fmaxf(fmaxf(nx, ny), nz), t_min);          // near / far planes by the sign of the direction (see k_trace_any4q)
+                            const float tf = fminf(fminf(fx_, fy_), fz_);
                             if (COUNT && ref[k] != NONE) c_boxes++;
-                            if (ref[k] != NONE && tf > tn && closest > tn) {
+                            if (tf > tn && closest > tn) {
                                 int r = ref[k];
 #pragma unroll
                                 for (int q = 0; q < 4; q++) {
