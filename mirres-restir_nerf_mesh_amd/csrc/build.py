@@ -20,6 +20,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # for one 16-lane pass while another wave's v_mfma was in flight (found by tests/test_gpu_fullsize.py::test_schedule_does_not_change_the_frame;
 # bisected to exactly this: no MFMA -> clean, no v_pk_* in the neighbour kernels -> clean). DESIGN.md §Two streams.
 PER_FILE = {f: ["-fno-slp-vectorize"] for f in ("passes.hip", "shading.hip", "bvh_trace.hip", "bvh_build.hip", "eaw.hip", "render.hip", "backward.hip", "normal.hip", "matnet.hip")}
+# matnet.hip: MFMA accumulators in VGPRs (no v_accvgpr_read between the layers of the register-chained MLP: -15 % VALU in k_mlp_mfma)
+PER_FILE["matnet.hip"] += ["-mllvm", "-amdgpu-mfma-vgpr-form"]
 
 
 def _newer(a, deps):
@@ -40,7 +42,7 @@ def build(force=False, verbose=True):
 
     def cc(job):
         src, obj = job
-        cmd = [HIPCC] + FLAGS + PER_FILE.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
+        cmd = [HIPCC] + FLAGS + PER_FILE.get(os.path.basename(src), []) + (os.environ.get("MIRRES_MATNET_FLAGS", "").split() if os.path.basename(src) == "matnet.hip" else []) + ["-c", src, "-o", obj]
         if verbose:
             print("[mirres build]", os.path.basename(src), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

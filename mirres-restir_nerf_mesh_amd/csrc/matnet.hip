@@ -173,8 +173,24 @@ MR_DEV int mfma_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 *
 // MODE 0: features given (enc_in fp16 [n,32]) -> out6[n,6];  MODE 1: positions of the compacted pixel list -> scatter kd / (rough, metal)
 // NT = 32-point tiles per wave, processed in lock-step so that NT independent accumulator chains keep the matrix pipe busy while the
 // previous MFMA of the same chain drains (a dependent 32x32x16 MFMA cannot issue back-to-back).
-MR_DEV float relu1(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, __builtin_huge_valf()); }  // one v_med3 (fmaxf costs an extra canonicalising max); no inline asm: the MFMA->VALU hazard tracking must see the read
+// ReLU + hi/lo split of eight accumulator values, four VALU ops per value and none of them packed-fp32 (hazard note):
+//   r  = max_i32(bits(x), 0)      ReLU on the bit pattern: a negative float is a negative integer (one v_max_i32, no canonicalising max);
+//   hi = r & 0xffffe000           the value truncated to an 11-bit significand: exactly representable in fp16 (normal range);
+//   lo = r - hi                   exact in fp32 (< 2^-10 r, 13 significant bits), rounded to fp16 by the packing conversion: |x - hi - lo| <= 2^-21 |x|;
+// both halves leave through v_cvt_pk_f16_f32 (two values per instruction).
+MR_DEV void relu_split8(const f32x16_t& acc, int first, half8_t& hi, half8_t& lo) {
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        const int r = max(__float_as_int(acc[first + t]), 0);
+        const float h = __int_as_float(r & (int)0xffffe000u);
+        hi[t] = (_Float16)h; lo[t] = (_Float16)(__int_as_float(r) - h);
+    }
+}
 
+// sigmoid of the MFMA kernels: v_exp_f32 + v_rcp_f32 (each 1 ulp; the scaled argument adds |x| * 6e-8 relative) instead of libm expf and an
+// IEEE division — 6 instead of ~30 VALU instructions per output, |error| < 2e-6 relative against the per-lane kernel's 1 / (1 + expf(-x)).
+// The outputs are continuous shading parameters (no decision hangs on the last bits), three orders of magnitude inside the 1e-3 parity bar.
+#define MR_SIGMOID(x) __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * (x)))
 template <int MODE, int NT>
 __global__ void __launch_bounds__(MR_BLOCK) k_mlp_mfma(MatNetD M, GridLevels L, const uint16_t* __restrict__ enc_in, const float* __restrict__ pos,
                                                        const int32_t* __restrict__ index, const uint32_t* __restrict__ d_count, int n_fixed,
@@ -203,6 +219,27 @@ __global__ void __launch_bounds__(MR_BLOCK) k_mlp_mfma(MatNetD M, GridLevels L, 
             split8(w8, wh[l][kk], wl[l][kk]);
         }
     }
+    int prow[NT];
+    half8_t f[NT][2];
+#pragma unroll
+    for (int mt = 0; mt < NT; mt++) prow[mt] = wave * NT * 32 + mt * 32 + j;       // the point this lane carries in the B operand / accumulator column
+    // MODE 0 streams the features from HBM: the fragments of the next batch are requested as soon as layer 0 has consumed the current ones,
+    // so the load latency hides behind layers 1, 2 and the epilogue
+    auto fetch = [&](int base_) {
+#pragma unroll
+        for (int mt = 0; mt < NT; mt++) {
+            const int q = base_ + prow[mt];
+#pragma unroll
+            for (int kk = 0; kk < 2; kk++) {
+                if (q < n) f[mt][kk] = *reinterpret_cast<const half8_t*>(enc_in + 32 * (size_t)q + kk * 16 + half * 8);
+                else {
+#pragma unroll
+                    for (int t = 0; t < 8; t++) f[mt][kk][t] = (_Float16)0.f;
+                }
+            }
+        }
+    };
+    if (MODE == 0) fetch(blockIdx.x * PTS);
     for (int base = blockIdx.x * PTS; base < n; base += gridDim.x * PTS) {
         int pix = 0;
         if (MODE == 1) {   // NT == 2: one point per thread
@@ -215,22 +252,14 @@ __global__ void __launch_bounds__(MR_BLOCK) k_mlp_mfma(MatNetD M, GridLevels L, 
             for (int q = 0; q < 32; q++) fRow[q] = valid ? enc[q] : __float2half(0.f);
             __syncthreads();
         }
-        int prow[NT], p[NT];
+        int p[NT];
         f32x16_t acc[NT];
-        half8_t f[NT][2];
 #pragma unroll
         for (int mt = 0; mt < NT; mt++) {
-            prow[mt] = wave * NT * 32 + mt * 32 + j;       // the point this lane carries in the B operand / accumulator column
             p[mt] = base + prow[mt];
+            if (MODE == 1) {
 #pragma unroll
-            for (int kk = 0; kk < 2; kk++) {
-                if (MODE == 0) {
-                    if (p[mt] < n) f[mt][kk] = *reinterpret_cast<const half8_t*>(enc_in + 32 * (size_t)p[mt] + kk * 16 + half * 8);
-                    else {
-#pragma unroll
-                        for (int t = 0; t < 8; t++) f[mt][kk][t] = (_Float16)0.f;
-                    }
-                } else f[mt][kk] = *reinterpret_cast<const half8_t*>(sF + (size_t)prow[mt] * MR_FROW + kk * 16 + half * 8);
+                for (int kk = 0; kk < 2; kk++) f[mt][kk] = *reinterpret_cast<const half8_t*>(sF + (size_t)prow[mt] * MR_FROW + kk * 16 + half * 8);
             }
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[mt][r] = 0.f;
@@ -243,6 +272,7 @@ __global__ void __launch_bounds__(MR_BLOCK) k_mlp_mfma(MatNetD M, GridLevels L, 
 #pragma unroll
             for (int mt = 0; mt < NT; mt++) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[0][kk], f[mt][kk], acc[mt], 0, 0, 0);
         }
+        if (MODE == 0) fetch(base + gridDim.x * PTS);
         // ---- layers 1, 2: ReLU + hi/lo split of the accumulator = next B operand
 #pragma unroll
         for (int l = 1; l < 3; l++) {
@@ -251,10 +281,7 @@ __global__ void __launch_bounds__(MR_BLOCK) k_mlp_mfma(MatNetD M, GridLevels L, 
             for (int mt = 0; mt < NT; mt++) {
 #pragma unroll
                 for (int kk = 0; kk < 2; kk++) {
-                    float x8[8];
-#pragma unroll
-                    for (int t = 0; t < 8; t++) x8[t] = relu1(acc[mt][kk * 8 + t]);
-                    split8(x8, xh[mt][kk], xl[mt][kk]);
+                    relu_split8(acc[mt], kk * 8, xh[mt][kk], xl[mt][kk]);
                 }
 #pragma unroll
                 for (int r = 0; r < 16; r++) acc[mt][r] = 0.f;
@@ -269,28 +296,32 @@ __global__ void __launch_bounds__(MR_BLOCK) k_mlp_mfma(MatNetD M, GridLevels L, 
                 for (int mt = 0; mt < NT; mt++) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[l][kk], xl[mt][kk], acc[mt], 0, 0, 0);
             }
         }
-        // ---- epilogue: rows 0..5 are the outputs: lanes 0-31 hold rows 0-3 (regs 0-3), lanes 32-63 rows 4,5 (regs 0,1)
+        // ---- epilogue: rows 0..5 are the outputs: lanes 0-31 hold rows 0-3 (regs 0-3), lanes 32-63 rows 4,5 (regs 0,1). Three sigmoids per
+        // lane and tile: the lower half takes channels 0-2 (kd), the upper half channels 3-5 (channel 3 comes over from lane j; MODE 1 has no
+        // use for it and skips the shuffle)
 #pragma unroll
         for (int mt = 0; mt < NT; mt++) {
             int px = 0;
             if (MODE == 1) px = __shfl(pix, mt * 32 + j, 64);   // pixel id lives in the thread that encoded the point (same wave, lane mt*32+j)
+            float a3 = 0.f;
+            if (MODE == 0) a3 = __shfl(acc[mt][3], j, 64);
+            const float a[3] = {half ? a3 : acc[mt][0], half ? acc[mt][0] : acc[mt][1], half ? acc[mt][1] : acc[mt][2]};
             if (p[mt] < n) {
-                const int nrow = half == 0 ? 4 : 2;
-                float o[4];
+                float o[3];
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int ch = r + 4 * half;
-                    const int c2 = ch < 6 ? ch : 5;
-                    float sg = 1.0f / (1.0f + expf(-acc[mt][r]));
-                    o[r] = sg * (M.mx[c2] - M.mn[c2]) + M.mn[c2];
+                for (int r = 0; r < 3; r++) {
+                    const float lo_ = half ? M.mn[3 + r] : M.mn[r], hi_ = half ? M.mx[3 + r] : M.mx[r];
+                    float sg = MR_SIGMOID(a[r]);
+                    o[r] = sg * (hi_ - lo_) + lo_;
                 }
                 if (MODE == 0) {
-                    for (int r = 0; r < nrow; r++) out6[6 * (size_t)p[mt] + r + 4 * half] = o[r];
+#pragma unroll
+                    for (int r = 0; r < 3; r++) out6[6 * (size_t)p[mt] + 3 * half + r] = o[r];
                 } else if (half == 0) {
                     float a0 = o[0], a1 = o[1], a2 = o[2];
                     if (use_scale) { a0 = fminf(fmaxf(a0 * sx, 0.f), 1.f); a1 = fminf(fmaxf(a1 * sy, 0.f), 1.f); a2 = fminf(fmaxf(a2 * sz, 0.f), 1.f); }
                     kd[3 * (size_t)px] = a0; kd[3 * (size_t)px + 1] = a1; kd[3 * (size_t)px + 2] = a2;
-                } else { rm[2 * (size_t)px] = o[0]; rm[2 * (size_t)px + 1] = o[1]; }
+                } else { rm[2 * (size_t)px] = o[1]; rm[2 * (size_t)px + 1] = o[2]; }
             }
         }
         if (MODE == 1) __syncthreads();
@@ -372,7 +403,8 @@ int mirres_matnet_fwd(const mirres_matnet_t* m, const float* pos, int n, float* 
 int mirres_matnet_mlp(const mirres_matnet_t* m, const uint16_t* enc, int n, float* out, void* stream) {
     if (!m || !enc || !out || n < 0) { set_error("mirres_matnet_mlp: bad argument"); return MIRRES_E_ARG; }
     if (n == 0) return MIRRES_OK;
-    int g = grid_for(n, 256); if (g > 256 * 8) g = 256 * 8;      // 2 tiles (64 points) per wave
+    static const int cap = [] { const char* e = getenv("MIRRES_MLP_GRID"); return e ? atoi(e) : 256 * 3; }();   // 3 resident blocks per CU (~160 registers per lane): every block stages and splits the weights once
+    int g = grid_for(n, 256); if (g > cap) g = cap;      // 2 tiles (64 points) per wave
     k_mlp_mfma<0, 2><<<g, MR_BLOCK, 0, (hipStream_t)stream>>>(matd(m), host_levels(nullptr), enc, nullptr, nullptr, nullptr, n, out, nullptr, nullptr, 0, 1.f, 1.f, 1.f);
     MR_LAUNCH_CHECK("matnet_mlp");
     return MIRRES_OK;

@@ -1,25 +1,21 @@
 #!/bin/bash
+# SQ counters of the MLP GEMM-phase kernel (scripts/dev_mlp_bench.py), averages per launch
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-python3 scripts/dev_mlp_bench.py 2>&1 | tail -2
-rm -rf gpurun_out/pk; mkdir -p gpurun_out/pk
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pk -o k -- python3 scripts/dev_mlp_bench.py > gpurun_out/pk/log 2>&1
-grep -E 'k_mlp_mfma|k_matnet_fwd' gpurun_out/pk/k_kernel_stats.csv | cut -c1-60,200-330
-rm -rf gpurun_out/pk
-rm -rf gpurun_out/pm; mkdir -p gpurun_out/pm
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE SQ_INSTS_MFMA --output-format csv -d gpurun_out/pm -o p -- python3 scripts/dev_mlp_bench.py > gpurun_out/pm/log 2>&1
+rm -rf gpurun_out/pm; mkdir -p gpurun_out/pm gpurun_out/out
+rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_SALU --output-format csv -d gpurun_out/pm -o p -- python3 scripts/dev_mlp_bench.py > gpurun_out/pm/log 2>&1
+rocprofv3 --pmc SQ_INST_CYCLES_VMEM SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS GRBM_GUI_ACTIVE SQ_WAVES --output-format csv -d gpurun_out/pm/b -o p -- python3 scripts/dev_mlp_bench.py > gpurun_out/pm/log2 2>&1
 python3 - <<'PY'
 import csv, glob, collections
 fs = glob.glob('gpurun_out/pm/**/*counter_collection.csv', recursive=True)
-if not fs: print(open('gpurun_out/pm/log').read()[-600:])
-else:
-    agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
-    for r in csv.DictReader(open(fs[0])):
-        if 'k_mlp_mfma' not in r['Kernel_Name']: continue
-        a = agg['k_mlp_mfma'][r['Counter_Name']]; a[0] += float(r['Counter_Value']); a[1] += 1
-    for k, cs in agg.items():
-        v = {c: x[0] / x[1] for c, x in cs.items()}
-        print(k, {c: round(x) for c, x in v.items()})
-        if 'SQ_VALU_MFMA_BUSY_CYCLES' in v and 'GRBM_GUI_ACTIVE' in v:
-            print("MfmaUtil = MFMA_BUSY / (GUI_ACTIVE * 1024 SIMDs) = %.1f %%" % (100 * v['SQ_VALU_MFMA_BUSY_CYCLES'] / (v['GRBM_GUI_ACTIVE'] * 1024)))
+if not fs: print(open('gpurun_out/pm/log').read()[-1500:])
+agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0,0]))
+for fn in fs:
+    for r in csv.DictReader(open(fn)):
+        k = r['Kernel_Name'].split('(')[0].replace('void ','').replace('mr::','')[:28]
+        a = agg[k][r['Counter_Name']]; a[0] += float(r['Counter_Value']); a[1] += 1
+for k, cs in agg.items():
+    if 'mlp_mfma' not in k: continue
+    print(k, {c: round(x[0]/x[1]/1e6, 3) for c, x in cs.items()}, 'launches', list(cs.values())[0][1])
 PY
+tail -3 gpurun_out/pm/log | cut -c1-300
 rm -rf gpurun_out/pm
