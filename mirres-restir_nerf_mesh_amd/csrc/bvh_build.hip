@@ -488,7 +488,7 @@ int mirres_bvh_create(mirres_bvh_t** out, int max_tris) {
     MR_HIP(hipMalloc(&b->top85q, sizeof(Node4q) * 85));
     MR_HIP(hipMalloc(&b->top341q, sizeof(Node4q) * 341));
     MR_HIP(hipMalloc(&b->root_box, sizeof(float) * 8));
-    MR_HIP(hipMalloc(&b->work, sizeof(uint32_t) * 10 * MR_WSET));
+    MR_HIP(hipMalloc(&b->work, sizeof(uint32_t) * 12 * MR_WSET));
     size_t tmp = 0;
     MR_HIP(rocprim::radix_sort_pairs(nullptr, tmp, b->keys_in, b->keys_out, b->vals_in, b->vals_out, T, 0, 32, 0));
     b->sort_tmp_bytes = tmp;

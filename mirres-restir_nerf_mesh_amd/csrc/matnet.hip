@@ -4,10 +4,9 @@
 // tiny-cuda-nn is an un-vendored, un-pinned dependency of the reference (readme.md:30); its published algorithm is
 // implemented here: 16 levels x 2 features, T = 2^19, base 16, per-level scale exp(ln(256)/15); levels 0-4 dense,
 // 5-15 hashed with primes (1, 2654435761, 805459861); pos = fmaf(scale, x, 0.5); fp16 table, fp16 accumulation of the
-// 8-corner interpolation; features level-major. The MLP runs in fp32 exactly like the reference's torch.nn.Linear
-// stack: each output is a k-ordered fmaf chain, which is also the exact semantics of v_mfma_f32_32x32x2_f32
-// (MI355X guide: "bit-for-bit a k-ordered f32 fmaf chain"), so the MFMA-tiled kernel and this per-lane kernel agree
-// bitwise.
+// 8-corner interpolation; features level-major. The MLP runs in fp32 like the reference's torch.nn.Linear stack: the
+// per-lane kernels (k_matnet_fwd / k_matnet_scatter) evaluate each output as a k-ordered fmaf chain; the MFMA-tiled kernel
+// (k_mlp_mfma, the production path) reproduces it to ~1e-6 with hi/lo-split fp16 operands on the matrix pipe.
 #include "engine.hpp"
 #include "device_math.hpp"
 #include <hip/hip_fp16.h>

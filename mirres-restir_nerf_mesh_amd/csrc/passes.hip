@@ -659,7 +659,9 @@ void mirres_ctx_destroy(mirres_ctx_t* c) {
     for (hipEvent_t e : c->ev_sync) (void)hipEventDestroy(e);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->ev_join_pt) (void)hipEventDestroy(c->ev_join_pt);
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
+    if (c->pt_stream) (void)hipStreamDestroy(c->pt_stream);
     delete c;
 }
 

@@ -167,7 +167,8 @@ static int carve(mirres_ctx* ctx, int Wc, int Hc, FrameBufs& B) {
 
 // K-sample batch of the path-tracing stages: queues + per-slot path state for K * N sample slots, one allocation kept in the context
 struct PtBatch {
-    int K; PtQueues q;
+    int K; PtQueues q;   // path-tracing stages
+    PtQueues qf;         // initial / final-visibility stages (their own rays, results and counter: they may run beside the path-tracing stages)
     float *prd, *pos[2], *rd[2], *occ[2], *n[2], *kd, *rm;
     float* cb;      // [max_bounce][3][K * N * 3] per-bounce colour / diffuse / specular of every slot
     uint32_t* maskb; // [max_bounce][K * N] per-bounce ray/colour masks (k_bounce_gen)
@@ -183,7 +184,7 @@ static int pt_batch_size() {   // MIRRES_PT_BATCH = samples per path-tracing lau
     int k = e ? atoi(e) : 16; if (k < 1) k = 1; if (k > 64) k = 64;
     return k;
 }
-static bool use_two_streams() { const char* e = getenv("MIRRES_STREAMS"); return !(e && e[0] == '1'); }   // MIRRES_STREAMS=1: everything on the caller's stream
+static int stream_count() { const char* e = getenv("MIRRES_STREAMS"); const int n = e ? atoi(e) : 3; return n < 1 ? 1 : (n > 3 ? 3 : n); }   // 1: everything on the caller's stream; 2: one bulk stream; 3 (default): path tracing on its own
 static int carve_batch(mirres_ctx* ctx, int N, int K, int max_bounce, size_t TS, PtBatch& PB) {
     if (K < 1) K = 1;
     while ((size_t)K * (size_t)N > 0x30000000ull && K > 1) K--;   // slot indices are 32-bit
@@ -192,7 +193,8 @@ static int carve_batch(mirres_ctx* ctx, int N, int K, int max_bounce, size_t TS,
     const int nb = max_bounce > 0 ? max_bounce : 1;
     size_t need = al(sizeof(Ray) * 2 * NV) + al(4 * 2 * NV) + al(sizeof(Ray) * NV) + al(sizeof(HitRec) * NV) + al(64) + 3 * al(4 * NV) + al(4 * 18 * NV)
                 + al(4 * 5 * NV) + 2 * (3 * al(4 * 3 * NV) + al(4 * NV)) + al(4 * 3 * NV) + al(4 * 2 * NV) + al(4 * 9 * NV * (size_t)nb) + al(4 * NV * (size_t)nb)
-                + 4 * al(4 * 8 * NV) + al(4 * 3 * (size_t)K * TS) + al(4 * (size_t)K * TS) + al(16 * (size_t)K * TS);
+                + 4 * al(4 * 8 * NV) + al(4 * 3 * (size_t)K * TS) + al(4 * (size_t)K * TS) + al(16 * (size_t)K * TS)
+                + al(sizeof(Ray) * NV) + 2 * al(4 * NV) + al(64);
     if (ctx->ptb_bytes < need) {
         if (ctx->ptb) { MR_HIP(hipDeviceSynchronize()); MR_HIP(hipFree(ctx->ptb)); ctx->ptb = nullptr; ctx->ptb_bytes = 0; }
         MR_HIP(hipMalloc(&ctx->ptb, need));
@@ -218,6 +220,9 @@ static int carve_batch(mirres_ctx* ctx, int N, int K, int max_bounce, size_t TS,
         r.light_data = (float*)take(4 * 8 * NV); r.light_pdf = nullptr; r.M = nullptr; r.weight = nullptr;
     }
     PB.tile_data = (float*)take(4 * 3 * (size_t)K * TS); PB.tile_pdf = (float*)take(4 * (size_t)K * TS); PB.tile_aux = (float*)take(16 * (size_t)K * TS);
+    PB.qf = PB.q;
+    PB.qf.any_rays = (Ray*)take(sizeof(Ray) * NV); PB.qf.any_hit = (int32_t*)take(4 * NV); PB.qf.slot_a = (int32_t*)take(4 * NV); PB.qf.counters = (uint32_t*)take(64);
+    PB.qf.cl_rays = nullptr; PB.qf.cl_hit = nullptr; PB.qf.mask_a = nullptr; PB.qf.slot_c = nullptr; PB.qf.pend = nullptr;
     return 0;
 }
 
@@ -315,14 +320,19 @@ int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args
     //   I(b)  initial resampling of the K samples (light tiles, candidates, shadow rays)              bulk stream, K * N slots per launch
     //   C(b)  temporal + spatial reuse, one sample after the other (needs the previous sample)        caller's stream, N pixels per launch
     //   F(b)  final visibility + evaluation + shading of the K samples -> totals 0..2                 bulk stream
-    //   PT(b) new direction + max_bounce indirect vertices of the K samples -> totals 3..5            bulk stream
-    // The branches share only read-only inputs (G-buffer, environment tables, BVH). The bulk stream's large launches fill the CUs the small
-    // sample-by-sample launches of the chain leave idle (a 2.3 M-ray traversal launch idles a third of the chip in its tail), and the launch
-    // gaps of one stream are covered by the other. Reservoir sets alternate with the batch parity; hand-offs are events:
-    //   bulk:   wait C(b-1) | F(b-1) | I(b+1) | signal | PT(b)            chain:  wait signal(b-1) | C(b) | signal
-    // Instrumented frames (counters / per-launch event timing) and MIRRES_STREAMS=1 run the same sequence on one stream.
-    hipStream_t sp = s;
-    const bool two_streams = use_two_streams() && ctx->instrument == 0;
+    //   PT(b) new direction + max_bounce indirect vertices of the K samples -> totals 3..5            path-tracing stream
+    // The branches share only read-only inputs (G-buffer, environment tables, BVH). The large launches of the bulk and path-tracing streams
+    // fill the CUs the small sample-by-sample launches of the chain leave idle (a 2.3 M-ray traversal launch idles a third of the chip in its
+    // tail), and the launch gaps and kernel tails of one stream are covered by the others. Reservoir sets alternate with the batch parity;
+    // hand-offs are events:
+    //   bulk:   wait C(b-1) | F(b-1) | I(b+1) | signal          chain:  wait signal(b-1) | C(b) | signal          path tracing: PT(0) PT(1) ...
+    // PT(b) reads nothing the ReSTIR stages write (its own rays, queues and totals 3..5), so only the frame's start and end order it against
+    // them. Every stream works on its own traversal head set (bvh_trace.hip) and no kernel accumulates across streams, so the frame is
+    // bit-identical for any stream count and batch size (tests/test_gpu_fullsize.py). MIRRES_STREAMS=2 puts PT(b) behind I(b+1) on the bulk
+    // stream; instrumented frames (counters / per-launch event timing) and MIRRES_STREAMS=1 run the same sequence on one stream.
+    hipStream_t sp = s, st = s;   // sp: I / F stages, st: path-tracing stages
+    const int nstreams = ctx->instrument == 0 ? stream_count() : 1;
+    const bool two_streams = nstreams >= 2;
     const int nbatch = (i1 - i0 + PB.K - 1) / PB.K;
     if (two_streams) {
         if (!ctx->aux_stream) {
@@ -330,16 +340,22 @@ int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args
             MR_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming)); MR_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
         }
         while ((int)ctx->ev_sync.size() < 2 * (nbatch + 1)) { hipEvent_t e; MR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ctx->ev_sync.push_back(e); }
-        sp = ctx->aux_stream;
+        sp = st = ctx->aux_stream;
         MR_HIP(hipEventRecord(ctx->ev_fork, s)); MR_HIP(hipStreamWaitEvent(sp, ctx->ev_fork, 0));
-        PB.q.lane = 1;
+        PB.q.lane = PB.qf.lane = 1;
+        if (nstreams >= 3) {   // the path-tracing stages read only the G-buffer: nothing orders them against the ReSTIR stages but the frame's start and end
+            if (!ctx->pt_stream) { MR_HIP(hipStreamCreateWithFlags(&ctx->pt_stream, hipStreamNonBlocking)); MR_HIP(hipEventCreateWithFlags(&ctx->ev_join_pt, hipEventDisableTiming)); }
+            st = ctx->pt_stream;
+            MR_HIP(hipStreamWaitEvent(st, ctx->ev_fork, 0));
+            PB.q.lane = 2;
+        }
     }
     auto ev_bulk = [&](int b) { return ctx->ev_sync[2 * (b + 1)]; };       // bulk stream reached "I(b+1) done" in iteration b (b = -1: I(0))
     auto ev_chain = [&](int b) { return ctx->ev_sync[2 * (b + 1) + 1]; };  // chain C(b) done
     auto batch_k = [&](int b) { const int ib = i0 + b * PB.K; return (i1 - ib < PB.K) ? (i1 - ib) : PB.K; };
     auto initial = [&](int b) -> int {
         const int ib = i0 + b * PB.K;
-        PtQueues Q = PB.q; Q.NV = batch_k(b) * N;
+        PtQueues Q = PB.qf; Q.NV = batch_k(b) * N;
         return launch_initial_batch(ctx, bvh, &E, &G, &PB.rinit[b & 1], PB.tile_data, PB.tile_pdf, PB.tile_aux, a->random_offset + passes * (uint32_t)ib, batch_k(b), &Q, sp);
     };
     const bool dbg_sum = getenv("MIRRES_DBG_SUM") != nullptr;
@@ -353,7 +369,7 @@ int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args
         // ---- bulk stream: F(b-1), I(b+1)
         if (b > 0) {
             if (two_streams) MR_HIP(hipStreamWaitEvent(sp, ev_chain(b - 1), 0));
-            PtQueues Q = PB.q; Q.NV = batch_k(b - 1) * N;
+            PtQueues Q = PB.qf; Q.NV = batch_k(b - 1) * N;
             rc = launch_final_batch(ctx, bvh, &E, occ, a->pos, a->normal, B.ray_dir, a->kd, a->rough_metal, &PB.rspat[(b - 1) & 1], batch_k(b - 1), &Q, B.tot[0], B.tot[1], B.tot[2],
                                     a->tape ? a->tape + 8 * (size_t)N * (size_t)((b - 1) * PB.K) : nullptr, sp);
             if (rc) return rc;
@@ -388,31 +404,32 @@ int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args
         PtQueues Q = PB.q; Q.NV = kk * N; Q.first_sample_is_zero = (ib == 0);
         uint32_t fi = a->random_offset + passes * (uint32_t)ib + 5;   // pass number of new_dir for a sample with a temporal pass before it
         mirres_path_t P0 = {occ, a->pos, a->normal, B.ray_dir, a->kd, a->rough_metal, PB.prd, PB.pos[0], PB.rd[0], PB.occ[0], PB.n[0]};
-        rc = launch_new_dir(ctx, bvh, &P0, fi, 0, sp, &Q); if (rc) return rc;
+        rc = launch_new_dir(ctx, bvh, &P0, fi, 0, st, &Q); if (rc) return rc;
         fi += 5;
         int src = 0;
         for (int bo = 1; bo <= max_bounce; bo++) {
             // material lookup at the new vertices: compacted slot list -> hash-grid gather -> MFMA MLP -> scatter (slot_c is free between passes)
-            if (a->mat && !(getenv("MIRRES_MATNET") && getenv("MIRRES_MATNET")[0] == 'v')) rc = launch_matnet_scatter_mfma(a->mat, PB.occ[src], PB.pos[src], Q.NV, PB.kd, PB.rm, a->use_scale, a->scale, Q.slot_c, &Q.counters[2], sp);
-            else rc = launch_matnet_scatter(a->mat, PB.occ[src], PB.pos[src], Q.NV, PB.kd, PB.rm, a->use_scale, a->scale, a->const_kd, a->const_rm, sp);
+            if (a->mat && !(getenv("MIRRES_MATNET") && getenv("MIRRES_MATNET")[0] == 'v')) rc = launch_matnet_scatter_mfma(a->mat, PB.occ[src], PB.pos[src], Q.NV, PB.kd, PB.rm, a->use_scale, a->scale, Q.slot_c, &Q.counters[2], st);
+            else rc = launch_matnet_scatter(a->mat, PB.occ[src], PB.pos[src], Q.NV, PB.kd, PB.rm, a->use_scale, a->scale, a->const_kd, a->const_rm, st);
             if (rc) return rc;
             mirres_path_t Pb = {PB.occ[src], PB.pos[src], PB.n[src], PB.rd[src], PB.kd, PB.rm, PB.prd, PB.pos[src ^ 1], PB.rd[src ^ 1], PB.occ[src ^ 1], PB.n[src ^ 1]};
             float* cb = PB.cb + (size_t)(bo - 1) * 9 * (size_t)Q.NV;
             Q.mask_a = PB.maskb + (size_t)(bo - 1) * (size_t)Q.NV;      // kept per bounce for k_pt_reduce
-            rc = launch_bounce(ctx, bvh, &E, &Pb, fi, (uint32_t)bo, cb, cb + 3 * (size_t)Q.NV, cb + 6 * (size_t)Q.NV, nullptr, nullptr, nullptr, sp, &Q); if (rc) return rc;
+            rc = launch_bounce(ctx, bvh, &E, &Pb, fi, (uint32_t)bo, cb, cb + 3 * (size_t)Q.NV, cb + 6 * (size_t)Q.NV, nullptr, nullptr, nullptr, st, &Q); if (rc) return rc;
             fi += 5;
             src ^= 1;
         }
-        if (max_bounce > 0) k_pt_reduce<<<grid_for(n3, MR_BLOCK), MR_BLOCK, 0, sp>>>(N, kk, max_bounce, PB.cb, PB.maskb, B.tot[3], B.tot[4], B.tot[5]);
+        if (max_bounce > 0) k_pt_reduce<<<grid_for(n3, MR_BLOCK), MR_BLOCK, 0, st>>>(N, kk, max_bounce, PB.cb, PB.maskb, B.tot[3], B.tot[4], B.tot[5]);
     }
     {   // F(last)
         if (two_streams) MR_HIP(hipStreamWaitEvent(sp, ev_chain(nbatch - 1), 0));
-        PtQueues Q = PB.q; Q.NV = batch_k(nbatch - 1) * N;
+        PtQueues Q = PB.qf; Q.NV = batch_k(nbatch - 1) * N;
         rc = launch_final_batch(ctx, bvh, &E, occ, a->pos, a->normal, B.ray_dir, a->kd, a->rough_metal, &PB.rspat[(nbatch - 1) & 1], batch_k(nbatch - 1), &Q, B.tot[0], B.tot[1], B.tot[2],
                                 a->tape ? a->tape + 8 * (size_t)N * (size_t)((nbatch - 1) * PB.K) : nullptr, sp);
         if (rc) return rc;
     }
     if (two_streams) { MR_HIP(hipEventRecord(ctx->ev_join, sp)); MR_HIP(hipStreamWaitEvent(s, ctx->ev_join, 0)); }
+    if (st != sp) { MR_HIP(hipEventRecord(ctx->ev_join_pt, st)); MR_HIP(hipStreamWaitEvent(s, ctx->ev_join_pt, 0)); }
     if (dbg_sum) {
         std::vector<unsigned long long> h(n_sums);
         MR_HIP(hipStreamSynchronize(s)); MR_HIP(hipMemcpy(h.data(), d_sums, 8 * (size_t)n_sums, hipMemcpyDeviceToHost)); (void)hipFree(d_sums);
