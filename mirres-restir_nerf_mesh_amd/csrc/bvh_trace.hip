@@ -773,7 +773,7 @@ static int trace_grid(size_t capacity) {
 int trace_any_queue(const mirres_bvh* bvh, const Ray* rays, const uint32_t* d_count, size_t capacity, int32_t* hit,
                     unsigned long long* stats, hipStream_t s, int lane, int timed) {
     g_timed_tag = timed;
-    static const int set_of_lane[3] = {0, 7, 9};                     // launches that may overlap on different streams use different head sets
+    static const int set_of_lane[4] = {0, 7, 9, 11};                    // launches that may overlap on different streams use different head sets
     uint32_t* const heads = bvh->work + set_of_lane[lane] * MR_WSET;
     MR_HIP(hipMemsetAsync(heads, 0, MR_WSET * sizeof(uint32_t), s));
     launch_any4q<false>(bvh, persist_grid(capacity), rays, d_count, (uint32_t)capacity, heads, hit, stats, s);
@@ -783,7 +783,7 @@ int trace_any_queue(const mirres_bvh* bvh, const Ray* rays, const uint32_t* d_co
 int trace_closest_queue(const mirres_bvh* bvh, const Ray* rays, const uint32_t* d_count, size_t capacity, HitRec* out,
                         unsigned long long* stats, hipStream_t s, int lane) {
     if (closest_mode() == 4) return closest_fast<false>(const_cast<mirres_bvh*>(bvh), rays, d_count, capacity, out, nullptr, nullptr, nullptr, nullptr, nullptr, stats, s);
-    static const int set_of_lane[3] = {1, 8, 10};
+    static const int set_of_lane[4] = {1, 8, 10, 10};
     uint32_t* const heads = bvh->work + set_of_lane[lane] * MR_WSET;
     MR_HIP(hipMemsetAsync(heads, 0, MR_WSET * sizeof(uint32_t), s));
     k_trace_persist<false><<<persist_grid(capacity), MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, d_count, (uint32_t)capacity, heads, nullptr, out,

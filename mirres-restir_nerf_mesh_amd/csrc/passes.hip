@@ -662,6 +662,8 @@ void mirres_ctx_destroy(mirres_ctx_t* c) {
     if (c->ev_join_pt) (void)hipEventDestroy(c->ev_join_pt);
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     if (c->pt_stream) (void)hipStreamDestroy(c->pt_stream);
+    if (c->ev_join_fin) (void)hipEventDestroy(c->ev_join_fin);
+    if (c->fin_stream) (void)hipStreamDestroy(c->fin_stream);
     delete c;
 }
 

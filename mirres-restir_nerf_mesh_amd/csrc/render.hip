@@ -168,7 +168,7 @@ static int carve(mirres_ctx* ctx, int Wc, int Hc, FrameBufs& B) {
 // K-sample batch of the path-tracing stages: queues + per-slot path state for K * N sample slots, one allocation kept in the context
 struct PtBatch {
     int K; PtQueues q;   // path-tracing stages
-    PtQueues qf;         // initial / final-visibility stages (their own rays, results and counter: they may run beside the path-tracing stages)
+    PtQueues qf, qv;     // initial / final-visibility stages (each its own rays, results and counter: the stages of different batches may run side by side)
     float *prd, *pos[2], *rd[2], *occ[2], *n[2], *kd, *rm;
     float* cb;      // [max_bounce][3][K * N * 3] per-bounce colour / diffuse / specular of every slot
     uint32_t* maskb; // [max_bounce][K * N] per-bounce ray/colour masks (k_bounce_gen)
@@ -184,7 +184,7 @@ static int pt_batch_size() {   // MIRRES_PT_BATCH = samples per path-tracing lau
     int k = e ? atoi(e) : 16; if (k < 1) k = 1; if (k > 64) k = 64;
     return k;
 }
-static int stream_count() { const char* e = getenv("MIRRES_STREAMS"); const int n = e ? atoi(e) : 3; return n < 1 ? 1 : (n > 3 ? 3 : n); }   // 1: everything on the caller's stream; 2: one bulk stream; 3 (default): path tracing on its own
+static int stream_count() { const char* e = getenv("MIRRES_STREAMS"); const int n = e ? atoi(e) : 3; return n < 1 ? 1 : (n > 4 ? 4 : n); }   // 1: everything on the caller's stream; 2: one bulk stream; 3 (default): path tracing on its own; 4: final stages too
 static int carve_batch(mirres_ctx* ctx, int N, int K, int max_bounce, size_t TS, PtBatch& PB) {
     if (K < 1) K = 1;
     while ((size_t)K * (size_t)N > 0x30000000ull && K > 1) K--;   // slot indices are 32-bit
@@ -194,7 +194,7 @@ static int carve_batch(mirres_ctx* ctx, int N, int K, int max_bounce, size_t TS,
     size_t need = al(sizeof(Ray) * 2 * NV) + al(4 * 2 * NV) + al(sizeof(Ray) * NV) + al(sizeof(HitRec) * NV) + al(64) + 3 * al(4 * NV) + al(4 * 18 * NV)
                 + al(4 * 5 * NV) + 2 * (3 * al(4 * 3 * NV) + al(4 * NV)) + al(4 * 3 * NV) + al(4 * 2 * NV) + al(4 * 9 * NV * (size_t)nb) + al(4 * NV * (size_t)nb)
                 + 4 * al(4 * 8 * NV) + al(4 * 3 * (size_t)K * TS) + al(4 * (size_t)K * TS) + al(16 * (size_t)K * TS)
-                + al(sizeof(Ray) * NV) + 2 * al(4 * NV) + al(64);
+                + 2 * (al(sizeof(Ray) * NV) + 2 * al(4 * NV) + al(64));
     if (ctx->ptb_bytes < need) {
         if (ctx->ptb) { MR_HIP(hipDeviceSynchronize()); MR_HIP(hipFree(ctx->ptb)); ctx->ptb = nullptr; ctx->ptb_bytes = 0; }
         MR_HIP(hipMalloc(&ctx->ptb, need));
@@ -223,6 +223,8 @@ static int carve_batch(mirres_ctx* ctx, int N, int K, int max_bounce, size_t TS,
     PB.qf = PB.q;
     PB.qf.any_rays = (Ray*)take(sizeof(Ray) * NV); PB.qf.any_hit = (int32_t*)take(4 * NV); PB.qf.slot_a = (int32_t*)take(4 * NV); PB.qf.counters = (uint32_t*)take(64);
     PB.qf.cl_rays = nullptr; PB.qf.cl_hit = nullptr; PB.qf.mask_a = nullptr; PB.qf.slot_c = nullptr; PB.qf.pend = nullptr;
+    PB.qv = PB.qf;
+    PB.qv.any_rays = (Ray*)take(sizeof(Ray) * NV); PB.qv.any_hit = (int32_t*)take(4 * NV); PB.qv.slot_a = (int32_t*)take(4 * NV); PB.qv.counters = (uint32_t*)take(64);
     return 0;
 }
 
@@ -330,7 +332,7 @@ int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args
     // them. Every stream works on its own traversal head set (bvh_trace.hip) and no kernel accumulates across streams, so the frame is
     // bit-identical for any stream count and batch size (tests/test_gpu_fullsize.py). MIRRES_STREAMS=2 puts PT(b) behind I(b+1) on the bulk
     // stream; instrumented frames (counters / per-launch event timing) and MIRRES_STREAMS=1 run the same sequence on one stream.
-    hipStream_t sp = s, st = s;   // sp: I / F stages, st: path-tracing stages
+    hipStream_t sp = s, st = s, sf = s;   // sp: I stages, sf: F stages, st: path-tracing stages
     const int nstreams = ctx->instrument == 0 ? stream_count() : 1;
     const bool two_streams = nstreams >= 2;
     const int nbatch = (i1 - i0 + PB.K - 1) / PB.K;
@@ -339,19 +341,26 @@ int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args
             MR_HIP(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
             MR_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming)); MR_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
         }
-        while ((int)ctx->ev_sync.size() < 2 * (nbatch + 1)) { hipEvent_t e; MR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ctx->ev_sync.push_back(e); }
-        sp = st = ctx->aux_stream;
+        while ((int)ctx->ev_sync.size() < 3 * (nbatch + 1)) { hipEvent_t e; MR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ctx->ev_sync.push_back(e); }
+        sp = st = sf = ctx->aux_stream;
         MR_HIP(hipEventRecord(ctx->ev_fork, s)); MR_HIP(hipStreamWaitEvent(sp, ctx->ev_fork, 0));
-        PB.q.lane = PB.qf.lane = 1;
+        PB.q.lane = PB.qf.lane = PB.qv.lane = 1;
         if (nstreams >= 3) {   // the path-tracing stages read only the G-buffer: nothing orders them against the ReSTIR stages but the frame's start and end
             if (!ctx->pt_stream) { MR_HIP(hipStreamCreateWithFlags(&ctx->pt_stream, hipStreamNonBlocking)); MR_HIP(hipEventCreateWithFlags(&ctx->ev_join_pt, hipEventDisableTiming)); }
             st = ctx->pt_stream;
             MR_HIP(hipStreamWaitEvent(st, ctx->ev_fork, 0));
             PB.q.lane = 2;
         }
+        if (nstreams >= 4) {
+            if (!ctx->fin_stream) { MR_HIP(hipStreamCreateWithFlags(&ctx->fin_stream, hipStreamNonBlocking)); MR_HIP(hipEventCreateWithFlags(&ctx->ev_join_fin, hipEventDisableTiming)); }
+            sf = ctx->fin_stream;
+            MR_HIP(hipStreamWaitEvent(sf, ctx->ev_fork, 0));
+            PB.qv.lane = 3;
+        }
     }
-    auto ev_bulk = [&](int b) { return ctx->ev_sync[2 * (b + 1)]; };       // bulk stream reached "I(b+1) done" in iteration b (b = -1: I(0))
-    auto ev_chain = [&](int b) { return ctx->ev_sync[2 * (b + 1) + 1]; };  // chain C(b) done
+    auto ev_bulk = [&](int b) { return ctx->ev_sync[3 * (b + 1)]; };       // bulk stream reached "I(b+1) done" in iteration b (b = -1: I(0))
+    auto ev_chain = [&](int b) { return ctx->ev_sync[3 * (b + 1) + 1]; };  // chain C(b) done
+    auto ev_fin = [&](int b) { return ctx->ev_sync[3 * (b + 1) + 2]; };    // F(b) done (only when the final stages have their own stream)
     auto batch_k = [&](int b) { const int ib = i0 + b * PB.K; return (i1 - ib < PB.K) ? (i1 - ib) : PB.K; };
     auto initial = [&](int b) -> int {
         const int ib = i0 + b * PB.K;
@@ -366,18 +375,20 @@ int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args
     if (two_streams) MR_HIP(hipEventRecord(ev_bulk(-1), sp));
     for (int b = 0; b < nbatch; b++) {
         const int ib = i0 + b * PB.K, kk = batch_k(b);
-        // ---- bulk stream: F(b-1), I(b+1)
+        // ---- bulk stream(s): F(b-1), I(b+1)
         if (b > 0) {
-            if (two_streams) MR_HIP(hipStreamWaitEvent(sp, ev_chain(b - 1), 0));
-            PtQueues Q = PB.qf; Q.NV = batch_k(b - 1) * N;
+            if (two_streams) { MR_HIP(hipStreamWaitEvent(sp, ev_chain(b - 1), 0)); if (sf != sp) MR_HIP(hipStreamWaitEvent(sf, ev_chain(b - 1), 0)); }
+            PtQueues Q = PB.qv; Q.NV = batch_k(b - 1) * N;
             rc = launch_final_batch(ctx, bvh, &E, occ, a->pos, a->normal, B.ray_dir, a->kd, a->rough_metal, &PB.rspat[(b - 1) & 1], batch_k(b - 1), &Q, B.tot[0], B.tot[1], B.tot[2],
-                                    a->tape ? a->tape + 8 * (size_t)N * (size_t)((b - 1) * PB.K) : nullptr, sp);
+                                    a->tape ? a->tape + 8 * (size_t)N * (size_t)((b - 1) * PB.K) : nullptr, sf);
             if (rc) return rc;
+            if (sf != sp) MR_HIP(hipEventRecord(ev_fin(b - 1), sf));
         }
         if (b + 1 < nbatch) { rc = initial(b + 1); if (rc) return rc; }
         if (two_streams) MR_HIP(hipEventRecord(ev_bulk(b), sp));
         // ---- chain: temporal + spatial reuse of samples ib .. ib+kk-1
         if (two_streams) MR_HIP(hipStreamWaitEvent(s, ev_bulk(b - 1), 0));
+        if (sf != sp && b >= 2) MR_HIP(hipStreamWaitEvent(s, ev_fin(b - 2), 0));   // C(b) overwrites the spatial reservoirs F(b-2) evaluates
         for (int k = 0; k < kk; k++) {
             const int i = ib + k;
             const uint32_t base = a->random_offset + passes * (uint32_t)i;
@@ -422,14 +433,15 @@ int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args
         if (max_bounce > 0) k_pt_reduce<<<grid_for(n3, MR_BLOCK), MR_BLOCK, 0, st>>>(N, kk, max_bounce, PB.cb, PB.maskb, B.tot[3], B.tot[4], B.tot[5]);
     }
     {   // F(last)
-        if (two_streams) MR_HIP(hipStreamWaitEvent(sp, ev_chain(nbatch - 1), 0));
-        PtQueues Q = PB.qf; Q.NV = batch_k(nbatch - 1) * N;
+        if (two_streams) MR_HIP(hipStreamWaitEvent(sf, ev_chain(nbatch - 1), 0));
+        PtQueues Q = PB.qv; Q.NV = batch_k(nbatch - 1) * N;
         rc = launch_final_batch(ctx, bvh, &E, occ, a->pos, a->normal, B.ray_dir, a->kd, a->rough_metal, &PB.rspat[(nbatch - 1) & 1], batch_k(nbatch - 1), &Q, B.tot[0], B.tot[1], B.tot[2],
-                                a->tape ? a->tape + 8 * (size_t)N * (size_t)((nbatch - 1) * PB.K) : nullptr, sp);
+                                a->tape ? a->tape + 8 * (size_t)N * (size_t)((nbatch - 1) * PB.K) : nullptr, sf);
         if (rc) return rc;
     }
     if (two_streams) { MR_HIP(hipEventRecord(ctx->ev_join, sp)); MR_HIP(hipStreamWaitEvent(s, ctx->ev_join, 0)); }
     if (st != sp) { MR_HIP(hipEventRecord(ctx->ev_join_pt, st)); MR_HIP(hipStreamWaitEvent(s, ctx->ev_join_pt, 0)); }
+    if (sf != sp) { MR_HIP(hipEventRecord(ctx->ev_join_fin, sf)); MR_HIP(hipStreamWaitEvent(s, ctx->ev_join_fin, 0)); }
     if (dbg_sum) {
         std::vector<unsigned long long> h(n_sums);
         MR_HIP(hipStreamSynchronize(s)); MR_HIP(hipMemcpy(h.data(), d_sums, 8 * (size_t)n_sums, hipMemcpyDeviceToHost)); (void)hipFree(d_sums);
