@@ -179,28 +179,39 @@ struct PtBatch {
 static mirres_res_t res_slot(const mirres_res_t& r, int k, size_t N) {   // packed 32-byte records (passes.hip resd(): light_pdf == NULL)
     mirres_res_t o; o.light_data = r.light_data + 8 * (size_t)k * N; o.light_pdf = nullptr; o.M = nullptr; o.weight = nullptr; return o;
 }
-static int pt_batch_size() {   // MIRRES_PT_BATCH = samples per path-tracing launch (default 16; 1 = sample by sample)
+static int pt_batch_size() {   // MIRRES_PT_BATCH = samples per batch (default 32: ~86 M slots, ~55 GB of pool at 1600^2; 1 = sample by sample)
     const char* e = getenv("MIRRES_PT_BATCH");   // read per frame (tests switch it)
-    int k = e ? atoi(e) : 16; if (k < 1) k = 1; if (k > 64) k = 64;
+    int k = e ? atoi(e) : 32; if (k < 1) k = 1; if (k > 64) k = 64;
     return k;
 }
 static int stream_count() { const char* e = getenv("MIRRES_STREAMS"); const int n = e ? atoi(e) : 3; return n < 1 ? 1 : (n > 4 ? 4 : n); }   // 1: everything on the caller's stream; 2: one bulk stream; 3 (default): path tracing on its own; 4: final stages too
 static int carve_batch(mirres_ctx* ctx, int N, int K, int max_bounce, size_t TS, PtBatch& PB) {
     if (K < 1) K = 1;
     while ((size_t)K * (size_t)N > 0x30000000ull && K > 1) K--;   // slot indices are 32-bit
-    const size_t NV = (size_t)K * (size_t)N;
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const int nb = max_bounce > 0 ? max_bounce : 1;
-    size_t need = al(sizeof(Ray) * 2 * NV) + al(4 * 2 * NV) + al(sizeof(Ray) * NV) + al(sizeof(HitRec) * NV) + al(64) + 3 * al(4 * NV) + al(4 * 18 * NV)
-                + al(4 * 5 * NV) + 2 * (3 * al(4 * 3 * NV) + al(4 * NV)) + al(4 * 3 * NV) + al(4 * 2 * NV) + al(4 * 9 * NV * (size_t)nb) + al(4 * NV * (size_t)nb)
-                + 4 * al(4 * 8 * NV) + al(4 * 3 * (size_t)K * TS) + al(4 * (size_t)K * TS) + al(16 * (size_t)K * TS)
-                + 2 * (al(sizeof(Ray) * NV) + 2 * al(4 * NV) + al(64));
+    auto bytes_for = [&](int k) {
+        const size_t NV = (size_t)k * (size_t)N;
+        return al(sizeof(Ray) * 2 * NV) + al(4 * 2 * NV) + al(sizeof(Ray) * NV) + al(sizeof(HitRec) * NV) + al(64) + 3 * al(4 * NV) + al(4 * 18 * NV)
+             + al(4 * 5 * NV) + 2 * (3 * al(4 * 3 * NV) + al(4 * NV)) + al(4 * 3 * NV) + al(4 * 2 * NV) + al(4 * 9 * NV * (size_t)nb) + al(4 * NV * (size_t)nb)
+             + 4 * al(4 * 8 * NV) + al(4 * 3 * (size_t)k * TS) + al(4 * (size_t)k * TS) + al(16 * (size_t)k * TS)
+             + 2 * (al(sizeof(Ray) * NV) + 2 * al(4 * NV) + al(64));
+    };
+    size_t need = bytes_for(K);
     if (ctx->ptb_bytes < need) {
         if (ctx->ptb) { MR_HIP(hipDeviceSynchronize()); MR_HIP(hipFree(ctx->ptb)); ctx->ptb = nullptr; ctx->ptb_bytes = 0; }
-        MR_HIP(hipMalloc(&ctx->ptb, need));
+        // ~670 bytes per slot: 55 GB for 32 samples of a 1600^2 frame. When the device cannot spare that (other tenants of the HBM), halve the batch
+        for (;;) {
+            const hipError_t e = hipMalloc(&ctx->ptb, need);
+            if (e == hipSuccess) break;
+            (void)hipGetLastError(); ctx->ptb = nullptr;
+            if (e != hipErrorOutOfMemory || K == 1) { set_error("mirres_render: cannot allocate the %zu-byte batch pool (%s)", need, hipGetErrorString(e)); return MIRRES_E_HIP; }
+            K = (K + 1) / 2; need = bytes_for(K);
+        }
         MR_HIP(hipMemset(ctx->ptb, 0, need));   // slots that never receive a vertex are read (and ignored) by the bounce kernels
         ctx->ptb_bytes = need;
     }
+    const size_t NV = (size_t)K * (size_t)N;
     char* p = ctx->ptb;
     auto take = [&](size_t b) { char* r = p; p += al(b); return r; };
     PB.K = K;
@@ -313,10 +324,12 @@ int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args
     if (i1 > i0) {   // an empty slice of the sample range (spp sharding with more ranks than samples) leaves the zeroed totals
     const int Kmax = pt_batch_size();
     const size_t TS = (size_t)ctx->cfg.light_tile_count * ctx->cfg.light_tile_size;
-    // K: the configured batch size, but at least ~4 batches per frame so that the chain of batch b overlaps the bulk work of its neighbours
-    // (a rank of an 8-GPU run renders 16 of 128 samples: K = 4)
+    // K: the configured batch size (or the whole sample range when that is shorter). The path-tracing stages do not depend on the ReSTIR stages,
+    // so even a single batch keeps several streams busy; larger batches mean fewer, larger launches (measured at 1600^2: 16 spp in one batch
+    // of 16 instead of four of 4: 53.6 -> 50.5 ms; 128 spp in batches of 16 / 32 / 64: 375 / 370 / 367 ms)
     int Kuse = Kmax;
-    { const int n = i1 - i0; if (n < 4 * Kuse) Kuse = (n + 3) / 4; if (Kuse < 4) Kuse = 4; if (Kuse > Kmax) Kuse = Kmax; if (Kuse > n) Kuse = n; }
+    { const char* e = getenv("MIRRES_MIN_BATCHES"); const int mb = e ? (atoi(e) > 0 ? atoi(e) : 1) : 1;
+      const int n = i1 - i0; if (n < mb * Kuse) Kuse = (n + mb - 1) / mb; if (Kuse < 1) Kuse = 1; if (Kuse > Kmax) Kuse = Kmax; if (Kuse > n) Kuse = n; }
     PtBatch PB; rc = carve_batch(ctx, N, Kuse, max_bounce, TS, PB); if (rc) return rc;
     // ---- schedule. Per batch b of K samples:
     //   I(b)  initial resampling of the K samples (light tiles, candidates, shadow rays)              bulk stream, K * N slots per launch
