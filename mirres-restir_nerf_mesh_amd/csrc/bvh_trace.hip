@@ -719,22 +719,25 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_closest4(BvhView B, co
 }
 
 static int persist_grid(size_t capacity);
-static int ensure_redo(mirres_bvh* bvh, size_t capacity) {
-    if (bvh->redo_cap >= capacity) return 0;
-    if (bvh->redo) { MR_HIP(hipDeviceSynchronize()); MR_HIP(hipFree(bvh->redo)); bvh->redo = nullptr; }
-    MR_HIP(hipMalloc(&bvh->redo, sizeof(uint32_t) * capacity));
-    bvh->redo_cap = capacity;
+static int ensure_redo(mirres_bvh* bvh, int alt, size_t capacity) {
+    if (bvh->redo_cap[alt] >= capacity) return 0;
+    if (bvh->redo[alt]) { MR_HIP(hipDeviceSynchronize()); MR_HIP(hipFree(bvh->redo[alt])); bvh->redo[alt] = nullptr; }
+    MR_HIP(hipMalloc(&bvh->redo[alt], sizeof(uint32_t) * capacity));
+    bvh->redo_cap[alt] = capacity;
     return 0;
 }
-// ordered fast path + reference-order recomputation of the handed-back rays (see k_trace_closest4)
+// ordered fast path + reference-order recomputation of the handed-back rays (see k_trace_closest4). `lane` 4 (the second path-tracing stream of
+// mirres_render) works on its own head sets and redo list, so two such traces may be in flight
 template <bool COUNT>
 static int closest_fast(mirres_bvh* bvh, const Ray* rays, const uint32_t* d_count, size_t capacity, HitRec* rec, int32_t* hit, float* t, float* pos,
-                        float* nrm, int32_t* prim, unsigned long long* stats, hipStream_t s) {
-    int rc = ensure_redo(bvh, capacity); if (rc) return rc;
-    MR_HIP(hipMemsetAsync(bvh->work + 4 * MR_WSET, 0, 3 * MR_WSET * sizeof(uint32_t), s));   // set 4 fast heads, set 5 [0] redo count, set 6 redo heads
-    k_trace_closest4<COUNT><<<persist_grid(capacity), MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, d_count, (uint32_t)capacity, bvh->work + 4 * MR_WSET, rec, hit, t, pos, nrm, prim,
-                                                                               bvh->redo, bvh->work + 5 * MR_WSET, stats);
-    k_trace_persist<false><<<256, MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, bvh->work + 5 * MR_WSET, 0u, bvh->work + 6 * MR_WSET, hit, rec, t, pos, nrm, prim, nullptr, bvh->redo);
+                        float* nrm, int32_t* prim, unsigned long long* stats, hipStream_t s, int lane = 0) {
+    const int alt = lane == 4 ? 1 : 0;
+    int rc = ensure_redo(bvh, alt, capacity); if (rc) return rc;
+    uint32_t* const w = bvh->work + (alt ? 12 : 4) * MR_WSET;   // set +0 fast heads, set +1 [0] redo count, set +2 redo heads
+    MR_HIP(hipMemsetAsync(w, 0, 3 * MR_WSET * sizeof(uint32_t), s));
+    k_trace_closest4<COUNT><<<persist_grid(capacity), MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, d_count, (uint32_t)capacity, w, rec, hit, t, pos, nrm, prim,
+                                                                               bvh->redo[alt], w + MR_WSET, stats);
+    k_trace_persist<false><<<256, MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, w + MR_WSET, 0u, w + 2 * MR_WSET, hit, rec, t, pos, nrm, prim, nullptr, bvh->redo[alt]);
     MR_LAUNCH_CHECK("closest_fast");
     return 0;
 }
@@ -773,7 +776,7 @@ static int trace_grid(size_t capacity) {
 int trace_any_queue(const mirres_bvh* bvh, const Ray* rays, const uint32_t* d_count, size_t capacity, int32_t* hit,
                     unsigned long long* stats, hipStream_t s, int lane, int timed) {
     g_timed_tag = timed;
-    static const int set_of_lane[4] = {0, 7, 9, 11};                    // launches that may overlap on different streams use different head sets
+    static const int set_of_lane[5] = {0, 7, 9, 11, 15};                    // launches that may overlap on different streams use different head sets
     uint32_t* const heads = bvh->work + set_of_lane[lane] * MR_WSET;
     MR_HIP(hipMemsetAsync(heads, 0, MR_WSET * sizeof(uint32_t), s));
     launch_any4q<false>(bvh, persist_grid(capacity), rays, d_count, (uint32_t)capacity, heads, hit, stats, s);
@@ -782,8 +785,8 @@ int trace_any_queue(const mirres_bvh* bvh, const Ray* rays, const uint32_t* d_co
 }
 int trace_closest_queue(const mirres_bvh* bvh, const Ray* rays, const uint32_t* d_count, size_t capacity, HitRec* out,
                         unsigned long long* stats, hipStream_t s, int lane) {
-    if (closest_mode() == 4) return closest_fast<false>(const_cast<mirres_bvh*>(bvh), rays, d_count, capacity, out, nullptr, nullptr, nullptr, nullptr, nullptr, stats, s);
-    static const int set_of_lane[4] = {1, 8, 10, 10};
+    if (closest_mode() == 4) return closest_fast<false>(const_cast<mirres_bvh*>(bvh), rays, d_count, capacity, out, nullptr, nullptr, nullptr, nullptr, nullptr, stats, s, lane);
+    static const int set_of_lane[5] = {1, 8, 10, 10, 16};
     uint32_t* const heads = bvh->work + set_of_lane[lane] * MR_WSET;
     MR_HIP(hipMemsetAsync(heads, 0, MR_WSET * sizeof(uint32_t), s));
     k_trace_persist<false><<<persist_grid(capacity), MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, d_count, (uint32_t)capacity, heads, nullptr, out,

@@ -5,10 +5,11 @@
 #include <vector>
 #include "../../include/mirres.h"
 
-// persistent-traversal work queue: MR_NQ sub-queue heads, one per 128-byte line (bvh_trace.hip grab_chunk); mirres_bvh::work holds 12 such sets
+// persistent-traversal work queue: MR_NQ sub-queue heads, one per 128-byte line (bvh_trace.hip grab_chunk); mirres_bvh::work holds MR_WSETS such sets
 #define MR_NQ 32
 #define MR_QSTRIDE 32
 #define MR_WSET (MR_NQ * MR_QSTRIDE)
+#define MR_WSETS 17
 
 namespace mr {
 
@@ -82,9 +83,10 @@ struct mirres_bvh {
     mr::LeafRec* leaves = nullptr;  // [T]
     mr::Node4q* top85q = nullptr, *top341q = nullptr;   // [85], [341] breadth-first prefixes of nodes4q, children inside tagged MR_TOPBIT
     float* root_box = nullptr;      // [6]
-    uint32_t* work = nullptr;       // [12 * MR_WSET] head sets of the persistent traversal kernels (0/1 frame loop, 2/3 API, 4-6 ordered closest + redo, 7/8 second stream, 9/10 third stream, 11 fourth stream)
+    uint32_t* work = nullptr;       // [MR_WSETS * MR_WSET] head sets of the persistent traversal kernels: 0/1 chain, 2/3 API, 4-6 ordered closest + redo, 7/8 bulk stream, 9/10 path-tracing stream,
+                                    // 11 final-stage stream, 12-14 ordered closest + redo and 15/16 any / closest of the second path-tracing stream
     unsigned long long* dbg = nullptr;   // see BvhView::dbg
-    uint32_t* redo = nullptr; size_t redo_cap = 0;   // ray ids handed back by the ordered closest-hit fast path
+    uint32_t* redo[2] = {nullptr, nullptr}; size_t redo_cap[2] = {0, 0};   // ray ids handed back by the ordered closest-hit fast path (one list per path-tracing stream)
     mr::BvhView view() const { mr::BvhView v; v.nodes = nodes; v.tris = tris; v.root_box = root_box; v.T = T; v.nodes4q = nodes4q; v.leaves = leaves; v.top85q = top85q; v.top341q = top341q; v.dbg = dbg; return v; }
 };
 
@@ -115,7 +117,9 @@ struct mirres_ctx {
     int y_off = 0, full_fy = 0;     // strip sharding (mirres_render): global row of local row 0 and the global height; full_fy == 0: the frame is the whole image
     const float* occ_own = nullptr; // strip sharding: occupancy with the halo rows zeroed (own-pixel tests of the spatial pass); NULL otherwise
     const float* grec = nullptr;    // set by mirres_render for the duration of a frame: packed 64-byte G records for the neighbour gathers of k_spatial_resolve
-    hipStream_t aux_stream = nullptr, pt_stream = nullptr, fin_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join_pt = nullptr, ev_join_fin = nullptr;
+    hipStream_t aux_stream = nullptr, pt_stream = nullptr, pt_stream2 = nullptr, fin_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join_pt = nullptr, ev_join_pt2 = nullptr, ev_join_fin = nullptr;
+    std::vector<hipEvent_t> ev_pt;   // k_pt_reduce hand-over between the two path-tracing streams
     std::vector<hipEvent_t> ev_sync; // cross-stream hand-offs of the batch pipeline   // second stream of mirres_render (path-tracing stages)
 };
 

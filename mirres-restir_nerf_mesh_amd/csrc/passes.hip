@@ -663,6 +663,9 @@ void mirres_ctx_destroy(mirres_ctx_t* c) {
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     if (c->pt_stream) (void)hipStreamDestroy(c->pt_stream);
     if (c->ev_join_fin) (void)hipEventDestroy(c->ev_join_fin);
+    if (c->ev_join_pt2) (void)hipEventDestroy(c->ev_join_pt2);
+    if (c->pt_stream2) (void)hipStreamDestroy(c->pt_stream2);
+    for (hipEvent_t e : c->ev_pt) (void)hipEventDestroy(e);
     if (c->fin_stream) (void)hipStreamDestroy(c->fin_stream);
     delete c;
 }

@@ -179,12 +179,27 @@ struct PtBatch {
 static mirres_res_t res_slot(const mirres_res_t& r, int k, size_t N) {   // packed 32-byte records (passes.hip resd(): light_pdf == NULL)
     mirres_res_t o; o.light_data = r.light_data + 8 * (size_t)k * N; o.light_pdf = nullptr; o.M = nullptr; o.weight = nullptr; return o;
 }
+// The per-slot path-tracing state of a batch can be worked on as two halves (slots [h * cap, (h + 1) * cap) of every array, their own counters):
+// two path-tracing streams then each advance a sub-batch of <= cap / N samples
+struct PtSet { PtQueues q; float *prd, *pos[2], *rd[2], *occ[2], *n[2], *kd, *rm, *cb; uint32_t* maskb; };
+static PtSet pt_set(const PtBatch& PB, int h, size_t cap, int nb) {
+    PtSet S; const size_t o = (size_t)h * cap;
+    S.q = PB.q;
+    S.q.any_rays = PB.q.any_rays + 2 * o; S.q.any_hit = PB.q.any_hit + 2 * o; S.q.cl_rays = PB.q.cl_rays + o; S.q.cl_hit = PB.q.cl_hit + o;
+    S.q.counters = PB.q.counters + 8 * h;
+    S.q.slot_a = PB.q.slot_a + o; S.q.mask_a = PB.q.mask_a + o; S.q.slot_c = PB.q.slot_c + o; S.q.pend = PB.q.pend + 18 * o;
+    S.prd = PB.prd + 5 * o;
+    for (int k = 0; k < 2; k++) { S.pos[k] = PB.pos[k] + 3 * o; S.rd[k] = PB.rd[k] + 3 * o; S.n[k] = PB.n[k] + 3 * o; S.occ[k] = PB.occ[k] + o; }
+    S.kd = PB.kd + 3 * o; S.rm = PB.rm + 2 * o;
+    S.cb = PB.cb + 9 * (size_t)nb * o; S.maskb = PB.maskb + (size_t)nb * o;
+    return S;
+}
 static int pt_batch_size() {   // MIRRES_PT_BATCH = samples per batch (default 32: ~86 M slots, ~55 GB of pool at 1600^2; 1 = sample by sample)
     const char* e = getenv("MIRRES_PT_BATCH");   // read per frame (tests switch it)
     int k = e ? atoi(e) : 32; if (k < 1) k = 1; if (k > 64) k = 64;
     return k;
 }
-static int stream_count() { const char* e = getenv("MIRRES_STREAMS"); const int n = e ? atoi(e) : 3; return n < 1 ? 1 : (n > 4 ? 4 : n); }   // 1: everything on the caller's stream; 2: one bulk stream; 3 (default): path tracing on its own; 4: final stages too
+static int stream_count() { const char* e = getenv("MIRRES_STREAMS"); const int n = e ? atoi(e) : 3; return n < 1 ? 1 : (n > 5 ? 5 : n); }   // 1: everything on the caller's stream; 2: + one bulk stream; 3 (default): + path tracing on its own; 4: + final stages on their own; 5: + a second path-tracing stream (4, 5: measured within noise of 3)
 static int carve_batch(mirres_ctx* ctx, int N, int K, int max_bounce, size_t TS, PtBatch& PB) {
     if (K < 1) K = 1;
     while ((size_t)K * (size_t)N > 0x30000000ull && K > 1) K--;   // slot indices are 32-bit
@@ -345,7 +360,7 @@ int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args
     // them. Every stream works on its own traversal head set (bvh_trace.hip) and no kernel accumulates across streams, so the frame is
     // bit-identical for any stream count and batch size (tests/test_gpu_fullsize.py). MIRRES_STREAMS=2 puts PT(b) behind I(b+1) on the bulk
     // stream; instrumented frames (counters / per-launch event timing) and MIRRES_STREAMS=1 run the same sequence on one stream.
-    hipStream_t sp = s, st = s, sf = s;   // sp: I stages, sf: F stages, st: path-tracing stages
+    hipStream_t sp = s, st = s, sf = s, st2 = nullptr;   // sp: I stages, sf: F stages, st (and st2): path-tracing stages
     const int nstreams = ctx->instrument == 0 ? stream_count() : 1;
     const bool two_streams = nstreams >= 2;
     const int nbatch = (i1 - i0 + PB.K - 1) / PB.K;
@@ -363,6 +378,11 @@ int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args
             st = ctx->pt_stream;
             MR_HIP(hipStreamWaitEvent(st, ctx->ev_fork, 0));
             PB.q.lane = 2;
+        }
+        if (nstreams >= 5 && PB.K >= 2) {   // two path-tracing streams, each advancing half-batches (+1 % at 128 spp, -4 % at 16 spp: not the default)
+            if (!ctx->pt_stream2) { MR_HIP(hipStreamCreateWithFlags(&ctx->pt_stream2, hipStreamNonBlocking)); MR_HIP(hipEventCreateWithFlags(&ctx->ev_join_pt2, hipEventDisableTiming)); }
+            st2 = ctx->pt_stream2;
+            MR_HIP(hipStreamWaitEvent(st2, ctx->ev_fork, 0));
         }
         if (nstreams >= 4) {
             if (!ctx->fin_stream) { MR_HIP(hipStreamCreateWithFlags(&ctx->fin_stream, hipStreamNonBlocking)); MR_HIP(hipEventCreateWithFlags(&ctx->ev_join_fin, hipEventDisableTiming)); }
@@ -384,6 +404,8 @@ int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args
     unsigned long long* d_sums = nullptr; int n_sums = 0;
     if (dbg_sum) { MR_HIP(hipMalloc(&d_sums, 8 * 4096)); MR_HIP(hipMemsetAsync(d_sums, 0, 8 * 4096, s)); }
     auto csum = [&](const void* p, size_t words) { if (dbg_sum && n_sums < 4096) k_checksum<<<1024, MR_BLOCK, 0, s>>>((const uint32_t*)p, words, d_sums + n_sums++); };
+    int pt_seq = 0;   // running index of the path-tracing sub-batches
+    if (st2) while (ctx->ev_pt.size() < 2) { hipEvent_t e; MR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ctx->ev_pt.push_back(e); }
     rc = initial(0); if (rc) return rc;
     if (two_streams) MR_HIP(hipEventRecord(ev_bulk(-1), sp));
     for (int b = 0; b < nbatch; b++) {
@@ -424,26 +446,39 @@ int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args
             csum(rs.light_data, 8 * (size_t)N);
         }
         if (two_streams) MR_HIP(hipEventRecord(ev_chain(b), s));
-        // ---- bulk stream: path-tracing stages of samples ib .. ib+kk-1 (new direction, then max_bounce indirect vertices)
-        PtQueues Q = PB.q; Q.NV = kk * N; Q.first_sample_is_zero = (ib == 0);
-        uint32_t fi = a->random_offset + passes * (uint32_t)ib + 5;   // pass number of new_dir for a sample with a temporal pass before it
-        mirres_path_t P0 = {occ, a->pos, a->normal, B.ray_dir, a->kd, a->rough_metal, PB.prd, PB.pos[0], PB.rd[0], PB.occ[0], PB.n[0]};
-        rc = launch_new_dir(ctx, bvh, &P0, fi, 0, st, &Q); if (rc) return rc;
-        fi += 5;
-        int src = 0;
-        for (int bo = 1; bo <= max_bounce; bo++) {
-            // material lookup at the new vertices: compacted slot list -> hash-grid gather -> MFMA MLP -> scatter (slot_c is free between passes)
-            if (a->mat && !(getenv("MIRRES_MATNET") && getenv("MIRRES_MATNET")[0] == 'v')) rc = launch_matnet_scatter_mfma(a->mat, PB.occ[src], PB.pos[src], Q.NV, PB.kd, PB.rm, a->use_scale, a->scale, Q.slot_c, &Q.counters[2], st);
-            else rc = launch_matnet_scatter(a->mat, PB.occ[src], PB.pos[src], Q.NV, PB.kd, PB.rm, a->use_scale, a->scale, a->const_kd, a->const_rm, st);
-            if (rc) return rc;
-            mirres_path_t Pb = {PB.occ[src], PB.pos[src], PB.n[src], PB.rd[src], PB.kd, PB.rm, PB.prd, PB.pos[src ^ 1], PB.rd[src ^ 1], PB.occ[src ^ 1], PB.n[src ^ 1]};
-            float* cb = PB.cb + (size_t)(bo - 1) * 9 * (size_t)Q.NV;
-            Q.mask_a = PB.maskb + (size_t)(bo - 1) * (size_t)Q.NV;      // kept per bounce for k_pt_reduce
-            rc = launch_bounce(ctx, bvh, &E, &Pb, fi, (uint32_t)bo, cb, cb + 3 * (size_t)Q.NV, cb + 6 * (size_t)Q.NV, nullptr, nullptr, nullptr, st, &Q); if (rc) return rc;
+        // ---- path-tracing stages of samples ib .. ib+kk-1 (new direction, then max_bounce indirect vertices), in sub-batches of Kp samples that
+        // alternate between the two halves of the per-slot state (and the two path-tracing streams, when there are two)
+        const int nbq = max_bounce > 0 ? max_bounce : 1;
+        const int Kp = st2 ? PB.K / 2 : PB.K;
+        for (int k0 = 0; k0 < kk; k0 += Kp, pt_seq++) {
+            const int ks = (kk - k0 < Kp) ? (kk - k0) : Kp, is = ib + k0, h = st2 ? (pt_seq & 1) : 0;
+            hipStream_t sq = h ? st2 : st;
+            PtSet T = pt_set(PB, h, (size_t)Kp * (size_t)N, nbq);
+            PtQueues Q = T.q; Q.NV = ks * N; Q.first_sample_is_zero = (is == 0); if (h) Q.lane = 4;
+            uint32_t fi = a->random_offset + passes * (uint32_t)is + 5;   // pass number of new_dir for a sample with a temporal pass before it
+            mirres_path_t P0 = {occ, a->pos, a->normal, B.ray_dir, a->kd, a->rough_metal, T.prd, T.pos[0], T.rd[0], T.occ[0], T.n[0]};
+            rc = launch_new_dir(ctx, bvh, &P0, fi, 0, sq, &Q); if (rc) return rc;
             fi += 5;
-            src ^= 1;
+            int src = 0;
+            for (int bo = 1; bo <= max_bounce; bo++) {
+                // material lookup at the new vertices: compacted slot list -> hash-grid gather -> MFMA MLP -> scatter (slot_c is free between passes)
+                if (a->mat && !(getenv("MIRRES_MATNET") && getenv("MIRRES_MATNET")[0] == 'v')) rc = launch_matnet_scatter_mfma(a->mat, T.occ[src], T.pos[src], Q.NV, T.kd, T.rm, a->use_scale, a->scale, Q.slot_c, &Q.counters[2], sq);
+                else rc = launch_matnet_scatter(a->mat, T.occ[src], T.pos[src], Q.NV, T.kd, T.rm, a->use_scale, a->scale, a->const_kd, a->const_rm, sq);
+                if (rc) return rc;
+                mirres_path_t Pb = {T.occ[src], T.pos[src], T.n[src], T.rd[src], T.kd, T.rm, T.prd, T.pos[src ^ 1], T.rd[src ^ 1], T.occ[src ^ 1], T.n[src ^ 1]};
+                float* cb = T.cb + (size_t)(bo - 1) * 9 * (size_t)Q.NV;
+                Q.mask_a = T.maskb + (size_t)(bo - 1) * (size_t)Q.NV;      // kept per bounce for k_pt_reduce
+                rc = launch_bounce(ctx, bvh, &E, &Pb, fi, (uint32_t)bo, cb, cb + 3 * (size_t)Q.NV, cb + 6 * (size_t)Q.NV, nullptr, nullptr, nullptr, sq, &Q); if (rc) return rc;
+                fi += 5;
+                src ^= 1;
+            }
+            if (max_bounce > 0) {
+                // totals 3..5 take the sub-batches in sample order whatever stream they ran on (fp32 sums: the order is part of the result)
+                if (st2 && pt_seq > 0) MR_HIP(hipStreamWaitEvent(sq, ctx->ev_pt[(pt_seq - 1) & 1], 0));
+                k_pt_reduce<<<grid_for(n3, MR_BLOCK), MR_BLOCK, 0, sq>>>(N, ks, max_bounce, T.cb, T.maskb, B.tot[3], B.tot[4], B.tot[5]);
+                if (st2) MR_HIP(hipEventRecord(ctx->ev_pt[pt_seq & 1], sq));
+            }
         }
-        if (max_bounce > 0) k_pt_reduce<<<grid_for(n3, MR_BLOCK), MR_BLOCK, 0, st>>>(N, kk, max_bounce, PB.cb, PB.maskb, B.tot[3], B.tot[4], B.tot[5]);
     }
     {   // F(last)
         if (two_streams) MR_HIP(hipStreamWaitEvent(sf, ev_chain(nbatch - 1), 0));
@@ -455,6 +490,7 @@ int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args
     if (two_streams) { MR_HIP(hipEventRecord(ctx->ev_join, sp)); MR_HIP(hipStreamWaitEvent(s, ctx->ev_join, 0)); }
     if (st != sp) { MR_HIP(hipEventRecord(ctx->ev_join_pt, st)); MR_HIP(hipStreamWaitEvent(s, ctx->ev_join_pt, 0)); }
     if (sf != sp) { MR_HIP(hipEventRecord(ctx->ev_join_fin, sf)); MR_HIP(hipStreamWaitEvent(s, ctx->ev_join_fin, 0)); }
+    if (st2) { MR_HIP(hipEventRecord(ctx->ev_join_pt2, st2)); MR_HIP(hipStreamWaitEvent(s, ctx->ev_join_pt2, 0)); }
     if (dbg_sum) {
         std::vector<unsigned long long> h(n_sums);
         MR_HIP(hipStreamSynchronize(s)); MR_HIP(hipMemcpy(h.data(), d_sums, 8 * (size_t)n_sums, hipMemcpyDeviceToHost)); (void)hipFree(d_sums);

@@ -25,7 +25,7 @@ def frame(K, st):
 ref = frame(1, 1)
 bad = 0
 for rep in range(REPS):
-    got = frame((1, 4, 16)[rep % 3], 2 + (rep // 3) % 3)
+    got = frame((1, 3, 4, 16)[rep % 4], 2 + (rep // 4) % 4)
     mm = [int((a != b).any(dim=1).sum()) for a, b in zip(ref, got)]
     if any(mm): bad += 1; print("rep", rep, "mismatch", mm, flush=True)
 print("frames with a mismatch:", bad, "of", REPS)
