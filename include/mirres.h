@@ -5,7 +5,8 @@
  *   - every pointer is a DEVICE pointer (HBM) unless its name starts with h_; all tensors are contiguous
  *     row-major fp32 / int32 exactly as the reference's torch tensors;
  *   - `stream` is a hipStream_t passed as void*; every call only ENQUEUES work on it (no host sync) unless stated;
- *   - return value: 0 = ok, negative = MIRRES_E_*; nothing is allocated inside a call except in *_create;
+ *   - return value: 0 = ok, negative = MIRRES_E_*; nothing is allocated inside a call except in *_create and on the first
+ *     use (or growth) of a pool kept in the context / BVH object: mirres_render's batch pool, the closest-hit redo lists;
  *   - pixelIndex = y * fx + x;  reservoir = (light_data f32[N,3], light_pdf f32[N], M i32[N], weight f32[N]).
  * Each entry point cites the reference interface it replaces (file:line relative to the reference repo).
  */
