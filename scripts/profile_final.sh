@@ -2,7 +2,7 @@
 # profiles for the round: kernel trace of the default bench command, PMC HBM traffic of the dominant kernel, MLP GEMM-phase kernel
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 R=${1:-r01}
-rm -rf gpurun_out/pf; mkdir -p gpurun_out/pf/kt gpurun_out/pf/fetch gpurun_out/pf/write gpurun_out/pf/mlp gpurun_out/out
+rm -rf gpurun_out/pf; mkdir -p gpurun_out/pf/kt gpurun_out/pf/fetch gpurun_out/pf/write gpurun_out/pf/mlp gpurun_out/pf/tr gpurun_out/out
 python3 bench.py > gpurun_out/out/${R}_bench_default.json 2> gpurun_out/out/${R}_bench_default.err
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pf/kt -o kt -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/pf/kt/log 2>&1
 grep '^{' gpurun_out/pf/kt/log | tail -1 > gpurun_out/out/${R}_bench_under_rocprof.json
@@ -12,6 +12,9 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pf/write -o w -- py
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pf/mlp -o m -- python3 scripts/dev_mlp_bench.py > gpurun_out/pf/mlp/log 2>&1
 cp gpurun_out/pf/mlp/m_kernel_stats.csv gpurun_out/out/${R}_mlp_kernel_stats.csv
 grep -E '^(mlp_mfma|valu)' gpurun_out/pf/mlp/log > gpurun_out/out/${R}_mlp_bench.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pf/tr -o t -- python3 scripts/train_step_bench.py --steps 3 > gpurun_out/pf/tr.log 2>&1
+cp gpurun_out/pf/tr/t_kernel_stats.csv gpurun_out/out/${R}_train_step_kernel_stats.csv
+grep '^stage-1' gpurun_out/pf/tr.log > gpurun_out/out/${R}_train_step.txt
 python3 - "$R" <<'PY'
 import csv, glob, collections, json, sys
 R = sys.argv[1]
