@@ -4,6 +4,9 @@ What can be imported of the hot path: everything else is Slang->CU
   * nerf/render_dump.py:safe_l2_normalize            — used by run_restir_di_with_pt (renderer_restir.py:486)
   * nerf/ScreenSpaceReSTIR/GenerateLightTiles.py:make_sampleable — the torch half (cumsum / sum / normalisation / forced 1.0 entries) of the
     importance tables; its two kernel launches are served by a fake module `m` that runs this repo's oracle restatement of those kernels.
+  * nerf/ScreenSpaceReSTIR/Denoising.py:EAWDenoise_use_phi / EAWDenoise_use_phi_no_di — the a-trous driver (iteration count, stepWidth /= 2
+    with int() at the launch, ping-pong of the colour buffer); its kernel launches are served the same way, so the fixture pins the DRIVER
+    (what mirres_render's finish and mirres-restir_nerf_mesh_amd/Denoising.py restate), not the kernel.
 The fixtures are data (inputs + outputs); no reference source text is stored.
 
     python tests/golden/gen_from_reference.py
@@ -70,8 +73,39 @@ def main():
         pdf_, cdf_, mpdf_, mcdf_ = glt.make_sampleable(FakeM(), torch.from_numpy(tex), Wc, Hc)
     finally:
         torch.zeros = real_zeros
+    # ---- EAW driver
+    den = load("nerf/ScreenSpaceReSTIR/Denoising.py", "ref_denoising")
+    fx, fy = 24, 20; Np = fx * fy
+    occ = (rng.random((Np, 1)) > 0.2).astype(np.float32)
+    col = rng.random((Np, 3)).astype(np.float32)
+    # a gently curved sheet (the filter's normal / position weights must not vanish: phi = (2.0, 0.1, 0.001))
+    yy, xx = np.meshgrid(np.arange(fy, dtype=np.float32), np.arange(fx, dtype=np.float32), indexing="ij")
+    pos = np.stack([xx * 0.01, yy * 0.01, 0.02 * np.sin(xx * 0.3) * np.cos(yy * 0.2)], -1).reshape(Np, 3).astype(np.float32)
+    nrm = np.stack([-0.3 * np.cos(xx * 0.3) * 0.2, 0.2 * np.sin(yy * 0.2) * 0.2, np.ones_like(xx)], -1).reshape(Np, 3).astype(np.float32)
+    nrm += rng.normal(size=(Np, 3)).astype(np.float32) * 0.02; nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    launches = []
+
+    class FakeDen:
+        def _run(self, PHI, framedim_x, framedim_y, stepWidth, occ_map, color, normal_map, pos_map, out_color):
+            def run():
+                launches.append(int(stepWidth))
+                o = O.eaw(framedim_x, framedim_y, stepWidth, PHI[0], PHI[1], PHI[2], occ_map.numpy(), color.numpy(), normal_map.numpy(), pos_map.numpy())
+                out_color.copy_(torch.from_numpy(np.asarray(o)).reshape(out_color.shape))
+            return Launch(run)
+        def process_EAWDenoise(self, **k): return self._run(**k)
+        def process_EAWDenoise_no_di(self, **k): return self._run(**k)
+
+    torch.zeros = cpu_zeros
+    try:
+        t = lambda a_: torch.from_numpy(a_.copy())
+        eaw_di = den.EAWDenoise_use_phi(FakeDen(), 2.0, 0.1, 0.001, 2, 2, fx, fy, t(occ), t(col), t(nrm), t(pos)).numpy()
+        eaw_nodi = den.EAWDenoise_use_phi_no_di(FakeDen(), 2.0, 0.1, 0.001, 4, 3, fx, fy, t(occ), t(col), t(nrm), t(pos)).numpy()
+    finally:
+        torch.zeros = real_zeros
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "ref_python.npz"), norm_in=x, norm_out=norm_out, env=env,
-                        pdf=pdf_.numpy().ravel(), cdf=cdf_.numpy().ravel(), mpdf=mpdf_.numpy().ravel(), mcdf=mcdf_.numpy().ravel())
+                        pdf=pdf_.numpy().ravel(), cdf=cdf_.numpy().ravel(), mpdf=mpdf_.numpy().ravel(), mcdf=mcdf_.numpy().ravel(),
+                        eaw_dims=np.array([fx, fy], np.int32), eaw_occ=occ, eaw_col=col, eaw_nrm=nrm, eaw_pos=pos, eaw_di=eaw_di, eaw_nodi=eaw_nodi,
+                        eaw_steps=np.array(launches, np.int32))
     print("wrote ref_python.npz")
 
 

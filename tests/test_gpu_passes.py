@@ -168,3 +168,18 @@ def test_eaw(env, oracle):
     one = torch.full((F.N, 3), 0.37, device="cuda")
     out = EAWDenoise_run_no_di(mods[7], 2.0, 0.1, 0.001, F.fx, F.fy, 2, T["occ"], one, T["normal"], T["pos"])
     np.testing.assert_allclose(out.cpu().numpy(), 0.37, rtol=1e-6)
+
+
+def test_eaw_driver_matches_the_reference_driver(env):
+    """EAWDenoise_use_phi / _no_di of the package (HIP kernel through the C ABI) against the fixture produced by the REFERENCE's own Denoising.py
+    driver run over the oracle kernel (tests/golden/ref_python.npz): pins the step schedule 2, 1 / 4, 2, 1 and the buffer hand-over."""
+    import os
+    F, W, mods, T, torch = env
+    from mirres_restir_nerf_mesh_amd.Denoising import EAWDenoise_use_phi, EAWDenoise_use_phi_no_di
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_python.npz"))
+    fx, fy = [int(v) for v in g["eaw_dims"]]
+    t = lambda k: torch.from_numpy(g[k]).cuda()
+    a = EAWDenoise_use_phi(mods[7], 2.0, 0.1, 0.001, 2, 2, fx, fy, t("eaw_occ"), t("eaw_col"), t("eaw_nrm"), t("eaw_pos"))
+    b = EAWDenoise_use_phi_no_di(mods[7], 2.0, 0.1, 0.001, 4, 3, fx, fy, t("eaw_occ"), t("eaw_col"), t("eaw_nrm"), t("eaw_pos"))
+    np.testing.assert_allclose(a.cpu().numpy(), g["eaw_di"], rtol=3e-5, atol=2e-6)
+    np.testing.assert_allclose(b.cpu().numpy(), g["eaw_nodi"], rtol=3e-5, atol=2e-6)
