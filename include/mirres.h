@@ -58,6 +58,8 @@ int mirres_bvh_build(mirres_bvh_t* bvh, const float* vert, int V, const int32_t*
  * mode 1: closest by exhaustion in the reference's traversal order (hit,t,pos,normal,prim written; NULL skips).
  * mode 2: closest, same outputs bit for bit, via the front-to-back 4-wide fast path + reference-order recomputation of the rays whose
  *         result could depend on the visiting order (t <= 0 hits, exact ties); may grow an internal n-entry buffer on first use.
+ * mode 3: occlusion as a conventional ray tracer answers it — some triangle is hit IN FRONT of the origin (t > 0); only `hit` is written.
+ *         This is what nerf/render_dump.py:batch_intersector (:8-27) asks of the external `intersector` (intersects_closest(...)[0]).
  * counters u32[n,4] (popped, entered-internal, leaves-tested, stack-overflow) may be NULL.                   */
 int mirres_bvh_trace(mirres_bvh_t* bvh, const float* rays, int n, int mode, int32_t* hit, float* t, float* pos, float* normal,
                      int32_t* prim, uint32_t* counters, void* stream);
@@ -146,6 +148,19 @@ int mirres_bilateral(int fx, int fy, float sigma, const float* col, const float*
 /* _bilateral_denoiser_func.backward (ops.py:181-185): col_grad f32[N,3] from grad_out f32[N,4] (its 4th channel carries no gradient to col). */
 int mirres_bilateral_bwd(int fx, int fy, float sigma, const float* nrm, const float* zdz, const float* grad_out4, float* scratch, float* col_grad,
                          void* stream);
+
+/* dump_render (nerf/render_dump.py:84-133) = dump_render_run_mesh (:136-215) + GGX_specular (:32-65) + get_light_rgbs (:70-82) +
+ * batch_intersector (:8-27): the reference's direct-lighting renderer without ReSTIR (`--use_brdf` alone, nerf/renderer.py:1131-1149;
+ * BASELINE configs[0]). n surface points (pos, normal, albedo, roughness, fresnel, rays_d: f32[n,3] each; roughness / fresnel are the
+ * 3-channel repeats of renderer.py:1134-1135), env_map f32[env_h,env_w,3], the fixed light set of generate_envir_map_dir
+ * (nerf/render_helper.py:8-26): light_dirs f32[L,3], light_area_weight f32[L] (may be NULL when equal_areas != 0 — sample_method
+ * 'stratifed_sample_equal_areas'). Occlusion = mode 3 of mirres_bvh_trace from pos + 0.001 dir for every light with clamped cosine > 1e-6.
+ * light_rgbs f32[L,3] receives get_light_rgbs; out_rgb (clamped to [0,1] when clamp_rgb, as dump_render does), out_diff, out_spec f32[n,3].
+ * Works through the points in chunks of <= 2^24 (point, light) pairs; the chunk's ray pool (40 B per pair) is kept in the BVH object.  */
+int mirres_dump_render(mirres_bvh_t* bvh, int n, int L, const float* pos, const float* normal, const float* albedo, const float* roughness,
+                       const float* fresnel, const float* rays_d, const float* env_map, int env_h, int env_w, const float* light_dirs,
+                       const float* light_area_weight, int equal_areas, int clamp_rgb, float* light_rgbs, float* out_rgb, float* out_diff,
+                       float* out_spec, void* stream);
 
 /* prepare_shading_normal (nerf/renderutils/ops.py:100-163; c_src/normal.cu): the shading normal render_stage1 hands to the path
  * (nerf/renderer.py:1013). All inputs f32[n,3] (broadcast inputs expanded by the caller); out f32[n,3]. The backward writes the six input

@@ -500,7 +500,7 @@ int mirres_bvh_create(mirres_bvh_t** out, int max_tris) {
 void mirres_bvh_destroy(mirres_bvh_t* b) {
     if (!b) return;
     void* ptrs[] = {b->ele_aabb, b->extent, b->keys_in, b->keys_out, b->vals_in, b->vals_out, b->parent, b->flags, b->own_info,
-                    b->own_aabb, b->nodes, b->tris, b->root_box, b->sort_tmp, b->work, b->redo[0], b->redo[1], b->nodes4q, b->leaves, b->top85q, b->top341q, b->pl_info, b->pl_aabb, b->pl_cid[0], b->pl_cid[1], b->pl_box[0], b->pl_box[1],
+                    b->own_aabb, b->nodes, b->tris, b->root_box, b->sort_tmp, b->work, b->redo[0], b->redo[1], b->dump_pool, b->nodes4q, b->leaves, b->top85q, b->top341q, b->pl_info, b->pl_aabb, b->pl_cid[0], b->pl_cid[1], b->pl_box[0], b->pl_box[1],
                     b->pl_nn, b->pl_flag, b->pl_scan, b->pl_state, b->pl_tmp};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete b;

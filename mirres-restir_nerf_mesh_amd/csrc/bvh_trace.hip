@@ -385,6 +385,7 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_persist(BvhView B, con
 // vector-L1 lookups of divergent gathers); (b' - o) * inv is monotone in b', so a decoded box passes whenever the exact one does and no
 // leaf the reference visits is missed. A leaf that passes the conservative test is re-tested against its exact LBVH box (LeafRec) before
 // the triangle test, so the set of triangles tested — and therefore the result — is the reference's, bit for bit.
+template <bool FRONT = false>   // FRONT: a conventional occlusion query — the hit must lie in front of the origin (t > 0); the reference's bvh_hit does not look at t
 MR_DEV bool tri_accepts_regs(float4 a, float4 b, float4 c, v3 ro, v3 d) {
     const v3 v0 = V3(a.x, a.y, a.z), E1 = V3(a.w, b.x, b.y), E2 = V3(b.z, b.w, c.x);
     const v3 P = cross(d, E2);
@@ -397,8 +398,10 @@ MR_DEV bool tri_accepts_regs(float4 a, float4 b, float4 c, v3 ro, v3 d) {
     const v3 Q = cross(Tv, E1);
     const float v = dot(d, Q) * invDet;
     if (v < 0 || u + v > 1) return false;
+    if (FRONT) return dot(E2, Q) * invDet > 0.f;
     return true;
 }
+// TIMED = 2: front-only occlusion (nerf/render_dump.py's external `intersector`, a conventional ray tracer) — the same traversal with t > 0 required
 template <bool COUNT, int TOPN, int TIMED = 0>   // TIMED: identical code under a second name, launched by bench.py's event-timed frame so that a rocprofv3
                                                  // kernel trace of the same command shows those launches as their own row
 __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const Ray* __restrict__ rays, const uint32_t* __restrict__ d_count,
@@ -481,7 +484,7 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const
                     const float etn = fmaxf(fmaxf(fmaxf(fminf(ex0, ex1), fminf(ey0, ey1)), fminf(ez0, ez1)), t_min);
                     const float etf = fminf(fminf(fmaxf(ex0, ex1), fmaxf(ey0, ey1)), fmaxf(ez0, ez1));
                     if (COUNT) c_boxes++;
-                    if (etf > etn && t_max > etn) { hit = tri_accepts_regs(l0, l1, l2, ro, d); if (COUNT) c_leaves++; }
+                    if (etf > etn && t_max > etn) { hit = tri_accepts_regs<TIMED == 2>(l0, l1, l2, ro, d); if (COUNT) c_leaves++; }
                 } else {
                     const float gx = __uint_as_float(h0.x), gy = __uint_as_float(h0.y), gz = __uint_as_float(h0.z);
                     const float sx = __uint_as_float((h0.w & 0xffu) << 23), sy = __uint_as_float((h0.w & 0xff00u) << 15), sz = __uint_as_float((h0.w & 0xff0000u) << 7);
@@ -783,6 +786,16 @@ int trace_any_queue(const mirres_bvh* bvh, const Ray* rays, const uint32_t* d_co
     MR_LAUNCH_CHECK("trace_any_queue");
     return 0;
 }
+// occlusion with hits in front of the origin only (API head set 2): render_dump.py's batch_intersector
+int trace_any_front_queue(const mirres_bvh* bvh, const Ray* rays, const uint32_t* d_count, size_t capacity, int32_t* hit, hipStream_t s) {
+    uint32_t* const heads = bvh->work + 2 * MR_WSET;
+    MR_HIP(hipMemsetAsync(heads, 0, MR_WSET * sizeof(uint32_t), s));
+    const int grid = persist_grid(capacity);
+    if (bvh->T - 1 >= 341 * 4) k_trace_any4q<false, 85, 2><<<grid, MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, d_count, (uint32_t)capacity, heads, hit, nullptr);
+    else k_trace_any4q<false, 0, 2><<<grid, MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, d_count, (uint32_t)capacity, heads, hit, nullptr);
+    MR_LAUNCH_CHECK("trace_any_front_queue");
+    return 0;
+}
 int trace_closest_queue(const mirres_bvh* bvh, const Ray* rays, const uint32_t* d_count, size_t capacity, HitRec* out,
                         unsigned long long* stats, hipStream_t s, int lane) {
     if (closest_mode() == 4) return closest_fast<false>(const_cast<mirres_bvh*>(bvh), rays, d_count, capacity, out, nullptr, nullptr, nullptr, nullptr, nullptr, stats, s, lane);
@@ -821,13 +834,17 @@ using namespace mr;
 
 extern "C" int mirres_bvh_trace(mirres_bvh_t* bvh, const float* rays, int n, int mode, int32_t* hit, float* t, float* pos, float* normal,
                                 int32_t* prim, uint32_t* counters, void* stream) {
-    if (!bvh || !rays || n < 0 || (mode != 0 && mode != 1 && mode != 2)) { set_error("mirres_bvh_trace: bad argument"); return MIRRES_E_ARG; }
+    if (!bvh || !rays || n < 0 || mode < 0 || mode > 3) { set_error("mirres_bvh_trace: bad argument"); return MIRRES_E_ARG; }
     if (bvh->T < 2) { set_error("mirres_bvh_trace: BVH not built"); return MIRRES_E_STATE; }
     if (n == 0) return MIRRES_OK;
     hipStream_t s = (hipStream_t)stream;
     const Ray* r = reinterpret_cast<const Ray*>(rays);
     const int g = trace_grid((size_t)n);
     if (mode == 2) return closest_fast<false>(bvh, r, nullptr, (size_t)n, nullptr, hit, t, pos, normal, prim, nullptr, s);
+    if (mode == 3) {
+        if (!hit) { set_error("mirres_bvh_trace: occlusion needs hit[]"); return MIRRES_E_ARG; }
+        return trace_any_front_queue(bvh, r, nullptr, (size_t)n, hit, s);
+    }
     if (mode == 0) {
         if (!hit) { set_error("mirres_bvh_trace: any-hit needs hit[]"); return MIRRES_E_ARG; }
         if (counters) k_trace_any<true><<<g, MR_TRACE_BLOCK, 0, s>>>(bvh->view(), r, nullptr, (uint32_t)n, hit, counters, nullptr);

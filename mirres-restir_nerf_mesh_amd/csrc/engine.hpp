@@ -86,6 +86,7 @@ struct mirres_bvh {
     uint32_t* work = nullptr;       // [MR_WSETS * MR_WSET] head sets of the persistent traversal kernels: 0/1 chain, 2/3 API, 4-6 ordered closest + redo, 7/8 bulk stream, 9/10 path-tracing stream,
                                     // 11 final-stage stream, 12-14 ordered closest + redo and 15/16 any / closest of the second path-tracing stream
     unsigned long long* dbg = nullptr;   // see BvhView::dbg
+    char* dump_pool = nullptr; size_t dump_pool_bytes = 0;   // mirres_dump_render: shadow rays / results / slots of one pixel chunk
     uint32_t* redo[2] = {nullptr, nullptr}; size_t redo_cap[2] = {0, 0};   // ray ids handed back by the ordered closest-hit fast path (one list per path-tracing stream)
     mr::BvhView view() const { mr::BvhView v; v.nodes = nodes; v.tris = tris; v.root_box = root_box; v.T = T; v.nodes4q = nodes4q; v.leaves = leaves; v.top85q = top85q; v.top341q = top341q; v.dbg = dbg; return v; }
 };
@@ -132,6 +133,7 @@ int check_hip(hipError_t e, const char* what);
 // queue tracing (bvh_trace.hip). count is read on the device; capacity bounds the grid-stride loop.
 int trace_any_queue(const mirres_bvh* bvh, const Ray* rays, const uint32_t* d_count, size_t capacity, int32_t* hit,
                     unsigned long long* stats, hipStream_t s, int lane = 0, int timed = 0);
+int trace_any_front_queue(const mirres_bvh* bvh, const Ray* rays, const uint32_t* d_count, size_t capacity, int32_t* hit, hipStream_t s);
 int trace_closest_queue(const mirres_bvh* bvh, const Ray* rays, const uint32_t* d_count, size_t capacity, HitRec* out,
                         unsigned long long* stats, hipStream_t s, int lane = 0);
 int trace_any(mirres_ctx* ctx, mirres_bvh* bvh, size_t cap, hipStream_t s);       // ctx->any_rays -> ctx->any_hit

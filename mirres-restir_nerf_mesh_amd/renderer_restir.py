@@ -104,6 +104,17 @@ class restirbvhWorker:
               "mirres_bvh_trace")
         return dict(hit=hit, t=t, pos=pos, normal=nrm, prim=prim)
 
+    def intersects_closest(self, rays_o, rays_d, stream_compaction=True):
+        """What nerf/render_dump.py:batch_intersector (:8-27) asks of its external `intersector`: (hit mask, ...) of a conventional ray tracer
+        (hits in front of the origin only — mirres_bvh_trace mode 3). The other five return values of the reference's intersector are unused there."""
+        n = rays_o.shape[0]
+        rays = torch.empty((n, 8), dtype=torch.float32, device=rays_o.device)
+        rays[:, 0:3] = rays_o; rays[:, 3] = 0.0; rays[:, 4:7] = rays_d; rays[:, 7] = 1e7
+        hit = torch.zeros(n, dtype=torch.int32, device=rays.device)
+        if n:
+            check(lib().mirres_bvh_trace(self.h, rays.data_ptr(), n, 3, hit.data_ptr(), None, None, None, None, None, stream_ptr()), "mirres_bvh_trace")
+        return hit > 0, None, None, None, None, None
+
     def InitialResampling_(self, m, pos_map, reservoirs, env_tex, env_width, env_height, framedim_x, framedim_y, frameIndex, occ_map, normal_depth, brdf_map,
                            ray_dir, pdf_, cdf_, mpdf_, mcdf_, light_data, light_uv, light_inv_pdf):
         return Resampling.InitialResampling_(m, self.LBVHNode_info, self.LBVHNode_aabb, self.vrt, self.v_ind, pos_map, reservoirs, env_tex, env_width, env_height,

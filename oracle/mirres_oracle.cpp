@@ -3,6 +3,7 @@
 // Orchestration restates restir_di_with_pt / run_restir_di_with_pt (nerf/renderer_restir.py:230-550).
 #include "orc_kernels.hpp"
 #include "orc_matnet.hpp"
+#include "orc_dump.hpp"
 #include <cstdio>
 #include <cstdlib>
 #ifdef _OPENMP
@@ -383,6 +384,32 @@ int orc_render(const OrcRenderArgs* A) {
         }
     }
     return 0;
+}
+
+// ---- nerf/render_dump.py (BASELINE configs[0]: direct lighting over a fixed lat-long light set, no ReSTIR)
+void orc_occluded_front(const int32_t* info, const float* aabb, const float* vert, const int32_t* tri, const float* rays, int n, int32_t* hit) {
+    Bvh B = {info, aabb, vert, tri};
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int i = 0; i < n; i++) { const float* r = rays + 8 * (size_t)i; hit[i] = bvh_occluded_front(B, mk3(r[0], r[1], r[2]), mk3(r[4], r[5], r[6]), r[3], r[7]) ? 1 : 0; }
+}
+void orc_dump_light_rgbs(const float* env, int H, int W, const float* dirs, int L, float* out) {
+    for (int l = 0; l < L; l++) st3(out, l, dump_light_rgb(env, H, W, ld3(dirs, l)));
+}
+void orc_ggx_specular(int n, int L, const float* normal, const float* pts2c, const float* pts2l /*[L,3]*/, const float* rough, const float* fresnel, float* out /*[n,L,3]*/) {
+    for (int i = 0; i < n; i++) for (int l = 0; l < L; l++)
+        st3(out, (size_t)i * L + l, ggx_specular(ld3(normal, i), ld3(pts2c, i), ld3(pts2l, l), ld3(rough, i), ld3(fresnel, i)));
+}
+void orc_dump_render(const int32_t* info, const float* aabb, const float* vert, const int32_t* tri, int n, int L, const float* pos, const float* normal,
+                     const float* albedo, const float* rough, const float* fresnel, const float* rays_d, const float* light_dirs, const float* light_w,
+                     const float* light_rgb, int equal_areas, int clamp_rgb, float* out_rgb, float* out_diff, float* out_spec) {
+    Bvh B = {info, aabb, vert, tri};
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int i = 0; i < n; i++) {
+        f3 c, d, s;
+        dump_render_point(B, ld3(pos, i), ld3(normal, i), ld3(albedo, i), ld3(rough, i), ld3(fresnel, i), ld3(rays_d, i), L, light_dirs, light_w, light_rgb, equal_areas != 0, c, d, s);
+        if (clamp_rgb) c = mk3(clampf(c.x, 0.f, 1.f), clampf(c.y, 0.f, 1.f), clampf(c.z, 0.f, 1.f));   // dump_render :129
+        st3(out_rgb, i, c); st3(out_diff, i, d); st3(out_spec, i, s);
+    }
 }
 
 int orc_num_threads() {

@@ -372,5 +372,50 @@ def render(fx, fy, spp, random_offset, bvh, vert, tri, env_map, occ, normal, dep
                 counters=cnt, occ=occ, avg_direct=avg)
 
 
+# ------------------------------------------------------------------ nerf/render_dump.py (BASELINE configs[0])
+def envir_map_dirs(envmap_h, envmap_w):
+    """generate_envir_map_dir (nerf/render_helper.py:8-26, is_jittor=False): lat-long light set, z up; (area weights [H*W], directions [H*W,3])."""
+    lat = np.pi / envmap_h; lng = 2 * np.pi / envmap_w
+    phi, theta = np.meshgrid(np.linspace(np.pi / 2 - 0.5 * lat, -np.pi / 2 + 0.5 * lat, envmap_h, dtype=np.float32),
+                             np.linspace(np.pi - 0.5 * lng, -np.pi + 0.5 * lng, envmap_w, dtype=np.float32), indexing="ij")
+    sin_phi = np.sin(np.float32(np.pi / 2) - phi)
+    w = (4 * np.float32(np.pi) * sin_phi / np.sum(sin_phi, dtype=np.float32)).astype(np.float32).reshape(-1)
+    d = np.stack([np.cos(theta) * np.cos(phi), np.sin(theta) * np.cos(phi), np.sin(phi)], -1).reshape(-1, 3).astype(np.float32)
+    return w, d
+
+
+def occluded_front(info, aabb, vert, tri, rays):
+    """A conventional occlusion query (hit in front of the origin) over the oracle's hierarchy: what render_dump.py expects of its `intersector`."""
+    rays = _c(rays, np.float32); n = rays.shape[0]; hit = np.zeros(n, np.int32)
+    lib().orc_occluded_front(_p(info, i32p), _p(aabb, f32p), _p(_c(vert, np.float32), f32p), _p(_c(tri, np.int32), i32p), _p(rays, f32p), n, _p(hit, i32p))
+    return hit
+
+
+def dump_light_rgbs(env_map, H, W, dirs):
+    env = _c(np.asarray(env_map, np.float32).reshape(H, W, 3), np.float32); dirs = _c(dirs, np.float32); L = dirs.shape[0]
+    out = np.zeros((L, 3), np.float32)
+    lib().orc_dump_light_rgbs(_p(env, f32p), H, W, _p(dirs, f32p), L, _p(out, f32p))
+    return out
+
+
+def ggx_specular(normal, pts2c, pts2l, rough, fresnel):
+    normal = _c(normal, np.float32); n = normal.shape[0]; pts2l = _c(pts2l, np.float32); L = pts2l.shape[0]
+    out = np.zeros((n, L, 3), np.float32)
+    lib().orc_ggx_specular(n, L, _p(normal, f32p), _p(_c(pts2c, np.float32), f32p), _p(pts2l, f32p), _p(_c(rough, np.float32), f32p), _p(_c(fresnel, np.float32), f32p), _p(out, f32p))
+    return out
+
+
+def dump_render(bvh, vert, tri, pos, normal, albedo, rough, fresnel, rays_d, env_map, env_h, env_w, light_w, light_dirs, equal_areas=False, clamp_rgb=True):
+    """dump_render (render_dump.py:84-133) with this oracle's front-only occlusion query as the intersector. Returns (rgb, diff, spec), each [n,3]."""
+    info, aabb = bvh
+    pos = _c(pos, np.float32); n = pos.shape[0]; light_dirs = _c(light_dirs, np.float32); L = light_dirs.shape[0]
+    lrgb = dump_light_rgbs(env_map, env_h, env_w, light_dirs)
+    o = [np.zeros((n, 3), np.float32) for _ in range(3)]
+    lib().orc_dump_render(_p(info, i32p), _p(aabb, f32p), _p(_c(vert, np.float32), f32p), _p(_c(tri, np.int32), i32p), n, L, _p(pos, f32p), _p(_c(normal, np.float32), f32p),
+                          _p(_c(albedo, np.float32), f32p), _p(_c(rough, np.float32), f32p), _p(_c(fresnel, np.float32), f32p), _p(_c(rays_d, np.float32), f32p),
+                          _p(light_dirs, f32p), _p(_c(light_w, np.float32), f32p), _p(lrgb, f32p), int(equal_areas), int(clamp_rgb), _p(o[0], f32p), _p(o[1], f32p), _p(o[2], f32p))
+    return o
+
+
 def num_threads():
     return int(lib().orc_num_threads())

@@ -7,6 +7,12 @@ What can be imported of the hot path: everything else is Slang->CU
   * nerf/ScreenSpaceReSTIR/Denoising.py:EAWDenoise_use_phi / EAWDenoise_use_phi_no_di — the a-trous driver (iteration count, stepWidth /= 2
     with int() at the launch, ping-pong of the colour buffer); its kernel launches are served the same way, so the fixture pins the DRIVER
     (what mirres_render's finish and mirres-restir_nerf_mesh_amd/Denoising.py restate), not the kernel.
+  * nerf/render_dump.py:dump_render / dump_render_run_mesh / GGX_specular / get_light_rgbs / batch_intersector and
+    nerf/render_helper.py:generate_envir_map_dir — BASELINE configs[0] (64 x 64, 1 spp, direct lighting over the fixed lat-long light set, no
+    ReSTIR): the reference's own code run end to end on CPU tensors, with a brute-force numpy Moeller-Trumbore loop (hits in front of the
+    origin) as the `intersector` object the reference expects from outside (nerf/renderer.py:179 sets it to None) — nothing of this repo's
+    engine or oracle is in the loop. render_helper.py cannot be imported (tinycudann / nvdiffrast at module top), so
+    the one pure-torch function is compiled from the file's AST and executed as is. -> tests/golden/config1_dump_render.npz
 The fixtures are data (inputs + outputs); no reference source text is stored.
 
     python tests/golden/gen_from_reference.py
@@ -28,6 +34,75 @@ def load(path, name):
     m = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(m)
     return m
+
+
+def load_function(path, name, namespace):
+    """Execute ONE top-level function of a reference file that cannot be imported as a module (its unrelated imports are missing here)."""
+    import ast
+    tree = ast.parse(open(os.path.join(REF, path)).read())
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == name][0]
+    code = compile(ast.Module(body=[fn], type_ignores=[]), os.path.join(REF, path), "exec")
+    exec(code, namespace)
+    return namespace[name]
+
+
+def config1(O, rd):
+    """BASELINE configs[0]: the reference's dump_render on a 64 x 64 G-buffer of the synthetic mesh (subdivision 3: 1 280 + 128 triangles)."""
+    import types
+    import mirres_restir_nerf_mesh_amd as M
+    rng = np.random.default_rng(3)
+    v, t = M.scene.make_mesh(3, 8)
+    info, aabb, _, _ = O.bvh_build(v, t)
+    Himg = Wimg = 64
+    eye, dirs = M.scene.camera_rays(Himg, Wimg)
+    r = O.trace(info, aabb, v, t, O.make_rays(np.repeat(eye[None], Himg * Wimg, 0), dirs), True)
+    mask = r["hit"] > 0
+    pos = r["pos"][mask].astype(np.float32); nrm = r["normal"][mask].astype(np.float32); rays_d = dirs[mask].astype(np.float32)
+    n = pos.shape[0]
+    albedo = (0.2 + 0.6 * rng.random((n, 3))).astype(np.float32)
+    rough = np.repeat((0.15 + 0.7 * rng.random((n, 1))).astype(np.float32), 3, 1)     # ks[:,1:2].repeat(1,3) (renderer.py:1134)
+    fresnel = np.repeat((0.02 + 0.1 * rng.random((n, 1))).astype(np.float32), 3, 1)   # ks[:,2:3].repeat(1,3)
+    env_h, env_w = 16, 32                                                            # --light_probe_res_hw
+    env = M.scene.make_env(env_h, env_w).astype(np.float32)
+    gen_dirs = load_function("nerf/render_helper.py", "generate_envir_map_dir", {"torch": torch, "np": np})
+    lw, ld = gen_dirs(env_h, env_w)
+    model = types.SimpleNamespace(light_area_weight=lw, fixed_viewdirs=ld)
+    n_queries = [0]
+
+    v0 = v[t[:, 0]].astype(np.float32); E1 = (v[t[:, 1]] - v[t[:, 0]]).astype(np.float32); E2 = (v[t[:, 2]] - v[t[:, 0]]).astype(np.float32)
+
+    class BruteForceIntersector:   # what batch_intersector expects: intersects_closest(o, d, stream_compaction=True) -> (hit mask, ...)
+        def intersects_closest(self, o, d, stream_compaction=True):
+            o = o.numpy().astype(np.float32); d = d.numpy().astype(np.float32)
+            n_queries[0] += o.shape[0]
+            hit = np.zeros(o.shape[0], bool)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                for c in range(0, o.shape[0], 4096):   # Moeller-Trumbore of every ray against every triangle, fp32
+                    oc = o[c:c + 4096, None, :]; dc = d[c:c + 4096, None, :]
+                    P = np.cross(dc, E2[None]); det = (E1[None] * P).sum(-1)
+                    inv = np.float32(1) / det
+                    Tv = oc - v0[None]
+                    u = (Tv * P).sum(-1) * inv
+                    Q = np.cross(Tv, E1[None])
+                    vv = (dc * Q).sum(-1) * inv
+                    tt = (E2[None] * Q).sum(-1) * inv
+                    ok = (np.abs(det) >= 1e-15) & (u >= 0) & (u <= 1) & (vv >= 0) & (u + vv <= 1) & (tt > 0)
+                    hit[c:c + 4096] = ok.any(1)
+            return torch.from_numpy(hit), None, None, None, None, None
+
+    T = lambda a: torch.from_numpy(a.copy())
+    out = {}
+    for method in ("stratified_sampling", "stratifed_sample_equal_areas"):
+        rgb, diff, spec = rd.dump_render(BruteForceIntersector(), T(pos), T(nrm), T(albedo), T(rough), T(fresnel), T(rays_d), T(env), env_h, env_w, model,
+                                         sample_method=method, color_chunk_size=1500, chunk_size=100000, device="cpu")
+        k = "w" if method == "stratified_sampling" else "e"
+        out["rgb_" + k] = rgb.numpy(); out["diff_" + k] = diff.numpy(); out["spec_" + k] = spec.numpy()
+    spec_pairs = rd.GGX_specular(T(nrm[:64]), T(-rays_d[:64]), ld.reshape(1, -1, 3).repeat(64, 1, 1), T(rough[:64]), T(fresnel[:64])).numpy()
+    light_rgbs = rd.get_light_rgbs(T(env), env_h, env_w, ld, device="cpu").numpy().reshape(-1, 3)
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "config1_dump_render.npz"), vert=v, tri=t, image_hw=np.array([Himg, Wimg], np.int32), mask=mask,
+                        pos=pos, normal=nrm, rays_d=rays_d, albedo=albedo, rough=rough, fresnel=fresnel, env=env, env_hw=np.array([env_h, env_w], np.int32),
+                        light_w=lw.numpy(), light_dirs=ld.numpy(), light_rgbs=light_rgbs, ggx_first64=spec_pairs, shadow_queries=np.int64(n_queries[0]), **out)
+    print("wrote config1_dump_render.npz: %d surface points, %d lights, %d shadow queries, mean rgb %.4f" % (n, ld.shape[0], n_queries[0], float(out["rgb_w"].mean())))
 
 
 def main():
@@ -107,6 +182,7 @@ def main():
                         eaw_dims=np.array([fx, fy], np.int32), eaw_occ=occ, eaw_col=col, eaw_nrm=nrm, eaw_pos=pos, eaw_di=eaw_di, eaw_nodi=eaw_nodi,
                         eaw_steps=np.array(launches, np.int32))
     print("wrote ref_python.npz")
+    config1(O, rd)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,95 @@
+"""GPU: BASELINE configs[0] — the reference's direct-lighting renderer without ReSTIR (nerf/render_dump.py) through the C ABI (mirres_dump_render,
+mirres_bvh_trace mode 3), against (1) the fixture produced by the REFERENCE's own Python (tests/golden/config1_dump_render.npz) and (2) the
+oracle on a larger case."""
+import os
+import types
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _worker(v, t):
+    import torch
+    from mirres_restir_nerf_mesh_amd import renderer_restir as RR
+    W = RR.restirbvhWorker(torch.from_numpy(v).cuda(), torch.from_numpy(t.astype(np.int32)).cuda())
+    W.update_mesh(W.vrt, W.v_ind)
+    return W
+
+
+def test_config1_matches_the_reference_python():
+    import torch
+    from mirres_restir_nerf_mesh_amd import render_dump as RD
+    from mirres_restir_nerf_mesh_amd.render_helper import generate_envir_map_dir
+    g = np.load(os.path.join(HERE, "golden", "config1_dump_render.npz"))
+    W = _worker(g["vert"], g["tri"])
+    eh, ew = [int(x) for x in g["env_hw"]]
+    lw, ld = generate_envir_map_dir(eh, ew)
+    np.testing.assert_allclose(ld.numpy(), g["light_dirs"], rtol=0, atol=5e-7)
+    np.testing.assert_allclose(lw.numpy(), g["light_w"], rtol=2e-6, atol=0)
+    model = types.SimpleNamespace(light_area_weight=torch.from_numpy(g["light_w"]), fixed_viewdirs=torch.from_numpy(g["light_dirs"]))
+    T = lambda k: torch.from_numpy(g[k]).cuda()
+    for k, method in (("w", "stratified_sampling"), ("e", "stratifed_sample_equal_areas")):
+        rgb, diff, spec = RD.dump_render(W, T("pos"), T("normal"), T("albedo"), T("rough"), T("fresnel"), T("rays_d"), T("env"), eh, ew, model, sample_method=method)
+        np.testing.assert_allclose(diff.cpu().numpy(), g["diff_" + k], rtol=1e-5, atol=2e-6)   # every visibility bit as the reference run had it
+        np.testing.assert_allclose(spec.cpu().numpy(), g["spec_" + k], rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(rgb.cpu().numpy(), g["rgb_" + k], rtol=1e-4, atol=1e-4)
+    raw = RD.dump_render_run_mesh(W, T("pos"), T("normal"), T("albedo"), T("rough"), T("fresnel"), T("rays_d"), T("env"), eh, ew, model)[0]
+    assert float(raw.max()) > 1.0 and float(rgb.max()) <= 1.0   # only dump_render clamps
+
+
+def test_front_occlusion_is_bit_exact_and_batch_intersector(oracle, scene_mod):
+    """mirres_bvh_trace mode 3 (what render_dump.py's batch_intersector asks of its intersector) against the oracle's front-only query and
+    against a brute-force loop, on shadow rays leaving a bumpy mesh; edge cases: no rays, rays starting behind everything."""
+    import torch
+    from mirres_restir_nerf_mesh_amd import render_dump as RD
+    v, t = scene_mod.make_mesh(4, 8)
+    W = _worker(v, t)
+    info, aabb, _, _ = oracle.bvh_build(v, t)
+    rng = np.random.default_rng(2)
+    eye, dirs = scene_mod.camera_rays(48, 48)
+    r = oracle.trace(info, aabb, v, t, oracle.make_rays(np.repeat(eye[None], 48 * 48, 0), dirs), True)
+    pos = r["pos"][r["hit"] > 0]
+    d = rng.normal(size=(pos.shape[0], 3)).astype(np.float32); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    o = (pos + d * 0.001).astype(np.float32)
+    ref = oracle.occluded_front(info, aabb, v, t, oracle.make_rays(o, d))
+    hit = W.intersects_closest(torch.from_numpy(o).cuda(), torch.from_numpy(d).cuda())[0]
+    assert np.array_equal(hit.cpu().numpy().astype(np.int32), ref) and 0.2 < ref.mean() < 0.8
+    quirk = oracle.trace(info, aabb, v, t, oracle.make_rays(o, d), False)["hit"]
+    assert (quirk != ref).sum() > 0   # the ReSTIR path's t-blind bvh_hit is a different predicate: it also reports triangles behind the origin
+    vis = RD.batch_intersector(W, torch.from_numpy(pos).cuda(), torch.from_numpy(d).cuda(), 0.001, 1000)
+    assert vis.shape == (pos.shape[0], 1) and np.array_equal(vis.cpu().numpy().ravel() == 0, ref > 0)
+    assert W.intersects_closest(torch.zeros((0, 3)).cuda(), torch.zeros((0, 3)).cuda())[0].numel() == 0
+    far = torch.tensor([[0.0, 0.0, 50.0]] * 4).cuda(); up = torch.tensor([[0.0, 0.0, 1.0]] * 4).cuda()
+    assert not bool(W.intersects_closest(far, up)[0].any())
+
+
+def test_dump_render_against_the_oracle_larger_case(oracle, scene_mod):
+    """More points than one wave, a light set that is not a power of two, ragged sizes."""
+    import torch
+    from mirres_restir_nerf_mesh_amd import render_dump as RD
+    v, t = scene_mod.make_mesh(5, 16)
+    W = _worker(v, t)
+    info, aabb, _, _ = oracle.bvh_build(v, t)
+    rng = np.random.default_rng(9)
+    eye, dirs = scene_mod.camera_rays(96, 80)
+    r = oracle.trace(info, aabb, v, t, oracle.make_rays(np.repeat(eye[None], dirs.shape[0], 0), dirs), True)
+    m = r["hit"] > 0
+    pos, nrm, rd = r["pos"][m].astype(np.float32), r["normal"][m].astype(np.float32), dirs[m].astype(np.float32)
+    n = pos.shape[0]
+    albedo = rng.random((n, 3)).astype(np.float32)
+    rough = np.repeat((0.1 + 0.8 * rng.random((n, 1))).astype(np.float32), 3, 1); fres = np.repeat((0.04 * np.ones((n, 1))).astype(np.float32), 3, 1)
+    eh, ew = 9, 21
+    env = scene_mod.make_env(eh, ew).astype(np.float32)
+    lw, ld = oracle.envir_map_dirs(eh, ew)
+    ref = oracle.dump_render((info, aabb), v, t, pos, nrm, albedo, rough, fres, rd, env, eh, ew, lw, ld)
+    model = types.SimpleNamespace(light_area_weight=torch.from_numpy(lw), fixed_viewdirs=torch.from_numpy(ld))
+    C = lambda a: torch.from_numpy(a).cuda()
+    got = RD.dump_render(W, C(pos), C(nrm), C(albedo), C(rough), C(fres), C(rd), C(env), eh, ew, model)
+    np.testing.assert_allclose(got[1].cpu().numpy(), ref[1], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(got[2].cpu().numpy(), ref[2], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(got[0].cpu().numpy(), ref[0], rtol=1e-4, atol=2e-5)
+    empty = RD.dump_render(W, C(pos[:0]), C(nrm[:0]), C(albedo[:0]), C(rough[:0]), C(fres[:0]), C(rd[:0]), C(env), eh, ew, model)
+    assert all(e.shape == (0, 3) for e in empty)
