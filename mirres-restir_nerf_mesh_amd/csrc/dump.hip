@@ -51,7 +51,7 @@ __global__ void __launch_bounds__(MR_DUMP_BLOCK) k_dump_gen(int p0, int np, int 
     const size_t total = (size_t)np * (size_t)L;
     bool want = false; v3 o = V3(0.f), d = V3(0.f);
     if (idx < total) {
-        const int p = p0 + (int)(idx / (size_t)L), l = (int)(idx % (size_t)L);
+        const int l = (int)(idx / (size_t)np), p = p0 + (int)(idx % (size_t)np);   // light-major: neighbouring rays share the direction and start at neighbouring points
         d = ld3(dirs, l);
         const v3 n = ld3(normal, p);
         const float cosine = fmaxf((d.x * n.x + d.y * n.y) + d.z * n.z, 0.0f);
@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(MR_BLOCK) k_dump_shade(int p0, int np, int L, 
     for (int l = 0; l < L; l++) {
         const v3 d = ld3(dirs, l);
         const float cosine = fmaxf((d.x * n.x + d.y * n.y) + d.z * n.z, 0.0f);
-        const int32_t sl = slot[(size_t)i * L + l];
+        const int32_t sl = slot[(size_t)l * np + i];
         const float vis = (sl >= 0 && hit[sl]) ? 0.f : 1.f;
         const v3 sp = ggx_specular(n, surf2c, d, ro, fr);
         const v3 light = ld3(light_rgb, l) * vis;
