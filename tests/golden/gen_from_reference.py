@@ -13,6 +13,7 @@ What can be imported of the hot path: everything else is Slang->CU
     origin) as the `intersector` object the reference expects from outside (nerf/renderer.py:179 sets it to None) — nothing of this repo's
     engine or oracle is in the loop. render_helper.py cannot be imported (tinycudann / nvdiffrast at module top), so
     the one pure-torch function is compiled from the file's AST and executed as is. -> tests/golden/config1_dump_render.npz
+  * nerf/utils.py:linear2srgb_torch (+ _clip_0to1_warn_torch) — the tone curve of the harness (SURVEY §8 a-H), taken by AST like above.
 The fixtures are data (inputs + outputs); no reference source text is stored.
 
     python tests/golden/gen_from_reference.py
@@ -177,12 +178,18 @@ def main():
         eaw_nodi = den.EAWDenoise_use_phi_no_di(FakeDen(), 2.0, 0.1, 0.001, 4, 3, fx, fy, t(occ), t(col), t(nrm), t(pos)).numpy()
     finally:
         torch.zeros = real_zeros
-    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "ref_python.npz"), norm_in=x, norm_out=norm_out, env=env,
+    ns = {"torch": torch, "np": np}
+    load_function("nerf/utils.py", "_clip_0to1_warn_torch", ns)
+    l2s = load_function("nerf/utils.py", "linear2srgb_torch", ns)
+    srgb_in = np.concatenate([np.array([-0.5, 0.0, 1e-7, 0.001, 0.0031308, 0.00313081, 0.5, 1.0, 1.7], np.float32), rng.random(55).astype(np.float32)])
+    srgb_out = l2s(torch.from_numpy(srgb_in.copy())).numpy()
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "ref_python.npz"), norm_in=x, norm_out=norm_out, env=env, srgb_in=srgb_in, srgb_out=srgb_out,
                         pdf=pdf_.numpy().ravel(), cdf=cdf_.numpy().ravel(), mpdf=mpdf_.numpy().ravel(), mcdf=mcdf_.numpy().ravel(),
                         eaw_dims=np.array([fx, fy], np.int32), eaw_occ=occ, eaw_col=col, eaw_nrm=nrm, eaw_pos=pos, eaw_di=eaw_di, eaw_nodi=eaw_nodi,
                         eaw_steps=np.array(launches, np.int32))
     print("wrote ref_python.npz")
-    config1(O, rd)
+    if "--skip-config1" not in sys.argv:
+        config1(O, rd)   # ~4 min: 800 k rays against 1 408 triangles by brute force
 
 
 if __name__ == "__main__":
