@@ -233,6 +233,44 @@ struct OrcRenderArgs {
     float* avg_direct;  // optional [N,3] un-denoised mean colour (total_color / spp)
 };
 
+// second half of run_restir_di_with_pt (renderer_restir.py:507-549) on the six raw sums (total colour, diffuse, specular, indirect colour,
+// indirect diffuse, indirect specular; divided by spp IN PLACE): averages, the five a-trous runs, composite, background = 1, nan_to_num.
+// Pinned by tests/golden/ref_python.npz (the reference's own function over prepared sums).
+void orc_eaw(int fx, int fy, int stepWidth, float c_phi, float n_phi, float p_phi, const float* occ, const float* color, const float* normal,
+             const float* pos, float* out);
+void orc_finish(int fx, int fy, int spp, const float* occ, const float* normal, const float* pos, const float* kd, const float* rs, int denoise_iter, int step_width,
+                float c_phi, float n_phi, float p_phi, float* const* sums, float* const* outs) {
+    const size_t N = (size_t)fx * fy;
+    const float inv = (float)spp;
+    std::vector<float> comb(3 * N);
+    for (size_t i = 0; i < 3 * N; i++) {
+        for (int k = 0; k < 6; k++) sums[k][i] /= inv;
+        comb[i] = sums[4][i] + sums[5][i];
+    }
+    auto denoise = [&](const float* in, float* out) {
+        std::vector<float> cur(in, in + 3 * N), nxt(3 * N);
+        float swf = (float)step_width;
+        for (int it = 0; it < denoise_iter; it++) {
+            const int sw = (int)swf;  // Denoising.py: stepWidth /= 2 (float), int(stepWidth) at launch
+            orc_eaw(fx, fy, sw, c_phi, n_phi, p_phi, occ, cur.data(), normal, pos, nxt.data());
+            cur.swap(nxt); swf = swf / 2;
+        }
+        std::memcpy(out, cur.data(), sizeof(float) * 3 * N);
+    };
+    denoise(sums[1], outs[1]); denoise(sums[2], outs[2]); denoise(comb.data(), outs[3]); denoise(sums[4], outs[4]); denoise(sums[5], outs[5]);
+    for (size_t i = 0; i < N; i++) {
+        float m = rs[2 * i + 1];
+        for (int k = 0; k < 3; k++) {
+            float d = kd[3 * i + k] * (1.0f - m);
+            float v = d * outs[1][3 * i + k] + outs[2][3 * i + k] + outs[3][3 * i + k];
+            if (occ[i] <= 0.1f) v = 1.0f;
+            if (std::isnan(v)) v = 0.f;                      // torch.nan_to_num(x, 0.0): nan->0, +-inf -> +-FLT_MAX
+            else if (std::isinf(v)) v = v > 0 ? 3.4028234663852886e38f : -3.4028234663852886e38f;
+            outs[0][3 * i + k] = v;
+        }
+    }
+}
+
 static void accumulate(std::vector<float>& a, const std::vector<float>& b) {
 #pragma omp parallel for
     for (long long i = 0; i < (long long)a.size(); i++) a[i] += b[i];
@@ -353,36 +391,9 @@ int orc_render(const OrcRenderArgs* A) {
         accumulate(total_color, color); accumulate(total_diff, cdiff); accumulate(total_spec, cspec);
     }
     if (A->counters) for (int k = 0; k < 4; k++) A->counters[k] += cnt[k];
-    // run_restir_di_with_pt :507-549
-    const float inv = (float)A->spp;
-    std::vector<float> comb(3 * N);
-    for (size_t i = 0; i < 3 * N; i++) {
-        total_color[i] /= inv; total_diff[i] /= inv; total_spec[i] /= inv; total_color_1[i] /= inv; total_diff_1[i] /= inv; total_spec_1[i] /= inv;
-        comb[i] = total_diff_1[i] + total_spec_1[i];
-    }
+    float* sums[6] = {total_color.data(), total_diff.data(), total_spec.data(), total_color_1.data(), total_diff_1.data(), total_spec_1.data()};
+    orc_finish(fx, fy, A->spp, A->occ, A->normal, A->pos, A->kd, A->rs, A->denoise_iter, A->step_width, A->c_phi, A->n_phi, A->p_phi, sums, A->outs);
     if (A->avg_direct) std::memcpy(A->avg_direct, total_color.data(), sizeof(float) * 3 * N);
-    auto denoise = [&](const std::vector<float>& in, float* out) {
-        std::vector<float> cur = in, nxt(3 * N);
-        int sw = A->step_width; float swf = (float)A->step_width;
-        for (int it = 0; it < A->denoise_iter; it++) {
-            sw = (int)swf;  // Denoising.py: stepWidth /= 2 (float), int(stepWidth) at launch
-            orc_eaw(fx, fy, sw, A->c_phi, A->n_phi, A->p_phi, A->occ, cur.data(), A->normal, A->pos, nxt.data());
-            cur.swap(nxt); swf = swf / 2;
-        }
-        std::memcpy(out, cur.data(), sizeof(float) * 3 * N);
-    };
-    denoise(total_diff, A->outs[1]); denoise(total_spec, A->outs[2]); denoise(comb, A->outs[3]); denoise(total_diff_1, A->outs[4]); denoise(total_spec_1, A->outs[5]);
-    for (size_t i = 0; i < N; i++) {
-        float m = A->rs[2 * i + 1];
-        for (int k = 0; k < 3; k++) {
-            float d = A->kd[3 * i + k] * (1.0f - m);
-            float v = d * A->outs[1][3 * i + k] + A->outs[2][3 * i + k] + A->outs[3][3 * i + k];
-            if (A->occ[i] <= 0.1f) v = 1.0f;
-            if (std::isnan(v)) v = 0.f;                      // torch.nan_to_num(x, 0.0): nan->0, +-inf -> +-FLT_MAX
-            else if (std::isinf(v)) v = v > 0 ? 3.4028234663852886e38f : -3.4028234663852886e38f;
-            A->outs[0][3 * i + k] = v;
-        }
-    }
     return 0;
 }
 

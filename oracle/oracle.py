@@ -372,6 +372,17 @@ def render(fx, fy, spp, random_offset, bvh, vert, tri, env_map, occ, normal, dep
                 counters=cnt, occ=occ, avg_direct=avg)
 
 
+def finish(fx, fy, spp, occ, normal, pos, kd, rs, sums, denoise_iter=2, step_width=2, c_phi=2.0, n_phi=0.1, p_phi=0.001):
+    """Second half of run_restir_di_with_pt (renderer_restir.py:507-549) on six raw sums [6,N,3] -> the six outputs [6,N,3]. `occ` already thresholded."""
+    N = fx * fy
+    s_ = [_c(np.array(a, np.float32, copy=True), np.float32) for a in sums]
+    o_ = [np.zeros((N, 3), np.float32) for _ in range(6)]
+    sp = (f32p * 6)(*[_p(a, f32p) for a in s_]); op = (f32p * 6)(*[_p(a, f32p) for a in o_])
+    lib().orc_finish(fx, fy, int(spp), _p(_c(occ, np.float32), f32p), _p(_c(normal, np.float32), f32p), _p(_c(pos, np.float32), f32p), _p(_c(kd, np.float32), f32p),
+                     _p(_c(rs, np.float32), f32p), int(denoise_iter), int(step_width), C.c_float(c_phi), C.c_float(n_phi), C.c_float(p_phi), sp, op)
+    return o_
+
+
 # ------------------------------------------------------------------ nerf/render_dump.py (BASELINE configs[0])
 def envir_map_dirs(envmap_h, envmap_w):
     """generate_envir_map_dir (nerf/render_helper.py:8-26, is_jittor=False): lat-long light set, z up; (area weights [H*W], directions [H*W,3])."""

@@ -13,6 +13,10 @@ What can be imported of the hot path: everything else is Slang->CU
     origin) as the `intersector` object the reference expects from outside (nerf/renderer.py:179 sets it to None) — nothing of this repo's
     engine or oracle is in the loop. render_helper.py cannot be imported (tinycudann / nvdiffrast at module top), so
     the one pure-torch function is compiled from the file's AST and executed as is. -> tests/golden/config1_dump_render.npz
+  * nerf/renderer_restir.py:run_restir_di_with_pt (:473-550) — the frame's pre / post processing (occupancy threshold, averaging by the sample
+    count, the five denoiser calls, kd (1 - metalness) D + S + I, background = 1, nan_to_num), executed from the file's AST (the module imports
+    slangpy) with `restir_di_with_pt` replaced by a function that hands back prepared sums and the a-trous drivers being the reference's own
+    Denoising.py over the oracle kernel. Pins what mirres_render's finish / mirres_render_finish restate.
   * nerf/utils.py:linear2srgb_torch (+ _clip_0to1_warn_torch) — the tone curve of the harness (SURVEY §8 a-H), taken by AST like above.
 The fixtures are data (inputs + outputs); no reference source text is stored.
 
@@ -183,7 +187,35 @@ def main():
     l2s = load_function("nerf/utils.py", "linear2srgb_torch", ns)
     srgb_in = np.concatenate([np.array([-0.5, 0.0, 1e-7, 0.001, 0.0031308, 0.00313081, 0.5, 1.0, 1.7], np.float32), rng.random(55).astype(np.float32)])
     srgb_out = l2s(torch.from_numpy(srgb_in.copy())).numpy()
+    # ---- run_restir_di_with_pt pre / post (the spp loop replaced by prepared sums)
+    spp_f = 7
+    sums = [(rng.random((Np, 3)) * spp_f * (0.5 + k)).astype(np.float32) for k in range(6)]   # total_color, diff, spec, color_1, diff_1, spec_1
+    f_occ = rng.choice(np.array([0.0, 0.05, 0.3, 0.5, 0.7, 1.0], np.float32), size=(Np, 1)).astype(np.float32)
+    f_kd = rng.random((Np, 3)).astype(np.float32); f_rm = rng.random((Np, 2)).astype(np.float32)
+    f_rd = rng.normal(size=(Np, 3)).astype(np.float32)
+    seen = {}
+
+    def fake_loop(use_scale, sx, sy, sz, mlp_mat, worker, spp_, fxx, fyy, *rest):
+        seen["occ_after_threshold"] = rest[-13].numpy().copy()      # occ_map as the loop receives it
+        seen["ray_dir_norm"] = rest[-7].numpy().copy()              # ray_dir_map after safe_l2_normalize
+        tt = [torch.from_numpy(a_.copy()) for a_ in sums]
+        return tt[0], tt[3], tt[1], tt[2], tt[4], tt[5], torch.zeros(1), spp_
+    ns2 = {"torch": torch, "np": np, "safe_l2_normalize": rd.safe_l2_normalize, "restir_di_with_pt": fake_loop,
+           "EAWDenoise_use_phi": den.EAWDenoise_use_phi, "EAWDenoise_use_phi_no_di": den.EAWDenoise_use_phi_no_di}
+    run_ref = load_function("nerf/renderer_restir.py", "run_restir_di_with_pt", ns2)
+    torch.zeros = cpu_zeros
+    try:
+        t = lambda a_: torch.from_numpy(a_.copy())
+        occ_t = t(f_occ)
+        fin = run_ref(False, 1.0, 1.0, 1.0, None, None, None, *([None] * 7), FakeDen(), *([None] * 7), 128, 1024,
+                      t(env), occ_t, t(nrm), torch.zeros(Np, 1), t(f_kd), t(f_rm), t(f_rd), t(pos), None, None, None, None,
+                      fx, fy, spp_f, 2, 2, 2.0, 0.1, 0.001)
+    finally:
+        torch.zeros = real_zeros
+    fin = [o.numpy() for o in fin]
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "ref_python.npz"), norm_in=x, norm_out=norm_out, env=env, srgb_in=srgb_in, srgb_out=srgb_out,
+                        fin_spp=np.int32(spp_f), fin_sums=np.stack(sums), fin_occ=f_occ, fin_kd=f_kd, fin_rm=f_rm, fin_rd=f_rd, fin_out=np.stack(fin),
+                        fin_occ_after=seen["occ_after_threshold"], fin_occ_inplace=occ_t.numpy(), fin_rd_norm=seen["ray_dir_norm"],
                         pdf=pdf_.numpy().ravel(), cdf=cdf_.numpy().ravel(), mpdf=mpdf_.numpy().ravel(), mcdf=mcdf_.numpy().ravel(),
                         eaw_dims=np.array([fx, fy], np.int32), eaw_occ=occ, eaw_col=col, eaw_nrm=nrm, eaw_pos=pos, eaw_di=eaw_di, eaw_nodi=eaw_nodi,
                         eaw_steps=np.array(launches, np.int32))

@@ -183,3 +183,27 @@ def test_eaw_driver_matches_the_reference_driver(env):
     b = EAWDenoise_use_phi_no_di(mods[7], 2.0, 0.1, 0.001, 4, 3, fx, fy, t("eaw_occ"), t("eaw_col"), t("eaw_nrm"), t("eaw_pos"))
     np.testing.assert_allclose(a.cpu().numpy(), g["eaw_di"], rtol=3e-5, atol=2e-6)
     np.testing.assert_allclose(b.cpu().numpy(), g["eaw_nodi"], rtol=3e-5, atol=2e-6)
+
+
+def test_render_finish_matches_the_reference_post_processing(env):
+    """mirres_render_finish (average, five a-trous runs, composite, background, nan_to_num) on prepared sums against the fixture produced by the
+    REFERENCE's own run_restir_di_with_pt (executed from its AST with the spp loop replaced by those sums; tests/golden/ref_python.npz)."""
+    import os, ctypes as C
+    F, W, mods, T, torch = env
+    from mirres_restir_nerf_mesh_amd import dist as D
+    from mirres_restir_nerf_mesh_amd._ops import get_ctx
+    from mirres_restir_nerf_mesh_amd._lib import lib, check, stream_ptr
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_python.npz"))
+    fx, fy = [int(v) for v in g["eaw_dims"]]; N = fx * fy
+    ctx = get_ctx(fx, fy)
+    c = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    gb = dict(occ=c(g["fin_occ"]), normal=c(g["eaw_nrm"]), depth=torch.zeros((N, 1), device="cuda"), kd=c(g["fin_kd"]), rm=c(g["fin_rm"]), ray_dir=c(g["fin_rd"]), pos=c(g["eaw_pos"]))
+    _, a, keep = D._finish_args(ctx, torch.full((8, 16, 3), 0.5, device="cuda"), gb, int(g["fin_spp"]), 2, 2, 2.0, 0.1, 0.001)
+    sums = [c(g["fin_sums"][k]) for k in range(6)]
+    outs = [torch.empty((N, 3), device="cuda") for _ in range(6)]
+    for k in range(6):
+        a.outs[k] = outs[k].data_ptr()
+    arr = (C.c_void_p * 6)(*[s_.data_ptr() for s_ in sums])
+    check(lib().mirres_render_finish(ctx.h, C.byref(a), arr, stream_ptr()), "mirres_render_finish")
+    for k in range(6):
+        np.testing.assert_allclose(outs[k].cpu().numpy(), g["fin_out"][k], rtol=3e-5, atol=3e-6, err_msg=str(k))
