@@ -4,6 +4,9 @@
 // PARITY UNPINNED: the reference holds no tests / golden vectors for this path and its Slang->CUDA
 // kernels cannot be compiled or imported here; the oracle is pinned only by
 // known-answer values derived from the reference formulas and by independent invariants (tests/).
+// What IS pinned by reference code run in the build container (tests/golden/gen_*.py): the frame loop and its pre / post
+// processing (orc_render against the reference's own Python loop executed over these kernels), the a-trous driver, the
+// importance-table construction, and nerf/render_dump.py (orc_dump.hpp).
 //
 // Fixed floating-point policy (shared, by contract, with the HIP product — not by shared code):
 //   * fp32 everywhere, IEEE division and sqrt, no FMA contraction (-ffp-contract=off),
