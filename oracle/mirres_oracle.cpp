@@ -59,6 +59,14 @@ int orc_bvh_build(const float* vert, int V, const int32_t* tri, int T, int32_t* 
     if (max_height) *max_height = st.max_height;
     return 0;
 }
+// the seven build kernels one by one (driven by the reference's own update_bvh in tests/golden/gen_reference_loop.py)
+void orc_bvh_elements(const float* vert, const int32_t* tri, int T, int32_t* ele_prim, float* ele) { bvh_elements(vert, tri, T, ele_prim, ele); }
+void orc_bvh_morton(int T, const float* gmin, const float* gmax, const float* ele, int32_t* codes) { bvh_morton(T, gmin, gmax, ele, codes); }
+void orc_bvh_radix_sort(int T, int32_t* a, int32_t* b) { bvh_radix_sort(T, a, b); }
+void orc_bvh_hierarchy(int T, const int32_t* ele_prim, const float* ele, const int32_t* sorted, int32_t* info, float* aabb, int32_t* cons) { bvh_hierarchy(T, ele_prim, ele, sorted, info, aabb, cons); }
+void orc_bvh_heights(int T, const int32_t* cons, int32_t* heights) { bvh_heights(T, cons, heights); }
+void orc_bvh_bbox_pass(int T, int eh, const int32_t* info, float* aabb, const int32_t* cons) { bvh_bbox_pass(T, eh, info, aabb, cons); }
+void orc_bvh_set_root(const int32_t* info, float* aabb) { bvh_set_root(info, aabb); }
 // rays [n,8] = (ox,oy,oz,tmin, dx,dy,dz,tmax). counters [n,4] optional (popped, entered, leaves, overflow).
 void orc_trace(const int32_t* info, const float* aabb, const float* vert, const int32_t* tri, const float* rays, int n, int want_normal,
                int32_t* hit, float* t, float* pos, float* normal, int32_t* prim, uint32_t* counters) {

@@ -41,12 +41,12 @@ struct BuildStats { int max_height; };
 
 // Restates restirbvhWorker.update_bvh (nerf/renderer_restir.py:25-89) and its 7 kernels.
 // info  int32[2T-1,3] (left,right,prim)   aabb  float[2T-1,6]   sorted int32[T,2] (code, elementIdx)
-static inline void bvh_build(const float* vert, int V, const int32_t* tri, int T,
-                             int32_t* info, float* aabb, int32_t* sorted_out, BuildStats* st) {
-    (void)V;
-    const int N = 2 * T - 1;
-    std::vector<float> ele(6 * (size_t)T);
-    // generateElements  get_elements.slang:3-39
+// The seven build kernels, one function each, so that the reference's own driver (restirbvhWorker.update_bvh, renderer_restir.py:25-89, executed
+// from its source by tests/golden/gen_reference_loop.py) can launch them in its order; bvh_build below is the oracle's restatement of that driver.
+// `cons` = g_lbvh_construction_infos i32[2T-1,2]: (parent, unused).
+
+// generateElements  get_elements.slang:3-39
+static inline void bvh_elements(const float* vert, const int32_t* tri, int T, int32_t* ele_prim, float* ele) {
     for (int p = 0; p < T; p++) {
         float mn[3] = {1e9f, 1e9f, 1e9f}, mx[3] = {-1e9f, -1e9f, -1e9f};
         for (int i = 0; i < 3; i++) {
@@ -60,16 +60,11 @@ static inline void bvh_build(const float* vert, int V, const int32_t* tri, int T
             ele[6 * p + k] = fminf(mn[k], mx[k]);
             ele[6 * p + 3 + k] = fmaxf(mn[k], mx[k]);
         }
+        if (ele_prim) ele_prim[p] = p;
     }
-    // scene extent  renderer_restir.py:34-40
-    float gmin[3] = {INFINITY, INFINITY, INFINITY}, gmax[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int p = 0; p < T; p++)
-        for (int k = 0; k < 3; k++) {
-            gmin[k] = fminf(gmin[k], ele[6 * p + k]);
-            gmax[k] = fmaxf(gmax[k], ele[6 * p + 3 + k]);
-        }
-    // morton_codes  lbvh_morton_codes.slang:46-80
-    std::vector<int32_t> a(2 * (size_t)T), b(2 * (size_t)T);
+}
+// morton_codes  lbvh_morton_codes.slang:46-80
+static inline void bvh_morton(int T, const float* gmin, const float* gmax, const float* ele, int32_t* codes) {
     for (int g = 0; g < T; g++) {
         float c[3];
         for (int k = 0; k < 3; k++) {
@@ -77,14 +72,16 @@ static inline void bvh_build(const float* vert, int V, const int32_t* tri, int T
             float center = mn + 0.5f * (mx - mn);
             c[k] = (center - gmin[k]) / (gmax[k] - gmin[k]);
         }
-        a[2 * g] = (int32_t)morton3d(c[0], c[1], c[2]);
-        a[2 * g + 1] = g;
+        codes[2 * g] = (int32_t)morton3d(c[0], c[1], c[2]);
+        codes[2 * g + 1] = g;
     }
-    // radix_sort  lbvh_single_radixsort.slang:28-138 : stable LSD, 4 x 8 bit, result back in `a`
+}
+// radix_sort  lbvh_single_radixsort.slang:28-138 : stable LSD, 4 x 8 bit, ping-pong, result back in `a`
+static inline void bvh_radix_sort(int T, int32_t* a, int32_t* b) {
     for (int it = 0; it < 4; it++) {
         int shift = 8 * it;
-        const std::vector<int32_t>& src = (it % 2 == 0) ? a : b;
-        std::vector<int32_t>& dst = (it % 2 == 0) ? b : a;
+        const int32_t* src = (it % 2 == 0) ? a : b;
+        int32_t* dst = (it % 2 == 0) ? b : a;
         uint32_t hist[256] = {0};
         for (int i = 0; i < T; i++) hist[((uint32_t)src[2 * i] >> shift) & 255u]++;
         uint32_t off[256]; uint32_t s = 0;
@@ -95,14 +92,13 @@ static inline void bvh_build(const float* vert, int V, const int32_t* tri, int T
             dst[2 * o] = src[2 * i]; dst[2 * o + 1] = src[2 * i + 1];
         }
     }
-    if (sorted_out) std::memcpy(sorted_out, a.data(), sizeof(int32_t) * 2 * (size_t)T);
-    const int32_t* sorted = a.data();
-    // hierarchy  lbvh_hierarchy.slang:111-245
-    std::vector<int32_t> parent(N, 0);
+}
+// hierarchy  lbvh_hierarchy.slang:111-245
+static inline void bvh_hierarchy(int T, const int32_t* ele_prim, const float* ele, const int32_t* sorted, int32_t* info, float* aabb, int32_t* cons) {
     const int LEAF = T - 1;
     for (int g = 0; g < T; g++) {
         int e = sorted[2 * g + 1];
-        info[3 * (LEAF + g) + 0] = 0; info[3 * (LEAF + g) + 1] = 0; info[3 * (LEAF + g) + 2] = e;  // ele_primitiveIdx[e] = e
+        info[3 * (LEAF + g) + 0] = 0; info[3 * (LEAF + g) + 1] = 0; info[3 * (LEAF + g) + 2] = ele_prim ? ele_prim[e] : e;
         for (int k = 0; k < 6; k++) aabb[6 * (LEAF + g) + k] = ele[6 * e + k];
     }
     for (int g = 0; g < T - 1; g++) {
@@ -134,50 +130,82 @@ static inline void bvh_build(const float* vert, int V, const int32_t* tri, int T
         int cB = (split + 1 == last) ? LEAF + split + 1 : split + 1;
         info[3 * g + 0] = cA; info[3 * g + 1] = cB; info[3 * g + 2] = 0;
         for (int k = 0; k < 3; k++) { aabb[6 * g + k] = 1e9f; aabb[6 * g + 3 + k] = -1e9f; }
-        parent[cA] = g; parent[cB] = g;
+        cons[2 * cA] = g; cons[2 * cB] = g;
     }
-    parent[0] = 0;
-    // get_bvh_height  lbvh_bounding_boxes.slang:151-173
-    int hmax = 0;
+    cons[0] = 0;
+}
+// get_bvh_height  lbvh_bounding_boxes.slang:151-173
+static inline void bvh_heights(int T, const int32_t* cons, int32_t* heights) {
+    const int LEAF = T - 1;
     for (int g = 0; g < T; g++) {
-        uint32_t n = (uint32_t)parent[LEAF + g]; int h = 0;
-        while (n != 0) { h++; n = (uint32_t)parent[n]; }
-        hmax = std::max(hmax, h);
+        uint32_t n = (uint32_t)cons[2 * (LEAF + g)]; int h = 0;
+        while (n != 0) { h++; n = (uint32_t)cons[2 * n]; }
+        heights[g] = h;
     }
-    if (st) st->max_height = hmax;
-    // get_bbox passes  :175-298 + renderer_restir.py:78-83
-    for (int eh = 1; eh <= hmax; eh++) {
-        for (int g = 0; g < T; g++) {
-            uint32_t n = (uint32_t)parent[LEAF + g]; int h = 0;
-            while (true) {
-                if (n == 0) break;
-                h++;
-                if (h > eh) break;
-                if (h == eh) {
-                    int L = info[3 * n], R = info[3 * n + 1];
-                    float mnA[3], mxA[3], mnB[3], mxB[3];
-                    for (int k = 0; k < 3; k++) {
-                        mnA[k] = aabb[6 * L + k]; mxA[k] = aabb[6 * L + 3 + k];
-                        mnB[k] = aabb[6 * R + k]; mxB[k] = aabb[6 * R + 3 + k];
-                        if (L == 0) { mnA[k] = 1e9f; mxA[k] = -1e9f; }
-                        if (R == 0) { mnB[k] = 1e9f; mxB[k] = -1e9f; }
-                        aabb[6 * n + k] = fminf(mnA[k], mnB[k]);
-                        aabb[6 * n + 3 + k] = fmaxf(mxA[k], mxB[k]);
-                    }
-                    break;
+}
+// get_bbox, one pass  :175-298
+static inline void bvh_bbox_pass(int T, int eh, const int32_t* info, float* aabb, const int32_t* cons) {
+    const int LEAF = T - 1;
+    for (int g = 0; g < T; g++) {
+        uint32_t n = (uint32_t)cons[2 * (LEAF + g)]; int h = 0;
+        while (true) {
+            if (n == 0) break;
+            h++;
+            if (h > eh) break;
+            if (h == eh) {
+                int L = info[3 * n], R = info[3 * n + 1];
+                float mnA[3], mxA[3], mnB[3], mxB[3];
+                for (int k = 0; k < 3; k++) {
+                    mnA[k] = aabb[6 * L + k]; mxA[k] = aabb[6 * L + 3 + k];
+                    mnB[k] = aabb[6 * R + k]; mxB[k] = aabb[6 * R + 3 + k];
+                    if (L == 0) { mnA[k] = 1e9f; mxA[k] = -1e9f; }
+                    if (R == 0) { mnB[k] = 1e9f; mxB[k] = -1e9f; }
+                    aabb[6 * n + k] = fminf(mnA[k], mnB[k]);
+                    aabb[6 * n + 3 + k] = fmaxf(mxA[k], mxB[k]);
                 }
-                n = (uint32_t)parent[n];
+                break;
             }
+            n = (uint32_t)cons[2 * n];
         }
     }
-    // set_root  :300-389
-    {
-        int L = info[0], R = info[1];
+}
+// set_root  :300-389
+static inline void bvh_set_root(const int32_t* info, float* aabb) {
+    int L = info[0], R = info[1];
+    for (int k = 0; k < 3; k++) {
+        aabb[k] = fminf(aabb[6 * L + k], aabb[6 * R + k]);
+        aabb[3 + k] = fmaxf(aabb[6 * L + 3 + k], aabb[6 * R + 3 + k]);
+    }
+}
+
+// restirbvhWorker.update_bvh (renderer_restir.py:25-89): the driver of the seven kernels
+static inline void bvh_build(const float* vert, int V, const int32_t* tri, int T,
+                             int32_t* info, float* aabb, int32_t* sorted_out, BuildStats* st) {
+    (void)V;
+    const int N = 2 * T - 1;
+    std::vector<float> ele(6 * (size_t)T);
+    std::vector<int32_t> ele_prim((size_t)T);
+    bvh_elements(vert, tri, T, ele_prim.data(), ele.data());
+    // scene extent  renderer_restir.py:34-40
+    float gmin[3] = {INFINITY, INFINITY, INFINITY}, gmax[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int p = 0; p < T; p++)
         for (int k = 0; k < 3; k++) {
-            aabb[k] = fminf(aabb[6 * L + k], aabb[6 * R + k]);
-            aabb[3 + k] = fmaxf(aabb[6 * L + 3 + k], aabb[6 * R + 3 + k]);
+            gmin[k] = fminf(gmin[k], ele[6 * p + k]);
+            gmax[k] = fmaxf(gmax[k], ele[6 * p + 3 + k]);
         }
-    }
+    std::vector<int32_t> a(2 * (size_t)T), b(2 * (size_t)T, 0);
+    bvh_morton(T, gmin, gmax, ele.data(), a.data());
+    bvh_radix_sort(T, a.data(), b.data());
+    if (sorted_out) std::memcpy(sorted_out, a.data(), sizeof(int32_t) * 2 * (size_t)T);
+    std::vector<int32_t> cons(2 * (size_t)N, 0);
+    bvh_hierarchy(T, ele_prim.data(), ele.data(), a.data(), info, aabb, cons.data());
+    std::vector<int32_t> heights((size_t)T);
+    bvh_heights(T, cons.data(), heights.data());
+    int hmax = 0;
+    for (int g = 0; g < T; g++) hmax = std::max(hmax, heights[g]);
+    if (st) st->max_height = hmax;
+    for (int eh = 1; eh <= hmax; eh++) bvh_bbox_pass(T, eh, info, aabb, cons.data());   // renderer_restir.py:78-83
+    bvh_set_root(info, aabb);
 }
 
 // ---------------------------------------------------------------- traversal  (utils/helperDi.slang:136-395)

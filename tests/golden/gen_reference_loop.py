@@ -3,6 +3,9 @@ the restirbvhWorker launch methods (:96-146) and the launch wrappers of nerf/Scr
 in this container (never on the GPU box) on CPU tensors, with the Slang module objects replaced by one fake module whose `process_*(...).launchRaw(...)`
 run this repo's ORACLE kernels on exactly the tensors the reference hands over.
 
+The BVH the loop traces comes from the reference's own `restirbvhWorker.update_bvh` (:25-89) executed the same way over the oracle's seven build
+kernels (scene extent by torch min / max, `range(tree_heights.max())` refit passes, set_root), and is compared with the oracle's bvh_build.
+
 What this pins: the orchestration the oracle's orc_render (and, through it, mirres_render) restates — frame-index schedule (random_offset +
 20 i + pass), the derived maps (normal_depth, brdf_map with its luminance weights / clamp / square), the two environment copies, reservoir
 ping-pong, which buffers alias which across samples, the material look-ups between bounces, the nine accumulations, averaging, denoising,
@@ -198,13 +201,55 @@ def main():
     wns = dict(ns)
     methods = ref_functions("nerf/renderer_restir.py", ["InitialResampling_", "SpatialResampling_", "EvaluateFinalSamples_get_vis"], wns, cls="restirbvhWorker")
 
-    class Worker:   # the attributes and launch methods run_restir_di_with_pt uses of restirbvhWorker; the BVH arrays come from the oracle's builder
+    build_log = []
+
+    class BuildM:   # stands for the five bvhworkers modules
+        def _l(self, name, fn):
+            def run(_):
+                build_log.append(name); fn()
+            return Launch(lambda g: (build_log.append(name), fn()), name)
+        def generateElements(self, vert, v_indx, ele_primitiveIdx, ele_aabb):
+            return self._l("generateElements", lambda: L.orc_bvh_elements(P(vert), PI(v_indx), v_indx.shape[0], PI(ele_primitiveIdx), P(ele_aabb)))
+        def pushConstantsMortonCodes(self, **k):
+            import types
+            return types.SimpleNamespace(**k)
+        def morton_codes(self, pc, ele_aabb, morton_codes_ele):
+            def fn():
+                gmin = np.array([float(pc.g_min_x), float(pc.g_min_y), float(pc.g_min_z)], np.float32)
+                gmax = np.array([float(pc.g_max_x), float(pc.g_max_y), float(pc.g_max_z)], np.float32)
+                L.orc_bvh_morton(int(pc.g_num_elements), gmin.ctypes.data_as(f32p), gmax.ctypes.data_as(f32p), P(ele_aabb), PI(morton_codes_ele))
+            return self._l("morton_codes", fn)
+        def radix_sort(self, g_num_elements, g_elements_in, g_elements_out):
+            return self._l("radix_sort", lambda: L.orc_bvh_radix_sort(g_num_elements, PI(g_elements_in), PI(g_elements_out)))
+        def hierarchy(self, g_num_elements, ele_primitiveIdx, ele_aabb, g_sorted_morton_codes, g_lbvh_info, g_lbvh_aabb, g_lbvh_construction_infos):
+            return self._l("hierarchy", lambda: L.orc_bvh_hierarchy(g_num_elements, PI(ele_primitiveIdx), P(ele_aabb), PI(g_sorted_morton_codes), PI(g_lbvh_info), P(g_lbvh_aabb),
+                                                                      PI(g_lbvh_construction_infos)))
+        def get_bvh_height(self, g_num_elements, g_lbvh_info, g_lbvh_aabb, g_lbvh_construction_infos, tree_heights):
+            return self._l("get_bvh_height", lambda: L.orc_bvh_heights(g_num_elements, PI(g_lbvh_construction_infos), PI(tree_heights)))
+        def get_bbox(self, g_num_elements, expected_height, g_lbvh_info, g_lbvh_aabb, g_lbvh_construction_infos):
+            return self._l("get_bbox%d" % expected_height, lambda: L.orc_bvh_bbox_pass(g_num_elements, expected_height, PI(g_lbvh_info), P(g_lbvh_aabb), PI(g_lbvh_construction_infos)))
+        def set_root(self, g_lbvh_info, g_lbvh_aabb):
+            return self._l("set_root", lambda: L.orc_bvh_set_root(PI(g_lbvh_info), P(g_lbvh_aabb)))
+
+    methods += ref_functions("nerf/renderer_restir.py", ["update_bvh", "update_mesh"], wns, cls="restirbvhWorker")
+
+    class Worker:   # the attributes and methods of restirbvhWorker the frame uses (its __init__ only loads the Slang modules)
         pass
     for fn in methods:
         setattr(Worker, fn.__name__, fn)
     W = Worker()
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a).copy())
-    W.LBVHNode_info, W.LBVHNode_aabb, W.vrt, W.v_ind = T(F.info.astype(np.int32)), T(F.aabb), T(F.vert), T(F.tri.astype(np.int32))
+    W.m_gen_ele = W.m_morton_codes = W.m_radixsort = W.m_hierarchy = W.m_bounding_box = BuildM()
+    real_zeros0 = torch.zeros
+    torch.zeros = lambda *a, **k: real_zeros0(*a, **{x: y for x, y in k.items() if x != "device"})
+    try:
+        W.update_mesh(T(F.vert), T(F.tri.astype(np.int32)))     # renderer.py:975
+    finally:
+        torch.zeros = real_zeros0
+    bvh_same = bool(np.array_equal(W.LBVHNode_info.numpy(), F.info) and np.array_equal(W.LBVHNode_aabb.numpy(), F.aabb))
+    print("update_bvh over the oracle's build kernels: %d launches (%s ... %s), identical to orc_bvh_build: %s" % (len(build_log), " ".join(build_log[:6]), build_log[-1], bvh_same))
+    assert bvh_same
+    del log[:]
 
     # load_m_for_restir's buffers (renderer_restir.py:189-217)
     nt = 128 * 1024
@@ -234,7 +279,8 @@ def main():
     print("launches: %d (%s ...), material look-ups: %d, random_offset %d" % (len(log), " ".join(log[:14]), mlp.calls, random_offset))
     print("max |reference loop over oracle kernels - orc_render| = %.3g; mean final colour %.4f" % (worst, float(outs[0].mean())))
     np.savez_compressed(os.path.join(HERE, "ref_loop.npz"), outs=outs, spp=np.int32(SPP), seed=np.int32(SEED), random_offset=np.int64(random_offset),
-                        launches=np.array(log), frame=np.array([FRAME["fx"], FRAME["fy"], FRAME["subdiv"], FRAME["ground"], FRAME["env_hw"][0], FRAME["env_hw"][1]], np.int32),
+                        launches=np.array(log), build_launches=np.array(build_log), bvh_info_crc=np.int64(int(np.bitwise_xor.reduce(W.LBVHNode_info.numpy().ravel().astype(np.int64) * np.arange(1, W.LBVHNode_info.numel() + 1)))),
+                        frame=np.array([FRAME["fx"], FRAME["fy"], FRAME["subdiv"], FRAME["ground"], FRAME["env_hw"][0], FRAME["env_hw"][1]], np.int32),
                         occ_after=occ_in.numpy())
     print("wrote ref_loop.npz")
 
