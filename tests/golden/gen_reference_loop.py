@@ -6,6 +6,9 @@ run this repo's ORACLE kernels on exactly the tensors the reference hands over.
 The BVH the loop traces comes from the reference's own `restirbvhWorker.update_bvh` (:25-89) executed the same way over the oracle's seven build
 kernels (scene extent by torch min / max, `range(tree_heights.max())` refit passes, set_root), and is compared with the oracle's bvh_build.
 
+`mlp_mat` is the reference's own `MLPTexture3D` / `_MLP` (nerf/render_helper.py:28-124, classes compiled from the AST: position normalisation and
+clamp, torch.nn.Linear stack, sigmoid and range) with `tcnn.Encoding` replaced by the oracle's hash-grid encoder (tiny-cuda-nn is not in the image).
+
 What this pins: the orchestration the oracle's orc_render (and, through it, mirres_render) restates — frame-index schedule (random_offset +
 20 i + pass), the derived maps (normal_depth, brdf_map with its luminance weights / clamp / square), the two environment copies, reservoir
 ping-pong, which buffers alias which across samples, the material look-ups between bounces, the nine accumulations, averaging, denoising,
@@ -50,6 +53,42 @@ def ref_functions(path, names, namespace, cls=None):
     return [namespace[n] for n in names]
 
 
+def ref_classes(path, names, namespace):
+    tree = ast.parse(open(os.path.join(REF, path)).read())
+    cls = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name in names]
+    assert len(cls) == len(names)
+    exec(compile(ast.Module(body=cls, type_ignores=[]), os.path.join(REF, path), "exec"), namespace)
+    return [namespace[n] for n in names]
+
+
+def reference_mlp(O, S, mat):
+    """The reference's MLPTexture3D over the oracle's hash-grid encoder, seeded like matnet_for. Returns (module, the enc_cfg it asked tcnn for)."""
+    import types
+    seen = {}
+
+    class Encoding:   # tcnn.Encoding(3, cfg): fp16 features [n,32]
+        n_output_dims = 32
+        def __init__(self, n_in, cfg): seen["n_in"], seen["cfg"] = n_in, dict(cfg)
+        def register_full_backward_hook(self, fn): pass
+        def __call__(self, x):
+            bits = O.hashgrid_encode(mat, x.detach().numpy().astype(np.float32))
+            return torch.from_numpy(bits.view(np.float16).reshape(-1, 32).copy())
+    ns = {"torch": torch, "np": np, "tcnn": types.SimpleNamespace(Encoding=Encoding, free_temporary_memory=lambda: None)}
+    _, MLPTexture3D = ref_classes("nerf/render_helper.py", ["_MLP", "MLPTexture3D"], ns)
+    params, w0, w1, w2 = S.make_matnet_params(seed=0)
+    mn, mx = S.material_min_max()
+    tc, mc = torch.Tensor.cuda, torch.nn.Module.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self; torch.nn.Module.cuda = lambda self, *a, **k: self   # the reference hard-codes .cuda(); no GPU here
+    try:
+        mlp = MLPTexture3D(torch.tensor([-1, -1, -1, 1, 1, 1], dtype=torch.float32), channels=6, min_max=[torch.from_numpy(mn), torch.from_numpy(mx)])
+    finally:
+        torch.Tensor.cuda, torch.nn.Module.cuda = tc, mc
+    with torch.no_grad():
+        for i, w in zip((0, 2, 4), (w0, w1, w2)):
+            mlp.net.net[i].weight.copy_(torch.from_numpy(w))
+    return mlp, seen
+
+
 def matnet_for(O, S):
     """Seeded material field (scene.make_matnet_params) as the oracle's struct + a stand-in for MLPTexture3D offering sample_no_di."""
     params, w0, w1, w2 = S.make_matnet_params(seed=0)
@@ -72,7 +111,14 @@ def main():
     S = M.scene
     F = SmallFrame(O, S, **FRAME)
     N, fx, fy = F.N, F.fx, F.fy
-    mat, mkeep, mlp = matnet_for(O, S)
+    mat, mkeep, mlp_standin = matnet_for(O, S)
+    mlp, enc_seen = reference_mlp(O, S, mat)
+    # the material field on its own: the reference's MLPTexture3D against the oracle's restatement
+    rngp = np.random.default_rng(5)
+    mat_pts = np.concatenate([(rngp.random((250, 3)) * 2.4 - 1.2), [[-1, -1, -1], [1, 1, 1], [0, 0, 0]]]).astype(np.float32)   # inside, outside (clamped), corners
+    mat_ref = mlp.sample_no_di(torch.from_numpy(mat_pts)).numpy()
+    mat_mine = np.asarray(O.matnet(mat, mat_pts)).reshape(-1, 6)
+    print("MLPTexture3D (reference classes over the oracle encoder) vs orc_matnet: max |d| = %.3g; tcnn config asked: %s" % (float(np.abs(mat_ref - mat_mine).max()), enc_seen["cfg"]))
     L = O.lib()
     f32p, i32p, u64p = O.f32p, O.i32p, O.u64p
     log = []
@@ -276,9 +322,11 @@ def main():
     mine = O.render(fx, fy, SPP, random_offset, (F.info, F.aabb), F.vert, F.tri, F.env, F.occ, F.normal, F.depth, F.kd, F.rm, F.ray_dir_raw, F.pos, mat=mat)
     names = ["final_color", "diffuse", "spec", "indirect", "indirect_diff", "indirect_spec"]
     worst = max(float(np.abs(outs[k] - mine[n]).max()) for k, n in enumerate(names))
-    print("launches: %d (%s ...), material look-ups: %d, random_offset %d" % (len(log), " ".join(log[:14]), mlp.calls, random_offset))
+    print("launches: %d (%s ...), random_offset %d" % (len(log), " ".join(log[:14]), random_offset))
     print("max |reference loop over oracle kernels - orc_render| = %.3g; mean final colour %.4f" % (worst, float(outs[0].mean())))
     np.savez_compressed(os.path.join(HERE, "ref_loop.npz"), outs=outs, spp=np.int32(SPP), seed=np.int32(SEED), random_offset=np.int64(random_offset),
+                        mat_pts=mat_pts, mat_out=mat_ref, enc_per_level_scale=np.float64(enc_seen["cfg"]["per_level_scale"]),
+                        enc_cfg=np.array([enc_seen["n_in"], enc_seen["cfg"]["n_levels"], enc_seen["cfg"]["n_features_per_level"], enc_seen["cfg"]["log2_hashmap_size"], enc_seen["cfg"]["base_resolution"]], np.int32),
                         launches=np.array(log), build_launches=np.array(build_log), bvh_info_crc=np.int64(int(np.bitwise_xor.reduce(W.LBVHNode_info.numpy().ravel().astype(np.int64) * np.arange(1, W.LBVHNode_info.numel() + 1)))),
                         frame=np.array([FRAME["fx"], FRAME["fy"], FRAME["subdiv"], FRAME["ground"], FRAME["env_hw"][0], FRAME["env_hw"][1]], np.int32),
                         occ_after=occ_in.numpy())

@@ -70,3 +70,23 @@ def test_mfma_mlp_matches_fp32_chain(oracle, scene_mod):
     pts = torch.rand((4096, 3), device="cuda", generator=g) * 2 - 1
     np.testing.assert_allclose(mlp.mlp_on_encoding(mlp.encode(pts)).cpu().numpy(), oracle.matnet(om, pts.cpu().numpy()), rtol=0, atol=4e-6)
     assert mlp.mlp_on_encoding(torch.empty((0, 32), dtype=torch.float16, device="cuda")).shape == (0, 6)
+
+
+def test_material_field_matches_the_reference_classes(scene_mod):
+    """MLPTexture3D.sample / sample_no_di of the package (hash grid + MFMA MLP through the C ABI) against the outputs of the REFERENCE's own
+    MLPTexture3D / _MLP classes run over the oracle's hash-grid encoder (tests/golden/ref_loop.npz, gen_reference_loop.py): same seeded weights,
+    points inside, outside (clamped) and on the corners of the AABB."""
+    import os
+    import torch
+    from mirres_restir_nerf_mesh_amd.render_helper import MLPTexture3D
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_loop.npz"))
+    params, w0, w1, w2 = scene_mod.make_matnet_params(seed=0)
+    mn, mx = scene_mod.material_min_max()
+    mlp = MLPTexture3D(torch.tensor([-1, -1, -1, 1, 1, 1], dtype=torch.float32), channels=6, min_max=(torch.from_numpy(mn).cuda(), torch.from_numpy(mx).cuda()), seed=1)
+    with torch.no_grad():
+        mlp.encoder.params.copy_(torch.from_numpy(params).cuda())
+        for i, w in zip((0, 2, 4), (w0, w1, w2)):
+            mlp.net.net[i].weight.copy_(torch.from_numpy(w).cuda())
+    x = torch.from_numpy(g["mat_pts"]).cuda()
+    np.testing.assert_allclose(mlp.sample_no_di(x).cpu().numpy(), g["mat_out"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(mlp.sample(x).detach().cpu().numpy(), g["mat_out"], rtol=0, atol=1e-5)
