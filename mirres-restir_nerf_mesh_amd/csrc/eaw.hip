@@ -44,6 +44,59 @@ __global__ void __launch_bounds__(MR_BLOCK) k_eaw(int fx, int fy, int step, floa
     st3(out, pi, sum / cum_w);
 }
 
+// The frame's five a-trous runs (diffuse, specular, indirect, indirect diffuse, indirect specular: run_restir_di_with_pt :521-533) share the
+// guides, hence the tap geometry and the normal / position weights; only the colour weight differs per buffer. One pass per iteration: per tap
+// 24 B of guides + 5 x 12 B of colours instead of 5 x 36 B, 7 exponentials instead of 15 — each buffer's result is the expression k_eaw
+// evaluates, bit for bit (weight = c_w * n_w * p_w in that order).
+struct Eaw5 { const float* in[5]; float* out[5]; };
+__global__ void __launch_bounds__(MR_BLOCK) k_eaw5(int fx, int fy, int step, float c_phi, float n_phi, float p_phi, const float* __restrict__ occ,
+                                                   const float* __restrict__ normal, const float* __restrict__ pos, Eaw5 B) {
+    const int pi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pi >= fx * fy) return;
+    if (occ[pi] < 0.1f) {
+#pragma unroll
+        for (int b = 0; b < 5; b++) st3(B.out[b], pi, ld3(B.in[b], pi));
+        return;
+    }
+    const int x = pi % fx, y = pi / fx;
+    const v3 nval = ld3(normal, pi), pval = ld3(pos, pi);
+    v3 cval[5], sum[5]; float cum_w[5];
+#pragma unroll
+    for (int b = 0; b < 5; b++) { cval[b] = ld3(B.in[b], pi); sum[b] = V3(0.f); cum_w[b] = 0.0f; }
+#pragma unroll 5
+    for (int i = 0; i < 25; i++) {
+        const int ox = (i % 5) - 2, oy = (i / 5) - 2;
+        const int ux = x + (int)((float)ox * step), uy = y + (int)((float)oy * step);
+        if (!(ux >= 0 && uy >= 0 && ux < fx && uy < fy)) continue;
+        const size_t qi = (size_t)uy * fx + ux;
+        const float kw = b3(i % 5) * b3(i / 5) / 256.0f;
+        v3 t = nval - ld3(normal, qi);
+        float dist2 = fmaxf(dot(t, t), 0.0f);
+        const float n_w = fminf(expf(-(dist2) / n_phi), 1.0f);
+        t = pval - ld3(pos, qi);
+        dist2 = fmaxf(dot(t, t), 0.0f);
+        const float p_w = fminf(expf(-(dist2) / p_phi), 1.0f);
+#pragma unroll
+        for (int b = 0; b < 5; b++) {
+            const v3 ctmp = ld3(B.in[b], qi);
+            const v3 tc = cval[b] - ctmp;
+            const float c_w = fminf(expf(-(dot(tc, tc)) / c_phi), 1.0f);
+            const float weight = c_w * n_w * p_w;
+            sum[b] = sum[b] + ctmp * weight * kw;
+            cum_w[b] += weight * kw;
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < 5; b++) st3(B.out[b], pi, sum[b] / cum_w[b]);
+}
+int launch_eaw5(int fx, int fy, int step, float c_phi, float n_phi, float p_phi, const float* occ, const float* const in[5], const float* normal, const float* pos,
+                float* const out[5], hipStream_t s) {
+    Eaw5 B; for (int b = 0; b < 5; b++) { B.in[b] = in[b]; B.out[b] = out[b]; }
+    k_eaw5<<<grid_for((size_t)fx * fy, MR_BLOCK), MR_BLOCK, 0, s>>>(fx, fy, step, c_phi, n_phi, p_phi, occ, normal, pos, B);
+    MR_LAUNCH_CHECK("eaw5");
+    return 0;
+}
+
 MR_DEV void atomic_add3(float* p, size_t i, v3 v) { atomicAdd(&p[3 * i], v.x); atomicAdd(&p[3 * i + 1], v.y); atomicAdd(&p[3 * i + 2], v.z); }
 
 // Adjoint of k_eaw (what Slang autodiff produces for process_EAWDenoise.bwd, Denoising.py:38-44):

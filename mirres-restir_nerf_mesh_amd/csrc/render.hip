@@ -21,6 +21,8 @@ int launch_direct_bwd(const float* tex, int Wc, int Hc, int N, int S, const floa
                       const float* tape, const float* g_color, const float* g_diff, const float* g_spec, float* g_normal, float* g_kd, float* g_rm, float* g_env,
                       hipStream_t s);
 int launch_bilateral5(int fx, int fy, float sigma, const float* const col[5], const float* nrm, const float* zdz, float* scratch, float* const out[5], hipStream_t s);
+int launch_eaw5(int fx, int fy, int step, float c_phi, float n_phi, float p_phi, const float* occ, const float* const in[5], const float* normal, const float* pos,
+                float* const out[5], hipStream_t s);
 int launch_matnet_scatter(const mirres_matnet_t* m, const float* occ, const float* pos, int n, float* kd, float* rm, int use_scale, const float* scale3,
                           const float* const_kd, const float* const_rm, hipStream_t s);
 int launch_matnet_scatter_mfma(const mirres_matnet_t* m, const float* occ, const float* pos, int n, float* kd, float* rm, int use_scale, const float* scale3,
@@ -266,17 +268,23 @@ static int finish(mirres_ctx* ctx, const mirres_render_args_t* a, float* tot[6],
         float* const dsts[5] = {a->outs[1], a->outs[2], a->outs[3], a->outs[4], a->outs[5]};
         int rc = launch_bilateral5(ctx->fx, ctx->fy, sigma, srcs, a->normal, a->gb_depth, B.bil, dsts, s); if (rc) return rc;   // one pass: the five buffers share the weights
     } else {
-    // EAWDenoise_use_phi(_no_di) (Denoising.py:154-251): stepWidth, then stepWidth/2, ...
-    for (int k = 0; k < 5; k++) {
-        const float* cur = srcs[k];
+    // EAWDenoise_use_phi(_no_di) (Denoising.py:154-251): stepWidth, then stepWidth/2, ... — the five buffers go through each iteration together
+    // (k_eaw5); intermediate results alternate between a scratch set (the idle bilateral area of the pool) and the outputs so that the last
+    // iteration lands in the outputs
+    if (a->denoise_iter <= 0) {
+        for (int k = 0; k < 5; k++) MR_HIP(hipMemcpyAsync(a->outs[k + 1], srcs[k], sizeof(float) * n3, hipMemcpyDeviceToDevice, s));
+    } else {
+        float* scratch[5]; float* outs5[5];
+        for (int k = 0; k < 5; k++) { scratch[k] = B.bil + n3 * (size_t)k; outs5[k] = a->outs[k + 1]; }
+        const float* cur[5] = {srcs[0], srcs[1], srcs[2], srcs[3], srcs[4]};
         float swf = (float)a->step_width;
         for (int it = 0; it < a->denoise_iter; it++) {
-            float* dst = (it == a->denoise_iter - 1) ? a->outs[k + 1] : ((it & 1) ? B.den_b : B.den_a);
-            int rc = mirres_eaw(ctx->fx, ctx->fy, (int)swf, a->c_phi, a->n_phi, a->p_phi, a->occ, cur, a->normal, a->pos, dst, s);
+            float* const* dst = ((a->denoise_iter - 1 - it) & 1) ? scratch : outs5;
+            int rc = launch_eaw5(ctx->fx, ctx->fy, (int)swf, a->c_phi, a->n_phi, a->p_phi, a->occ, cur, a->normal, a->pos, dst, s);
             if (rc) return rc;
-            cur = dst; swf = swf / 2;
+            for (int k = 0; k < 5; k++) cur[k] = dst[k];
+            swf = swf / 2;
         }
-        if (a->denoise_iter <= 0) MR_HIP(hipMemcpyAsync(a->outs[k + 1], cur, sizeof(float) * n3, hipMemcpyDeviceToDevice, s));
     }
     }
     k_composite<<<grid_for(N, MR_BLOCK), MR_BLOCK, 0, s>>>(N, a->occ, a->kd, a->rough_metal, a->outs[1], a->outs[2], a->outs[3], a->outs[0]);
