@@ -122,7 +122,7 @@ struct mirres_ctx {
     hipStream_t aux_stream = nullptr, pt_stream = nullptr, pt_stream2 = nullptr, fin_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join_pt = nullptr, ev_join_pt2 = nullptr, ev_join_fin = nullptr;
     std::vector<hipEvent_t> ev_pt;   // k_pt_reduce hand-over between the two path-tracing streams
-    std::vector<hipEvent_t> ev_sync; // cross-stream hand-offs of the batch pipeline   // second stream of mirres_render (path-tracing stages)
+    std::vector<hipEvent_t> ev_sync; // cross-stream hand-offs of the batch pipeline (mirres_render)
 };
 
 namespace mr {
@@ -146,7 +146,7 @@ struct PtQueues {
     uint32_t* counters;                 // [0] shadow rays, [1] continuation rays, [2] material-net list
     int32_t* slot_a; uint32_t* mask_a; int32_t* slot_c; float* pend;
     int N, NV;                          // pixels, sample slots (K * N)
-    int lane;                           // 1: launched on the context's second stream (own traversal head sets)
+    int lane;                           // stream of mirres_render the queue is worked on (0 chain, 1 bulk, 2 / 4 path tracing, 3 final stages): own traversal head sets
     int first_sample_is_zero;           // sample 0 of the frame has one pass fewer before the path-tracing stages (no temporal pass)
 };
 int launch_initial_batch(mirres_ctx* ctx, mirres_bvh* bvh, const mirres_env_t* env, const mirres_gbuf_t* g, const mirres_res_t* res, float* tile_data,

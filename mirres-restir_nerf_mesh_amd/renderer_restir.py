@@ -314,7 +314,7 @@ def render_fused(ctx, bvh_restir_worker, mlp_mat, use_scale, scale, env_map, occ
 
 
 class _FusedLoop(torch.autograd.Function):
-    """The spp loop of restir_di_with_pt as ONE forward call (mirres_render, batched + two streams) that records a per-sample tape, and ONE backward
+    """The spp loop of restir_di_with_pt as ONE forward call (mirres_render, batched, several streams) that records a per-sample tape, and ONE backward
     call (mirres_render_bwd) for what the reference differentiates on this path: EvaluateFinalSamples_di + FinalShading of every sample
     (Resampling.py:116-214) — gradients w.r.t. env_map, normal, kd, (roughness, metallic). The indirect sums carry no gradient
     (process_path_tracing_divided_no_grad). Returns the six raw sums of the loop."""

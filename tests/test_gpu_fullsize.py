@@ -93,8 +93,8 @@ def test_frame_properties_at_full_size(big, scene_mod):
 
 
 def test_schedule_does_not_change_the_frame_at_full_size(big, scene_mod, monkeypatch):
-    """The frame loop's scheduling choices — K samples of the path-tracing stages per launch, those stages on a second stream — must not
-    change a single bit of any output: 1600 x 1600, 6 samples, K = 1 on one stream against K = 4 (ragged last batch) on two streams."""
+    """The frame loop's scheduling choices — K samples per batched launch, the stages spread over 1 to 5 streams — must not change a single bit
+    of any output: 1600 x 1600, 6 samples, K = 1 on one stream against K = 4 / 3 / 2 (ragged batches, uneven path-tracing halves) on 2 .. 5 streams."""
     v, t, W, RR, harness, torch = big
     from mirres_restir_nerf_mesh_amd._ops import get_ctx
     g = harness.build_gbuffer(W, 800, 800, 2)
