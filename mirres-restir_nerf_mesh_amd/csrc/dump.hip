@@ -152,7 +152,8 @@ extern "C" int mirres_dump_render(mirres_bvh_t* bvh, int n, int L, const float* 
     MR_LAUNCH_CHECK("dump_light_rgb");
     if (n == 0) return MIRRES_OK;
     // pixel chunks of at most 2^24 (point, light) pairs: 40 bytes of pool per pair (ray, result, slot), kept in the BVH object
-    const size_t cap_pairs = (size_t)1 << 24;
+    size_t cap_pairs = (size_t)1 << 24;
+    { const char* e = getenv("MIRRES_DUMP_CHUNK"); if (e && atoll(e) > 0) cap_pairs = (size_t)atoll(e); }   // tests force several chunks on small inputs
     int np_max = (int)(cap_pairs / (size_t)L); if (np_max < 1) np_max = 1; if (np_max > n) np_max = n;
     const size_t pairs = (size_t)np_max * (size_t)L;
     const size_t need = pairs * (sizeof(Ray) + 4 + 4) + 256;

@@ -36,6 +36,16 @@ def test_config1_matches_the_reference_python():
         np.testing.assert_allclose(diff.cpu().numpy(), g["diff_" + k], rtol=1e-5, atol=2e-6)   # every visibility bit as the reference run had it
         np.testing.assert_allclose(spec.cpu().numpy(), g["spec_" + k], rtol=1e-4, atol=1e-4)
         np.testing.assert_allclose(rgb.cpu().numpy(), g["rgb_" + k], rtol=1e-4, atol=1e-4)
+    # the point chunks (<= 2^24 (point, light) pairs each) do not show: 1 562 points in chunks of 39 points give the same bits
+    import os as _os
+    one = RD.dump_render(W, T("pos"), T("normal"), T("albedo"), T("rough"), T("fresnel"), T("rays_d"), T("env"), eh, ew, model)
+    _os.environ["MIRRES_DUMP_CHUNK"] = "20000"
+    try:
+        many = RD.dump_render(W, T("pos"), T("normal"), T("albedo"), T("rough"), T("fresnel"), T("rays_d"), T("env"), eh, ew, model)
+    finally:
+        del _os.environ["MIRRES_DUMP_CHUNK"]
+    for a_, b_ in zip(one, many):
+        assert torch.equal(a_, b_)
     raw = RD.dump_render_run_mesh(W, T("pos"), T("normal"), T("albedo"), T("rough"), T("fresnel"), T("rays_d"), T("env"), eh, ew, model)[0]
     assert float(raw.max()) > 1.0 and float(rgb.max()) <= 1.0   # only dump_render clamps
 
