@@ -37,15 +37,24 @@ def linear2srgb(x):
     return torch.where(x <= 0.0031308, 12.92 * x, 1.055 * torch.pow(x + 1e-6, 1.0 / 2.4) - 0.055)
 
 
+def scale_img_hwc(x, size):
+    """nerf/renderer.py:61-76 for the case the harness uses (minification): plain bilinear resampling, align_corners False, NO antialiasing — for the
+    exact 2x down-scale of --ssaa 2 that is the 2 x 2 box average."""
+    assert x.shape[0] >= size[0] and x.shape[1] >= size[1]
+    if x.shape[0] == size[0] and x.shape[1] == size[1]:
+        return x
+    return torch.nn.functional.interpolate(x.permute(2, 0, 1)[None], size, mode="bilinear")[0].permute(1, 2, 0).contiguous()
+
+
 def postprocess(final_color, occ, H, W, ssaa):
-    """clamp[0,1] -> sRGB -> x alpha -> bilinear SSAA down-scale -> + (1-alpha) * 1  (nerf/renderer.py:1125-1129,1162-1164,1208-1209,1265-1267,1301-1302)."""
+    """clamp[0,1] -> sRGB -> x alpha -> SSAA down-scale (scale_img_hwc) -> + (1-alpha) * 1  (nerf/renderer.py:1125-1129,1162-1164,1208-1209,1265-1267,1301-1302)."""
     h, w = H * ssaa, W * ssaa
     img = linear2srgb(torch.clamp(final_color, 0.0, 1.0)).view(h, w, 3)
     alpha = (occ.view(h, w, 1) > 0.5).float()
     img = img * alpha
     if ssaa > 1:
-        img = torch.nn.functional.interpolate(img.permute(2, 0, 1)[None], size=(H, W), mode="bilinear", align_corners=False, antialias=True)[0].permute(1, 2, 0)
-        alpha = torch.nn.functional.interpolate(alpha.permute(2, 0, 1)[None], size=(H, W), mode="bilinear", align_corners=False, antialias=True)[0].permute(1, 2, 0)
+        img = scale_img_hwc(img, (H, W))
+        alpha = scale_img_hwc(alpha, (H, W))
     return img + (1 - alpha) * 1.0
 
 

@@ -17,6 +17,7 @@ What can be imported of the hot path: everything else is Slang->CU
     count, the five denoiser calls, kd (1 - metalness) D + S + I, background = 1, nan_to_num), executed from the file's AST (the module imports
     slangpy) with `restir_di_with_pt` replaced by a function that hands back prepared sums and the a-trous drivers being the reference's own
     Denoising.py over the oracle kernel. Pins what mirres_render's finish / mirres_render_finish restate.
+  * nerf/renderer.py:scale_img_nhwc / scale_img_hwc (:61-76) — the --ssaa down-scale of the harness (plain bilinear, no antialiasing), by AST.
   * nerf/utils.py:linear2srgb_torch (+ _clip_0to1_warn_torch) — the tone curve of the harness (SURVEY §8 a-H), taken by AST like above.
 The fixtures are data (inputs + outputs); no reference source text is stored.
 
@@ -213,7 +214,14 @@ def main():
     finally:
         torch.zeros = real_zeros
     fin = [o.numpy() for o in fin]
+    ns3 = {"torch": torch, "np": np}
+    load_function("nerf/renderer.py", "scale_img_nhwc", ns3)
+    scale_hwc = load_function("nerf/renderer.py", "scale_img_hwc", ns3)
+    ssaa_in = rng.random((12, 16, 3)).astype(np.float32)
+    ssaa_out2 = scale_hwc(torch.from_numpy(ssaa_in.copy()), (6, 8)).numpy()      # --ssaa 2
+    ssaa_out4 = scale_hwc(torch.from_numpy(ssaa_in.copy()), (3, 4)).numpy()      # --ssaa 4
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "ref_python.npz"), norm_in=x, norm_out=norm_out, env=env, srgb_in=srgb_in, srgb_out=srgb_out,
+                        ssaa_in=ssaa_in, ssaa_out2=ssaa_out2, ssaa_out4=ssaa_out4,
                         fin_spp=np.int32(spp_f), fin_sums=np.stack(sums), fin_occ=f_occ, fin_kd=f_kd, fin_rm=f_rm, fin_rd=f_rd, fin_out=np.stack(fin),
                         fin_occ_after=seen["occ_after_threshold"], fin_occ_inplace=occ_t.numpy(), fin_rd_norm=seen["ray_dir_norm"],
                         pdf=pdf_.numpy().ravel(), cdf=cdf_.numpy().ravel(), mpdf=mpdf_.numpy().ravel(), mcdf=mcdf_.numpy().ravel(),
