@@ -86,6 +86,7 @@ void orc_trace(const int32_t* info, const float* aabb, const float* vert, const 
 // ---- environment
 void orc_make_sampleable(const float* tex, int W, int H, float* pdf, float* cdf, float* mpdf, float* mcdf) { make_sampleable(tex, W, H, pdf, cdf, mpdf, mcdf); }
 void orc_neighbor_offsets(int count, float* out) { neighbor_offsets(count, out); }
+void orc_neighbor_offsets_raw(int count, float* out) { neighbor_offsets_raw(count, out); }
 void orc_env_weights(const float* tex, int W, int H, float* weight) { env_weights(tex, W, H, weight); }
 void orc_distribution2d(int W, int H, float* pdf, float* cdf) { distribution2d(W, H, pdf, cdf); }
 void orc_env_le(const float* tex, int W, int H, const float* dirs, int n, float* out) {

@@ -182,8 +182,9 @@ static inline void make_sampleable(const float* tex, int W, int H, float* pdf, f
     mcdf[H] = 1.f;
 }
 
-// createNeighborOffsetTexture  make_sampleable.slang:186-205 ; values then /127 (renderer_restir.py:220-221)
-static inline void neighbor_offsets(int count, float* out) {
+// createNeighborOffsetTexture  make_sampleable.slang:186-205 (raw = what the kernel writes); load_m_for_restir then divides by 127
+// (renderer_restir.py:220-221)
+static inline void neighbor_offsets_raw(int count, float* out) {
     const int R = 254;
     const float phi2 = 1.f / 1.3247179572447f;
     float u = 0.5f, v = 0.5f;
@@ -193,9 +194,13 @@ static inline void neighbor_offsets(int count, float* out) {
         if (v >= 1.f) v -= 1.f;
         float rSq = (u - 0.5f) * (u - 0.5f) + (v - 0.5f) * (v - 0.5f);
         if (rSq > 0.25f) continue;
-        out[index++] = (float)(int)((u - 0.5f) * R) / 127;
-        out[index++] = (float)(int)((v - 0.5f) * R) / 127;
+        out[index++] = (float)(int)((u - 0.5f) * R);
+        out[index++] = (float)(int)((v - 0.5f) * R);
     }
+}
+static inline void neighbor_offsets(int count, float* out) {
+    neighbor_offsets_raw(count, out);
+    for (int i = 0; i < 2 * count; i++) out[i] = out[i] / 127;
 }
 
 // process_GenerateLightTiles  GenerateLightTiles.slang:16-62 (scalar seeds splat to both lanes)

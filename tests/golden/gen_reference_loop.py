@@ -6,6 +6,9 @@ run this repo's ORACLE kernels on exactly the tensors the reference hands over.
 The BVH the loop traces comes from the reference's own `restirbvhWorker.update_bvh` (:25-89) executed the same way over the oracle's seven build
 kernels (scene extent by torch min / max, `range(tree_heights.max())` refit passes, set_root), and is compared with the oracle's bvh_build.
 
+The buffers come from the reference's own `load_m_for_restir` (:148-228) — `slangpy.loadModule` replaced by a recorder that returns the fake module
+and keeps the `defines` each Slang file is compiled with (the ReSTIR constants), the neighbour-offset kernel served by the oracle.
+
 `mlp_mat` is the reference's own `MLPTexture3D` / `_MLP` (nerf/render_helper.py:28-124, classes compiled from the AST: position normalisation and
 clamp, torch.nn.Linear stack, sigmoid and range) with `tcnn.Encoding` replaced by the oracle's hash-grid encoder (tiny-cuda-nn is not in the image).
 
@@ -297,22 +300,38 @@ def main():
     assert bvh_same
     del log[:]
 
-    # load_m_for_restir's buffers (renderer_restir.py:189-217)
-    nt = 128 * 1024
-    light_data, light_uv, light_inv_pdf = torch.zeros((nt, 3)), torch.zeros((nt, 2), dtype=torch.int), torch.zeros((nt, 1))
-    mk_res = lambda: (torch.zeros((N, 3)), torch.zeros((N, 1)), torch.zeros((N, 1), dtype=torch.int), torch.zeros((N, 1)))
-    reservoirs, prev_reservoirs = mk_res(), mk_res()
-    final_samples = (torch.zeros((N, 3)), torch.zeros((N, 1)), torch.zeros((N, 3)))
-    noff = T(O.neighbor_offsets(8192)).reshape(8192, 2)
+    # the reference's own load_m_for_restir (renderer_restir.py:148-228)
+    import time as _time, types as _types
     m = FakeM()
+    defines = {}
+
+    def createNeighborOffsetTexture(sampleCount, neighborOffsets):
+        return Launch(lambda g_: L.orc_neighbor_offsets_raw(int(sampleCount), P(neighborOffsets)), "createNeighborOffsetTexture")
+    m.createNeighborOffsetTexture = createNeighborOffsetTexture
+
+    def loadModule(path, defines_=None, **k):
+        defines.update(k.get("defines", defines_) or {})
+        return m
     real_zeros, real_ones = torch.zeros, torch.ones
     strip = lambda f: (lambda *a, **k: f(*a, **{x: y for x, y in k.items() if x != "device"}))
+    torch.zeros, torch.ones = strip(real_zeros), strip(real_ones)
+    lns = {"torch": torch, "np": np, "time": _time, "slangpy": _types.SimpleNamespace(loadModule=lambda path, defines=None: loadModule(path, defines))}
+    (load_ref,) = ref_functions("nerf/renderer_restir.py", ["load_m_for_restir"], lns)
+    try:
+        mods = load_ref(fx, fy)
+    finally:
+        torch.zeros, torch.ones = real_zeros, real_ones
+    del log[:]
+    assert all(x is m for x in mods[:8])
+    light_data, light_uv, light_inv_pdf, reservoirs, prev_reservoirs, final_samples, noff, tile_count, tile_size = mods[8:17]
+    layout = [(tuple(t_.shape), str(t_.dtype)) for t_ in (light_data, light_uv, light_inv_pdf, *reservoirs, *prev_reservoirs, *final_samples, noff)]
+    print("load_m_for_restir: defines %s; tiles %d x %d; neighbour offsets max |d| vs the oracle %.3g" % (defines, tile_count, tile_size, float(np.abs(noff.numpy() - O.neighbor_offsets(8192).reshape(8192, 2)).max())))
     torch.zeros, torch.ones = strip(real_zeros), strip(real_ones)
     np.random.seed(SEED); random_offset = int(np.random.randint(2**20)); np.random.seed(SEED)   # what the loop will draw (:245)
     occ_in = T(F.occ).reshape(N, 1)
     try:
         outs = ns["run_restir_di_with_pt"](False, 1.0, 1.0, 1.0, mlp, None, W, m, m, m, m, m, m, m, m,
-                                           light_data, light_uv, light_inv_pdf, reservoirs, prev_reservoirs, final_samples, noff, 128, 1024,
+                                           light_data, light_uv, light_inv_pdf, reservoirs, prev_reservoirs, final_samples, noff, tile_count, tile_size,
                                            T(F.env), occ_in, T(F.normal), T(F.depth).reshape(N, 1), T(F.kd), T(F.rm), T(F.ray_dir_raw), T(F.pos),
                                            None, None, None, None, fx, fy, SPP, 2, 2, 2.0, 0.1, 0.001)
     finally:
@@ -327,6 +346,8 @@ def main():
     np.savez_compressed(os.path.join(HERE, "ref_loop.npz"), outs=outs, spp=np.int32(SPP), seed=np.int32(SEED), random_offset=np.int64(random_offset),
                         mat_pts=mat_pts, mat_out=mat_ref, enc_per_level_scale=np.float64(enc_seen["cfg"]["per_level_scale"]),
                         enc_cfg=np.array([enc_seen["n_in"], enc_seen["cfg"]["n_levels"], enc_seen["cfg"]["n_features_per_level"], enc_seen["cfg"]["log2_hashmap_size"], enc_seen["cfg"]["base_resolution"]], np.int32),
+                        defines_keys=np.array(sorted(defines)), defines_vals=np.array([int(defines[k_]) for k_ in sorted(defines)], np.int32),
+                        buffer_layout=np.array(["%s %s" % l_ for l_ in layout]), neighbor_offsets=noff.numpy(), tile_count_size=np.array([tile_count, tile_size], np.int32),
                         launches=np.array(log), build_launches=np.array(build_log), bvh_info_crc=np.int64(int(np.bitwise_xor.reduce(W.LBVHNode_info.numpy().ravel().astype(np.int64) * np.arange(1, W.LBVHNode_info.numel() + 1)))),
                         frame=np.array([FRAME["fx"], FRAME["fy"], FRAME["subdiv"], FRAME["ground"], FRAME["env_hw"][0], FRAME["env_hw"][1]], np.int32),
                         occ_after=occ_in.numpy())

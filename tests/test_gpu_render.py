@@ -66,6 +66,28 @@ def test_frame_matches_the_reference_loop(oracle, scene_mod):
         assert psnr(np.clip(got[k], 0, 1), np.clip(r, 0, 1)) >= 35.0, n
 
 
+def test_load_m_for_restir_matches_the_reference(oracle, scene_mod):
+    """The 17-tuple of load_m_for_restir and the engine's default constants against what the REFERENCE's own load_m_for_restir produced
+    (tests/golden/ref_loop.npz: buffer shapes / dtypes, neighbour offsets, the `defines` its Slang modules are compiled with)."""
+    import os
+    import torch
+    from mirres_restir_nerf_mesh_amd import renderer_restir as RR, _lib
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_loop.npz"))
+    fx, fy = int(g["frame"][0]), int(g["frame"][1])
+    mods = RR.load_m_for_restir(fx, fy)
+    assert len(mods) == 17 and mods[15] == int(g["tile_count_size"][0]) and mods[16] == int(g["tile_count_size"][1])
+    light_data, light_uv, light_inv_pdf, reservoirs, prev_reservoirs, final_samples, noff = mods[8:15]
+    mine = ["%s %s" % (tuple(t.shape), str(t.dtype)) for t in (light_data, light_uv, light_inv_pdf, *reservoirs, *prev_reservoirs, *final_samples, noff)]
+    assert mine == [str(x) for x in g["buffer_layout"]]
+    assert np.array_equal(noff.cpu().numpy(), g["neighbor_offsets"])
+    D = dict(zip([str(k_) for k_ in g["defines_keys"]], [int(v) for v in g["defines_vals"]]))
+    c = _lib.default_config()
+    assert (c.light_tile_count, c.light_tile_size, c.screen_tile_size, c.initial_light_samples, c.initial_brdf_samples, c.max_history, c.neighbor_offset_count,
+            c.neighbor_count, int(c.gather_radius)) == tuple(D[k_] for k_ in ("LIGHT_TILE_COUNT", "LIGHT_TILE_SIZE", "SCREEN_TILE_SIZE", "INITIAL_LIGHT_SAMPLE_COUNT",
+            "INITIAL_BRDF_SAMPLE_COUNT", "MAX_HISTORY_LENGTH", "NEIGHBOR_OFFSET_COUNT", "NEIGHBOR_COUNT", "GATHER_RADIUS"))
+    assert c.max_bounce == 2 and abs(c.vis_near - 0.01) < 1e-9          # FinalShading.slang:7 MAX_Bounce, vis_near (:247)
+
+
 def test_three_indirect_bounces_and_albedo_scale(oracle, scene_mod):
     """BASELINE configs[3] / [4] switches: `use_scale` albedo scaling of the looked-up materials (relighting, renderer_restir.py:404-408, with the
     clamp of the whole map) and a THIRD indirect bounce (MAX_Bounce is a runtime parameter here; the reference unrolls two) — one sample against the
