@@ -202,6 +202,7 @@ def test_stage1_training_step_backward(oracle, scene_mod):
     FinalShading / EvaluateFinalSamples_di / EAWDenoise_run exactly where the reference's do (Resampling.py, Denoising.py)."""
     F, W, mods, RR, torch = _setup(oracle, scene_mod, fx=40, fy=32)
     from mirres_restir_nerf_mesh_amd.render_helper import MLPTexture3D
+    torch.manual_seed(0)     # the MLP's kaiming init draws from the global generator: without this the test's inputs depend on what ran before it
     mn, mx = scene_mod.material_min_max(me_max=0.3)
     mlp = MLPTexture3D(torch.tensor([-1, -1, -1, 1, 1, 1], dtype=torch.float32), channels=6, min_max=(torch.from_numpy(mn).cuda(), torch.from_numpy(mx).cuda()), seed=11)
     with torch.no_grad():
@@ -230,7 +231,7 @@ def test_stage1_training_step_backward(oracle, scene_mod):
                                     kd.detach(), rm.detach(), cu(F.ray_dir_raw), cu(F.pos), z(N, 1), z(N, 4), z(N, 3), z(N, 3), F.fx, F.fy, 2, 2, 2, 2.0, 0.1, 0.001)
     RR.set_random_offset(None)
     loss2 = (out2[0][fg] - target[fg]).abs().mean() + 0.1 * (out2[1][fg].mean() + out2[2][fg].mean())
-    assert float(loss2) < float(loss) + 1e-4
+    assert float(loss2) < float(loss) + 1e-4, (float(loss), float(loss2))
 
 
 def test_pt_batch_is_bit_identical(oracle, scene_mod, monkeypatch):
