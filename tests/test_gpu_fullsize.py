@@ -33,6 +33,15 @@ def test_lbvh_structure_at_full_size(big):
     assert torch.equal(W.LBVHNode_info, i0) and torch.equal(W.LBVHNode_aabb, a0)
 
 
+def test_lbvh_equals_the_oracle_at_full_size(big, oracle):
+    """The node arrays the caller gets back (LBVHNode_info / LBVHNode_aabb, 335 872 triangles) are the oracle builder's, bit for bit — the oracle whose
+    driver is pinned to the reference's own update_bvh (tests/golden/gen_reference_loop.py). Also exercises the 3-level union pyramid of the refit."""
+    v, t, W, RR, harness, torch = big
+    info, aabb, srt, h = oracle.bvh_build(v, t)
+    assert np.array_equal(W.LBVHNode_info.cpu().numpy(), info)
+    assert np.array_equal(W.LBVHNode_aabb.cpu().numpy(), aabb)
+
+
 def test_traversal_kernels_agree_at_full_size(big):
     import ctypes as C
     v, t, W, RR, harness, torch = big
