@@ -1,4 +1,4 @@
-"""GPU, BASELINE-size inputs (T = 335 872 triangles, 1600 x 1600 internal frame): size-independent properties instead of an oracle run
+"""GPU, BASELINE-size inputs (T = 335 872 triangles, 1600 x 1600 internal frame): the BVH and a 40 000-ray sample against the oracle bit for bit; for whole frames size-independent properties instead of an oracle run
 (the oracle needs minutes at this size): LBVH structure, agreement of the three traversal kernels with each other, frame-level sanity."""
 import numpy as np
 import pytest
@@ -42,7 +42,7 @@ def test_lbvh_equals_the_oracle_at_full_size(big, oracle):
     assert np.array_equal(W.LBVHNode_aabb.cpu().numpy(), aabb)
 
 
-def test_traversal_kernels_agree_at_full_size(big):
+def test_traversal_kernels_agree_at_full_size(big, oracle):
     import ctypes as C
     v, t, W, RR, harness, torch = big
     from mirres_restir_nerf_mesh_amd._lib import lib, check
@@ -75,6 +75,17 @@ def test_traversal_kernels_agree_at_full_size(big):
     fn = torch.cross(vv[tri[:, 1]] - vv[tri[:, 0]], vv[tri[:, 2]] - vv[tri[:, 0]], dim=1)
     dist = ((p[m] - vv[tri[:, 0]]) * torch.nn.functional.normalize(fn, dim=1)).sum(1).abs()
     assert float(dist.max()) < 1e-4
+    # and on a 40 000-ray sample the oracle (bvh_hit in the reference's order, on the oracle's own hierarchy) reports the same hit bit, primitive,
+    # distance, point and normal: "BVH hit indices match the reference bit-exact" at BASELINE size. Mode 3 against the front-only oracle query.
+    sel = torch.randperm(n, generator=torch.Generator().manual_seed(3))[:40000].cuda()
+    info, aabb, _, _ = oracle.bvh_build(v, t)
+    r = oracle.trace(info, aabb, v, t, rays[sel].cpu().numpy(), True)
+    assert np.array_equal(hit[sel].cpu().numpy(), r["hit"]) and np.array_equal(pr[sel].cpu().numpy(), r["prim"])
+    mm = r["hit"] > 0
+    assert np.array_equal(tt[sel].cpu().numpy()[mm], r["t"][mm]) and np.array_equal(p[sel].cpu().numpy()[mm], r["pos"][mm]) and np.array_equal(nn[sel].cpu().numpy()[mm], r["normal"][mm])
+    h3 = torch.zeros(n, dtype=torch.int32, device="cuda")
+    check(lib().mirres_bvh_trace(W.h, rays.data_ptr(), n, 3, h3.data_ptr(), None, None, None, None, None, None), "front")
+    assert np.array_equal(h3[sel].cpu().numpy(), oracle.occluded_front(info, aabb, v, t, rays[sel].cpu().numpy()))
 
 
 def test_frame_properties_at_full_size(big, scene_mod):
