@@ -65,17 +65,19 @@ def cpu_baseline(S, args):
         km = O.matnet(mat, r["pos"])
         kd = km[:, 0:3].copy(); rm = km[:, 4:6].copy()
     env = S.make_env(256, 512)
+    last = {}
     def run(n_spp):
         t0 = time.time()
         O.bvh_build(v, t)
-        O.render(fx, fy, n_spp, 12345, (info, aabb), v, t, env, occ, nrm, depth, kd, rm, rd, r["pos"], mat=mat, max_bounce=args.bounces)
+        last["out"] = O.render(fx, fy, n_spp, 12345, (info, aabb), v, t, env, occ, nrm, depth, kd, rm, rd, r["pos"], mat=mat, max_bounce=args.bounces)
         return time.time() - t0
     cal = run(1)                                           # calibration pass, then size the sample for ~15 s of CPU work
     spp = int(max(2, min(256, round(15.0 / max(cal, 1e-3)))))
     dt = run(spp)
+    frame = dict(fx=fx, fy=fy, spp=spp, occ=occ, normal=nrm, depth=depth, kd=kd, rm=rm, ray_dir=rd, pos=r["pos"], env=env, final_color=last["out"]["final_color"])
     return {"value": round(N * spp / dt / 1e6, 6), "unit": "Msamples/s", "cores": O.num_threads(), "kind": "port",
             "sample": "%dx%d px, %d spp, same mesh (T=%d) / env / material, LBVH build + full frame (CPU restatement of the reference kernels, not reference code); "
-                      "%.1f s of CPU work" % (fx, fy, spp, len(t), dt)}
+                      "%.1f s of CPU work" % (fx, fy, spp, len(t), dt)}, frame
 
 
 def main():
@@ -196,7 +198,13 @@ def main():
                 pass
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(S, args)
+        cpu, cf = cpu_baseline(S, args)
+        # the same small frame (same inputs, seed and sample count) through the HIP path: the PSNR half of BASELINE's metric, against the CPU oracle
+        cu = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+        small, _, _ = RR.render_fused(get_ctx(cf["fx"], cf["fy"], max_bounce=args.bounces), W, mlp, False, (1, 1, 1), cu(cf["env"]), cu(cf["occ"][:, None]), cu(cf["normal"]),
+                                      cu(cf["depth"][:, None]), cu(cf["kd"]), cu(cf["rm"]), cu(cf["ray_dir"]), cu(cf["pos"]), cf["spp"], 2, 2, 2.0, 0.1, 0.001, 12345)
+        mse = float(((small[0].clamp(0, 1) - cu(cf["final_color"]).clamp(0, 1)) ** 2).mean().item())
+        cpu["psnr_hip_vs_oracle_db"] = round(-10.0 * float(np.log10(max(mse, 1e-20))), 2)
 
     if rank == 0:
         fc = out[0]
