@@ -162,6 +162,16 @@ int mirres_dump_render(mirres_bvh_t* bvh, int n, int L, const float* pos, const 
                        const float* light_area_weight, int equal_areas, int clamp_rgb, float* light_rgbs, float* out_rgb, float* out_diff,
                        float* out_spec, void* stream);
 
+/* The step in front of the path: what render_stage1 gets from nvdiffrast (an un-vendored dependency of the reference).
+ * mirres_raster_raycast stands in for dr.rasterize (nerf/renderer.py:983): primary rays f32[n,8] (as mirres_bvh_trace) are cast through the BVH
+ * (closest hit) and rast f32[n,4] receives nvdiffrast's raster record (u, v, t, triangle_id + 1), zeros where nothing is hit; vert f32[V,3] /
+ * tri i32[T,3] are the arrays the BVH was built from. mirres_interpolate(_bwd) = dr.interpolate without attribute derivatives (:985, :996,
+ * :998): out f32[n,C] = u a[i0] + v a[i1] + (1-u-v) a[i2] (0 where triangle_id = 0); the backward ACCUMULATES into g_attr f32[V,C] and writes
+ * g_uv f32[n,2] (either may be NULL). dr.texture and dr.antialias are not provided.                                                      */
+int mirres_raster_raycast(mirres_bvh_t* bvh, const float* rays, int n, const float* vert, const int32_t* tri, float* rast, void* stream);
+int mirres_interpolate(const float* attr, int C, const float* rast, const int32_t* tri, int n, float* out, void* stream);
+int mirres_interpolate_bwd(const float* attr, int C, const float* rast, const int32_t* tri, int n, const float* g_out, float* g_attr, float* g_uv, void* stream);
+
 /* prepare_shading_normal (nerf/renderutils/ops.py:100-163; c_src/normal.cu): the shading normal render_stage1 hands to the path
  * (nerf/renderer.py:1013). All inputs f32[n,3] (broadcast inputs expanded by the caller); out f32[n,3]. The backward writes the six input
  * gradients (any may be NULL).                                                                                                   */

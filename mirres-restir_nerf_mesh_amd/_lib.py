@@ -88,6 +88,9 @@ SIGNATURES = {
     "mirres_eaw": (C.c_int, [C.c_int, C.c_int, C.c_int, f32, f32, f32, vp, vp, vp, vp, vp, vp]),
     "mirres_prepare_shading_normal": (C.c_int, [C.c_longlong, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp]),
     "mirres_prepare_shading_normal_bwd": (C.c_int, [C.c_longlong, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "mirres_raster_raycast": (C.c_int, [vp, vp, C.c_int, vp, vp, vp, vp]),
+    "mirres_interpolate": (C.c_int, [vp, C.c_int, vp, vp, C.c_int, vp, vp]),
+    "mirres_interpolate_bwd": (C.c_int, [vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, vp]),
     "mirres_dump_render": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
     "mirres_bilateral": (C.c_int, [C.c_int, C.c_int, C.c_float, vp, vp, vp, vp, vp, vp]),
     "mirres_bilateral_bwd": (C.c_int, [C.c_int, C.c_int, C.c_float, vp, vp, vp, vp, vp, vp]),

@@ -1,0 +1,114 @@
+// raster.hip — the step in front of the path: primary visibility and attribute interpolation for the G-buffer, which the reference
+// gets from nvdiffrast (dr.rasterize / dr.interpolate, nerf/renderer.py:983-998; nvdiffrast is an un-vendored dependency, readme.md). Here the
+// primary rays are cast through the path's own BVH (closest hit, mirres_bvh_trace mode 2) and the hit is turned into nvdiffrast's raster record
+// (u, v, depth, triangle_id + 1) so that interpolation and its gradients follow dr.interpolate's published contract:
+//   out = u a[i0] + v a[i1] + (1 - u - v) a[i2],   d out / d a[i_k] = barycentric weight,   d out / d(u, v) = (a[i0] - a[i2], a[i1] - a[i2]).
+// dr.texture taps and dr.antialias (visibility gradients) are not provided.
+#include "engine.hpp"
+#include "device_math.hpp"
+
+namespace mr {
+
+#define MR_BLOCK 256
+
+// barycentrics of the hit on its triangle: the Moeller-Trumbore (u, v) of bvh_hit (weights of v1, v2) re-expressed in nvdiffrast's order (weights of v0, v1)
+__global__ void __launch_bounds__(MR_BLOCK) k_rast_record(int n, const float* __restrict__ rays, const int32_t* __restrict__ hit, const float* __restrict__ t,
+                                                          const int32_t* __restrict__ prim, const float* __restrict__ vert, const int32_t* __restrict__ tri,
+                                                          float* __restrict__ rast) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (hit[i]) {
+        const int p = prim[i];
+        const int32_t* ti = tri + 3 * (size_t)p;
+        const v3 v0 = ld3(vert, ti[0]), E1 = ld3(vert, ti[1]) - v0, E2 = ld3(vert, ti[2]) - v0;
+        const v3 o = V3(rays[8 * (size_t)i], rays[8 * (size_t)i + 1], rays[8 * (size_t)i + 2]);
+        const v3 d = normalize(V3(rays[8 * (size_t)i + 4], rays[8 * (size_t)i + 5], rays[8 * (size_t)i + 6]));   // bvh_hit normalises the direction
+        const v3 P = cross(d, E2);
+        const float invDet = 1 / dot(E1, P);
+        const v3 Tv = o - v0;
+        const float u = dot(Tv, P) * invDet;
+        const v3 Q = cross(Tv, E1);
+        const float v = dot(d, Q) * invDet;
+        r = make_float4(1.f - u - v, u, t[i], (float)(p + 1));
+    }
+    reinterpret_cast<float4*>(rast)[i] = r;
+}
+
+__global__ void __launch_bounds__(MR_BLOCK) k_interpolate(const float* __restrict__ attr, int C, const float* __restrict__ rast, const int32_t* __restrict__ tri, int n,
+                                                          float* __restrict__ out) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)n * C) return;
+    const int i = (int)(idx / C), c = (int)(idx % C);
+    const float4 r = reinterpret_cast<const float4*>(rast)[i];
+    const int p = (int)r.w - 1;
+    float o = 0.f;
+    if (p >= 0) {
+        const int32_t* ti = tri + 3 * (size_t)p;
+        const float a0 = attr[(size_t)ti[0] * C + c], a1 = attr[(size_t)ti[1] * C + c], a2 = attr[(size_t)ti[2] * C + c];
+        o = r.x * a0 + r.y * a1 + (1.f - r.x - r.y) * a2;
+    }
+    out[idx] = o;
+}
+
+__global__ void __launch_bounds__(MR_BLOCK) k_interpolate_bwd(const float* __restrict__ attr, int C, const float* __restrict__ rast, const int32_t* __restrict__ tri, int n,
+                                                              const float* __restrict__ g_out, float* __restrict__ g_attr, float* __restrict__ g_uv) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 r = reinterpret_cast<const float4*>(rast)[i];
+    const int p = (int)r.w - 1;
+    float gu = 0.f, gv = 0.f;
+    if (p >= 0) {
+        const int32_t* ti = tri + 3 * (size_t)p;
+        const float b2 = 1.f - r.x - r.y;
+        for (int c = 0; c < C; c++) {
+            const float g = g_out[(size_t)i * C + c];
+            if (g_attr) {
+                atomicAdd(&g_attr[(size_t)ti[0] * C + c], r.x * g); atomicAdd(&g_attr[(size_t)ti[1] * C + c], r.y * g); atomicAdd(&g_attr[(size_t)ti[2] * C + c], b2 * g);
+            }
+            if (g_uv) {
+                const float a0 = attr[(size_t)ti[0] * C + c], a1 = attr[(size_t)ti[1] * C + c], a2 = attr[(size_t)ti[2] * C + c];
+                gu += g * (a0 - a2); gv += g * (a1 - a2);
+            }
+        }
+    }
+    if (g_uv) { g_uv[2 * (size_t)i] = gu; g_uv[2 * (size_t)i + 1] = gv; }
+}
+
+}  // namespace mr
+
+using namespace mr;
+
+extern "C" int mirres_raster_raycast(mirres_bvh_t* bvh, const float* rays, int n, const float* vert, const int32_t* tri, float* rast, void* stream) {
+    if (!bvh || n < 0 || (n > 0 && (!rays || !vert || !tri || !rast))) { set_error("mirres_raster_raycast: bad argument"); return MIRRES_E_ARG; }
+    if (bvh->T < 2) { set_error("mirres_raster_raycast: BVH not built"); return MIRRES_E_STATE; }
+    if (n == 0) return MIRRES_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t need = (size_t)n * 12 + 256;          // hit, t, prim of the batch (kept in the BVH object's scratch pool)
+    if (bvh->dump_pool_bytes < need) {
+        if (bvh->dump_pool) { MR_HIP(hipDeviceSynchronize()); MR_HIP(hipFree(bvh->dump_pool)); bvh->dump_pool = nullptr; bvh->dump_pool_bytes = 0; }
+        MR_HIP(hipMalloc(&bvh->dump_pool, need));
+        bvh->dump_pool_bytes = need;
+    }
+    int32_t* hit = reinterpret_cast<int32_t*>(bvh->dump_pool); float* t = reinterpret_cast<float*>(hit + n); int32_t* prim = reinterpret_cast<int32_t*>(t + n);
+    int rc = mirres_bvh_trace(bvh, rays, n, 2, hit, t, nullptr, nullptr, prim, nullptr, stream); if (rc) return rc;
+    k_rast_record<<<grid_for(n, MR_BLOCK), MR_BLOCK, 0, s>>>(n, rays, hit, t, prim, vert, tri, rast);
+    MR_LAUNCH_CHECK("raster_raycast");
+    return MIRRES_OK;
+}
+
+extern "C" int mirres_interpolate(const float* attr, int C, const float* rast, const int32_t* tri, int n, float* out, void* stream) {
+    if (C <= 0 || n < 0 || (n > 0 && (!attr || !rast || !tri || !out))) { set_error("mirres_interpolate: bad argument"); return MIRRES_E_ARG; }
+    if (n == 0) return MIRRES_OK;
+    k_interpolate<<<grid_for((size_t)n * C, MR_BLOCK), MR_BLOCK, 0, (hipStream_t)stream>>>(attr, C, rast, tri, n, out);
+    MR_LAUNCH_CHECK("interpolate");
+    return MIRRES_OK;
+}
+
+extern "C" int mirres_interpolate_bwd(const float* attr, int C, const float* rast, const int32_t* tri, int n, const float* g_out, float* g_attr, float* g_uv, void* stream) {
+    if (C <= 0 || n < 0 || (n > 0 && (!attr || !rast || !tri || !g_out)) || (!g_attr && !g_uv)) { set_error("mirres_interpolate_bwd: bad argument"); return MIRRES_E_ARG; }
+    if (n == 0) return MIRRES_OK;
+    k_interpolate_bwd<<<grid_for(n, MR_BLOCK), MR_BLOCK, 0, (hipStream_t)stream>>>(attr, C, rast, tri, n, g_out, g_attr, g_uv);
+    MR_LAUNCH_CHECK("interpolate_bwd");
+    return MIRRES_OK;
+}

@@ -1,0 +1,69 @@
+"""The step in front of the path: what nerf/renderer.py:978-998 gets from nvdiffrast and meshutils — primary visibility, attribute
+interpolation with gradients to the vertex attributes, smooth vertex normals — on the engine's own BVH (csrc/raster.hip).
+
+    rast = rasterize_raycast(worker, rays_o, rays_d)          # stands in for dr.rasterize: [n,4] = (u, v, t, triangle_id + 1)
+    xyzs = interpolate(vertices, rast, triangles)             # dr.interpolate(vertices, rast, triangles)[0]
+    v_nrm, t_nrm_idx = auto_normals(vertices, triangles)      # meshutils.py:14-39
+    gb_normal = interpolate(v_nrm, rast, t_nrm_idx)
+
+dr.texture and dr.antialias (the jittered smoothness taps and the visibility gradient, :1001-1010, :1184-1206) are not provided."""
+import torch
+
+from ._lib import lib, check, stream_ptr
+
+
+@torch.no_grad()
+def rasterize_raycast(worker, rays_o, rays_d):
+    """Primary rays through worker's BVH (closest hit). Returns rast f32[n,4] in nvdiffrast's layout; the triangle id is exact in fp32 below 2^24 triangles."""
+    n = rays_o.shape[0]
+    rays = torch.empty((n, 8), dtype=torch.float32, device=rays_o.device)
+    rays[:, 0:3] = rays_o; rays[:, 3] = 0.0; rays[:, 4:7] = rays_d; rays[:, 7] = 1e7
+    rast = torch.zeros((n, 4), dtype=torch.float32, device=rays.device)
+    vert = worker.vrt.detach().float().contiguous(); tri = worker.v_ind.detach().to(torch.int32).contiguous()
+    check(lib().mirres_raster_raycast(worker.h, rays.data_ptr(), n, vert.data_ptr(), tri.data_ptr(), rast.data_ptr(), stream_ptr()), "mirres_raster_raycast")
+    return rast
+
+
+class _Interpolate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, attr, rast, tri):
+        attr_c = attr.detach().float().contiguous(); rast_c = rast.detach().float().contiguous(); tri_c = tri.detach().to(torch.int32).contiguous()
+        n, C = rast_c.shape[0], attr_c.shape[1]
+        out = torch.empty((n, C), dtype=torch.float32, device=attr_c.device)
+        check(lib().mirres_interpolate(attr_c.data_ptr(), C, rast_c.data_ptr(), tri_c.data_ptr(), n, out.data_ptr(), stream_ptr()), "mirres_interpolate")
+        ctx.save_for_backward(attr_c, rast_c, tri_c)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        attr, rast, tri = ctx.saved_tensors
+        g_out = g_out.contiguous().float()
+        n, C = rast.shape[0], attr.shape[1]
+        g_attr = torch.zeros_like(attr) if ctx.needs_input_grad[0] else None
+        g_uv = torch.empty((n, 2), dtype=torch.float32, device=attr.device) if ctx.needs_input_grad[1] else None
+        if g_attr is not None or g_uv is not None:
+            check(lib().mirres_interpolate_bwd(attr.data_ptr(), C, rast.data_ptr(), tri.data_ptr(), n, g_out.data_ptr(), g_attr.data_ptr() if g_attr is not None else None,
+                                               g_uv.data_ptr() if g_uv is not None else None, stream_ptr()), "mirres_interpolate_bwd")
+        g_rast = None
+        if g_uv is not None:
+            g_rast = torch.zeros_like(rast); g_rast[:, 0:2] = g_uv
+        return g_attr, g_rast, None
+
+
+def interpolate(attr, rast, tri):
+    """dr.interpolate(attr[None], rast, tri)[0] for one image flattened to [n,4] / [n,C]: attr f32[V,C] -> f32[n,C]; zeros where rast's triangle id is 0."""
+    return _Interpolate.apply(attr, rast, tri)
+
+
+def auto_normals(v_pos, t_pos_idx):
+    """meshutils.py:14-39: area-weighted vertex normals (face normals splatted to the vertices), degenerate ones replaced by (0, 0, 1)."""
+    i0, i1, i2 = (t_pos_idx[:, k].to(torch.int64) for k in range(3))
+    v0, v1, v2 = v_pos[i0, :], v_pos[i1, :], v_pos[i2, :]
+    face_normals = torch.cross(v1 - v0, v2 - v0, dim=-1)
+    v_nrm = torch.zeros_like(v_pos)
+    for i in (i0, i1, i2):
+        v_nrm.scatter_add_(0, i[:, None].repeat(1, 3), face_normals)
+    d = torch.sum(v_nrm * v_nrm, -1, keepdim=True)
+    v_nrm = torch.where(d > 1e-20, v_nrm, torch.tensor([0.0, 0.0, 1.0], dtype=torch.float32, device=v_pos.device))
+    v_nrm = v_nrm / torch.sqrt(torch.clamp(torch.sum(v_nrm * v_nrm, -1, keepdim=True), min=1e-20))
+    return v_nrm, t_pos_idx

@@ -18,6 +18,8 @@ What can be imported of the hot path: everything else is Slang->CU
     slangpy) with `restir_di_with_pt` replaced by a function that hands back prepared sums and the a-trous drivers being the reference's own
     Denoising.py over the oracle kernel. Pins what mirres_render's finish / mirres_render_finish restate.
   * nerf/renderer.py:scale_img_nhwc / scale_img_hwc (:61-76) — the --ssaa down-scale of the harness (plain bilinear, no antialiasing), by AST.
+  * meshutils.py:auto_normals (+ length / dot / safe_normalize) — smooth vertex normals of the G-buffer front end, by AST
+    (the module imports pymeshlab); `device='cuda'` of its fallback normal redirected to CPU.
   * nerf/utils.py:linear2srgb_torch (+ _clip_0to1_warn_torch) — the tone curve of the harness (SURVEY §8 a-H), taken by AST like above.
 The fixtures are data (inputs + outputs); no reference source text is stored.
 
@@ -220,7 +222,21 @@ def main():
     ssaa_in = rng.random((12, 16, 3)).astype(np.float32)
     ssaa_out2 = scale_hwc(torch.from_numpy(ssaa_in.copy()), (6, 8)).numpy()      # --ssaa 2
     ssaa_out4 = scale_hwc(torch.from_numpy(ssaa_in.copy()), (3, 4)).numpy()      # --ssaa 4
+    import mirres_restir_nerf_mesh_amd as M
+    an_v, an_t = M.scene.make_mesh(2, 4)
+    an_v = np.concatenate([an_v, [[5.0, 5.0, 5.0]]]).astype(np.float32)        # an unreferenced vertex: the degenerate-normal fallback (0, 0, 1)
+    ns4 = {"torch": torch, "np": np}
+    for fn_ in ("length", "dot", "safe_normalize"):
+        load_function("meshutils.py", fn_, ns4)
+    auto_n = load_function("meshutils.py", "auto_normals", ns4)
+    real_tensor = torch.tensor
+    torch.tensor = lambda *a_, **k_: real_tensor(*a_, **{kk: vv for kk, vv in k_.items() if kk != "device"})
+    try:
+        an_out = auto_n(torch.from_numpy(an_v), torch.from_numpy(an_t.astype(np.int32)))[0].numpy()
+    finally:
+        torch.tensor = real_tensor
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "ref_python.npz"), norm_in=x, norm_out=norm_out, env=env, srgb_in=srgb_in, srgb_out=srgb_out,
+                        an_vert=an_v, an_tri=an_t.astype(np.int32), an_out=an_out,
                         ssaa_in=ssaa_in, ssaa_out2=ssaa_out2, ssaa_out4=ssaa_out4,
                         fin_spp=np.int32(spp_f), fin_sums=np.stack(sums), fin_occ=f_occ, fin_kd=f_kd, fin_rm=f_rm, fin_rd=f_rd, fin_out=np.stack(fin),
                         fin_occ_after=seen["occ_after_threshold"], fin_occ_inplace=occ_t.numpy(), fin_rd_norm=seen["ray_dir_norm"],
