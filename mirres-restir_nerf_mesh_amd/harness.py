@@ -33,6 +33,45 @@ def build_gbuffer(worker, H, W, ssaa=1, azimuth_deg=30.0, elevation_deg=30.0, kd
     return dict(fx=w, fy=h, occ=occ, pos=pos.contiguous(), normal=normal, depth=depth, kd=kd_map, rm=rm, ray_dir=rays_d, eye=eye)
 
 
+def build_gbuffer_stage1(worker, vertices, triangles, H, W, ssaa=1, azimuth_deg=30.0, elevation_deg=30.0, mlp_mat=None):
+    """The front half of render_stage1 (nerf/renderer.py:978-1022, 1083-1094) on the engine's own operators: raster record by casting the primary rays
+    (raster.rasterize_raycast, for dr.rasterize), xyzs / smooth normal / geometric normal by raster.interpolate (dr.interpolate), auto_normals,
+    renderutils.prepare_shading_normal, safe_normalize, material field. Differentiable w.r.t. `vertices` through the interpolations (the visibility
+    term of dr.antialias is not modelled). Returns the dict build_gbuffer returns, plus `rast`."""
+    from . import raster
+    from .renderutils.ops import prepare_shading_normal
+    h, w = H * ssaa, W * ssaa
+    eye, rd = scene.camera_rays(h, w, azimuth_deg, elevation_deg)
+    dev = vertices.device
+    rays_d = torch.from_numpy(rd).to(dev)
+    eye_t = torch.from_numpy(eye).to(dev)
+    rays_o = eye_t[None].expand(h * w, 3).contiguous()
+    rast = raster.rasterize_raycast(worker, rays_o, rays_d)
+    tri = triangles.to(torch.int32)
+    xyzs = raster.interpolate(vertices, rast, tri)                                                         # :985
+    v_nrm, t_nrm_idx = raster.auto_normals(vertices, tri)                                                  # :978
+    v0, v1, v2 = (vertices[tri[:, k].long(), :] for k in range(3))
+    fn = torch.cross(v1 - v0, v2 - v0, dim=-1)
+    face_normals = fn / torch.sqrt(torch.clamp(torch.sum(fn * fn, -1, keepdim=True), min=1e-20))           # safe_normalize (:994)
+    face_idx = torch.arange(0, tri.shape[0], dtype=torch.int32, device=dev)[:, None].repeat(1, 3)
+    gb_geometric_normal = raster.interpolate(face_normals, rast, face_idx)                                 # :996
+    gb_normal = raster.interpolate(v_nrm, rast, t_nrm_idx)                                                 # :998
+    gb_tangent = torch.zeros_like(gb_normal)
+    sh = lambda x: x.view(1, h, w, 3)
+    nrm = prepare_shading_normal(sh(xyzs), eye_t.view(1, 1, 1, 3), None, sh(gb_normal), sh(gb_tangent), sh(gb_geometric_normal), two_sided_shading=True, opengl=True)  # :1013
+    nrm = nrm.reshape(-1, 3)
+    nrm = nrm / torch.sqrt(torch.clamp(torch.sum(nrm * nrm, -1, keepdim=True), min=1e-20))                 # :1014
+    occ = (rast[:, 3:4] > 0).float()                                                                       # mask (:1028)
+    N = h * w
+    kdks = mlp_mat.sample(xyzs) if mlp_mat is not None else None
+    if kdks is not None:
+        kd_map = kdks[:, 0:3].contiguous(); rm = torch.cat((kdks[:, 4:5], kdks[:, 5:6]), dim=-1).contiguous()   # :1020, :1092
+    else:
+        kd_map = torch.full((N, 3), 0.6, device=dev); rm = torch.tensor([0.5, 0.0], device=dev)[None].expand(N, 2).contiguous()
+    depth = torch.norm(xyzs - rays_o, dim=1, keepdim=True)                                                 # :1096
+    return dict(fx=w, fy=h, occ=occ, pos=xyzs, normal=nrm * occ, depth=depth, kd=kd_map, rm=rm, ray_dir=rays_d, eye=eye, rast=rast)
+
+
 def linear2srgb(x):
     return torch.where(x <= 0.0031308, 12.92 * x, 1.055 * torch.pow(x + 1e-6, 1.0 / 2.4) - 0.055)
 

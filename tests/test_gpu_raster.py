@@ -55,3 +55,29 @@ def test_auto_normals_matches_the_reference(scene_mod):
     vn, idx = RS.auto_normals(torch.from_numpy(g["an_vert"]).cuda(), torch.from_numpy(g["an_tri"]).cuda())
     np.testing.assert_allclose(vn.cpu().numpy(), g["an_out"], rtol=2e-5, atol=2e-6)
     assert np.array_equal(idx.cpu().numpy(), g["an_tri"])
+
+
+def test_stage1_front_half_gbuffer(scene_mod):
+    """harness.build_gbuffer_stage1 = render_stage1's front half on the engine's operators: agrees with the face-normal G-buffer on visibility and
+    position, produces unit shading normals close to the geometric ones on the smooth mesh, and carries gradients back to the vertex positions."""
+    import torch
+    from mirres_restir_nerf_mesh_amd import renderer_restir as RR, harness
+    v, t = scene_mod.make_mesh(5, 8)
+    vt = torch.from_numpy(v).cuda().requires_grad_(True); tt = torch.from_numpy(t).cuda()
+    W = RR.restirbvhWorker(vt.detach(), tt); W.update_mesh(W.vrt, W.v_ind)
+    g1 = harness.build_gbuffer_stage1(W, vt, tt, 48, 40)
+    g0 = harness.build_gbuffer(W, 48, 40)
+    fg = g0["occ"][:, 0] > 0.5
+    assert torch.equal(g1["occ"], g0["occ"]) and float((g1["pos"][fg] - g0["pos"][fg]).abs().max()) < 2e-5
+    n1 = g1["normal"][fg]
+    assert torch.allclose(n1.norm(dim=1), torch.ones_like(n1[:, 0]), atol=1e-5)
+    cosang = (n1 * g0["normal"][fg]).sum(1)
+    assert float(cosang.mean()) > 0.97 and float((cosang > 0.5).float().mean()) > 0.99        # smooth normals stay near the face normals of the smooth mesh
+    assert (g1["normal"][~fg] == 0).all()
+    loss = (g1["pos"] ** 2).sum() + (g1["normal"] * torch.tensor([0.3, 0.5, 0.8], device="cuda")).sum()
+    loss.backward()
+    assert torch.isfinite(vt.grad).all() and float(vt.grad.abs().sum()) > 0
+    out = RR.render_fused(__import__("mirres_restir_nerf_mesh_amd._ops", fromlist=["get_ctx"]).get_ctx(g1["fx"], g1["fy"]), W, None, False, (1, 1, 1),
+                          torch.from_numpy(scene_mod.make_env(32, 64)).cuda(), g1["occ"].clone(), g1["normal"].detach().contiguous(), g1["depth"].detach().contiguous(), g1["kd"],
+                          g1["rm"], g1["ray_dir"], g1["pos"].detach().contiguous(), 2, 2, 2, 2.0, 0.1, 0.001, 5)[0]
+    assert torch.isfinite(out[0]).all() and float(out[0][fg].mean()) > 0.01                    # and it feeds the path
