@@ -171,6 +171,10 @@ int mirres_dump_render(mirres_bvh_t* bvh, int n, int L, const float* pos, const 
 int mirres_raster_raycast(mirres_bvh_t* bvh, const float* rays, int n, const float* vert, const int32_t* tri, float* rast, void* stream);
 int mirres_interpolate(const float* attr, int C, const float* rast, const int32_t* tri, int n, float* out, void* stream);
 int mirres_interpolate_bwd(const float* attr, int C, const float* rast, const int32_t* tri, int n, const float* g_out, float* g_attr, float* g_uv, void* stream);
+/* dr.texture(tex, uv, filter_mode='linear', boundary_mode='clamp') (nerf/renderer.py:1004, 1008: the jittered taps of the smoothness
+ * regularisers): tex f32[H,W,C], uv f32[n,2] in [0,1] (texel centres at (i + 0.5) / W) -> out f32[n,C]; the backward ACCUMULATES into g_tex. */
+int mirres_texture2d(const float* tex, int H, int W, int C, const float* uv, int n, float* out, void* stream);
+int mirres_texture2d_bwd(int H, int W, int C, const float* uv, int n, const float* g_out, float* g_tex, void* stream);
 
 /* prepare_shading_normal (nerf/renderutils/ops.py:100-163; c_src/normal.cu): the shading normal render_stage1 hands to the path
  * (nerf/renderer.py:1013). All inputs f32[n,3] (broadcast inputs expanded by the caller); out f32[n,3]. The backward writes the six input

@@ -3,7 +3,8 @@
 // primary rays are cast through the path's own BVH (closest hit, mirres_bvh_trace mode 2) and the hit is turned into nvdiffrast's raster record
 // (u, v, depth, triangle_id + 1) so that interpolation and its gradients follow dr.interpolate's published contract:
 //   out = u a[i0] + v a[i1] + (1 - u - v) a[i2],   d out / d a[i_k] = barycentric weight,   d out / d(u, v) = (a[i0] - a[i2], a[i1] - a[i2]).
-// dr.texture taps and dr.antialias (visibility gradients) are not provided.
+// dr.texture (linear filter, clamp boundary: the jittered taps of the smoothness regularisers, :1001-1010) is k_texture below; dr.antialias
+// (visibility gradients) is not provided.
 #include "engine.hpp"
 #include "device_math.hpp"
 
@@ -75,9 +76,54 @@ __global__ void __launch_bounds__(MR_BLOCK) k_interpolate_bwd(const float* __res
     if (g_uv) { g_uv[2 * (size_t)i] = gu; g_uv[2 * (size_t)i + 1] = gv; }
 }
 
+// dr.texture(tex[H,W,C], uv[n,2], filter_mode='linear', boundary_mode='clamp') (nerf/renderer.py:1004,1008): texel centres at (i + 0.5) / W, the
+// four taps clamped to the edge. Same arithmetic as F.grid_sample(bilinear, padding 'border', align_corners=False) on uv * 2 - 1.
+MR_DEV void tex_taps(float u, float v, int W, int H, int& x0, int& x1, int& y0, int& y1, float& fx, float& fy) {
+    float x = u * W - 0.5f, y = v * H - 0.5f;
+    x = fminf(fmaxf(x, 0.f), (float)(W - 1)); y = fminf(fmaxf(y, 0.f), (float)(H - 1));
+    const float xf = floorf(x), yf = floorf(y);
+    x0 = (int)xf; y0 = (int)yf; x1 = min(x0 + 1, W - 1); y1 = min(y0 + 1, H - 1);
+    fx = x - xf; fy = y - yf;
+}
+__global__ void __launch_bounds__(MR_BLOCK) k_texture(const float* __restrict__ tex, int H, int W, int C, const float* __restrict__ uv, int n, float* __restrict__ out) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)n * C) return;
+    const int i = (int)(idx / C), c = (int)(idx % C);
+    int x0, x1, y0, y1; float fx, fy;
+    tex_taps(uv[2 * (size_t)i], uv[2 * (size_t)i + 1], W, H, x0, x1, y0, y1, fx, fy);
+    const float t00 = tex[((size_t)y0 * W + x0) * C + c], t01 = tex[((size_t)y0 * W + x1) * C + c];
+    const float t10 = tex[((size_t)y1 * W + x0) * C + c], t11 = tex[((size_t)y1 * W + x1) * C + c];
+    out[idx] = (t00 * (1.f - fx) + t01 * fx) * (1.f - fy) + (t10 * (1.f - fx) + t11 * fx) * fy;
+}
+__global__ void __launch_bounds__(MR_BLOCK) k_texture_bwd(int H, int W, int C, const float* __restrict__ uv, int n, const float* __restrict__ g_out, float* __restrict__ g_tex) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)n * C) return;
+    const int i = (int)(idx / C), c = (int)(idx % C);
+    int x0, x1, y0, y1; float fx, fy;
+    tex_taps(uv[2 * (size_t)i], uv[2 * (size_t)i + 1], W, H, x0, x1, y0, y1, fx, fy);
+    const float g = g_out[idx];
+    atomicAdd(&g_tex[((size_t)y0 * W + x0) * C + c], g * (1.f - fx) * (1.f - fy)); atomicAdd(&g_tex[((size_t)y0 * W + x1) * C + c], g * fx * (1.f - fy));
+    atomicAdd(&g_tex[((size_t)y1 * W + x0) * C + c], g * (1.f - fx) * fy); atomicAdd(&g_tex[((size_t)y1 * W + x1) * C + c], g * fx * fy);
+}
+
 }  // namespace mr
 
 using namespace mr;
+
+extern "C" int mirres_texture2d(const float* tex, int H, int W, int C, const float* uv, int n, float* out, void* stream) {
+    if (H <= 0 || W <= 0 || C <= 0 || n < 0 || !tex || (n > 0 && (!uv || !out))) { set_error("mirres_texture2d: bad argument"); return MIRRES_E_ARG; }
+    if (n == 0) return MIRRES_OK;
+    k_texture<<<grid_for((size_t)n * C, MR_BLOCK), MR_BLOCK, 0, (hipStream_t)stream>>>(tex, H, W, C, uv, n, out);
+    MR_LAUNCH_CHECK("texture2d");
+    return MIRRES_OK;
+}
+extern "C" int mirres_texture2d_bwd(int H, int W, int C, const float* uv, int n, const float* g_out, float* g_tex, void* stream) {
+    if (H <= 0 || W <= 0 || C <= 0 || n < 0 || !g_tex || (n > 0 && (!uv || !g_out))) { set_error("mirres_texture2d_bwd: bad argument"); return MIRRES_E_ARG; }
+    if (n == 0) return MIRRES_OK;
+    k_texture_bwd<<<grid_for((size_t)n * C, MR_BLOCK), MR_BLOCK, 0, (hipStream_t)stream>>>(H, W, C, uv, n, g_out, g_tex);
+    MR_LAUNCH_CHECK("texture2d_bwd");
+    return MIRRES_OK;
+}
 
 extern "C" int mirres_raster_raycast(mirres_bvh_t* bvh, const float* rays, int n, const float* vert, const int32_t* tri, float* rast, void* stream) {
     if (!bvh || n < 0 || (n > 0 && (!rays || !vert || !tri || !rast))) { set_error("mirres_raster_raycast: bad argument"); return MIRRES_E_ARG; }

@@ -6,7 +6,9 @@ interpolation with gradients to the vertex attributes, smooth vertex normals —
     v_nrm, t_nrm_idx = auto_normals(vertices, triangles)      # meshutils.py:14-39
     gb_normal = interpolate(v_nrm, rast, t_nrm_idx)
 
-dr.texture and dr.antialias (the jittered smoothness taps and the visibility gradient, :1001-1010, :1184-1206) are not provided."""
+    nrm_jitter = texture(gb_normal.view(h, w, 3), jitter)     # dr.texture(..., filter_mode='linear', boundary_mode='clamp') (:1004, :1008)
+
+dr.antialias (the visibility gradient, :1184-1206) is not provided."""
 import torch
 
 from ._lib import lib, check, stream_ptr
@@ -67,3 +69,29 @@ def auto_normals(v_pos, t_pos_idx):
     v_nrm = torch.where(d > 1e-20, v_nrm, torch.tensor([0.0, 0.0, 1.0], dtype=torch.float32, device=v_pos.device))
     v_nrm = v_nrm / torch.sqrt(torch.clamp(torch.sum(v_nrm * v_nrm, -1, keepdim=True), min=1e-20))
     return v_nrm, t_pos_idx
+
+
+class _Texture(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tex, uv):
+        tex_c = tex.detach().float().contiguous(); uv_c = uv.detach().float().contiguous().view(-1, 2)
+        H, W, C_ = tex_c.shape; n = uv_c.shape[0]
+        out = torch.empty((n, C_), dtype=torch.float32, device=tex_c.device)
+        check(lib().mirres_texture2d(tex_c.data_ptr(), H, W, C_, uv_c.data_ptr(), n, out.data_ptr(), stream_ptr()), "mirres_texture2d")
+        ctx.save_for_backward(uv_c); ctx.dims = (H, W, C_)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        (uv,) = ctx.saved_tensors; H, W, C_ = ctx.dims
+        g_tex = None
+        if ctx.needs_input_grad[0]:
+            g_tex = torch.zeros((H, W, C_), dtype=torch.float32, device=uv.device)
+            check(lib().mirres_texture2d_bwd(H, W, C_, uv.data_ptr(), uv.shape[0], g_out.contiguous().float().data_ptr(), g_tex.data_ptr(), stream_ptr()), "mirres_texture2d_bwd")
+        return g_tex, None
+
+
+def texture(tex, uv):
+    """dr.texture(tex[None], uv[None], filter_mode='linear', boundary_mode='clamp')[0]: tex f32[H,W,C], uv f32[...,2] in [0,1] -> f32[prod(...), C];
+    gradients flow to tex (the taps' coordinates are constants in the reference: jitter = pixel_grid + noise)."""
+    return _Texture.apply(tex, uv)

@@ -81,3 +81,22 @@ def test_stage1_front_half_gbuffer(scene_mod):
                           torch.from_numpy(scene_mod.make_env(32, 64)).cuda(), g1["occ"].clone(), g1["normal"].detach().contiguous(), g1["depth"].detach().contiguous(), g1["kd"],
                           g1["rm"], g1["ray_dir"], g1["pos"].detach().contiguous(), 2, 2, 2, 2.0, 0.1, 0.001, 5)[0]
     assert torch.isfinite(out[0]).all() and float(out[0][fg].mean()) > 0.01                    # and it feeds the path
+
+
+def test_texture_taps_against_grid_sample():
+    """raster.texture (dr.texture, linear filter, clamp boundary) against torch's grid_sample with the same convention (bilinear, border padding,
+    align_corners False), forward and the gradient to the texture; coordinates inside, on the border and outside [0, 1]."""
+    import torch
+    from mirres_restir_nerf_mesh_amd import raster as RS
+    gen = torch.Generator(device="cuda").manual_seed(4)
+    H, W, C = 13, 21, 5
+    tex = torch.rand((H, W, C), device="cuda", generator=gen, requires_grad=True)
+    uv = torch.rand((4000, 2), device="cuda", generator=gen) * 1.3 - 0.15
+    uv[:4] = torch.tensor([[0.0, 0.0], [1.0, 1.0], [0.5 / W, 0.5 / H], [1.0 - 0.5 / W, 0.3]], device="cuda")
+    out = RS.texture(tex, uv)
+    tex2 = tex.detach().clone().requires_grad_(True)
+    ref = torch.nn.functional.grid_sample(tex2.permute(2, 0, 1)[None], (uv * 2 - 1).view(1, 1, -1, 2), mode="bilinear", padding_mode="border", align_corners=False)[0, :, 0].t()
+    assert torch.allclose(out, ref, rtol=1e-5, atol=1e-6)
+    gw = torch.randn_like(out)
+    (out * gw).sum().backward(); (ref * gw).sum().backward()
+    assert torch.allclose(tex.grad, tex2.grad, rtol=1e-4, atol=1e-4)
