@@ -58,17 +58,16 @@ def interpolate(attr, rast, tri):
 
 
 def auto_normals(v_pos, t_pos_idx):
-    """meshutils.py:14-39: area-weighted vertex normals (face normals splatted to the vertices), degenerate ones replaced by (0, 0, 1)."""
-    i0, i1, i2 = (t_pos_idx[:, k].to(torch.int64) for k in range(3))
-    v0, v1, v2 = v_pos[i0, :], v_pos[i1, :], v_pos[i2, :]
-    face_normals = torch.cross(v1 - v0, v2 - v0, dim=-1)
-    v_nrm = torch.zeros_like(v_pos)
-    for i in (i0, i1, i2):
-        v_nrm.scatter_add_(0, i[:, None].repeat(1, 3), face_normals)
-    d = torch.sum(v_nrm * v_nrm, -1, keepdim=True)
-    v_nrm = torch.where(d > 1e-20, v_nrm, torch.tensor([0.0, 0.0, 1.0], dtype=torch.float32, device=v_pos.device))
-    v_nrm = v_nrm / torch.sqrt(torch.clamp(torch.sum(v_nrm * v_nrm, -1, keepdim=True), min=1e-20))
-    return v_nrm, t_pos_idx
+    """meshutils.py:14-39: area-weighted vertex normals — every face's (unnormalised) normal added to its three vertices, then normalised; a vertex
+    whose sum is (numerically) zero gets (0, 0, 1). Returns (v_nrm [V,3], t_pos_idx) like the reference. Differentiable w.r.t. v_pos."""
+    idx = t_pos_idx.to(torch.int64)
+    corners = v_pos[idx]                                              # [T,3,3]
+    fn = torch.cross(corners[:, 1] - corners[:, 0], corners[:, 2] - corners[:, 0], dim=-1)
+    acc = torch.zeros_like(v_pos).index_add_(0, idx[:, 0], fn).index_add_(0, idx[:, 1], fn).index_add_(0, idx[:, 2], fn)
+    sq = (acc * acc).sum(-1, keepdim=True)
+    up = torch.zeros(3, dtype=v_pos.dtype, device=v_pos.device); up[2] = 1.0
+    acc = torch.where(sq > 1e-20, acc, up)
+    return acc / (acc * acc).sum(-1, keepdim=True).clamp(min=1e-20).sqrt(), t_pos_idx
 
 
 class _Texture(torch.autograd.Function):

@@ -9,18 +9,19 @@ from . import _lib
 from ._lib import lib, check, stream_ptr
 
 def generate_envir_map_dir(envmap_h, envmap_w, is_jittor=False):
-    """nerf/render_helper.py:8-26: the fixed lat-long light set of the non-ReSTIR renderer (render_dump.py): (area weights [H*W], directions [H*W,3]),
-    z up, row 0 at the zenith. Set-up code (run once per model, network.py:131), plain torch as in the reference."""
-    lat_step_size = np.pi / envmap_h
-    lng_step_size = 2 * np.pi / envmap_w
-    phi, theta = torch.meshgrid([torch.linspace(np.pi / 2 - 0.5 * lat_step_size, -np.pi / 2 + 0.5 * lat_step_size, envmap_h),
-                                 torch.linspace(np.pi - 0.5 * lng_step_size, -np.pi + 0.5 * lng_step_size, envmap_w)], indexing='ij')
-    sin_phi = torch.sin(torch.pi / 2 - phi)
-    light_area_weight = (4 * torch.pi * sin_phi / torch.sum(sin_phi)).to(torch.float32).reshape(-1)
+    """nerf/render_helper.py:8-26: the fixed lat-long light set of the non-ReSTIR renderer (render_dump.py). Returns (solid-angle weights [H*W] summing
+    to 4 pi, unit directions [H*W,3]): z up, row 0 nearest the zenith, latitude / longitude sampled at the cell centres, longitude running from +pi down.
+    Set-up code (once per model, network.py:131), plain torch as in the reference; `is_jittor` perturbs every direction inside its cell."""
+    dlat, dlng = np.pi / envmap_h, 2 * np.pi / envmap_w
+    lat = torch.linspace(np.pi / 2 - 0.5 * dlat, -np.pi / 2 + 0.5 * dlat, envmap_h)[:, None].expand(envmap_h, envmap_w)
+    lng = torch.linspace(np.pi - 0.5 * dlng, -np.pi + 0.5 * dlng, envmap_w)[None, :].expand(envmap_h, envmap_w)
+    colat_sin = torch.sin(torch.pi / 2 - lat)
+    weights = (4 * torch.pi * colat_sin / colat_sin.sum()).to(torch.float32).reshape(-1)
     if is_jittor:
-        phi = phi + lat_step_size * (torch.rand_like(phi) - 0.5); theta = theta + lng_step_size * (torch.rand_like(theta) - 0.5)
-    view_dirs = torch.stack([torch.cos(theta) * torch.cos(phi), torch.sin(theta) * torch.cos(phi), torch.sin(phi)], dim=-1).view(-1, 3)
-    return light_area_weight, view_dirs
+        lat = lat + dlat * (torch.rand_like(lat) - 0.5); lng = lng + dlng * (torch.rand_like(lng) - 0.5)
+    cl = torch.cos(lat)
+    dirs = torch.stack((torch.cos(lng) * cl, torch.sin(lng) * cl, torch.sin(lat)), dim=-1).reshape(-1, 3)
+    return weights, dirs
 
 
 GRADIENT_SCALING = 128.0  # render_helper.py:77-80: MLP input-grad hook x128 (=> grid grads x128), encoder input-grad hook /128
