@@ -213,7 +213,9 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_closest(BvhView B, con
 // are still traversing, idle lanes pull the next rays of the chunk with pure ballot/popcount arithmetic (no atomics). Per-ray
 // arithmetic and visit order are exactly those of traverse<>, so results are bit-identical to the simple kernels.
 #define MR_CHUNK_MAX 1024
+#ifndef MR_REFILL
 #define MR_REFILL 40
+#endif
 // Work distribution. A single queue-head word serialises at ~88 returning atomics/us on MI355X: with 64-ray chunks a 2.3 M-ray launch needs
 // 36 k of them = 0.41 ms — the whole kernel. The ray queue is therefore cut into MR_NQ contiguous sub-queues with their own head words
 // (128 B apart: different L2 channels); a wave starts on sub-queue (wave id mod MR_NQ), takes chunks from it and moves to the next one when
@@ -764,7 +766,8 @@ static int closest_mode() {   // 4 (default): ordered compressed 4-wide fast pat
 }
 static int persist_grid(size_t capacity) {
     size_t want = (capacity + MR_TRACE_BLOCK - 1) / MR_TRACE_BLOCK;
-    size_t cap = 256 * 6;                                       // 6 resident blocks per CU: measured faster than 8 (forcing <= 64 VGPRs spills; the kernels are
+    static const size_t cap_blocks = [] { const char* e = getenv("MIRRES_TRACE_BLOCKS_PER_CU"); const int v = e ? atoi(e) : 6; return (size_t)(v >= 1 && v <= 16 ? v : 6); }();
+    size_t cap = 256 * cap_blocks;                                       // 6 resident blocks per CU: measured faster than 8 (forcing <= 64 VGPRs spills; the kernels are
                                                                 // VALU-issue bound while CUs hold waves — DESIGN.md §5 — so more occupancy buys nothing)
     return (int)(want < 1 ? 1 : (want > cap ? cap : want));
 }
