@@ -296,6 +296,9 @@ struct MatNetB { const __half2* grid; const float *w0, *w1, *w2; float aabb_min[
 // point); one LDS reduction over the four waves and one global atomic per entry per workgroup at the end.
 #define MR_BW_WAVES (MR_BLOCK / 64)
 #define MR_BW_LD 33     // padded row of the staged [64][32] factors
+#define MR_BW_TABLE_LOG2 10
+#define MR_BW_TABLE (1 << MR_BW_TABLE_LOG2)   // per-wave aggregation table of the coarse grid levels: keys in U (4 KB of 8.4), values in V (8 KB of 8.4)
+#define MR_BW_COARSE 8
 __global__ void __launch_bounds__(MR_BLOCK) k_matnet_bwd(MatNetB M, GridLevelsB L, const float* __restrict__ pos, int n, const float* __restrict__ gout,
                                                          float* __restrict__ g_params, float* __restrict__ g_w0, float* __restrict__ g_w1, float* __restrict__ g_w2) {
     __shared__ float sw0[1024], sw1[1024], sw2[192];
@@ -380,24 +383,48 @@ __global__ void __launch_bounds__(MR_BLOCK) k_matnet_bwd(MatNetB M, GridLevelsB 
             }
             __builtin_amdgcn_wave_barrier();
         }
-        // hash-grid gradient: fp32 atomics into the master-precision gradient table (tcnn accumulates its grid gradient the same way)
-        if (g_params && live) {
-            for (int lv = 0; lv < MR_LEVELS; lv++) {
-                const float scale = L.scale[lv]; const uint32_t res = L.res[lv], size = L.size[lv];
-                float p[3]; uint32_t pg[3];
+        // hash-grid gradient: fp32 atomics into the master-precision gradient table (tcnn accumulates its grid gradient the same way). The 64
+        // points of a wave are neighbouring pixels: on the coarse levels they fall into a handful of cells, and 164 M scattered global atomics
+        // (with that contention) were what the kernel waited for. Levels < MR_BW_COARSE therefore go through a per-wave LDS table (the wave's
+        // staging area, free after the outer products: open addressing, two probes, overflow straight to global memory), flushed per tile.
+        if (g_params) {
+            int* const keys = reinterpret_cast<int*>(U); float* const vals = V;
+            for (int e = lane; e < MR_BW_TABLE; e += 64) { keys[e] = -1; vals[2 * e] = 0.f; vals[2 * e + 1] = 0.f; }
+            __builtin_amdgcn_wave_barrier();
+            if (live) {
+                for (int lv = 0; lv < MR_LEVELS; lv++) {
+                    const float scale = L.scale[lv]; const uint32_t res = L.res[lv], size = L.size[lv];
+                    float p[3]; uint32_t pg[3];
 #pragma unroll
-                for (int d = 0; d < 3; d++) { float q = fmaf(scale, x[d], 0.5f); float fl = floorf(q); pg[d] = (uint32_t)(int)fl; p[d] = q - fl; }
-                const float g0 = ga0[2 * lv], g1 = ga0[2 * lv + 1];
-                if (g0 == 0.f && g1 == 0.f) continue;
+                    for (int d = 0; d < 3; d++) { float q = fmaf(scale, x[d], 0.5f); float fl = floorf(q); pg[d] = (uint32_t)(int)fl; p[d] = q - fl; }
+                    const float g0 = ga0[2 * lv], g1 = ga0[2 * lv + 1];
+                    if (g0 == 0.f && g1 == 0.f) continue;
 #pragma unroll
-                for (uint32_t idx = 0; idx < 8; idx++) {
-                    float w = 1.f; uint32_t pl[3];
+                    for (uint32_t idx = 0; idx < 8; idx++) {
+                        float w = 1.f; uint32_t pl[3];
 #pragma unroll
-                    for (int d = 0; d < 3; d++) { if ((idx & (1u << d)) == 0) { w *= 1 - p[d]; pl[d] = pg[d]; } else { w *= p[d]; pl[d] = pg[d] + 1; } }
-                    size_t e = (size_t)L.offset[lv] + grid_index_b(size, res, pl[0], pl[1], pl[2]);
-                    atomicAdd(&g_params[2 * e], w * g0); atomicAdd(&g_params[2 * e + 1], w * g1);
+                        for (int d = 0; d < 3; d++) { if ((idx & (1u << d)) == 0) { w *= 1 - p[d]; pl[d] = pg[d]; } else { w *= p[d]; pl[d] = pg[d] + 1; } }
+                        const size_t e = (size_t)L.offset[lv] + grid_index_b(size, res, pl[0], pl[1], pl[2]);
+                        bool done = false;
+                        if (lv < MR_BW_COARSE) {
+                            uint32_t h = ((uint32_t)e * 2654435761u) >> (32 - MR_BW_TABLE_LOG2);
+#pragma unroll
+                            for (int probe = 0; probe < 2 && !done; probe++) {
+                                const int old = atomicCAS(&keys[h], -1, (int)e);
+                                if (old == -1 || old == (int)e) { atomicAdd(&vals[2 * h], w * g0); atomicAdd(&vals[2 * h + 1], w * g1); done = true; }
+                                h = (h + 1) & (MR_BW_TABLE - 1);
+                            }
+                        }
+                        if (!done) { atomicAdd(&g_params[2 * e], w * g0); atomicAdd(&g_params[2 * e + 1], w * g1); }
+                    }
                 }
             }
+            __builtin_amdgcn_wave_barrier();
+            for (int e = lane; e < MR_BW_TABLE; e += 64) {
+                const int key = keys[e];
+                if (key >= 0) { atomicAdd(&g_params[2 * (size_t)key], vals[2 * e]); atomicAdd(&g_params[2 * (size_t)key + 1], vals[2 * e + 1]); }
+            }
+            __builtin_amdgcn_wave_barrier();
         }
     }
     // reduce the four waves' register accumulators through LDS (entry e = lane + 64 j  <->  [o = e / 32][k = e % 32]), one global atomic per entry
