@@ -139,6 +139,10 @@ int mirres_eaw(int fx, int fy, int step_width, float c_phi, float n_phi, float p
 /* EAWDenoise_run.backward (Denoising.py:30-48): grads w.r.t. colour, normal and position are ACCUMULATED.      */
 int mirres_eaw_bwd(int fx, int fy, int step_width, float c_phi, float n_phi, float p_phi, const float* occ, const float* color,
                    const float* normal, const float* pos, const float* grad_out, float* g_color, float* g_normal, float* g_pos, void* stream);
+/* The same adjoint computed as a gather (two passes, no atomics, deterministic; scratch4 f32[N,4] is overwritten). The three gradient buffers are
+ * accumulated into like mirres_eaw_bwd's.                                                                                                      */
+int mirres_eaw_bwd_gather(int fx, int fy, int step_width, float c_phi, float n_phi, float p_phi, const float* occ, const float* color, const float* normal,
+                          const float* pos, const float* grad_out, float* scratch4, float* g_color, float* g_normal, float* g_pos, void* stream);
 
 /* bilateral_denoiser (nerf/renderutils/ops.py:173-211; c_src/denoising.cu:14-130): the alternative denoiser of run_restir_di_with_pt
  * (--use_bi_de, renderer_restir.py:529-541). sigma = max(2 * factor, 1e-4); window radius 2 ceil(2.5 sigma) + 1. col f32[N,3],

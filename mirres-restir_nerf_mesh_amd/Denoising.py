@@ -31,9 +31,10 @@ class EAWDenoise_run(torch.autograd.Function):
         grad_color = torch.zeros_like(color)
         grad_normal = torch.zeros_like(normal_map)
         grad_pos = torch.zeros_like(pos_map)
-        check(lib().mirres_eaw_bwd(int(fx), int(fy), int(step), float(c_phi), float(n_phi), float(p_phi), occ_map.data_ptr(), color.data_ptr(),
-                                   normal_map.data_ptr(), pos_map.data_ptr(), grad_out_color.data_ptr(), grad_color.data_ptr(), grad_normal.data_ptr(),
-                                   grad_pos.data_ptr(), stream_ptr()), "mirres_eaw_bwd")
+        scratch = torch.empty((color.shape[0], 4), dtype=torch.float32, device=color.device)
+        check(lib().mirres_eaw_bwd_gather(int(fx), int(fy), int(step), float(c_phi), float(n_phi), float(p_phi), occ_map.data_ptr(), color.data_ptr(),
+                                          normal_map.data_ptr(), pos_map.data_ptr(), grad_out_color.data_ptr(), scratch.data_ptr(), grad_color.data_ptr(),
+                                          grad_normal.data_ptr(), grad_pos.data_ptr(), stream_ptr()), "mirres_eaw_bwd_gather")
         return (None, None, None, None, None, None, None, None, grad_color, grad_normal, grad_pos)
 
 

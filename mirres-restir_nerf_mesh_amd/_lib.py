@@ -97,6 +97,7 @@ SIGNATURES = {
     "mirres_bilateral": (C.c_int, [C.c_int, C.c_int, C.c_float, vp, vp, vp, vp, vp, vp]),
     "mirres_bilateral_bwd": (C.c_int, [C.c_int, C.c_int, C.c_float, vp, vp, vp, vp, vp, vp]),
     "mirres_eaw_bwd": (C.c_int, [C.c_int, C.c_int, C.c_int, f32, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "mirres_eaw_bwd_gather": (C.c_int, [C.c_int, C.c_int, C.c_int, f32, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "mirres_matnet_grid_entries": (C.c_int, []),
     "mirres_matnet_pack_grid": (C.c_int, [vp, vp, C.c_int64, vp]),
     "mirres_matnet_fwd": (C.c_int, [PMAT, vp, C.c_int, vp, vp, vp]),

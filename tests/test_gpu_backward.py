@@ -109,6 +109,15 @@ def test_eaw_backward(env, oracle):
                 return float(fwd(*a))
         num = _dd(f, args[i].double(), d.double(), eps)
         assert abs(ana - num) <= 0.03 * abs(num) + 2e-2, (nm, ana, num)
+    # the gather form used by EAWDenoise_run.backward and the scatter form (mirres_eaw_bwd) are the same adjoint
+    from mirres_restir_nerf_mesh_amd._lib import lib, check
+    gout = w.contiguous()
+    gs = [torch.zeros_like(t) for t in (col, nrm, pos)]
+    check(lib().mirres_eaw_bwd(F.fx, F.fy, 2, phis[0], phis[1], phis[2], occ.data_ptr(), col.data_ptr(), nrm.data_ptr(), pos.data_ptr(), gout.data_ptr(), gs[0].data_ptr(),
+                               gs[1].data_ptr(), gs[2].data_ptr(), None), "mirres_eaw_bwd")
+    torch.cuda.synchronize()
+    for a, b_ in zip(gs, (x[0].grad, x[1].grad, x[2].grad)):
+        assert torch.allclose(a, b_, rtol=1e-4, atol=1e-5), float((a - b_).abs().max())
 
 
 def test_matnet_backward(env, oracle, scene_mod):
