@@ -429,11 +429,39 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const
     bool exhausted = false, have = false;
     float ox = 0, oy = 0, oz = 0, ix = 0, iy = 0, iz = 0; v3 d = V3(0.f), ro = V3(0.f);
     float t_min = 0.f, t_max = 0.f;
-    int cur = 0, sp = 0; uint32_t ridx = 0;
+    int cur = 0, sp = 0, sbase = 0; uint32_t ridx = 0;   // the lane's deferred entries live in [sbase, sp)
     uint32_t spill[MR_STACK - MR_ANY_LDS];
     unsigned long long c_boxes = 0, c_nodes = 0, c_leaves = 0;
     while (true) {
         const uint64_t need = __ballot(!have);
+        if (need && exhausted) {
+            // ---- the tail of the launch: the queue is empty and the wave waits for its longest rays. A shadow ray's answer is an OR over subtrees, so
+            // a lane with deferred entries hands its OLDEST one (the bottom of its stack: usually the largest subtree) to an idle lane, which searches
+            // it for the same ray; whoever finds an occluder writes 1 (the slot was zeroed when the ray was loaded).
+            const uint64_t donors = __ballot(have && sp > sbase && sbase < MR_ANY_LDS);
+            if (donors) {
+                const int nd = __popcll(donors), ni = __popcll(need);
+                const int my_idle = __popcll(need & lt_mask), my_don = __popcll(donors & lt_mask);
+                const bool take = !have && my_idle < nd;
+                const bool give = have && sp > sbase && sbase < MR_ANY_LDS && my_don < ni;
+                uint64_t m = donors;
+                if (take) for (int t = 0; t < my_idle; t++) m &= m - 1;
+                const int src = take ? __builtin_ctzll(m) : lane;
+                const float s_ox = __shfl(ox, src, 64), s_oy = __shfl(oy, src, 64), s_oz = __shfl(oz, src, 64);
+                const float s_ix = __shfl(ix, src, 64), s_iy = __shfl(iy, src, 64), s_iz = __shfl(iz, src, 64);
+                const float s_dx = __shfl(d.x, src, 64), s_dy = __shfl(d.y, src, 64), s_dz = __shfl(d.z, src, 64);
+                const float s_tmin = __shfl(t_min, src, 64), s_tmax = __shfl(t_max, src, 64);
+                const uint32_t s_ridx = (uint32_t)__shfl((int)ridx, src, 64);
+                const int s_base = __shfl(sbase, src, 64);
+                if (take) {
+                    ox = s_ox; oy = s_oy; oz = s_oz; ix = s_ix; iy = s_iy; iz = s_iz; d = V3(s_dx, s_dy, s_dz); ro = V3(s_ox, s_oy, s_oz);
+                    t_min = s_tmin; t_max = s_tmax; ridx = s_ridx;
+                    cur = (int)lds[s_base * MR_TRACE_BLOCK + ((threadIdx.x & ~63) | src)];
+                    sp = 0; sbase = 0; have = true;
+                }
+                if (give) sbase++;
+            }
+        }
         if (need && !exhausted) {
             if (chunk_next >= chunk_end) exhausted = !grab_chunk(work_head, n, q_per, chunk, q_cur, q_fail, chunk_next, chunk_end, lane);
             if (!exhausted) {
@@ -446,12 +474,12 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const
                     { float dx = d.x, dy = d.y, dz = d.z;
                       if (dx == 0.f) dx = 0.000001f; if (dy == 0.f) dy = 0.000001f; if (dz == 0.f) dz = 0.000001f;
                       ix = 1.0f / dx; iy = 1.0f / dy; iz = 1.0f / dz; }
-                    sp = 0;
+                    sp = 0; sbase = 0;
+                    hit_out[idx] = 0;          // set to 1 by whichever lane finds an occluder (the owner or, in the tail, a helper)
                     const float o3[3] = {ox, oy, oz}, i3[3] = {ix, iy, iz};
                     Slab s0 = slab(B.root_box, B.root_box + 3, o3, i3, t_min);
                     if (COUNT) c_boxes++;
                     if (s0.tf > s0.tn && t_max > s0.tn) { cur = TOPN > 0 ? MR_TOPBIT : 0; have = true; }
-                    else hit_out[idx] = 0;
                 }
                 const uint32_t want = (uint32_t)__popcll(need);
                 chunk_next = (chunk_next + want < chunk_end) ? chunk_next + want : chunk_end;
@@ -522,12 +550,13 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const
                 bool done = hit;
                 if (!hit) {
                     if (next != 0x7fffffff) cur = next;
-                    else if (sp > 0) { --sp; cur = (int)((sp < MR_ANY_LDS) ? lds_stack[sp * MR_TRACE_BLOCK] : spill[sp - MR_ANY_LDS]); }
+                    else if (sp > sbase) { --sp; cur = (int)((sp < MR_ANY_LDS) ? lds_stack[sp * MR_TRACE_BLOCK] : spill[sp - MR_ANY_LDS]); }
                     else done = true;
                 }
-                if (done) { have = false; hit_out[ridx] = hit ? 1 : 0; }
+                if (done) { have = false; if (hit) hit_out[ridx] = 1; }
             }
-        } while (__popcll(__ballot(have)) >= MR_REFILL || (exhausted && __ballot(have)));
+            // in the tail leave the loop as soon as an idle lane and a lane with deferred work coexist (hand-over above)
+        } while (exhausted ? (__ballot(have) && !(__ballot(!have) && __ballot(have && sp > sbase && sbase < MR_ANY_LDS))) : (__popcll(__ballot(have)) >= MR_REFILL));
     }
     if (B.dbg && (threadIdx.x & 63) == 0) B.dbg[2 * (blockIdx.x * (MR_TRACE_BLOCK / 64) + (threadIdx.x >> 6)) + 1] = wall_clock64();
     if (COUNT && stats) { atomicAdd(&stats[2], c_boxes); atomicAdd(&stats[3], c_nodes); atomicAdd(&stats[4], c_leaves); }
