@@ -127,3 +127,60 @@ def test_shadow_rays_on_a_ploc_hierarchy(torch_cuda, oracle, scene_mod, monkeypa
         check(lib().mirres_bvh_trace(w.h, dr.data_ptr(), len(rays), 0, hit0.data_ptr(), None, None, None, None, None, None), name)
         torch.cuda.synchronize()
         assert np.array_equal(hit0.cpu().numpy(), ref["hit"]), name
+
+
+def test_traversal_quirks_on_a_hand_made_mesh(torch_cuda, oracle):
+    """The edge cases of SURVEY §8 a-7..a-9 on a mesh built for them, every trace mode against the oracle bit for bit: axis-aligned flat triangles (their
+    boxes have zero thickness and can never be entered: `tmax <= tmin`), duplicated triangles (exact distance ties: the ordered fast path must hand them
+    to the reference-order redo), a zero-area triangle (|det| < 1e-15), hits behind the origin (triangle_hit does not look at t), rays with zero
+    direction components and axis-parallel rays, origins on vertices / edges, tiny and huge t_max."""
+    torch = torch_cuda
+    from mirres_restir_nerf_mesh_amd.renderer_restir import restirbvhWorker
+    from mirres_restir_nerf_mesh_amd._lib import lib, check
+    rng = np.random.default_rng(12)
+    V, T = [], []
+    def quad(a, b, c, d):
+        i = len(V); V.extend([a, b, c, d]); T.extend([[i, i + 1, i + 2], [i, i + 2, i + 3]])
+    # a unit cube of axis-aligned faces (never hit by the reference), two tilted walls, a tilted floor, duplicates of one wall, a degenerate sliver
+    for z in (0.0, 1.0): quad([0, 0, z], [1, 0, z], [1, 1, z], [0, 1, z])
+    for x in (0.0, 1.0): quad([x, 0, 0], [x, 1, 0], [x, 1, 1], [x, 0, 1])
+    for y in (0.0, 1.0): quad([0, y, 0], [1, y, 0], [1, y, 1], [0, y, 1])
+    quad([-1, -1, 0.2], [2, -1, 0.25], [2.1, 2, 0.3], [-1.05, 2, 0.22])
+    wall = ([0.3, -0.5, -0.5], [0.35, 1.5, -0.5], [0.4, 1.5, 1.5], [0.33, -0.5, 1.5])
+    quad(*wall); quad(*wall); quad(*wall)                                   # three coincident walls: exact ties
+    quad([0.7, -0.5, -0.4], [0.72, 1.4, -0.5], [0.9, 1.5, 1.6], [0.75, -0.6, 1.5])
+    i = len(V); V.extend([[0.5, 0.5, 0.5], [0.5, 0.5, 0.5], [0.6, 0.6, 0.6]]); T.append([i, i + 1, i + 2])   # zero area
+    for _ in range(40):                                                     # filler so that the hierarchy has some depth
+        c = rng.random(3) * 3 - 1; e = (rng.random((3, 3)) - 0.5) * 0.4
+        i = len(V); V.extend([c, c + e[0], c + e[1]]); T.append([i, i + 1, i + 2])
+    v = np.array(V, np.float32); t = np.array(T, np.int32)
+    w = restirbvhWorker(torch.from_numpy(v).cuda(), torch.from_numpy(t).cuda()); w.update_mesh(w.vrt, w.v_ind)
+    info, aabb, _, _ = oracle.bvh_build(v, t)
+    assert np.array_equal(w.LBVHNode_info.cpu().numpy(), info) and np.array_equal(w.LBVHNode_aabb.cpu().numpy(), aabb)
+    n = 6000
+    o = (rng.random((n, 3)) * 3 - 1).astype(np.float32); d = rng.normal(size=(n, 3)).astype(np.float32)
+    d[0::7, 0] = 0; d[1::7, 1] = 0; d[2::7, 2] = 0; d[3::49] = [0, 0, 1]; d[4::49] = [1, 0, 0]; d[5::49] = [0, -1, 0]   # zero components, axis-parallel
+    o[6::11] = v[rng.integers(0, len(v), size=len(o[6::11]))]                                                          # origins on vertices
+    o[7::13] = (0.5 * (v[t[rng.integers(0, len(t), size=len(o[7::13])), 0]] + v[t[rng.integers(0, len(t), size=len(o[7::13])), 1]])).astype(np.float32)
+    o[8::5, 0] = 0.5; o[8::5, 1] = 0.5; o[8::5, 2] = 0.5                                                               # inside the cube, between the walls
+    tmax = np.full(n, 1e7, np.float32); tmax[::9] = 0.05; tmax[1::9] = 1e-4
+    rays = oracle.make_rays(o, d); rays[:, 7] = tmax
+    ref = oracle.trace(info, aabb, v, t, rays, True, True)
+    assert (ref["hit"] > 0).mean() > 0.3 and (ref["t"][ref["hit"] > 0] < 0).any()         # behind-the-origin hits occur
+    dr = torch.from_numpy(rays).cuda()
+    for mode in (1, 2):
+        hit = torch.zeros(n, dtype=torch.int32, device="cuda"); tt = torch.zeros(n, device="cuda"); pos = torch.zeros((n, 3), device="cuda")
+        nrm = torch.zeros((n, 3), device="cuda"); pr = torch.zeros(n, dtype=torch.int32, device="cuda")
+        check(lib().mirres_bvh_trace(w.h, dr.data_ptr(), n, mode, hit.data_ptr(), tt.data_ptr(), pos.data_ptr(), nrm.data_ptr(), pr.data_ptr(), None, None), "mode %d" % mode)
+        torch.cuda.synchronize()
+        m = ref["hit"] > 0
+        assert np.array_equal(hit.cpu().numpy(), ref["hit"]) and np.array_equal(pr.cpu().numpy(), ref["prim"]), mode
+        assert np.array_equal(_bits(tt.cpu().numpy()[m]), _bits(ref["t"][m])) and np.array_equal(_bits(nrm.cpu().numpy()[m]), _bits(ref["normal"][m])), mode
+    h0 = torch.zeros(n, dtype=torch.int32, device="cuda")
+    check(lib().mirres_bvh_trace(w.h, dr.data_ptr(), n, 0, h0.data_ptr(), None, None, None, None, None, None), "any")
+    assert np.array_equal(h0.cpu().numpy(), ref["hit"])
+    h3 = torch.zeros(n, dtype=torch.int32, device="cuda")
+    check(lib().mirres_bvh_trace(w.h, dr.data_ptr(), n, 3, h3.data_ptr(), None, None, None, None, None, None), "front")
+    assert np.array_equal(h3.cpu().numpy(), oracle.occluded_front(info, aabb, v, t, rays))
+    # the axis-aligned cube faces (triangles 0..11) are never reported: their boxes cannot be entered
+    assert not np.isin(ref["prim"][ref["hit"] > 0], np.arange(12)).any()
