@@ -373,3 +373,45 @@ def test_fused_training_gradients_match_the_stepwise_loop(oracle, scene_mod, mon
         cos = float((a * b).sum() / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
         rel = float(np.linalg.norm(a - b) / (np.linalg.norm(a) + 1e-30))
         assert cos > 0.999 and rel < 0.05, "%s: cos %.6f rel %.4f" % (name, cos, rel)
+
+
+def test_degenerate_frames(oracle, scene_mod):
+    """Edge cases of the frame against the oracle: a frame that is not a multiple of any tile size (7 x 5), an all-background frame, a black environment
+    (every row of the importance table takes the uniform fallback), and material extremes (roughness at its floor, metallic 1) — no NaN, background = 1,
+    per-pixel agreement as in the 1-spp test."""
+    import torch
+    from mirres_restir_nerf_mesh_amd import renderer_restir as RR
+    from mirres_restir_nerf_mesh_amd._ops import get_ctx
+    names = ["final_color", "diffuse", "spec", "indirect", "indirect_diff", "indirect_spec"]
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+    def both(F, W, env, occ, kd, rm, spp=1, seed=31):
+        outs, _, _ = RR.render_fused(get_ctx(F.fx, F.fy), W, None, False, (1, 1, 1), cu(env), cu(occ[:, None].copy()), cu(F.normal), cu(F.depth[:, None]), cu(kd), cu(rm),
+                                     cu(F.ray_dir_raw), cu(F.pos), spp, 2, 2, 2.0, 0.1, 0.001, seed)
+        ref = oracle.render(F.fx, F.fy, spp, seed, (F.info, F.aabb), F.vert, F.tri, env, occ, F.normal, F.depth, kd, rm, F.ray_dir_raw, F.pos, mat=None)
+        return [o.cpu().numpy() for o in outs], ref
+
+    def worker(F):
+        W = RR.restirbvhWorker(torch.from_numpy(F.vert).cuda(), torch.from_numpy(F.tri).cuda()); W.update_mesh(W.vrt, W.v_ind)
+        return W
+    # (a) ragged tiny frame, 2 samples
+    F = SmallFrame(oracle, scene_mod, fx=7, fy=5, subdiv=2, ground=4, env_hw=(8, 16))
+    W = worker(F)
+    got, ref = both(F, W, F.env, F.occ, F.kd, F.rm, spp=2)
+    for g_, n_ in zip(got, names):
+        assert np.isfinite(g_).all() and (np.abs(g_ - ref[n_]).max(axis=1) <= 1e-3).mean() >= 0.9, n_
+    # (b) nothing but background
+    got, ref = both(F, W, F.env, np.zeros_like(F.occ), F.kd, F.rm)
+    assert all(np.isfinite(g_).all() for g_ in got) and (got[0] == 1.0).all() and (ref["final_color"] == 1.0).all() and all((g_ == 0).all() for g_ in got[1:])
+    # (c) black environment: zero radiance everywhere, no NaN from the empty importance table
+    F2 = SmallFrame(oracle, scene_mod, fx=24, fy=20, subdiv=2, ground=4, env_hw=(8, 16))
+    W2 = worker(F2)
+    got, ref = both(F2, W2, np.zeros_like(F2.env), F2.occ, F2.kd, F2.rm)
+    fg = F2.occ > 0.5
+    assert all(np.isfinite(g_).all() for g_ in got) and all((g_[fg] == 0).all() for g_ in got) and (ref["final_color"][fg] == 0).all() and (got[0][~fg] == 1).all()
+    # (d) material extremes
+    rm = F2.rm.copy(); rm[::2, 0] = 0.0; rm[1::2, 0] = 1.0; rm[::3, 1] = 1.0; rm[1::3, 1] = 0.0
+    kd = F2.kd.copy(); kd[::5] = 0.0; kd[1::5] = 1.0
+    got, ref = both(F2, W2, F2.env, F2.occ, kd, rm)
+    for g_, n_ in zip(got, names):
+        assert np.isfinite(g_).all() and (np.abs(g_ - ref[n_]).max(axis=1) <= 1e-3).mean() >= 0.97, n_
