@@ -8,12 +8,15 @@ class SmallFrame:
     """Mesh + G-buffer + env tables built with the oracle only (no GPU). fx x fy pixels, constant or textured materials."""
 
     def __init__(self, O, S, fx=48, fy=40, subdiv=3, ground=16, env_hw=(32, 64), seed=0, rough=0.45, metal=0.0, varied=True):
+        import os
+        sweep = int(os.environ.get("MIRRES_TEST_SEED", "0"))      # robustness sweeps: another view, other materials, same tests
+        seed += sweep
         self.O, self.fx, self.fy = O, fx, fy
         N = fx * fy
         self.N = N
         self.vert, self.tri = S.make_mesh(subdiv, ground)
         self.info, self.aabb, self.sorted, self.height = O.bvh_build(self.vert, self.tri)
-        eye, rd = S.camera_rays(fy, fx)
+        eye, rd = S.camera_rays(fy, fx, 30.0 + 47.0 * sweep, 30.0 - 7.0 * (sweep % 5)) if sweep else S.camera_rays(fy, fx)
         self.eye = eye
         self.ray_dir_raw = rd
         rays = O.make_rays(np.repeat(eye[None], N, 0), rd)
