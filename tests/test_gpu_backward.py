@@ -60,7 +60,8 @@ def test_final_shading_backward(env, oracle):
             with torch.no_grad():
                 return float(fwd(*a))
         num = _dd(f, args[i].double(), d.double(), 2e-3)
-        assert abs(ana - num) <= 0.03 * abs(num) + 1e-3 * abs(ana) + 1e-2, (nm, ana, num)
+        mag = float((x[i].grad.double() * d).abs().sum())      # the directional derivative is a sum of signed per-element terms: tolerance on their magnitude
+        assert abs(ana - num) <= 0.03 * abs(num) + 1e-3 * mag + 1e-2, (nm, ana, num, mag)
 
 
 def test_eval_final_backward_is_exact_for_linear_env(env, oracle):
