@@ -809,11 +809,11 @@ static int trace_grid(size_t capacity) {
 }
 
 int trace_any_queue(const mirres_bvh* bvh, const Ray* rays, const uint32_t* d_count, size_t capacity, int32_t* hit,
-                    unsigned long long* stats, hipStream_t s, int lane, int timed) {
+                    unsigned long long* stats, hipStream_t s, int lane, int timed, bool heads_clean) {
     g_timed_tag = timed;
     static const int set_of_lane[5] = {0, 7, 9, 11, 15};                    // launches that may overlap on different streams use different head sets
     uint32_t* const heads = bvh->work + set_of_lane[lane] * MR_WSET;
-    MR_HIP(hipMemsetAsync(heads, 0, MR_WSET * sizeof(uint32_t), s));
+    if (!heads_clean) MR_HIP(hipMemsetAsync(heads, 0, MR_WSET * sizeof(uint32_t), s));   // heads_clean: the previous consumer zeroed them (k_spatial_resolve in mirres_render's chain)
     launch_any4q<false>(bvh, persist_grid(capacity), rays, d_count, (uint32_t)capacity, heads, hit, stats, s);
     MR_LAUNCH_CHECK("trace_any_queue");
     return 0;

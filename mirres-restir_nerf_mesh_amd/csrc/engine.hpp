@@ -119,6 +119,7 @@ struct mirres_ctx {
     int y_off = 0, full_fy = 0;     // strip sharding (mirres_render): global row of local row 0 and the global height; full_fy == 0: the frame is the whole image
     const float* occ_own = nullptr; // strip sharding: occupancy with the halo rows zeroed (own-pixel tests of the spatial pass); NULL otherwise
     const float* grec = nullptr;    // set by mirres_render for the duration of a frame: packed 64-byte G records for the neighbour gathers of k_spatial_resolve
+    bool chain_reset = false, chain_clean = false;   // mirres_render's chain: k_spatial_resolve leaves the ray counter and the lane-0 work heads zeroed for the next sample
     hipStream_t aux_stream = nullptr, pt_stream = nullptr, pt_stream2 = nullptr, fin_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join_pt = nullptr, ev_join_pt2 = nullptr, ev_join_fin = nullptr;
     std::vector<hipEvent_t> ev_pt;   // k_pt_reduce hand-over between the two path-tracing streams
@@ -133,7 +134,7 @@ int check_hip(hipError_t e, const char* what);
 
 // queue tracing (bvh_trace.hip). count is read on the device; capacity bounds the grid-stride loop.
 int trace_any_queue(const mirres_bvh* bvh, const Ray* rays, const uint32_t* d_count, size_t capacity, int32_t* hit,
-                    unsigned long long* stats, hipStream_t s, int lane = 0, int timed = 0);
+                    unsigned long long* stats, hipStream_t s, int lane = 0, int timed = 0, bool heads_clean = false);
 int trace_any_front_queue(const mirres_bvh* bvh, const Ray* rays, const uint32_t* d_count, size_t capacity, int32_t* hit, hipStream_t s);
 int trace_closest_queue(const mirres_bvh* bvh, const Ray* rays, const uint32_t* d_count, size_t capacity, HitRec* out,
                         unsigned long long* stats, hipStream_t s, int lane = 0);

@@ -382,7 +382,14 @@ __global__ void __launch_bounds__(MR_GEN_BLOCK) k_spatial_gen(mirres_config_t C,
 template <int MR_MAX_NB>
 __global__ void __launch_bounds__(MR_BLOCK) k_spatial_resolve(mirres_config_t C, EnvD E, GBufD G, ResD R, ResD PR, const float* __restrict__ noff,
                                                               uint32_t frameIndex, int fx, int fy, int N, int y_off, const float* __restrict__ occ_own,
-                                                              const int32_t* __restrict__ slot, const uint32_t* __restrict__ mask_in, const int32_t* __restrict__ hit) {
+                                                              const int32_t* __restrict__ slot, const uint32_t* __restrict__ mask_in, const int32_t* __restrict__ hit,
+                                                              uint32_t* __restrict__ reset_counter, uint32_t* __restrict__ reset_heads) {
+    // mirres_render's chain: the shadow-ray launch of this pass has finished (stream order), so the ray counter and the traversal work heads it used
+    // are zeroed here for the next sample's pass instead of by two separate fill launches per sample
+    if (reset_heads && blockIdx.x == 0) {
+        for (int i = threadIdx.x; i < MR_WSET; i += MR_BLOCK) reset_heads[i] = 0u;
+        if (threadIdx.x == 0) *reset_counter = 0u;
+    }
     const int pi = tile_pixel(fx, fy, 16, N);
     if (pi >= N) return;
     const GPix gc = load_gpix(G, pi);
@@ -570,7 +577,7 @@ int trace_any_q(mirres_ctx* ctx, mirres_bvh* bvh, const Ray* rays, const uint32_
     hipEvent_t *e0 = nullptr, *e1 = nullptr;
     if (ctx->instrument & 2) { int rc = ev_pair(ctx->ev_any, ctx->ev_any_used, &e0, &e1); if (rc) return rc; MR_HIP(hipEventRecord(*e0, s)); }
     int rc = (ctx->instrument & 1) ? trace_any_queue_counted(bvh, rays, count, cap, hit, ctx->stats, s, (ctx->instrument & 4) != 0)
-                                   : trace_any_queue(bvh, rays, count, cap, hit, ctx->stats, s, lane, (ctx->instrument & 2) != 0);
+                                   : trace_any_queue(bvh, rays, count, cap, hit, ctx->stats, s, lane, (ctx->instrument & 2) != 0, lane == 0 && ctx->chain_reset && ctx->chain_clean);
     if (e1) MR_HIP(hipEventRecord(*e1, s));
     return rc;
 }
@@ -746,7 +753,9 @@ int mirres_restir_spatial(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_env
     if (!ctx || !bvh || !env || !g || !res || !prev_res) { set_error("mirres_restir_spatial: null"); return MIRRES_E_ARG; }
     hipStream_t s = (hipStream_t)stream; const int N = (int)ctx->N; const int grd = grid_for(N, MR_BLOCK);
     const float* noff = neighbor_offsets ? neighbor_offsets : ctx->noff;
-    MR_HIP(hipMemsetAsync(&ctx->counters[0], 0, sizeof(uint32_t), s));
+    const bool fold = ctx->chain_reset;                         // inside mirres_render's chain (its own stream, its own work heads)
+    if (!(fold && ctx->chain_clean)) MR_HIP(hipMemsetAsync(&ctx->counters[0], 0, sizeof(uint32_t), s));
+    uint32_t* const rc_ = fold ? &ctx->counters[0] : nullptr; uint32_t* const rh_ = fold ? bvh->work : nullptr;   // lane 0 = head set 0
     const bool nb5 = ctx->cfg.neighbor_count <= 5;
     if (nb5) k_spatial_gen<5><<<tile_grid(ctx->fx, ctx->fy, 32), MR_GEN_BLOCK, 0, s>>>(ctx->cfg, gbufd(g), resd(prev_res), noff, frameIndex, ctx->fx, ctx->fy, N, ctx->y_off, ctx->occ_own, ctx->any_rays, &ctx->counters[0],
                                                                                    ctx->slot_a, ctx->mask_a);
@@ -756,9 +765,10 @@ int mirres_restir_spatial(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_env
     GBufD gr = gbufd(g);
     if (ctx->grec) gr.rec = reinterpret_cast<const float4*>(ctx->grec);   // mirres_render: same values, one 64-byte record per neighbour instead of three arrays
     if (nb5) k_spatial_resolve<5><<<tile_grid(ctx->fx, ctx->fy, 16), MR_BLOCK, 0, s>>>(ctx->cfg, envh(env), gr, resd(res), resd(prev_res), noff, frameIndex, ctx->fx, ctx->fy, N, ctx->y_off, ctx->occ_own,
-                                                                                   ctx->slot_a, ctx->mask_a, ctx->any_hit);
+                                                                                   ctx->slot_a, ctx->mask_a, ctx->any_hit, rc_, rh_);
     else k_spatial_resolve<8><<<tile_grid(ctx->fx, ctx->fy, 16), MR_BLOCK, 0, s>>>(ctx->cfg, envh(env), gr, resd(res), resd(prev_res), noff, frameIndex, ctx->fx, ctx->fy, N, ctx->y_off, ctx->occ_own,
-                                                                               ctx->slot_a, ctx->mask_a, ctx->any_hit);
+                                                                               ctx->slot_a, ctx->mask_a, ctx->any_hit, rc_, rh_);
+    if (fold) ctx->chain_clean = true;
     MR_LAUNCH_CHECK("restir_spatial");
     return MIRRES_OK;
 }

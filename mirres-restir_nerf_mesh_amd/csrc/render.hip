@@ -335,7 +335,7 @@ int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args
     }
     mirres_gbuf_t G = {occ, a->pos, B.nd, B.brdf, B.ray_dir};          // own-pixel stages (initial, temporal)
     mirres_gbuf_t Gt = {a->occ, a->pos, B.nd, B.brdf, B.ray_dir};      // spatial reuse: neighbours in the halo rows are real pixels
-    struct GrecGuard { mirres_ctx* c; ~GrecGuard() { c->grec = nullptr; } } grec_guard{ctx};
+    struct GrecGuard { mirres_ctx* c; ~GrecGuard() { c->grec = nullptr; c->chain_reset = false; c->chain_clean = false; } } grec_guard{ctx};
     ctx->grec = B.grec;   // packed copy for the neighbour gathers of the spatial merge; cleared when this call returns (the launches captured the pointer)
     const uint32_t passes = 20;  // mTotalRISPasses (:242)
     const int max_bounce = ctx->cfg.max_bounce;
@@ -399,6 +399,7 @@ int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args
             PB.qv.lane = 3;
         }
     }
+    ctx->chain_reset = two_streams; ctx->chain_clean = false;   // with the other stages on their own streams and work heads, the chain's spatial passes clean up after themselves
     auto ev_bulk = [&](int b) { return ctx->ev_sync[3 * (b + 1)]; };       // bulk stream reached "I(b+1) done" in iteration b (b = -1: I(0))
     auto ev_chain = [&](int b) { return ctx->ev_sync[3 * (b + 1) + 1]; };  // chain C(b) done
     auto ev_fin = [&](int b) { return ctx->ev_sync[3 * (b + 1) + 2]; };    // F(b) done (only when the final stages have their own stream)
