@@ -323,8 +323,7 @@ int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args
     k_flip_env<<<grid_for((size_t)Wc * Hc, MR_BLOCK), MR_BLOCK, 0, s>>>(Wc, Hc, a->env_map, B.tex);
     rc = mirres_env_make_sampleable(B.tex, Wc, Hc, B.pdf, B.cdf, B.mpdf, B.mcdf, s); if (rc) return rc;
     // zero-initialised state of restir_di_with_pt (:252-302)
-    MR_HIP(hipMemsetAsync(B.r_ld[0], 0, sizeof(float) * (size_t)(B.vis - B.r_ld[0]), s));   // both reservoirs
-    MR_HIP(hipMemsetAsync(B.tot[0], 0, sizeof(float) * (size_t)(B.tex - B.tot[0]), s));      // totals .. new_rm
+    MR_HIP(hipMemsetAsync(B.tot[0], 0, sizeof(float) * (size_t)(B.c1 - B.tot[0]), s));       // the six running totals (the reservoirs and the path state live in the batch pool)
     mirres_env_t E = {B.tex, Wc, Hc, B.pdf, B.cdf, B.mpdf, B.mcdf};
     // strip sharding: `occ` (halo rows zeroed) selects the pixels this rank computes; the spatial pass tests neighbours against the true G-buffer
     const float* occ = a->occ;
