@@ -72,6 +72,35 @@ def build_gbuffer_stage1(worker, vertices, triangles, H, W, ssaa=1, azimuth_deg=
     return dict(fx=w, fy=h, occ=occ, pos=xyzs, normal=nrm * occ, depth=depth, kd=kd_map, rm=rm, ray_dir=rays_d, eye=eye, rast=rast)
 
 
+def render_stage1_outputs(worker, vertices, voffsets, triangles, mlp_mat, env_map, mods, H, W, spp, ssaa=1, azimuth_deg=30.0, elevation_deg=30.0,
+                          jitter_std=0.01, bg_color=1.0, gb_depth=None, de=2, c=2.0, n=0.1, p=0.001):
+    """`render_stage1` for `--stage 1 --use_brdf --use_restir` training (nerf/renderer.py:960-1302) as far as the material / light / geometry
+    branch goes: moved mesh -> BVH update -> G-buffer front half (build_gbuffer_stage1) -> jittered material taps (:1016-1022) ->
+    run_restir_di_with_pt (:1112-1123) -> clamp, tone curve, alpha (:1125-1129, 1162-1164, 1208).  Returns the entries of the reference's
+    `outputs` dict that losses.stage1_loss reads, except `image` (the NeRF colour branch belongs to stage 0) — and without dr.antialias, whose
+    silhouette gradients are not modelled.  `gb_depth` ([N, 2]: z, |dz|; :1070-1081) selects the --use_bi_de bilateral finish, None the a-trous one.  (normal_grad, which needs the perturbed-normal texture the --use_brdf path never enables, is zero)."""
+    from . import renderer_restir as RR
+    moved = vertices + voffsets
+    worker.update_mesh(moved.detach().contiguous(), triangles)
+    g = build_gbuffer_stage1(worker, moved, triangles, H, W, ssaa, azimuth_deg, elevation_deg, mlp_mat)
+    fx, fy = g["fx"], g["fy"]; N = fx * fy
+    dev = moved.device
+    xyzs = g["pos"]
+    tex_jitter = mlp_mat.sample(xyzs + torch.normal(mean=0.0, std=jitter_std, size=xyzs.shape, device=dev))
+    tex = mlp_mat.sample(xyzs)
+    kd_grad = torch.abs(tex_jitter[:, 0:3] - tex[:, 0:3])
+    ks_grad = torch.abs(tex_jitter[:, 3:6] - tex[:, 3:6]) * torch.tensor([0.0, 1.0, 1.0], device=dev)[None, :]       # the o-component is left out
+    z = lambda *s: torch.zeros(s, device=dev)
+    out = RR.run_restir_di_with_pt(False, 1.0, 1.0, 1.0, mlp_mat, gb_depth, worker, *mods[:8], *mods[8:17], env_map, g["occ"].clone(), g["normal"],
+                                   g["depth"], g["kd"], g["rm"], g["ray_dir"], xyzs.detach(), z(N, 1), z(N, 4), z(N, 3), z(N, 3), fx, fy, spp, de,
+                                   2 ** (de - 1), c, n, p)
+    alpha = g["occ"]
+    image_brdf = alpha * linear2srgb(torch.clamp(torch.nan_to_num(out[0], 0.0), 0.0, 1.0)) + (1 - alpha) * bg_color            # :1209, :1301
+    lit = lambda x: alpha * torch.clamp(x, 0.0, 1.0)                                                                # :1182-1186 without the antialias
+    return dict(image_brdf=image_brdf, diffuse_light=lit(out[1]), specular_light=lit(out[2]), img_brdf_indirect=lit(out[3].detach()),
+                kd_grad=kd_grad * alpha, ks_grad=ks_grad * alpha, normal_grad=torch.zeros((N, 1), device=dev), occ=alpha, fx=fx, fy=fy)   # :1350-1352
+
+
 def linear2srgb(x):
     return torch.where(x <= 0.0031308, 12.92 * x, 1.055 * torch.pow(x + 1e-6, 1.0 / 2.4) - 0.055)
 

@@ -40,6 +40,8 @@ class _bilateral_denoiser_func(torch.autograd.Function):
 
 def bilateral_denoiser(h, w, input, factor=1.0):
     """input f32[h*w, 8] = (colour, normal, z, |dz|) -> f32[h*w, 3]; differentiable w.r.t. the colour (ops.py:190-199)."""
+    if input.shape[-1] != 8:
+        raise ValueError("bilateral_denoiser: input must have 8 channels (colour 3, normal 3, z, |dz|), got %d" % input.shape[-1])
     input = input.reshape(h * w, input.shape[-1])
     sigma = max(factor * 2, 0.0001)
     col_w = _bilateral_denoiser_func.apply(input[:, 0:3], input[:, 3:6], input[:, 6:8], sigma, h, w)

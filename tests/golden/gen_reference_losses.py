@@ -1,0 +1,69 @@
+"""Fixture generator (runs in the build container only): executes the reference's OWN stage-1 loss functions on seeded inputs and stores inputs,
+values and input gradients in tests/golden/ref_losses.npz.
+
+Taken from /root/reference/nerf/utils.py by AST (the module itself does not import here: its unrelated dependencies are missing):
+  luma, value, _clip_0to1_warn_torch, linear2srgb_torch, linear_to_srgb (its @torch.jit.script decorator dropped), shading_loss,
+  material_smoothness_grad, material_extra_kd_smoothness_grad, laplacian_uniform, laplacian_cot, laplacian_smooth_loss.
+Nothing of the reference's text is stored: only the numbers it produced.
+"""
+import ast
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+
+
+def load_functions(path, names, ns):
+    tree = ast.parse(open(os.path.join(REF, path)).read())
+    for n in tree.body:
+        if isinstance(n, ast.FunctionDef) and n.name in names:
+            n.decorator_list = []
+            exec(compile(ast.Module(body=[n], type_ignores=[]), os.path.join(REF, path), "exec"), ns)
+    missing = [n for n in names if n not in ns]
+    assert not missing, missing
+    return ns
+
+
+def main():
+    import mirres_restir_nerf_mesh_amd as M
+    ns = {"torch": torch, "np": np, "nn": torch.nn}
+    load_functions("nerf/utils.py", ["luma", "value", "_clip_0to1_warn_torch", "linear2srgb_torch", "linear_to_srgb", "shading_loss",
+                                     "material_smoothness_grad", "material_extra_kd_smoothness_grad", "laplacian_uniform", "laplacian_cot",
+                                     "laplacian_smooth_loss"], ns)
+    g = torch.Generator().manual_seed(77)
+    out = {}
+    # shading_loss: lights spanning the tone curve's knee, the log clip at e - 1 and the eps clamps; a reference colour with negative entries
+    # (gt - indirect can be negative, utils.py:1050)
+    n = 4096
+    d = (torch.rand(n, 3, generator=g) ** 3 * 3.0); d[:64] = 0.0; d[64:128] *= 1e-4
+    s = (torch.rand(n, 3, generator=g) ** 2 * 1.5); s[:32] = 0.0
+    ref = torch.rand(n, 3, generator=g) * 2.2 - 0.2
+    d.requires_grad_(True); s.requires_grad_(True)
+    l = ns["shading_loss"](d, s, ref, 0.0015, 0.000025)
+    l.backward()
+    out.update(sh_d=d.detach().numpy(), sh_s=s.detach().numpy(), sh_ref=ref.numpy(), sh_loss=np.float64(l.item()), sh_gd=d.grad.numpy(), sh_gs=s.grad.numpy())
+    # smoothness terms
+    kdg = torch.rand(24, 20, 3, generator=g).requires_grad_(True); ksg = torch.rand(24, 20, 1, generator=g); nrg = torch.rand(24, 20, 1, generator=g)
+    ao = torch.rand(24, 20, 3, generator=g)
+    out.update(ms_kd=kdg.detach().numpy(), ms_ks=ksg.numpy(), ms_nrm=nrg.numpy(), ms_ao=ao.numpy(),
+               ms_loss=np.float64(ns["material_smoothness_grad"](kdg, ksg, nrg, lambda_kd=0.005, lambda_ks=0.0025, lambda_nrm=0.00025).item()),
+               ms_extra=np.float64(ns["material_extra_kd_smoothness_grad"](kdg, ao, 0.3).item()))
+    # uniform-Laplacian smoothness on the synthetic mesh with seeded offsets (closed part + the open floor: boundary vertices included)
+    v, t = M.scene.make_mesh(2, 4)
+    verts = torch.from_numpy(np.asarray(v, np.float32)); faces = torch.from_numpy(np.asarray(t, np.int32))
+    off = (torch.rand(verts.shape, generator=g) - 0.5) * 0.05
+    off.requires_grad_(True)
+    l = ns["laplacian_smooth_loss"](verts + off, faces)
+    l.backward()
+    out.update(lap_v=verts.numpy(), lap_t=faces.numpy(), lap_off=off.detach().numpy(), lap_loss=np.float64(l.item()), lap_goff=off.grad.numpy())
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "ref_losses.npz"), **out)
+    print({k: (v.shape if hasattr(v, "shape") and v.shape else float(v)) for k, v in out.items()})
+
+
+if __name__ == "__main__":
+    main()

@@ -190,3 +190,12 @@ def test_rgbe_roundtrip(tmp_path):
     m = img.max(axis=2, keepdims=True)
     assert np.all(np.abs(back - img) <= m / 128.0 + 1e-9)      # 8-bit mantissa shared by the texel
     assert np.all(back[0, 0] == 0)
+
+
+def test_bilateral_denoiser_rejects_a_wrong_channel_count():
+    """The --use_bi_de filter reads colour 3 + normal 3 + (z, |dz|) per pixel; a [N, 7] input (a plain depth column instead of the pair,
+    nerf/renderer.py:1080) would make the kernel read past the buffer, so the host wrapper refuses it before any launch."""
+    import torch
+    from mirres_restir_nerf_mesh_amd.renderutils.ops import bilateral_denoiser
+    with pytest.raises(ValueError, match="8 channels"):
+        bilateral_denoiser(4, 4, torch.zeros(16, 7), 2.0)

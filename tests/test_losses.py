@@ -1,0 +1,113 @@
+"""Stage-1 loss / optimiser glue against the reference's own functions (tests/golden/ref_losses.npz, produced by
+tests/golden/gen_reference_losses.py from nerf/utils.py), plus closed-form cases for the two pytorch3d-defined regularisers."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from mirres_restir_nerf_mesh_amd import losses
+
+G = os.path.join(os.path.dirname(__file__), "golden", "ref_losses.npz")
+
+
+@pytest.fixture(scope="module")
+def g():
+    return np.load(G)
+
+
+def test_shading_loss_value_and_gradients(g):
+    """nerf/utils.py:306-318 on 4096 pixels spanning both branches of both tone curves, the log clip and the eps clamps: value to 1e-6 relative,
+    input gradients to 1e-6 of their scale."""
+    d = torch.from_numpy(g["sh_d"]).requires_grad_(True); s = torch.from_numpy(g["sh_s"]).requires_grad_(True)
+    l = losses.shading_loss(d, s, torch.from_numpy(g["sh_ref"]), 0.0015, 0.000025)
+    l.backward()
+    assert abs(float(l.detach()) - float(g["sh_loss"])) <= 1e-6 * abs(float(g["sh_loss"]))
+    for mine, ref in ((d.grad.numpy(), g["sh_gd"]), (s.grad.numpy(), g["sh_gs"])):
+        np.testing.assert_allclose(mine, ref, rtol=2e-5, atol=1e-6 * float(np.abs(ref).max()))
+
+
+def test_material_smoothness_terms(g):
+    kd = torch.from_numpy(g["ms_kd"])
+    l = losses.material_smoothness_grad(kd, torch.from_numpy(g["ms_ks"]), torch.from_numpy(g["ms_nrm"]), lambda_kd=0.005, lambda_ks=0.0025, lambda_nrm=0.00025)
+    assert abs(float(l.detach()) - float(g["ms_loss"])) <= 1e-6 * abs(float(g["ms_loss"]))
+    e = losses.material_extra_kd_smoothness_grad(kd, torch.from_numpy(g["ms_ao"]), 0.3)
+    assert abs(float(e.detach()) - float(g["ms_extra"])) <= 1e-6 * abs(float(g["ms_extra"]))
+
+
+def test_uniform_laplacian_value_and_gradient(g):
+    """laplacian_smooth_loss (nerf/utils.py:231-274, sparse D - A) on the synthetic mesh (closed part + open floor) with seeded offsets."""
+    v = torch.from_numpy(g["lap_v"]); t = torch.from_numpy(g["lap_t"]); off = torch.from_numpy(g["lap_off"]).requires_grad_(True)
+    l = losses.laplacian_smooth_loss(v + off, t)
+    l.backward()
+    assert abs(float(l.detach()) - float(g["lap_loss"])) <= 2e-6 * abs(float(g["lap_loss"]))
+    np.testing.assert_allclose(off.grad.numpy(), g["lap_goff"], rtol=1e-4, atol=1e-6 * float(np.abs(g["lap_goff"]).max()))
+    with pytest.raises(NotImplementedError):
+        losses.laplacian_smooth_loss(v, t, cotan=True)
+
+
+def _cube():
+    v = torch.tensor([[x, y, z] for x in (0., 1.) for y in (0., 1.) for z in (0., 1.)])
+    quads = [(0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)]
+    f = torch.tensor([t for a, b, c, d in quads for t in ((a, b, c), (a, c, d))])
+    return v, f
+
+
+def test_pytorch3d_defined_regularisers_closed_form():
+    """mesh_edge_loss / mesh_normal_consistency follow pytorch3d's published definitions (pytorch3d is not in the reference tree: unpinned).
+    Unit square of two triangles: edges 1, 1, 1, 1, sqrt 2 -> mean squared length 6 / 5; coplanar faces -> consistency 0.  Unit cube of twelve
+    triangles: 18 edges (12 of length 1, 6 face diagonals) -> (12 + 12) / 18; 6 coplanar pairs + 12 right-angle pairs -> 12 / 18.  Regular
+    tetrahedron: outward normals meet at cos = -1/3 -> 4 / 3.  Orientation of the index order must not matter."""
+    sq_v = torch.tensor([[0., 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0]]); sq_f = torch.tensor([[0, 1, 2], [0, 2, 3]])
+    assert abs(float(losses.mesh_edge_loss(sq_v, sq_f)) - 1.2) < 1e-6
+    assert abs(float(losses.mesh_normal_consistency(sq_v, sq_f))) < 1e-6
+    assert abs(float(losses.mesh_normal_consistency(sq_v, torch.tensor([[0, 1, 2], [2, 0, 3]])))) < 1e-6
+    v, f = _cube()
+    assert abs(float(losses.mesh_edge_loss(v, f)) - 24.0 / 18.0) < 1e-6
+    assert abs(float(losses.mesh_normal_consistency(v, f)) - 12.0 / 18.0) < 1e-6
+    assert abs(float(losses.mesh_edge_loss(v, f, target_length=1.0)) - 6 * (2 ** 0.5 - 1) ** 2 / 18) < 1e-6
+    tv = torch.tensor([[1., 1, 1], [1, -1, -1], [-1, 1, -1], [-1, -1, 1]]); tf = torch.tensor([[0, 1, 2], [0, 3, 1], [0, 2, 3], [1, 3, 2]])
+    assert abs(float(losses.mesh_normal_consistency(tv, tf)) - 4.0 / 3.0) < 1e-6
+    assert float(losses.mesh_normal_consistency(sq_v, sq_f[:1])) == 0.0          # no shared edge: zero, still differentiable
+
+
+def test_stage1_loss_is_the_sum_of_its_terms_and_step_rescales():
+    """stage1_loss assembles train_step's terms with main.py's default weights; stage1_optimizer_step applies x 64 to the environment-map gradient
+    and / 8 to the hash-grid gradient before the material / light steps and clamps the light at 0.01 (nerf/utils.py:1565-1589) — seen through
+    plain SGD, where the parameter change is the (rescaled) gradient."""
+    torch.manual_seed(5)
+    n = 96
+    v, f = _cube()
+    voff = (torch.rand(8, 3) * 0.1).requires_grad_(True)
+    base = torch.full((4, 8, 3), 0.5).requires_grad_(True); grid = torch.rand(64, 2).requires_grad_(True)
+    gt = torch.rand(n, 3); gt_lin = gt ** 2.2
+    def outputs():
+        lit = base.mean() * (grid.mean() + 1.0)
+        return dict(image=torch.rand(n, 3, generator=torch.Generator().manual_seed(1)), image_brdf=(torch.rand(n, 3, generator=torch.Generator().manual_seed(2)) * lit).clamp(0, 1),
+                    diffuse_light=torch.rand(n, 3, generator=torch.Generator().manual_seed(3)) * lit, specular_light=torch.rand(n, 3, generator=torch.Generator().manual_seed(4)) * lit * 0.2,
+                    img_brdf_indirect=torch.full((n, 3), 0.05), kd_grad=torch.rand(n, 3, generator=torch.Generator().manual_seed(6)) * grid.mean(),
+                    ks_grad=torch.rand(n, 1, generator=torch.Generator().manual_seed(7)), normal_grad=torch.rand(n, 1, generator=torch.Generator().manual_seed(8)))
+    opt = types.SimpleNamespace(use_brdf=True)
+    o = outputs()
+    total = losses.stage1_loss(o, gt, gt_lin, opt, vertices=v, voffsets=voff, triangles=f)
+    parts = (((o["image"] - gt) ** 2).mean(-1) + 0.02 * (o["image_brdf"] - gt).abs().mean(-1)).mean() \
+        + losses.shading_loss(o["diffuse_light"], o["specular_light"], gt_lin - o["img_brdf_indirect"], 0.0015, 0.000025) \
+        + losses.material_smoothness_grad(o["kd_grad"], o["ks_grad"], o["normal_grad"], 0.005, 0.0025, 0.00025) \
+        + 0.001 * losses.laplacian_smooth_loss(v + voff, f) + 0.1 * losses.offsets_loss(voff)
+    assert abs(float(total.detach()) - float(parts.detach())) < 1e-7
+    # the outer mesh of --bound > 1 counts a tenth
+    assert abs(float(losses.offsets_loss(voff, 5).detach()) - float(((voff[:5] ** 2).sum(-1).mean() + 0.1 * (voff[5:] ** 2).sum(-1).mean()).detach())) < 1e-7
+    gb, gg, gv = torch.autograd.grad(total, (base, grid, voff))
+    o_geo = torch.optim.SGD([voff], lr=1.0); o_mat = torch.optim.SGD([grid], lr=1.0); o_light = torch.optim.SGD([base], lr=1.0)
+    b0, g0, v0 = base.detach().clone(), grid.detach().clone(), voff.detach().clone()
+    val = losses.stage1_optimizer_step(losses.stage1_loss(outputs(), gt, gt_lin, opt, vertices=v, voffsets=voff, triangles=f), o_geo, o_mat, o_light,
+                                       light_base=base, encoder_params=grid)
+    assert abs(val - float(total.detach())) < 1e-7
+    np.testing.assert_allclose((v0 - voff.detach()).numpy(), gv.numpy(), rtol=1e-5, atol=2e-8)      # v0 - (v0 - g) rounds at the scale of v0
+    np.testing.assert_allclose((g0 - grid.detach()).numpy(), gg.numpy() / 8.0, rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose((b0 - base.detach()).numpy(), gb.numpy() * 64.0, rtol=1e-5, atol=1e-7)
+    with torch.no_grad():
+        base.fill_(0.0)
+    losses.stage1_optimizer_step(losses.stage1_loss(outputs(), gt, gt_lin, opt), o_geo, o_mat, o_light, light_base=base, encoder_params=grid)
+    assert float(base.detach().min()) >= np.float32(0.01)
