@@ -1,0 +1,93 @@
+"""Reading the files a reference run leaves behind: stage-0 PLY meshes and stage-1 `.pth` checkpoints in the layout of
+Trainer.save_checkpoint (nerf/utils.py:1840-1920).  The checkpoint files here are written by hand in that layout (keys as the reference model's
+state dict names them); no reference run is available in this container to produce a real one."""
+import os
+import struct
+
+import numpy as np
+import pytest
+import torch
+
+from mirres_restir_nerf_mesh_amd import checkpoint as CK
+from mirres_restir_nerf_mesh_amd import scene
+
+
+def test_ply_round_trip_and_variants(tmp_path):
+    v, t = scene.make_mesh(2, 4)
+    for binary in (True, False):
+        p = str(tmp_path / ("m%d.ply" % binary))
+        CK.write_ply(p, v, t, binary=binary)
+        v2, t2 = CK.read_ply(p)
+        assert v2.dtype == np.float32 and t2.dtype == np.int32
+        assert np.array_equal(v2, v.astype(np.float32)) and np.array_equal(t2, t)
+    # big-endian file with extra vertex properties (normals, colour bytes), double coordinates, a quad and an unrelated element in between
+    vv = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0], [0.5, 0.5, 1]], np.float64)
+    head = ("ply\nformat binary_big_endian 1.0\ncomment made by hand\nelement vertex 5\nproperty double x\nproperty double y\nproperty double z\n"
+            "property float nx\nproperty uchar red\nelement misc 2\nproperty short a\nelement face 2\nproperty list uchar uint vertex_indices\nend_header\n")
+    body = b"".join(struct.pack(">dddfB", *r, 0.25, 7) for r in vv) + struct.pack(">hh", 1, 2) + struct.pack(">B4I", 4, 0, 1, 2, 3) + struct.pack(">B3I", 3, 0, 1, 4)
+    p = str(tmp_path / "be.ply")
+    open(p, "wb").write(head.encode() + body)
+    v3, t3 = CK.read_ply(p)
+    assert np.array_equal(v3, vv.astype(np.float32)) and t3.tolist() == [[0, 1, 2], [0, 2, 3], [0, 1, 4]]     # the quad is fan-split
+    open(str(tmp_path / "bad.ply"), "wb").write(b"solid not a ply\n")
+    with pytest.raises(ValueError):
+        CK.read_ply(str(tmp_path / "bad.ply"))
+    bad = head.replace("element face 2", "element face 1").encode() + b"".join(struct.pack(">dddfB", *r, 0.25, 7) for r in vv) + struct.pack(">hh", 1, 2) + struct.pack(">B3I", 3, 0, 1, 9)
+    open(str(tmp_path / "oob.ply"), "wb").write(bad)
+    with pytest.raises(ValueError, match="out of range"):
+        CK.read_ply(str(tmp_path / "oob.ply"))
+
+
+def test_stage0_mesh_cascades(tmp_path):
+    """nerf/renderer.py:146-171: the updated mesh wins when present, cascades are concatenated with shifted indices, --ckpt scratch ignores updates."""
+    d = tmp_path / "mesh_stage0"; d.mkdir()
+    v0, t0 = scene.make_mesh(1, 2); v1, t1 = scene.make_mesh(2, 2)
+    CK.write_ply(str(d / "mesh_0.ply"), v0, t0)
+    CK.write_ply(str(d / "mesh_0_updated.ply"), v0 * 1.5, t0)
+    CK.write_ply(str(d / "mesh_1.ply"), v1, t1)
+    v, t, vc, fc = CK.load_stage0_mesh(str(tmp_path), cascade=2)
+    assert vc.tolist() == [0, v0.shape[0], v0.shape[0] + v1.shape[0]] and fc.tolist() == [0, t0.shape[0], t0.shape[0] + t1.shape[0]]
+    assert np.array_equal(v[:vc[1]], (v0 * 1.5).astype(np.float32)) and np.array_equal(v[vc[1]:], v1.astype(np.float32))
+    assert np.array_equal(t[:fc[1]], t0) and np.array_equal(t[fc[1]:], t1 + v0.shape[0])
+    v_s, _, _, _ = CK.load_stage0_mesh(str(tmp_path), cascade=1, from_scratch=True)
+    assert np.array_equal(v_s, v0.astype(np.float32))
+
+
+def _reference_layout(n_vert=12, n_grid=64, half_light=False):
+    g = torch.Generator().manual_seed(3)
+    model = {"vertices_offsets": torch.rand(n_vert, 3, generator=g) * 0.01, "mlp_mat_opt.encoder.params": torch.rand(n_grid, generator=g),
+             "mlp_mat_opt.net.net.0.weight": torch.rand(32, 32, generator=g), "mlp_mat_opt.net.net.2.weight": torch.rand(32, 32, generator=g),
+             "mlp_mat_opt.net.net.4.weight": torch.rand(6, 32, generator=g),
+             # stage-0 entries of the same state dict that this path ignores
+             "aabb_train": torch.tensor([-1., -1, -1, 1, 1, 1]), "density_bitfield": torch.zeros(16, dtype=torch.uint8), "color_net.0.weight": torch.rand(8, 8, generator=g)}
+    light = torch.rand(8, 16, 3, generator=g) + 0.01
+    return {"epoch": 7, "global_step": 1234, "stats": {"results": []}, "stage": 1, "light_base": light.half() if half_light else light, "model": model}
+
+
+def test_read_checkpoint_in_the_reference_layout(tmp_path):
+    ck = _reference_layout(half_light=True)
+    p = str(tmp_path / "ngp_stage1_ep0007.pth")
+    torch.save(ck, p)
+    r = CK.read_checkpoint(p)
+    assert r["epoch"] == 7 and r["global_step"] == 1234 and r["stage"] == 1
+    assert torch.equal(r["vertices_offsets"], ck["model"]["vertices_offsets"]) and torch.equal(r["grid_params"], ck["model"]["mlp_mat_opt.encoder.params"])
+    assert all(torch.equal(a, ck["model"]["mlp_mat_opt.net.net.%d.weight" % i]) for a, i in zip(r["mlp_weights"], (0, 2, 4)))
+    assert r["light_base"].dtype == torch.float32 and torch.equal(r["light_base"], ck["light_base"].float())
+    voff, light = CK.apply_checkpoint(r, None, n_vertices=12, device="cpu")
+    assert torch.equal(voff, r["vertices_offsets"]) and torch.equal(light, r["light_base"])
+    with pytest.raises(ValueError, match="12 vertices"):
+        CK.apply_checkpoint(r, None, n_vertices=13, device="cpu")
+    # a bare state dict (load_checkpoint's first branch, :1942-1946): no light, no counters
+    p2 = str(tmp_path / "bare.pth"); torch.save(ck["model"], p2)
+    r2 = CK.read_checkpoint(p2)
+    assert r2["light_base"] is None and r2["epoch"] is None and torch.equal(r2["grid_params"], r["grid_params"])
+    # a material field with a layer missing is refused, a file without any material field reads as None
+    broken = dict(ck["model"]); del broken["mlp_mat_opt.net.net.2.weight"]
+    p3 = str(tmp_path / "broken.pth"); torch.save({"model": broken}, p3)
+    with pytest.raises(KeyError, match="net.2"):
+        CK.read_checkpoint(p3)
+    p4 = str(tmp_path / "stage0.pth"); torch.save({"model": {"aabb_train": torch.zeros(6)}, "epoch": 1}, p4)
+    r4 = CK.read_checkpoint(p4)
+    assert r4["grid_params"] is None and r4["mlp_weights"] is None and r4["vertices_offsets"] is None
+    with pytest.raises(KeyError):
+        CK.apply_checkpoint(r4, mlp_mat=object())

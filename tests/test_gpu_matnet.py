@@ -90,3 +90,29 @@ def test_material_field_matches_the_reference_classes(scene_mod):
     x = torch.from_numpy(g["mat_pts"]).cuda()
     np.testing.assert_allclose(mlp.sample_no_di(x).cpu().numpy(), g["mat_out"], rtol=0, atol=1e-5)
     np.testing.assert_allclose(mlp.sample(x).detach().cpu().numpy(), g["mat_out"], rtol=0, atol=1e-5)
+
+
+def test_checkpoint_round_trip_through_the_reference_layout(scene_mod, tmp_path):
+    """checkpoint.save_checkpoint writes Trainer.save_checkpoint's layout (nerf/utils.py:1843-1854); read_checkpoint + apply_checkpoint restore a
+    freshly constructed MLPTexture3D to bit-identical outputs, hand back offsets and light, and refuse a field of the wrong size."""
+    import torch
+    from mirres_restir_nerf_mesh_amd import checkpoint as CK
+    from mirres_restir_nerf_mesh_amd.render_helper import MLPTexture3D
+    mn, mx = scene_mod.material_min_max()
+    mk = lambda seed: MLPTexture3D(torch.tensor([-1, -1, -1, 1, 1, 1], dtype=torch.float32), channels=6,
+                                   min_max=(torch.from_numpy(mn).cuda(), torch.from_numpy(mx).cuda()), seed=seed)
+    torch.manual_seed(1); a = mk(5)
+    with torch.no_grad():
+        a.encoder.params.mul_(1e3)
+    voff = torch.rand(100, 3, device="cuda") * 0.01; light = torch.rand(16, 32, 3, device="cuda") + 0.01
+    p = str(tmp_path / "ngp_stage1.pth")
+    CK.save_checkpoint(p, a, voff, light, epoch=3, global_step=77)
+    torch.manual_seed(2); b = mk(9)
+    x = torch.rand(5000, 3, device="cuda") * 2 - 1
+    assert not torch.equal(a.sample(x), b.sample(x))
+    r = CK.read_checkpoint(p)
+    voff2, light2 = CK.apply_checkpoint(r, b, n_vertices=100)
+    assert torch.equal(a.sample(x), b.sample(x)) and torch.equal(voff2, voff) and torch.equal(light2, light) and r["global_step"] == 77
+    r["grid_params"] = r["grid_params"][:-2]
+    with pytest.raises(ValueError, match="encoder.params"):
+        CK.apply_checkpoint(r, b)
