@@ -13,6 +13,6 @@ __all__ = ["_lib", "scene"]
 def __getattr__(name):
     # torch-facing modules are imported lazily so that `import mirres_restir_nerf_mesh_amd` stays cheap
     import importlib
-    if name in ("renderer_restir", "Resampling", "Denoising", "GenerateLightTiles", "render_helper", "dist", "harness", "losses", "raster", "render_dump", "checkpoint"):
+    if name in ("renderer_restir", "Resampling", "Denoising", "GenerateLightTiles", "render_helper", "dist", "harness", "losses", "raster", "render_dump", "checkpoint", "meters"):
         return importlib.import_module("." + name, __name__)
     raise AttributeError(name)

@@ -3,7 +3,7 @@ values and input gradients in tests/golden/ref_losses.npz.
 
 Taken from /root/reference/nerf/utils.py by AST (the module itself does not import here: its unrelated dependencies are missing):
   luma, value, _clip_0to1_warn_torch, linear2srgb_torch, linear_to_srgb (its @torch.jit.script decorator dropped), shading_loss,
-  material_smoothness_grad, material_extra_kd_smoothness_grad, laplacian_uniform, laplacian_cot, laplacian_smooth_loss.
+  material_smoothness_grad, material_extra_kd_smoothness_grad, laplacian_uniform, laplacian_cot, laplacian_smooth_loss, and the class PSNRMeter.
 Nothing of the reference's text is stored: only the numbers it produced.
 """
 import ast
@@ -21,7 +21,7 @@ sys.path.insert(0, ROOT)
 def load_functions(path, names, ns):
     tree = ast.parse(open(os.path.join(REF, path)).read())
     for n in tree.body:
-        if isinstance(n, ast.FunctionDef) and n.name in names:
+        if isinstance(n, (ast.FunctionDef, ast.ClassDef)) and n.name in names:
             n.decorator_list = []
             exec(compile(ast.Module(body=[n], type_ignores=[]), os.path.join(REF, path), "exec"), ns)
     missing = [n for n in names if n not in ns]
@@ -31,10 +31,10 @@ def load_functions(path, names, ns):
 
 def main():
     import mirres_restir_nerf_mesh_amd as M
-    ns = {"torch": torch, "np": np, "nn": torch.nn}
+    ns = {"torch": torch, "np": np, "nn": torch.nn, "os": os}
     load_functions("nerf/utils.py", ["luma", "value", "_clip_0to1_warn_torch", "linear2srgb_torch", "linear_to_srgb", "shading_loss",
                                      "material_smoothness_grad", "material_extra_kd_smoothness_grad", "laplacian_uniform", "laplacian_cot",
-                                     "laplacian_smooth_loss"], ns)
+                                     "laplacian_smooth_loss", "PSNRMeter"], ns)
     g = torch.Generator().manual_seed(77)
     out = {}
     # shading_loss: lights spanning the tone curve's knee, the log clip at e - 1 and the eps clamps; a reference colour with negative entries
@@ -61,8 +61,13 @@ def main():
     l = ns["laplacian_smooth_loss"](verts + off, faces)
     l.backward()
     out.update(lap_v=verts.numpy(), lap_t=faces.numpy(), lap_off=off.detach().numpy(), lap_loss=np.float64(l.item()), lap_goff=off.grad.numpy())
+    # PSNRMeter over three frames
+    pp = torch.rand(3, 9, 11, 3, generator=g); tt = (pp + 0.05 * torch.randn(3, 9, 11, 3, generator=g)).clamp(0, 1)
+    m = ns["PSNRMeter"]()
+    each = [m.update(a, b) for a, b in zip(pp, tt)]
+    out.update(psnr_pred=pp.numpy(), psnr_truth=tt.numpy(), psnr_each=np.array(each, np.float64), psnr_mean=np.float64(m.measure()), psnr_report=np.array(m.report()))
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "ref_losses.npz"), **out)
-    print({k: (v.shape if hasattr(v, "shape") and v.shape else float(v)) for k, v in out.items()})
+    print({k: (v.shape if hasattr(v, "shape") and v.shape else v) for k, v in out.items()})
 
 
 if __name__ == "__main__":
