@@ -72,6 +72,71 @@ def build_gbuffer_stage1(worker, vertices, triangles, H, W, ssaa=1, azimuth_deg=
     return dict(fx=w, fy=h, occ=occ, pos=xyzs, normal=nrm * occ, depth=depth, kd=kd_map, rm=rm, ray_dir=rays_d, eye=eye, rast=rast)
 
 
+def get_rays(pose, intrinsics, H, W):
+    """Full-frame camera rays of nerf/utils.py:350-423 (N = -1): pixel centres (i + 0.5, j + 0.5), camera looks down -z with y flipped, directions
+    NOT normalised (their z component is -1 in camera space), origin = the pose's translation.  `pose` [4, 4] cam2world, `intrinsics` (fx, fy, cx, cy).
+    Returns (rays_o [H*W, 3], rays_d [H*W, 3]) in row-major pixel order."""
+    fx, fy, cx, cy = (float(v) for v in intrinsics)
+    dev = pose.device
+    j, i = torch.meshgrid(torch.arange(H, dtype=torch.float32, device=dev) + 0.5, torch.arange(W, dtype=torch.float32, device=dev) + 0.5, indexing="ij")
+    cam = torch.stack(((i - cx) / fx, -(j - cy) / fy, -torch.ones_like(i)), dim=-1).view(-1, 3)
+    rays_d = cam @ pose[:3, :3].to(torch.float32).t()
+    rays_o = pose[:3, 3].to(torch.float32)[None].expand_as(rays_d)
+    return rays_o.contiguous(), rays_d.contiguous()
+
+
+def view_dirs(rays_d, H, W, ssaa=1):
+    """The per-pixel view directions render_stage1 shades with (nerf/renderer.py:935-946): with --ssaa > 1 the H x W directions are magnified
+    with nearest-neighbour lookup (every ssaa x ssaa block shares its output pixel's direction), then safe_normalize."""
+    d = rays_d.view(H, W, 3)
+    if ssaa > 1:
+        d = d.repeat_interleave(ssaa, dim=0).repeat_interleave(ssaa, dim=1)
+    d = d.reshape(-1, 3)
+    return (d / torch.sqrt(torch.clamp(torch.sum(d * d, -1, keepdim=True), min=1e-20))).contiguous()
+
+
+def build_gbuffer_from_pose(worker, pose, intrinsics, H, W, ssaa=1, mlp_mat=None, kd=(0.6, 0.6, 0.6), roughness=0.5, metallic=0.0):
+    """build_gbuffer for a dataset camera: primary visibility by casting the pixel-centre rays of the internal (ssaa-scaled) frame through the
+    BVH (intrinsics scaled by ssaa, which is where nvdiffrast's raster samples sit), shading directions as the reference forms them (view_dirs)."""
+    h, w = H * ssaa, W * ssaa
+    dev = worker.vrt.device
+    pose = pose.to(dev)
+    fx, fy, cx, cy = (float(v) for v in intrinsics)
+    rays_o, rays_hi = get_rays(pose, (fx * ssaa, fy * ssaa, cx * ssaa, cy * ssaa), h, w)
+    rays_hi = rays_hi / torch.norm(rays_hi, dim=1, keepdim=True)
+    r = worker.trace(rays_o, rays_hi.contiguous(), closest=True)
+    occ = r["hit"].to(torch.float32)[:, None].contiguous()
+    pos = r["pos"].contiguous()
+    normal = torch.where(occ > 0.5, r["normal"], torch.zeros_like(r["normal"])).contiguous()
+    depth = torch.norm(pos - rays_o, dim=1, keepdim=True).contiguous()
+    N = h * w
+    if mlp_mat is not None:
+        kdks = mlp_mat.sample_no_di(pos)
+        kd_map = kdks[:, 0:3].contiguous(); rm = torch.cat((kdks[:, 4:5], kdks[:, 5:6]), dim=-1).contiguous()
+    else:
+        kd_map = torch.tensor(kd, dtype=torch.float32, device=dev)[None].expand(N, 3).contiguous()
+        rm = torch.tensor([roughness, metallic], dtype=torch.float32, device=dev)[None].expand(N, 2).contiguous()
+    dirs = view_dirs(get_rays(pose, (fx, fy, cx, cy), H, W)[1], H, W, ssaa)
+    return dict(fx=w, fy=h, occ=occ, pos=pos, normal=normal, depth=depth, kd=kd_map, rm=rm, ray_dir=dirs, eye=pose[:3, 3].detach().cpu().numpy())
+
+
+def test_view(worker, mlp_mat, env_map, pose, intrinsics, H, W, spp, ssaa=1, random_offset=0, de=2, c=2.0, n=0.1, p=0.001, max_bounce=None):
+    """One `--test --spp N` frame of the BRDF branch (Trainer.test_step -> render_stage1(is_test=True), nerf/renderer.py:1083-1129, 1162-1164,
+    1208-1209, 1265-1302): G-buffer for the dataset camera, the fused frame (mirres_render), tone curve, alpha, SSAA down-scale, white background.
+    Returns the [H, W, 3] image in [0, 1]."""
+    from . import renderer_restir as RR
+    from ._ops import get_ctx
+    g = build_gbuffer_from_pose(worker, pose, intrinsics, H, W, ssaa, mlp_mat)
+    ctx = get_ctx(g["fx"], g["fy"]) if max_bounce is None else get_ctx(g["fx"], g["fy"], max_bounce=max_bounce)
+    occ = g["occ"].clone()
+    out = RR.render_fused(ctx, worker, mlp_mat, False, (1, 1, 1), env_map, occ, g["normal"], g["depth"], g["kd"], g["rm"], g["ray_dir"], g["pos"],
+                          spp, de, 2 ** (de - 1), c, n, p, random_offset)[0]
+    return postprocess(torch.nan_to_num(out[0], 0.0), g["occ"], H, W, ssaa)
+
+
+test_view.__test__ = False      # not a pytest case
+
+
 def render_stage1_outputs(worker, vertices, voffsets, triangles, mlp_mat, env_map, mods, H, W, spp, ssaa=1, azimuth_deg=30.0, elevation_deg=30.0,
                           jitter_std=0.01, bg_color=1.0, gb_depth=None, de=2, c=2.0, n=0.1, p=0.001):
     """`render_stage1` for `--stage 1 --use_brdf --use_restir` training (nerf/renderer.py:960-1302) as far as the material / light / geometry

@@ -1,0 +1,103 @@
+"""`--test --spp N` evaluation of a reference workspace on the HIP path: stage-0 mesh (+ stage-1 vertex offsets), material field and
+environment map from a reference checkpoint, dataset cameras from a NeRF-blender `transforms_*.json`, one fused frame per view, PNG results and
+PSNR / SSIM against the dataset images when they can be read.
+
+    python scripts/evaluate.py --workspace <ws> --ckpt <ws>/checkpoints/ngp_stage1_ep0100.pth --transforms <data>/transforms_test.json \
+        [--spp 512 --ssaa 2 --downscale 1 --cascade 1 --out <ws>/results_brdf --limit 0 --synthetic]
+
+`--synthetic` builds a throw-away workspace (synthetic mesh, random material field, sky map, four orbit cameras) first and evaluates that — the
+smoke run of this script on a box without a reference workspace.  Camera convention: the blender `transform_matrix` is the cam2world pose with its
+translation scaled by `--scale` and shifted by `--offset` (nerf_matrix_to_ngp, nerf/provider.py:18-21; pass the values the reference run used)."""
+import argparse, json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import numpy as np, torch
+import mirres_restir_nerf_mesh_amd as M
+from mirres_restir_nerf_mesh_amd import renderer_restir as RR, harness, checkpoint as CK, meters
+from mirres_restir_nerf_mesh_amd.render_helper import MLPTexture3D
+
+
+def nerf_pose(pose, scale=1.0, offset=(0.0, 0.0, 0.0)):
+    """nerf_matrix_to_ngp of this reference (nerf/provider.py:18-21): the rotation is kept, the translation is scaled and shifted."""
+    p = np.array(pose, np.float32)
+    p[:3, 3] = p[:3, 3] * scale + np.asarray(offset, np.float32)
+    return p
+
+
+def synthetic_workspace(root, H=100, W=100):
+    os.makedirs(os.path.join(root, "mesh_stage0"), exist_ok=True); os.makedirs(os.path.join(root, "checkpoints"), exist_ok=True)
+    v, t = M.scene.make_mesh(5, 16)
+    CK.write_ply(os.path.join(root, "mesh_stage0", "mesh_0.ply"), v, t)
+    mn, mx = M.scene.material_min_max()
+    torch.manual_seed(0)
+    mlp = MLPTexture3D(torch.tensor([-1, -1, -1, 1, 1, 1], dtype=torch.float32), channels=6, min_max=(torch.from_numpy(mn).cuda(), torch.from_numpy(mx).cuda()), seed=1)
+    with torch.no_grad():
+        mlp.encoder.params.mul_(2e3)
+    ck = os.path.join(root, "checkpoints", "ngp_stage1_ep0001.pth")
+    CK.save_checkpoint(ck, mlp, torch.zeros(v.shape[0], 3), torch.from_numpy(M.scene.make_env(64, 128)), epoch=1)
+    frames = []
+    for k in range(4):
+        az, el = np.deg2rad(30.0 + 90.0 * k), np.deg2rad(30.0)
+        eye = 3.2 * np.array([np.cos(el) * np.cos(az), np.cos(el) * np.sin(az), np.sin(el)])
+        fwd = -eye / np.linalg.norm(eye); right = np.cross(fwd, [0.0, 0.0, 1.0]); right /= np.linalg.norm(right); up = np.cross(right, fwd)
+        pose = np.eye(4); pose[:3, :3] = np.stack([right, up, -fwd], 1); pose[:3, 3] = eye
+        frames.append({"file_path": "./test/r_%d" % k, "transform_matrix": pose.tolist()})
+    tf = os.path.join(root, "transforms_test.json")
+    json.dump({"camera_angle_x": 0.6911, "w": W, "h": H, "frames": frames}, open(tf, "w"))
+    return ck, tf
+
+
+def main():
+    p = argparse.ArgumentParser()
+    p.add_argument("--workspace"); p.add_argument("--ckpt"); p.add_argument("--transforms"); p.add_argument("--out")
+    p.add_argument("--spp", type=int, default=512); p.add_argument("--ssaa", type=int, default=2); p.add_argument("--downscale", type=int, default=1)
+    p.add_argument("--cascade", type=int, default=1); p.add_argument("--limit", type=int, default=0); p.add_argument("--H", type=int, default=800); p.add_argument("--W", type=int, default=800)
+    p.add_argument("--scale", type=float, default=1.0); p.add_argument("--offset", type=float, nargs=3, default=[0.0, 0.0, 0.0]); p.add_argument("--synthetic", action="store_true")
+    a = p.parse_args()
+    if a.synthetic:
+        a.workspace = a.workspace or os.path.join(ROOT, "gpurun_out", "eval_ws")
+        a.ckpt, a.transforms = synthetic_workspace(a.workspace, a.H // a.downscale, a.W // a.downscale)
+    if not (a.workspace and a.ckpt and a.transforms):
+        p.error("--workspace, --ckpt and --transforms are required (or --synthetic)")
+    out_dir = a.out or os.path.join(a.workspace, "results_brdf")
+    v, t, v_cumsum, _ = CK.load_stage0_mesh(a.workspace, a.cascade)
+    ck = CK.read_checkpoint(a.ckpt)
+    mn, mx = M.scene.material_min_max()          # --kd_min/--kd_max/--ks_min/--ks_max defaults of main.py
+    mlp = MLPTexture3D(torch.tensor([-1, -1, -1, 1, 1, 1], dtype=torch.float32), channels=6, min_max=(torch.from_numpy(mn).cuda(), torch.from_numpy(mx).cuda()))
+    voff, light = CK.apply_checkpoint(ck, mlp, n_vertices=v.shape[0])
+    if light is None:
+        raise SystemExit("%s has no light_base (a --use_brdf stage-1 checkpoint is needed)" % a.ckpt)
+    verts = torch.from_numpy(v).cuda() + (voff if voff is not None else 0)
+    W = RR.restirbvhWorker(verts.contiguous(), torch.from_numpy(t).cuda()); W.update_mesh(W.vrt, W.v_ind)
+    tf = json.load(open(a.transforms)); base = os.path.dirname(os.path.abspath(a.transforms))
+    Hh, Ww = int(tf.get("h", a.H)) // a.downscale, int(tf.get("w", a.W)) // a.downscale
+    focal = 0.5 * Ww / np.tan(0.5 * tf["camera_angle_x"])
+    intr = (focal, focal, Ww * 0.5, Hh * 0.5)
+    frames = tf["frames"][: a.limit] if a.limit > 0 else tf["frames"]
+    pm, sm = meters.PSNRMeter(), meters.SSIMMeter()
+    name = os.path.splitext(os.path.basename(a.ckpt))[0]
+    t_render = 0.0
+    for i, fr in enumerate(frames):
+        pose = nerf_pose(fr["transform_matrix"], a.scale, a.offset)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        img = harness.test_view(W, mlp, light, torch.from_numpy(pose), intr, Hh, Ww, a.spp, a.ssaa, random_offset=i * 7919)
+        torch.cuda.synchronize(); t_render += time.perf_counter() - t0
+        files = meters.write_test_frame(out_dir, name, i, img)
+        gt_path = os.path.join(base, fr["file_path"] + ".png")
+        note = ""
+        if os.path.exists(gt_path):
+            from PIL import Image
+            gt = np.asarray(Image.open(gt_path).resize((Ww, Hh), Image.BILINEAR)).astype(np.float32) / 255.0
+            if gt.shape[-1] == 4:
+                gt = gt[..., :3] * gt[..., 3:] + (1 - gt[..., 3:])                      # white background, as the reference's loader composes it
+            gt_t = torch.from_numpy(gt).cuda()
+            note = "  PSNR %.3f  SSIM %.4f" % (pm.update(img, gt_t), sm.update(img, gt_t))
+        print("[%d/%d] %s%s" % (i + 1, len(frames), os.path.basename(files[0]), note), flush=True)
+    n = len(frames)
+    print("rendered %d views %dx%d ssaa %d spp %d: %.1f ms/view (%.1f Msamples/s)" % (n, Ww, Hh, a.ssaa, a.spp, 1e3 * t_render / max(n, 1),
+                                                                                     n * Ww * Hh * a.ssaa ** 2 * a.spp / max(t_render, 1e-9) / 1e6))
+    if pm.N:
+        print(pm.report(), sm.report())
+
+
+if __name__ == "__main__":
+    main()

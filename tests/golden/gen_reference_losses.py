@@ -3,7 +3,8 @@ values and input gradients in tests/golden/ref_losses.npz.
 
 Taken from /root/reference/nerf/utils.py by AST (the module itself does not import here: its unrelated dependencies are missing):
   luma, value, _clip_0to1_warn_torch, linear2srgb_torch, linear_to_srgb (its @torch.jit.script decorator dropped), shading_loss,
-  material_smoothness_grad, material_extra_kd_smoothness_grad, laplacian_uniform, laplacian_cot, laplacian_smooth_loss, and the class PSNRMeter.
+  material_smoothness_grad, material_extra_kd_smoothness_grad, laplacian_uniform, laplacian_cot, laplacian_smooth_loss, the class PSNRMeter,
+  custom_meshgrid, safe_normalize, get_rays; from nerf/renderer.py: scale_img_nhwc, scale_img_hwc.
 Nothing of the reference's text is stored: only the numbers it produced.
 """
 import ast
@@ -66,6 +67,20 @@ def main():
     m = ns["PSNRMeter"]()
     each = [m.update(a, b) for a, b in zip(pp, tt)]
     out.update(psnr_pred=pp.numpy(), psnr_truth=tt.numpy(), psnr_each=np.array(each, np.float64), psnr_mean=np.float64(m.measure()), psnr_report=np.array(m.report()))
+    # get_rays (nerf/utils.py:350-423, full frame) for a seeded pose, and the shading directions of render_stage1 under --ssaa 2
+    # (nerf/renderer.py:935-946: scale_img_hwc(mag='nearest') + safe_normalize)
+    from packaging import version as pver
+    ns["pver"] = pver
+    load_functions("nerf/utils.py", ["custom_meshgrid", "safe_normalize", "get_rays"], ns)
+    rns = {"torch": torch}
+    load_functions("nerf/renderer.py", ["scale_img_nhwc", "scale_img_hwc"], rns)
+    q, _ = torch.linalg.qr(torch.randn(3, 3, generator=g))
+    pose = torch.eye(4); pose[:3, :3] = q; pose[:3, 3] = torch.tensor([0.3, -1.2, 2.5])
+    Hh, Ww = 7, 9
+    intr = np.array([11.5, 12.25, 4.4, 3.6], np.float32)
+    r = ns["get_rays"](pose[None], intr, Hh, Ww, -1)
+    dirs = ns["safe_normalize"](rns["scale_img_hwc"](r["rays_d"].view(Hh, Ww, 3), (Hh * 2, Ww * 2), mag="nearest").view(-1, 3).contiguous())
+    out.update(rays_pose=pose.numpy(), rays_intr=intr, rays_hw=np.array([Hh, Ww], np.int32), rays_o=r["rays_o"].numpy(), rays_d=r["rays_d"].numpy(), rays_dirs_ssaa2=dirs.numpy())
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "ref_losses.npz"), **out)
     print({k: (v.shape if hasattr(v, "shape") and v.shape else v) for k, v in out.items()})
 

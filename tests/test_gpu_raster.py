@@ -100,3 +100,38 @@ def test_texture_taps_against_grid_sample():
     gw = torch.randn_like(out)
     (out * gw).sum().backward(); (ref * gw).sum().backward()
     assert torch.allclose(tex.grad, tex2.grad, rtol=1e-4, atol=1e-4)
+
+
+def test_pose_camera_gbuffer_and_test_view(scene_mod):
+    """harness.build_gbuffer_from_pose (dataset camera: cam2world pose + (fx, fy, cx, cy), rays as nerf/utils.py:get_rays forms them) sees what
+    build_gbuffer sees for the same camera, hands the path unit shading directions, and harness.test_view (the `--test --spp N` frame of the BRDF
+    branch: G-buffer -> mirres_render -> tone curve, alpha, SSAA, white background) returns a finite [H, W, 3] image in [0, 1] whose background is
+    exactly white and whose ssaa 2 rendering agrees with the ssaa 1 one up to sampling noise and edge coverage."""
+    import torch
+    from mirres_restir_nerf_mesh_amd import renderer_restir as RR, harness
+    v, t = scene_mod.make_mesh(4, 8)
+    W = RR.restirbvhWorker(torch.from_numpy(v).cuda(), torch.from_numpy(t).cuda()); W.update_mesh(W.vrt, W.v_ind)
+    H, Wd = 40, 48
+    az = el = np.deg2rad(30.0)
+    eye = 3.2 * np.array([np.cos(el) * np.cos(az), np.cos(el) * np.sin(az), np.sin(el)])
+    fwd = -eye / np.linalg.norm(eye); right = np.cross(fwd, [0.0, 0.0, 1.0]); right /= np.linalg.norm(right); cup = np.cross(right, fwd)
+    pose = np.eye(4); pose[:3, :3] = np.stack([right, cup, -fwd], axis=1); pose[:3, 3] = eye
+    focal = 0.5 * Wd / np.tan(0.5 * 0.6911)
+    intr = (focal, focal, Wd * 0.5, H * 0.5)
+    pose_t = torch.from_numpy(pose.astype(np.float32))
+    g0 = harness.build_gbuffer(W, H, Wd)
+    g1 = harness.build_gbuffer_from_pose(W, pose_t, intr, H, Wd)
+    both = (g0["occ"][:, 0] > 0.5) & (g1["occ"][:, 0] > 0.5)
+    assert int(((g0["occ"] > 0.5) != (g1["occ"] > 0.5)).sum()) <= 2 and int(both.sum()) > 200
+    assert float((g0["pos"][both] - g1["pos"][both]).abs().max()) < 1e-4
+    d0 = g0["ray_dir"] / g0["ray_dir"].norm(dim=1, keepdim=True)
+    assert float((d0 - g1["ray_dir"]).abs().max()) < 1e-5 and torch.allclose(g1["ray_dir"].norm(dim=1), torch.ones(H * Wd, device="cuda"), atol=1e-5)
+    env = torch.from_numpy(scene_mod.make_env(32, 64)).cuda()
+    img2 = harness.test_view(W, None, env, pose_t, intr, H, Wd, spp=8, ssaa=2, random_offset=5)
+    img1 = harness.test_view(W, None, env, pose_t, intr, H, Wd, spp=8, ssaa=1, random_offset=5)
+    for img in (img1, img2):
+        assert tuple(img.shape) == (H, Wd, 3) and torch.isfinite(img).all() and float(img.min()) >= 0.0 and float(img.max()) <= 1.0 + 1e-6      # linear2srgb_torch(1) = 1.055 (1 + 1e-6)^(1/2.4) - 0.055, a hair above 1
+        assert torch.equal(img[0, 0], torch.ones(3, device="cuda")) and torch.equal(img[-1, -1], torch.ones(3, device="cuda"))
+    bg = (g1["occ"].view(H, Wd) < 0.5)
+    assert torch.equal(img1[bg], torch.ones_like(img1[bg]))
+    assert harness.psnr(img2, img1) > 18.0

@@ -199,3 +199,18 @@ def test_bilateral_denoiser_rejects_a_wrong_channel_count():
     from mirres_restir_nerf_mesh_amd.renderutils.ops import bilateral_denoiser
     with pytest.raises(ValueError, match="8 channels"):
         bilateral_denoiser(4, 4, torch.zeros(16, 7), 2.0)
+
+
+def test_camera_rays_and_shading_directions_against_the_reference():
+    """harness.get_rays / view_dirs against nerf/utils.py:get_rays and render_stage1's `dirs` (scale_img_hwc(mag='nearest') + safe_normalize,
+    nerf/renderer.py:935-946) run on the same pose (fixture ref_losses.npz)."""
+    import torch
+    from mirres_restir_nerf_mesh_amd import harness
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_losses.npz"))
+    H, W = (int(v) for v in g["rays_hw"])
+    ro, rd = harness.get_rays(torch.from_numpy(g["rays_pose"]), g["rays_intr"], H, W)
+    np.testing.assert_allclose(ro.numpy(), g["rays_o"], rtol=0, atol=0)
+    np.testing.assert_allclose(rd.numpy(), g["rays_d"], rtol=1e-6, atol=1e-7)
+    d2 = harness.view_dirs(rd, H, W, 2)
+    np.testing.assert_allclose(d2.numpy(), g["rays_dirs_ssaa2"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(harness.view_dirs(rd, H, W, 1).norm(dim=1).numpy(), 1.0, rtol=1e-6)
