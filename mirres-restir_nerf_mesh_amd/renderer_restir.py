@@ -285,8 +285,16 @@ def render_fused(ctx, bvh_restir_worker, mlp_mat, use_scale, scale, env_map, occ
     a.env_map, a.Hc, a.Wc = env.data_ptr(), env.shape[0], env.shape[1]
     if not occ_map.is_contiguous():
         raise _lib.MirresError("occ_map is modified in place and must be contiguous")
+    if env.dim() != 3 or env.shape[2] != 3:
+        raise _lib.MirresError("env_map must be [Hc, Wc, 3], got %s" % (tuple(env.shape),))
+    if occ_map.dtype != torch.float32 or occ_map.numel() != N:
+        raise _lib.MirresError("occ_map must be float32 with %d elements (framedim_x * framedim_y), got %s %s" % (N, occ_map.dtype, tuple(occ_map.shape)))
     a.occ = occ_map.data_ptr(); keep.append(occ_map)     # thresholded in place; mirres_render_bwd / mirres_render_finish read it again
-    for name, t in (("normal", normal_map), ("depth", depth_map), ("kd", diffuse_map), ("rough_metal", roughness_specular), ("ray_dir", ray_dir_map), ("pos", pos_map)):
+    # the kernels index these as [N, width] rows: a tensor of another size would be read out of bounds, so it is refused here
+    for name, t, width in (("normal", normal_map, 3), ("depth", depth_map, 1), ("kd", diffuse_map, 3), ("rough_metal", roughness_specular, 2), ("ray_dir", ray_dir_map, 3),
+                           ("pos", pos_map, 3)):
+        if t.numel() != N * width:
+            raise _lib.MirresError("%s must have %d x %d elements, got %s" % (name, N, width, tuple(t.shape)))
         t = _f32(t.detach()); keep.append(t); setattr(a, name, t.data_ptr())
     if mlp_mat is not None:
         st = mlp_mat._struct(); keep.append(st)

@@ -463,3 +463,21 @@ def test_stage1_loop_with_reference_losses(scene_mod):
     for name, a, b in zip(("voff", "grid", "w0", "env"), p0, (voff, mlp.encoder.params, mlp.net.net[0].weight, env)):
         assert float((a - b.detach()).abs().max()) > 0, name
     assert vals[2] < vals[0], vals
+
+
+def test_frame_refuses_wrongly_sized_inputs(oracle, scene_mod):
+    """The per-pixel inputs are indexed as [N, width] rows by the kernels; the host mirror refuses any other size instead of launching."""
+    F, W, mods, RR, torch = _setup(oracle, scene_mod)
+    from mirres_restir_nerf_mesh_amd._ops import get_ctx
+    from mirres_restir_nerf_mesh_amd._lib import MirresError
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    good = dict(env=cu(F.env), occ=cu(F.occ[:, None].copy()), normal=cu(F.normal), depth=cu(F.depth[:, None]), kd=cu(F.kd), rm=cu(F.rm), rd=cu(F.ray_dir_raw), pos=cu(F.pos))
+    def call(**over):
+        a = dict(good); a.update(over)
+        return RR.render_fused(get_ctx(F.fx, F.fy), W, None, False, (1, 1, 1), a["env"], a["occ"].clone(), a["normal"], a["depth"], a["kd"], a["rm"], a["rd"], a["pos"],
+                               1, 2, 2, 2.0, 0.1, 0.001, 1)
+    call()
+    for key, bad in (("normal", good["normal"][:-1]), ("depth", torch.cat((good["depth"], good["depth"]), 1)), ("rm", good["rm"][:, :1]), ("pos", good["pos"][:10]),
+                     ("occ", good["occ"][:-3]), ("env", good["env"].reshape(-1, 3))):
+        with pytest.raises(MirresError):
+            call(**{key: bad.contiguous()})
