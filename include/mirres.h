@@ -136,6 +136,10 @@ int mirres_pt_bounce(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_env_t* e
 /* EAWDenoise_run.forward / EAWDenoise_run_no_di (Denoising.py:10-60; EAWDenoise.slang:50-302)                 */
 int mirres_eaw(int fx, int fy, int step_width, float c_phi, float n_phi, float p_phi, const float* occ, const float* color,
                const float* normal, const float* pos, float* out, void* stream);
+/* process_normal_ao (EAWDenoise.slang:591-651, launched at nerf/renderer.py:1153-1158 when --lambda_extra_kd > 0): per foreground pixel the weight
+ * clamp(50 (1 - mean over the 8 x 8 window's foreground pixels of clamp(n_q . n_p, 0, 1)), 0, 1) written to the three channels of out_ao f32[N,3];
+ * background pixels get 0. ray_dir is an argument of the reference kernel that it never reads and is not taken here.                             */
+int mirres_normal_ao(int fx, int fy, const float* occ, const float* normal, float* out_ao, void* stream);
 /* EAWDenoise_run.backward (Denoising.py:30-48): grads w.r.t. colour, normal and position are ACCUMULATED.      */
 int mirres_eaw_bwd(int fx, int fy, int step_width, float c_phi, float n_phi, float p_phi, const float* occ, const float* color,
                    const float* normal, const float* pos, const float* grad_out, float* g_color, float* g_normal, float* g_pos, void* stream);

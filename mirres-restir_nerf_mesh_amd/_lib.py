@@ -86,6 +86,7 @@ SIGNATURES = {
     "mirres_pt_new_dir": (C.c_int, [vp, vp, PPATH, u32, u32, vp]),
     "mirres_pt_bounce": (C.c_int, [vp, vp, PENV, PPATH, u32, u32, vp, vp, vp, vp]),
     "mirres_eaw": (C.c_int, [C.c_int, C.c_int, C.c_int, f32, f32, f32, vp, vp, vp, vp, vp, vp]),
+    "mirres_normal_ao": (C.c_int, [C.c_int, C.c_int, vp, vp, vp, vp]),
     "mirres_prepare_shading_normal": (C.c_int, [C.c_longlong, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp]),
     "mirres_prepare_shading_normal_bwd": (C.c_int, [C.c_longlong, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]),
     "mirres_raster_raycast": (C.c_int, [vp, vp, C.c_int, vp, vp, vp, vp]),

@@ -16,6 +16,20 @@ class Module:
     def __repr__(self):
         return "<mirres module %s>" % self.name
 
+    def process_normal_ao(self, framedim_x, framedim_y, occ_map, normal_map, ray_dir, out_ao):
+        """The one kernel the reference launches straight off the denoising module handle (nerf/renderer.py:1153-1158):
+        `m.process_normal_ao(framedim_x=..., ..., out_ao=out_ao).launchRaw(blockSize=..., gridSize=...)`.  The launch shape is the engine's own."""
+        n = int(framedim_x) * int(framedim_y)
+        for name, t, width in (("occ_map", occ_map, 1), ("normal_map", normal_map, 3), ("out_ao", out_ao, 3)):
+            if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != n * width:
+                raise _lib.MirresError("process_normal_ao: %s must be a contiguous float32 [%d, %d] tensor" % (name, n, width))
+        mod = self
+
+        class _Launch:
+            def launchRaw(self, blockSize=None, gridSize=None):
+                check(lib().mirres_normal_ao(int(framedim_x), int(framedim_y), occ_map.data_ptr(), normal_map.data_ptr(), out_ao.data_ptr(), stream_ptr()), "mirres_normal_ao")
+        return _Launch()
+
 
 class Context:
     def __init__(self, fx, fy, cfg=None):

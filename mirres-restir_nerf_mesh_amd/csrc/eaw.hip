@@ -380,9 +380,41 @@ int launch_bilateral_divided(int fx, int fy, float sigma, const float* col, cons
     MR_LAUNCH_CHECK("bilateral_divided");
     return 0;
 }
+// process_normal_ao (EAWDenoise.slang:591-651): 8 x 8 window (offsets -4 .. 3 in x and y) of foreground neighbours, mean of clamp(n_q . n_p, 0, 1),
+// weight = clamp(50 (1 - mean), 0, 1) splat to three channels; background pixels get 0.  The sum runs x-offset outer, y-offset inner as written there.
+__global__ void __launch_bounds__(MR_BLOCK) k_normal_ao(int fx, int fy, const float* __restrict__ occ, const float* __restrict__ normal, float* __restrict__ out) {
+    const int pi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pi >= fx * fy) return;
+    float v = 0.f;
+    if (!(occ[pi] < 0.1f)) {
+        const int x = pi % fx, y = pi / fx;
+        const v3 nv = ld3(normal, pi);
+        float sum = 0.f; int count = 0;
+        for (int i = -4; i < 4; i++)
+            for (int j = -4; j < 4; j++) {
+                const int ux = x + i, uy = y + j;
+                if (ux < 0 || uy < 0 || ux >= fx || uy >= fy) continue;
+                const int q = uy * fx + ux;
+                if (occ[q] < 0.1f) continue;
+                sum += fminf(1.0f, fmaxf(dot(ld3(normal, q), nv), 0.0f));
+                count++;
+            }
+        const float w = 1.f - sum / (float)count;
+        v = fminf(fmaxf(w * 50.f, 0.f), 1.f);
+    }
+    st3(out, pi, V3(v));
+}
+
 }  // namespace mr
 
 extern "C" {
+
+int mirres_normal_ao(int fx, int fy, const float* occ, const float* normal, float* out_ao, void* stream) {
+    if (fx <= 0 || fy <= 0 || !occ || !normal || !out_ao) { set_error("mirres_normal_ao: bad argument"); return MIRRES_E_ARG; }
+    k_normal_ao<<<grid_for((size_t)fx * fy, MR_BLOCK), MR_BLOCK, 0, (hipStream_t)stream>>>(fx, fy, occ, normal, out_ao);
+    MR_LAUNCH_CHECK("normal_ao");
+    return MIRRES_OK;
+}
 
 int mirres_eaw(int fx, int fy, int step_width, float c_phi, float n_phi, float p_phi, const float* occ, const float* color, const float* normal,
                const float* pos, float* out, void* stream) {

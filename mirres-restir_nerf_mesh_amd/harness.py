@@ -138,7 +138,7 @@ test_view.__test__ = False      # not a pytest case
 
 
 def render_stage1_outputs(worker, vertices, voffsets, triangles, mlp_mat, env_map, mods, H, W, spp, ssaa=1, azimuth_deg=30.0, elevation_deg=30.0,
-                          jitter_std=0.01, bg_color=1.0, gb_depth=None, de=2, c=2.0, n=0.1, p=0.001):
+                          jitter_std=0.01, bg_color=1.0, gb_depth=None, with_normal_ao=False, de=2, c=2.0, n=0.1, p=0.001):
     """`render_stage1` for `--stage 1 --use_brdf --use_restir` training (nerf/renderer.py:960-1302) as far as the material / light / geometry
     branch goes: moved mesh -> BVH update -> G-buffer front half (build_gbuffer_stage1) -> jittered material taps (:1016-1022) ->
     run_restir_di_with_pt (:1112-1123) -> clamp, tone curve, alpha (:1125-1129, 1162-1164, 1208).  Returns the entries of the reference's
@@ -159,11 +159,17 @@ def render_stage1_outputs(worker, vertices, voffsets, triangles, mlp_mat, env_ma
     out = RR.run_restir_di_with_pt(False, 1.0, 1.0, 1.0, mlp_mat, gb_depth, worker, *mods[:8], *mods[8:17], env_map, g["occ"].clone(), g["normal"],
                                    g["depth"], g["kd"], g["rm"], g["ray_dir"], xyzs.detach(), z(N, 1), z(N, 4), z(N, 3), z(N, 3), fx, fy, spp, de,
                                    2 ** (de - 1), c, n, p)
+    extra = {}
+    if with_normal_ao:      # --lambda_extra_kd > 0 (:1150-1158, 1226-1228): the kernel is launched off the denoising module handle, as the reference does
+        out_ao = torch.zeros((N, 3), dtype=torch.float32, device=dev)
+        mods[7].process_normal_ao(framedim_x=int(fx), framedim_y=int(fy), occ_map=g["occ"], normal_map=g["normal"].detach().contiguous(), ray_dir=g["ray_dir"], out_ao=out_ao) \
+            .launchRaw(blockSize=(16, 16, 1), gridSize=((int(fx) + 15) // 16, (int(fy) + 15) // 16, 1))
+        extra["normal_ao"] = (g["occ"] * torch.clamp(out_ao, 0.0, 1.0)).detach()
     alpha = g["occ"]
     image_brdf = alpha * linear2srgb(torch.clamp(torch.nan_to_num(out[0], 0.0), 0.0, 1.0)) + (1 - alpha) * bg_color            # :1209, :1301
     lit = lambda x: alpha * torch.clamp(x, 0.0, 1.0)                                                                # :1182-1186 without the antialias
     return dict(image_brdf=image_brdf, diffuse_light=lit(out[1]), specular_light=lit(out[2]), img_brdf_indirect=lit(out[3].detach()),
-                kd_grad=kd_grad * alpha, ks_grad=ks_grad * alpha, normal_grad=torch.zeros((N, 1), device=dev), occ=alpha, fx=fx, fy=fy)   # :1350-1352
+                kd_grad=kd_grad * alpha, ks_grad=ks_grad * alpha, normal_grad=torch.zeros((N, 1), device=dev), occ=alpha, fx=fx, fy=fy, **extra)   # :1350-1352
 
 
 def linear2srgb(x):

@@ -145,6 +145,33 @@ void orc_bounce(const OrcFrame* f, const OrcPath* p, uint32_t frameIndex, uint32
     Config C = cfg(f); Bvh B = bvh(f); Env E = env(f); PathBufs P = pathbufs(p);
     ORC_PIXEL_LOOP(f->fx, f->fy, counters, bounce_pixel(C, B, E, P, f->fx, frameIndex, bounce_count, color, diff_color, spec_color, x, y, tc));
 }
+// process_normal_ao (EAWDenoise.slang:591-651): offsets -4 .. 3, x-offset outer / y-offset inner, foreground neighbours only
+void orc_normal_ao(int fx, int fy, const float* occ, const float* normal, float* out) {
+#pragma omp parallel for
+    for (int y = 0; y < fy; y++)
+        for (int x = 0; x < fx; x++) {
+            const int pi = y * fx + x;
+            float v = 0.f;
+            if (!(occ[pi] < 0.1f)) {
+                const float nx = normal[3 * pi], ny = normal[3 * pi + 1], nz = normal[3 * pi + 2];
+                float sum = 0.f; int count = 0;
+                for (int i = -4; i < 4; i++)
+                    for (int j = -4; j < 4; j++) {
+                        const int ux = x + i, uy = y + j;
+                        if (ux < 0 || uy < 0 || ux >= fx || uy >= fy) continue;
+                        const int q = uy * fx + ux;
+                        if (occ[q] < 0.1f) continue;
+                        float d = normal[3 * q] * nx + normal[3 * q + 1] * ny + normal[3 * q + 2] * nz;
+                        d = d > 0.0f ? d : 0.0f; d = d < 1.0f ? d : 1.0f;
+                        sum += d; count++;
+                    }
+                float w = (1.f - sum / (float)count) * 50.f;
+                v = w < 0.f ? 0.f : (w > 1.f ? 1.f : w);
+            }
+            out[3 * pi] = out[3 * pi + 1] = out[3 * pi + 2] = v;
+        }
+}
+
 void orc_eaw(int fx, int fy, int stepWidth, float c_phi, float n_phi, float p_phi, const float* occ, const float* color, const float* normal,
              const float* pos, float* out) {
 #pragma omp parallel for

@@ -279,6 +279,13 @@ def eaw(fx, fy, step, c_phi, n_phi, p_phi, occ, color, normal, pos):
     return out
 
 
+def normal_ao(fx, fy, occ, normal):
+    """process_normal_ao (EAWDenoise.slang:591-651)."""
+    out = np.zeros((fx * fy, 3), np.float32)
+    lib().orc_normal_ao(int(fx), int(fy), _p(_c(occ, np.float32), f32p), _p(_c(normal, np.float32), f32p), _p(out, f32p))
+    return out
+
+
 def prepare_shading_normal(pos, view_pos, perturbed_nrm, smooth_nrm, smooth_tng, geom_nrm, two_sided_shading=True, opengl=True):
     """nerf/renderutils: bsdf_prepare_shading_normal (ops.py:84-121) == c_src/normal.cu forward, restated in numpy float32 (test infrastructure).
     safeNormalize = v / |v| (0 for the zero vector, vec3f.h:87-91); bend threshold 0.1 (normal.cu:12)."""

@@ -101,3 +101,29 @@ def test_env_lookup_vs_numpy(oracle):
     ref = (T[cy0, cx0] * (1 - u) + T[cy0, cx1] * u) * (1 - v) + (T[cy1, cx0] * (1 - u) + T[cy1, cx1] * u) * v
     np.testing.assert_allclose(got, ref, rtol=0, atol=3e-5)
     assert np.all(oracle.env_le(tex, W, H, np.array([[0, 1, 0], [0, -1, 0]], np.float32)) == 0)     # poles return 0 (lightDi.slang:125-126)
+
+
+def test_normal_ao_known_answers(oracle):
+    """process_normal_ao (EAWDenoise.slang:591-651) by hand: uniform normals -> 0; a vertical crease at x = 6 of a 12-wide frame -> the window
+    (x offsets -4 .. 3, so it reaches 3 pixels right and 4 left) flags x = 3 .. 9: one foreign column out of seven or eight gives > 6, clamped to 1;
+    a 30-degree crease gives 50 (1 - cos 30) k / n for k foreign columns of n valid ones; background pixels are 0 and are skipped as neighbours; the value is splat
+    to three channels."""
+    fx, fy = 12, 10
+    occ = np.ones(fx * fy, np.float32)
+    flat = np.tile(np.array([0, 0, 1], np.float32), (fx * fy, 1))
+    assert np.all(oracle.normal_ao(fx, fy, occ, flat) == 0)
+    crease = flat.copy().reshape(fy, fx, 3); crease[:, 6:] = [1, 0, 0]
+    a = oracle.normal_ao(fx, fy, occ, crease.reshape(-1, 3)).reshape(fy, fx, 3)
+    assert np.array_equal(a[..., 0], a[..., 1]) and np.array_equal(a[..., 0], a[..., 2])
+    assert a[5, :, 0].tolist() == [0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 0, 0]
+    c30 = np.float32(np.cos(np.deg2rad(30.0))); s30 = np.float32(np.sin(np.deg2rad(30.0)))
+    soft = flat.copy().reshape(fy, fx, 3); soft[:, 6:] = [s30, 0, c30]
+    b = oracle.normal_ao(fx, fy, occ, soft.reshape(-1, 3)).reshape(fy, fx, 3)[5, :, 0]
+    d = float(np.float32(s30 * 0 + 0 + c30 * 1))
+    assert abs(b[3] - 50 * (1 - (6 + d) / 7)) < 1e-5        # x = 3 sees columns 0 .. 6 (x - 4 is outside): one foreign of seven
+    assert b[5] == 1.0 and b[2] == 0        # three foreign columns of eight: 50 (1 - cos 30) 3 / 8 = 2.5, clamped
+    # x = 9 sees columns 5 .. 11 only (7 valid): one foreign
+    assert abs(b[9] - 50 * (1 - (6 + d) / 7)) < 1e-5
+    hole = occ.copy().reshape(fy, fx); hole[:, 6:] = 0
+    h = oracle.normal_ao(fx, fy, hole.reshape(-1), crease.reshape(-1, 3)).reshape(fy, fx, 3)
+    assert np.all(h[:, 6:] == 0) and np.all(h[:, :6] == 0)          # the foreign half is background: not counted, and itself 0
