@@ -210,9 +210,11 @@ int mirres_matnet_mlp(const mirres_matnet_t* m, const uint16_t* enc, int n, floa
 /* renderer_restir.py:398-408 fused: evaluate where occ>=0.5 and scatter kd / (roughness, metallic) in place.    */
 int mirres_matnet_scatter(const mirres_matnet_t* m, const float* occ, const float* pos, int n, float* kd, float* rough_metal,
                           int use_scale, const float* h_scale3, void* stream);
-/* backward of sample(): grads to the fp32 master grid (atomic), MLP weights and nothing else.                    */
+/* backward of sample(): grads to the fp32 master grid (atomic, accumulated), the MLP weights (accumulated) and, when g_pos != NULL,
+ * the sample positions f32[n,3] (overwritten; tcnn's HashGrid input gradient x 1/(aabb_max-aabb_min), zero where the clamp to the
+ * AABB is active - render_helper.py:93-98).                                                                       */
 int mirres_matnet_bwd(const mirres_matnet_t* m, const float* pos, int n, const float* grad_out, float* g_params_f32, float* g_w0,
-                      float* g_w1, float* g_w2, void* stream);
+                      float* g_w1, float* g_w2, float* g_pos, void* stream);
 
 /* ------------------------------------------------------------------ whole frame: run_restir_di_with_pt (renderer_restir.py:473-550) */
 typedef struct mirres_render_args {
@@ -232,7 +234,8 @@ typedef struct mirres_render_args {
                                          average/denoise/composite (raw sums are left in outs[0..5]); 0,0 = all  */
     /* Multi-GPU strip sharding (exact: bit-identical to one GPU for the rows a rank owns). The context is created for the rank's
      * LOCAL frame = its own rows plus up to 30 halo rows (the spatial gather radius) on either side; all per-pixel inputs cover the
-     * local frame. strip_full_fy = height of the whole frame (0 = no strip sharding), strip_y_off = global row of local row 0,
+     * local frame (which may extend below the image by rows the caller padded with background, occ = 0, so that strips of different
+     * heights share a context size). strip_full_fy = height of the whole frame (0 = no strip sharding), strip_y_off = global row of local row 0,
      * [own_y0, own_y1) = the local rows this rank owns. Halo rows are only read (G-buffer, reservoirs); `halo` is called once per
      * sample, on the host while the frame is being enqueued, between temporal and spatial reuse: it must enqueue — on the same
      * stream — the exchange that fills the halo rows of `records` (packed reservoirs, f32[local pixels, 8]) with the neighbouring

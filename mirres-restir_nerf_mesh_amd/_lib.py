@@ -104,7 +104,7 @@ SIGNATURES = {
     "mirres_matnet_fwd": (C.c_int, [PMAT, vp, C.c_int, vp, vp, vp]),
     "mirres_matnet_mlp": (C.c_int, [PMAT, vp, C.c_int, vp, vp]),
     "mirres_matnet_scatter": (C.c_int, [PMAT, vp, vp, C.c_int, vp, vp, C.c_int, C.POINTER(C.c_float), vp]),
-    "mirres_matnet_bwd": (C.c_int, [PMAT, vp, C.c_int, vp, vp, vp, vp, vp, vp]),
+    "mirres_matnet_bwd": (C.c_int, [PMAT, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp]),
     "mirres_render": (C.c_int, [vp, vp, PARGS, vp]),
     "mirres_render_bwd": (C.c_int, [vp, PARGS, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]),
     "mirres_render_finish": (C.c_int, [vp, PARGS, C.POINTER(vp), vp]),

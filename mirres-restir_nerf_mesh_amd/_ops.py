@@ -1,5 +1,8 @@
 """Thin torch<->C-ABI glue shared by the reference-shaped modules. Every function enqueues on the current torch stream."""
+import collections
 import ctypes as C
+import os
+
 import torch
 
 from . import _lib
@@ -63,17 +66,36 @@ class Context:
         check(lib().mirres_ctx_set_instrument(self.h, int(on)), "mirres_ctx_set_instrument")
 
 
-_CTX_CACHE = {}
+_CTX_CACHE = collections.OrderedDict()      # (device, fx, fy, max_bounce) -> Context, least recently used first
+
+
+def _ctx_cache_limit():
+    """A context lazily owns its batch pool (~670 B x K x N: 55 GB at 1600^2 with K = 32), so the cache is bounded: MIRRES_CTX_CACHE contexts
+    (default 3) per process, least recently used dropped first.  A dropped context is destroyed (pool freed) as soon as nothing else refers to it —
+    module handles returned by load_m_for_restir keep theirs alive."""
+    try:
+        return max(1, int(os.environ.get("MIRRES_CTX_CACHE", "3")))
+    except ValueError:
+        return 3
 
 
 def get_ctx(fx, fy, max_bounce=None):
-    key = (int(fx), int(fy), max_bounce)
-    if key not in _CTX_CACHE:
-        cfg = _lib.default_config()
-        if max_bounce is not None:
-            cfg.max_bounce = int(max_bounce)
-        _CTX_CACHE[key] = Context(fx, fy, cfg)
-    return _CTX_CACHE[key]
+    """The engine context of an fx x fy frame on the current device.  `max_bounce=None` means the configuration default, and both spellings share one
+    context (and one pool)."""
+    cfg = _lib.default_config()
+    if max_bounce is not None:
+        cfg.max_bounce = int(max_bounce)
+    dev = torch.cuda.current_device() if torch.cuda.is_available() else -1
+    key = (dev, int(fx), int(fy), int(cfg.max_bounce))
+    ctx = _CTX_CACHE.get(key)
+    if ctx is None:
+        limit = _ctx_cache_limit()
+        while len(_CTX_CACHE) >= limit:
+            _CTX_CACHE.popitem(last=False)          # the evicted Context frees its pools in __del__ once unreferenced
+        ctx = _CTX_CACHE[key] = Context(fx, fy, cfg)
+    else:
+        _CTX_CACHE.move_to_end(key)
+    return ctx
 
 
 def _f32(t):

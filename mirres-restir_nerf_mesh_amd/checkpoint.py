@@ -15,7 +15,8 @@ import struct
 import numpy as np
 import torch
 
-__all__ = ["read_ply", "write_ply", "load_stage0_mesh", "read_checkpoint", "apply_checkpoint", "save_checkpoint"]
+__all__ = ["read_ply", "write_ply", "load_stage0_mesh", "read_checkpoint", "apply_checkpoint", "save_checkpoint", "material_config",
+           "resolve_material_config", "material_field_args", "cascade_of_bound"]
 
 _PLY_TYPES = {"char": "b", "int8": "b", "uchar": "B", "uint8": "B", "short": "h", "int16": "h", "ushort": "H", "uint16": "H", "int": "i", "int32": "i",
               "uint": "I", "uint32": "I", "float": "f", "float32": "f", "double": "d", "float64": "d"}
@@ -136,6 +137,62 @@ def load_stage0_mesh(workspace, cascade=1, mesh="", from_scratch=False):
 
 _MAT = "mlp_mat_opt."
 
+# The reference's CLI defaults for what fixes the decoding of a material field (main.py:39,109-110,167-170).  They are NOT stored in a reference
+# checkpoint: an evaluation must be given the training run's values.
+_MATERIAL_DEFAULTS = dict(bound=2.0, roughness_min=0.08, me_max=0.0, kd_min=(0.0, 0.0, 0.0), kd_max=(1.0, 1.0, 1.0))
+
+
+def material_config(**kw):
+    """The constants that decode a material field, main.py's defaults overridden by `kw` (bound, roughness_min, me_max, kd_min, kd_max)."""
+    bad = set(kw) - set(_MATERIAL_DEFAULTS)
+    if bad:
+        raise KeyError("unknown material-field constant(s): %s" % ", ".join(sorted(bad)))
+    c = dict(_MATERIAL_DEFAULTS); c.update({k: v for k, v in kw.items() if v is not None})
+    c["bound"] = float(c["bound"]); c["roughness_min"] = float(c["roughness_min"]); c["me_max"] = float(c["me_max"])
+    c["kd_min"] = tuple(float(x) for x in c["kd_min"]); c["kd_max"] = tuple(float(x) for x in c["kd_max"])
+    if not c["bound"] > 0:
+        raise ValueError("bound must be positive")
+    return c
+
+
+_material_config = material_config      # save_checkpoint has a parameter of the same name
+
+
+def resolve_material_config(recorded=None, warn=None, **cli):
+    """Command-line values win; otherwise what the checkpoint recorded; otherwise main.py's defaults — with a warning, because a reference checkpoint
+    records none of them and decoding it with another run's `--bound` / `--me_max` / `--roughness_min` gives wrong materials without any error."""
+    import warnings
+    warn = warn or (lambda m: warnings.warn(m, stacklevel=3))
+    given = {k: v for k, v in cli.items() if v is not None}
+    if recorded is None:
+        missing = [k for k in ("bound", "roughness_min", "me_max") if k not in given]
+        if missing:
+            warn("checkpoint records no material-field constants; using main.py's defaults for %s — pass the training run's values if they differ"
+                 % ", ".join("--%s %s" % (k, _MATERIAL_DEFAULTS[k]) for k in missing))
+        return material_config(**given)
+    rec = material_config(**recorded)
+    out = material_config(**{**rec, **given})
+    for k in given:
+        if out[k] != rec[k]:
+            warn("--%s %s differs from the value the checkpoint was written with (%s)" % (k, out[k], rec[k]))
+    return out
+
+
+def cascade_of_bound(bound):
+    """nerf/renderer.py:97."""
+    import math
+    return 1 + math.ceil(math.log2(bound)) if bound > 1 else 1
+
+
+def material_field_args(cfg):
+    """(AABB [6], mlp_min [6], mlp_max [6]) exactly as nerf/network.py:119-125 builds them from the options: AABB = +-bound;
+    min = (kd_min, 0, roughness_min, 0), max = (kd_max, 0, 1, me_max)  (main.py:167-170)."""
+    b = cfg["bound"]
+    aabb = torch.tensor([-b, -b, -b, b, b, b], dtype=torch.float32)
+    mn = torch.tensor(list(cfg["kd_min"]) + [0.0, cfg["roughness_min"], 0.0], dtype=torch.float32)
+    mx = torch.tensor(list(cfg["kd_max"]) + [0.0, 1.0, cfg["me_max"]], dtype=torch.float32)
+    return aabb, mn, mx
+
 
 def read_checkpoint(path, map_location="cpu"):
     """A reference `.pth` -> dict(vertices_offsets, grid_params, mlp_weights (3 tensors), light_base, epoch, global_step, stage).  Accepts both forms
@@ -151,7 +208,8 @@ def read_checkpoint(path, map_location="cpu"):
         raise KeyError("%s: incomplete material field (%s)" % (path, ", ".join(k for k, h in zip(("encoder.params", "net.0", "net.2", "net.4"), have) if not h)))
     top = ck if isinstance(ck, dict) and "model" in ck else {}
     return dict(vertices_offsets=f32(model.get("vertices_offsets")), grid_params=f32(grid), mlp_weights=[f32(w) for w in ws] if all(have) else None,
-                light_base=f32(top.get("light_base")), epoch=top.get("epoch"), global_step=top.get("global_step"), stage=top.get("stage"))
+                light_base=f32(top.get("light_base")), epoch=top.get("epoch"), global_step=top.get("global_step"), stage=top.get("stage"),
+                material_config=top.get("material_config"))
 
 
 def apply_checkpoint(ck, mlp_mat=None, n_vertices=None, device="cuda"):
@@ -175,9 +233,18 @@ def apply_checkpoint(ck, mlp_mat=None, n_vertices=None, device="cuda"):
     return to(voff), to(ck["light_base"])
 
 
-def save_checkpoint(path, mlp_mat, vertices_offsets, light_base, epoch=0, global_step=0, stage=1):
-    """The same file layout, written from this engine's objects (Trainer.save_checkpoint with full=False, :1843-1854, 1912-1920)."""
+def save_checkpoint(path, mlp_mat, vertices_offsets, light_base, epoch=0, global_step=0, stage=1, material_config=None):
+    """The same file layout, written from this engine's objects (Trainer.save_checkpoint with full=False, :1843-1854, 1912-1920), plus one extra
+    top-level key the reference's loader ignores: `material_config` (the AABB / output-range constants the field was trained with, read back from the
+    module when not given) so that an evaluation of this file cannot silently decode it with another run's `--bound` / `--me_max`."""
+    if material_config is None:
+        lo, hi = (t.detach().cpu().tolist() for t in mlp_mat.AABB)
+        mn, mx = (t.detach().cpu().tolist() for t in mlp_mat.min_max)
+        if not (lo[0] == lo[1] == lo[2] == -hi[0] and hi[0] == hi[1] == hi[2]):
+            raise ValueError("material field AABB %s..%s is not +-bound: pass material_config explicitly" % (lo, hi))
+        material_config = _material_config(bound=hi[0], roughness_min=mn[4], me_max=mx[5], kd_min=mn[:3], kd_max=mx[:3])
     model = {"vertices_offsets": vertices_offsets.detach().cpu(), _MAT + "encoder.params": mlp_mat.encoder.params.detach().cpu()}
     for i in (0, 2, 4):
         model[_MAT + "net.net.%d.weight" % i] = mlp_mat.net.net[i].weight.detach().cpu()
-    torch.save({"epoch": epoch, "global_step": global_step, "stats": {}, "stage": stage, "light_base": light_base.detach().cpu(), "model": model}, path)
+    torch.save({"epoch": epoch, "global_step": global_step, "stats": {}, "stage": stage, "light_base": light_base.detach().cpu(), "model": model,
+                "material_config": dict(material_config)}, path)

@@ -300,7 +300,8 @@ struct MatNetB { const __half2* grid; const float *w0, *w1, *w2; float aabb_min[
 #define MR_BW_TABLE (1 << MR_BW_TABLE_LOG2)   // per-wave aggregation table of the coarse grid levels: keys in U (4 KB of 8.4), values in V (8 KB of 8.4)
 #define MR_BW_COARSE 8
 __global__ void __launch_bounds__(MR_BLOCK) k_matnet_bwd(MatNetB M, GridLevelsB L, const float* __restrict__ pos, int n, const float* __restrict__ gout,
-                                                         float* __restrict__ g_params, float* __restrict__ g_w0, float* __restrict__ g_w1, float* __restrict__ g_w2) {
+                                                         float* __restrict__ g_params, float* __restrict__ g_w0, float* __restrict__ g_w1, float* __restrict__ g_w2,
+                                                         float* __restrict__ g_pos) {
     __shared__ float sw0[1024], sw1[1024], sw2[192];
     __shared__ float sU[MR_BW_WAVES][64 * MR_BW_LD], sV[MR_BW_WAVES][64 * MR_BW_LD];
     for (int i = threadIdx.x; i < 1024; i += blockDim.x) { sw0[i] = M.w0[i]; sw1[i] = M.w1[i]; }
@@ -317,10 +318,10 @@ __global__ void __launch_bounds__(MR_BLOCK) k_matnet_bwd(MatNetB M, GridLevelsB 
         const int i = tile * 64 + lane;
         const bool live = i < n;
         float a0[32], h1[32], h2[32], gz2[6], gh2[32], gh1[32], ga0[32];
-        float x[3] = {0.f, 0.f, 0.f};
+        float x[3] = {0.f, 0.f, 0.f}, xraw[3] = {0.f, 0.f, 0.f};
         if (live) {
 #pragma unroll
-            for (int d = 0; d < 3; d++) x[d] = fminf(fmaxf((pos[3 * (size_t)i + d] - M.aabb_min[d]) / (M.aabb_max[d] - M.aabb_min[d]), 0.f), 1.f);
+            for (int d = 0; d < 3; d++) { xraw[d] = (pos[3 * (size_t)i + d] - M.aabb_min[d]) / (M.aabb_max[d] - M.aabb_min[d]); x[d] = fminf(fmaxf(xraw[d], 0.f), 1.f); }
         }
         // forward recompute
         for (int lv = 0; lv < MR_LEVELS; lv++) {
@@ -349,6 +350,40 @@ __global__ void __launch_bounds__(MR_BLOCK) k_matnet_bwd(MatNetB M, GridLevelsB 
         for (int k = 0; k < 32; k++) { float acc = 0.f; for (int o = 0; o < 6; o++) acc += gz2[o] * sw2[o * 32 + k]; gh2[k] = h2[k] > 0.f ? acc : 0.f; }
         for (int k = 0; k < 32; k++) { float acc = 0.f; for (int o = 0; o < 32; o++) acc += gh2[o] * sw1[o * 32 + k]; gh1[k] = h1[k] > 0.f ? acc : 0.f; }
         for (int k = 0; k < 32; k++) { float acc = 0.f; for (int o = 0; o < 32; o++) acc += gh1[o] * sw0[o * 32 + k]; ga0[k] = acc; }
+        // Position gradient (the reference's sample() is differentiable in its argument: tcnn's HashGrid returns dL/dx, the x128 / /128 hooks of
+        // render_helper.py:41,78-80 cancel on this route, and kd / ks losses reach `vertices_offsets` through dr.interpolate, nerf/renderer.py:1017-1018).
+        // d enc[f] / d x_d = scale * sum_corners (+-1 along d) * (product of the other two weights) * table[corner][f]   (tcnn grid.h, dy_dx with
+        // pos_derivative = 1 for linear interpolation; tcnn differences the fp16 entries and accumulates in fp16, here the sum is fp32);
+        // d x / d pos = 1 / (aabb_max - aabb_min), torch.clamp passes the gradient on [0, 1] inclusive and blocks it outside.
+        if (g_pos && live) {
+            float gx[3] = {0.f, 0.f, 0.f};
+            for (int lv = 0; lv < MR_LEVELS; lv++) {
+                const float g0 = ga0[2 * lv], g1 = ga0[2 * lv + 1];
+                if (g0 == 0.f && g1 == 0.f) continue;
+                const float scale = L.scale[lv]; const uint32_t res = L.res[lv], size = L.size[lv];
+                const __half2* g = M.grid + L.offset[lv];
+                float p[3]; uint32_t pg[3];
+#pragma unroll
+                for (int d = 0; d < 3; d++) { float q = fmaf(scale, x[d], 0.5f); float fl = floorf(q); pg[d] = (uint32_t)(int)fl; p[d] = q - fl; }
+                float lx[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+                for (uint32_t idx = 0; idx < 8; idx++) {
+                    float wd[3]; uint32_t pl[3];
+#pragma unroll
+                    for (int d = 0; d < 3; d++) { if ((idx & (1u << d)) == 0) { wd[d] = 1 - p[d]; pl[d] = pg[d]; } else { wd[d] = p[d]; pl[d] = pg[d] + 1; } }
+                    const __half2 v = g[grid_index_b(size, res, pl[0], pl[1], pl[2])];
+                    const float sv = g0 * __low2float(v) + g1 * __high2float(v);
+                    lx[0] += ((idx & 1u) ? sv : -sv) * (wd[1] * wd[2]);
+                    lx[1] += ((idx & 2u) ? sv : -sv) * (wd[0] * wd[2]);
+                    lx[2] += ((idx & 4u) ? sv : -sv) * (wd[0] * wd[1]);
+                }
+#pragma unroll
+                for (int d = 0; d < 3; d++) gx[d] += scale * lx[d];
+            }
+#pragma unroll
+            for (int d = 0; d < 3; d++)
+                g_pos[3 * (size_t)i + d] = (xraw[d] >= 0.f && xraw[d] <= 1.f) ? gx[d] / (M.aabb_max[d] - M.aabb_min[d]) : 0.f;
+        }
         // weight gradients: three staged outer-product sums over the wave's 64 points (wave-synchronous: a wave owns its U / V)
         {   // gW2[o][k] += gz2[o] * h2[k]   (6 x 32 = 192 entries: lane owns e = lane + 64 j, j < 3)
             for (int o = 0; o < 6; o++) U[lane * MR_BW_LD + o] = gz2[o];
@@ -462,14 +497,14 @@ int mirres_final_shading_bwd(mirres_ctx_t* ctx, const float* occ, const float* n
 }
 
 int mirres_matnet_bwd(const mirres_matnet_t* m, const float* pos, int n, const float* grad_out, float* g_params_f32, float* g_w0,
-                      float* g_w1, float* g_w2, void* stream) {
+                      float* g_w1, float* g_w2, float* g_pos, void* stream) {
     if (!m || !pos || !grad_out || n < 0) { set_error("mirres_matnet_bwd: bad argument"); return MIRRES_E_ARG; }
     if (n == 0) return MIRRES_OK;
     MatNetB M; M.grid = reinterpret_cast<const __half2*>(m->grid_f16); M.w0 = m->w0; M.w1 = m->w1; M.w2 = m->w2;
     for (int i = 0; i < 3; i++) { M.aabb_min[i] = m->aabb_min[i]; M.aabb_max[i] = m->aabb_max[i]; }
     for (int i = 0; i < 6; i++) { M.mn[i] = m->out_min[i]; M.mx[i] = m->out_max[i]; }
     int grd = grid_for(n, MR_BLOCK); if (grd > 256 * 4) grd = 256 * 4;      // workgroups loop over point tiles and keep the weight gradients in registers
-    k_matnet_bwd<<<grd, MR_BLOCK, 0, (hipStream_t)stream>>>(M, host_levels_b(), pos, n, grad_out, g_params_f32, g_w0, g_w1, g_w2);
+    k_matnet_bwd<<<grd, MR_BLOCK, 0, (hipStream_t)stream>>>(M, host_levels_b(), pos, n, grad_out, g_params_f32, g_w0, g_w1, g_w2, g_pos);
     MR_LAUNCH_CHECK("matnet_bwd");
     return MIRRES_OK;
 }

@@ -214,17 +214,35 @@ static int carve_batch(mirres_ctx* ctx, int N, int K, int max_bounce, size_t TS,
              + 4 * al(4 * 8 * NV) + al(4 * 3 * (size_t)k * TS) + al(4 * (size_t)k * TS) + al(16 * (size_t)k * TS)
              + 2 * (al(sizeof(Ray) * NV) + 2 * al(4 * NV) + al(64));
     };
+    // A request the device could not hold last time is not repeated every frame (each retry costs a device synchronisation, a free of the working
+    // pool and a failing multi-GB hipMalloc): the batch size that fitted is remembered and later requests are clamped to it.
+    if (ctx->ptb_kcap > 0 && K > ctx->ptb_kcap) K = ctx->ptb_kcap;
     size_t need = bytes_for(K);
     if (ctx->ptb_bytes < need) {
-        if (ctx->ptb) { MR_HIP(hipDeviceSynchronize()); MR_HIP(hipFree(ctx->ptb)); ctx->ptb = nullptr; ctx->ptb_bytes = 0; }
-        // ~670 bytes per slot: 55 GB for 32 samples of a 1600^2 frame. When the device cannot spare that (other tenants of the HBM), halve the batch
-        for (;;) {
-            const hipError_t e = hipMalloc(&ctx->ptb, need);
-            if (e == hipSuccess) break;
-            (void)hipGetLastError(); ctx->ptb = nullptr;
-            if (e != hipErrorOutOfMemory || K == 1) { set_error("mirres_render: cannot allocate the %zu-byte batch pool (%s)", need, hipGetErrorString(e)); return MIRRES_E_HIP; }
-            K = (K + 1) / 2; need = bytes_for(K);
-        }
+        // ~670 bytes per slot: 55 GB for 32 samples of a 1600^2 frame. The larger pool is allocated BEFORE the working one is given up, so that a
+        // failure leaves the context with the pool it had; only when both do not fit together is the old one freed first. When the device cannot
+        // spare the request at all (other tenants of the HBM), the batch is halved until it fits.
+        char* fresh = nullptr;
+        // MIRRES_POOL_LIMIT_MB: refuse larger pools as if the device were full (how the tests exercise the fall-back without filling 288 GB)
+        const char* lim_s = getenv("MIRRES_POOL_LIMIT_MB"); const size_t lim = lim_s ? (size_t)atoll(lim_s) << 20 : 0;
+        auto hipMalloc = [&](char** p, size_t b) -> hipError_t { if (lim && b > lim) return hipErrorOutOfMemory; return ::hipMalloc(p, b); };
+        hipError_t e = hipMalloc(&fresh, need);
+        if (e != hipSuccess) {
+            (void)hipGetLastError(); fresh = nullptr;
+            if (e != hipErrorOutOfMemory) { set_error("mirres_render: cannot allocate the %zu-byte batch pool (%s)", need, hipGetErrorString(e)); return MIRRES_E_HIP; }
+            if (ctx->ptb) { MR_HIP(hipDeviceSynchronize()); MR_HIP(hipFree(ctx->ptb)); ctx->ptb = nullptr; ctx->ptb_bytes = 0; }
+            for (;;) {
+                e = hipMalloc(&fresh, need);
+                if (e == hipSuccess) break;
+                (void)hipGetLastError(); fresh = nullptr;
+                if (e != hipErrorOutOfMemory || K == 1) {   // nothing fits now: no pool, no remembered size — the next frame starts over
+                    ctx->ptb_kcap = 0; set_error("mirres_render: cannot allocate the %zu-byte batch pool (%s)", need, hipGetErrorString(e)); return MIRRES_E_HIP;
+                }
+                K = (K + 1) / 2; need = bytes_for(K);
+                ctx->ptb_kcap = K;
+            }
+        } else if (ctx->ptb) { MR_HIP(hipDeviceSynchronize()); MR_HIP(hipFree(ctx->ptb)); ctx->ptb = nullptr; ctx->ptb_bytes = 0; }
+        ctx->ptb = fresh;
         MR_HIP(hipMemset(ctx->ptb, 0, need));   // slots that never receive a vertex are read (and ignored) by the bounce kernels
         ctx->ptb_bytes = need;
     }
@@ -305,7 +323,9 @@ int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args
     const int Wc = a->Wc, Hc = a->Hc;
     FrameBufs B; int rc = carve(ctx, Wc, Hc, B); if (rc) return rc;
     const bool strip = a->strip_full_fy > 0;
-    if (strip && !(a->own_y0 >= 0 && a->own_y0 < a->own_y1 && a->own_y1 <= ctx->fy && a->strip_y_off >= 0 && a->strip_y_off + ctx->fy <= a->strip_full_fy)) {
+    // the local frame may extend below the image (rows the caller padded with background so that strips of different views share a context size);
+    // the own rows must lie inside it
+    if (strip && !(a->own_y0 >= 0 && a->own_y0 < a->own_y1 && a->own_y1 <= ctx->fy && a->strip_y_off >= 0 && a->strip_y_off + a->own_y1 <= a->strip_full_fy)) {
         set_error("mirres_render: strip rows [%d,%d) of a %d-row local frame at global row %d of %d", a->own_y0, a->own_y1, ctx->fy, a->strip_y_off, a->strip_full_fy);
         return MIRRES_E_ARG;
     }
@@ -368,6 +388,20 @@ int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args
     // bit-identical for any stream count and batch size (tests/test_gpu_fullsize.py). MIRRES_STREAMS=2 puts PT(b) behind I(b+1) on the bulk
     // stream; instrumented frames (counters / per-launch event timing) and MIRRES_STREAMS=1 run the same sequence on one stream.
     hipStream_t sp = s, st = s, sf = s, st2 = nullptr;   // sp: I stages, sf: F stages, st (and st2): path-tracing stages
+    unsigned long long* d_sums = nullptr;
+    // Whatever way this call returns, the caller's stream is ordered after every side stream that was forked from it (an error exit must not
+    // leave work running on the side streams that the caller's next enqueue could race with), and the debug buffer is released.
+    struct Join {
+        mirres_ctx* c; hipStream_t s; hipStream_t *sp, *st, *sf, *st2; unsigned long long** sums; bool done;
+        void run() {
+            if (done) return; done = true;
+            if (*sp != s && c->ev_join) { (void)hipEventRecord(c->ev_join, *sp); (void)hipStreamWaitEvent(s, c->ev_join, 0); }
+            if (*st != *sp && c->ev_join_pt) { (void)hipEventRecord(c->ev_join_pt, *st); (void)hipStreamWaitEvent(s, c->ev_join_pt, 0); }
+            if (*sf != *sp && c->ev_join_fin) { (void)hipEventRecord(c->ev_join_fin, *sf); (void)hipStreamWaitEvent(s, c->ev_join_fin, 0); }
+            if (*st2 && c->ev_join_pt2) { (void)hipEventRecord(c->ev_join_pt2, *st2); (void)hipStreamWaitEvent(s, c->ev_join_pt2, 0); }
+        }
+        ~Join() { run(); if (*sums) { (void)hipStreamSynchronize(s); (void)hipFree(*sums); *sums = nullptr; } }
+    } join{ctx, s, &sp, &st, &sf, &st2, &d_sums, false};
     const int nstreams = ctx->instrument == 0 ? stream_count() : 1;
     const bool two_streams = nstreams >= 2;
     const int nbatch = (i1 - i0 + PB.K - 1) / PB.K;
@@ -409,7 +443,7 @@ int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args
         return launch_initial_batch(ctx, bvh, &E, &G, &PB.rinit[b & 1], PB.tile_data, PB.tile_pdf, PB.tile_aux, a->random_offset + passes * (uint32_t)ib, batch_k(b), &Q, sp);
     };
     const bool dbg_sum = getenv("MIRRES_DBG_SUM") != nullptr;
-    unsigned long long* d_sums = nullptr; int n_sums = 0;
+    int n_sums = 0;
     if (dbg_sum) { MR_HIP(hipMalloc(&d_sums, 8 * 4096)); MR_HIP(hipMemsetAsync(d_sums, 0, 8 * 4096, s)); }
     auto csum = [&](const void* p, size_t words) { if (dbg_sum && n_sums < 4096) k_checksum<<<1024, MR_BLOCK, 0, s>>>((const uint32_t*)p, words, d_sums + n_sums++); };
     int pt_seq = 0;   // running index of the path-tracing sub-batches
@@ -495,13 +529,10 @@ int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args
                                 a->tape ? a->tape + 8 * (size_t)N * (size_t)((nbatch - 1) * PB.K) : nullptr, sf);
         if (rc) return rc;
     }
-    if (two_streams) { MR_HIP(hipEventRecord(ctx->ev_join, sp)); MR_HIP(hipStreamWaitEvent(s, ctx->ev_join, 0)); }
-    if (st != sp) { MR_HIP(hipEventRecord(ctx->ev_join_pt, st)); MR_HIP(hipStreamWaitEvent(s, ctx->ev_join_pt, 0)); }
-    if (sf != sp) { MR_HIP(hipEventRecord(ctx->ev_join_fin, sf)); MR_HIP(hipStreamWaitEvent(s, ctx->ev_join_fin, 0)); }
-    if (st2) { MR_HIP(hipEventRecord(ctx->ev_join_pt2, st2)); MR_HIP(hipStreamWaitEvent(s, ctx->ev_join_pt2, 0)); }
+    join.run();
     if (dbg_sum) {
         std::vector<unsigned long long> h(n_sums);
-        MR_HIP(hipStreamSynchronize(s)); MR_HIP(hipMemcpy(h.data(), d_sums, 8 * (size_t)n_sums, hipMemcpyDeviceToHost)); (void)hipFree(d_sums);
+        MR_HIP(hipStreamSynchronize(s)); MR_HIP(hipMemcpy(h.data(), d_sums, 8 * (size_t)n_sums, hipMemcpyDeviceToHost)); (void)hipFree(d_sums); d_sums = nullptr;
         for (int k = 0; k < n_sums; k++) fprintf(stderr, "[sum %d] %016llx\n", k, h[k]);
     }
     }

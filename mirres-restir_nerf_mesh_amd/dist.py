@@ -65,6 +65,7 @@ def render_sharded(ctx, worker, mlp_mat, env_map, g, spp, random_offset, rank, w
 
 # ------------------------------------------------------------------------------------------------ exact strip sharding
 HALO_ROWS = 30   # = mirres_config_t.gather_radius (SpatialResampling.slang:33-39)
+STRIP_ROW_QUANTUM = 32   # local strip frames are padded (background rows) to a multiple of this many rows: see render_strips
 
 
 def strip_bounds(fy, world, occ=None, fx=None, halo=HALO_ROWS, bg_weight=0.2):
@@ -188,14 +189,26 @@ def render_strips(ctx_full, worker, mlp_mat, env_map, g, spp, random_offset, ran
     bounds = strip_bounds(fy, world, g["occ"] if balanced else None, fx)      # cost-balanced strip heights (same on every rank)
     y0, y1, lo, hi = strip_rows(fy, rank, world, bounds=bounds)
     sl = slice(lo * fx, hi * fx)
-    loc = {k: g[k][sl].contiguous() for k in ("occ", "normal", "depth", "kd", "rm", "ray_dir", "pos")}
-    ctx_loc = get_ctx(fx, hi - lo, max_bounce)
+    # Balanced strip heights follow the view's occupancy, so every camera would ask for a context (and a multi-GB batch pool) of its own height.
+    # The local frame is therefore padded at the bottom with background rows (occ = 0: no stage works on them, no neighbour accepts them) up to a
+    # multiple of STRIP_ROW_QUANTUM rows: a multi-view run cycles through a handful of context sizes that the bounded cache (_ops.get_ctx) holds.
+    rows = hi - lo
+    rows_pad = -(-rows // STRIP_ROW_QUANTUM) * STRIP_ROW_QUANTUM
+
+    def _local(t):
+        t = t[sl]
+        if rows_pad == rows:
+            return t.contiguous()
+        out = torch.zeros((rows_pad * fx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        out[:rows * fx] = t
+        return out
+    loc = {k: _local(g[k]) for k in ("occ", "normal", "depth", "kd", "rm", "ray_dir", "pos")}
+    ctx_loc = get_ctx(fx, rows_pad, max_bounce)
     plan = halo_plan(fy, fx, rank, world, bounds=bounds)
-    n_loc = (hi - lo) * fx
 
     def _halo(user, records, sample, stream):
         try:
-            exchange_halos(device_view(records, (hi - lo, fx, 8)), plan, group)
+            exchange_halos(device_view(records, (rows_pad, fx, 8)), plan, group)
             return 0
         except Exception as e:      # surfaced by mirres_render as MIRRES_E_STATE
             import sys
@@ -244,17 +257,21 @@ def allreduce_gradients(tensors, group=None, average=True):
         return
     grads = []
     for t in tensors:
-        g = t.grad if isinstance(t, torch.nn.Parameter) or (t.requires_grad and t.grad is not None) else t
-        if g is None:
-            t.grad = torch.zeros_like(t); g = t.grad
+        if t.requires_grad:         # a parameter or a plain trainable leaf (the reference's `light_base`: EnvironmentLight is not an nn.Module)
+            if t.grad is None:      # e.g. a strip rank that saw only background: its contribution is zero, and it must still take part
+                t.grad = torch.zeros_like(t)
+            g = t.grad
+        else:
+            g = t                   # already a gradient tensor
         grads.append(g)
     if not grads:
         return
-    flat = torch.cat([g.reshape(-1).to(torch.float32) for g in grads])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-    if average:
-        flat /= dist.get_world_size(group)
-    o = 0
-    for g in grads:
-        n = g.numel()
-        g.copy_(flat[o:o + n].view_as(g)); o += n
+    with torch.no_grad():
+        flat = torch.cat([g.reshape(-1).to(torch.float32) for g in grads])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        if average:
+            flat /= dist.get_world_size(group)
+        o = 0
+        for g in grads:
+            n = g.numel()
+            g.copy_(flat[o:o + n].view_as(g)); o += n

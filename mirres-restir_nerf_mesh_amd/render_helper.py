@@ -75,6 +75,7 @@ class _MLP(torch.nn.Module):
 class _MatNetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, owner, pos, params, w0, w1, w2):
+        ctx.pos_dtype = pos.dtype
         pos = pos.detach().contiguous().float()
         n = pos.shape[0]
         out = torch.empty((n, 6), dtype=torch.float32, device=pos.device)
@@ -93,10 +94,15 @@ class _MatNetFn(torch.autograd.Function):
         w = [owner.net.net[i].weight for i in (0, 2, 4)]
         gw = [torch.zeros_like(t) for t in w]
         st = owner._struct()
+        # sample() is differentiable in its argument too (tcnn's HashGrid returns input gradients; the reference sends kd / ks loss and smoothness
+        # gradients to `vertices_offsets` this way, nerf/renderer.py:1017-1018): the x128 / /128 hooks cancel on this route (render_helper.py:41,78-80)
+        g_pos = torch.empty_like(pos) if ctx.needs_input_grad[1] else None
         check(lib().mirres_matnet_bwd(C.byref(st), pos.data_ptr(), pos.shape[0], grad_out.data_ptr(), gp.data_ptr(), gw[0].data_ptr(), gw[1].data_ptr(),
-                                      gw[2].data_ptr(), stream_ptr()), "mirres_matnet_bwd")
-        # the reference's hooks scale the gradient that reaches the encoder by 128 (render_helper.py:41,78-80)
-        return None, None, gp * GRADIENT_SCALING, gw[0], gw[1], gw[2]
+                                      gw[2].data_ptr(), g_pos.data_ptr() if g_pos is not None and pos.shape[0] else None, stream_ptr()), "mirres_matnet_bwd")
+        if g_pos is not None and g_pos.dtype != ctx.pos_dtype:
+            g_pos = g_pos.to(ctx.pos_dtype)
+        # the reference's hooks scale the gradient that reaches the encoder's parameters by 128
+        return None, g_pos, gp * GRADIENT_SCALING, gw[0], gw[1], gw[2]
 
 
 class MLPTexture3D(torch.nn.Module):

@@ -3,7 +3,12 @@ environment map from a reference checkpoint, dataset cameras from a NeRF-blender
 PSNR / SSIM against the dataset images when they can be read.
 
     python scripts/evaluate.py --workspace <ws> --ckpt <ws>/checkpoints/ngp_stage1_ep0100.pth --transforms <data>/transforms_test.json \
-        [--spp 512 --ssaa 2 --downscale 1 --cascade 1 --out <ws>/results_brdf --limit 0 --synthetic]
+        [--spp 512 --ssaa 2 --downscale 1 --bound 2 --roughness_min 0.08 --me_max 0 --out <ws>/results_brdf --limit 0 --synthetic]
+
+The material-field constants are the reference's CLI ones and MUST equal the training run's (nerf/network.py:119-125): `--bound` (hash-grid AABB
+= +-bound, main.py:39 default 2; also the mesh cascade count 1 + ceil(log2(bound)), nerf/renderer.py:97, unless `--cascade` overrides it),
+`--roughness_min` / `--me_max` (main.py:109-110,169-170) and, for completeness, `--kd_min` / `--kd_max` (main.py:167-168).  Checkpoints written by
+this package record them (`material_config`); a flag given on the command line wins, a mismatch with the recorded value is reported.
 
 `--synthetic` builds a throw-away workspace (synthetic mesh, random material field, sky map, four orbit cameras) first and evaluates that — the
 smoke run of this script on a box without a reference workspace.  Camera convention: the blender `transform_matrix` is the cam2world pose with its
@@ -33,7 +38,8 @@ def synthetic_workspace(root, H=100, W=100):
     with torch.no_grad():
         mlp.encoder.params.mul_(2e3)
     ck = os.path.join(root, "checkpoints", "ngp_stage1_ep0001.pth")
-    CK.save_checkpoint(ck, mlp, torch.zeros(v.shape[0], 3), torch.from_numpy(M.scene.make_env(64, 128)), epoch=1)
+    CK.save_checkpoint(ck, mlp, torch.zeros(v.shape[0], 3), torch.from_numpy(M.scene.make_env(64, 128)), epoch=1,
+                       material_config=CK.material_config(bound=1.0))
     frames = []
     for k in range(4):
         az, el = np.deg2rad(30.0 + 90.0 * k), np.deg2rad(30.0)
@@ -50,7 +56,12 @@ def main():
     p = argparse.ArgumentParser()
     p.add_argument("--workspace"); p.add_argument("--ckpt"); p.add_argument("--transforms"); p.add_argument("--out")
     p.add_argument("--spp", type=int, default=512); p.add_argument("--ssaa", type=int, default=2); p.add_argument("--downscale", type=int, default=1)
-    p.add_argument("--cascade", type=int, default=1); p.add_argument("--limit", type=int, default=0); p.add_argument("--H", type=int, default=800); p.add_argument("--W", type=int, default=800)
+    p.add_argument("--cascade", type=int, default=None, help="mesh cascades; default 1 + ceil(log2(bound)) as nerf/renderer.py:97")
+    p.add_argument("--bound", type=float, default=None, help="main.py --bound (default 2): material-field AABB = +-bound")
+    p.add_argument("--roughness_min", type=float, default=None, help="main.py --roughness_min (default 0.08)")
+    p.add_argument("--me_max", type=float, default=None, help="main.py --me_max (default 0.0)")
+    p.add_argument("--kd_min", type=float, nargs=3, default=None); p.add_argument("--kd_max", type=float, nargs=3, default=None)
+    p.add_argument("--limit", type=int, default=0); p.add_argument("--H", type=int, default=800); p.add_argument("--W", type=int, default=800)
     p.add_argument("--scale", type=float, default=1.0); p.add_argument("--offset", type=float, nargs=3, default=[0.0, 0.0, 0.0]); p.add_argument("--synthetic", action="store_true")
     a = p.parse_args()
     if a.synthetic:
@@ -59,10 +70,12 @@ def main():
     if not (a.workspace and a.ckpt and a.transforms):
         p.error("--workspace, --ckpt and --transforms are required (or --synthetic)")
     out_dir = a.out or os.path.join(a.workspace, "results_brdf")
-    v, t, v_cumsum, _ = CK.load_stage0_mesh(a.workspace, a.cascade)
     ck = CK.read_checkpoint(a.ckpt)
-    mn, mx = M.scene.material_min_max()          # --kd_min/--kd_max/--ks_min/--ks_max defaults of main.py
-    mlp = MLPTexture3D(torch.tensor([-1, -1, -1, 1, 1, 1], dtype=torch.float32), channels=6, min_max=(torch.from_numpy(mn).cuda(), torch.from_numpy(mx).cuda()))
+    cfg = CK.resolve_material_config(ck.get("material_config"), bound=a.bound, roughness_min=a.roughness_min, me_max=a.me_max, kd_min=a.kd_min, kd_max=a.kd_max)
+    cascade = a.cascade if a.cascade is not None else CK.cascade_of_bound(cfg["bound"])
+    v, t, v_cumsum, _ = CK.load_stage0_mesh(a.workspace, cascade)
+    aabb, mn, mx = CK.material_field_args(cfg)     # nerf/network.py:119-125
+    mlp = MLPTexture3D(aabb, channels=6, min_max=(mn.cuda(), mx.cuda()))
     voff, light = CK.apply_checkpoint(ck, mlp, n_vertices=v.shape[0])
     if light is None:
         raise SystemExit("%s has no light_base (a --use_brdf stage-1 checkpoint is needed)" % a.ckpt)

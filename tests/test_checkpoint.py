@@ -91,3 +91,33 @@ def test_read_checkpoint_in_the_reference_layout(tmp_path):
     assert r4["grid_params"] is None and r4["mlp_weights"] is None and r4["vertices_offsets"] is None
     with pytest.raises(KeyError):
         CK.apply_checkpoint(r4, mlp_mat=object())
+
+
+def test_material_field_constants_follow_the_reference_cli():
+    """nerf/network.py:119-125 + main.py:39,109-110,167-170: AABB = +-bound, min = (kd_min, 0, roughness_min, 0), max = (kd_max, 0, 1, me_max);
+    cascades = 1 + ceil(log2(bound)) (nerf/renderer.py:97).  A reference checkpoint records none of them: evaluation warns and uses main.py's defaults;
+    command-line values win over recorded ones and a mismatch is reported."""
+    aabb, mn, mx = CK.material_field_args(CK.material_config())
+    assert aabb.tolist() == [-2, -2, -2, 2, 2, 2] and mn.tolist() == pytest.approx([0, 0, 0, 0, 0.08, 0]) and mx.tolist() == [1, 1, 1, 0, 1, 0]
+    aabb, mn, mx = CK.material_field_args(CK.material_config(bound=1, me_max=0.5, roughness_min=0.2))     # configs/OWL/gamepad.txt: --me_max 0.5
+    assert aabb.tolist() == [-1, -1, -1, 1, 1, 1] and mn[4].item() == pytest.approx(0.2) and mx.tolist() == [1, 1, 1, 0, 1, 0.5]
+    assert [CK.cascade_of_bound(b) for b in (0.5, 1, 1.5, 2, 3, 4, 16)] == [1, 1, 2, 2, 3, 3, 5]
+    with pytest.raises(KeyError):
+        CK.material_config(bond=1)
+    msgs = []
+    c = CK.resolve_material_config(None, warn=msgs.append, me_max=0.5)
+    assert c["bound"] == 2.0 and c["me_max"] == 0.5 and len(msgs) == 1 and "--bound 2.0" in msgs[0] and "me_max" not in msgs[0]
+    msgs.clear()
+    c = CK.resolve_material_config(dict(bound=1.0, me_max=0.5), warn=msgs.append)
+    assert c["bound"] == 1.0 and c["me_max"] == 0.5 and c["roughness_min"] == 0.08 and not msgs
+    c = CK.resolve_material_config(dict(bound=1.0, me_max=0.5), warn=msgs.append, bound=2.0, me_max=0.5)
+    assert c["bound"] == 2.0 and len(msgs) == 1 and "--bound" in msgs[0]
+
+
+def test_read_checkpoint_returns_recorded_material_constants(tmp_path):
+    ck = _reference_layout()
+    p = str(tmp_path / "a.pth"); torch.save(ck, p)
+    assert CK.read_checkpoint(p)["material_config"] is None                    # the reference's own files carry none
+    ck["material_config"] = CK.material_config(bound=1.0, me_max=0.5)
+    p = str(tmp_path / "b.pth"); torch.save(ck, p)
+    assert CK.read_checkpoint(p)["material_config"]["me_max"] == 0.5

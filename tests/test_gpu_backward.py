@@ -155,3 +155,50 @@ def test_matnet_backward(env, oracle, scene_mod):
         P.copy_(base + eps * d); a = float(loss()); P.copy_(base - eps * d); b = float(loss()); P.copy_(base)
     num = (a - b) / (2 * eps)
     assert ana > 0 and abs(ana - num) <= 0.05 * abs(num), (ana, num)
+
+
+def test_matnet_position_gradient(oracle, scene_mod):
+    """MLPTexture3D.sample is differentiable in its argument (tcnn's HashGrid input gradient; the reference routes kd / ks loss gradients to
+    `vertices_offsets` through it, nerf/renderer.py:1017-1018).  mirres_matnet_bwd's d/dpos against autograd through a plain-torch fp64 restatement
+    of the same field (tests/util.py): inside the AABB, on its faces (torch.clamp passes the gradient at 0 and 1) and outside (blocked)."""
+    import torch
+    from util import torch_material_field
+    from mirres_restir_nerf_mesh_amd.render_helper import MLPTexture3D
+    params, w0, w1, w2 = scene_mod.make_matnet_params(seed=4)
+    mn, mx = scene_mod.material_min_max(me_max=0.6)
+    lo, hi = (-1.0, -2.0, -1.0), (1.0, 2.0, 3.0)                     # anisotropic box: the 1 / (max - min) factor differs per axis
+    mlp = MLPTexture3D(torch.tensor(lo + hi, dtype=torch.float32), channels=6, min_max=(torch.from_numpy(mn).cuda(), torch.from_numpy(mx).cuda()), seed=1)
+    with torch.no_grad():
+        mlp.encoder.params.copy_(torch.from_numpy(params).cuda())
+        for i, w in zip((0, 2, 4), (w0, w1, w2)):
+            mlp.net.net[i].weight.copy_(torch.from_numpy(w).cuda())
+    g = torch.Generator(device="cuda").manual_seed(7)
+    n = 20000
+    u = torch.rand((n, 3), device="cuda", generator=g) * 1.2 - 0.1              # normalised coordinates in [-0.1, 1.1]: some points outside
+    u[:6] = torch.tensor([[0, 0.3, 0.4], [1, 0.5, 0.5], [0.2, 0, 1], [0.5, 0.5, 0.5], [-0.01, 0.5, 0.5], [0.5, 1.01, 0.5]], device="cuda")
+    lo_t, hi_t = torch.tensor(lo, device="cuda"), torch.tensor(hi, device="cuda")
+    pos = (lo_t + u * (hi_t - lo_t)).contiguous()
+    wgt = torch.rand((n, 6), device="cuda", generator=g)
+    p1 = pos.clone().requires_grad_(True)
+    out = mlp.sample(p1)
+    (out * wgt).sum().backward()
+    assert p1.grad is not None and p1.grad.shape == (n, 3) and torch.isfinite(p1.grad).all()
+    p2 = pos.clone().requires_grad_(True)
+    ref = torch_material_field(oracle, params, w0, w1, w2, lo, hi, mn, mx, p2)
+    (ref * wgt.double()).sum().backward()
+    assert float((out.detach().double() - ref.detach()).abs().max()) < 2e-4           # forward: fp16 interpolation against fp64
+    got, want = p1.grad.double(), p2.grad
+    xn = (pos.double() - lo_t.double()) / (hi_t.double() - lo_t.double())
+    outside = (xn < 0) | (xn > 1)
+    assert outside.any() and bool((got[outside] == 0).all()) and bool((want[outside] == 0).all())
+    assert bool((got[1, 0] != 0)) and bool((got[0, 0] != 0))                             # on the faces x = 1 / x = 0 the gradient passes (clamp is inclusive)
+    scale = want.abs().mean()
+    err = (got - want).abs()
+    # the forward's fp16 rounding can flip a ReLU that sits at zero: a handful of points differ by a whole unit's contribution
+    ok = err <= 2e-3 * want.abs() + 2e-3 * scale
+    assert float(ok.double().mean()) > 0.995, (float(ok.double().mean()), float(err.max()), float(scale))
+    assert float((got * want).sum() / (want * want).sum()) == pytest.approx(1.0, abs=2e-3)
+    # a detached argument gets no gradient buffer and the parameter gradients are unchanged by asking for d/dpos
+    mlp.zero_grad(); (mlp.sample(pos) * wgt).sum().backward(); gp0 = mlp.encoder.params.grad.clone(); gw0 = mlp.net.net[0].weight.grad.clone()
+    mlp.zero_grad(); p3 = pos.clone().requires_grad_(True); (mlp.sample(p3) * wgt).sum().backward()
+    assert torch.allclose(mlp.encoder.params.grad, gp0, rtol=1e-4, atol=1e-6 * float(gp0.abs().max())) and torch.allclose(mlp.net.net[0].weight.grad, gw0, rtol=1e-3, atol=1e-5 * float(gw0.abs().max()))

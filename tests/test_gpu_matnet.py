@@ -113,6 +113,11 @@ def test_checkpoint_round_trip_through_the_reference_layout(scene_mod, tmp_path)
     r = CK.read_checkpoint(p)
     voff2, light2 = CK.apply_checkpoint(r, b, n_vertices=100)
     assert torch.equal(a.sample(x), b.sample(x)) and torch.equal(voff2, voff) and torch.equal(light2, light) and r["global_step"] == 77
+    # the constants that decode the field (AABB / output ranges: the reference's --bound, --roughness_min, --me_max) are recorded from the module
+    mc = r["material_config"]
+    assert mc["bound"] == 1.0 and mc["roughness_min"] == pytest.approx(0.08) and mc["me_max"] == 0.0
+    aabb, mn2, mx2 = CK.material_field_args(CK.resolve_material_config(mc))
+    assert aabb.tolist() == [-1, -1, -1, 1, 1, 1] and np.allclose(mn2.numpy(), mn) and np.allclose(mx2.numpy(), mx)
     r["grid_params"] = r["grid_params"][:-2]
     with pytest.raises(ValueError, match="encoder.params"):
         CK.apply_checkpoint(r, b)

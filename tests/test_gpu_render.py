@@ -486,3 +486,60 @@ def test_frame_refuses_wrongly_sized_inputs(oracle, scene_mod):
                      ("occ", good["occ"][:-3]), ("env", good["env"].reshape(-1, 3))):
         with pytest.raises(MirresError):
             call(**{key: bad.contiguous()})
+
+
+def test_context_cache_is_bounded_and_keyed_by_the_resolved_configuration(monkeypatch):
+    """_ops.get_ctx: `max_bounce=None` and the configuration default share one context (one batch pool), the cache holds at most MIRRES_CTX_CACHE
+    contexts (least recently used dropped first) and a dropped context is destroyed once nothing refers to it."""
+    import gc, weakref
+    from mirres_restir_nerf_mesh_amd import _ops, _lib
+    monkeypatch.setenv("MIRRES_CTX_CACHE", "2")
+    _ops._CTX_CACHE.clear()
+    d = int(_lib.default_config().max_bounce)
+    a = _ops.get_ctx(24, 16)
+    assert _ops.get_ctx(24, 16, max_bounce=d) is a and _ops.get_ctx(24, 16, None) is a and len(_ops._CTX_CACHE) == 1
+    b = _ops.get_ctx(24, 16, max_bounce=d + 1)
+    assert b is not a and len(_ops._CTX_CACHE) == 2
+    wa = weakref.ref(a); ha = a.h
+    _ops.get_ctx(24, 16)                      # touch a: b is now the least recently used
+    c = _ops.get_ctx(32, 16)
+    assert len(_ops._CTX_CACHE) == 2 and _ops.get_ctx(24, 16) is a and _ops.get_ctx(32, 16) is c
+    wb = weakref.ref(b); del b; gc.collect()
+    assert wb() is None                       # evicted and unreferenced: destroyed (its pools are freed in __del__)
+    del a; gc.collect()
+    assert wa() is not None                   # still cached
+    _ops._CTX_CACHE.clear(); del c; gc.collect()
+    assert wa() is None
+
+
+def test_batch_pool_fallback_keeps_the_frame_and_is_remembered(oracle, scene_mod, monkeypatch):
+    """When the device cannot hold the K-sample batch pool, carve_batch halves K until it fits (MIRRES_POOL_LIMIT_MB stands in for a full HBM),
+    remembers the size that fitted for the following frames, and — the frame being independent of the batch size — returns the same bits."""
+    F, W, mods, RR, torch = _setup(oracle, scene_mod, fx=40, fy=32)
+    from mirres_restir_nerf_mesh_amd import _ops
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    def frame(ctx):
+        outs, _, _ = RR.render_fused(ctx, W, None, False, (1, 1, 1), cu(F.env), cu(F.occ[:, None].copy()), cu(F.normal), cu(F.depth[:, None]), cu(F.kd), cu(F.rm),
+                                     cu(F.ray_dir_raw), cu(F.pos), 8, 2, 2, 2.0, 0.1, 0.001, 31337)
+        torch.cuda.synchronize()
+        return [o.clone() for o in outs]
+    _ops._CTX_CACHE.clear()
+    ref = frame(_ops.get_ctx(F.fx, F.fy))                 # 8 samples in one batch
+    _ops._CTX_CACHE.clear()
+    # ~670 B per slot x 1280 pixels ~ 0.86 MB per sample + 8 MB of light tiles per sample: a 30 MB cap admits a batch of 2 or 3, not 8
+    monkeypatch.setenv("MIRRES_POOL_LIMIT_MB", "30")
+    ctx = _ops.get_ctx(F.fx, F.fy)
+    a = frame(ctx); b = frame(ctx)
+    for x, y, z in zip(ref, a, b):
+        assert torch.equal(x, y) and torch.equal(x, z)
+    monkeypatch.setenv("MIRRES_POOL_LIMIT_MB", "1")       # not even one sample fits: a clean error, and the context recovers afterwards
+    _ops._CTX_CACHE.clear()
+    ctx = _ops.get_ctx(F.fx, F.fy)
+    from mirres_restir_nerf_mesh_amd._lib import MirresError
+    with pytest.raises(MirresError, match="batch pool"):
+        frame(ctx)
+    monkeypatch.delenv("MIRRES_POOL_LIMIT_MB")
+    c = frame(ctx)
+    for x, y in zip(ref, c):
+        assert torch.equal(x, y)
+    _ops._CTX_CACHE.clear()

@@ -160,8 +160,14 @@ def _grad_worker(rank, world, port, out):
     torch.manual_seed(0)
     w = torch.nn.Parameter(torch.zeros(7, 3)); e = torch.nn.Parameter(torch.zeros(4, 5, 3)); unused = torch.nn.Parameter(torch.zeros(2))
     w.grad = torch.full((7, 3), float(rank + 1)); e.grad = torch.arange(60, dtype=torch.float32).reshape(4, 5, 3) * (rank + 1)
-    allreduce_gradients([w, e, unused])
-    torch.save(dict(w=w.grad, e=e.grad, u=unused.grad), os.path.join(out, "g%d.pt" % rank))
+    # the reference's `light_base` is a plain leaf tensor with requires_grad (EnvironmentLight is not an nn.Module, nerf/utils.py:1853): rank 1 saw only
+    # background and has no gradient for it — its VALUES must not enter the bucket; `raw` is an already-formed gradient tensor
+    light = torch.full((3, 2, 3), 0.5 + rank, requires_grad=True)
+    if rank == 0:
+        light.grad = torch.full((3, 2, 3), 4.0)
+    raw = torch.full((5,), 10.0 * (rank + 1))
+    allreduce_gradients([w, e, unused, light, raw])
+    torch.save(dict(w=w.grad, e=e.grad, u=unused.grad, light=light.detach(), lg=light.grad, raw=raw), os.path.join(out, "g%d.pt" % rank))
     dist.destroy_process_group()
 
 
@@ -176,6 +182,8 @@ def test_gradient_allreduce_gloo_world2(tmp_path):
         assert torch.allclose(d["w"], torch.full((7, 3), 1.5))
         assert torch.allclose(d["e"], torch.arange(60, dtype=torch.float32).reshape(4, 5, 3) * 1.5)
         assert torch.equal(d["u"], torch.zeros(2))
+        assert torch.equal(d["light"], torch.full((3, 2, 3), 0.5 + r)) and torch.allclose(d["lg"], torch.full((3, 2, 3), 2.0))   # values untouched, missing grad = 0
+        assert torch.allclose(d["raw"], torch.full((5,), 15.0))
 
 
 def test_rgbe_roundtrip(tmp_path):

@@ -60,3 +60,42 @@ def match_fraction(a, b, rtol=1e-4, atol=1e-6):
 def psnr(a, b, peak=1.0):
     mse = float(np.mean((np.asarray(a, np.float64) - np.asarray(b, np.float64)) ** 2))
     return 99.0 if mse == 0 else 10.0 * np.log10(peak * peak / mse)
+
+
+def torch_material_field(O, params_f32, w0, w1, w2, aabb_min, aabb_max, mn, mx, pos, dtype=None):
+    """Plain-torch reference of MLPTexture3D.sample (render_helper.py:93-104) with autograd: position normalisation + clamp, the hash-grid encoding
+    (tcnn's published algorithm: `fmaf(scale, x, 0.5)`, floor, 8-corner trilinear weights, dense / coherent-prime-hash index; the table holds the
+    fp16-rounded parameters but the interpolation is carried out in `dtype`, not fp16), the bias-free 32-32-32-6 ReLU MLP, sigmoid and range.
+    `pos` may require grad; everything stays on pos.device.  The level layout comes from the oracle (`hashgrid_layout`)."""
+    import torch
+    dtype = dtype or torch.float64
+    dev = pos.device
+    total, off, res, sc = O.hashgrid_layout()
+    tab = torch.from_numpy(O.to_f16_bits(params_f32).view(np.float16).astype(np.float64).reshape(-1, 2)).to(dev, dtype)
+    lo = torch.tensor(aabb_min, dtype=dtype, device=dev); hi = torch.tensor(aabb_max, dtype=dtype, device=dev)
+    x = torch.clamp((pos.to(dtype) - lo) / (hi - lo), 0, 1)
+    feats = []
+    for lv in range(16):
+        size = int(off[lv + 1]) - int(off[lv]); r = int(res[lv])
+        q = float(sc[lv]) * x + 0.5
+        cell = torch.floor(q.detach()).to(torch.int64)
+        w = q - cell.to(dtype)
+        acc = 0
+        for idx in range(8):
+            c = [cell[:, d] + ((idx >> d) & 1) for d in range(3)]
+            wt = 1
+            for d in range(3):
+                wt = wt * (w[:, d] if (idx >> d) & 1 else 1 - w[:, d])
+            if r * r * r <= size:          # dense level (the stride never exceeds the level's size)
+                index = c[0] + c[1] * r + c[2] * r * r
+            else:
+                m32 = 0xFFFFFFFF
+                index = ((c[0] * 1) & m32) ^ ((c[1] * 2654435761) & m32) ^ ((c[2] * 805459861) & m32)
+            index = index % size + int(off[lv])
+            acc = acc + wt[:, None] * tab[index]
+        feats.append(acc)
+    a = torch.cat(feats, dim=1)
+    W = [torch.as_tensor(t).to(dev, dtype) for t in (w0, w1, w2)]
+    h = torch.relu(a @ W[0].T); h = torch.relu(h @ W[1].T); z = h @ W[2].T
+    mn_t = torch.tensor(np.asarray(mn, np.float64), device=dev, dtype=dtype); mx_t = torch.tensor(np.asarray(mx, np.float64), device=dev, dtype=dtype)
+    return torch.sigmoid(z) * (mx_t - mn_t) + mn_t
