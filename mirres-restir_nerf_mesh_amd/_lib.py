@@ -3,7 +3,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmirres.so")
+# MIRRES_LIB: another build of the same library (A/B measurements of kernel variants); it must export the full ABI like the in-tree one
+LIB_PATH = os.environ.get("MIRRES_LIB") or os.path.join(_HERE, "libmirres.so")
 _lib = None
 
 vp = C.c_void_p

@@ -391,7 +391,7 @@ __global__ void __launch_bounds__(256) k_pack4q(int T, const int32_t* __restrict
     float cb[4][6];
     for (int k = 0; k < nc; k++) for (int a = 0; a < 6; a++) cb[k][a] = aabb[6 * (size_t)c[k] + a];
     Node4q n;
-    n.exps = 0; n.pad[0] = n.pad[1] = 0;
+    n.step_x = n.step_y = n.step_z = 0.f;
     for (int a = 0; a < 3; a++) {
         float lo = cb[0][a], hi = cb[0][3 + a];
         for (int k = 1; k < nc; k++) { lo = fminf(lo, cb[k][a]); hi = fmaxf(hi, cb[k][3 + a]); }
@@ -415,7 +415,7 @@ __global__ void __launch_bounds__(256) k_pack4q(int T, const int32_t* __restrict
             }
             wlo |= ql << (8 * k); whi |= qh << (8 * k);
         }
-        n.org[a] = lo; n.exps |= E << (8 * a); n.qlo[a] = wlo; n.qhi[a] = whi;
+        n.org[a] = lo; (a == 0 ? n.step_x : a == 1 ? n.step_y : n.step_z) = st; n.qlo[a] = wlo; n.qhi[a] = whi;
     }
     for (int k = 0; k < 4; k++) n.ref[k] = (k < nc) ? ((c[k] >= LEAF) ? ~(c[k] - LEAF) : c[k]) : 0x7fffffff;
     nodes4q[g] = n;
@@ -445,7 +445,7 @@ __global__ void __launch_bounds__(256) k_top4q(int T, const Node4q* __restrict__
         const int id = s_id[e];
         Node4q n;
         if (id >= 0) n = nodes4q[id];
-        else { n.org[0] = n.org[1] = n.org[2] = 0.f; n.exps = 0x434343u; for (int a = 0; a < 3; a++) { n.qlo[a] = 0xffffffffu; n.qhi[a] = 0u; } n.pad[0] = n.pad[1] = 0;
+        else { n.org[0] = n.org[1] = n.org[2] = 0.f; n.step_x = n.step_y = n.step_z = q_step(67u); for (int a = 0; a < 3; a++) { n.qlo[a] = 0xffffffffu; n.qhi[a] = 0u; }
                for (int k = 0; k < 4; k++) n.ref[k] = 0x7fffffff; }
         for (int k = 0; k < 4; k++) {
             const int cslot = 4 * e + 1 + k;

@@ -387,6 +387,61 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_persist(BvhView B, con
 // vector-L1 lookups of divergent gathers); (b' - o) * inv is monotone in b', so a decoded box passes whenever the exact one does and no
 // leaf the reference visits is missed. A leaf that passes the conservative test is re-tested against its exact LBVH box (LeafRec) before
 // the triangle test, so the set of triangles tested — and therefore the result — is the reference's, bit for bit.
+// ---------------------------------------------------------------- interior boxes of the compressed tree: one fma per plane
+// Interior boxes only steer the search: any test that passes whenever the exact slab test of a descendant leaf's own box passes is admissible
+// (see above). The decoded-plane test  t = (fmaf(q, s, g) - o) * inv  costs cvt + fma + sub + mul per plane; algebraically it is
+//   t = q * (s * inv) + (g - o) * inv,
+// i.e. ONE fma per plane once  S = s * inv  (exact: s is a power of two) and  B = (g - o) * inv  are formed per node and axis. The two
+// expressions round differently, so the fused one is made conservative by a margin m per axis, subtracted from the entry and added to the exit
+// distances. With u = 2^-24, D = q s + g the decoded plane (|D| <= Bs, the largest coordinate magnitude of the scene box) and R = (D - o) inv:
+//   decoded form:  |t_dec - R|  <=  u |inv| (|D| + 2 |D - o|)            <= 3 u |inv| (Bs + |o|)
+//   fused form:    |t_fus -+ m - R| <= u |inv| (2 |g - o| + 2 |D - o|) + 2 u m  <= 4 u |inv| (Bs + |o|) + 2 u m
+// so m = 16 u |inv| (Bs + |o|) = 2^-20 |inv| (Bs + |o|) puts the fused entry distance at or below, and the fused exit distance at or above, the
+// decoded ones — which in turn bound every descendant leaf's exact slab values (monotonicity of (b - o) * inv in b, DESIGN.md §Traversal
+// exactness). The margin is ~1e-6 of the scene size in t: nothing against the 8-bit quantisation of the boxes. Directions with an infinite
+// reciprocal (a denormal component) yield inf / NaN planes on that axis; fmaxf / fminf drop NaNs, +-inf margins only widen, and a normalised
+// direction has at least one finite reciprocal, so such a ray is tested on its remaining axes: permissive, never wrong.
+struct RayCons { float mx, my, mz; };
+MR_DEV float scene_bound(const float* __restrict__ root_box) {
+    float b = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; i++) b = fmaxf(b, fabsf(root_box[i]));
+    return b;
+}
+MR_DEV RayCons ray_margins(float bs, float ox, float oy, float oz, float ix, float iy, float iz) {
+    RayCons c; const float k = 9.5367431640625e-07f;   // 2^-20
+    c.mx = k * fabsf(ix) * (bs + fabsf(ox)); c.my = k * fabsf(iy) * (bs + fabsf(oy)); c.mz = k * fabsf(iz) * (bs + fabsf(oz));
+    return c;
+}
+struct NodeCons { float Sx, Sy, Sz, Bnx, Bny, Bnz, Bfx, Bfy, Bfz; uint32_t nqx, fqx, nqy, fqy, nqz, fqz; };
+MR_DEV NodeCons node_cons(const uint4& h0, const uint4& h1, const uint4& h2, float ox, float oy, float oz, float ix, float iy, float iz, const RayCons& m) {
+    NodeCons c;
+    const float gx = __uint_as_float(h0.x), gy = __uint_as_float(h0.y), gz = __uint_as_float(h0.z);
+    const float sx = __uint_as_float(h0.w), sy = __uint_as_float(h2.z), sz = __uint_as_float(h2.w);   // Node4q::step_x/y/z
+    // near / far plane of each axis picked by the sign of the direction (nqx = the byte word holding the planes the ray meets first); an unused
+    // entry has lo = 255 > hi = 0 on every axis (entry beyond exit by the whole node extent) and is also excluded by its reference
+    c.nqx = ix >= 0.f ? h1.x : h1.w; c.fqx = ix >= 0.f ? h1.w : h1.x;
+    c.nqy = iy >= 0.f ? h1.y : h2.x; c.fqy = iy >= 0.f ? h2.x : h1.y;
+    c.nqz = iz >= 0.f ? h1.z : h2.y; c.fqz = iz >= 0.f ? h2.y : h1.z;
+    c.Sx = sx * ix; c.Sy = sy * iy; c.Sz = sz * iz;
+    const float bx = (gx - ox) * ix, by = (gy - oy) * iy, bz = (gz - oz) * iz;
+    c.Bnx = bx - m.mx; c.Bny = by - m.my; c.Bnz = bz - m.mz;
+    c.Bfx = bx + m.mx; c.Bfy = by + m.my; c.Bfz = bz + m.mz;
+    return c;
+}
+// entry / exit distance of child k (compile-time k: the byte selects fold into v_cvt_f32_ubyteK)
+template <int K>
+MR_DEV void child_slab(const NodeCons& c, float t_min, float& tn, float& tf) {
+    const float nx = fmaf((float)((c.nqx >> (8 * K)) & 0xffu), c.Sx, c.Bnx), fx_ = fmaf((float)((c.fqx >> (8 * K)) & 0xffu), c.Sx, c.Bfx);
+    const float ny = fmaf((float)((c.nqy >> (8 * K)) & 0xffu), c.Sy, c.Bny), fy_ = fmaf((float)((c.fqy >> (8 * K)) & 0xffu), c.Sy, c.Bfy);
+    const float nz = fmaf((float)((c.nqz >> (8 * K)) & 0xffu), c.Sz, c.Bnz), fz_ = fmaf((float)((c.fqz >> (8 * K)) & 0xffu), c.Sz, c.Bfz);
+    tn = fmaxf(fmaxf(fmaxf(nx, ny), nz), t_min);
+    tf = fminf(fminf(fx_, fy_), fz_);
+}
+MR_DEV void child_slabs(const NodeCons& c, float t_min, float tn[4], float tf[4]) {
+    child_slab<0>(c, t_min, tn[0], tf[0]); child_slab<1>(c, t_min, tn[1], tf[1]); child_slab<2>(c, t_min, tn[2], tf[2]); child_slab<3>(c, t_min, tn[3], tf[3]);
+}
+
 template <bool FRONT = false>   // FRONT: a conventional occlusion query — the hit must lie in front of the origin (t > 0); the reference's bvh_hit does not look at t
 MR_DEV bool tri_accepts_regs(float4 a, float4 b, float4 c, v3 ro, v3 d) {
     const v3 v0 = V3(a.x, a.y, a.z), E1 = V3(a.w, b.x, b.y), E2 = V3(b.z, b.w, c.x);
@@ -403,6 +458,12 @@ MR_DEV bool tri_accepts_regs(float4 a, float4 b, float4 c, v3 ro, v3 d) {
     if (FRONT) return dot(E2, Q) * invDet > 0.f;
     return true;
 }
+#ifdef MR_EXP_PHASES   // experiment: where a shadow-ray wave spends its cycles (s_memtime around the phases; B.dbg gets 5 words per wave)
+#define MR_PH_NOW() ({ asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); (long long)clock64(); })
+#define MR_PH(x) x
+#else
+#define MR_PH(x)
+#endif
 // TIMED = 2: front-only occlusion (nerf/render_dump.py's external `intersector`, a conventional ray tracer) — the same traversal with t > 0 required
 template <bool COUNT, int TOPN, int TIMED = 0>   // TIMED: identical code under a second name, launched by bench.py's event-timed frame so that a rocprofv3
                                                  // kernel trace of the same command shows those launches as their own row
@@ -416,7 +477,9 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const
         for (int i = threadIdx.x; i < TOPN * 4; i += MR_TRACE_BLOCK) s_top[i] = src[i];
         __syncthreads();
     }
+#ifndef MR_EXP_PHASES
     if (B.dbg && (threadIdx.x & 63) == 0) B.dbg[2 * (blockIdx.x * (MR_TRACE_BLOCK / 64) + (threadIdx.x >> 6))] = wall_clock64();
+#endif
     uint32_t* const lds_stack = lds + threadIdx.x;
     const uint32_t n = d_count ? *d_count : n_fixed;
     const int lane = lane_id();
@@ -429,10 +492,14 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const
     bool exhausted = false, have = false;
     float ox = 0, oy = 0, oz = 0, ix = 0, iy = 0, iz = 0; v3 d = V3(0.f), ro = V3(0.f);
     float t_min = 0.f, t_max = 0.f;
+    RayCons rc; rc.mx = rc.my = rc.mz = 0.f;
+    const float scene_bs = scene_bound(B.root_box);
     int cur = 0, sp = 0, sbase = 0; uint32_t ridx = 0;   // the lane's deferred entries live in [sbase, sp)
     uint32_t spill[MR_STACK - MR_ANY_LDS];
     unsigned long long c_boxes = 0, c_nodes = 0, c_leaves = 0;
+    MR_PH(long long ph_refill = 0; long long ph_mem = 0; long long ph_cmp = 0; long long ph_iters = 0; const long long ph_begin = MR_PH_NOW();)
     while (true) {
+        MR_PH(const long long ph_a = MR_PH_NOW();)
         const uint64_t need = __ballot(!have);
         if (need && exhausted) {
             // ---- the tail of the launch: the queue is empty and the wave waits for its longest rays. A shadow ray's answer is an OR over subtrees, so
@@ -455,6 +522,7 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const
                 const int s_base = __shfl(sbase, src, 64);
                 if (take) {
                     ox = s_ox; oy = s_oy; oz = s_oz; ix = s_ix; iy = s_iy; iz = s_iz; d = V3(s_dx, s_dy, s_dz); ro = V3(s_ox, s_oy, s_oz);
+                    rc = ray_margins(scene_bs, ox, oy, oz, ix, iy, iz);
                     t_min = s_tmin; t_max = s_tmax; ridx = s_ridx;
                     cur = (int)lds[s_base * MR_TRACE_BLOCK + ((threadIdx.x & ~63) | src)];
                     sp = 0; sbase = 0; have = true;
@@ -475,6 +543,7 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const
                       if (dx == 0.f) dx = 0.000001f; if (dy == 0.f) dy = 0.000001f; if (dz == 0.f) dz = 0.000001f;
                       ix = 1.0f / dx; iy = 1.0f / dy; iz = 1.0f / dz; }
                     sp = 0; sbase = 0;
+                    rc = ray_margins(scene_bs, ox, oy, oz, ix, iy, iz);
                     hit_out[idx] = 0;          // set to 1 by whichever lane finds an occluder (the owner or, in the tail, a helper)
                     const float o3[3] = {ox, oy, oz}, i3[3] = {ix, iy, iz};
                     Slab s0 = slab(B.root_box, B.root_box + 3, o3, i3, t_min);
@@ -485,8 +554,10 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const
                 chunk_next = (chunk_next + want < chunk_end) ? chunk_next + want : chunk_end;
             }
         }
+        MR_PH(ph_refill += MR_PH_NOW() - ph_a;)
         if (!__ballot(have)) { if (exhausted) break; else continue; }
         do {
+            MR_PH(const long long ph_0 = MR_PH_NOW(); long long ph_1 = ph_0; ph_iters++;)
             if (have) {
                 // one 64-byte record per iteration — a Node4q or a LeafRec — fetched before the type is looked at, so that a wave pays ONE memory
                 // round trip per iteration however its lanes split between nodes and leaves (the slowest lane sets the wave's pace)
@@ -500,6 +571,7 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const
                     h0 = nd[0]; h1 = nd[1]; h2 = nd[2]; rf = nd[3];
                     if (COUNT) c_nodes++;    // 64-byte records fetched from global memory (nodes served from LDS are not charged)
                 }
+                MR_PH(asm volatile("" :: "v"(h0.x), "v"(h1.x), "v"(h2.x), "v"(rf.x), "v"(rf.w)); ph_1 = MR_PH_NOW();)
                 bool hit = false;
                 int next = 0x7fffffff; float next_tn = 0.f;
                 if (leaf) {
@@ -516,26 +588,21 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const
                     if (COUNT) c_boxes++;
                     if (etf > etn && t_max > etn) { hit = tri_accepts_regs<TIMED == 2>(l0, l1, l2, ro, d); if (COUNT) c_leaves++; }
                 } else {
-                    const float gx = __uint_as_float(h0.x), gy = __uint_as_float(h0.y), gz = __uint_as_float(h0.z);
-                    const float sx = __uint_as_float((h0.w & 0xffu) << 23), sy = __uint_as_float((h0.w & 0xff00u) << 15), sz = __uint_as_float((h0.w & 0xff0000u) << 7);
-                    const uint32_t nqx = ix >= 0.f ? h1.x : h1.w, fqx = ix >= 0.f ? h1.w : h1.x;
-                    const uint32_t nqy = iy >= 0.f ? h1.y : h2.x, fqy = iy >= 0.f ? h2.x : h1.y;
-                    const uint32_t nqz = iz >= 0.f ? h1.z : h2.y, fqz = iz >= 0.f ? h2.y : h1.z;
+                    // conservative boxes: one fma per plane (node_cons / child_slab above)
+                    const NodeCons nc = node_cons(h0, h1, h2, ox, oy, oz, ix, iy, iz, rc);
                     const int ref[4] = {(int)rf.x, (int)rf.y, (int)rf.z, (int)rf.w};
+                    float tn4[4], tf4[4];
+                    child_slabs(nc, t_min, tn4, tf4);
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
-                        // conservative box: decode (exactly the expression k_pack4q rounded against), then the reference's slab test
-                        // near / far plane of each axis picked by the sign of the direction (nqx = the byte word holding the planes the ray meets first):
-                        // (near - o) * inv <= (far - o) * inv exactly as min / max of the two products would give; an unused entry has lo = 255 > hi = 0
-                        // on every axis, hence tn > tf and it fails by itself
-                        const float nx = (fmaf((float)((nqx >> (8 * k)) & 0xffu), sx, gx) - ox) * ix, fx_ = (fmaf((float)((fqx >> (8 * k)) & 0xffu), sx, gx) - ox) * ix;
-                        const float ny = (fmaf((float)((nqy >> (8 * k)) & 0xffu), sy, gy) - oy) * iy, fy_ = (fmaf((float)((fqy >> (8 * k)) & 0xffu), sy, gy) - oy) * iy;
-                        const float nz = (fmaf((float)((nqz >> (8 * k)) & 0xffu), sz, gz) - oz) * iz, fz_ = (fmaf((float)((fqz >> (8 * k)) & 0xffu), sz, gz) - oz) * iz;
-                        const float tn = fmaxf(fmaxf(fmaxf(nx, ny), nz), t_min);
-                        const float tf = fminf(fminf(fx_, fy_), fz_);
-                        const bool ok = tf > tn && t_max > tn;
+                        const float tn = tn4[k], tf = tf4[k];
+                        // interior boxes only steer: `t_max > tn` (a pure cull; the leaf's exact test applies it) is left out — every compare is 4 issue
+                        // cycles per wave (scripts/ubench/valu_rates.hip) and shadow rays towards the environment have no far limit to cull with.
+                        // Unused slots (lo = 255 > hi = 0) fail the decoded test by themselves; with the margins a node thinner than 2^-19 of the
+                        // scene on all three axes could let one through, so the reference is looked at — on the rarely taken side of the branch.
+                        const bool ok = tf > tn;
                         if (COUNT && ref[k] != 0x7fffffff) c_boxes++;
-                        if (ok) {
+                        if (ok && ref[k] != 0x7fffffff) {
                             if (next == 0x7fffffff) { next = ref[k]; next_tn = tn; }
                             else {
                                 int far = ref[k];
@@ -555,10 +622,15 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const
                 }
                 if (done) { have = false; if (hit) hit_out[ridx] = 1; }
             }
+            MR_PH(ph_mem += ph_1 - ph_0; ph_cmp += MR_PH_NOW() - ph_1;)
             // in the tail leave the loop as soon as an idle lane and a lane with deferred work coexist (hand-over above)
         } while (exhausted ? (__ballot(have) && !(__ballot(!have) && __ballot(have && sp > sbase && sbase < MR_ANY_LDS))) : (__popcll(__ballot(have)) >= MR_REFILL));
     }
+#ifndef MR_EXP_PHASES
     if (B.dbg && (threadIdx.x & 63) == 0) B.dbg[2 * (blockIdx.x * (MR_TRACE_BLOCK / 64) + (threadIdx.x >> 6)) + 1] = wall_clock64();
+#endif
+    MR_PH(if (B.dbg && (threadIdx.x & 63) == 0) { unsigned long long* o = B.dbg + 5 * (blockIdx.x * (MR_TRACE_BLOCK / 64) + (threadIdx.x >> 6));
+            o[0] = (unsigned long long)(MR_PH_NOW() - ph_begin); o[1] = (unsigned long long)ph_refill; o[2] = (unsigned long long)ph_mem; o[3] = (unsigned long long)ph_cmp; o[4] = (unsigned long long)ph_iters; })
     if (COUNT && stats) { atomicAdd(&stats[2], c_boxes); atomicAdd(&stats[3], c_nodes); atomicAdd(&stats[4], c_leaves); }
     if (stats && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[0], (unsigned long long)n);
 }
@@ -597,6 +669,8 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_closest4(BvhView B, co
     bool exhausted = false, have = false, fin = false;
     float ox = 0, oy = 0, oz = 0, ix = 0, iy = 0, iz = 0; v3 d = V3(0.f), ro = V3(0.f);
     float t_min = 0.f, closest = 0.f, best_u = 0.f, best_v = 0.f;
+    RayCons rc; rc.mx = rc.my = rc.mz = 0.f;
+    const float scene_bs = scene_bound(B.root_box);
     const int NONE = 0x7fffffff;
     int cur = NONE, sp = 0, best_slot = -1; uint32_t ridx = 0; bool any_hit = false, need_redo = false;
     uint2 spill[MR_STACK - MR_LDS_STACK];
@@ -616,6 +690,7 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_closest4(BvhView B, co
                       if (dx == 0.f) dx = 0.000001f; if (dy == 0.f) dy = 0.000001f; if (dz == 0.f) dz = 0.000001f;
                       ix = 1.0f / dx; iy = 1.0f / dy; iz = 1.0f / dz; }
                     sp = 0; any_hit = false; need_redo = false; best_u = 0.f; best_v = 0.f; best_slot = -1;
+                    rc = ray_margins(scene_bs, ox, oy, oz, ix, iy, iz);
                     const float o3[3] = {ox, oy, oz}, i3[3] = {ix, iy, iz};
                     Slab s0 = slab(B.root_box, B.root_box + 3, o3, i3, t_min);
                     if (COUNT) c_boxes++;
@@ -686,23 +761,18 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_closest4(BvhView B, co
                             }
                         }
                     } else {
-                        const float gx = __uint_as_float(h0.x), gy = __uint_as_float(h0.y), gz = __uint_as_float(h0.z);
-                        const float sx = __uint_as_float((h0.w & 0xffu) << 23), sy = __uint_as_float((h0.w & 0xff00u) << 15), sz = __uint_as_float((h0.w & 0xff0000u) << 7);
-                        const uint32_t nqx = ix >= 0.f ? h1.x : h1.w, fqx = ix >= 0.f ? h1.w : h1.x;
-                        const uint32_t nqy = iy >= 0.f ? h1.y : h2.x, fqy = iy >= 0.f ? h2.x : h1.y;
-                        const uint32_t nqz = iz >= 0.f ? h1.z : h2.y, fqz = iz >= 0.f ? h2.y : h1.z;
+                        // conservative boxes: one fma per plane (node_cons / child_slab); a smaller entry distance culls less and never wrongly
+                        const NodeCons nc = node_cons(h0, h1, h2, ox, oy, oz, ix, iy, iz, rc);
                         const int ref[4] = {(int)rf.x, (int)rf.y, (int)rf.z, (int)rf.w};
+                        float tn4[4], tf4[4];
+                        child_slabs(nc, t_min, tn4, tf4);
                         // children that may still hold something nearer, kept in descending entry distance (n <= 4)
                         int nref[4]; float ntn[4]; int nn = 0;
 #pragma unroll
                         for (int k = 0; k < 4; k++) {
-                            const float nx = (fmaf((float)((nqx >> (8 * k)) & 0xffu), sx, gx) - ox) * ix, fx_ = (fmaf((float)((fqx >> (8 * k)) & 0xffu), sx, gx) - ox) * ix;
-                            const float ny = (fmaf((float)((nqy >> (8 * k)) & 0xffu), sy, gy) - oy) * iy, fy_ = (fmaf((float)((fqy >> (8 * k)) & 0xffu), sy, gy) - oy) * iy;
-                            const float nz = (fmaf((float)((nqz >> (8 * k)) & 0xffu), sz, gz) - oz) * iz, fz_ = (fmaf((float)((fqz >> (8 * k)) & 0xffu), sz, gz) - oz) * iz;
-                            float tn = fmaxf(fmaxf(fmaxf(nx, ny), nz), t_min);          // near / far planes by the sign of the direction (see k_trace_any4q)
-                            const float tf = fminf(fminf(fx_, fy_), fz_);
+                            float tn = tn4[k]; const float tf = tf4[k];
                             if (COUNT && ref[k] != NONE) c_boxes++;
-                            if (tf > tn && closest > tn) {
+                            if (tf > tn && closest > tn && ref[k] != NONE) {   // unused slots: see k_trace_any4q
                                 int r = ref[k];
 #pragma unroll
                                 for (int q = 0; q < 4; q++) {

@@ -27,9 +27,9 @@ struct __attribute__((aligned(64))) WideNode {
 // contains the LBVH box it stands for. Only used by the shadow-ray kernel, whose result depends on the leaves' own boxes alone
 // (bvh_trace.hip): leaves that pass the conservative test are re-tested against their exact box, stored with the triangle in LeafRec.
 struct __attribute__((aligned(64))) Node4q {
-    float org[3]; uint32_t exps;          // biased exponents of the x/y/z step in bytes 0..2
-    uint32_t qlo[3], qhi[3];              // byte k of qlo[a] / qhi[a] = child k's min / max along axis a
-    uint32_t pad[2];
+    float org[3]; float step_x;           // quantisation steps (powers of two) as floats: no unpacking in the traversal (an `and` + a shift per axis and
+    uint32_t qlo[3], qhi[3];              // visit otherwise); byte k of qlo[a] / qhi[a] = child k's min / max along axis a
+    float step_y, step_z;
     int32_t ref[4];                       // >=0 node id, <0 ~leaf slot, 0x7fffffff = unused entry; inside an LDS-staged prefix: MR_TOPBIT | index
 };
 struct __attribute__((aligned(64))) LeafRec {  // 64 B: triangle (v0, e1, e2) + the leaf's exact LBVH box + primitive id
