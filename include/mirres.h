@@ -183,6 +183,15 @@ int mirres_interpolate_bwd(const float* attr, int C, const float* rast, const in
  * regularisers): tex f32[H,W,C], uv f32[n,2] in [0,1] (texel centres at (i + 0.5) / W) -> out f32[n,C]; the backward ACCUMULATES into g_tex. */
 int mirres_texture2d(const float* tex, int H, int W, int C, const float* uv, int n, float* out, void* stream);
 int mirres_texture2d_bwd(int H, int W, int C, const float* uv, int n, const float* g_out, float* g_tex, void* stream);
+/* dr.antialias (nerf/renderer.py:1184-1206; nvdiffrast is un-vendored: the published algorithm, csrc/antialias.hip): color f32[H*W,C], rast f32[H*W,4]
+ * (mirres_raster_raycast's record: .z orders the two triangles of a pixel pair by distance, .w = triangle id + 1), pos_clip f32[V,4] clip-space
+ * vertex positions (pixel (i, j)'s centre is NDC ((2i + 1) / W - 1, (2j + 1) / H - 1)), tri i32[T,3], opp i32[T,3] the vertex across each edge
+ * (v_k, v_k+1) in the neighbouring triangle or -1 (topology: depends on `tri` only).  out f32[H*W,C], written without atomics (deterministic).
+ * _bwd: g_color f32[H*W,C] (overwritten) and / or g_pos f32[V,4] (ACCUMULATED with atomics; scaled by pos_gradient_boost); either may be NULL. */
+int mirres_antialias(int W, int H, int C, const float* color, const float* rast, const float* pos_clip, const int32_t* tri, const int32_t* opp,
+                     float* out, void* stream);
+int mirres_antialias_bwd(int W, int H, int C, const float* color, const float* rast, const float* pos_clip, const int32_t* tri, const int32_t* opp,
+                         const float* g_out, float* g_color, float* g_pos, float pos_gradient_boost, void* stream);
 
 /* prepare_shading_normal (nerf/renderutils/ops.py:100-163; c_src/normal.cu): the shading normal render_stage1 hands to the path
  * (nerf/renderer.py:1013). All inputs f32[n,3] (broadcast inputs expanded by the caller); out f32[n,3]. The backward writes the six input

@@ -95,6 +95,8 @@ SIGNATURES = {
     "mirres_interpolate_bwd": (C.c_int, [vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, vp]),
     "mirres_texture2d": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, vp]),
     "mirres_texture2d_bwd": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, vp, vp]),
+    "mirres_antialias": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp]),
+    "mirres_antialias_bwd": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, C.c_float, vp]),
     "mirres_dump_render": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
     "mirres_bilateral": (C.c_int, [C.c_int, C.c_int, C.c_float, vp, vp, vp, vp, vp, vp]),
     "mirres_bilateral_bwd": (C.c_int, [C.c_int, C.c_int, C.c_float, vp, vp, vp, vp, vp, vp]),

@@ -4,7 +4,7 @@
 // (u, v, depth, triangle_id + 1) so that interpolation and its gradients follow dr.interpolate's published contract:
 //   out = u a[i0] + v a[i1] + (1 - u - v) a[i2],   d out / d a[i_k] = barycentric weight,   d out / d(u, v) = (a[i0] - a[i2], a[i1] - a[i2]).
 // dr.texture (linear filter, clamp boundary: the jittered taps of the smoothness regularisers, :1001-1010) is k_texture below; dr.antialias
-// (visibility gradients) is not provided.
+// (visibility gradients) lives in antialias.hip.
 #include "engine.hpp"
 #include "device_math.hpp"
 

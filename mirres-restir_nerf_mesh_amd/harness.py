@@ -33,19 +33,30 @@ def build_gbuffer(worker, H, W, ssaa=1, azimuth_deg=30.0, elevation_deg=30.0, kd
     return dict(fx=w, fy=h, occ=occ, pos=pos.contiguous(), normal=normal, depth=depth, kd=kd_map, rm=rm, ray_dir=rays_d, eye=eye)
 
 
-def build_gbuffer_stage1(worker, vertices, triangles, H, W, ssaa=1, azimuth_deg=30.0, elevation_deg=30.0, mlp_mat=None):
+def build_gbuffer_stage1(worker, vertices, triangles, H, W, ssaa=1, azimuth_deg=30.0, elevation_deg=30.0, mlp_mat=None, pose=None, intrinsics=None):
     """The front half of render_stage1 (nerf/renderer.py:978-1022, 1083-1094) on the engine's own operators: raster record by casting the primary rays
     (raster.rasterize_raycast, for dr.rasterize), xyzs / smooth normal / geometric normal by raster.interpolate (dr.interpolate), auto_normals,
-    renderutils.prepare_shading_normal, safe_normalize, material field. Differentiable w.r.t. `vertices` through the interpolations (the visibility
-    term of dr.antialias is not modelled). Returns the dict build_gbuffer returns, plus `rast`."""
+    renderutils.prepare_shading_normal, safe_normalize, material field. Differentiable w.r.t. `vertices` through the interpolations and the material
+    field's position gradient. Returns the dict build_gbuffer returns, plus `rast`.  Camera: the synthetic orbit view (azimuth / elevation), or a
+    dataset camera (`pose` [4,4] cam2world + `intrinsics` (fx, fy, cx, cy) at H x W) — then the dict also carries `mvp` (mvp_from_pose at the internal
+    resolution) and `vertices_clip` [V,4] (:981), what dr.antialias needs."""
     from . import raster
     from .renderutils.ops import prepare_shading_normal
     h, w = H * ssaa, W * ssaa
-    eye, rd = scene.camera_rays(h, w, azimuth_deg, elevation_deg)
     dev = vertices.device
-    rays_d = torch.from_numpy(rd).to(dev)
-    eye_t = torch.from_numpy(eye).to(dev)
-    rays_o = eye_t[None].expand(h * w, 3).contiguous()
+    cam = {}
+    if pose is not None:
+        pose = pose.to(dev)
+        fx_, fy_, cx_, cy_ = (float(v) * ssaa for v in intrinsics)
+        rays_o, rays_d = get_rays(pose, (fx_, fy_, cx_, cy_), h, w)
+        eye_t = pose[:3, 3].to(torch.float32).contiguous(); eye = eye_t.detach().cpu().numpy()
+        mvp = mvp_from_pose(pose, (fx_, fy_, cx_, cy_), h, w)
+        cam = dict(mvp=mvp, vertices_clip=torch.cat((vertices, torch.ones_like(vertices[:, :1])), dim=1) @ mvp.t())      # :981
+    else:
+        eye, rd = scene.camera_rays(h, w, azimuth_deg, elevation_deg)
+        rays_d = torch.from_numpy(rd).to(dev)
+        eye_t = torch.from_numpy(eye).to(dev)
+        rays_o = eye_t[None].expand(h * w, 3).contiguous()
     rast = raster.rasterize_raycast(worker, rays_o, rays_d)
     tri = triangles.to(torch.int32)
     xyzs = raster.interpolate(vertices, rast, tri)                                                         # :985
@@ -69,7 +80,7 @@ def build_gbuffer_stage1(worker, vertices, triangles, H, W, ssaa=1, azimuth_deg=
     else:
         kd_map = torch.full((N, 3), 0.6, device=dev); rm = torch.tensor([0.5, 0.0], device=dev)[None].expand(N, 2).contiguous()
     depth = torch.norm(xyzs - rays_o, dim=1, keepdim=True)                                                 # :1096
-    return dict(fx=w, fy=h, occ=occ, pos=xyzs, normal=nrm * occ, depth=depth, kd=kd_map, rm=rm, ray_dir=rays_d, eye=eye, rast=rast)
+    return dict(fx=w, fy=h, occ=occ, pos=xyzs, normal=nrm * occ, depth=depth, kd=kd_map, rm=rm, ray_dir=rays_d, eye=eye, rast=rast, **cam)
 
 
 def get_rays(pose, intrinsics, H, W):
@@ -83,6 +94,18 @@ def get_rays(pose, intrinsics, H, W):
     rays_d = cam @ pose[:3, :3].to(torch.float32).t()
     rays_o = pose[:3, 3].to(torch.float32)[None].expand_as(rays_d)
     return rays_o.contiguous(), rays_d.contiguous()
+
+
+def mvp_from_pose(pose, intrinsics, H, W, near=0.05, far=1000.0):
+    """The model-view-projection matrix the dataset hands to render_stage1 (nerf/provider.py:277-288): an OpenGL-style perspective projection with
+    the image's y axis flipped (row 0 at the top, like get_rays) times the inverse of the cam2world pose.  `near` = --min_near (main.py default 0.05),
+    far = 1000.  vertices_clip = pad(vertices, 1) @ mvp.T (nerf/renderer.py:981); pixel (i, j)'s centre is NDC ((2i + 1) / W - 1, (2j + 1) / H - 1)."""
+    fx, fy, cx, cy = (float(v) for v in intrinsics)
+    y = H / (2.0 * fy)
+    aspect = W / H
+    proj = torch.tensor([[1 / (y * aspect), 0, 0, 0], [0, -1 / y, 0, 0], [0, 0, -(far + near) / (far - near), -(2 * far * near) / (far - near)], [0, 0, -1, 0]],
+                        dtype=torch.float32, device=pose.device)
+    return proj @ torch.inverse(pose.to(torch.float32))
 
 
 def view_dirs(rays_d, H, W, ssaa=1):
@@ -138,16 +161,21 @@ test_view.__test__ = False      # not a pytest case
 
 
 def render_stage1_outputs(worker, vertices, voffsets, triangles, mlp_mat, env_map, mods, H, W, spp, ssaa=1, azimuth_deg=30.0, elevation_deg=30.0,
-                          jitter_std=0.01, bg_color=1.0, gb_depth=None, with_normal_ao=False, de=2, c=2.0, n=0.1, p=0.001):
+                          jitter_std=0.01, bg_color=1.0, gb_depth=None, with_normal_ao=False, de=2, c=2.0, n=0.1, p=0.001, pose=None, intrinsics=None,
+                          topology=None, pos_gradient_boost=1.0):
     """`render_stage1` for `--stage 1 --use_brdf --use_restir` training (nerf/renderer.py:960-1302) as far as the material / light / geometry
     branch goes: moved mesh -> BVH update -> G-buffer front half (build_gbuffer_stage1) -> jittered material taps (:1016-1022) ->
-    run_restir_di_with_pt (:1112-1123) -> clamp, tone curve, alpha (:1125-1129, 1162-1164, 1208).  Returns the entries of the reference's
-    `outputs` dict that losses.stage1_loss reads, except `image` (the NeRF colour branch belongs to stage 0) — and without dr.antialias, whose
-    silhouette gradients are not modelled.  `gb_depth` ([N, 2]: z, |dz|; :1070-1081) selects the --use_bi_de bilateral finish, None the a-trous one.  (normal_grad, which needs the perturbed-normal texture the --use_brdf path never enables, is zero)."""
+    run_restir_di_with_pt (:1112-1123) -> clamp, tone curve (:1125-1129, 1162-1164) -> dr.antialias of alpha and of every output image (:1184-1200;
+    the indirect images detached, as there) -> alpha (:1208-1240).  Returns the entries of the reference's `outputs` dict that losses.stage1_loss
+    reads, except `image` (the NeRF colour branch belongs to stage 0).  With a dataset camera (`pose`, `intrinsics`) the antialias step runs and the
+    image loss reaches the vertex positions through visibility; with the synthetic orbit camera (no projection matrix) it is skipped.  `topology` =
+    raster.antialias_topology(triangles) (built per call when None).  `gb_depth` ([N, 2]: z, |dz|; :1070-1081) selects the --use_bi_de bilateral
+    finish, None the a-trous one.  (normal_grad, which needs the perturbed-normal texture the --use_brdf path never enables, is zero)."""
     from . import renderer_restir as RR
+    from . import raster
     moved = vertices + voffsets
     worker.update_mesh(moved.detach().contiguous(), triangles)
-    g = build_gbuffer_stage1(worker, moved, triangles, H, W, ssaa, azimuth_deg, elevation_deg, mlp_mat)
+    g = build_gbuffer_stage1(worker, moved, triangles, H, W, ssaa, azimuth_deg, elevation_deg, mlp_mat, pose=pose, intrinsics=intrinsics)
     fx, fy = g["fx"], g["fy"]; N = fx * fy
     dev = moved.device
     xyzs = g["pos"]
@@ -160,16 +188,27 @@ def render_stage1_outputs(worker, vertices, voffsets, triangles, mlp_mat, env_ma
                                    g["depth"], g["kd"], g["rm"], g["ray_dir"], xyzs.detach(), z(N, 1), z(N, 4), z(N, 3), z(N, 3), fx, fy, spp, de,
                                    2 ** (de - 1), c, n, p)
     extra = {}
+    out_ao = None
     if with_normal_ao:      # --lambda_extra_kd > 0 (:1150-1158, 1226-1228): the kernel is launched off the denoising module handle, as the reference does
         out_ao = torch.zeros((N, 3), dtype=torch.float32, device=dev)
         mods[7].process_normal_ao(framedim_x=int(fx), framedim_y=int(fy), occ_map=g["occ"], normal_map=g["normal"].detach().contiguous(), ray_dir=g["ray_dir"], out_ao=out_ao) \
             .launchRaw(blockSize=(16, 16, 1), gridSize=((int(fx) + 15) // 16, (int(fy) + 15) // 16, 1))
-        extra["normal_ao"] = (g["occ"] * torch.clamp(out_ao, 0.0, 1.0)).detach()
     alpha = g["occ"]
-    image_brdf = alpha * linear2srgb(torch.clamp(torch.nan_to_num(out[0], 0.0), 0.0, 1.0)) + (1 - alpha) * bg_color            # :1209, :1301
-    lit = lambda x: alpha * torch.clamp(x, 0.0, 1.0)                                                                # :1182-1186 without the antialias
-    return dict(image_brdf=image_brdf, diffuse_light=lit(out[1]), specular_light=lit(out[2]), img_brdf_indirect=lit(out[3].detach()),
-                kd_grad=kd_grad * alpha, ks_grad=ks_grad * alpha, normal_grad=torch.zeros((N, 1), device=dev), occ=alpha, fx=fx, fy=fy, **extra)   # :1350-1352
+    brdf_rgbs = linear2srgb(torch.clamp(torch.nan_to_num(out[0], 0.0), 0.0, 1.0))                                   # :1125-1129, 1162-1164
+    if "vertices_clip" in g:
+        tri32 = triangles.to(torch.int32)
+        topo = topology if topology is not None else raster.antialias_topology(tri32)
+        rast4 = g["rast"].view(1, fy, fx, 4); clip = g["vertices_clip"][None]
+        aa = lambda x: raster.antialias(x.view(1, fy, fx, x.shape[-1]), rast4, clip, tri32, topology_hash=topo, pos_gradient_boost=pos_gradient_boost) \
+            .view(N, x.shape[-1]).clamp(0, 1)                                                                        # :1184-1200
+        alpha = aa(alpha)
+    else:
+        aa = lambda x: torch.clamp(x, 0.0, 1.0)
+    if out_ao is not None:
+        extra["normal_ao"] = (alpha * aa(out_ao.detach())).detach()                                                 # :1195, 1226-1228
+    image_brdf = alpha * aa(brdf_rgbs) + (1 - alpha) * bg_color                                                     # :1186, 1209, 1301
+    return dict(image_brdf=image_brdf, diffuse_light=alpha * aa(out[1]), specular_light=alpha * aa(out[2]), img_brdf_indirect=(alpha * aa(out[3].detach())).detach(),
+                kd_grad=kd_grad * g["occ"], ks_grad=ks_grad * g["occ"], normal_grad=torch.zeros((N, 1), device=dev), occ=alpha, fx=fx, fy=fy, **extra)   # :1350-1352
 
 
 def linear2srgb(x):

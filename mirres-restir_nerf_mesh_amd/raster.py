@@ -8,7 +8,8 @@ interpolation with gradients to the vertex attributes, smooth vertex normals —
 
     nrm_jitter = texture(gb_normal.view(h, w, 3), jitter)     # dr.texture(..., filter_mode='linear', boundary_mode='clamp') (:1004, :1008)
 
-dr.antialias (the visibility gradient, :1184-1206) is not provided."""
+    topo = antialias_topology(triangles)                      # once per index buffer
+    img = antialias(img.view(1, h, w, 3), rast.view(1, h, w, 4), vertices_clip, triangles, topology_hash=topo, pos_gradient_boost=...)   # dr.antialias (:1184-1206)"""
 import torch
 
 from ._lib import lib, check, stream_ptr
@@ -94,3 +95,76 @@ def texture(tex, uv):
     """dr.texture(tex[None], uv[None], filter_mode='linear', boundary_mode='clamp')[0]: tex f32[H,W,C], uv f32[...,2] in [0,1] -> f32[prod(...), C];
     gradients flow to tex (the taps' coordinates are constants in the reference: jitter = pixel_grid + noise)."""
     return _Texture.apply(tex, uv)
+
+
+def antialias_topology(tri):
+    """For every edge (v_k, v_k+1) of every triangle: the vertex opposite that edge in the neighbouring triangle, or -1 on a boundary edge — what
+    dr.antialias needs to tell silhouette edges from interior ones (nvdiffrast's `antialias_construct_topology_hash`).  Depends on the index buffer
+    only: built once per mesh (torch sort over the 3 T directed edges; set-up, not per-frame work).  An edge shared by more than two triangles pairs
+    each triangle with the next one in sorted order.  Returns i32[T,3] on tri's device."""
+    t = tri.detach().to(torch.int64)
+    T = t.shape[0]
+    a = torch.stack((t[:, 0], t[:, 1], t[:, 2]), 1).reshape(-1)            # edge k starts at v_k ...
+    b = torch.stack((t[:, 1], t[:, 2], t[:, 0]), 1).reshape(-1)            # ... ends at v_k+1 ...
+    c = torch.stack((t[:, 2], t[:, 0], t[:, 1]), 1).reshape(-1)            # ... and faces v_k+2
+    lo, hi = torch.minimum(a, b), torch.maximum(a, b)
+    key = lo * (int(t.max().item()) + 1 if T else 1) + hi
+    order = torch.argsort(key, stable=True)
+    ks = key[order]; cs = c[order]
+    opp_sorted = torch.full_like(cs, -1)
+    same_next = torch.zeros_like(ks, dtype=torch.bool); same_prev = torch.zeros_like(ks, dtype=torch.bool)
+    if ks.numel() > 1:
+        eq = ks[1:] == ks[:-1]
+        same_next[:-1] = eq; same_prev[1:] = eq
+    nxt = torch.roll(cs, -1); prv = torch.roll(cs, 1)
+    opp_sorted = torch.where(same_next, nxt, torch.where(same_prev, prv, opp_sorted))
+    opp = torch.empty_like(opp_sorted); opp[order] = opp_sorted
+    return opp.view(T, 3).to(torch.int32).contiguous()
+
+
+class _Antialias(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, color, rast, pos, tri, opp, H, W, boost):
+        col = color.detach().float().contiguous(); r = rast.detach().float().contiguous(); p = pos.detach().float().contiguous()
+        t = tri.detach().to(torch.int32).contiguous()
+        C_ = col.shape[-1]
+        out = torch.empty_like(col)
+        check(lib().mirres_antialias(W, H, C_, col.data_ptr(), r.data_ptr(), p.data_ptr(), t.data_ptr(), opp.data_ptr(), out.data_ptr(), stream_ptr()), "mirres_antialias")
+        ctx.save_for_backward(col, r, p, t, opp); ctx.dims = (H, W, C_, float(boost))
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        col, r, p, t, opp = ctx.saved_tensors; H, W, C_, boost = ctx.dims
+        g = g_out.contiguous().float()
+        g_col = torch.empty_like(col) if ctx.needs_input_grad[0] else None
+        g_pos = torch.zeros_like(p) if ctx.needs_input_grad[2] else None
+        if g_col is not None or g_pos is not None:
+            check(lib().mirres_antialias_bwd(W, H, C_, col.data_ptr(), r.data_ptr(), p.data_ptr(), t.data_ptr(), opp.data_ptr(), g.data_ptr(),
+                                             g_col.data_ptr() if g_col is not None else None, g_pos.data_ptr() if g_pos is not None else None, boost, stream_ptr()),
+                  "mirres_antialias_bwd")
+        return g_col, None, g_pos, None, None, None, None, None
+
+
+def antialias(color, rast, pos, tri, topology_hash=None, pos_gradient_boost=1.0):
+    """dr.antialias(color, rast, pos, tri, topology_hash=None, pos_gradient_boost=1.0) for one image: color [1,H,W,C] (or [H,W,C]), rast [1,H,W,4]
+    as rasterize_raycast returns it (reshaped), pos [1,V,4] / [V,4] clip-space vertex positions, tri [T,3].  `topology_hash` = antialias_topology(tri)
+    (built on the fly when None, as nvdiffrast does).  Differentiable w.r.t. color and pos; returns the shape of `color`."""
+    shape = color.shape
+    if color.dim() == 4:
+        if shape[0] != 1:
+            raise ValueError("antialias: one image per call (minibatch of 1), got %s" % (tuple(shape),))
+        H, W, C_ = shape[1:]
+    elif color.dim() == 3:
+        H, W, C_ = shape
+    else:
+        raise ValueError("antialias: color must be [1,H,W,C] or [H,W,C]")
+    if rast.numel() != H * W * 4:
+        raise ValueError("antialias: rast has %d values, expected %d x %d x 4" % (rast.numel(), H, W))
+    p = pos.reshape(-1, 4)
+    if topology_hash is None:
+        topology_hash = antialias_topology(tri)
+    if topology_hash.shape != tri.shape or topology_hash.dtype != torch.int32:
+        raise ValueError("antialias: topology_hash must be antialias_topology(tri) (i32[T,3])")
+    out = _Antialias.apply(color.reshape(H * W, C_), rast.reshape(H * W, 4), p, tri, topology_hash.contiguous(), int(H), int(W), float(pos_gradient_boost))
+    return out.view(shape)

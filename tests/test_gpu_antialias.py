@@ -1,0 +1,171 @@
+"""dr.antialias on the HIP path (csrc/antialias.hip) — nvdiffrast is un-vendored, so the checker is an independent numpy statement of
+the published algorithm (tests/util.py antialias_ref), finite differences of it for the position gradient, and structural properties."""
+import numpy as np
+import pytest
+
+from util import antialias_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def _view(scene_mod, H, W, az=35.0, el=25.0, dist=3.2):
+    import torch
+    from mirres_restir_nerf_mesh_amd import renderer_restir as RR, harness, raster
+    v, t = scene_mod.make_mesh(2, 2)
+    verts = torch.from_numpy(v).cuda(); tris = torch.from_numpy(t).cuda()
+    Wk = RR.restirbvhWorker(verts, tris); Wk.update_mesh(Wk.vrt, Wk.v_ind)
+    a, e = np.deg2rad(az), np.deg2rad(el)
+    eye = dist * np.array([np.cos(e) * np.cos(a), np.cos(e) * np.sin(a), np.sin(e)])
+    fwd = -eye / np.linalg.norm(eye); right = np.cross(fwd, [0.0, 0.0, 1.0]); right /= np.linalg.norm(right); up = np.cross(right, fwd)
+    pose = np.eye(4, dtype=np.float32); pose[:3, :3] = np.stack([right, up, -fwd], 1); pose[:3, 3] = eye
+    pose = torch.from_numpy(pose).cuda()
+    focal = 0.5 * W / np.tan(0.5 * 0.6911)
+    intr = (focal, focal, W * 0.5, H * 0.5)
+    ro, rd = harness.get_rays(pose, intr, H, W)
+    rast = raster.rasterize_raycast(Wk, ro, rd)
+    mvp = harness.mvp_from_pose(pose, intr, H, W)
+    clip = torch.cat((verts, torch.ones_like(verts[:, :1])), 1) @ mvp.t()
+    return Wk, verts, tris, rast, clip.contiguous(), raster
+
+
+def test_projection_matches_the_ray_cast(scene_mod):
+    """mvp_from_pose (nerf/provider.py:277-288) and get_rays describe the same camera: the centre of every covered pixel lies inside the projection
+    of the triangle its raster record names — the pixel convention mirres_antialias assumes for pos_clip."""
+    import torch
+    H, W = 48, 64
+    Wk, verts, tris, rast, clip, raster = _view(scene_mod, H, W)
+    r = rast.cpu().numpy(); c = clip.cpu().numpy().astype(np.float64); t = tris.cpu().numpy()
+    hit = np.nonzero(r[:, 3] > 0)[0]
+    assert len(hit) > 300
+    px = (c[:, 0] / c[:, 3] + 1) * 0.5 * W; py = (c[:, 1] / c[:, 3] + 1) * 0.5 * H
+    worst = 0.0
+    for p in hit:
+        i0, i1, i2 = t[int(r[p, 3]) - 1]
+        A = np.array([[px[i0] - px[i2], px[i1] - px[i2]], [py[i0] - py[i2], py[i1] - py[i2]]])
+        b = np.array([(p % W) + 0.5 - px[i2], (p // W) + 0.5 - py[i2]])
+        u, v = np.linalg.solve(A, b)
+        worst = max(worst, -min(u, v, 1 - u - v))
+    assert worst < 2e-3, worst                       # inside up to the rounding of the fp32 ray cast at the shared edges
+
+
+def test_antialias_forward_matches_the_published_algorithm(scene_mod):
+    import torch
+    H, W = 40, 56
+    Wk, verts, tris, rast, clip, raster = _view(scene_mod, H, W)
+    topo = raster.antialias_topology(tris)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    occ = (rast[:, 3:4] > 0).float()
+    color = (torch.rand((H * W, 3), device="cuda", generator=g) * 0.5 + 0.25) * occ + (1 - occ) * torch.tensor([0.9, 0.1, 0.2], device="cuda")
+    out = raster.antialias(color.view(1, H, W, 3), rast.view(1, H, W, 4), clip[None], tris, topology_hash=topo)
+    assert out.shape == (1, H, W, 3)
+    ref, pairs = antialias_ref(color.cpu().numpy(), rast.cpu().numpy(), clip.cpu().numpy(), tris.cpu().numpy(), topo.cpu().numpy(), H, W)
+    got = out.view(-1, 3).cpu().numpy()
+    assert len(pairs) > 60
+    np.testing.assert_allclose(got, ref, rtol=0, atol=2e-5)
+    # only pixels on a silhouette change, every changed pixel moves towards its neighbour's colour, and the image keeps its range
+    changed = np.nonzero(np.abs(got - color.cpu().numpy()).max(1) > 1e-6)[0]
+    touched = set(p for p0, p1, a, _, _ in pairs for p in ((p1,) if a > 0 else (p0,) if a < 0 else ()))
+    assert set(changed.tolist()) <= touched and len(changed) > 40
+    assert got.min() >= 0.1 - 1e-6 and got.max() <= 0.9 + 1e-6
+    # an image of one colour is a fixed point; without a topology argument the hash is built on the fly (nvdiffrast's default) with the same result
+    flat = torch.full((1, H, W, 3), 0.37, device="cuda")
+    assert torch.equal(raster.antialias(flat, rast.view(1, H, W, 4), clip[None], tris, topology_hash=topo), flat)
+    assert torch.equal(raster.antialias(color.view(H, W, 3), rast.view(H, W, 4), clip, tris).view(-1, 3), out.view(-1, 3))
+    # deterministic (a gather, no atomics)
+    assert torch.equal(raster.antialias(color.view(1, H, W, 3), rast.view(1, H, W, 4), clip[None], tris, topology_hash=topo), out)
+
+
+def test_antialias_gradients(scene_mod):
+    """Colour gradient: the operator is linear in the colours (the weights depend on geometry only), so <g, A c> = <A^T g, c> for any c — checked with
+    the backward's A^T g.  Position gradient: central differences of the float64 numpy statement along random clip-space directions."""
+    import torch
+    H, W = 32, 40
+    Wk, verts, tris, rast, clip, raster = _view(scene_mod, H, W, az=70.0, el=15.0)
+    topo = raster.antialias_topology(tris)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    color = torch.rand((1, H, W, 3), device="cuda", generator=g)
+    gout = torch.rand((1, H, W, 3), device="cuda", generator=g) - 0.5
+    c1 = color.clone().requires_grad_(True); p1 = clip.clone().requires_grad_(True)
+    out = raster.antialias(c1, rast.view(1, H, W, 4), p1[None], tris, topology_hash=topo, pos_gradient_boost=1.0)
+    out.backward(gout)
+    c2 = torch.rand((1, H, W, 3), device="cuda", generator=g)
+    lhs = float((gout.double() * raster.antialias(c2, rast.view(1, H, W, 4), clip[None], tris, topology_hash=topo).double()).sum())
+    rhs = float((c1.grad.double() * c2.double()).sum())
+    assert abs(lhs - rhs) <= 1e-5 * max(1.0, abs(lhs))
+    # position gradient
+    assert p1.grad.shape == clip.shape and torch.isfinite(p1.grad).all() and float(p1.grad[:, 2].abs().max()) == 0.0      # clip z does not enter
+    rn, tn, on = rast.cpu().numpy(), tris.cpu().numpy(), topo.cpu().numpy()
+    cn, gn = color.view(-1, 3).cpu().numpy().astype(np.float64), gout.view(-1, 3).cpu().numpy().astype(np.float64)
+    base = clip.cpu().numpy().astype(np.float64)
+    loss = lambda P: float((antialias_ref(cn, rn, P, tn, on, H, W)[0] * gn).sum())
+    gp = p1.grad.cpu().numpy().astype(np.float64)
+    used = np.nonzero(np.abs(gp).sum(1) > 0)[0]
+    assert len(used) > 10
+    rng = np.random.default_rng(3)
+    ok = 0
+    for trial in range(6):
+        d = np.zeros_like(base); sel = rng.choice(used, size=min(8, len(used)), replace=False)
+        d[sel] = rng.standard_normal((len(sel), 4)) * np.array([1, 1, 0, 1])
+        eps = 1e-5
+        num = (loss(base + eps * d) - loss(base - eps * d)) / (2 * eps)
+        ana = float((gp * d).sum())
+        if abs(num - ana) <= 2e-3 * max(abs(num), abs(ana)) + 1e-6:
+            ok += 1
+    assert ok >= 5, ok                               # a perturbation may move a crossing over a pixel centre (the function has kinks there)
+    # pos_gradient_boost scales the position gradient and nothing else
+    c3 = color.clone().requires_grad_(True); p3 = clip.clone().requires_grad_(True)
+    raster.antialias(c3, rast.view(1, H, W, 4), p3[None], tris, topology_hash=topo, pos_gradient_boost=3.0).backward(gout)
+    # (the position gradient is accumulated with atomics: the summation order, hence the last bits, vary from run to run)
+    assert torch.allclose(p3.grad, 3.0 * p1.grad, rtol=1e-4, atol=1e-5 * float(p1.grad.abs().max())) and torch.equal(c3.grad, c1.grad)
+
+
+def test_stage1_outputs_with_a_dataset_camera_carry_the_visibility_gradient(scene_mod):
+    """harness.render_stage1_outputs with `pose` / `intrinsics` (the camera a dataset hands to render_stage1, with its mvp): dr.antialias runs on alpha and
+    on every output image (nerf/renderer.py:1184-1200), so an image loss that depends only on COVERAGE (alpha) has a non-zero gradient w.r.t. the
+    vertex offsets — zero without the operator (orbit camera path: alpha is a constant mask)."""
+    import torch
+    from mirres_restir_nerf_mesh_amd import renderer_restir as RR, harness, raster
+    from mirres_restir_nerf_mesh_amd.render_helper import MLPTexture3D
+    torch.manual_seed(0)
+    v, t = scene_mod.make_mesh(3, 4)
+    vt = torch.from_numpy(v).cuda(); tt = torch.from_numpy(t).cuda()
+    Wk = RR.restirbvhWorker(vt, tt); Wk.update_mesh(Wk.vrt, Wk.v_ind)
+    mn, mx = scene_mod.material_min_max(me_max=0.3)
+    mlp = MLPTexture3D(torch.tensor([-1, -1, -1, 1, 1, 1], dtype=torch.float32), channels=6, min_max=(torch.from_numpy(mn).cuda(), torch.from_numpy(mx).cuda()), seed=11)
+    with torch.no_grad():
+        mlp.encoder.params.mul_(2e3)
+    H, Wd = 32, 40
+    mods = RR.load_m_for_restir(Wd, H)
+    env = torch.full((32, 64, 3), 0.5, device="cuda", requires_grad=True)
+    a, e = np.deg2rad(30.0), np.deg2rad(30.0)
+    eye = 3.2 * np.array([np.cos(e) * np.cos(a), np.cos(e) * np.sin(a), np.sin(e)])
+    fwd = -eye / np.linalg.norm(eye); right = np.cross(fwd, [0.0, 0.0, 1.0]); right /= np.linalg.norm(right); up = np.cross(right, fwd)
+    pose = np.eye(4, dtype=np.float32); pose[:3, :3] = np.stack([right, up, -fwd], 1); pose[:3, 3] = eye
+    pose = torch.from_numpy(pose).cuda()
+    focal = 0.5 * Wd / np.tan(0.5 * 0.6911)
+    intr = (focal, focal, Wd * 0.5, H * 0.5)
+    topo = raster.antialias_topology(tt)
+    voff = torch.zeros_like(vt).requires_grad_(True)
+    RR.set_random_offset(77)
+    out = harness.render_stage1_outputs(Wk, vt, voff, tt, mlp, env, mods, H, Wd, 2, pose=pose, intrinsics=intr, topology=topo)
+    RR.set_random_offset(None)
+    alpha = out["occ"]
+    assert alpha.requires_grad and float(alpha.detach().min()) >= 0 and float(alpha.detach().max()) <= 1
+    frac = ((alpha.detach() > 1e-4) & (alpha.detach() < 1 - 1e-4)).float().mean()
+    assert 0.005 < float(frac) < 0.3                        # fractional coverage on the silhouette only
+    assert torch.isfinite(out["image_brdf"]).all() and out["image_brdf"].shape == (H * Wd, 3)
+    (g,) = torch.autograd.grad(alpha.sum(), voff, retain_graph=True)
+    assert torch.isfinite(g).all() and float(g.abs().sum()) > 0
+    # growing the object along the gradient grows the covered area (a directional finite difference of the same rendering)
+    step = 2e-3 * g / g.abs().max()
+    with torch.no_grad():
+        cov = []
+        for sgn in (+1.0, -1.0):
+            RR.set_random_offset(77)
+            o2 = harness.render_stage1_outputs(Wk, vt, (sgn * step).contiguous(), tt, mlp, env, mods, H, Wd, 2, pose=pose, intrinsics=intr, topology=topo)
+            cov.append(float(o2["occ"].sum()))
+        RR.set_random_offset(None)
+    assert cov[0] > cov[1], cov
+    # the whole image loss now reaches the geometry as well
+    (g2,) = torch.autograd.grad(((out["image_brdf"] - 0.2) ** 2).mean(), voff)
+    assert torch.isfinite(g2).all() and float(g2.abs().sum()) > 0

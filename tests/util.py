@@ -99,3 +99,67 @@ def torch_material_field(O, params_f32, w0, w1, w2, aabb_min, aabb_max, mn, mx, 
     h = torch.relu(a @ W[0].T); h = torch.relu(h @ W[1].T); z = h @ W[2].T
     mn_t = torch.tensor(np.asarray(mn, np.float64), device=dev, dtype=dtype); mx_t = torch.tensor(np.asarray(mx, np.float64), device=dev, dtype=dtype)
     return torch.sigmoid(z) * (mx_t - mn_t) + mn_t
+
+
+def antialias_ref(color, rast, pos, tri, opp, H, W):
+    """Plain-numpy (float64, pixel loops) statement of the published dr.antialias algorithm as csrc/antialias.hip documents it — independent code, same
+    rules: for every horizontally / vertically adjacent pixel pair with different triangle ids take the nearer triangle (background defers), find its
+    silhouette edges (boundary edge, or the neighbour across lies on the same side in screen space), the nearest crossing u in [0, 1] of the segment
+    between the two pixel centres, alpha = u - 1/2, and blend: alpha > 0 -> out[p1] += alpha (in[p0] - in[p1]); alpha < 0 -> out[p0] += -alpha (in[p1] - in[p0]).
+    Returns (out [H*W, C], list of (p0, p1, alpha, va, vb))."""
+    color = np.asarray(color, np.float64); rast = np.asarray(rast, np.float64); pos = np.asarray(pos, np.float64)
+    out = color.copy()
+    pairs = []
+
+    def proj(v, cx, cy):
+        x, y, z, w = pos[v]
+        if not w > 0:
+            return None
+        return np.array([(x / w + 1) * 0.5 * W - cx, (y / w + 1) * 0.5 * H - cy])
+
+    for lo in range(H * W):
+        for axis, hi in ((0, lo + 1 if (lo % W) + 1 < W else -1), (1, lo + W if lo + W < H * W else -1)):
+            if hi < 0:
+                continue
+            t0, t1 = int(rast[lo, 3]) - 1, int(rast[hi, 3]) - 1
+            if t0 == t1:
+                continue
+            first = t0 >= 0
+            if t0 >= 0 and t1 >= 0:
+                first = not (rast[hi, 2] < rast[lo, 2])
+            t = t0 if first else t1
+            p0, p1 = (lo, hi) if first else (hi, lo)
+            s = 1.0 if first else -1.0
+            cx, cy = (p0 % W) + 0.5, (p0 // W) + 0.5
+            P = [proj(int(v), cx, cy) for v in tri[t]]
+            if any(q is None for q in P):
+                continue
+            best = None
+            for k in range(3):
+                a, b, c = P[k], P[(k + 1) % 3], P[(k + 2) % 3]
+                o = int(opp[t, k])
+                if o >= 0:
+                    q = proj(o, cx, cy)
+                    if q is None:
+                        continue
+                    e = b - a
+                    sc = e[0] * (c[1] - a[1]) - e[1] * (c[0] - a[0]); so = e[0] * (q[1] - a[1]) - e[1] * (q[0] - a[0])
+                    if (sc > 0) != (so > 0):
+                        continue
+                ad, ao, bd, bo = a[axis], a[1 - axis], b[axis], b[1 - axis]
+                if (ao > 0) == (bo > 0):
+                    continue
+                u = s * (ad * bo - bd * ao) / (bo - ao)
+                if not (0 <= u <= 1):
+                    continue
+                if best is None or u < best[0]:
+                    best = (u, int(tri[t][k]), int(tri[t][(k + 1) % 3]))
+            if best is None:
+                continue
+            alpha = best[0] - 0.5
+            if alpha > 0:
+                out[p1] += alpha * (color[p0] - color[p1])
+            elif alpha < 0:
+                out[p0] += -alpha * (color[p1] - color[p0])
+            pairs.append((p0, p1, alpha, best[1], best[2]))
+    return out, pairs
