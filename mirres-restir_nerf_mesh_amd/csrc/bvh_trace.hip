@@ -29,16 +29,19 @@ namespace mr {
 struct Slab { float tn, tf; };
 
 // aabb_hit (helperDi.slang:149-170) split into its closest-independent part. The reference computes t0/t1 per axis, swaps them when
-// inv < 0 and folds them with `t0 > t_min ? t0 : t_min` / `t1 < t_max ? t1 : t_max`. Because (b - o) * inv is monotone in b, the swap is
-// exactly min/max of the two products, and the folds are max/min (identical for non-NaN inputs; a +-0 difference cannot change a later
-// comparison) — which maps to v_min/v_max/v_max3/v_min3 instead of compare + 2 cndmask per axis.
+// inv < 0 and folds them with `t0 > t_min ? t0 : t_min` / `t1 < t_max ? t1 : t_max`, rejecting when t_max <= t_min. The folds are max / min that
+// IGNORE a NaN plane (the comparison is false), which is what fmaxf / fminf do -> v_max3 / v_min3; the swap is kept as a select on the sign
+// of the reciprocal rather than min / max of the two products: for finite products the two are the same ((b - o) * inv is monotone in b),
+// but a NaN product — 0 * inf: the origin exactly on a box plane and an infinite reciprocal (a denormal direction component) — must stay in
+// ITS slot to be ignored there, as in the reference; min / max would replace it by the other plane. Same instruction count either way.
 MR_DEV Slab slab(const float* __restrict__ bmin, const float* __restrict__ bmax, const float o[3], const float inv[3], float t_min) {
     const float ax = (bmin[0] - o[0]) * inv[0], bx = (bmax[0] - o[0]) * inv[0];
     const float ay = (bmin[1] - o[1]) * inv[1], by = (bmax[1] - o[1]) * inv[1];
     const float az = (bmin[2] - o[2]) * inv[2], bz = (bmax[2] - o[2]) * inv[2];
+    const bool sx = inv[0] < 0.f, sy = inv[1] < 0.f, sz = inv[2] < 0.f;
     Slab s;
-    s.tn = fmaxf(fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz)), t_min);
-    s.tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    s.tn = fmaxf(fmaxf(fmaxf(sx ? bx : ax, sy ? by : ay), sz ? bz : az), t_min);
+    s.tf = fminf(fminf(sx ? ax : bx, sy ? ay : by), sz ? az : bz);
     return s;
 }
 
@@ -583,8 +586,9 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const
                     const float ex0 = (l2.y - ox) * ix, ex1 = (l3.x - ox) * ix;
                     const float ey0 = (l2.z - oy) * iy, ey1 = (l3.y - oy) * iy;
                     const float ez0 = (l2.w - oz) * iz, ez1 = (l3.z - oz) * iz;
-                    const float etn = fmaxf(fmaxf(fmaxf(fminf(ex0, ex1), fminf(ey0, ey1)), fminf(ez0, ez1)), t_min);
-                    const float etf = fminf(fminf(fmaxf(ex0, ex1), fmaxf(ey0, ey1)), fmaxf(ez0, ez1));
+                    const bool nx_ = ix < 0.f, ny_ = iy < 0.f, nz_ = iz < 0.f;           // the reference's swap (see slab(): a NaN plane stays in its slot)
+                    const float etn = fmaxf(fmaxf(fmaxf(nx_ ? ex1 : ex0, ny_ ? ey1 : ey0), nz_ ? ez1 : ez0), t_min);
+                    const float etf = fminf(fminf(nx_ ? ex0 : ex1, ny_ ? ey0 : ey1), nz_ ? ez0 : ez1);
                     if (COUNT) c_boxes++;
                     if (etf > etn && t_max > etn) { hit = tri_accepts_regs<TIMED == 2>(l0, l1, l2, ro, d); if (COUNT) c_leaves++; }
                 } else {
@@ -732,8 +736,9 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_closest4(BvhView B, co
                         const float ex0 = (l2.y - ox) * ix, ex1 = (l3.x - ox) * ix;
                         const float ey0 = (l2.z - oy) * iy, ey1 = (l3.y - oy) * iy;
                         const float ez0 = (l2.w - oz) * iz, ez1 = (l3.z - oz) * iz;
-                        const float etn = fmaxf(fmaxf(fmaxf(fminf(ex0, ex1), fminf(ey0, ey1)), fminf(ez0, ez1)), t_min);
-                        const float etf = fminf(fminf(fmaxf(ex0, ex1), fmaxf(ey0, ey1)), fmaxf(ez0, ez1));
+                        const bool nx_ = ix < 0.f, ny_ = iy < 0.f, nz_ = iz < 0.f;       // the reference's swap (see slab(): a NaN plane stays in its slot)
+                        const float etn = fmaxf(fmaxf(fmaxf(nx_ ? ex1 : ex0, ny_ ? ey1 : ey0), nz_ ? ez1 : ez0), t_min);
+                        const float etf = fminf(fminf(nx_ ? ex0 : ex1, ny_ ? ey0 : ey1), nz_ ? ez0 : ez1);
                         if (COUNT) c_boxes++;
                         if (etf > etn && closest == etn && any_hit) need_redo = true;
                         if (etf > etn && closest > etn) {

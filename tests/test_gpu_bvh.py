@@ -184,3 +184,55 @@ def test_traversal_quirks_on_a_hand_made_mesh(torch_cuda, oracle):
     assert np.array_equal(h3.cpu().numpy(), oracle.occluded_front(info, aabb, v, t, rays))
     # the axis-aligned cube faces (triangles 0..11) are never reported: their boxes cannot be entered
     assert not np.isin(ref["prim"][ref["hit"] > 0], np.arange(12)).any()
+
+
+def test_fused_interior_slab_test_on_hostile_geometry(torch_cuda, oracle):
+    """The compressed 4-wide tree's interior boxes are tested with one fma per plane, made conservative by a per-ray margin (bvh_trace.hip, node_cons):
+    every trace mode must still equal the oracle bit for bit where that margin matters — clusters of near-coincident tiny triangles (nodes far thinner
+    than 2^-19 of the scene: unused child slots could pass the fused test), a scene spanning +-100 with origins up to 1e3 away, directions with
+    denormal or zero components (infinite reciprocals) and grazing rays along the cluster planes."""
+    torch = torch_cuda
+    from mirres_restir_nerf_mesh_amd.renderer_restir import restirbvhWorker
+    from mirres_restir_nerf_mesh_amd._lib import lib, check
+    rng = np.random.default_rng(21)
+    V, T = [], []
+    centres = (rng.random((24, 3)) * 200 - 100).astype(np.float64)
+    for c in centres:
+        k = int(rng.integers(1, 7))                                   # 1..6 triangles per cluster: nodes with 1, 2, 3 real children occur
+        for _ in range(k):
+            e = rng.normal(size=(3, 3)) * rng.choice([1e-7, 1e-5, 1e-3])
+            i = len(V); V.extend([c + e[0], c + e[1], c + e[2]]); T.append([i, i + 1, i + 2])
+    for _ in range(300):                                              # ordinary geometry around them
+        c = rng.random(3) * 200 - 100; e = rng.normal(size=(3, 3)) * 6.0
+        i = len(V); V.extend([c, c + e[0], c + e[1]]); T.append([i, i + 1, i + 2])
+    v = np.array(V, np.float32); t = np.array(T, np.int32)
+    w = restirbvhWorker(torch.from_numpy(v).cuda(), torch.from_numpy(t).cuda()); w.update_mesh(w.vrt, w.v_ind)
+    info, aabb, _, _ = oracle.bvh_build(v, t)
+    assert np.array_equal(w.LBVHNode_info.cpu().numpy(), info) and np.array_equal(w.LBVHNode_aabb.cpu().numpy(), aabb)
+    n = 20000
+    o = (rng.random((n, 3)) * 240 - 120).astype(np.float32); d = rng.normal(size=(n, 3)).astype(np.float32)
+    tgt = v[t[rng.integers(0, len(t), size=n), 0]]                    # most rays aim at (or start from) a triangle: hits are common
+    aim = rng.random(n) < 0.7
+    d[aim] = (tgt[aim] + rng.normal(size=(int(aim.sum()), 3)).astype(np.float32) * 1e-3) - o[aim]
+    o[0::17] = tgt[0::17] + (rng.normal(size=(len(o[0::17]), 3)) * 1e-6).astype(np.float32)     # origins inside the tiny clusters
+    o[1::19] *= 8.0                                                    # far outside the scene box
+    d[2::23, 0] = np.float32(1e-40); d[3::23, 1] = np.float32(-1e-42); d[4::23, 2] = 0.0         # denormal / zero components
+    d[5::29] = [1e-39, 1.0, 0.0]
+    rays = oracle.make_rays(o, d)
+    ref = oracle.trace(info, aabb, v, t, rays, True, True)
+    assert 0.1 < (ref["hit"] > 0).mean() < 0.95
+    dr = torch.from_numpy(rays).cuda()
+    for mode in (1, 2):
+        hit = torch.zeros(n, dtype=torch.int32, device="cuda"); tt = torch.zeros(n, device="cuda"); pos = torch.zeros((n, 3), device="cuda")
+        nrm = torch.zeros((n, 3), device="cuda"); pr = torch.zeros(n, dtype=torch.int32, device="cuda")
+        check(lib().mirres_bvh_trace(w.h, dr.data_ptr(), n, mode, hit.data_ptr(), tt.data_ptr(), pos.data_ptr(), nrm.data_ptr(), pr.data_ptr(), None, None), "mode %d" % mode)
+        torch.cuda.synchronize()
+        m = ref["hit"] > 0
+        assert np.array_equal(hit.cpu().numpy(), ref["hit"]) and np.array_equal(pr.cpu().numpy(), ref["prim"]), mode
+        assert np.array_equal(_bits(tt.cpu().numpy()[m]), _bits(ref["t"][m])), mode
+    h0 = torch.zeros(n, dtype=torch.int32, device="cuda")
+    check(lib().mirres_bvh_trace(w.h, dr.data_ptr(), n, 0, h0.data_ptr(), None, None, None, None, None, None), "any")
+    assert np.array_equal(h0.cpu().numpy(), ref["hit"])
+    h3 = torch.zeros(n, dtype=torch.int32, device="cuda")
+    check(lib().mirres_bvh_trace(w.h, dr.data_ptr(), n, 3, h3.data_ptr(), None, None, None, None, None, None), "front")
+    assert np.array_equal(h3.cpu().numpy(), oracle.occluded_front(info, aabb, v, t, rays))
