@@ -143,17 +143,31 @@ def build_gbuffer_from_pose(worker, pose, intrinsics, H, W, ssaa=1, mlp_mat=None
     return dict(fx=w, fy=h, occ=occ, pos=pos, normal=normal, depth=depth, kd=kd_map, rm=rm, ray_dir=dirs, eye=pose[:3, 3].detach().cpu().numpy())
 
 
-def test_view(worker, mlp_mat, env_map, pose, intrinsics, H, W, spp, ssaa=1, random_offset=0, de=2, c=2.0, n=0.1, p=0.001, max_bounce=None):
+def test_view(worker, mlp_mat, env_map, pose, intrinsics, H, W, spp, ssaa=1, random_offset=0, de=2, c=2.0, n=0.1, p=0.001, max_bounce=None,
+              albedo_scale=None, shard=None, rank=0, world=1, group=None):
     """One `--test --spp N` frame of the BRDF branch (Trainer.test_step -> render_stage1(is_test=True), nerf/renderer.py:1083-1129, 1162-1164,
     1208-1209, 1265-1302): G-buffer for the dataset camera, the fused frame (mirres_render), tone curve, alpha, SSAA down-scale, white background.
-    Returns the [H, W, 3] image in [0, 1]."""
+    Returns the [H, W, 3] image in [0, 1].
+    Relighting (`--envmap_path`, :1025-1026, 1086-1089, 1109-1111): pass the external map as `env_map` and `albedo_scale` = (--albedo_scale_x, _y,
+    _z): the primary albedo is scaled here and `use_scale` does the same at the indirect hits.
+    One view on several GPUs: `shard` = "strips" (exact row strips + halo exchange + all-gather of radiance rows, dist.render_strips) or "spp"
+    (sample slices + all-reduce, dist.render_sharded) with this process's `rank` of `world`; every rank returns the whole image."""
     from . import renderer_restir as RR
+    from . import dist as MD
     from ._ops import get_ctx
     g = build_gbuffer_from_pose(worker, pose, intrinsics, H, W, ssaa, mlp_mat)
+    use_scale = albedo_scale is not None
+    scale = tuple(float(x) for x in albedo_scale) if use_scale else (1.0, 1.0, 1.0)
+    if use_scale:
+        g["kd"] = (g["kd"] * torch.tensor(scale, dtype=torch.float32, device=g["kd"].device)[None, :]).contiguous()      # :1086-1089
     ctx = get_ctx(g["fx"], g["fy"]) if max_bounce is None else get_ctx(g["fx"], g["fy"], max_bounce=max_bounce)
-    occ = g["occ"].clone()
-    out = RR.render_fused(ctx, worker, mlp_mat, False, (1, 1, 1), env_map, occ, g["normal"], g["depth"], g["kd"], g["rm"], g["ray_dir"], g["pos"],
-                          spp, de, 2 ** (de - 1), c, n, p, random_offset)[0]
+    if world > 1 and shard == "strips":
+        out = MD.render_strips(ctx, worker, mlp_mat, env_map, g, spp, random_offset, rank, world, de, 2 ** (de - 1), c, n, p, use_scale, scale, group, max_bounce)
+    elif world > 1 and shard == "spp":
+        out = MD.render_sharded(ctx, worker, mlp_mat, env_map, g, spp, random_offset, rank, world, de, 2 ** (de - 1), c, n, p, use_scale, scale, group)
+    else:
+        out = RR.render_fused(ctx, worker, mlp_mat, use_scale, scale, env_map, g["occ"].clone(), g["normal"], g["depth"], g["kd"], g["rm"], g["ray_dir"], g["pos"],
+                              spp, de, 2 ** (de - 1), c, n, p, random_offset)[0]
     return postprocess(torch.nan_to_num(out[0], 0.0), g["occ"], H, W, ssaa)
 
 

@@ -10,6 +10,14 @@ The material-field constants are the reference's CLI ones and MUST equal the tra
 `--roughness_min` / `--me_max` (main.py:109-110,169-170) and, for completeness, `--kd_min` / `--kd_max` (main.py:167-168).  Checkpoints written by
 this package record them (`material_config`); a flag given on the command line wins, a mismatch with the recorded value is reported.
 
+Relighting (reference: `--test --envmap_path X.hdr --albedo_scale_x/y/z`, nerf/network.py:134-139, nerf/renderer.py:1025-1026, 1086-1089, 1109-1111):
+`--envmap_path` replaces the trained environment map by a Radiance .hdr file (any size) and switches the albedo scaling on.
+
+Several GPUs (`python -m torch.distributed.run --nproc-per-node N scripts/evaluate.py ... --shard views|strips|spp`): `views` (default) deals the
+dataset views round-robin to the ranks — no data-path communication, metrics reduced at the end; `strips` / `spp` render EVERY view on all ranks
+(exact row strips with per-sample halo exchange and an all-gather of the radiance rows / sample slices with one all-reduce; dist.py) — what a single
+large frame wants.  Rank 0 writes the images of the frames it holds (all of them for strips / spp).
+
 `--synthetic` builds a throw-away workspace (synthetic mesh, random material field, sky map, four orbit cameras) first and evaluates that — the
 smoke run of this script on a box without a reference workspace.  Camera convention: the blender `transform_matrix` is the cam2world pose with its
 translation scaled by `--scale` and shifted by `--offset` (nerf_matrix_to_ngp, nerf/provider.py:18-21; pass the values the reference run used)."""
@@ -63,10 +71,24 @@ def main():
     p.add_argument("--kd_min", type=float, nargs=3, default=None); p.add_argument("--kd_max", type=float, nargs=3, default=None)
     p.add_argument("--limit", type=int, default=0); p.add_argument("--H", type=int, default=800); p.add_argument("--W", type=int, default=800)
     p.add_argument("--scale", type=float, default=1.0); p.add_argument("--offset", type=float, nargs=3, default=[0.0, 0.0, 0.0]); p.add_argument("--synthetic", action="store_true")
+    p.add_argument("--envmap_path", default="None", help="main.py --envmap_path: Radiance .hdr environment map for relighting")
+    p.add_argument("--albedo_scale_x", type=float, default=1.0); p.add_argument("--albedo_scale_y", type=float, default=1.0); p.add_argument("--albedo_scale_z", type=float, default=1.0)
+    p.add_argument("--shard", choices=("views", "strips", "spp"), default="views", help="how N > 1 ranks (torch.distributed.run) divide the work")
     a = p.parse_args()
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        backend = os.environ.get("MIRRES_DIST_BACKEND", "nccl")
+        dist.init_process_group(backend, **({"device_id": torch.device("cuda", torch.cuda.current_device())} if backend == "nccl" else {}))
     if a.synthetic:
         a.workspace = a.workspace or os.path.join(ROOT, "gpurun_out", "eval_ws")
-        a.ckpt, a.transforms = synthetic_workspace(a.workspace, a.H // a.downscale, a.W // a.downscale)
+        if rank == 0:
+            a.ckpt, a.transforms = synthetic_workspace(a.workspace, a.H // a.downscale, a.W // a.downscale)
+        if world > 1:
+            dist.barrier()
+        a.ckpt, a.transforms = os.path.join(a.workspace, "checkpoints", "ngp_stage1_ep0001.pth"), os.path.join(a.workspace, "transforms_test.json")
     if not (a.workspace and a.ckpt and a.transforms):
         p.error("--workspace, --ckpt and --transforms are required (or --synthetic)")
     out_dir = a.out or os.path.join(a.workspace, "results_brdf")
@@ -77,6 +99,10 @@ def main():
     aabb, mn, mx = CK.material_field_args(cfg)     # nerf/network.py:119-125
     mlp = MLPTexture3D(aabb, channels=6, min_max=(mn.cuda(), mx.cuda()))
     voff, light = CK.apply_checkpoint(ck, mlp, n_vertices=v.shape[0])
+    albedo_scale = None
+    if a.envmap_path != "None":      # relighting: the external map as it is (no clamp), albedo scaling on (network.py:134-139, renderer.py:1109-1111)
+        light = torch.from_numpy(np.ascontiguousarray(harness.read_hdr(a.envmap_path))).cuda()
+        albedo_scale = (a.albedo_scale_x, a.albedo_scale_y, a.albedo_scale_z)
     if light is None:
         raise SystemExit("%s has no light_base (a --use_brdf stage-1 checkpoint is needed)" % a.ckpt)
     verts = torch.from_numpy(v).cuda() + (voff if voff is not None else 0)
@@ -89,11 +115,18 @@ def main():
     pm, sm = meters.PSNRMeter(), meters.SSIMMeter()
     name = os.path.splitext(os.path.basename(a.ckpt))[0]
     t_render = 0.0
+    n_mine = 0
     for i, fr in enumerate(frames):
+        if world > 1 and a.shard == "views" and i % world != rank:
+            continue
+        n_mine += 1
         pose = nerf_pose(fr["transform_matrix"], a.scale, a.offset)
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        img = harness.test_view(W, mlp, light, torch.from_numpy(pose), intr, Hh, Ww, a.spp, a.ssaa, random_offset=i * 7919)
+        img = harness.test_view(W, mlp, light, torch.from_numpy(pose), intr, Hh, Ww, a.spp, a.ssaa, random_offset=i * 7919, albedo_scale=albedo_scale,
+                                shard=a.shard if world > 1 and a.shard != "views" else None, rank=rank, world=world)
         torch.cuda.synchronize(); t_render += time.perf_counter() - t0
+        if world > 1 and a.shard != "views" and rank != 0:
+            continue                                                       # every rank holds the whole frame; rank 0 writes and scores it
         files = meters.write_test_frame(out_dir, name, i, img)
         gt_path = os.path.join(base, fr["file_path"] + ".png")
         note = ""
@@ -106,10 +139,17 @@ def main():
             note = "  PSNR %.3f  SSIM %.4f" % (pm.update(img, gt_t), sm.update(img, gt_t))
         print("[%d/%d] %s%s" % (i + 1, len(frames), os.path.basename(files[0]), note), flush=True)
     n = len(frames)
-    print("rendered %d views %dx%d ssaa %d spp %d: %.1f ms/view (%.1f Msamples/s)" % (n, Ww, Hh, a.ssaa, a.spp, 1e3 * t_render / max(n, 1),
-                                                                                     n * Ww * Hh * a.ssaa ** 2 * a.spp / max(t_render, 1e-9) / 1e6))
-    if pm.N:
-        print(pm.report(), sm.report())
+    if world > 1:      # wall time of the job = the slowest rank; metric sums over the ranks that scored frames
+        red = torch.tensor([t_render, pm.V, float(pm.N), sm.V, float(sm.N)], dtype=torch.float64, device="cuda")
+        tmax = red[:1].clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX); dist.all_reduce(red, op=dist.ReduceOp.SUM)
+        t_render = float(tmax.item()); pm.V, pm.N, sm.V, sm.N = float(red[1]), int(red[2]), float(red[3]), int(red[4])
+    if rank == 0:
+        print("rendered %d views %dx%d ssaa %d spp %d on %d GPU(s)%s: %.1f ms/view (%.1f Msamples/s)" % (
+            n, Ww, Hh, a.ssaa, a.spp, world, (" [%s]" % a.shard) if world > 1 else "", 1e3 * t_render / max(n, 1), n * Ww * Hh * a.ssaa ** 2 * a.spp / max(t_render, 1e-9) / 1e6))
+        if pm.N:
+            print(pm.report(), sm.report())
+    if world > 1:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
