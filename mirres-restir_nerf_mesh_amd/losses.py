@@ -153,11 +153,15 @@ def stage1_loss(outputs, gt_rgb, gt_rgb_linear, opt, vertices=None, voffsets=Non
 
 
 def stage1_optimizer_step(loss, optimizer, optimizer_mat=None, optimizer_light=None, light_base=None, encoder_params=None, scheduler=None,
-                          scheduler_mat=None, scheduler_light=None):
+                          scheduler_mat=None, scheduler_light=None, grad_sync=None):
     """backward + the three optimiser steps of nerf/utils.py:1565-1589: geometry first, then the environment-map gradient x 64 and the hash-grid
     gradient / 8, material and light steps, and the light clamped at 0.01 from below.  (The reference wraps the geometry step in a GradScaler; fp16
-    is off on this path, where the scaler is the identity.)  The caller zeroes the three optimisers' gradients before rendering, as :1555-1558 does."""
+    is off on this path, where the scaler is the identity.)  The caller zeroes the three optimisers' gradients before rendering, as :1555-1558 does.
+    `grad_sync` (data-parallel training: one view or strip per rank) is called between the backward pass and the first optimiser step — e.g.
+    `lambda: dist.allreduce_gradients([voffsets, *mlp.parameters(), light_base])`, one flat RCCL all-reduce of every parameter gradient."""
     loss.backward()
+    if grad_sync is not None:
+        grad_sync()
     optimizer.step()
     if scheduler is not None:
         scheduler.step()
