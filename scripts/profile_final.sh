@@ -1,18 +1,19 @@
 #!/bin/bash
 # profiles for the round: kernel trace of the default bench command, PMC HBM traffic of the dominant kernel, MLP GEMM-phase kernel
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-R=${1:-r01}
+R=${1:-r02}
+RP="timeout -k 5 600 rocprofv3"     # every profiler pass under its own limit: a counter set the tool rejects must not hold the box
 rm -rf gpurun_out/pf; mkdir -p gpurun_out/pf/kt gpurun_out/pf/fetch gpurun_out/pf/write gpurun_out/pf/mlp gpurun_out/pf/tr gpurun_out/out
 python3 bench.py > gpurun_out/out/${R}_bench_default.json 2> gpurun_out/out/${R}_bench_default.err
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pf/kt -o kt -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/pf/kt/log 2>&1
+$RP --kernel-trace --stats --output-format csv -d gpurun_out/pf/kt -o kt -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/pf/kt/log 2>&1
 grep '^{' gpurun_out/pf/kt/log | tail -1 > gpurun_out/out/${R}_bench_under_rocprof.json
 cp gpurun_out/pf/kt/kt_kernel_stats.csv gpurun_out/out/${R}_kernel_stats.csv
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pf/fetch -o f -- python3 bench.py --spp 8 --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > gpurun_out/pf/fetch/log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pf/write -o w -- python3 bench.py --spp 8 --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > gpurun_out/pf/write/log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pf/mlp -o m -- python3 scripts/dev_mlp_bench.py > gpurun_out/pf/mlp/log 2>&1
+$RP --pmc FETCH_SIZE --output-format csv -d gpurun_out/pf/fetch -o f -- python3 bench.py --spp 8 --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > gpurun_out/pf/fetch/log 2>&1
+$RP --pmc WRITE_SIZE --output-format csv -d gpurun_out/pf/write -o w -- python3 bench.py --spp 8 --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > gpurun_out/pf/write/log 2>&1
+$RP --kernel-trace --stats --output-format csv -d gpurun_out/pf/mlp -o m -- python3 scripts/dev_mlp_bench.py > gpurun_out/pf/mlp/log 2>&1
 cp gpurun_out/pf/mlp/m_kernel_stats.csv gpurun_out/out/${R}_mlp_kernel_stats.csv
 grep -E '^(mlp_mfma|valu)' gpurun_out/pf/mlp/log > gpurun_out/out/${R}_mlp_bench.txt
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pf/tr -o t -- python3 scripts/train_step_bench.py --steps 3 > gpurun_out/pf/tr.log 2>&1
+$RP --kernel-trace --stats --output-format csv -d gpurun_out/pf/tr -o t -- python3 scripts/train_step_bench.py --steps 3 > gpurun_out/pf/tr.log 2>&1
 cp gpurun_out/pf/tr/t_kernel_stats.csv gpurun_out/out/${R}_train_step_kernel_stats.csv
 grep '^stage-1' gpurun_out/pf/tr.log > gpurun_out/out/${R}_train_step.txt
 python3 - "$R" <<'PY'
@@ -40,6 +41,10 @@ json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate pa
            "k_trace_any_hbm_bytes_per_launch": round((2 * f['avg_KB'] + w['avg_KB']) * 1024)}, open('gpurun_out/out/pmc_traffic.json', 'w'), indent=1)
 print(open('gpurun_out/out/pmc_traffic.json').read())
 PY
+# round 2: the shadow-ray kernel alone (frame-like ray set): SQ / TA / TCP / TD counters per launch, per-phase wave cycles, instruction issue costs
+bash scripts/pmc_any.sh any 1600 7 3 0 > gpurun_out/out/${R}_pmc_any4q.txt 2>&1
+cp gpurun_out/pmc_any/summary.json gpurun_out/out/${R}_pmc_any4q.json 2>/dev/null
+hipcc --offload-arch=gfx950 -O3 -w scripts/ubench/valu_rates.hip -o /tmp/valu_rates 2>/dev/null && timeout -k 3 120 /tmp/valu_rates > gpurun_out/out/${R}_valu_rates.txt 2>&1
 rm -rf gpurun_out/pf
 cat gpurun_out/out/${R}_bench_default.json | cut -c1-1800
 head -12 gpurun_out/out/${R}_kernel_stats.csv | cut -c1-160
