@@ -185,7 +185,8 @@ def main():
                 "own_bytes_per_ray": round(own_bytes_any / max(1, rays_any), 1), "own_achieved": round(own_achieved, 2), "own_frac": round(own_achieved / 8000.0, 5),
                 "note": "achieved = SURVEY 8d algorithmic bytes (reference layout, reference traversal's visit counts on the same rays) / event-timed duration; "
                         "it exceeds the HBM peak because the production kernel stops at the first occluder, walks a 4-wide tree near-first and fetches 64-byte compressed "
-                        "records (own_*: the bytes it actually requests), and the 43 MB layout is cache resident (traffic = HBM bytes from PMC); the kernel is VALU-issue bound",
+                        "records (own_*: the bytes it actually requests), and the 43 MB layout is cache resident (traffic = HBM bytes from PMC); the kernel is bound by issue slots and the "
+                        "dependent chain of a traversal step, not by memory: fetching every record twice costs +1.5 % (DESIGN.md section 5, round 2)",
                 "closest_launch_ms": round(ms_cl / max(1, n_cl), 4), "closest_achieved": round(bytes_cl / (ms_cl * 1e-3) / 1e9, 2) if ms_cl > 0 else 0.0, "rays_per_pixel_sample": round(total_rays / (float(N) * prof_spp), 3),
                 "per_ray": {"any_reference": [round(st[k] / max(1, rays_any), 2) for k in ("popped", "entered", "leaves")], "any_production": [round(own[k] / max(1, rays_any), 2) for k in ("popped", "entered", "leaves")],
                             "closest": [round(st[k] / max(1, rays_cl), 2) for k in ("cl_popped", "cl_entered", "cl_leaves")]},
