@@ -225,14 +225,14 @@ static int carve_batch(mirres_ctx* ctx, int N, int K, int max_bounce, size_t TS,
         char* fresh = nullptr;
         // MIRRES_POOL_LIMIT_MB: refuse larger pools as if the device were full (how the tests exercise the fall-back without filling 288 GB)
         const char* lim_s = getenv("MIRRES_POOL_LIMIT_MB"); const size_t lim = lim_s ? (size_t)atoll(lim_s) << 20 : 0;
-        auto hipMalloc = [&](char** p, size_t b) -> hipError_t { if (lim && b > lim) return hipErrorOutOfMemory; return ::hipMalloc(p, b); };
-        hipError_t e = hipMalloc(&fresh, need);
+        auto pool_alloc = [&](char** p, size_t b) -> hipError_t { if (lim && b > lim) return hipErrorOutOfMemory; return hipMalloc(p, b); };
+        hipError_t e = pool_alloc(&fresh, need);
         if (e != hipSuccess) {
             (void)hipGetLastError(); fresh = nullptr;
             if (e != hipErrorOutOfMemory) { set_error("mirres_render: cannot allocate the %zu-byte batch pool (%s)", need, hipGetErrorString(e)); return MIRRES_E_HIP; }
             if (ctx->ptb) { MR_HIP(hipDeviceSynchronize()); MR_HIP(hipFree(ctx->ptb)); ctx->ptb = nullptr; ctx->ptb_bytes = 0; }
             for (;;) {
-                e = hipMalloc(&fresh, need);
+                e = pool_alloc(&fresh, need);
                 if (e == hipSuccess) break;
                 (void)hipGetLastError(); fresh = nullptr;
                 if (e != hipErrorOutOfMemory || K == 1) {   // nothing fits now: no pool, no remembered size — the next frame starts over
