@@ -180,7 +180,7 @@ def render_stage1_outputs(worker, vertices, voffsets, triangles, mlp_mat, env_ma
     """`render_stage1` for `--stage 1 --use_brdf --use_restir` training (nerf/renderer.py:960-1302) as far as the material / light / geometry
     branch goes: moved mesh -> BVH update -> G-buffer front half (build_gbuffer_stage1) -> jittered material taps (:1016-1022) ->
     run_restir_di_with_pt (:1112-1123) -> clamp, tone curve (:1125-1129, 1162-1164) -> dr.antialias of alpha and of every output image (:1184-1200;
-    the indirect images detached, as there) -> alpha (:1208-1240).  Returns the entries of the reference's `outputs` dict that losses.stage1_loss
+    the indirect images detached, as there) -> alpha (:1208-1240) -> SSAA down-scale to H x W when ssaa > 1 (:1265-1297) -> background (:1301).  Returns the entries of the reference's `outputs` dict that losses.stage1_loss
     reads, except `image` (the NeRF colour branch belongs to stage 0).  With a dataset camera (`pose`, `intrinsics`) the antialias step runs and the
     image loss reaches the vertex positions through visibility; with the synthetic orbit camera (no projection matrix) it is skipped.  `topology` =
     raster.antialias_topology(triangles) (built per call when None).  `gb_depth` ([N, 2]: z, |dz|; :1070-1081) selects the --use_bi_de bilateral
@@ -220,9 +220,14 @@ def render_stage1_outputs(worker, vertices, voffsets, triangles, mlp_mat, env_ma
         aa = lambda x: torch.clamp(x, 0.0, 1.0)
     if out_ao is not None:
         extra["normal_ao"] = (alpha * aa(out_ao.detach())).detach()                                                 # :1195, 1226-1228
-    image_brdf = alpha * aa(brdf_rgbs) + (1 - alpha) * bg_color                                                     # :1186, 1209, 1301
-    return dict(image_brdf=image_brdf, diffuse_light=alpha * aa(out[1]), specular_light=alpha * aa(out[2]), img_brdf_indirect=(alpha * aa(out[3].detach())).detach(),
-                kd_grad=kd_grad * g["occ"], ks_grad=ks_grad * g["occ"], normal_grad=torch.zeros((N, 1), device=dev), occ=alpha, fx=fx, fy=fy, **extra)   # :1350-1352
+    res = dict(image_brdf=alpha * aa(brdf_rgbs), diffuse_light=alpha * aa(out[1]), specular_light=alpha * aa(out[2]),                      # :1186, 1209-1240
+               img_brdf_indirect=(alpha * aa(out[3].detach())).detach(), kd_grad=kd_grad * g["occ"], ks_grad=ks_grad * g["occ"],
+               normal_grad=torch.zeros((N, 1), device=dev), occ=alpha, **extra)
+    if ssaa > 1:      # every image goes through the SSAA down-scale before the losses see it (:1265-1297); T = 1 - alpha is scaled like the images
+        res = {k: scale_img_hwc(v.view(fy, fx, v.shape[-1]), (H, W)).reshape(H * W, v.shape[-1]) for k, v in res.items()}
+        fx, fy = W, H
+    res["image_brdf"] = res["image_brdf"] + (1 - res["occ"]) * bg_color                                            # :1301
+    return dict(res, fx=fx, fy=fy)                                                                                 # :1350-1352
 
 
 def linear2srgb(x):
