@@ -68,7 +68,7 @@ def test_stage1_front_half_gbuffer(scene_mod):
     g1 = harness.build_gbuffer_stage1(W, vt, tt, 48, 40)
     g0 = harness.build_gbuffer(W, 48, 40)
     fg = g0["occ"][:, 0] > 0.5
-    assert torch.equal(g1["occ"], g0["occ"]) and float((g1["pos"][fg] - g0["pos"][fg]).abs().max()) < 2e-5
+    assert torch.equal(g1["occ"], g0["occ"]) and float((g1["pos"].detach()[fg] - g0["pos"].detach()[fg]).abs().max()) < 2e-5
     n1 = g1["normal"][fg]
     assert torch.allclose(n1.norm(dim=1), torch.ones_like(n1[:, 0]), atol=1e-5)
     cosang = (n1 * g0["normal"][fg]).sum(1)
