@@ -62,3 +62,6 @@ def test_argument_validation_without_gpu():
     assert L.mirres_ctx_create(C.byref(h), 0, 10, None) < 0
     assert L.mirres_eaw(0, 4, 1, 1.0, 1.0, 1.0, None, None, None, None, None, None) < 0
     assert L.mirres_matnet_fwd(None, None, 4, None, None, None) < 0
+    assert L.mirres_matnet_bwd(None, None, 4, None, None, None, None, None, None, None) < 0
+    assert L.mirres_antialias(8, 8, 3, None, None, None, None, None, None, None) < 0 and b"mirres_antialias" in L.mirres_last_error()
+    assert L.mirres_antialias_bwd(8, 8, 3, None, None, None, None, None, None, None, None, 1.0, None) < 0
