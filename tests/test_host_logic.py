@@ -272,3 +272,38 @@ def test_mvp_and_rays_describe_one_camera():
     j, i = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
     want = torch.stack(((2 * i + 1) / W - 1, (2 * j + 1) / H - 1), -1).view(-1, 2)
     assert float((ndc - want).abs().max()) < 1e-5 and bool((clip[:, 3] > 0).all())
+
+
+def test_antialias_reference_statement_on_analytic_edges():
+    """tests/util.py antialias_ref (the checker of the HIP operator) on cases with a closed-form answer: a half-plane-like triangle whose straight edge
+    crosses pixel rows at a known abscissa — the blend weight of the partly covered pixel must equal its covered fraction along the row (and the
+    pixel on the inside gives colour away when the edge cuts before the midpoint); a shared interior edge between two coplanar triangles blends nothing."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from util import antialias_ref
+    H, W = 6, 16
+    def clip_of(px, py):                    # pixel coordinates -> clip space with w = 1 (pixel centre (i, j) <-> NDC ((2i + 1) / W - 1, ...))
+        return [2 * px / W - 1, 2 * py / H - 1, 0.0, 1.0]
+    for edge_x in (10.3, 9.8):
+        pos = np.array([clip_of(-50, -50), clip_of(edge_x, -50), clip_of(edge_x, 50), clip_of(-50, 50)], np.float64)
+        tri = np.array([[0, 1, 2], [0, 2, 3]], np.int32)
+        opp = np.array([[-1, -1, 3], [1, -1, -1]], np.int32)        # edge (0, 2) is shared
+        rast = np.zeros((H * W, 4)); color = np.zeros((H * W, 3))
+        for p in range(H * W):
+            x, y = (p % W) + 0.5, (p // W) + 0.5
+            if x < edge_x:
+                rast[p] = [0.3, 0.3, 1.0, 1 if (y - (-50)) * (edge_x + 50) < (x + 50) * 100 else 2]      # below / above the diagonal (0, 2)
+                color[p] = [1.0, 0.5, 0.25]
+        out, pairs = antialias_ref(color, rast, pos, tri, opp, H, W)
+        inside = int(np.floor(edge_x - 0.5)); outside = inside + 1          # the pixel pair the edge passes between (centres at +0.5)
+        u = edge_x - (inside + 0.5)
+        for row in range(H):
+            pi, po = row * W + inside, row * W + outside
+            if u > 0.5:       # the triangle reaches into the outside pixel: it takes (u - 1/2) of the inside colour = its covered fraction of the row
+                np.testing.assert_allclose(out[po], (u - 0.5) * color[pi], atol=1e-12); np.testing.assert_allclose(out[pi], color[pi], atol=1e-12)
+            else:             # the edge cuts before the midpoint: the inside pixel is partly uncovered and gives (1/2 - u) away
+                np.testing.assert_allclose(out[pi], color[pi] * (1 - (0.5 - u)), atol=1e-12); np.testing.assert_allclose(out[po], 0.0, atol=1e-12)
+        touched = {p for p0, p1, a, _, _ in pairs for p in (p0, p1)}
+        assert touched == {row * W + c for row in range(H) for c in (inside, outside)}          # only the silhouette pairs; the shared diagonal blends nothing
+        changed = np.nonzero(np.abs(out - color).max(1) > 0)[0]
+        assert set(changed.tolist()) <= touched
