@@ -230,6 +230,11 @@ def render_stage1_outputs(worker, vertices, voffsets, triangles, mlp_mat, env_ma
     return dict(res, fx=fx, fy=fy)                                                                                 # :1350-1352
 
 
+def srgb_to_linear(x):
+    """nerf/utils.py:57-58: the inverse tone curve the data loader applies to the training images (`images_linear`, :927) for the shading loss."""
+    return torch.where(x < 0.04045, x / 12.92, ((x + 0.055) / 1.055) ** 2.4)
+
+
 def linear2srgb(x):
     return torch.where(x <= 0.0031308, 12.92 * x, 1.055 * torch.pow(x + 1e-6, 1.0 / 2.4) - 0.055)
 

@@ -19,9 +19,7 @@ from mirres_restir_nerf_mesh_amd import renderer_restir as RR, harness, losses, 
 from mirres_restir_nerf_mesh_amd.render_helper import MLPTexture3D
 
 
-def srgb_to_linear(x):
-    """nerf/utils.py:108-118."""
-    return torch.where(x <= 0.04045, x / 12.92, torch.pow(torch.clamp((x + 0.055) / 1.055, min=1e-8), 2.4))
+srgb_to_linear = harness.srgb_to_linear      # nerf/utils.py:57-58 (pinned to the reference's function in tests/test_losses.py)
 
 
 def orbit_pose(az_deg, el_deg, dist=3.2):

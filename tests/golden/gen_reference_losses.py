@@ -4,7 +4,7 @@ values and input gradients in tests/golden/ref_losses.npz.
 Taken from /root/reference/nerf/utils.py by AST (the module itself does not import here: its unrelated dependencies are missing):
   luma, value, _clip_0to1_warn_torch, linear2srgb_torch, linear_to_srgb (its @torch.jit.script decorator dropped), shading_loss,
   material_smoothness_grad, material_extra_kd_smoothness_grad, laplacian_uniform, laplacian_cot, laplacian_smooth_loss, the class PSNRMeter,
-  custom_meshgrid, safe_normalize, get_rays; from nerf/renderer.py: scale_img_nhwc, scale_img_hwc.
+  custom_meshgrid, safe_normalize, get_rays, srgb_to_linear; from nerf/renderer.py: scale_img_nhwc, scale_img_hwc.
 Nothing of the reference's text is stored: only the numbers it produced.
 """
 import ast
@@ -81,6 +81,10 @@ def main():
     r = ns["get_rays"](pose[None], intr, Hh, Ww, -1)
     dirs = ns["safe_normalize"](rns["scale_img_hwc"](r["rays_d"].view(Hh, Ww, 3), (Hh * 2, Ww * 2), mag="nearest").view(-1, 3).contiguous())
     out.update(rays_pose=pose.numpy(), rays_intr=intr, rays_hw=np.array([Hh, Ww], np.int32), rays_o=r["rays_o"].numpy(), rays_d=r["rays_d"].numpy(), rays_dirs_ssaa2=dirs.numpy())
+    # srgb_to_linear (nerf/utils.py:57-58): what the data loader applies to the training images for the shading loss (images_linear, :927)
+    load_functions("nerf/utils.py", ["srgb_to_linear"], ns)
+    xs = torch.cat((torch.rand(4000, generator=g), torch.tensor([0.0, 0.04045, 0.040449999, 0.0404501, 1.0, 0.5])))
+    out.update(s2l_in=xs.numpy(), s2l_out=ns["srgb_to_linear"](xs).numpy())
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "ref_losses.npz"), **out)
     print({k: (v.shape if hasattr(v, "shape") and v.shape else v) for k, v in out.items()})
 
