@@ -4,7 +4,8 @@ values and input gradients in tests/golden/ref_losses.npz.
 Taken from /root/reference/nerf/utils.py by AST (the module itself does not import here: its unrelated dependencies are missing):
   luma, value, _clip_0to1_warn_torch, linear2srgb_torch, linear_to_srgb (its @torch.jit.script decorator dropped), shading_loss,
   material_smoothness_grad, material_extra_kd_smoothness_grad, laplacian_uniform, laplacian_cot, laplacian_smooth_loss, the class PSNRMeter,
-  custom_meshgrid, safe_normalize, get_rays, srgb_to_linear; from nerf/renderer.py: scale_img_nhwc, scale_img_hwc.
+  custom_meshgrid, safe_normalize, get_rays, srgb_to_linear; from nerf/renderer.py: scale_img_nhwc, scale_img_hwc; from nerf/provider.py: the
+  statements of NeRFDataset.__init__ that build the projection matrix.
 Nothing of the reference's text is stored: only the numbers it produced.
 """
 import ast
@@ -81,6 +82,24 @@ def main():
     r = ns["get_rays"](pose[None], intr, Hh, Ww, -1)
     dirs = ns["safe_normalize"](rns["scale_img_hwc"](r["rays_d"].view(Hh, Ww, 3), (Hh * 2, Ww * 2), mag="nearest").view(-1, 3).contiguous())
     out.update(rays_pose=pose.numpy(), rays_intr=intr, rays_hw=np.array([Hh, Ww], np.int32), rays_o=r["rays_o"].numpy(), rays_d=r["rays_d"].numpy(), rays_dirs_ssaa2=dirs.numpy())
+    # the dataset's projection matrix (nerf/provider.py:277-288): the statements of NeRFDataset.__init__ that build it, executed from the file's AST on a
+    # stand-in `self` (the module needs cv2 / the data folder) -> mvp = projection @ inverse(pose)
+    import types
+    tree = ast.parse(open(os.path.join(REF, "nerf/provider.py")).read())
+    stmts = []
+    for node in ast.walk(tree):
+        if isinstance(node, ast.FunctionDef) and node.name == "__init__":
+            for st in node.body:
+                if not (isinstance(st, ast.Assign) and len(st.targets) == 1 and 270 <= st.lineno <= 290):
+                    continue
+                tg = st.targets[0]
+                if (isinstance(tg, ast.Name) and tg.id in ("y", "aspect")) or (isinstance(tg, ast.Attribute) and tg.attr in ("near", "far", "projection")):
+                    stmts.append(st)
+    assert len(stmts) >= 5, [s_.lineno for s_ in stmts]
+    me = types.SimpleNamespace(H=30, W=50, opt=types.SimpleNamespace(min_near=0.05))
+    pns = {"self": me, "np": np, "torch": torch, "fl_y": 61.0}
+    exec(compile(ast.Module(body=stmts, type_ignores=[]), "provider.py", "exec"), pns)
+    out.update(proj_hw=np.array([30, 50], np.int32), proj_fl=np.float32(61.0), proj_near=np.float32(0.05), proj_out=np.asarray(me.projection, np.float32))
     # srgb_to_linear (nerf/utils.py:57-58): what the data loader applies to the training images for the shading loss (images_linear, :927)
     load_functions("nerf/utils.py", ["srgb_to_linear"], ns)
     xs = torch.cat((torch.rand(4000, generator=g), torch.tensor([0.0, 0.04045, 0.040449999, 0.0404501, 1.0, 0.5])))

@@ -121,3 +121,12 @@ def test_srgb_to_linear_matches_the_reference_function(g):
     assert np.array_equal(got, g["s2l_out"])
     back = harness.linear2srgb(torch.from_numpy(g["s2l_out"])).numpy()                      # and the forward curve inverts it (up to its 1e-6 offset)
     assert np.abs(back - g["s2l_in"]).max() < 2e-5
+
+
+def test_projection_matrix_matches_the_reference_dataset(g):
+    """harness.mvp_from_pose with an identity pose against the projection matrix nerf/provider.py:277-287 builds (its own statements, executed)."""
+    import torch
+    from mirres_restir_nerf_mesh_amd import harness
+    H, W = (int(v) for v in g["proj_hw"]); fl = float(g["proj_fl"])
+    got = harness.mvp_from_pose(torch.eye(4), (fl, fl, W * 0.5, H * 0.5), H, W, near=float(g["proj_near"])).numpy()
+    np.testing.assert_allclose(got, g["proj_out"], rtol=1e-6, atol=1e-7)
