@@ -121,3 +121,21 @@ def test_read_checkpoint_returns_recorded_material_constants(tmp_path):
     ck["material_config"] = CK.material_config(bound=1.0, me_max=0.5)
     p = str(tmp_path / "b.pth"); torch.save(ck, p)
     assert CK.read_checkpoint(p)["material_config"]["me_max"] == 0.5
+
+
+def test_reads_a_checkpoint_written_by_the_reference_code():
+    """tests/golden/ref_checkpoint_stage1.pth was written by the reference's OWN Trainer.save_checkpoint (nerf/utils.py:1838-1883, executed from its AST
+    over a model built from the reference's MLPTexture3D / _MLP classes; gen_reference_checkpoint.py): read_checkpoint must find every tensor under the
+    names that code used, and the generator also checked the other direction (a file written by checkpoint.save_checkpoint loads through the
+    reference's own load_checkpoint)."""
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    want = np.load(os.path.join(here, "ref_checkpoint_stage1.npz"))
+    r = CK.read_checkpoint(os.path.join(here, "ref_checkpoint_stage1.pth"))
+    assert r["epoch"] == int(want["epoch"]) and r["global_step"] == int(want["global_step"]) and r["stage"] == 1 and r["material_config"] is None
+    assert np.array_equal(r["vertices_offsets"].numpy(), want["voff"]) and np.array_equal(r["grid_params"].numpy(), want["grid"])
+    assert all(np.array_equal(a.numpy(), want[k]) for a, k in zip(r["mlp_weights"], ("w0", "w1", "w2")))
+    assert np.array_equal(r["light_base"].numpy(), want["light"]) and r["light_base"].dtype == torch.float32
+    assert set(want["keys"].tolist()) >= {"vertices_offsets", "mlp_mat_opt.encoder.params", "mlp_mat_opt.net.net.0.weight", "mlp_mat_opt.net.net.2.weight", "mlp_mat_opt.net.net.4.weight"}
+    assert bool(want["package_file_loads_in_reference"])
+    voff, light = CK.apply_checkpoint(r, None, n_vertices=12, device="cpu")
+    assert torch.equal(voff, r["vertices_offsets"]) and torch.equal(light, r["light_base"])
