@@ -5,7 +5,7 @@ Taken from /root/reference/nerf/utils.py by AST (the module itself does not impo
   luma, value, _clip_0to1_warn_torch, linear2srgb_torch, linear_to_srgb (its @torch.jit.script decorator dropped), shading_loss,
   material_smoothness_grad, material_extra_kd_smoothness_grad, laplacian_uniform, laplacian_cot, laplacian_smooth_loss, the class PSNRMeter,
   custom_meshgrid, safe_normalize, get_rays, srgb_to_linear; from nerf/renderer.py: scale_img_nhwc, scale_img_hwc; from nerf/provider.py: the
-  statements of NeRFDataset.__init__ that build the projection matrix.
+  statements of NeRFDataset.__init__ that build the projection matrix; the method Trainer.train_step itself (stage-1 branch).
 Nothing of the reference's text is stored: only the numbers it produced.
 """
 import ast
@@ -100,6 +100,34 @@ def main():
     pns = {"self": me, "np": np, "torch": torch, "fl_y": 61.0}
     exec(compile(ast.Module(body=stmts, type_ignores=[]), "provider.py", "exec"), pns)
     out.update(proj_hw=np.array([30, 50], np.int32), proj_fl=np.float32(61.0), proj_near=np.float32(0.05), proj_out=np.asarray(me.projection, np.float32))
+    # Trainer.train_step for stage 1 (nerf/utils.py:912-1135), the method itself executed from the AST on RGBA training pixels: background compositing,
+    # the linearised target, every term with main.py's default weights — `render_stage1` replaced by a stub that hands back prepared outputs
+    tree_u = ast.parse(open(os.path.join(REF, "nerf/utils.py")).read())
+    tr_body = [n for n in tree_u.body if isinstance(n, ast.ClassDef) and n.name == "Trainer"][0].body
+    fn = [n for n in tr_body if isinstance(n, ast.FunctionDef) and n.name == "train_step"][0]
+    load_functions("nerf/utils.py", ["srgb_to_linear", "act_voffsets"], ns)
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), os.path.join(REF, "nerf/utils.py"), "exec"), ns)
+    Hh, Ww = 12, 10; Np = Hh * Ww
+    rgba = torch.rand(Np, 4, generator=g); rgba[:30, 3] = 0.0; rgba[30:60, 3] = 1.0
+    outs_in = {k: torch.rand(*shape, generator=g) for k, shape in (("image_brdf", (Np, 3)), ("diffuse_light", (Np, 3)), ("specular_light", (Np, 3)),
+                                                                  ("img_brdf_indirect", (Np, 3)), ("kd_grad", (Hh, Ww, 3)), ("ks_grad", (Hh, Ww, 3)), ("normal_grad", (Hh, Ww, 1)))}
+    outs_in["image"] = torch.rand(Np, 3, generator=g)
+    leaf = {k: v.clone().requires_grad_(True) for k, v in outs_in.items() if k != "img_brdf_indirect"}
+    ts_off = ((torch.rand(verts.shape, generator=g) - 0.5) * 0.02).requires_grad_(True)
+    model = types.SimpleNamespace(vertices=verts, vertices_offsets=ts_off, triangles=faces, v_cumsum=[0, verts.shape[0]],
+                                  render_stage1=lambda *a_, **k_: dict(leaf, img_brdf_indirect=outs_in["img_brdf_indirect"]))
+    optd = dict(stage=1, use_brdf=True, color_space="srgb", sdf=False, progressive_level=False, background="white", refine=False, bound=1, iters=7500,
+                lambda_rgb=1.0, lambda_rgb_brdf=0.02, lambda_mask=0.0, lambda_lpips=0.0, lambda_brdf_diffuse=0.0015, lambda_brdf_specular=0.000025, lambda_kd=0.005,
+                lambda_ks=0.0025, lambda_nrm=0.00025, lambda_extra_kd=0.0, lambda_lap=0.001, lambda_normal=0.0, lambda_edgelen=0.0, lambda_offsets=0.1, lambda_tv=0.0,
+                adaptive_num_rays=False, diffuse_step=1000, diffuse_only=False)
+    me = types.SimpleNamespace(opt=types.SimpleNamespace(**optd), model=model, global_step=10, device="cpu", criterion=torch.nn.MSELoss(reduction="none"),
+                               criterion_brdf=torch.nn.L1Loss(reduction="none"))
+    data = dict(rays_o=torch.zeros(Np, 3), rays_d=torch.zeros(Np, 3), index=[0], images=rgba.clone(), mvp=torch.eye(4)[None], H=Hh, W=Ww)
+    _, _, ts_gt, ts_loss = ns["train_step"](me, data)
+    ts_loss.backward()
+    out.update(ts_rgba=rgba.numpy(), ts_gt=ts_gt.detach().numpy(), ts_loss=np.float64(ts_loss.item()), ts_voff=ts_off.detach().numpy(), ts_gvoff=ts_off.grad.numpy(),
+               ts_indirect=outs_in["img_brdf_indirect"].numpy(), **{"ts_in_" + k: v.detach().numpy() for k, v in leaf.items()},
+               **{"ts_g_" + k: v.grad.numpy() for k, v in leaf.items()})
     # srgb_to_linear (nerf/utils.py:57-58): what the data loader applies to the training images for the shading loss (images_linear, :927)
     load_functions("nerf/utils.py", ["srgb_to_linear"], ns)
     xs = torch.cat((torch.rand(4000, generator=g), torch.tensor([0.0, 0.04045, 0.040449999, 0.0404501, 1.0, 0.5])))

@@ -130,3 +130,28 @@ def test_projection_matrix_matches_the_reference_dataset(g):
     H, W = (int(v) for v in g["proj_hw"]); fl = float(g["proj_fl"])
     got = harness.mvp_from_pose(torch.eye(4), (fl, fl, W * 0.5, H * 0.5), H, W, near=float(g["proj_near"])).numpy()
     np.testing.assert_allclose(got, g["proj_out"], rtol=1e-6, atol=1e-7)
+
+
+def test_stage1_loss_matches_the_reference_train_step(g):
+    """losses.stage1_loss — and the target preparation of scripts/train_stage1.py (white background compositing, linearised target) — against the
+    reference's own Trainer.train_step (nerf/utils.py:912-1135, the method executed from its AST with render_stage1 replaced by prepared outputs;
+    gen_reference_losses.py): the scalar and its gradients w.r.t. every rendered output and the vertex offsets, with main.py's default weights."""
+    import types
+    import torch
+    from mirres_restir_nerf_mesh_amd import harness, losses
+    rgba = torch.from_numpy(g["ts_rgba"])
+    gt = rgba[:, :3] * rgba[:, 3:] + (1 - rgba[:, 3:])                                  # :948-955 with --background white
+    gt_lin = harness.srgb_to_linear(rgba[:, :3]) * rgba[:, 3:]
+    np.testing.assert_allclose(gt.numpy(), g["ts_gt"], rtol=0, atol=1e-7)
+    names = ("image", "image_brdf", "diffuse_light", "specular_light", "kd_grad", "ks_grad", "normal_grad")
+    outs = {k: torch.from_numpy(g["ts_in_" + k]).clone().requires_grad_(True) for k in names}
+    voff = torch.from_numpy(g["ts_voff"]).clone().requires_grad_(True)
+    verts = torch.from_numpy(g["lap_v"]); faces = torch.from_numpy(g["lap_t"])
+    loss = losses.stage1_loss(dict(outs, img_brdf_indirect=torch.from_numpy(g["ts_indirect"])), gt, gt_lin, types.SimpleNamespace(use_brdf=True), vertices=verts, voffsets=voff,
+                              triangles=faces)
+    assert abs(float(loss.detach()) - float(g["ts_loss"])) <= 1e-6 * abs(float(g["ts_loss"]))
+    loss.backward()
+    for k in names:
+        ref = g["ts_g_" + k]
+        np.testing.assert_allclose(outs[k].grad.numpy(), ref, rtol=1e-5, atol=1e-6 * max(np.abs(ref).max(), 1e-12), err_msg=k)
+    np.testing.assert_allclose(voff.grad.numpy(), g["ts_gvoff"], rtol=1e-5, atol=1e-6 * np.abs(g["ts_gvoff"]).max())
