@@ -5,7 +5,8 @@ Taken from /root/reference/nerf/utils.py by AST (the module itself does not impo
   luma, value, _clip_0to1_warn_torch, linear2srgb_torch, linear_to_srgb (its @torch.jit.script decorator dropped), shading_loss,
   material_smoothness_grad, material_extra_kd_smoothness_grad, laplacian_uniform, laplacian_cot, laplacian_smooth_loss, the class PSNRMeter,
   custom_meshgrid, safe_normalize, get_rays, srgb_to_linear; from nerf/renderer.py: scale_img_nhwc, scale_img_hwc; from nerf/provider.py: the
-  statements of NeRFDataset.__init__ that build the projection matrix; the method Trainer.train_step itself (stage-1 branch).
+  statements of NeRFDataset.__init__ that build the projection matrix; the methods Trainer.train_step (stage-1 branch) and
+  Trainer.train_one_epoch themselves; nerf/render_helper.py: the class EnvironmentLight.
 Nothing of the reference's text is stored: only the numbers it produced.
 """
 import ast
@@ -128,6 +129,45 @@ def main():
     out.update(ts_rgba=rgba.numpy(), ts_gt=ts_gt.detach().numpy(), ts_loss=np.float64(ts_loss.item()), ts_voff=ts_off.detach().numpy(), ts_gvoff=ts_off.grad.numpy(),
                ts_indirect=outs_in["img_brdf_indirect"].numpy(), **{"ts_in_" + k: v.detach().numpy() for k, v in leaf.items()},
                **{"ts_g_" + k: v.grad.numpy() for k, v in leaf.items()})
+    # Trainer.train_one_epoch (nerf/utils.py:1518-1660), the method itself: zero_grad of the three optimisers, backward, geometry step + schedule, the x64 /
+    # /8 gradient rescaling, material and light steps + schedules, the light clamp — three iterations over a stub loader, train_step replaced by a
+    # closed-form loss of the three parameter groups; EnvironmentLight is the reference's own class (nerf/render_helper.py:126-146)
+    import tqdm
+    fn_epoch = [n for n in tr_body if isinstance(n, ast.FunctionDef) and n.name == "train_one_epoch"][0]
+    ens = {"torch": torch, "np": np, "tqdm": tqdm, "os": os}
+    exec(compile(ast.Module(body=[fn_epoch], type_ignores=[]), os.path.join(REF, "nerf/utils.py"), "exec"), ens)
+    rh = ast.parse(open(os.path.join(REF, "nerf/render_helper.py")).read())
+    el = [n for n in rh.body if isinstance(n, ast.ClassDef) and n.name == "EnvironmentLight"][0]
+    el.body = [n for n in el.body if not (isinstance(n, ast.FunctionDef) and n.name == "generate_image")]        # needs nvdiffrast; not on this path
+    exec(compile(ast.Module(body=[el], type_ignores=[]), "render_helper.py", "exec"), ens)
+    o_voff0 = (torch.rand(10, 3, generator=g) - 0.5) * 0.02; o_grid0 = (torch.rand(40, generator=g) - 0.5) * 2e-4; o_w0 = torch.rand(6, 8, generator=g) - 0.5
+    o_light0 = torch.rand(4, 6, 3, generator=g) * 0.05                                                          # small values: the clamp at 0.01 becomes active
+    c_voff = torch.rand(10, 3, generator=g) - 0.5; c_grid = torch.rand(40, generator=g) - 0.5; c_w = torch.rand(6, 8, generator=g) - 0.5; c_light = torch.rand(4, 6, 3, generator=g) - 0.3
+    voff_p = torch.nn.Parameter(o_voff0.clone()); grid_p = torch.nn.Parameter(o_grid0.clone()); w_p = torch.nn.Parameter(o_w0.clone())
+    lgt = ens["EnvironmentLight"](o_light0.clone().requires_grad_(True))
+    def closed_form(vo, gr, w, li):
+        return (c_voff * vo).sum() + 3.0 * (vo ** 2).sum() + (c_grid * gr).sum() + (c_w * w).sum() + 0.5 * (w ** 2).sum() + (c_light * li).sum() + 0.2 * (li ** 2).sum()
+    mdl = types.SimpleNamespace(train=lambda: None, cuda_ray=False, lgt=lgt, mlp_mat_opt=types.SimpleNamespace(encoder=types.SimpleNamespace(params=grid_p)))
+    iters = 7500
+    opt_geo = torch.optim.Adam([{"params": [voff_p], "lr": 1e-4, "weight_decay": 0}], eps=1e-15)                 # main.py:267, nerf/renderer.py:201
+    opt_mat = torch.optim.Adam([{"params": [grid_p, w_p], "lr": 0.03}]); opt_lgt = torch.optim.Adam([{"params": lgt.parameters(), "lr": 0.09}])   # network.py:293-301
+    sch_geo = torch.optim.lr_scheduler.LambdaLR(opt_geo, lambda it: 0.01 + 0.99 * (it / 500) if it <= 500 else 0.1 ** ((it - 500) / (iters - 500)))   # main.py:285
+    brdf = lambda it: max(0.0, 10 ** (-(it - 0) * 0.0002))                                                    # utils.py:819-823 (warmup_iter = 0)
+    sch_mat = torch.optim.lr_scheduler.LambdaLR(opt_mat, brdf); sch_lgt = torch.optim.lr_scheduler.LambdaLR(opt_lgt, brdf)
+    class Loader:
+        batch_size = 1
+        def __len__(self): return 3
+        def __iter__(self): return iter([{}, {}, {}])
+    tr = types.SimpleNamespace(opt=types.SimpleNamespace(use_brdf=True, stage=1, refine=False, sdf=False, update_extra_interval=16), epoch=1, local_rank=0, world_size=1,
+                               report_metric_at_train=False, metrics=[], metrics_brdf=[], model=mdl, global_step=0, local_step=0, optimizer=opt_geo, optimizer_mat=opt_mat,
+                               optimizer_light=opt_lgt, lr_scheduler=sch_geo, scheduler_mat=sch_mat, scheduler_light=sch_lgt, scaler=torch.cuda.amp.GradScaler(enabled=False),
+                               scheduler_update_every_step=True, use_tensorboardX=False, ema=None, stats={"loss": []}, log=lambda *a_, **k_: None,
+                               post_train_step=lambda: None)
+    tr.train_step = lambda data: (None, None, None, closed_form(voff_p, grid_p, w_p, lgt.base))
+    ens["train_one_epoch"](tr, Loader())
+    out.update(os_voff0=o_voff0.numpy(), os_grid0=o_grid0.numpy(), os_w0=o_w0.numpy(), os_light0=o_light0.numpy(), os_c_voff=c_voff.numpy(), os_c_grid=c_grid.numpy(),
+               os_c_w=c_w.numpy(), os_c_light=c_light.numpy(), os_voff3=voff_p.detach().numpy(), os_grid3=grid_p.detach().numpy(), os_w3=w_p.detach().numpy(),
+               os_light3=lgt.base.detach().numpy(), os_losses=np.array(tr.stats["loss"], np.float64), os_steps=np.int64(tr.global_step))
     # srgb_to_linear (nerf/utils.py:57-58): what the data loader applies to the training images for the shading loss (images_linear, :927)
     load_functions("nerf/utils.py", ["srgb_to_linear"], ns)
     xs = torch.cat((torch.rand(4000, generator=g), torch.tensor([0.0, 0.04045, 0.040449999, 0.0404501, 1.0, 0.5])))

@@ -155,3 +155,31 @@ def test_stage1_loss_matches_the_reference_train_step(g):
         ref = g["ts_g_" + k]
         np.testing.assert_allclose(outs[k].grad.numpy(), ref, rtol=1e-5, atol=1e-6 * max(np.abs(ref).max(), 1e-12), err_msg=k)
     np.testing.assert_allclose(voff.grad.numpy(), g["ts_gvoff"], rtol=1e-5, atol=1e-6 * np.abs(g["ts_gvoff"]).max())
+
+
+def test_optimizer_step_matches_the_reference_epoch_loop(g):
+    """losses.stage1_optimizer_step against the reference's own Trainer.train_one_epoch (nerf/utils.py:1518-1660, the method executed from its AST with
+    the reference's EnvironmentLight class; gen_reference_losses.py): three iterations from the same initial state on the same closed-form loss — geometry
+    step and schedule, light gradient x 64, hash-grid gradient / 8, material and light steps and schedules, the clamp of the light at 0.01 — must leave
+    every parameter where the reference's loop left it."""
+    import torch
+    from mirres_restir_nerf_mesh_amd import losses
+    t = lambda k: torch.from_numpy(g[k]).clone()
+    voff = t("os_voff0").requires_grad_(True); grid = t("os_grid0").requires_grad_(True); w = t("os_w0").requires_grad_(True); light = t("os_light0").requires_grad_(True)
+    cv, cg, cw, cl = t("os_c_voff"), t("os_c_grid"), t("os_c_w"), t("os_c_light")
+    f = lambda: (cv * voff).sum() + 3.0 * (voff ** 2).sum() + (cg * grid).sum() + (cw * w).sum() + 0.5 * (w ** 2).sum() + (cl * light).sum() + 0.2 * (light ** 2).sum()
+    iters = 7500
+    o_geo = torch.optim.Adam([{"params": [voff], "lr": 1e-4, "weight_decay": 0}], eps=1e-15)
+    o_mat = torch.optim.Adam([{"params": [grid, w], "lr": 0.03}]); o_lgt = torch.optim.Adam([{"params": [light], "lr": 0.09}])
+    s_geo = torch.optim.lr_scheduler.LambdaLR(o_geo, lambda it: 0.01 + 0.99 * (it / 500) if it <= 500 else 0.1 ** ((it - 500) / (iters - 500)))
+    brdf = lambda it: max(0.0, 10 ** (-it * 0.0002))
+    s_mat = torch.optim.lr_scheduler.LambdaLR(o_mat, brdf); s_lgt = torch.optim.lr_scheduler.LambdaLR(o_lgt, brdf)
+    vals = []
+    for _ in range(int(g["os_steps"])):
+        for o in (o_geo, o_mat, o_lgt):
+            o.zero_grad()
+        vals.append(losses.stage1_optimizer_step(f(), o_geo, o_mat, o_lgt, light_base=light, encoder_params=grid, scheduler=s_geo, scheduler_mat=s_mat, scheduler_light=s_lgt))
+    assert abs(np.mean(vals) - float(g["os_losses"][0])) <= 1e-6 * abs(float(g["os_losses"][0]))
+    for name, p in (("voff", voff), ("grid", grid), ("w", w), ("light", light)):
+        np.testing.assert_allclose(p.detach().numpy(), g["os_%s3" % name], rtol=1e-6, atol=1e-9, err_msg=name)
+    assert float(light.detach().min()) == np.float32(0.01)                    # the clamp was active in this run
