@@ -1,13 +1,16 @@
 """Mirror of nerf/ScreenSpaceReSTIR/Resampling.py (reference): launch wrappers + the two differentiable operators,
 running on the MI355X engine. Functions that take the LBVH node arrays find the owning restirbvhWorker through them."""
 import ctypes as C
+import weakref
 import torch
 
 from . import _lib
 from ._lib import lib, check, stream_ptr
 from ._ops import _f32, env_struct, gbuf_struct, res_struct, path_struct
 
-_BVH_OWNERS = {}  # LBVHNode_info.data_ptr() -> restirbvhWorker
+# LBVHNode_info.data_ptr() -> restirbvhWorker.  Weak: the registry must not keep a worker (and the device memory of its BVH) alive once the caller has
+# dropped it — with a plain dict the worker's __del__ could never run.
+_BVH_OWNERS = weakref.WeakValueDictionary()
 
 
 def _owner(LBVHNode_info):

@@ -236,3 +236,25 @@ def test_fused_interior_slab_test_on_hostile_geometry(torch_cuda, oracle):
     h3 = torch.zeros(n, dtype=torch.int32, device="cuda")
     check(lib().mirres_bvh_trace(w.h, dr.data_ptr(), n, 3, h3.data_ptr(), None, None, None, None, None, None), "front")
     assert np.array_equal(h3.cpu().numpy(), oracle.occluded_front(info, aabb, v, t, rays))
+
+
+def test_worker_is_released_when_dropped(torch_cuda, scene_mod):
+    """The registry that maps LBVHNode_info back to its worker (the reference's launch wrappers pass the node arrays, not the worker) holds weak
+    references: a worker the caller drops is destroyed — its native BVH freed — instead of living until the process ends."""
+    import gc, weakref
+    torch = torch_cuda
+    from mirres_restir_nerf_mesh_amd import Resampling
+    from mirres_restir_nerf_mesh_amd.renderer_restir import restirbvhWorker
+    v, t = scene_mod.make_mesh(2, 2)
+    n0 = len(Resampling._BVH_OWNERS)
+    w = restirbvhWorker(torch.from_numpy(v).cuda(), torch.from_numpy(t).cuda()); w.update_mesh(w.vrt, w.v_ind)
+    info = w.LBVHNode_info
+    assert len(Resampling._BVH_OWNERS) == n0 + 1 and Resampling._owner(info) is w
+    w.update_mesh(w.vrt, w.v_ind)                      # a rebuild re-registers under the (possibly new) array, never twice
+    assert len(Resampling._BVH_OWNERS) == n0 + 1
+    info = w.LBVHNode_info
+    r = weakref.ref(w); del w; gc.collect()
+    assert r() is None and len(Resampling._BVH_OWNERS) == n0
+    from mirres_restir_nerf_mesh_amd._lib import MirresError
+    with pytest.raises(MirresError, match="live restirbvhWorker"):
+        Resampling._owner(info)
