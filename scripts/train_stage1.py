@@ -30,12 +30,15 @@ def orbit_pose(az_deg, el_deg, dist=3.2):
     return pose
 
 
-def synthetic_dataset(root, H, W, n_views=6, spp=64):
+def synthetic_dataset(root, H, W, n_views=6, spp=64, mesh_error=0.0):
     """A hidden target scene (material field with seeded weights, sky with a sun) rendered through the HIP path into a NeRF-blender style folder."""
     from mirres_restir_nerf_mesh_amd import meters
     os.makedirs(os.path.join(root, "mesh_stage0"), exist_ok=True); os.makedirs(os.path.join(root, "train"), exist_ok=True)
     v, t = M.scene.make_mesh(4, 8)
-    CK.write_ply(os.path.join(root, "mesh_stage0", "mesh_0.ply"), v, t)
+    # the "stage-0" mesh the training starts from: the true one, or one with a smooth error (the object inflated and sheared by `mesh_error`) for
+    # the vertex offsets to remove — the images below are always rendered from the true mesh
+    v0 = v if mesh_error == 0 else (v * (1.0 + mesh_error * np.array([1.0, 0.6, 0.8], np.float32)) + mesh_error * 0.5 * v[:, [1, 2, 0]]).astype(np.float32)
+    CK.write_ply(os.path.join(root, "mesh_stage0", "mesh_0.ply"), v0, t)
     aabb, mn, mx = CK.material_field_args(CK.material_config(bound=1.0))
     target = MLPTexture3D(aabb, channels=6, min_max=(mn.cuda(), mx.cuda()), seed=1)
     params, w0, w1, w2 = M.scene.make_matnet_params(seed=0)
@@ -67,6 +70,8 @@ def main():
     p.add_argument("--cascade", type=int, default=None); p.add_argument("--light_probe_res_hw", type=int, nargs=2, default=[256, 512])
     p.add_argument("--scale", type=float, default=1.0); p.add_argument("--offset", type=float, nargs=3, default=[0.0, 0.0, 0.0])
     p.add_argument("--save_interval", type=int, default=500); p.add_argument("--seed", type=int, default=0); p.add_argument("--H", type=int, default=96); p.add_argument("--W", type=int, default=96)
+    p.add_argument("--mesh_error", type=float, default=0.0, help="--synthetic: relative error of the starting mesh against the one the images show")
+    p.add_argument("--freeze", nargs="*", default=[], choices=["geometry", "material", "light"], help="parameter groups left untouched (their learning rate set to 0)")
     p.add_argument("--pos_gradient_boost", type=float, default=1.0); p.add_argument("--lambda_extra_kd", type=float, default=0.0); p.add_argument("--quiet", action="store_true")
     a = p.parse_args()
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -80,7 +85,7 @@ def main():
     if a.synthetic:
         a.workspace = a.workspace or os.path.join(ROOT, "gpurun_out", "train_ws")
         if rank == 0:
-            synthetic_dataset(a.workspace, a.H, a.W)
+            synthetic_dataset(a.workspace, a.H, a.W, mesh_error=a.mesh_error)
         if world > 1:
             dist.barrier()
         a.transforms = os.path.join(a.workspace, "transforms_train.json"); a.bound = a.bound or 1.0
@@ -126,9 +131,9 @@ def main():
         pose[:3, 3] = pose[:3, 3] * a.scale + torch.tensor(a.offset)
     mods = RR.load_m_for_restir(Wd * a.ssaa, H * a.ssaa)
     # ---- optimisers and schedules (main.py:267-285, utils.py:820-829)
-    o_geo = torch.optim.Adam([{"params": [voff], "lr": a.lr_vert, "weight_decay": 0}], eps=1e-15)
-    o_mat = torch.optim.Adam([{"params": mlp.parameters(), "lr": a.learning_rate_mat}])
-    o_lgt = torch.optim.Adam([{"params": [env], "lr": a.learning_rate_lgt}])
+    o_geo = torch.optim.Adam([{"params": [voff], "lr": 0.0 if "geometry" in a.freeze else a.lr_vert, "weight_decay": 0}], eps=1e-15)
+    o_mat = torch.optim.Adam([{"params": mlp.parameters(), "lr": 0.0 if "material" in a.freeze else a.learning_rate_mat}])
+    o_lgt = torch.optim.Adam([{"params": [env], "lr": 0.0 if "light" in a.freeze else a.learning_rate_lgt}])
     s_geo = torch.optim.lr_scheduler.LambdaLR(o_geo, lambda it: 0.01 + 0.99 * (it / 500) if it <= 500 else 0.1 ** ((it - 500) / max(1, a.iters - 500)))
     brdf_sched = lambda it: max(0.0, 10 ** (-it * 0.0002))
     s_mat = torch.optim.lr_scheduler.LambdaLR(o_mat, brdf_sched); s_lgt = torch.optim.lr_scheduler.LambdaLR(o_lgt, brdf_sched)
