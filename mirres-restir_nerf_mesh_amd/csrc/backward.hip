@@ -278,6 +278,14 @@ static GridLevelsB host_levels_b() {
     }
     return L;
 }
+// (T)(weight * value) of tcnn's interpolation (grid.h): the fp32 product is ROUNDED TO fp32 and then to fp16. Left to itself the compiler turns
+// fptrunc(fmul) into v_fma_mixlo_f16 — one rounding of the exact product — whenever it does not happen to pack the multiplication with a neighbour
+// (round 2: -fno-vectorize changed 1 feature in ~10^4 by one fp16 ulp against tcnn's two-step rounding); the empty asm pins the two-step form in every build.
+MR_DEV __half2 weighted_half2_b(float w, __half2 v) {      // as matnet.hip's weighted_half2 (the forward recompute must reproduce the forward's bits)
+    float p0 = w * __low2float(v), p1 = w * __high2float(v);
+    asm("" : "+v"(p0), "+v"(p1));
+    return __floats2half2_rn(p0, p1);
+}
 MR_DEV uint32_t grid_index_b(uint32_t size, uint32_t res, uint32_t px, uint32_t py, uint32_t pz) {
     uint32_t stride = 1, index = 0;
     if (stride <= size) { index += px * stride; stride *= res; }
@@ -330,16 +338,16 @@ __global__ void __launch_bounds__(MR_BLOCK) k_matnet_bwd(MatNetB M, GridLevelsB 
             float p[3]; uint32_t pg[3];
 #pragma unroll
             for (int d = 0; d < 3; d++) { float q = fmaf(scale, x[d], 0.5f); float fl = floorf(q); pg[d] = (uint32_t)(int)fl; p[d] = q - fl; }
-            __half r0 = __float2half(0.f), r1 = __float2half(0.f);
+            __half2 r = __floats2half2_rn(0.f, 0.f);
 #pragma unroll
             for (uint32_t idx = 0; idx < 8; idx++) {
                 float w = 1.f; uint32_t pl[3];
 #pragma unroll
                 for (int d = 0; d < 3; d++) { if ((idx & (1u << d)) == 0) { w *= 1 - p[d]; pl[d] = pg[d]; } else { w *= p[d]; pl[d] = pg[d] + 1; } }
                 const __half2 v = g[grid_index_b(size, res, pl[0], pl[1], pl[2])];
-                r0 = __hadd(r0, __float2half(w * __low2float(v))); r1 = __hadd(r1, __float2half(w * __high2float(v)));
+                r = __hadd2(r, weighted_half2_b(w, v));
             }
-            a0[2 * lv] = __half2float(r0); a0[2 * lv + 1] = __half2float(r1);
+            a0[2 * lv] = __low2float(r); a0[2 * lv + 1] = __high2float(r);
         }
         float z2[6];
         for (int o = 0; o < 32; o++) { float acc = 0.f; for (int k = 0; k < 32; k++) acc = fmaf(a0[k], sw0[o * 32 + k], acc); h1[o] = fmaxf(acc, 0.f); }

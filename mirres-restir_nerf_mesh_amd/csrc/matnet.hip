@@ -47,6 +47,16 @@ MR_DEV uint32_t grid_index(uint32_t size, uint32_t res, uint32_t px, uint32_t py
     return index % size;
 }
 
+// (T)(weight * value) of tcnn's interpolation (grid.h): the fp32 product is ROUNDED TO fp32 and then to fp16. Left to itself the compiler turns
+// fptrunc(fmul) into v_fma_mixlo_f16 — one rounding of the exact product — whenever it does not happen to pack the multiplication with a neighbour
+// (round 2: -fno-vectorize changed 1 feature in ~10^4 by one fp16 ulp against tcnn's two-step rounding); the empty asm pins the two-step form in every build.
+// Both features of a table entry at once: the two fp16 roundings in one v_cvt_pk_f16_f32 (round to nearest even, like v_cvt_f16_f32) and the two
+// fp16 additions in one v_pk_add_f16 — packed fp16, written out so that the instruction count does not depend on what a vectoriser finds.
+MR_DEV __half2 weighted_half2(float w, __half2 v) {
+    float p0 = w * __low2float(v), p1 = w * __high2float(v);
+    asm("" : "+v"(p0), "+v"(p1));
+    return __floats2half2_rn(p0, p1);
+}
 // encode one point (already normalised to [0,1]^3) into 32 fp16 features
 MR_DEV void encode_point(const GridLevels& L, const __half2* __restrict__ grid, const float x[3], __half enc[32]) {
 #pragma unroll 1
@@ -56,7 +66,7 @@ MR_DEV void encode_point(const GridLevels& L, const __half2* __restrict__ grid, 
         float pos[3]; uint32_t pg[3];
 #pragma unroll
         for (int d = 0; d < 3; d++) { float p = fmaf(scale, x[d], 0.5f); float fl = floorf(p); pg[d] = (uint32_t)(int)fl; pos[d] = p - fl; }
-        __half r0 = __float2half(0.f), r1 = __float2half(0.f);
+        __half2 r = __floats2half2_rn(0.f, 0.f);
 #pragma unroll
         for (uint32_t idx = 0; idx < 8; idx++) {
             float w = 1.f; uint32_t pl[3];
@@ -65,10 +75,9 @@ MR_DEV void encode_point(const GridLevels& L, const __half2* __restrict__ grid, 
                 if ((idx & (1u << d)) == 0) { w *= 1 - pos[d]; pl[d] = pg[d]; } else { w *= pos[d]; pl[d] = pg[d] + 1; }
             }
             const __half2 v = g[grid_index(size, res, pl[0], pl[1], pl[2])];
-            r0 = __hadd(r0, __float2half(w * __low2float(v)));
-            r1 = __hadd(r1, __float2half(w * __high2float(v)));
+            r = __hadd2(r, weighted_half2(w, v));
         }
-        enc[2 * lv] = r0; enc[2 * lv + 1] = r1;
+        enc[2 * lv] = __low2half(r); enc[2 * lv + 1] = __high2half(r);
     }
 }
 

@@ -34,6 +34,26 @@ def test_library_exports_every_declared_symbol():
     assert lib.mirres_matnet_grid_entries() == 6299960
 
 
+def test_no_packed_fp32_in_the_device_code(tmp_path):
+    """DESIGN.md §Two streams: a packed-fp32 VALU instruction next to another wave's MFMA gave wrong 16-lane passes on this pool, so the library is
+    built without either vectoriser; and the encoder's two-step fp16 rounding must not be contracted into v_fma_mixlo_f16."""
+    import subprocess
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("no llvm-objdump")
+    import glob, shutil
+    from mirres_restir_nerf_mesh_amd import _lib
+    so = shutil.copy(_lib.LIB_PATH, str(tmp_path))            # --offloading extracts the code objects next to the file it is given
+    subprocess.run([objdump, "--offloading", so], capture_output=True, text=True, cwd=str(tmp_path))
+    parts = glob.glob(so + ".*gfx950")
+    if not parts:
+        pytest.skip("llvm-objdump did not extract the device code objects")
+    asm = "".join(subprocess.run([objdump, "-d", f], capture_output=True, text=True).stdout for f in parts)
+    assert "v_mfma" in asm and "s_endpgm" in asm
+    bad = [l for l in asm.splitlines() if re.search(r"\bv_pk_(mul|add|fma)_f32\b|\bv_fma_mixlo_f16\b", l)]
+    assert not bad, bad[:5]
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     from mirres_restir_nerf_mesh_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)
