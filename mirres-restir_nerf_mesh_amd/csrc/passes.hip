@@ -19,13 +19,40 @@ int trace_any_queue_counted(const mirres_bvh* bvh, const Ray* rays, const uint32
 
 // 2-D tile -> pixel mapping for the kernels that gather from neighbouring pixels (spatial pass: +-30 px): a square tile of threads touches a
 // (T+60)^2 window instead of the (blockDim+60) x 61 strip a row-major block touches, which is what the L1/L2 hit rate of the gathers follows.
+#ifndef MR_TILE_MAP
+#define MR_TILE_MAP 2
+#endif
+// MR_TILE_MAP 0: row-major tiles. 1: eight contiguous bands of tile rows, one per XCD. 2: 128 x 128 px chunks of tiles dealt to the XCDs in turn.
+// (Workgroups go to the eight XCDs round-robin by block index and every XCD has its own L2.)
 MR_DEV int tile_pixel(int fx, int fy, int tw, int N) {
-    const int tiles_x = (fx + tw - 1) / tw;
-    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const int tiles_x = (fx + tw - 1) / tw, tiles_y = (fy + tw - 1) / tw;
+    int tx, ty;
+#if MR_TILE_MAP == 0
+    tx = blockIdx.x % tiles_x; ty = blockIdx.x / tiles_x;
+#elif MR_TILE_MAP == 1
+    const int t = (int)(blockIdx.x & 7u) * ((tiles_x * tiles_y + 7) >> 3) + (int)(blockIdx.x >> 3);
+    if (t >= tiles_x * tiles_y) return N;
+    tx = t % tiles_x; ty = t / tiles_x;
+#else
+    const int ch = 128 / tw, chunks_x = (tiles_x + ch - 1) / ch;
+    const int j = (int)(blockIdx.x >> 3), chunk = (int)(blockIdx.x & 7u) + 8 * (j / (ch * ch)), w = j % (ch * ch);
+    tx = (chunk % chunks_x) * ch + w % ch; ty = (chunk / chunks_x) * ch + w / ch;
+    if (tx >= tiles_x || ty >= tiles_y) return N;
+#endif
     const int x = tx * tw + (int)(threadIdx.x % tw), y = ty * tw + (int)(threadIdx.x / tw);
     return (x < fx && y < fy) ? y * fx + x : N;   // N = "no pixel"
 }
-static int tile_grid(int fx, int fy, int tw) { return ((fx + tw - 1) / tw) * ((fy + tw - 1) / tw); }
+static int tile_grid(int fx, int fy, int tw) {
+    const int tiles_x = (fx + tw - 1) / tw, tiles_y = (fy + tw - 1) / tw;
+#if MR_TILE_MAP == 0
+    return tiles_x * tiles_y;
+#elif MR_TILE_MAP == 1
+    return 8 * ((tiles_x * tiles_y + 7) / 8);
+#else
+    const int ch = 128 / tw, chunks = ((tiles_x + ch - 1) / ch) * ((tiles_y + ch - 1) / ch);
+    return 8 * ((chunks + 7) / 8) * ch * ch;
+#endif
+}
 
 // G-buffer / reservoir views. The ABI layout is the reference's SoA (one array per field). mirres_render's internal buffers use packed records so
 // that a neighbour gather touches one or two cache lines instead of seven:  GBufD::rec = 64 B per pixel {n.xyz depth | ray_dir.xyz occ | brdf.xyz 0 |
