@@ -44,7 +44,7 @@ def build(force=False, verbose=True):
 
     def cc(job):
         src, obj = job
-        cmd = [HIPCC] + FLAGS + PER_FILE.get(os.path.basename(src), []) + (os.environ.get("MIRRES_MATNET_FLAGS", "").split() if os.path.basename(src) == "matnet.hip" else []) + (os.environ.get("MIRRES_TRACE_FLAGS", "").split() if os.path.basename(src) == "bvh_trace.hip" else []) + (os.environ.get("MIRRES_PASSES_FLAGS", "").split() if os.path.basename(src) == "passes.hip" else []) + ["-c", src, "-o", obj]
+        cmd = [HIPCC] + FLAGS + os.environ.get("MIRRES_EXTRA_FLAGS", "").split() + PER_FILE.get(os.path.basename(src), []) + (os.environ.get("MIRRES_MATNET_FLAGS", "").split() if os.path.basename(src) == "matnet.hip" else []) + (os.environ.get("MIRRES_TRACE_FLAGS", "").split() if os.path.basename(src) == "bvh_trace.hip" else []) + (os.environ.get("MIRRES_PASSES_FLAGS", "").split() if os.path.basename(src) == "passes.hip" else []) + ["-c", src, "-o", obj]
         if verbose:
             print("[mirres build]", os.path.basename(src), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -25,38 +25,38 @@ MR_DEV v3 schlick3(v3 f0, float f90, float c) { float p = pow5(c); return V3(f0.
 MR_DEV float lambda_ggx(float a2, float c) {  // brdf.slang:34-40
     if (c <= 0) return 0;
     float c2 = c * c;
-    float tan2 = fmaxf(1 - c2, 0) / c2;
-    return 0.5f * (-1 + sqrtf(1 + a2 * tan2));
+    float tan2 = mr_div(fmaxf(1 - c2, 0), c2);
+    return 0.5f * (-1 + mr_sqrt(1 + a2 * tan2));
 }
 MR_DEV float ndf_ggx(float alpha, float c) {  // brdf.slang:42-49
     float a2 = alpha * alpha;
     float d = ((c * a2 - c) * c + 1);
-    return a2 / (d * d * 3.141592653589793f);
+    return mr_div(a2, d * d * 3.141592653589793f);
 }
-MR_DEV float g_separable(float alpha, float ci, float co) { float a2 = alpha * alpha; return 1 / ((1 + lambda_ggx(a2, ci)) * (1 + lambda_ggx(a2, co))); }
-MR_DEV float g_correlated(float alpha, float ci, float co) { float a2 = alpha * alpha; return 1 / (1 + lambda_ggx(a2, ci) + lambda_ggx(a2, co)); }
+MR_DEV float g_separable(float alpha, float ci, float co) { float a2 = alpha * alpha; return mr_rcp((1 + lambda_ggx(a2, ci)) * (1 + lambda_ggx(a2, co))); }
+MR_DEV float g_correlated(float alpha, float ci, float co) { float a2 = alpha * alpha; return mr_rcp(1 + lambda_ggx(a2, ci) + lambda_ggx(a2, co)); }
 MR_DEV float pdf_ggx_ndf(float alpha, float c) { return ndf_ggx(alpha, c) * c; }
 
 MR_DEV v2 disk_concentric(float ux, float uy) {  // brdf.slang:76-96
     ux = 2.f * ux - 1.f; uy = 2.f * uy - 1.f;
     if (ux == 0.f && uy == 0.f) return V2(ux, uy);
     float phi, r;
-    if (fabsf(ux) > fabsf(uy)) { r = ux; phi = (uy / ux) * 0.785398163397448309616f; }
-    else { r = uy; phi = 1.57079632679489661923f - (ux / uy) * 0.785398163397448309616f; }
+    if (fabsf(ux) > fabsf(uy)) { r = ux; phi = mr_div(uy, ux) * 0.785398163397448309616f; }
+    else { r = uy; phi = 1.57079632679489661923f - mr_div(ux, uy) * 0.785398163397448309616f; }
     return V2(r * cosf(phi), r * sinf(phi));
 }
 MR_DEV v3 cosine_hemisphere(float ux, float uy, float& pdf) {
     v2 d = disk_concentric(ux, uy);
-    float z = sqrtf(fmaxf(0.f, 1.f - dot(d, d)));
+    float z = mr_sqrt(fmaxf(0.f, 1.f - dot(d, d)));
     pdf = z * 0.31830988f;
     return V3(d.x, d.y, z);
 }
 MR_DEV v3 sample_ggx_ndf(float alpha, float ux, float uy, float& pdf) {  // brdf.slang:113-124
     float a2 = alpha * alpha;
     float phi = uy * (2 * 3.141592653589793f);
-    float tan2 = a2 * ux / (1 - ux);
-    float c = 1 / sqrtf(1 + tan2);
-    float r = sqrtf(fmaxf(1 - c * c, 0));
+    float tan2 = mr_div(a2 * ux, 1 - ux);
+    float c = mr_rcp(mr_sqrt(1 + tan2));
+    float r = mr_sqrt(fmaxf(1 - c * c, 0));
     pdf = pdf_ggx_ndf(alpha, c);
     return V3(cosf(phi) * r, sinf(phi) * r, c);
 }
@@ -67,7 +67,7 @@ struct Ctx { v3 N, V; float alpha, wd, ws, mix; Basis b; v3 Vl; };
 MR_DEV Ctx make_ctx(v3 N, v3 ray_dir, v3 brdf) {
     Ctx c; c.N = N; c.V = -ray_dir; c.alpha = brdf.z; c.wd = brdf.x; c.ws = brdf.y;
     float wsum = c.wd + c.ws;
-    c.mix = wsum > 1e-7f ? (c.wd / wsum) : 1.f;
+    c.mix = wsum > 1e-7f ? mr_div(c.wd, wsum) : 1.f;
     c.b = basis(N); c.Vl = to_local(c.b, c.V);
     return c;
 }
@@ -77,9 +77,9 @@ MR_DEV float eval_brdf(const Ctx& c, v3 L) {
     float NdotH = saturate(dot(c.N, H)), LdotH = saturate(dot(L, H));
     float D = ndf_ggx(c.alpha, NdotH);
     float G = g_separable(c.alpha, NdotV, NdotL);
-    float F = c.ws < 1e-8f ? 0.f : schlick(c.ws, 1.f, LdotH) / c.ws;
+    float F = c.ws < 1e-8f ? 0.f : mr_div(schlick(c.ws, 1.f, LdotH), c.ws);
     float diffuse = NdotL * 0.31830988f;
-    float specular = fmaxf(0.f, D * G * F / (4.f * NdotV));
+    float specular = fmaxf(0.f, mr_div(D * G * F, 4.f * NdotV));
     return NdotL > 0.f ? lerpf(specular, diffuse, c.mix) : 0.f;
 }
 MR_DEV float target(const Ctx& c, v3 emission, v3 L) { return fmaxf(0.f, luminance(emission) * eval_brdf(c, L)); }
@@ -87,7 +87,7 @@ MR_DEV float pdf_brdf(const Ctx& c, v3 dir) {
     float ct = saturate(dot(c.N, dir));
     float diffusePdf = ct * 0.31830988f;
     v3 h = normalize(to_local(c.b, dir + c.V));
-    float specularPdf = pdf_ggx_ndf(c.alpha, h.z) / (4.f * saturate(dot(h, c.Vl)));
+    float specularPdf = mr_div(pdf_ggx_ndf(c.alpha, h.z), 4.f * saturate(dot(h, c.Vl)));
     return ct > 0.f ? lerpf(specularPdf, diffusePdf, c.mix) : 0.f;
 }
 MR_DEV bool sample_brdf(const Ctx& c, float xa, float xb, float xc, v3& dir) {
@@ -103,7 +103,7 @@ struct Frame { v3 x, y, z; };
 MR_DEV Frame create_frame(v3 n) {  // helperDi.slang:9-28
     Frame f; f.z = n;
     float sign = (n.z > 0) ? 1.0f : -1.0f;
-    const float a = -1.0f / (sign + n.z);
+    const float a = mr_div(-1.0f, sign + n.z);
     const float b = n.x * n.y * a;
     f.x = V3(1.0f + sign * n.x * n.x * a, sign * b, -sign * n.x);
     f.y = V3(b, sign + n.y * n.y * a, -n.y);
@@ -129,7 +129,7 @@ MR_DEV float specular_pdf(v3 wo, v3 wi, float alpha) {  // :201-221
     if (fminf(wo.z, wi.z) < 1e-6f) return 0.f;
     if (alpha == 0.f) return 0.f;
     v3 h = normalize(wo + wi);
-    return pdf_ggx_ndf(alpha, h.z) / (4.f * dot(wo, h));
+    return mr_div(pdf_ggx_ndf(alpha, h.z), 4.f * dot(wo, h));
 }
 MR_DEV bool diffuse_sample(v3 wo, v3& wi, float& pdf, uint32_t& sg) {  // :157-171 (1 burn + 2 draws)
     rnd(sg);
@@ -179,7 +179,7 @@ MR_DEV bool falcor_sample(float pD, float pS, v3 wo, v3& wi, float& pdf, uint32_
         valid = specular_sample(alpha, wo, wi, pdf, sg);
         if (WEIGHT) weight = falcor_eval(pD, pS, alpha, spec_albedo, diff_albedo, wo, wi);
         pdf *= pS;
-        if (sqrtf(alpha) > 0.15f) { if (pD > 0.f) pdf += pD * diffuse_pdf(wo, wi); }
+        if (mr_sqrt(alpha) > 0.15f) { if (pD > 0.f) pdf += pD * diffuse_pdf(wo, wi); }
         else specularBounce = 1;
         if (WEIGHT) weight = weight / pdf;
     }
@@ -197,7 +197,7 @@ MR_DEV Lobes lobes(v3 diffuse, float roughness, float metallic, v3 ray_dir, v3 n
     float sw = luminance(schlick3(L.specular, 1.f, dot(-ray_dir, normal)));
     L.pS = sw * (metallic + dielectric);
     float nf = L.pD + L.pS;
-    if (nf > 0.f) { nf = 1.f / nf; L.pD *= nf; L.pS *= nf; }
+    if (nf > 0.f) { nf = mr_rcp(nf); L.pD *= nf; L.pS *= nf; }
     return L;
 }
 }  // namespace shade

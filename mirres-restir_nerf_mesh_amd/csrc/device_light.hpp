@@ -67,18 +67,18 @@ MR_DEV bool sample_li(const EnvD& E, float r0, float r1, v3& dir, float& out_pdf
     float ux = r0, uy = r1;
     const int w_ = E.W, h_ = E.H;
     int row = find_interval(0, h_ + 1, uy, E.mcdf);
-    uy = clampf((uy - E.mcdf[row]) / E.mpdf[row], 0.0f, 1.0f);
+    uy = clampf(mr_div(uy - E.mcdf[row], E.mpdf[row]), 0.0f, 1.0f);
     int row_start = row * (w_ + 1);
     int col = find_interval(row_start, row_start + (w_ + 1), ux, E.cdf);
-    ux = clampf((ux - E.cdf[row * (w_ + 1) + col]) / E.pdf[row * w_ + col], 0.0f, 1.0f);
-    ux = clampf((ux + col) / w_, 0.0f, 1.0f);
-    uy = clampf((uy + row) / h_, 0.0f, 1.0f);
+    ux = clampf(mr_div(ux - E.cdf[row * (w_ + 1) + col], E.pdf[row * w_ + col]), 0.0f, 1.0f);
+    ux = clampf(mr_div(ux + col, (float)w_), 0.0f, 1.0f);
+    uy = clampf(mr_div(uy + row, (float)h_), 0.0f, 1.0f);
     int r2 = clampi(row, 0, h_ - 1), c2 = clampi(col, 0, w_ - 1);
     float pdf = E.pdf[r2 * w_ + c2] * E.mpdf[r2] * w_ * h_;
     float theta = uy * PI, phi = ux * 2 * PI;
     float cos_theta = cosf(theta), cos_phi = cosf(phi), sin_theta = sinf(theta), sin_phi = sinf(phi);
     dir = V3(sin_theta * cos_phi, cos_theta, sin_theta * sin_phi);
-    if (fabsf(sin_theta) >= 1e-4f) pdf = pdf / (2 * PI * PI * sin_theta);
+    if (fabsf(sin_theta) >= 1e-4f) pdf = mr_div(pdf, 2 * PI * PI * sin_theta);
     else pdf = 0.0f;
     out_pdf = pdf;
     light_uv = V2(ux, 1 - uy);
@@ -97,7 +97,7 @@ MR_DEV float pdf_li(const EnvD& E, v3 dir) {
     int col = (int)(phi * 0.1591549f * E.W);
     int row = (int)(theta * 0.31830988f * E.H);
     row = clampi(row, 0, E.H - 1); col = clampi(col, 0, E.W - 1);
-    return (E.pdf[row * E.W + col] * E.mpdf[row] * E.W * E.H) / (2 * PI * PI * sin_theta);
+    return mr_div(E.pdf[row * E.W + col] * E.mpdf[row] * E.W * E.H, 2 * PI * PI * sin_theta);
 }
 
 // uv2xy (helper.slang:26-36)

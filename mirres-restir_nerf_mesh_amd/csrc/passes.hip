@@ -4,6 +4,9 @@
 // EvaluateFinalSamples_get_vis) is split into   generate (per pixel, emits COMPACTED shadow rays with one atomic per
 // wave) -> trace (bvh_trace.hip, any-hit queue) -> resolve (per pixel, consumes hit bits).  The rays a pixel emits
 // depend only on pass inputs, never on another ray's result, so the split is exact (DESIGN.md §Wavefront split).
+#ifndef MR_LEAN_FP
+#define MR_LEAN_FP 1      // device_math.hpp: short division / square-root sequences, bit-identical to the compiler's for the renderer's operand range
+#endif
 #include "engine.hpp"
 #include "device_math.hpp"
 #include "device_light.hpp"
@@ -237,7 +240,7 @@ __global__ void __launch_bounds__(MR_GEN_BLOCK) k_initial_gen(mirres_config_t C,
                 const v3 ldir = V3(ax.x, ax.y, ax.z);
                 float targetPdf = fmaxf(0.f, ax.w * rtarget::eval_brdf(ctx, ldir));   // rtarget::target with the precomputed luminance
                 float sourcePdf = lerpf(lpdf, rtarget::pdf_brdf(ctx, ldir), ratio);  // res.slang:79-91
-                float w = targetPdf / sourcePdf;                                       // res.slang:93-113
+                float w = mr_div(targetPdf, sourcePdf);                                // res.slang:93-113
                 s.weightSum += w; s.M += 1.f;
                 if (rnd(sg) * s.weightSum < w) { s.light_data = ld; s.inv_pdf = lpdf; s.weight = targetPdf; }
             }
@@ -253,13 +256,13 @@ __global__ void __launch_bounds__(MR_GEN_BLOCK) k_initial_gen(mirres_config_t C,
                 v3 em = env_radiance(E, dir);
                 float targetPdf = rtarget::target(ctx, em, dir);
                 float sourcePdf = lerpf(lpdf, rtarget::pdf_brdf(ctx, dir), ratio);
-                float w = targetPdf / sourcePdf;
+                float w = mr_div(targetPdf, sourcePdf);
                 s.weightSum += w; s.M += 1.f;
                 if (rnd(sg) * s.weightSum < w) { s.light_data = ld; s.inv_pdf = lpdf; s.weight = targetPdf; }
             }
             if (s.light_data.x > 0.1f) { want = true; rpos = load_gpos(G, pi); rdir = oct_decode(V2(s.light_data.y, s.light_data.z)); }
             // reservoir as if the sample is visible; k_initial_resolve empties it when the shadow ray hits (:269-281)
-            s.weight = s.weight > 0.f ? (s.weightSum / s.M) / s.weight : 0.f;
+            s.weight = s.weight > 0.f ? mr_div(mr_div(s.weightSum, s.M), s.weight) : 0.f;
             s.M = 1.f;
             store_ris(R, sv, s);
         }
@@ -321,14 +324,14 @@ __global__ void __launch_bounds__(MR_BLOCK) k_temporal(mirres_config_t C, EnvD E
     v3 sem = env_radiance(E, sdir);
     float currentPdf = rtarget::target(ctx, sem, sdir);
     float prevPdf = rtarget::target(pctx, sem, sdir);
-    float normalization = (usedPrev ? prevPdf : currentPdf) / (cur.M * currentPdf + prev.M * prevPdf);
-    s.weight = s.weight > 0.f ? (s.weightSum * normalization) / s.weight : 0.f;
+    float normalization = mr_div(usedPrev ? prevPdf : currentPdf, cur.M * currentPdf + prev.M * prevPdf);
+    s.weight = s.weight > 0.f ? mr_div(s.weightSum * normalization, s.weight) : 0.f;
     store_ris(R, pi, s);
 }
 
 // ---------------------------------------------------------------- spatial resampling (SpatialResampling.slang:178-322)
-MR_DEV float m_factor(float q0, float q1) { return q0 == 0.f ? 1.f : clampf(powf(fminf(q1 / q0, 1.f), 8.f), 0.f, 1.f); }
-MR_DEV float pairwise_mis(float q0, float q1, float N0, float N1) { return (q1 == 0.f) ? 0.f : (N0 * q0) / (q0 * N0 + q1 * N1); }
+MR_DEV float m_factor(float q0, float q1) { return q0 == 0.f ? 1.f : clampf(powf(fminf(mr_div(q1, q0), 1.f), 8.f), 0.f, 1.f); }
+MR_DEV float pairwise_mis(float q0, float q1, float N0, float N1) { return (q1 == 0.f) ? 0.f : mr_div(N0 * q0, q0 * N0 + q1 * N1); }
 
 // neighbour acceptance in the reference's order of `continue`s (:236-258): in bounds -> normal / depth similar -> neighbour reservoir M != 0 ->
 // neighbour is foreground. The loads of all candidate neighbours are issued before any test is looked at (a runtime loop with early-outs made
@@ -479,7 +482,7 @@ __global__ void __launch_bounds__(MR_BLOCK) k_spatial_resolve(mirres_config_t C,
         if (rnd(sg) * s.weightSum < w) { s.light_data = cur.light_data; s.inv_pdf = cur.light_pdf; s.weight = curTarget; s.vcode = cur.vcode; }
     }
     s.M = (float)cur.M;
-    s.weight = s.weight > 0.f ? (s.weightSum / validNeighbors) / s.weight : 0.f;
+    s.weight = s.weight > 0.f ? mr_div(mr_div(s.weightSum, (float)validNeighbors), s.weight) : 0.f;
     store_ris(R, pi, s);
 }
 

@@ -3,6 +3,9 @@
 // as generate -> trace -> resolve wavefront stages: a vertex emits up to two shadow rays (NEE, BSDF-MIS) into the
 // any-hit queue and one continuation ray into the closest-hit queue; the contributions that depend on visibility are
 // parked per pixel (18 floats) and committed by the resolve stage in the reference's summation order.
+#ifndef MR_LEAN_FP
+#define MR_LEAN_FP 1      // device_math.hpp: short division / square-root sequences, bit-identical to the compiler's for the renderer's operand range
+#endif
 #include "engine.hpp"
 #include "device_math.hpp"
 #include "device_light.hpp"
@@ -175,7 +178,7 @@ __global__ void __launch_bounds__(MR_GEN_BLOCK) k_bounce_gen(mirres_path_t P, En
                     if (!is_black(total_f)) {
                         nee_dir = normalize(samp_dir);
                         mask |= 1u;
-                        float mis = lightPdf * lightPdf / (lightPdf * lightPdf + scatteringPdf * scatteringPdf);  // power_heuristic
+                        float mis = mr_div(lightPdf * lightPdf, lightPdf * lightPdf + scatteringPdf * scatteringPdf);  // power_heuristic
                         v3 a = thr * total_f * Li * mis, b = thr * diff_f * Li * mis, c = thr * spec_f * Li * mis;
                         pd[0] = a.x; pd[1] = a.y; pd[2] = a.z; pd[3] = b.x; pd[4] = b.y; pd[5] = b.z; pd[6] = c.x; pd[7] = c.y; pd[8] = c.z;
                     }
@@ -199,7 +202,7 @@ __global__ void __launch_bounds__(MR_GEN_BLOCK) k_bounce_gen(mirres_path_t P, En
                             if (sampledSpecular == 0) {
                                 lightPdf = pdf_li(E, safe_wi);
                                 if (lightPdf == 0.0f) lightZero = true;
-                                weight = scatteringPdf * scatteringPdf / (scatteringPdf * scatteringPdf + lightPdf * lightPdf);
+                                weight = mr_div(scatteringPdf * scatteringPdf, scatteringPdf * scatteringPdf + lightPdf * lightPdf);
                             }
                             bsdf_dir = safe_wi;
                             mask |= 2u;
