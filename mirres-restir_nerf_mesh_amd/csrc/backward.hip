@@ -5,6 +5,9 @@
 //   * mirres_matnet_bwd        : backward of MLPTexture3D.sample (render_helper.py:93-104): fp32 MLP weight gradients
 //     (block-level LDS reduction, then one atomic per weight per block) and hash-grid gradients scattered with fp32 atomics
 //     into the fp32 master table (tcnn accumulates its grid gradient the same way).
+#ifndef MR_LEAN_FP
+#define MR_LEAN_FP 1      // device_math.hpp: short division / square-root sequences (same bits as the compiler's for the renderer's operand range)
+#endif
 #include "engine.hpp"
 #include "device_math.hpp"
 #include "device_light.hpp"
@@ -40,12 +43,12 @@ template <int NP> MR_DEV Dual<NP> operator+(Dual<NP> a, float s) { a.v += s; ret
 template <int NP> MR_DEV Dual<NP> operator+(float s, Dual<NP> a) { a.v += s; return a; }
 template <int NP> MR_DEV Dual<NP> operator-(float s, Dual<NP> a) { return mk<NP>(s) - a; }
 template <int NP> MR_DEV Dual<NP> operator-(Dual<NP> a, float s) { a.v -= s; return a; }
-template <int NP> MR_DEV Dual<NP> operator/(Dual<NP> a, Dual<NP> b) { Dual<NP> r; r.v = a.v / b.v; float ib = 1.0f / b.v;
+template <int NP> MR_DEV Dual<NP> operator/(Dual<NP> a, Dual<NP> b) { Dual<NP> r; r.v = mr_div(a.v, b.v); float ib = mr_rcp(b.v);
 #pragma unroll
     for (int i = 0; i < NP; i++) r.d[i] = (a.d[i] - r.v * b.d[i]) * ib; return r; }
 template <int NP> MR_DEV Dual<NP> operator/(float s, Dual<NP> b) { return mk<NP>(s) / b; }
-template <int NP> MR_DEV Dual<NP> operator/(Dual<NP> a, float s) { return a * (1.0f / s); }
-template <int NP> MR_DEV Dual<NP> dsqrt(Dual<NP> a) { Dual<NP> r; r.v = sqrtf(a.v); float k = a.v > 0.f ? 0.5f / r.v : 0.f;
+template <int NP> MR_DEV Dual<NP> operator/(Dual<NP> a, float s) { return a * mr_rcp(s); }
+template <int NP> MR_DEV Dual<NP> dsqrt(Dual<NP> a) { Dual<NP> r; r.v = mr_sqrt(a.v); float k = a.v > 0.f ? mr_div(0.5f, r.v) : 0.f;
 #pragma unroll
     for (int i = 0; i < NP; i++) r.d[i] = a.d[i] * k; return r; }
 template <int NP> MR_DEV Dual<NP> dmax0(Dual<NP> a) { return a.v > 0.f ? a : mk<NP>(0.f); }  // max(a, 0)
@@ -205,7 +208,7 @@ __global__ void __launch_bounds__(MR_BLOCK) k_direct_bwd(EnvD E, int N, int S, c
     if (live && occ[pi] > 0.1f) {
         const v3 n = ld3(normal, pi), k = ld3(kd, pi);
         v3 rd = ld3(ray_dir_raw, pi);
-        { const float l = fmaxf(sqrtf(dot(rd, rd)), 1e-6f); rd = V3(rd.x / l, rd.y / l, rd.z / l); }   // the forward's k_prep (F.normalize, eps 1e-6)
+        { const float l = fmaxf(mr_sqrt(dot(rd, rd)), 1e-6f); rd = V3(mr_div(rd.x, l), mr_div(rd.y, l), mr_div(rd.z, l)); }   // the forward's k_prep (F.normalize, eps 1e-6)
         const float rough = rm[2 * (size_t)pi], metal = rm[2 * (size_t)pi + 1];
         const v3 gc = ld3(g_color, pi), gd = ld3(g_diff, pi), gs = ld3(g_spec, pi);
         for (int s = sub; s < S; s += MR_DBW_SPLIT) {

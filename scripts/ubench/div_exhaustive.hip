@@ -57,7 +57,7 @@ __device__ __forceinline__ float rsq(float x) { return __builtin_amdgcn_rsqf(x);
 // S1: y = rsq(x); s = x*y; one residual correction with h = y/2; zero / infinity passed through      rsq mul mul fma fma (+ class select)
 __device__ __forceinline__ float sqrt_s1(float x) {
     float y = rsq(x); float s = x * y; float h = 0.5f * y; float r = __builtin_fmaf(-s, s, x); s = __builtin_fmaf(r, h, s);
-    return __builtin_amdgcn_classf(x, 0x260) ? x : s;      // +-0, +inf -> x (as the compiler's sequence does)
+    return __builtin_amdgcn_classf(x, 0x2f0) ? x : s;      // +-0, +inf -> x (as the compiler's sequence does); +-denormal -> x (instead of a NaN)
 }
 // S2: S1 with a second residual correction
 __device__ __forceinline__ float sqrt_s2(float x) {
@@ -102,7 +102,7 @@ __global__ void k_special(const float* vals, int n, unsigned long long* out, flo
     }
     if (i < n) {          // sqrt of every value as well
         const float x = vals[i]; const float r0 = sqrtf(x), r1 = sqrt_s1(x);
-        if (!(__float_as_uint(r0) == __float_as_uint(r1) || (r0 != r0 && r1 != r1))) { const unsigned long long s = atomicAdd(&out[3], 1ull); if (s < 4) { ex[48 + s * 2] = x; ex[48 + s * 2 + 1] = r1; } }
+        if (!(__float_as_uint(r0) == __float_as_uint(r1) || (r0 != r0 && r1 != r1))) { if (abs(expo(x)) <= 100) atomicAdd(&out[6], 1ull); const unsigned long long s = atomicAdd(&out[3], 1ull); if (s < 4) { ex[48 + s * 2] = x; ex[48 + s * 2 + 1] = r1; } }
     }
 }
 
@@ -121,8 +121,8 @@ int main(int argc, char** argv) {
         float* dv; unsigned long long* out; float* ex; hipMalloc(&dv, n * 4); hipMalloc(&out, 64); hipMalloc(&ex, 64 * 4); hipMemset(out, 0, 64); hipMemset(ex, 0, 256); { unsigned long long big = 1000; hipMemcpy(out + 4, &big, 8, hipMemcpyHostToDevice); }
         hipMemcpy(dv, vals, n * 4, hipMemcpyHostToDevice);
         k_special<<<(n * n + 255) / 256, 256>>>(dv, n, out, ex); hipDeviceSynchronize();
-        unsigned long long o[6]; float e[64]; hipMemcpy(o, out, 48, hipMemcpyDeviceToHost); hipMemcpy(e, ex, 256, hipMemcpyDeviceToHost);
-        printf("division A + v_div_fixup over %d x %d operands (zeros, denormals, infinities, NaN, every exponent): mismatches vs IEEE — zero/inf/NaN operands %llu; normal operands and quotient with |exponent| <= 100: %llu; outside that range: %llu;  sqrt S1 on the same values: %llu\n", n, n, o[0], o[1], o[2], o[3]);
+        unsigned long long o[7]; float e[64]; hipMemcpy(o, out, 56, hipMemcpyDeviceToHost); hipMemcpy(e, ex, 256, hipMemcpyDeviceToHost);
+        printf("division A + v_div_fixup over %d x %d operands (zeros, denormals, infinities, NaN, every exponent): mismatches vs IEEE — zero/inf/NaN operands %llu; normal operands and quotient with |exponent| <= 100: %llu; outside that range: %llu;  sqrt S1 on the same values: %llu, of which with |exponent| <= 100: %llu\n", n, n, o[0], o[1], o[2], o[3], o[6]);
         printf("   outside: least extreme exponent with a mismatch %llu; mismatches worse than one ulp (or non-finite) %llu\n", o[4], o[5]);
         for (int c = 0; c < 3; c++) for (int k = 0; k < 4 && k < (int)o[c]; k++) printf("   class %d: %g / %g = %g, got %g\n", c, e[(c * 4 + k) * 4], e[(c * 4 + k) * 4 + 1], e[(c * 4 + k) * 4 + 2], e[(c * 4 + k) * 4 + 3]);
         for (int k = 0; k < 4 && k < (int)o[3]; k++) printf("   sqrt(%g) got %g\n", e[48 + 2 * k], e[48 + 2 * k + 1]);
