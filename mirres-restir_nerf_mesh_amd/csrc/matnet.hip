@@ -57,6 +57,38 @@ MR_DEV __half2 weighted_half2(float w, __half2 v) {
     asm("" : "+v"(p0), "+v"(p1));
     return __floats2half2_rn(p0, p1);
 }
+// The eight table entries of a cell, tcnn's grid_index for every corner (dx, dy, dz) at once — same values as grid_index(size, res, px + dx, py + dy,
+// pz + dz), without its per-corner multiplications and its u32 modulo (a ~30-instruction sequence, eight times per level: it was most of the
+// encoder's instructions). The level kind is uniform, so the branch is scalar:
+//   hashed (res^3 > size, size = 2^19): (px + dx) ^ (py + dy) * P1 ^ (pz + dz) * P2 with the products of the +1 corners formed by one addition
+//     (u32 arithmetic wraps, (p + 1) * P = p * P + P), and `% size` = `& (size - 1)`;
+//   dense: px + py * res + pz * res^2 plus the corner strides; an index can pass `size` only at the far faces (a corner coordinate equal to res),
+//     where it stays below 2 * size (res + res^2 + res^3 < 2 res^3), so `% size` is one conditional subtraction — the modulo is kept behind a
+//     branch no wave takes for points inside the unit cube.
+MR_DEV void corner_indices(uint32_t size, uint32_t res, const uint32_t pg[3], uint32_t idx[8]) {
+    const bool hashed = (uint64_t)res * res * res > (uint64_t)size && (size & (size - 1u)) == 0u;
+    const bool dense = (uint64_t)res * res * res <= (uint64_t)size;
+    if (hashed) {
+        const uint32_t m = size - 1u;
+        const uint32_t hx[2] = {pg[0], pg[0] + 1u};
+        const uint32_t y0 = pg[1] * 2654435761u, z0 = pg[2] * 805459861u;
+        const uint32_t hy[2] = {y0, y0 + 2654435761u}, hz[2] = {z0, z0 + 805459861u};
+#pragma unroll
+        for (uint32_t c = 0; c < 8; c++) idx[c] = (hx[c & 1u] ^ hy[(c >> 1) & 1u] ^ hz[c >> 2]) & m;
+    } else if (dense) {
+        const uint32_t r2 = res * res, base = pg[0] + pg[1] * res + pg[2] * r2;
+#pragma unroll
+        for (uint32_t c = 0; c < 8; c++) {
+            uint32_t i = base + (c & 1u) + ((c >> 1) & 1u) * res + (c >> 2) * r2;
+            i = i >= size ? i - size : i;
+            if (i >= size) i %= size;
+            idx[c] = i;
+        }
+    } else {
+#pragma unroll
+        for (uint32_t c = 0; c < 8; c++) idx[c] = grid_index(size, res, pg[0] + (c & 1u), pg[1] + ((c >> 1) & 1u), pg[2] + (c >> 2));
+    }
+}
 // encode one point (already normalised to [0,1]^3) into 32 fp16 features
 MR_DEV void encode_point(const GridLevels& L, const __half2* __restrict__ grid, const float x[3], __half enc[32]) {
 #pragma unroll 1
@@ -66,16 +98,18 @@ MR_DEV void encode_point(const GridLevels& L, const __half2* __restrict__ grid, 
         float pos[3]; uint32_t pg[3];
 #pragma unroll
         for (int d = 0; d < 3; d++) { float p = fmaf(scale, x[d], 0.5f); float fl = floorf(p); pg[d] = (uint32_t)(int)fl; pos[d] = p - fl; }
+        uint32_t ci[8];
+        corner_indices(size, res, pg, ci);
+        __half2 v[8];
+#pragma unroll
+        for (uint32_t idx = 0; idx < 8; idx++) v[idx] = g[ci[idx]];
         __half2 r = __floats2half2_rn(0.f, 0.f);
 #pragma unroll
         for (uint32_t idx = 0; idx < 8; idx++) {
-            float w = 1.f; uint32_t pl[3];
+            float w = 1.f;
 #pragma unroll
-            for (int d = 0; d < 3; d++) {
-                if ((idx & (1u << d)) == 0) { w *= 1 - pos[d]; pl[d] = pg[d]; } else { w *= pos[d]; pl[d] = pg[d] + 1; }
-            }
-            const __half2 v = g[grid_index(size, res, pl[0], pl[1], pl[2])];
-            r = __hadd2(r, weighted_half2(w, v));
+            for (int d = 0; d < 3; d++) w *= (idx & (1u << d)) == 0 ? 1 - pos[d] : pos[d];
+            r = __hadd2(r, weighted_half2(w, v[idx]));
         }
         enc[2 * lv] = __low2half(r); enc[2 * lv + 1] = __high2half(r);
     }
