@@ -11,6 +11,7 @@
 #include "engine.hpp"
 #include "device_math.hpp"
 #include "device_light.hpp"
+#include "device_grid.hpp"
 #include <hip/hip_fp16.h>
 #include <cmath>
 
@@ -262,42 +263,7 @@ int launch_direct_bwd(const float* tex, int Wc, int Hc, int N, int S, const floa
     return 0;
 }
 
-// ---------------------------------------------------------------- material-field backward
-#define MR_LEVELS 16
-struct GridLevelsB { float scale[MR_LEVELS]; uint32_t res[MR_LEVELS]; uint32_t size[MR_LEVELS]; uint32_t offset[MR_LEVELS]; };
-static GridLevelsB host_levels_b() {
-    GridLevelsB L;
-    const float log2_pls = log2f(1.4472692012786865f);
-    uint32_t offset = 0;
-    for (int i = 0; i < MR_LEVELS; i++) {
-        float scale = exp2f(i * log2_pls) * 16 - 1.0f;
-        uint32_t res = (uint32_t)ceilf(scale) + 1;
-        uint64_t dense = (uint64_t)res * res * res;
-        uint32_t params = dense > 0x7fffffffull ? 0x7fffffffu : (uint32_t)dense;
-        params = (params + 7u) / 8u * 8u;
-        if (params > (1u << 19)) params = 1u << 19;
-        L.scale[i] = scale; L.res[i] = res; L.size[i] = params; L.offset[i] = offset;
-        offset += params;
-    }
-    return L;
-}
-// (T)(weight * value) of tcnn's interpolation (grid.h): the fp32 product is ROUNDED TO fp32 and then to fp16. Left to itself the compiler turns
-// fptrunc(fmul) into v_fma_mixlo_f16 — one rounding of the exact product — whenever it does not happen to pack the multiplication with a neighbour
-// (round 2: -fno-vectorize changed 1 feature in ~10^4 by one fp16 ulp against tcnn's two-step rounding); the empty asm pins the two-step form in every build.
-MR_DEV __half2 weighted_half2_b(float w, __half2 v) {      // as matnet.hip's weighted_half2 (the forward recompute must reproduce the forward's bits)
-    float p0 = w * __low2float(v), p1 = w * __high2float(v);
-    asm("" : "+v"(p0), "+v"(p1));
-    return __floats2half2_rn(p0, p1);
-}
-MR_DEV uint32_t grid_index_b(uint32_t size, uint32_t res, uint32_t px, uint32_t py, uint32_t pz) {
-    uint32_t stride = 1, index = 0;
-    if (stride <= size) { index += px * stride; stride *= res; }
-    if (stride <= size) { index += py * stride; stride *= res; }
-    if (stride <= size) { index += pz * stride; stride *= res; }
-    if (size < stride) index = (px * 1u) ^ (py * 2654435761u) ^ (pz * 805459861u);
-    return index % size;
-}
-
+// ---------------------------------------------------------------- material-field backward (level table and index arithmetic: device_grid.hpp)
 struct MatNetB { const __half2* grid; const float *w0, *w1, *w2; float aabb_min[3], aabb_max[3], mn[6], mx[6]; };
 
 // Weight gradients are outer-product sums over the points (gW1[o][k] = sum_p gh2_p[o] * h1_p[k], ...). The first version added every
@@ -310,6 +276,8 @@ struct MatNetB { const __half2* grid; const float *w0, *w1, *w2; float aabb_min[
 #define MR_BW_TABLE_LOG2 10
 #define MR_BW_TABLE (1 << MR_BW_TABLE_LOG2)   // per-wave aggregation table of the coarse grid levels: keys in U (4 KB of 8.4), values in V (8 KB of 8.4)
 #define MR_BW_COARSE 8
+typedef GridLevels GridLevelsB;
+static GridLevelsB host_levels_b() { return host_levels(nullptr); }
 __global__ void __launch_bounds__(MR_BLOCK) k_matnet_bwd(MatNetB M, GridLevelsB L, const float* __restrict__ pos, int n, const float* __restrict__ gout,
                                                          float* __restrict__ g_params, float* __restrict__ g_w0, float* __restrict__ g_w1, float* __restrict__ g_w2,
                                                          float* __restrict__ g_pos) {
@@ -341,14 +309,17 @@ __global__ void __launch_bounds__(MR_BLOCK) k_matnet_bwd(MatNetB M, GridLevelsB 
             float p[3]; uint32_t pg[3];
 #pragma unroll
             for (int d = 0; d < 3; d++) { float q = fmaf(scale, x[d], 0.5f); float fl = floorf(q); pg[d] = (uint32_t)(int)fl; p[d] = q - fl; }
+            uint32_t ci[8]; corner_indices(size, res, pg, ci);
+            __half2 cv[8];
+#pragma unroll
+            for (uint32_t idx = 0; idx < 8; idx++) cv[idx] = g[ci[idx]];
             __half2 r = __floats2half2_rn(0.f, 0.f);
 #pragma unroll
             for (uint32_t idx = 0; idx < 8; idx++) {
-                float w = 1.f; uint32_t pl[3];
+                float w = 1.f;
 #pragma unroll
-                for (int d = 0; d < 3; d++) { if ((idx & (1u << d)) == 0) { w *= 1 - p[d]; pl[d] = pg[d]; } else { w *= p[d]; pl[d] = pg[d] + 1; } }
-                const __half2 v = g[grid_index_b(size, res, pl[0], pl[1], pl[2])];
-                r = __hadd2(r, weighted_half2_b(w, v));
+                for (int d = 0; d < 3; d++) w *= (idx & (1u << d)) == 0 ? 1 - p[d] : p[d];
+                r = __hadd2(r, weighted_half2(w, cv[idx]));
             }
             a0[2 * lv] = __low2float(r); a0[2 * lv + 1] = __high2float(r);
         }
@@ -377,12 +348,13 @@ __global__ void __launch_bounds__(MR_BLOCK) k_matnet_bwd(MatNetB M, GridLevelsB 
 #pragma unroll
                 for (int d = 0; d < 3; d++) { float q = fmaf(scale, x[d], 0.5f); float fl = floorf(q); pg[d] = (uint32_t)(int)fl; p[d] = q - fl; }
                 float lx[3] = {0.f, 0.f, 0.f};
+                uint32_t ci[8]; corner_indices(size, res, pg, ci);
 #pragma unroll
                 for (uint32_t idx = 0; idx < 8; idx++) {
-                    float wd[3]; uint32_t pl[3];
+                    float wd[3];
 #pragma unroll
-                    for (int d = 0; d < 3; d++) { if ((idx & (1u << d)) == 0) { wd[d] = 1 - p[d]; pl[d] = pg[d]; } else { wd[d] = p[d]; pl[d] = pg[d] + 1; } }
-                    const __half2 v = g[grid_index_b(size, res, pl[0], pl[1], pl[2])];
+                    for (int d = 0; d < 3; d++) wd[d] = (idx & (1u << d)) == 0 ? 1 - p[d] : p[d];
+                    const __half2 v = g[ci[idx]];
                     const float sv = g0 * __low2float(v) + g1 * __high2float(v);
                     lx[0] += ((idx & 1u) ? sv : -sv) * (wd[1] * wd[2]);
                     lx[1] += ((idx & 2u) ? sv : -sv) * (wd[0] * wd[2]);
@@ -445,12 +417,13 @@ __global__ void __launch_bounds__(MR_BLOCK) k_matnet_bwd(MatNetB M, GridLevelsB 
                     for (int d = 0; d < 3; d++) { float q = fmaf(scale, x[d], 0.5f); float fl = floorf(q); pg[d] = (uint32_t)(int)fl; p[d] = q - fl; }
                     const float g0 = ga0[2 * lv], g1 = ga0[2 * lv + 1];
                     if (g0 == 0.f && g1 == 0.f) continue;
+                    uint32_t ci[8]; corner_indices(size, res, pg, ci);
 #pragma unroll
                     for (uint32_t idx = 0; idx < 8; idx++) {
-                        float w = 1.f; uint32_t pl[3];
+                        float w = 1.f;
 #pragma unroll
-                        for (int d = 0; d < 3; d++) { if ((idx & (1u << d)) == 0) { w *= 1 - p[d]; pl[d] = pg[d]; } else { w *= p[d]; pl[d] = pg[d] + 1; } }
-                        const size_t e = (size_t)L.offset[lv] + grid_index_b(size, res, pl[0], pl[1], pl[2]);
+                        for (int d = 0; d < 3; d++) w *= (idx & (1u << d)) == 0 ? 1 - p[d] : p[d];
+                        const size_t e = (size_t)L.offset[lv] + ci[idx];
                         bool done = false;
                         if (lv < MR_BW_COARSE) {
                             uint32_t h = ((uint32_t)e * 2654435761u) >> (32 - MR_BW_TABLE_LOG2);
