@@ -84,4 +84,34 @@ MR_DEV void corner_indices(uint32_t size, uint32_t res, const uint32_t pg[3], ui
         for (uint32_t c = 0; c < 8; c++) idx[c] = grid_index(size, res, pg[0] + (c & 1u), pg[1] + ((c >> 1) & 1u), pg[2] + (c >> 2));
     }
 }
+// The eight entries of a cell in four 8-byte gathers where the table allows it: the corners (dx = 0, 1) of one (dy, dz) are neighbours in memory
+// on a dense level (indices i, i + 1) and, on a hashed level, whenever px is even ((px + 1) ^ h = (px ^ h) ^ 1: the two entries of one aligned pair).
+// Elsewhere — odd px on a hashed level, the wrap at a dense level's far face — the second entry is fetched by its own (lane-masked) gather.
+// Same entries, same values: the encoder's time goes into these gathers (one L1 tag look-up per distinct line per instruction), not into arithmetic.
+struct __attribute__((packed, aligned(4))) GridPair { uint32_t x, y; };
+MR_DEV __half2 as_half2(uint32_t u) { __half2 h; __builtin_memcpy(&h, &u, 4); return h; }
+MR_DEV void gather_cell(const __half2* __restrict__ g, const uint32_t ci[8], bool hashed, __half2 v[8]) {
+#pragma unroll
+    for (int c = 0; c < 8; c += 2) {
+        const uint32_t i0 = ci[c], i1 = ci[c + 1];
+#ifndef MR_PAIR_MODE
+#define MR_PAIR_MODE 3
+#endif
+        if ((hashed && !(MR_PAIR_MODE & 2)) || (!hashed && !(MR_PAIR_MODE & 1))) { v[c] = g[i0]; v[c + 1] = g[i1]; }
+        else if (hashed) {
+            const uint2 pr = *reinterpret_cast<const uint2*>(g + (i0 & ~1u));
+            const bool odd = (i0 & 1u) != 0u;
+            v[c] = as_half2(odd ? pr.y : pr.x);
+            uint32_t o = odd ? pr.x : pr.y;
+            if ((i0 ^ i1) != 1u) o = *reinterpret_cast<const uint32_t*>(g + i1);
+            v[c + 1] = as_half2(o);
+        } else {
+            const GridPair pr = *reinterpret_cast<const GridPair*>(g + i0);
+            v[c] = as_half2(pr.x);
+            uint32_t o = pr.y;
+            if (i1 != i0 + 1u) o = *reinterpret_cast<const uint32_t*>(g + i1);
+            v[c + 1] = as_half2(o);
+        }
+    }
+}
 }  // namespace mr

@@ -29,8 +29,7 @@ MR_DEV void encode_point(const GridLevels& L, const __half2* __restrict__ grid, 
         uint32_t ci[8];
         corner_indices(size, res, pg, ci);
         __half2 v[8];
-#pragma unroll
-        for (uint32_t idx = 0; idx < 8; idx++) v[idx] = g[ci[idx]];
+        gather_cell(g, ci, (uint64_t)res * res * res > (uint64_t)size && (size & (size - 1u)) == 0u, v);
         __half2 r = __floats2half2_rn(0.f, 0.f);
 #pragma unroll
         for (uint32_t idx = 0; idx < 8; idx++) {
