@@ -18,7 +18,17 @@ int trace_any_queue_counted(const mirres_bvh* bvh, const Ray* rays, const uint32
                             unsigned long long* stats, hipStream_t s, int reference_order);
 
 #define MR_BLOCK 256
-#define MR_GEN_BLOCK 1024   // ray-generating kernels: one queue atomic per 1024 pixels
+// Block sizes of the ray-generating kernels. They are long, register-heavy (78-80 VGPRs: six waves per SIMD) per-thread programs, and a block is placed
+// only when a CU has room for ALL its waves: with 1024 threads (four waves per SIMD per block) a CU held ONE block — four of the six possible waves,
+// and nothing at all beside another stream's block. 512 / 256 threads fill the six: k_initial_gen 10.3 -> 7.3 ms per 32-sample batch, k_bounce_gen
+// 4.9 -> 4.0 ms, frame 974 -> 1029 Msamples/s (round 2; per-kernel sizes picked on the frame: 256 / 512 / 512).
+#ifndef MR_GEN_BLOCK
+#define MR_GEN_BLOCK 512    // ray-generating kernels: one queue atomic per block
+#endif
+#ifndef MR_IGEN_BLOCK
+#define MR_IGEN_BLOCK 256
+#endif
+#define MR_SGEN_BLOCK 1024  // k_spatial_gen: one 32 x 32 pixel tile per block
 
 // 2-D tile -> pixel mapping for the kernels that gather from neighbouring pixels (spatial pass: +-30 px): a square tile of threads touches a
 // (T+60)^2 window instead of the (blockDim+60) x 61 strip a row-major block touches, which is what the L1/L2 hit rate of the gathers follows.
@@ -208,7 +218,7 @@ __global__ void __launch_bounds__(MR_BLOCK) k_tile_aux(EnvD E, int total, const 
 }
 
 // ---------------------------------------------------------------- initial resampling (InitialResampling.slang:151-295)
-__global__ void __launch_bounds__(MR_GEN_BLOCK) k_initial_gen(mirres_config_t C, EnvD E, GBufD G, ResD R, const float* __restrict__ tile_data,
+__global__ void __launch_bounds__(MR_IGEN_BLOCK) k_initial_gen(mirres_config_t C, EnvD E, GBufD G, ResD R, const float* __restrict__ tile_data,
                                                           const float* __restrict__ tile_pdf, const float4* __restrict__ tile_aux, uint32_t frameIndex0, int fx, int N,
                                                           int NV, int TS, int y_off, Ray* __restrict__ q, uint32_t* __restrict__ q_count, int32_t* __restrict__ slot_out) {
     // slot sv = k * N + pixel: sample k of a K-sample batch (NV = K * N; K = 1 for the stepwise ABI) — reservoir at sv, G-buffer at the pixel,
@@ -337,7 +347,7 @@ MR_DEV float pairwise_mis(float q0, float q1, float N0, float N1) { return (q1 =
 // neighbour is foreground. The loads of all candidate neighbours are issued before any test is looked at (a runtime loop with early-outs made
 // each of the ~15 gathers of a pixel wait for the previous one: the kernel spent its time on dependent L2 round trips); the tests are unchanged.
 template <int MR_MAX_NB>   // 5 (the reference's neighbour count) or 8: bounds the unrolled gathers, i.e. the registers held
-__global__ void __launch_bounds__(MR_GEN_BLOCK) k_spatial_gen(mirres_config_t C, GBufD G, ResD PR, const float* __restrict__ noff, uint32_t frameIndex,
+__global__ void __launch_bounds__(MR_SGEN_BLOCK) k_spatial_gen(mirres_config_t C, GBufD G, ResD PR, const float* __restrict__ noff, uint32_t frameIndex,
                                                           int fx, int fy, int N, int y_off, const float* __restrict__ occ_own, Ray* __restrict__ q,
                                                           uint32_t* __restrict__ q_count, int32_t* __restrict__ slot_out, uint32_t* __restrict__ mask_out) {
     // strip sharding: y_off = global row of local row 0 (seeds), occ_own = occupancy with the halo rows zeroed (which pixels this rank merges);
@@ -632,7 +642,7 @@ int launch_initial_batch(mirres_ctx* ctx, mirres_bvh* bvh, const mirres_env_t* e
     MR_HIP(hipMemsetAsync(&q->counters[0], 0, sizeof(uint32_t), s));
     k_light_tiles<<<grid_for((size_t)K * TS, MR_BLOCK), MR_BLOCK, 0, s>>>(envh(env), frame0, K * TS, TS, tile_data, nullptr, tile_pdf);       // pass 0 (+1 inside)
     k_tile_aux<<<grid_for((size_t)K * TS, MR_BLOCK), MR_BLOCK, 0, s>>>(envh(env), K * TS, tile_data, reinterpret_cast<float4*>(tile_aux));
-    k_initial_gen<<<grid_for(NV, MR_GEN_BLOCK), MR_GEN_BLOCK, 0, s>>>(ctx->cfg, envh(env), gbufd(g), resd(res), tile_data, tile_pdf, reinterpret_cast<const float4*>(tile_aux),
+    k_initial_gen<<<grid_for(NV, MR_IGEN_BLOCK), MR_IGEN_BLOCK, 0, s>>>(ctx->cfg, envh(env), gbufd(g), resd(res), tile_data, tile_pdf, reinterpret_cast<const float4*>(tile_aux),
                                                                        frame0 + 2, ctx->fx, N, NV, TS, ctx->y_off, q->any_rays, &q->counters[0], q->slot_a);       // pass 2
     int rc = trace_any_q(ctx, bvh, q->any_rays, &q->counters[0], (size_t)NV, q->any_hit, s, q->lane); if (rc) return rc;
     k_initial_resolve<<<grid_for(NV, MR_BLOCK), MR_BLOCK, 0, s>>>(resd(res), NV, q->slot_a, q->any_hit);
@@ -760,7 +770,7 @@ int mirres_restir_initial(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_env
     MR_HIP(hipMemsetAsync(&ctx->counters[0], 0, sizeof(uint32_t), s));
     const int TS = ctx->cfg.light_tile_count * ctx->cfg.light_tile_size;
     k_tile_aux<<<grid_for(TS, MR_BLOCK), MR_BLOCK, 0, s>>>(envh(env), TS, light_data, reinterpret_cast<float4*>(ctx->tile_aux));
-    k_initial_gen<<<grid_for(N, MR_GEN_BLOCK), MR_GEN_BLOCK, 0, s>>>(ctx->cfg, envh(env), gbufd(g), resd(res), light_data, light_inv_pdf, reinterpret_cast<const float4*>(ctx->tile_aux), frameIndex, ctx->fx, N, N, TS, 0, ctx->any_rays,
+    k_initial_gen<<<grid_for(N, MR_IGEN_BLOCK), MR_IGEN_BLOCK, 0, s>>>(ctx->cfg, envh(env), gbufd(g), resd(res), light_data, light_inv_pdf, reinterpret_cast<const float4*>(ctx->tile_aux), frameIndex, ctx->fx, N, N, TS, 0, ctx->any_rays,
                                             &ctx->counters[0], ctx->slot_a);
     int rc = trace_any(ctx, bvh, (size_t)N, s); if (rc) return rc;
     k_initial_resolve<<<grd, MR_BLOCK, 0, s>>>(resd(res), N, ctx->slot_a, ctx->any_hit);
@@ -787,9 +797,9 @@ int mirres_restir_spatial(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_env
     if (!(fold && ctx->chain_clean)) MR_HIP(hipMemsetAsync(&ctx->counters[0], 0, sizeof(uint32_t), s));
     uint32_t* const rc_ = fold ? &ctx->counters[0] : nullptr; uint32_t* const rh_ = fold ? bvh->work : nullptr;   // lane 0 = head set 0
     const bool nb5 = ctx->cfg.neighbor_count <= 5;
-    if (nb5) k_spatial_gen<5><<<tile_grid(ctx->fx, ctx->fy, 32), MR_GEN_BLOCK, 0, s>>>(ctx->cfg, gbufd(g), resd(prev_res), noff, frameIndex, ctx->fx, ctx->fy, N, ctx->y_off, ctx->occ_own, ctx->any_rays, &ctx->counters[0],
+    if (nb5) k_spatial_gen<5><<<tile_grid(ctx->fx, ctx->fy, 32), MR_SGEN_BLOCK, 0, s>>>(ctx->cfg, gbufd(g), resd(prev_res), noff, frameIndex, ctx->fx, ctx->fy, N, ctx->y_off, ctx->occ_own, ctx->any_rays, &ctx->counters[0],
                                                                                    ctx->slot_a, ctx->mask_a);
-    else k_spatial_gen<8><<<tile_grid(ctx->fx, ctx->fy, 32), MR_GEN_BLOCK, 0, s>>>(ctx->cfg, gbufd(g), resd(prev_res), noff, frameIndex, ctx->fx, ctx->fy, N, ctx->y_off, ctx->occ_own, ctx->any_rays, &ctx->counters[0],
+    else k_spatial_gen<8><<<tile_grid(ctx->fx, ctx->fy, 32), MR_SGEN_BLOCK, 0, s>>>(ctx->cfg, gbufd(g), resd(prev_res), noff, frameIndex, ctx->fx, ctx->fy, N, ctx->y_off, ctx->occ_own, ctx->any_rays, &ctx->counters[0],
                                                                                ctx->slot_a, ctx->mask_a);
     int rc = trace_any(ctx, bvh, ctx->any_cap, s); if (rc) return rc;
     GBufD gr = gbufd(g);

@@ -19,7 +19,13 @@ int trace_closest_queue_counted(const mirres_bvh* bvh, const Ray* rays, const ui
                                 unsigned long long* stats, hipStream_t s);
 
 #define MR_BLOCK 256
-#define MR_GEN_BLOCK 1024   // ray-generating kernels: one queue atomic per 1024 pixels
+#ifndef MR_GEN_BLOCK
+#define MR_GEN_BLOCK 512    // ray-generating kernels: one queue atomic per block
+#endif
+#ifndef MR_BGEN_BLOCK
+#define MR_BGEN_BLOCK MR_GEN_BLOCK
+#endif
+#define MR_SGEN_BLOCK 1024  // k_spatial_gen: one 32 x 32 pixel tile per block
 
 MR_DEV void put_ray(Ray* q, uint32_t slot, v3 pos, v3 dir, float vis_near) {
     v3 o = pos + vis_near * dir;
@@ -131,7 +137,7 @@ __global__ void __launch_bounds__(MR_BLOCK) k_new_dir_resolve(mirres_path_t P, i
 }
 
 // ---------------------------------------------------------------- process_path_tracing_divided_no_grad (FinalShading.slang:641-1009)
-__global__ void __launch_bounds__(MR_GEN_BLOCK) k_bounce_gen(mirres_path_t P, EnvD E, int max_bounce, float vis_near, uint32_t frameIndex, uint32_t bounce_count,
+__global__ void __launch_bounds__(MR_BGEN_BLOCK) k_bounce_gen(mirres_path_t P, EnvD E, int max_bounce, float vis_near, uint32_t frameIndex, uint32_t bounce_count,
                                                          int fx, int N, int NV, int first_is_zero, int y_off, int sparse, float* __restrict__ color, float* __restrict__ diff_color, float* __restrict__ spec_color,
                                                          Ray* __restrict__ qa, uint32_t* __restrict__ qa_count, Ray* __restrict__ qc, uint32_t* __restrict__ qc_count,
                                                          int32_t* __restrict__ slot_a, uint32_t* __restrict__ mask_out, int32_t* __restrict__ slot_c,
@@ -301,7 +307,7 @@ int launch_bounce(mirres_ctx* ctx, mirres_bvh* bvh, const mirres_env_t* env, con
     const PtQueues Q = qq ? *qq : ctx_queues(ctx);
     const int NV = Q.NV, grd = grid_for(NV, MR_BLOCK);
     MR_HIP(hipMemsetAsync(&Q.counters[0], 0, 2 * sizeof(uint32_t), s));
-    k_bounce_gen<<<grid_for(NV, MR_GEN_BLOCK), MR_GEN_BLOCK, 0, s>>>(*p, envh(env), ctx->cfg.max_bounce, ctx->cfg.vis_near, frameIndex, bounce_count, ctx->fx, Q.N, NV, Q.first_sample_is_zero, ctx->y_off, qq ? 1 : 0,
+    k_bounce_gen<<<grid_for(NV, MR_BGEN_BLOCK), MR_BGEN_BLOCK, 0, s>>>(*p, envh(env), ctx->cfg.max_bounce, ctx->cfg.vis_near, frameIndex, bounce_count, ctx->fx, Q.N, NV, Q.first_sample_is_zero, ctx->y_off, qq ? 1 : 0,
                                                                       color, dc, sc, Q.any_rays, &Q.counters[0], Q.cl_rays, &Q.counters[1], Q.slot_a, Q.mask_a, Q.slot_c, Q.pend);
     int rc = trace_any_q(ctx, bvh, Q.any_rays, &Q.counters[0], 2 * (size_t)NV, Q.any_hit, s, Q.lane); if (rc) return rc;
     rc = trace_closest_q(ctx, bvh, Q.cl_rays, &Q.counters[1], (size_t)NV, Q.cl_hit, s, Q.lane); if (rc) return rc;
