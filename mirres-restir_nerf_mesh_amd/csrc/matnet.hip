@@ -297,16 +297,36 @@ __global__ void __launch_bounds__(MR_BLOCK) k_mlp_mfma(MatNetD M, GridLevels L, 
     }
 }
 
-// compacted list of pixels whose vertex needs a material lookup (occ >= 0.5): replaces torch.where (renderer_restir.py:398)
-__global__ void __launch_bounds__(1024) k_active_list(const float* __restrict__ occ, int n, int32_t* __restrict__ index, uint32_t* __restrict__ count,
-                                                      float* __restrict__ kd, int clamp_all) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool want = i < n && occ[i] >= 0.5f;
-    const uint32_t slot = block_append(count, want);
-    if (want) index[slot] = i;
-    if (clamp_all && i < n) {  // torch.clamp(new_diffuse_map, 0, 1) over the whole map when use_scale (:408); active pixels are clamped by the MLP kernel
+// compacted list of pixels whose vertex needs a material lookup (occ >= 0.5): replaces torch.where (renderer_restir.py:398).
+// One queue-head word takes ~88 atomics per microsecond, so the list is built with ONE atomic per 4096 slots: a thread looks at 16 consecutive
+// slots (four 16-byte loads), the block scans the per-thread counts, and the indices go out in slot order (680 -> ~200 us for 82 M slots; with one
+// slot per thread the kernel was nothing but its 80 k atomics).
+#define MR_AL_PER 16
+__global__ void __launch_bounds__(MR_BLOCK) k_active_list(const float* __restrict__ occ, int n, int32_t* __restrict__ index, uint32_t* __restrict__ count,
+                                                          float* __restrict__ kd, int clamp_all) {
+    const size_t base = ((size_t)blockIdx.x * MR_BLOCK + threadIdx.x) * MR_AL_PER;
+    uint32_t bits = 0;
+    if (base + MR_AL_PER <= (size_t)n) {
 #pragma unroll
-        for (int k = 0; k < 3; k++) kd[3 * (size_t)i + k] = fminf(fmaxf(kd[3 * (size_t)i + k], 0.f), 1.f);
+        for (int j = 0; j < MR_AL_PER; j += 4) {
+            const float4 o = *reinterpret_cast<const float4*>(occ + base + j);
+            bits |= (o.x >= 0.5f ? 1u : 0u) << j | (o.y >= 0.5f ? 2u : 0u) << j | (o.z >= 0.5f ? 4u : 0u) << j | (o.w >= 0.5f ? 8u : 0u) << j;
+        }
+    } else {
+        for (int j = 0; j < MR_AL_PER; j++) if (base + j < (size_t)n && occ[base + j] >= 0.5f) bits |= 1u << j;
+    }
+    const uint32_t cnt = __popc(bits);
+    uint32_t slot = block_append(count, cnt > 0, cnt);
+#pragma unroll
+    for (int j = 0; j < MR_AL_PER; j++) if (bits & (1u << j)) index[slot++] = (int32_t)(base + j);
+    if (clamp_all) {  // torch.clamp(new_diffuse_map, 0, 1) over the whole map when use_scale (:408); active pixels are clamped by the MLP kernel
+        for (int j = 0; j < MR_AL_PER; j++) {
+            const size_t i = base + j;
+            if (i < (size_t)n) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) kd[3 * i + k] = fminf(fmaxf(kd[3 * i + k], 0.f), 1.f);
+            }
+        }
     }
 }
 
@@ -327,7 +347,7 @@ int launch_matnet_scatter_mfma(const mirres_matnet_t* m, const float* occ, const
                                int32_t* index, uint32_t* count, hipStream_t s) {
     float sx = scale3 ? scale3[0] : 1.f, sy = scale3 ? scale3[1] : 1.f, sz = scale3 ? scale3[2] : 1.f;
     MR_HIP(hipMemsetAsync(count, 0, sizeof(uint32_t), s));
-    k_active_list<<<grid_for(n, 1024), 1024, 0, s>>>(occ, n, index, count, kd, use_scale);
+    k_active_list<<<grid_for(n, MR_BLOCK * MR_AL_PER), MR_BLOCK, 0, s>>>(occ, n, index, count, kd, use_scale);
     int g = grid_for(n, MR_BLOCK); if (g > 256 * 8) g = 256 * 8;
     k_mlp_mfma<1, 2><<<g, MR_BLOCK, 0, s>>>(matd(m), host_levels(nullptr), nullptr, pos, index, count, 0, nullptr, kd, rm, use_scale, sx, sy, sz);
     MR_LAUNCH_CHECK("matnet_scatter_mfma");
