@@ -28,7 +28,10 @@ int trace_any_queue_counted(const mirres_bvh* bvh, const Ray* rays, const uint32
 #ifndef MR_IGEN_BLOCK
 #define MR_IGEN_BLOCK 256
 #endif
-#define MR_SGEN_BLOCK 1024  // k_spatial_gen: one 32 x 32 pixel tile per block
+#ifndef MR_SGEN_TILE
+#define MR_SGEN_TILE 16
+#endif
+#define MR_SGEN_BLOCK (MR_SGEN_TILE * MR_SGEN_TILE)  // k_spatial_gen: one square pixel tile per block
 
 // 2-D tile -> pixel mapping for the kernels that gather from neighbouring pixels (spatial pass: +-30 px): a square tile of threads touches a
 // (T+60)^2 window instead of the (blockDim+60) x 61 strip a row-major block touches, which is what the L1/L2 hit rate of the gathers follows.
@@ -352,7 +355,7 @@ __global__ void __launch_bounds__(MR_SGEN_BLOCK) k_spatial_gen(mirres_config_t C
                                                           uint32_t* __restrict__ q_count, int32_t* __restrict__ slot_out, uint32_t* __restrict__ mask_out) {
     // strip sharding: y_off = global row of local row 0 (seeds), occ_own = occupancy with the halo rows zeroed (which pixels this rank merges);
     // neighbours are tested against the true G-buffer, halo rows included
-    const int pi = tile_pixel(fx, fy, 32, N);
+    const int pi = tile_pixel(fx, fy, MR_SGEN_TILE, N);
     uint32_t mask = 0, cnt = 0;
     int nb[MR_MAX_NB];
     v3 cpos = V3(0.f), cdir = V3(0.f);
@@ -797,9 +800,9 @@ int mirres_restir_spatial(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_env
     if (!(fold && ctx->chain_clean)) MR_HIP(hipMemsetAsync(&ctx->counters[0], 0, sizeof(uint32_t), s));
     uint32_t* const rc_ = fold ? &ctx->counters[0] : nullptr; uint32_t* const rh_ = fold ? bvh->work : nullptr;   // lane 0 = head set 0
     const bool nb5 = ctx->cfg.neighbor_count <= 5;
-    if (nb5) k_spatial_gen<5><<<tile_grid(ctx->fx, ctx->fy, 32), MR_SGEN_BLOCK, 0, s>>>(ctx->cfg, gbufd(g), resd(prev_res), noff, frameIndex, ctx->fx, ctx->fy, N, ctx->y_off, ctx->occ_own, ctx->any_rays, &ctx->counters[0],
+    if (nb5) k_spatial_gen<5><<<tile_grid(ctx->fx, ctx->fy, MR_SGEN_TILE), MR_SGEN_BLOCK, 0, s>>>(ctx->cfg, gbufd(g), resd(prev_res), noff, frameIndex, ctx->fx, ctx->fy, N, ctx->y_off, ctx->occ_own, ctx->any_rays, &ctx->counters[0],
                                                                                    ctx->slot_a, ctx->mask_a);
-    else k_spatial_gen<8><<<tile_grid(ctx->fx, ctx->fy, 32), MR_SGEN_BLOCK, 0, s>>>(ctx->cfg, gbufd(g), resd(prev_res), noff, frameIndex, ctx->fx, ctx->fy, N, ctx->y_off, ctx->occ_own, ctx->any_rays, &ctx->counters[0],
+    else k_spatial_gen<8><<<tile_grid(ctx->fx, ctx->fy, MR_SGEN_TILE), MR_SGEN_BLOCK, 0, s>>>(ctx->cfg, gbufd(g), resd(prev_res), noff, frameIndex, ctx->fx, ctx->fy, N, ctx->y_off, ctx->occ_own, ctx->any_rays, &ctx->counters[0],
                                                                                ctx->slot_a, ctx->mask_a);
     int rc = trace_any(ctx, bvh, ctx->any_cap, s); if (rc) return rc;
     GBufD gr = gbufd(g);
