@@ -264,6 +264,14 @@ int mirres_render_bwd(mirres_ctx_t* ctx, const mirres_render_args_t* a, int samp
 /* second half of run_restir_di_with_pt (:507-549) on already-summed accumulators (after an all-reduce).         */
 int mirres_render_finish(mirres_ctx_t* ctx, const mirres_render_args_t* a, float* sums[6], void* stream);
 
+/* Self-check of the arithmetic the shading kernels are built on (no reference counterpart: the reference relies on nvcc's IEEE division).
+ * The shading translation units divide and take square roots with short instruction sequences (csrc/device_math.hpp, mr_div / mr_rcp /
+ * mr_sqrt) that must return the bits of the IEEE-754 operations. This runs them against the compiler's correctly rounded `a / b`, `1 / b`
+ * and `sqrtf` on the device: every significand pair (a, b) in [1, 2) x S, S = 2^log2_b significands spread over [1, 2) plus the last 256
+ * (log2_b = 23: all 2^46 pairs, ~50 s on an MI355X), every reciprocal of [1, 2), and every square root of [1, 4).
+ * out[0] = pairs tested, out[1..3] = mismatches of mr_div, mr_rcp, mr_sqrt (all must be 0). Blocks until done.                          */
+int mirres_selfcheck_arith(int log2_b, unsigned long long out[4], void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -111,6 +111,7 @@ SIGNATURES = {
     "mirres_render": (C.c_int, [vp, vp, PARGS, vp]),
     "mirres_render_bwd": (C.c_int, [vp, PARGS, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]),
     "mirres_render_finish": (C.c_int, [vp, PARGS, C.POINTER(vp), vp]),
+    "mirres_selfcheck_arith": (C.c_int, [C.c_int, C.POINTER(C.c_uint64), vp]),
 }
 
 
