@@ -137,6 +137,9 @@ __global__ void __launch_bounds__(MR_BLOCK) k_new_dir_resolve(mirres_path_t P, i
 }
 
 // ---------------------------------------------------------------- process_path_tracing_divided_no_grad (FinalShading.slang:641-1009)
+#ifdef MR_BGEN_WAVES
+__attribute__((amdgpu_waves_per_eu(MR_BGEN_WAVES, MR_BGEN_WAVES)))
+#endif
 __global__ void __launch_bounds__(MR_BGEN_BLOCK) k_bounce_gen(mirres_path_t P, EnvD E, int max_bounce, float vis_near, uint32_t frameIndex, uint32_t bounce_count,
                                                          int fx, int N, int NV, int first_is_zero, int y_off, int sparse, float* __restrict__ color, float* __restrict__ diff_color, float* __restrict__ spec_color,
                                                          Ray* __restrict__ qa, uint32_t* __restrict__ qa_count, Ray* __restrict__ qc, uint32_t* __restrict__ qc_count,
