@@ -597,6 +597,24 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const
                     const int ref[4] = {(int)rf.x, (int)rf.y, (int)rf.z, (int)rf.w};
                     float tn4[4], tf4[4];
                     child_slabs(nc, t_min, tn4, tf4);
+                    // A node defers at most three entries. While all three fit the LDS part of the stack (always, on trees of ordinary depth) the
+                    // per-entry range checks of the general path — two compares and a select each, 4 issue cycles apiece — are not needed.
+                    if (sp + 3 <= MR_ANY_LDS) {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const float tn = tn4[k], tf = tf4[k];
+                            const bool ok = tf > tn;
+                            if (COUNT && ref[k] != 0x7fffffff) c_boxes++;
+                            if (ok && ref[k] != 0x7fffffff) {
+                                if (next == 0x7fffffff) { next = ref[k]; next_tn = tn; }
+                                else {
+                                    int far = ref[k];
+                                    if (tn < next_tn) { far = next; next = ref[k]; next_tn = tn; }
+                                    lds_stack[sp * MR_TRACE_BLOCK] = (uint32_t)far; sp++;
+                                }
+                            }
+                        }
+                    } else {
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
                         const float tn = tn4[k], tf = tf4[k];
@@ -616,6 +634,7 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const
                                 if (sp < MR_STACK) sp++;
                             }
                         }
+                    }
                     }
                 }
                 bool done = hit;
