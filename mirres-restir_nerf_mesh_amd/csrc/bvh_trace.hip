@@ -451,7 +451,9 @@ MR_DEV bool tri_accepts_regs(float4 a, float4 b, float4 c, v3 ro, v3 d) {
     const v3 P = cross(d, E2);
     const float det = dot(E1, P);
     if (det > -1e-15f && det < 1e-15f) return false;
-    const float invDet = 1 / det;
+    // |det| >= 1e-15 here (or NaN / inf, which v_div_fixup_f32 treats as the compiler's division does): inside the range in which the short
+    // reciprocal returns the bits of 1 / det (device_math.hpp; mirres_selfcheck_arith) unless |det| > 2^102, i.e. triangle edges beyond 2^51
+    const float invDet = lean_rcp(det);
     const v3 Tv = ro - v0;
     const float u = dot(Tv, P) * invDet;
     if (u < 0 || u > 1) return false;

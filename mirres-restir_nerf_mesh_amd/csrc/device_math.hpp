@@ -24,6 +24,12 @@ namespace mr {
 #ifndef MR_LEAN_FP
 #define MR_LEAN_FP 0
 #endif
+// the short reciprocal under its own name, for single call sites of translation units that otherwise keep the compiler's operations
+MR_DEV float lean_rcp(float b) {
+    float r = __builtin_amdgcn_rcpf(b);
+    r = __builtin_fmaf(__builtin_fmaf(-b, r, 1.0f), r, r);
+    return __builtin_amdgcn_div_fixupf(__builtin_fmaf(__builtin_fmaf(-b, r, 1.0f), r, r), b, 1.0f);
+}
 #if MR_LEAN_FP
 MR_DEV float mr_div(float a, float b) {
     float r = __builtin_amdgcn_rcpf(b);
