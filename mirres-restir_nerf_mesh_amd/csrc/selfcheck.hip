@@ -1,7 +1,9 @@
 // selfcheck.hip — mirres_selfcheck_arith: the short division / square-root sequences of the shading kernels (device_math.hpp under MR_LEAN_FP)
 // against the compiler's IEEE-754 operations, exhaustively over significands (include/mirres.h). Same header, same flags as passes.hip / shading.hip:
 // what is checked is the code that ships, not a copy of it (scripts/ubench/div_exhaustive.hip is the stand-alone study that chose the sequences).
+#ifndef MR_LEAN_FP
 #define MR_LEAN_FP 1
+#endif
 #include "engine.hpp"
 #include "device_math.hpp"
 
