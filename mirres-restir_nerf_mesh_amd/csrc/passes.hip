@@ -38,6 +38,12 @@ int trace_any_queue_counted(const mirres_bvh* bvh, const Ray* rays, const uint32
 #ifndef MR_TILE_MAP
 #define MR_TILE_MAP 2
 #endif
+#ifndef MR_CHUNK_PX
+#define MR_CHUNK_PX 128
+#endif
+#ifndef MR_SRES_TILE
+#define MR_SRES_TILE 16
+#endif
 // MR_TILE_MAP 0: row-major tiles. 1: eight contiguous bands of tile rows, one per XCD. 2: 128 x 128 px chunks of tiles dealt to the XCDs in turn.
 // (Workgroups go to the eight XCDs round-robin by block index and every XCD has its own L2.)
 MR_DEV int tile_pixel(int fx, int fy, int tw, int N) {
@@ -50,7 +56,7 @@ MR_DEV int tile_pixel(int fx, int fy, int tw, int N) {
     if (t >= tiles_x * tiles_y) return N;
     tx = t % tiles_x; ty = t / tiles_x;
 #else
-    const int ch = 128 / tw, chunks_x = (tiles_x + ch - 1) / ch;
+    const int ch = MR_CHUNK_PX / tw, chunks_x = (tiles_x + ch - 1) / ch;
     const int j = (int)(blockIdx.x >> 3), chunk = (int)(blockIdx.x & 7u) + 8 * (j / (ch * ch)), w = j % (ch * ch);
     tx = (chunk % chunks_x) * ch + w % ch; ty = (chunk / chunks_x) * ch + w / ch;
     if (tx >= tiles_x || ty >= tiles_y) return N;
@@ -65,7 +71,7 @@ static int tile_grid(int fx, int fy, int tw) {
 #elif MR_TILE_MAP == 1
     return 8 * ((tiles_x * tiles_y + 7) / 8);
 #else
-    const int ch = 128 / tw, chunks = ((tiles_x + ch - 1) / ch) * ((tiles_y + ch - 1) / ch);
+    const int ch = MR_CHUNK_PX / tw, chunks = ((tiles_x + ch - 1) / ch) * ((tiles_y + ch - 1) / ch);
     return 8 * ((chunks + 7) / 8) * ch * ch;
 #endif
 }
@@ -423,17 +429,17 @@ __global__ void __launch_bounds__(MR_SGEN_BLOCK) k_spatial_gen(mirres_config_t C
 }
 
 template <int MR_MAX_NB>
-__global__ void __launch_bounds__(MR_BLOCK) k_spatial_resolve(mirres_config_t C, EnvD E, GBufD G, ResD R, ResD PR, const float* __restrict__ noff,
+__global__ void __launch_bounds__(MR_SRES_TILE * MR_SRES_TILE) k_spatial_resolve(mirres_config_t C, EnvD E, GBufD G, ResD R, ResD PR, const float* __restrict__ noff,
                                                               uint32_t frameIndex, int fx, int fy, int N, int y_off, const float* __restrict__ occ_own,
                                                               const int32_t* __restrict__ slot, const uint32_t* __restrict__ mask_in, const int32_t* __restrict__ hit,
                                                               uint32_t* __restrict__ reset_counter, uint32_t* __restrict__ reset_heads) {
     // mirres_render's chain: the shadow-ray launch of this pass has finished (stream order), so the ray counter and the traversal work heads it used
     // are zeroed here for the next sample's pass instead of by two separate fill launches per sample
     if (reset_heads && blockIdx.x == 0) {
-        for (int i = threadIdx.x; i < MR_WSET; i += MR_BLOCK) reset_heads[i] = 0u;
+        for (int i = threadIdx.x; i < MR_WSET; i += MR_SRES_TILE * MR_SRES_TILE) reset_heads[i] = 0u;
         if (threadIdx.x == 0) *reset_counter = 0u;
     }
-    const int pi = tile_pixel(fx, fy, 16, N);
+    const int pi = tile_pixel(fx, fy, MR_SRES_TILE, N);
     if (pi >= N) return;
     const GPix gc = load_gpix(G, pi);
     if ((occ_own ? occ_own[pi] : gc.occ) < 0.1f) { store_zero(R, pi); return; }
@@ -807,9 +813,9 @@ int mirres_restir_spatial(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_env
     int rc = trace_any(ctx, bvh, ctx->any_cap, s); if (rc) return rc;
     GBufD gr = gbufd(g);
     if (ctx->grec) gr.rec = reinterpret_cast<const float4*>(ctx->grec);   // mirres_render: same values, one 64-byte record per neighbour instead of three arrays
-    if (nb5) k_spatial_resolve<5><<<tile_grid(ctx->fx, ctx->fy, 16), MR_BLOCK, 0, s>>>(ctx->cfg, envh(env), gr, resd(res), resd(prev_res), noff, frameIndex, ctx->fx, ctx->fy, N, ctx->y_off, ctx->occ_own,
+    if (nb5) k_spatial_resolve<5><<<tile_grid(ctx->fx, ctx->fy, MR_SRES_TILE), MR_SRES_TILE * MR_SRES_TILE, 0, s>>>(ctx->cfg, envh(env), gr, resd(res), resd(prev_res), noff, frameIndex, ctx->fx, ctx->fy, N, ctx->y_off, ctx->occ_own,
                                                                                    ctx->slot_a, ctx->mask_a, ctx->any_hit, rc_, rh_);
-    else k_spatial_resolve<8><<<tile_grid(ctx->fx, ctx->fy, 16), MR_BLOCK, 0, s>>>(ctx->cfg, envh(env), gr, resd(res), resd(prev_res), noff, frameIndex, ctx->fx, ctx->fy, N, ctx->y_off, ctx->occ_own,
+    else k_spatial_resolve<8><<<tile_grid(ctx->fx, ctx->fy, MR_SRES_TILE), MR_SRES_TILE * MR_SRES_TILE, 0, s>>>(ctx->cfg, envh(env), gr, resd(res), resd(prev_res), noff, frameIndex, ctx->fx, ctx->fy, N, ctx->y_off, ctx->occ_own,
                                                                                ctx->slot_a, ctx->mask_a, ctx->any_hit, rc_, rh_);
     if (fold) ctx->chain_clean = true;
     MR_LAUNCH_CHECK("restir_spatial");
