@@ -369,6 +369,14 @@ __global__ void __launch_bounds__(256) k_pack4q(int T, const int32_t* __restrict
         for (int k = 0; k < 3; k++) { r.lo[k] = bx[k]; r.hi[k] = bx[3 + k]; }
         r.prim = prim;
         leaves[g] = r;
+        if (g == 0) {   // leaves[T]: the "null leaf" every unused child slot refers to — an inverted box no ray passes, so the traversal kernels need no
+                        // test for unused slots (their decoded boxes fail by themselves; should one ever pass, this record's exact test rejects it)
+            LeafRec z;
+#pragma unroll
+            for (int k = 0; k < 3; k++) { z.v0[k] = 0.f; z.e1[k] = 0.f; z.e2[k] = 0.f; z.lo[k] = 3.0e38f; z.hi[k] = -3.0e38f; }
+            z.prim = -1;
+            leaves[T] = z;
+        }
     }
     if (g >= T - 1) return;
     // children: start from the node's two LBVH children and keep opening the internal entry with the largest surface area until there are
@@ -403,7 +411,7 @@ __global__ void __launch_bounds__(256) k_pack4q(int T, const int32_t* __restrict
         const float st = q_step(E);
         uint32_t wlo = 0, whi = 0;
         for (int k = 0; k < 4; k++) {
-            uint32_t ql = 255u, qh = 0u;   // unused entry (never tested: ref = 0x7fffffff)
+            uint32_t ql = 255u, qh = 0u;   // unused entry: entry beyond exit by the whole node extent; refers to the null leaf
             if (k < nc) {
                 const float fl = fminf(fmaxf(floorf((cb[k][a] - lo) / st), 0.f), 255.f);
                 const float fh = fminf(fmaxf(ceilf((cb[k][3 + a] - lo) / st), 0.f), 255.f);
@@ -417,7 +425,7 @@ __global__ void __launch_bounds__(256) k_pack4q(int T, const int32_t* __restrict
         }
         n.org[a] = lo; (a == 0 ? n.step_x : a == 1 ? n.step_y : n.step_z) = st; n.qlo[a] = wlo; n.qhi[a] = whi;
     }
-    for (int k = 0; k < 4; k++) n.ref[k] = (k < nc) ? ((c[k] >= LEAF) ? ~(c[k] - LEAF) : c[k]) : 0x7fffffff;
+    for (int k = 0; k < 4; k++) n.ref[k] = (k < nc) ? ((c[k] >= LEAF) ? ~(c[k] - LEAF) : c[k]) : ~T;      // ~T: the null leaf (leaves[T])
     nodes4q[g] = n;
 }
 
@@ -434,8 +442,8 @@ __global__ void __launch_bounds__(256) k_top4q(int T, const Node4q* __restrict__
         for (int e = first + t; e < first + cnt; e += 256) {
             const int id = s_id[e];
             for (int k = 0; k < 4; k++) {
-                int r = id >= 0 ? nodes4q[id].ref[k] : 0x7fffffff;
-                s_id[4 * e + 1 + k] = (r >= 0 && r != 0x7fffffff) ? r : -1;
+                int r = id >= 0 ? nodes4q[id].ref[k] : -1;
+                s_id[4 * e + 1 + k] = r >= 0 ? r : -1;         // leaves (the null leaf among them) are negative
             }
         }
         first += cnt; cnt *= 4;
@@ -446,10 +454,10 @@ __global__ void __launch_bounds__(256) k_top4q(int T, const Node4q* __restrict__
         Node4q n;
         if (id >= 0) n = nodes4q[id];
         else { n.org[0] = n.org[1] = n.org[2] = 0.f; n.step_x = n.step_y = n.step_z = q_step(67u); for (int a = 0; a < 3; a++) { n.qlo[a] = 0xffffffffu; n.qhi[a] = 0u; }
-               for (int k = 0; k < 4; k++) n.ref[k] = 0x7fffffff; }
+               for (int k = 0; k < 4; k++) n.ref[k] = ~T; }
         for (int k = 0; k < 4; k++) {
             const int cslot = 4 * e + 1 + k;
-            const bool internal = id >= 0 && n.ref[k] >= 0 && n.ref[k] != 0x7fffffff;
+            const bool internal = id >= 0 && n.ref[k] >= 0;
             if (internal && cslot < TOPN) n.ref[k] = 0x20000000 | cslot;
         }
         top[e] = n;
@@ -508,7 +516,7 @@ int mirres_bvh_create(mirres_bvh_t** out, int max_tris) {
     MR_HIP(hipMalloc(&b->nodes, sizeof(WideNode) * T));
     MR_HIP(hipMalloc(&b->tris, sizeof(TriRec) * T));
     MR_HIP(hipMalloc(&b->nodes4q, sizeof(Node4q) * T));
-    MR_HIP(hipMalloc(&b->leaves, sizeof(LeafRec) * T));
+    MR_HIP(hipMalloc(&b->leaves, sizeof(LeafRec) * ((size_t)T + 1)));      // + the null leaf
     MR_HIP(hipMalloc(&b->top85q, sizeof(Node4q) * 85));
     MR_HIP(hipMalloc(&b->top341q, sizeof(Node4q) * 341));
     MR_HIP(hipMalloc(&b->root_box, sizeof(float) * 8));

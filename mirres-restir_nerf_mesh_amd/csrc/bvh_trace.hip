@@ -422,7 +422,7 @@ MR_DEV NodeCons node_cons(const uint4& h0, const uint4& h1, const uint4& h2, flo
     const float gx = __uint_as_float(h0.x), gy = __uint_as_float(h0.y), gz = __uint_as_float(h0.z);
     const float sx = __uint_as_float(h0.w), sy = __uint_as_float(h2.z), sz = __uint_as_float(h2.w);   // Node4q::step_x/y/z
     // near / far plane of each axis picked by the sign of the direction (nqx = the byte word holding the planes the ray meets first); an unused
-    // entry has lo = 255 > hi = 0 on every axis (entry beyond exit by the whole node extent) and is also excluded by its reference
+    // entry has lo = 255 > hi = 0 on every axis (entry beyond exit by the whole node extent) and refers to the null leaf
     c.nqx = ix >= 0.f ? h1.x : h1.w; c.fqx = ix >= 0.f ? h1.w : h1.x;
     c.nqy = iy >= 0.f ? h1.y : h2.x; c.fqy = iy >= 0.f ? h2.x : h1.y;
     c.nqz = iz >= 0.f ? h1.z : h2.y; c.fqz = iz >= 0.f ? h2.y : h1.z;
@@ -606,8 +606,8 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const
                         for (int k = 0; k < 4; k++) {
                             const float tn = tn4[k], tf = tf4[k];
                             const bool ok = tf > tn;
-                            if (COUNT && ref[k] != 0x7fffffff) c_boxes++;
-                            if (ok && ref[k] != 0x7fffffff) {
+                            if (COUNT && ref[k] != ~B.T) c_boxes++;
+                            if (ok) {
                                 if (next == 0x7fffffff) { next = ref[k]; next_tn = tn; }
                                 else {
                                     int far = ref[k];
@@ -623,10 +623,10 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const
                         // interior boxes only steer: `t_max > tn` (a pure cull; the leaf's exact test applies it) is left out — every compare is 4 issue
                         // cycles per wave (scripts/ubench/valu_rates.hip) and shadow rays towards the environment have no far limit to cull with.
                         // Unused slots (lo = 255 > hi = 0) fail the decoded test by themselves; with the margins a node thinner than 2^-19 of the
-                        // scene on all three axes could let one through, so the reference is looked at — on the rarely taken side of the branch.
+                        // scene on all three axes could let one through — it then leads to the null leaf (leaves[T]), whose exact box no ray passes.
                         const bool ok = tf > tn;
-                        if (COUNT && ref[k] != 0x7fffffff) c_boxes++;
-                        if (ok && ref[k] != 0x7fffffff) {
+                        if (COUNT && ref[k] != ~B.T) c_boxes++;
+                        if (ok) {
                             if (next == 0x7fffffff) { next = ref[k]; next_tn = tn; }
                             else {
                                 int far = ref[k];
@@ -797,8 +797,8 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_closest4(BvhView B, co
 #pragma unroll
                         for (int k = 0; k < 4; k++) {
                             float tn = tn4[k]; const float tf = tf4[k];
-                            if (COUNT && ref[k] != NONE) c_boxes++;
-                            if (tf > tn && closest > tn && ref[k] != NONE) {   // unused slots: see k_trace_any4q
+                            if (COUNT && ref[k] != ~B.T) c_boxes++;
+                            if (tf > tn && closest > tn) {   // unused slots: see k_trace_any4q
                                 int r = ref[k];
 #pragma unroll
                                 for (int q = 0; q < 4; q++) {
