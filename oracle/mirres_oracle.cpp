@@ -21,6 +21,7 @@ struct OrcFrame {
     const float* env_tex; int env_w, env_h;
     const float *pdf, *cdf, *mpdf, *mcdf;
     int max_bounce;
+    int neighbor_count, initial_light_samples, max_history;   // 0 = the reference's constant (orc_kernels.hpp Config); tests of the runtime configuration set them
 };
 struct OrcRes { float* light_data; float* light_pdf; int32_t* M; float* weight; };
 
@@ -28,7 +29,14 @@ static inline GBuf gbuf(const OrcFrame* f) { GBuf g; g.fx = f->fx; g.fy = f->fy;
 static inline Bvh bvh(const OrcFrame* f) { Bvh b; b.info = f->info; b.aabb = f->aabb; b.vert = f->vert; b.tri = f->tri; return b; }
 static inline Env env(const OrcFrame* f) { Env e; e.tex = f->env_tex; e.W = f->env_w; e.H = f->env_h; e.pdf = f->pdf; e.cdf = f->cdf; e.mpdf = f->mpdf; e.mcdf = f->mcdf; return e; }
 static inline Reservoirs res(const OrcRes* r) { Reservoirs o; o.light_data = r->light_data; o.light_pdf = r->light_pdf; o.M = r->M; o.weight = r->weight; return o; }
-static inline Config cfg(const OrcFrame* f) { Config c; if (f->max_bounce > 0) c.max_bounce = f->max_bounce; return c; }
+static inline Config cfg(const OrcFrame* f) {
+    Config c;
+    if (f->max_bounce > 0) c.max_bounce = f->max_bounce;
+    if (f->neighbor_count > 0) c.neighbor_count = f->neighbor_count;
+    if (f->initial_light_samples > 0) c.initial_light_samples = f->initial_light_samples;
+    if (f->max_history > 0) c.max_history = f->max_history;
+    return c;
+}
 
 #define ORC_PIXEL_LOOP(FX, FY, COUNTERS, BODY)                                            \
     {                                                                                     \

@@ -54,7 +54,8 @@ class Frame(C.Structure):
                 ("occ", f32p), ("pos", f32p), ("normal_depth", f32p), ("brdf", f32p), ("ray_dir", f32p),
                 ("info", i32p), ("aabb", f32p), ("vert", f32p), ("tri", i32p),
                 ("env_tex", f32p), ("env_w", C.c_int), ("env_h", C.c_int),
-                ("pdf", f32p), ("cdf", f32p), ("mpdf", f32p), ("mcdf", f32p), ("max_bounce", C.c_int)]
+                ("pdf", f32p), ("cdf", f32p), ("mpdf", f32p), ("mcdf", f32p), ("max_bounce", C.c_int),
+                ("neighbor_count", C.c_int), ("initial_light_samples", C.c_int), ("max_history", C.c_int)]
 
 
 class Res(C.Structure):
@@ -187,7 +188,8 @@ class Keep:
         a = _c(a, dt); self.refs.append(a); return a
 
 
-def make_frame(keep, fx, fy, occ, pos, normal_depth, brdf, ray_dir, bvh, vert, tri, env_tex, env_w, env_h, tables, max_bounce=2):
+def make_frame(keep, fx, fy, occ, pos, normal_depth, brdf, ray_dir, bvh, vert, tri, env_tex, env_w, env_h, tables, max_bounce=2,
+               neighbor_count=0, initial_light_samples=0, max_history=0):
     f = Frame()
     f.fx, f.fy = fx, fy
     f.occ = _p(keep(occ), f32p); f.pos = _p(keep(pos), f32p); f.normal_depth = _p(keep(normal_depth), f32p)
@@ -197,6 +199,7 @@ def make_frame(keep, fx, fy, occ, pos, normal_depth, brdf, ray_dir, bvh, vert, t
     f.env_tex = _p(keep(env_tex), f32p); f.env_w, f.env_h = env_w, env_h
     f.pdf, f.cdf, f.mpdf, f.mcdf = (_p(keep(t), f32p) for t in tables)
     f.max_bounce = max_bounce
+    f.neighbor_count, f.initial_light_samples, f.max_history = neighbor_count, initial_light_samples, max_history   # 0: the reference's constants
     return f
 
 

@@ -116,6 +116,49 @@ def test_reservoir_chain(env, oracle):
     assert np.abs(gc.cpu().numpy() - c).max() <= 1e-3   # north-star bar: 1e-3 per channel abs
 
 
+def test_reservoir_passes_with_other_constants(env, oracle, scene_mod):
+    """The ReSTIR constants are runtime configuration on both sides (mirres_config_t / the oracle's Config): 16 light candidates, a history cap of 7
+    and SEVEN spatial neighbours — more than five selects the second instantiation of the spatial kernels (k_spatial_gen<8> / k_spatial_resolve<8>),
+    which no other test reaches. initial -> temporal -> spatial against the oracle, as test_reservoir_chain does for the defaults."""
+    F, W, _, T, torch = env
+    from mirres_restir_nerf_mesh_amd import Resampling as RS, _lib, _ops
+    O = oracle; N = F.N
+    fr = O.make_frame(F.keep, F.fx, F.fy, F.occ, F.pos, F.normal_depth, F.brdf, F.ray_dir, (F.info, F.aabb), F.vert, F.tri, F.tex, F.Wc, F.Hc, F.tables,
+                      neighbor_count=7, initial_light_samples=16, max_history=7)
+    cfg = _lib.default_config(); cfg.neighbor_count, cfg.initial_light_samples, cfg.max_history = 7, 16, 7
+    m = _ops.Module("restir (non-default constants)", _ops.Context(F.fx, F.fy, cfg))
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    tile_ld, _, tile_pdf = O.light_tiles(fr, 2000)
+    g_tile_ld, g_tile_pdf = cu(tile_ld), cu(tile_pdf)
+    r0 = O.new_reservoirs(N); O.initial(fr, r0, tile_ld, tile_pdf, 2002)
+    g0 = _new_res(torch, N)
+    W.InitialResampling_(m, T["pos"], g0, T["tex"], F.Wc, F.Hc, F.fx, F.fy, 2002, T["occ"], T["nd"], T["brdf"], T["rd"], T["pdf"], T["cdf"], T["mpdf"], T["mcdf"],
+                         g_tile_ld, None, g_tile_pdf)
+    _cmp_res(g0, r0, "initial, 16 candidates")
+    ref_default = O.new_reservoirs(N); O.initial(F.frame, ref_default, tile_ld, tile_pdf, 2002)
+    assert not np.array_equal(ref_default[0], r0[0])          # the constant reaches the oracle: 32 candidates select differently
+    # temporal: several rounds so that the history cap binds (M <= 7 x current M)
+    prev = [a.copy() for a in r0]
+    for it in range(9):
+        cur = O.new_reservoirs(N); O.initial(fr, cur, tile_ld, tile_pdf, 2100 + 2 * it)
+        ref = [a.copy() for a in cur]
+        O.temporal(fr, ref, prev, F.occ, F.normal_depth, F.brdf, F.ray_dir, 2101 + 2 * it)
+        if it == 8:
+            g1 = tuple(cu(a.reshape(N, -1)) for a in cur); gp = tuple(cu(a.reshape(N, -1)) for a in prev)
+            RS.TemporalResampling(m, g1, gp, T["tex"], F.Wc, F.Hc, F.fx, F.fy, 2101 + 2 * it, T["occ"], T["nd"], T["brdf"], T["rd"], T["occ"], T["nd"], T["brdf"], T["rd"], None)
+            _cmp_res(g1, ref, "temporal, history cap 7")
+        prev = ref
+    assert prev[2].max() == 8 and prev[2].max() < 9           # 1 + min(M_prev, 7): the cap of 7 binds (the default of 20 would allow 10 here)
+    # spatial with seven neighbours
+    sref = O.new_reservoirs(N); cnt = np.zeros(4, np.uint64)
+    O.spatial(fr, sref, prev, F.noff, 2200, cnt)
+    s5 = O.new_reservoirs(N); O.spatial(F.frame, s5, prev, F.noff, 2200, np.zeros(4, np.uint64))
+    assert not np.array_equal(s5[3], sref[3])                 # seven neighbours merge differently from five
+    gs = _new_res(torch, N); gprev = tuple(cu(a.reshape(N, -1)) for a in prev)
+    W.SpatialResampling_(m, T["pos"], gs, gprev, T["noff"], T["tex"], F.Wc, F.Hc, F.fx, F.fy, 2200, T["occ"], T["nd"], T["brdf"], T["rd"])
+    _cmp_res(gs, sref, "spatial, 7 neighbours")
+
+
 def test_path_vertices(env, oracle):
     """new_dir + two bounce kernels on oracle state; hit / stop flags exact, radiance within tolerance."""
     F, W, mods, T, torch = env
