@@ -272,6 +272,18 @@ int mirres_render_finish(mirres_ctx_t* ctx, const mirres_render_args_t* a, float
  * out[0] = pairs tested, out[1..3] = mismatches of mr_div, mr_rcp, mr_sqrt (all must be 0). Blocks until done.                          */
 int mirres_selfcheck_arith(int log2_b, unsigned long long out[4], void* stream);
 
+/* The transcendental functions of the path on the device (no reference counterpart: the reference calls CUDA's math library in
+ * utils/lightDi.slang:119-132,181-209,312-330, utils/brdf.slang:76-124, EAWDenoise.slang:50-302, res.slang:53-61; here they are the fixed
+ * arithmetic of include/mirres_fmath.h, the same header the CPU oracle includes).  fn: 0 sin, 1 cos, 2 acos, 3 exp, 4 exp2, 5 pow5,
+ * 6 x^8, 7 x^128, 8 sigmoid (one argument, `a`); 16 atan2(a, b); 17 b / a with the short division of the shading kernels (mr_div);
+ * 18 the short square root (mr_sqrt).
+ * mirres_fmath_eval: out[i] = fn(a[i], b[i]) for n device floats (b may be NULL for one-argument functions).
+ * mirres_fmath_checksum: over the argument bit patterns first .. first + count - 1 (for fn >= 16 the second argument is a fixed hash of the
+ * first), *out = sum of result_bits * (2 * argument_bits + 1) mod 2^64 with NaN results canonical — order-free, so the host can form the same
+ * sum from the same header (oracle/fmath_check.cpp) and tests/test_gpu_fmath.py can compare device and host over all 2^32 arguments. Blocks. */
+int mirres_fmath_eval(int fn, const float* a, const float* b, float* out, long long n, void* stream);
+int mirres_fmath_checksum(int fn, unsigned int first, unsigned long long count, unsigned long long* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

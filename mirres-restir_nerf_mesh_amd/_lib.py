@@ -112,6 +112,8 @@ SIGNATURES = {
     "mirres_render_bwd": (C.c_int, [vp, PARGS, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]),
     "mirres_render_finish": (C.c_int, [vp, PARGS, C.POINTER(vp), vp]),
     "mirres_selfcheck_arith": (C.c_int, [C.c_int, C.POINTER(C.c_uint64), vp]),
+    "mirres_fmath_eval": (C.c_int, [C.c_int, vp, vp, vp, C.c_longlong, vp]),
+    "mirres_fmath_checksum": (C.c_int, [C.c_int, C.c_uint, C.c_uint64, C.POINTER(C.c_uint64), vp]),
 }
 
 

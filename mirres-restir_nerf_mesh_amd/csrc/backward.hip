@@ -100,7 +100,7 @@ MR_DEV void shade_dual(v3 n_, v3 rd, v3 kd_, float rough_, float metal_, v3 dir,
     if (alpha.v < 0.01f * 0.01f) alpha = mk<NP>(0.f);
     float pD = luminance(kd_) * (1.f - metal_);
     float cosv = dot(-rd, n_);
-    float p5 = powf(fmaxf(1 - cosv, 0), 5);
+    float p5 = mrf_pow5(fmaxf(1 - cosv, 0));
     v3 sp_ = V3(0.04f) * (1.0f - metal_) + kd_ * metal_;
     float pS = luminance(V3(sp_.x + (1 - sp_.x) * p5, sp_.y + (1 - sp_.y) * p5, sp_.z + (1 - sp_.z) * p5)) * (metal_ + (1.f - metal_));
     D3<NP> dv = mk3<NP>(V3(0.f)), sv = mk3<NP>(V3(0.f));
@@ -328,7 +328,7 @@ __global__ void __launch_bounds__(MR_BLOCK) k_matnet_bwd(MatNetB M, GridLevelsB 
         for (int o = 0; o < 32; o++) { float acc = 0.f; for (int k = 0; k < 32; k++) acc = fmaf(h1[k], sw1[o * 32 + k], acc); h2[o] = fmaxf(acc, 0.f); }
         for (int o = 0; o < 6; o++) { float acc = 0.f; for (int k = 0; k < 32; k++) acc = fmaf(h2[k], sw2[o * 32 + k], acc); z2[o] = acc; }
         // backward through the MLP (a dead lane carries zeros)
-        for (int o = 0; o < 6; o++) { float sg = 1.0f / (1.0f + expf(-z2[o])); gz2[o] = live ? gout[6 * (size_t)i + o] * (M.mx[o] - M.mn[o]) * sg * (1.f - sg) : 0.f; }
+        for (int o = 0; o < 6; o++) { float sg = mrf_sigmoid(z2[o]); gz2[o] = live ? gout[6 * (size_t)i + o] * (M.mx[o] - M.mn[o]) * sg * (1.f - sg) : 0.f; }
         for (int k = 0; k < 32; k++) { float acc = 0.f; for (int o = 0; o < 6; o++) acc += gz2[o] * sw2[o * 32 + k]; gh2[k] = h2[k] > 0.f ? acc : 0.f; }
         for (int k = 0; k < 32; k++) { float acc = 0.f; for (int o = 0; o < 32; o++) acc += gh2[o] * sw1[o * 32 + k]; gh1[k] = h1[k] > 0.f ? acc : 0.f; }
         for (int k = 0; k < 32; k++) { float acc = 0.f; for (int o = 0; o < 32; o++) acc += gh1[o] * sw0[o * 32 + k]; ga0[k] = acc; }

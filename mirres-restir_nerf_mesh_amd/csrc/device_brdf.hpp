@@ -17,9 +17,9 @@ MR_DEV Basis basis(v3 N) { Basis b; b.B = perp_stark(N); b.T = cross(b.B, N); b.
 MR_DEV v3 to_local(const Basis& b, v3 w) { return V3(dot(b.B, w), dot(b.T, w), dot(b.N, w)); }
 MR_DEV v3 to_global(const Basis& b, v3 w) { return b.B * w.x + b.T * w.y + b.N * w.z; }
 
-// evalFresnelSchlick's pow(max(1-c,0),5) as three multiplications: within 2 ulp of powf (itself not bit-identical between ocml and glibc),
-// ~40 VALU instructions cheaper per BRDF evaluation (33 evaluations per pixel in the initial pass).
-MR_DEV float pow5(float c) { const float x = fmaxf(1 - c, 0); const float x2 = x * x; return x2 * x2 * x; }
+// evalFresnelSchlick's pow(max(1-c,0),5): mrf_pow5 (include/mirres_fmath.h: six operations, <= 2 ulp, the same bits on the host) instead of a library powf
+// (~40 VALU instructions; 33 evaluations per pixel in the initial pass).
+MR_DEV float pow5(float c) { return mrf_pow5(fmaxf(1 - c, 0)); }
 MR_DEV float schlick(float f0, float f90, float c) { return f0 + (f90 - f0) * pow5(c); }
 MR_DEV v3 schlick3(v3 f0, float f90, float c) { float p = pow5(c); return V3(f0.x + (f90 - f0.x) * p, f0.y + (f90 - f0.y) * p, f0.z + (f90 - f0.z) * p); }
 MR_DEV float lambda_ggx(float a2, float c) {  // brdf.slang:34-40
@@ -43,7 +43,8 @@ MR_DEV v2 disk_concentric(float ux, float uy) {  // brdf.slang:76-96
     float phi, r;
     if (fabsf(ux) > fabsf(uy)) { r = ux; phi = mr_div(uy, ux) * 0.785398163397448309616f; }
     else { r = uy; phi = 1.57079632679489661923f - mr_div(ux, uy) * 0.785398163397448309616f; }
-    return V2(r * cosf(phi), r * sinf(phi));
+    float sp, cp; mrf_sincos(phi, &sp, &cp);
+    return V2(r * cp, r * sp);
 }
 MR_DEV v3 cosine_hemisphere(float ux, float uy, float& pdf) {
     v2 d = disk_concentric(ux, uy);
@@ -58,7 +59,8 @@ MR_DEV v3 sample_ggx_ndf(float alpha, float ux, float uy, float& pdf) {  // brdf
     float c = mr_rcp(mr_sqrt(1 + tan2));
     float r = mr_sqrt(fmaxf(1 - c * c, 0));
     pdf = pdf_ggx_ndf(alpha, c);
-    return V3(cosf(phi) * r, sinf(phi) * r, c);
+    float sp, cp; mrf_sincos(phi, &sp, &cp);
+    return V3(cp * r, sp * r, c);
 }
 
 namespace rtarget {  // utils/brdf.slang:155-212, res.slang:70-91

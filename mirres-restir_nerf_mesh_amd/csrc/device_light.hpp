@@ -23,10 +23,10 @@ MR_DEV v3 eval_bi(const float* __restrict__ tex, float u_, float v_, int width, 
 
 // env_le (lightDi.slang:119-132)
 MR_DEV v3 env_le(v3 dir, const float* __restrict__ tex, int width, int height) {
-    float theta = acosf(dir.y);
-    float sin_theta = sinf(theta);
+    float theta = mrf_acos(dir.y);
+    float sin_theta = mrf_sin(theta);
     if (fabsf(sin_theta) < 1e-4f) return V3(0.f);
-    float phi = atan2f(dir.z, dir.x);
+    float phi = mrf_atan2(dir.z, dir.x);
     if (phi < 0) phi += 6.2831853f;
     return eval_bi(tex, phi * 0.1591549f, 1 - theta * 0.31830988f, width, height);
 }
@@ -35,10 +35,10 @@ MR_DEV v3 env_radiance(const EnvD& E, v3 L) { return env_le(ngp_dir(L), E.tex, E
 
 // bilinear footprint of env_le(dir) for the backward scatter: 4 texel indices + weights; false at the poles
 MR_DEV bool env_le_footprint(v3 dir, int width, int height, int idx[4], float w[4]) {
-    float theta = acosf(dir.y);
-    float sin_theta = sinf(theta);
+    float theta = mrf_acos(dir.y);
+    float sin_theta = mrf_sin(theta);
     if (fabsf(sin_theta) < 1e-4f) return false;
-    float phi = atan2f(dir.z, dir.x);
+    float phi = mrf_atan2(dir.z, dir.x);
     if (phi < 0) phi += 6.2831853f;
     float x = (phi * 0.1591549f) * width - 0.5f, y = (1 - theta * 0.31830988f) * height - 0.5f;
     int x0 = (int)x, y0 = (int)y;
@@ -76,7 +76,8 @@ MR_DEV bool sample_li(const EnvD& E, float r0, float r1, v3& dir, float& out_pdf
     int r2 = clampi(row, 0, h_ - 1), c2 = clampi(col, 0, w_ - 1);
     float pdf = E.pdf[r2 * w_ + c2] * E.mpdf[r2] * w_ * h_;
     float theta = uy * PI, phi = ux * 2 * PI;
-    float cos_theta = cosf(theta), cos_phi = cosf(phi), sin_theta = sinf(theta), sin_phi = sinf(phi);
+    float cos_theta, cos_phi, sin_theta, sin_phi;
+    mrf_sincos(theta, &sin_theta, &cos_theta); mrf_sincos(phi, &sin_phi, &cos_phi);
     dir = V3(sin_theta * cos_phi, cos_theta, sin_theta * sin_phi);
     if (fabsf(sin_theta) >= 1e-4f) pdf = mr_div(pdf, 2 * PI * PI * sin_theta);
     else pdf = 0.0f;
@@ -89,10 +90,10 @@ MR_DEV bool sample_li(const EnvD& E, float r0, float r1, v3& dir, float& out_pdf
 MR_DEV float pdf_li(const EnvD& E, v3 dir) {
     const float PI = 3.141592653589793f;
     v3 w = V3(clampf(dir.x, -1.0f, 1.0f), clampf(dir.y, -1.0f, 1.0f), clampf(dir.z, -1.0f, 1.0f));
-    float theta = acosf(w.y);
-    float sin_theta = sinf(theta);
+    float theta = mrf_acos(w.y);
+    float sin_theta = mrf_sin(theta);
     if (fabsf(sin_theta) < 1e-4f) return 0;
-    float phi = atan2f(w.z, w.x);
+    float phi = mrf_atan2(w.z, w.x);
     if (phi < 0) phi += 6.2831853f;
     int col = (int)(phi * 0.1591549f * E.W);
     int row = (int)(theta * 0.31830988f * E.H);

@@ -53,6 +53,14 @@ MR_DEV float mr_div(float a, float b) { return a / b; }
 MR_DEV float mr_rcp(float b) { return 1.0f / b; }
 MR_DEV float mr_sqrt(float x) { return sqrtf(x); }
 #endif
+}  // namespace mr
+
+// The transcendental functions of the path (acos, atan2, sin, cos, exp, exp2, integer powers): fixed sequences of IEEE operations shared with the
+// host-side checker of the tests — include/mirres_fmath.h.  Its square root (acos: argument in [2^-25, 1/2] or zero) may be the short sequence above: same bits there.
+#define MRF_SQRT(x) ::mr::mr_sqrt(x)
+#include "mirres_fmath.h"
+
+namespace mr {
 
 struct v2 { float x, y; };
 struct v3 { float x, y, z; };

@@ -26,8 +26,8 @@ __global__ void __launch_bounds__(MR_BLOCK) k_dump_light_rgb(const float* __rest
     if (l >= L) return;
     const float PI = 3.14159265358979323846f;
     const v3 d = ld3(dirs, l);
-    const float phi = acosf(d.z) - 1e-6f;
-    const float theta = atan2f(d.y, d.x);
+    const float phi = mrf_acos(d.z) - 1e-6f;
+    const float theta = mrf_atan2(d.y, d.x);
     const float qy = (phi / PI) * 2 - 1;
     const float qx = -theta / PI;
     const float x = ((qx + 1) * W - 1) / 2, y = ((qy + 1) * H - 1) / 2;
@@ -79,7 +79,7 @@ MR_DEV v3 ggx_specular(v3 normal, v3 pts2c, v3 pts2l, v3 rough, v3 fresnel) {
     const float NoH = fminf(fmaxf((N.x * Hh.x + N.y * Hh.y) + N.z * Hh.z, 1e-6f), 1.f);
     const float VoH = fminf(fmaxf((Vd.x * Hh.x + Vd.y * Hh.y) + Vd.z * Hh.z, 1e-6f), 1.f);
     const float FMi = ((-5.55473f) * VoH - 6.98316f) * VoH;
-    const float p2 = powf(2.0f, FMi);
+    const float p2 = mrf_exp2(FMi);
     const float r3[3] = {rough.x, rough.y, rough.z}, f3[3] = {fresnel.x, fresnel.y, fresnel.z};
     float out[3];
 #pragma unroll

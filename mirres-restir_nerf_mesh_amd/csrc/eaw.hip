@@ -30,13 +30,13 @@ __global__ void __launch_bounds__(MR_BLOCK) k_eaw(int fx, int fy, int step, floa
         const v3 ctmp = ld3(color, qi);
         v3 t = cval - ctmp;
         float dist2 = dot(t, t);
-        const float c_w = fminf(expf(-(dist2) / c_phi), 1.0f);
+        const float c_w = fminf(mrf_exp(-(dist2) / c_phi), 1.0f);
         t = nval - ld3(normal, qi);
         dist2 = fmaxf(dot(t, t), 0.0f);
-        const float n_w = fminf(expf(-(dist2) / n_phi), 1.0f);
+        const float n_w = fminf(mrf_exp(-(dist2) / n_phi), 1.0f);
         t = pval - ld3(pos, qi);
         dist2 = fmaxf(dot(t, t), 0.0f);
-        const float p_w = fminf(expf(-(dist2) / p_phi), 1.0f);
+        const float p_w = fminf(mrf_exp(-(dist2) / p_phi), 1.0f);
         const float weight = c_w * n_w * p_w;
         sum = sum + ctmp * weight * kw;
         cum_w += weight * kw;
@@ -72,15 +72,15 @@ __global__ void __launch_bounds__(MR_BLOCK) k_eaw5(int fx, int fy, int step, flo
         const float kw = b3(i % 5) * b3(i / 5) / 256.0f;
         v3 t = nval - ld3(normal, qi);
         float dist2 = fmaxf(dot(t, t), 0.0f);
-        const float n_w = fminf(expf(-(dist2) / n_phi), 1.0f);
+        const float n_w = fminf(mrf_exp(-(dist2) / n_phi), 1.0f);
         t = pval - ld3(pos, qi);
         dist2 = fmaxf(dot(t, t), 0.0f);
-        const float p_w = fminf(expf(-(dist2) / p_phi), 1.0f);
+        const float p_w = fminf(mrf_exp(-(dist2) / p_phi), 1.0f);
 #pragma unroll
         for (int b = 0; b < 5; b++) {
             const v3 ctmp = ld3(B.in[b], qi);
             const v3 tc = cval[b] - ctmp;
-            const float c_w = fminf(expf(-(dot(tc, tc)) / c_phi), 1.0f);
+            const float c_w = fminf(mrf_exp(-(dot(tc, tc)) / c_phi), 1.0f);
             const float weight = c_w * n_w * p_w;
             sum[b] = sum[b] + ctmp * weight * kw;
             cum_w[b] += weight * kw;
@@ -118,9 +118,9 @@ __global__ void __launch_bounds__(MR_BLOCK) k_eaw_bwd(int fx, int fy, int step, 
         const size_t qi = (size_t)uy * fx + ux;
         const float kw = b3(i % 5) * b3(i / 5) / 256.0f;
         const v3 ctmp = ld3(color, qi);
-        v3 t = cval - ctmp; const float cw = fminf(expf(-dot(t, t) / c_phi), 1.0f);
-        t = nval - ld3(normal, qi); const float nw = fminf(expf(-fmaxf(dot(t, t), 0.f) / n_phi), 1.0f);
-        t = pval - ld3(pos, qi); const float pw = fminf(expf(-fmaxf(dot(t, t), 0.f) / p_phi), 1.0f);
+        v3 t = cval - ctmp; const float cw = fminf(mrf_exp(-dot(t, t) / c_phi), 1.0f);
+        t = nval - ld3(normal, qi); const float nw = fminf(mrf_exp(-fmaxf(dot(t, t), 0.f) / n_phi), 1.0f);
+        t = pval - ld3(pos, qi); const float pw = fminf(mrf_exp(-fmaxf(dot(t, t), 0.f) / p_phi), 1.0f);
         const float w = cw * nw * pw;
         S = S + ctmp * w * kw; W += w * kw;
     }
@@ -134,9 +134,9 @@ __global__ void __launch_bounds__(MR_BLOCK) k_eaw_bwd(int fx, int fy, int step, 
         const size_t qi = (size_t)uy * fx + ux;
         const float kw = b3(i % 5) * b3(i / 5) / 256.0f;
         const v3 ctmp = ld3(color, qi);
-        const v3 tc = cval - ctmp; const float cw = fminf(expf(-dot(tc, tc) / c_phi), 1.0f);
-        const v3 tn = nval - ld3(normal, qi); const float nw = fminf(expf(-fmaxf(dot(tn, tn), 0.f) / n_phi), 1.0f);
-        const v3 tp = pval - ld3(pos, qi); const float pw = fminf(expf(-fmaxf(dot(tp, tp), 0.f) / p_phi), 1.0f);
+        const v3 tc = cval - ctmp; const float cw = fminf(mrf_exp(-dot(tc, tc) / c_phi), 1.0f);
+        const v3 tn = nval - ld3(normal, qi); const float nw = fminf(mrf_exp(-fmaxf(dot(tn, tn), 0.f) / n_phi), 1.0f);
+        const v3 tp = pval - ld3(pos, qi); const float pw = fminf(mrf_exp(-fmaxf(dot(tp, tp), 0.f) / p_phi), 1.0f);
         const float w = cw * nw * pw;
         v3 g_ci = gS * (w * kw);                       // through the tap value in S
         const float g_w = (dot(gS, ctmp) + gW) * kw;   // through w_i in S and W
@@ -175,9 +175,9 @@ __global__ void __launch_bounds__(MR_BLOCK) k_eaw_bwd_sums(int fx, int fy, int s
         const size_t qi = (size_t)uy * fx + ux;
         const float kw = b3(i % 5) * b3(i / 5) / 256.0f;
         const v3 ctmp = ld3(color, qi);
-        v3 t = cval - ctmp; const float cw = fminf(expf(-dot(t, t) / c_phi), 1.0f);
-        t = nval - ld3(normal, qi); const float nw = fminf(expf(-fmaxf(dot(t, t), 0.f) / n_phi), 1.0f);
-        t = pval - ld3(pos, qi); const float pw = fminf(expf(-fmaxf(dot(t, t), 0.f) / p_phi), 1.0f);
+        v3 t = cval - ctmp; const float cw = fminf(mrf_exp(-dot(t, t) / c_phi), 1.0f);
+        t = nval - ld3(normal, qi); const float nw = fminf(mrf_exp(-fmaxf(dot(t, t), 0.f) / n_phi), 1.0f);
+        t = pval - ld3(pos, qi); const float pw = fminf(mrf_exp(-fmaxf(dot(t, t), 0.f) / p_phi), 1.0f);
         const float w = cw * nw * pw;
         S = S + ctmp * w * kw; W += w * kw;
     }
@@ -205,9 +205,9 @@ __global__ void __launch_bounds__(MR_BLOCK) k_eaw_bwd_gather(int fx, int fy, int
         if (!fg && !rfg) continue;
         const float kw = b3(i % 5) * b3(i / 5) / 256.0f;
         const v3 cr = ld3(color, ri);
-        const v3 tc = cval - cr; const float cw = fminf(expf(-dot(tc, tc) / c_phi), 1.0f);
-        const v3 tn = nval - ld3(normal, ri); const float nw = fminf(expf(-fmaxf(dot(tn, tn), 0.f) / n_phi), 1.0f);
-        const v3 tp = pval - ld3(pos, ri); const float pw = fminf(expf(-fmaxf(dot(tp, tp), 0.f) / p_phi), 1.0f);
+        const v3 tc = cval - cr; const float cw = fminf(mrf_exp(-dot(tc, tc) / c_phi), 1.0f);
+        const v3 tn = nval - ld3(normal, ri); const float nw = fminf(mrf_exp(-fmaxf(dot(tn, tn), 0.f) / n_phi), 1.0f);
+        const v3 tp = pval - ld3(pos, ri); const float pw = fminf(mrf_exp(-fmaxf(dot(tp, tp), 0.f) / p_phi), 1.0f);
         const float w = cw * nw * pw;
         if (fg) {      // p as the centre, r as its tap: the terms k_eaw_bwd keeps in g_c0 / g_n0 / g_p0
             const float g_w = (dot(gS_p, cr) + gW_p) * kw;
@@ -275,9 +275,9 @@ __global__ void __launch_bounds__(MR_BLOCK) k_bilateral(int fx, int fy, float si
             const v3 t_nrm = V3(ta.w, tb.x, tb.y);
             const float dist_sqr = (float)(dx * dx + dy * dy);
             const float dist = sqrtf(dist_sqr);
-            const float w_xy = expf(-dist_sqr / (2.0f * variance));
-            const float w_normal = powf(fminf(fmaxf(dot(t_nrm, c_nrm), MR_BIL_EPS), 1.0f), 128.0f);
-            const float w_depth = expf(-(fabsf(tb.z - c_z) / fmaxf((MODE == 2 ? tb.w : c_dz) * dist, MR_BIL_EPS)));
+            const float w_xy = mrf_exp(-dist_sqr / (2.0f * variance));
+            const float w_normal = mrf_pow2k(fminf(fmaxf(dot(t_nrm, c_nrm), MR_BIL_EPS), 1.0f), 7);
+            const float w_depth = mrf_exp(-(fabsf(tb.z - c_z) / fmaxf((MODE == 2 ? tb.w : c_dz) * dist, MR_BIL_EPS)));
             const float w = w_xy * w_normal * w_depth;
             if (MODE == 2) acc = acc + V3(grad_out4[4 * qi], grad_out4[4 * qi + 1], grad_out4[4 * qi + 2]) * w;
             else { acc = acc + V3(ta.x, ta.y, ta.z) * w; accum_w += w; }
@@ -324,7 +324,7 @@ __global__ void __launch_bounds__(MR_BLOCK) k_bilateral5(int fx, int fy, float s
         const int dy = i / wdt - rad, dx = i % wdt - rad;
         const float dist_sqr = (float)(dx * dx + dy * dy);
         s_dist[i] = sqrtf(dist_sqr);
-        s_wxy[i] = expf(-dist_sqr / (2.0f * variance));
+        s_wxy[i] = mrf_exp(-dist_sqr / (2.0f * variance));
     }
     __syncthreads();
     const int tiles_x = (fx + 15) >> 4;
@@ -347,8 +347,8 @@ __global__ void __launch_bounds__(MR_BLOCK) k_bilateral5(int fx, int fy, float s
             const float4* __restrict__ t = rec + 5 * ((size_t)yy * fx + xx);
             const float4 t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3], t4 = t[4];
             const int li = (dy + rad) * wdt + (dx + rad);
-            const float w_normal = powf(fminf(fmaxf(dot(V3(t0.x, t0.y, t0.z), c_nrm), MR_BIL_EPS), 1.0f), 128.0f);
-            const float w_depth = expf(-(fabsf(t0.w - c_z) / fmaxf(c_dz * s_dist[li], MR_BIL_EPS)));
+            const float w_normal = mrf_pow2k(fminf(fmaxf(dot(V3(t0.x, t0.y, t0.z), c_nrm), MR_BIL_EPS), 1.0f), 7);
+            const float w_depth = mrf_exp(-(fabsf(t0.w - c_z) / fmaxf(c_dz * s_dist[li], MR_BIL_EPS)));
             const float w = s_wxy[li] * w_normal * w_depth;
             acc[0] = acc[0] + V3(t1.y, t1.z, t1.w) * w; acc[1] = acc[1] + V3(t2.x, t2.y, t2.z) * w; acc[2] = acc[2] + V3(t2.w, t3.x, t3.y) * w;
             acc[3] = acc[3] + V3(t3.z, t3.w, t4.x) * w; acc[4] = acc[4] + V3(t4.y, t4.z, t4.w) * w;

@@ -68,7 +68,7 @@ MR_DEV void mlp_point(const float* sw0, const float* sw1, const float* sw2, cons
     for (int o = 0; o < 6; o++) { float acc = 0.f;
 #pragma unroll
         for (int k = 0; k < 32; k++) acc = fmaf(a[k], sw2[o * 32 + k], acc);
-        float s = 1.0f / (1.0f + expf(-acc));
+        float s = mrf_sigmoid(acc);
         out[o] = s * (M.mx[o] - M.mn[o]) + M.mn[o]; }
 }
 MR_DEV void normalise_pos(const MatNetD& M, const float* __restrict__ pos, size_t i, float x[3]) {

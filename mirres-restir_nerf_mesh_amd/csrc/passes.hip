@@ -139,10 +139,11 @@ __global__ void __launch_bounds__(MR_BLOCK) k_env_weight(const float* __restrict
     const float PI = 3.141592653589793f;
     int h = i / W, w = i % W;
     float v = (h + .5f) / H;
-    float sin_theta = sinf(PI * v);
+    float sin_theta = mrf_sin(PI * v);
     float ux = (w + .5f) / W;
     float theta = v * PI, phi = ux * 2 * PI;
-    float cos_theta = cosf(theta), cos_phi = cosf(phi), sin_theta_dir = sinf(theta), sin_phi = sinf(phi);
+    float cos_theta, cos_phi, sin_theta_dir, sin_phi;
+    mrf_sincos(theta, &sin_theta_dir, &cos_theta); mrf_sincos(phi, &sin_phi, &cos_phi);
     v3 raw = V3(sin_theta_dir * cos_phi, cos_theta, sin_theta_dir * sin_phi);
     float wv = luminance(env_le(ngp_dir(raw), tex, W, H));
     pdf[i] = wv * sin_theta;
@@ -349,7 +350,7 @@ __global__ void __launch_bounds__(MR_BLOCK) k_temporal(mirres_config_t C, EnvD E
 }
 
 // ---------------------------------------------------------------- spatial resampling (SpatialResampling.slang:178-322)
-MR_DEV float m_factor(float q0, float q1) { return q0 == 0.f ? 1.f : clampf(powf(fminf(mr_div(q1, q0), 1.f), 8.f), 0.f, 1.f); }
+MR_DEV float m_factor(float q0, float q1) { return q0 == 0.f ? 1.f : clampf(mrf_pow2k(fminf(mr_div(q1, q0), 1.f), 3), 0.f, 1.f); }
 MR_DEV float pairwise_mis(float q0, float q1, float N0, float N1) { return (q1 == 0.f) ? 0.f : mr_div(N0 * q0, q0 * N0 + q1 * N1); }
 
 // neighbour acceptance in the reference's order of `continue`s (:236-258): in bounds -> normal / depth similar -> neighbour reservoir M != 0 ->

@@ -211,11 +211,11 @@ void orc_bilateral(int fx, int fy, float sigma, const float* col, const float* n
                     if (yy < 0 || xx < 0 || yy >= fy || xx >= fx) continue;
                     const size_t qi = (size_t)yy * fx + xx;
                     const float dist_sqr = (float)(dx * dx + dy * dy), dist = std::sqrt(dist_sqr);
-                    const float w_xy = std::exp(-dist_sqr / (2.0f * variance));
+                    const float w_xy = mrf_exp(-dist_sqr / (2.0f * variance));
                     const float nd = (nrm[3 * qi] * nrm[3 * pi] + nrm[3 * qi + 1] * nrm[3 * pi + 1]) + nrm[3 * qi + 2] * nrm[3 * pi + 2];
-                    const float w_normal = std::pow(std::min(std::max(nd, 0.0001f), 1.0f), 128.0f);
+                    const float w_normal = mrf_pow2k(std::min(std::max(nd, 0.0001f), 1.0f), 7);
                     const float den = std::max((mode == 1 ? zdz[2 * qi + 1] : cdz) * dist, 0.0001f);
-                    const float w_depth = std::exp(-(std::fabs(zdz[2 * qi] - cz) / den));
+                    const float w_depth = mrf_exp(-(std::fabs(zdz[2 * qi] - cz) / den));
                     const float w = w_xy * w_normal * w_depth;
                     if (mode == 1) { ax += grad4[4 * qi] * w; ay += grad4[4 * qi + 1] * w; az += grad4[4 * qi + 2] * w; }
                     else { ax += col[3 * qi] * w; ay += col[3 * qi + 1] * w; az += col[3 * qi + 2] * w; aw += w; }

@@ -20,8 +20,8 @@ u64p = C.POINTER(C.c_ulonglong)
 
 def build(force=False):
     so = os.path.join(_HERE, "liborc.so")
-    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".cpp", ".hpp"))]
-    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".cpp", ".hpp"))] + [os.path.join(_HERE, "..", "include", "mirres_fmath.h")]
+    if force or not os.path.exists(so) or not os.path.exists(os.path.join(_HERE, "libfmathcheck.so")) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
     return so
 

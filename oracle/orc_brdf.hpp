@@ -21,9 +21,9 @@ static inline f3 perp_stark(f3 u) {  // brdf.slang:1-13
 static inline f3 to_local(f3 w, f3 N) { f3 B = perp_stark(N); f3 T = cross(B, N); return mk3(dot(B, w), dot(T, w), dot(N, w)); }
 static inline f3 to_global(f3 w, f3 N) { f3 B = perp_stark(N); f3 T = cross(B, N); return B * w.x + T * w.y + N * w.z; }
 
-static inline float fresnel_schlick(float f0, float f90, float c) { return f0 + (f90 - f0) * powf(fmaxf(1 - c, 0), 5); }
+static inline float fresnel_schlick(float f0, float f90, float c) { return f0 + (f90 - f0) * mrf_pow5(fmaxf(1 - c, 0)); }
 static inline f3 fresnel_schlick3(f3 f0, float f90, float c) {
-    float p = powf(fmaxf(1 - c, 0), 5);
+    float p = mrf_pow5(fmaxf(1 - c, 0));
     return mk3(f0.x + (f90 - f0.x) * p, f0.y + (f90 - f0.y) * p, f0.z + (f90 - f0.z) * p);
 }
 static inline float lambda_ggx(float alphaSqr, float c) {  // brdf.slang:34-40
@@ -55,7 +55,7 @@ static inline f2 sample_disk_concentric(f2 u) {  // brdf.slang:76-96
     float phi, r;
     if (fabsf(u.x) > fabsf(u.y)) { r = u.x; phi = (u.y / u.x) * M_PI_4_F; }
     else { r = u.y; phi = M_PI_2_F - (u.x / u.y) * M_PI_4_F; }
-    return mk2(r * cosf(phi), r * sinf(phi));
+    return mk2(r * mrf_cos(phi), r * mrf_sin(phi));
 }
 static inline f3 sample_cosine_hemisphere_concentric(f2 u, float& pdf) {
     const float M_1_PI_F = 0.31830988f;
@@ -72,7 +72,7 @@ static inline f3 sample_ggx_ndf(float alpha, f2 u, float& pdf) {  // brdf.slang:
     float c = 1 / sqrtf(1 + tan2);
     float r = sqrtf(fmaxf(1 - c * c, 0));
     pdf = pdf_ggx_ndf(alpha, c);
-    return mk3(cosf(phi) * r, sinf(phi) * r, c);
+    return mk3(mrf_cos(phi) * r, mrf_sin(phi) * r, c);
 }
 
 namespace rt {  // utils/brdf.slang:155-212

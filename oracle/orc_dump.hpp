@@ -38,8 +38,8 @@ static inline bool bvh_occluded_front(const Bvh& B, f3 o, f3 d, float t_min, flo
 // get_light_rgbs (render_dump.py:70-82): lat-long lookup through F.grid_sample(bilinear, zeros padding, align_corners=False)
 static inline f3 dump_light_rgb(const float* env /*[H,W,3]*/, int H, int W, f3 d) {
     const float PI = 3.14159265358979323846f;
-    const float phi = acosf(d.z) - 1e-6f;
-    const float theta = atan2f(d.y, d.x);
+    const float phi = mrf_acos(d.z) - 1e-6f;
+    const float theta = mrf_atan2(d.y, d.x);
     const float qy = (phi / PI) * 2 - 1;
     const float qx = -theta / PI;
     const float x = ((qx + 1) * W - 1) / 2, y = ((qy + 1) * H - 1) / 2;   // grid_sampler_unnormalize, align_corners=False
@@ -66,7 +66,7 @@ static inline f3 ggx_specular(f3 normal, f3 pts2c, f3 pts2l, f3 rough, f3 fresne
     const float NoH = clampf((N.x * Hh.x + N.y * Hh.y) + N.z * Hh.z, 1e-6f, 1.f);
     const float VoH = clampf((V.x * Hh.x + V.y * Hh.y) + V.z * Hh.z, 1e-6f, 1.f);
     const float FMi = ((-5.55473f) * VoH - 6.98316f) * VoH;
-    const float p2 = powf(2.0f, FMi);
+    const float p2 = mrf_exp2(FMi);
     float out[3]; const float r3[3] = {rough.x, rough.y, rough.z}, f3_[3] = {fresnel.x, fresnel.y, fresnel.z};
     for (int c = 0; c < 3; c++) {
         const float alpha = r3[c] * r3[c], alpha2 = alpha * alpha;

@@ -159,7 +159,7 @@ static inline void temporal_pixel(const Config& C, const Env& E, const GBuf& G, 
 }
 
 // ------------------------------------------------------------ process_SpatialResampling_  SpatialResampling.slang:178-322
-static inline float m_factor(float q0, float q1) { return q0 == 0.f ? 1.f : clampf(powf(fminf(q1 / q0, 1.f), 8.f), 0.f, 1.f); }
+static inline float m_factor(float q0, float q1) { return q0 == 0.f ? 1.f : clampf(mrf_pow2k(fminf(q1 / q0, 1.f), 3), 0.f, 1.f); }
 static inline float pairwise_mis(float q0, float q1, float N0, float N1) { return (q1 == 0.f) ? 0.f : (N0 * q0) / (q0 * N0 + q1 * N1); }
 
 static inline void spatial_pixel(const Config& C, const Bvh& B, const Env& E, const GBuf& G, const Reservoirs& R,
@@ -437,15 +437,15 @@ static inline void eaw_pixel(int fx, int fy, int stepWidth, float c_phi, float n
         f3 ctmp = ld3(color, qi);
         f3 t = cval - ctmp;
         float dist2 = dot(t, t);
-        float c_w = fminf(expf(-(dist2) / c_phi), 1.0f);
+        float c_w = fminf(mrf_exp(-(dist2) / c_phi), 1.0f);
         f3 ntmp = ld3(normal, qi);
         t = nval - ntmp;
         dist2 = fmaxf(dot(t, t), 0.0f);
-        float n_w = fminf(expf(-(dist2) / n_phi), 1.0f);
+        float n_w = fminf(mrf_exp(-(dist2) / n_phi), 1.0f);
         f3 ptmp = ld3(pos, qi);
         t = pval - ptmp;
         dist2 = fmaxf(dot(t, t), 0.0f);
-        float p_w = fminf(expf(-(dist2) / p_phi), 1.0f);
+        float p_w = fminf(mrf_exp(-(dist2) / p_phi), 1.0f);
         float weight = c_w * n_w * p_w;
         sum += ctmp * weight * kw;
         cum_w += weight * kw;

@@ -40,10 +40,10 @@ static inline f3 eval_bi(const float* tex, f2 uv, int width, int height) {
 // utils/lightDi.slang:119-132
 static inline f3 env_le(f3 dir, const float* tex, int width, int height) {
     const float TWO_PI = 6.2831853f, INV_TWO_PI = 0.1591549f, INV_PI = 0.31830988f;
-    float theta = acosf(dir.y);
-    float sin_theta = sinf(theta);
+    float theta = mrf_acos(dir.y);
+    float sin_theta = mrf_sin(theta);
     if (fabsf(sin_theta) < 1e-4f) return mk3(0.f);
-    float phi = atan2f(dir.z, dir.x);
+    float phi = mrf_atan2(dir.z, dir.x);
     if (phi < 0) phi += TWO_PI;
     f2 uv = mk2(phi * INV_TWO_PI, 1 - theta * INV_PI);
     return eval_bi(tex, uv, width, height);
@@ -91,7 +91,7 @@ static inline bool sample_li(const Env& E, f2 rnd, f3& dir, float& out_pdf, f2& 
     int r2 = clampi(row, 0, h_ - 1), c2 = clampi(col, 0, w_ - 1);
     float pdf = E.pdf[r2 * w_ + c2] * E.mpdf[r2] * w_ * h_;
     float theta = uv.y * PI, phi = uv.x * 2 * PI;
-    float cos_theta = cosf(theta), cos_phi = cosf(phi), sin_theta = sinf(theta), sin_phi = sinf(phi);
+    float cos_theta = mrf_cos(theta), cos_phi = mrf_cos(phi), sin_theta = mrf_sin(theta), sin_phi = mrf_sin(phi);
     dir = mk3(sin_theta * cos_phi, cos_theta, sin_theta * sin_phi);
     if (fabsf(sin_theta) >= 1e-4f) pdf = pdf / (2 * PI * PI * sin_theta);
     else pdf = 0.0f;
@@ -104,10 +104,10 @@ static inline bool sample_li(const Env& E, f2 rnd, f3& dir, float& out_pdf, f2& 
 static inline float pdf_li(const Env& E, f3 dir) {
     const float TWO_PI = 6.2831853f, INV_TWO_PI = 0.1591549f, INV_PI = 0.31830988f, PI = 3.141592653589793f;
     f3 w = mk3(clampf(dir.x, -1.0f, 1.0f), clampf(dir.y, -1.0f, 1.0f), clampf(dir.z, -1.0f, 1.0f));
-    float theta = acosf(w.y);
-    float sin_theta = sinf(theta);
+    float theta = mrf_acos(w.y);
+    float sin_theta = mrf_sin(theta);
     if (fabsf(sin_theta) < 1e-4f) return 0;
-    float phi = atan2f(w.z, w.x);
+    float phi = mrf_atan2(w.z, w.x);
     if (phi < 0) phi += TWO_PI;
     int col = (int)(phi * INV_TWO_PI * E.W);
     int row = (int)(theta * INV_PI * E.H);
@@ -121,10 +121,10 @@ static inline void env_weights(const float* tex, int W, int H, float* weight) {
     for (int h = 0; h < H; h++)
         for (int w = 0; w < W; w++) {
             float v = (h + .5f) / H;
-            float sin_theta = sinf(PI * v);
+            float sin_theta = mrf_sin(PI * v);
             f2 uv = mk2((w + .5f) / W, v);
             float theta = uv.y * PI, phi = uv.x * 2 * PI;
-            float cos_theta = cosf(theta), cos_phi = cosf(phi), sin_theta_dir = sinf(theta), sin_phi = sinf(phi);
+            float cos_theta = mrf_cos(theta), cos_phi = mrf_cos(phi), sin_theta_dir = mrf_sin(theta), sin_phi = mrf_sin(phi);
             f3 raw = mk3(sin_theta_dir * cos_phi, cos_theta, sin_theta_dir * sin_phi);
             float wv = luminance(env_le(ngp_dir(raw), tex, W, H));
             wv *= sin_theta;
@@ -149,10 +149,10 @@ static inline void make_sampleable(const float* tex, int W, int H, float* pdf, f
     for (int h = 0; h < H; h++)
         for (int w = 0; w < W; w++) {
             float v = (h + .5f) / H;
-            float sin_theta = sinf(PI * v);
+            float sin_theta = mrf_sin(PI * v);
             f2 uv = mk2((w + .5f) / W, v);
             float theta = uv.y * PI, phi = uv.x * 2 * PI;
-            float cos_theta = cosf(theta), cos_phi = cosf(phi), sin_theta_dir = sinf(theta), sin_phi = sinf(phi);
+            float cos_theta = mrf_cos(theta), cos_phi = mrf_cos(phi), sin_theta_dir = mrf_sin(theta), sin_phi = mrf_sin(phi);
             f3 raw = mk3(sin_theta_dir * cos_phi, cos_theta, sin_theta_dir * sin_phi);
             float wv = luminance(env_le(ngp_dir(raw), tex, W, H));
             wv *= sin_theta;

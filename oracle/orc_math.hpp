@@ -23,6 +23,9 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+// acos / atan2 / sin / cos / exp / exp2 / integer powers: the SAME fixed arithmetic as the HIP product (include/mirres_fmath.h, <= 2 ulp from
+// the correctly rounded functions — oracle/fmath_check.cpp), so that discrete sampler decisions can be compared pixel by pixel.
+#include "../include/mirres_fmath.h"
 
 namespace orc {
 

@@ -89,7 +89,7 @@ static inline void matnet_eval(const MatNet& M, const float p[3], float out[6]) 
     for (int o = 0; o < 32; o++) { float acc = 0.f; for (int k = 0; k < 32; k++) acc = fmaf(h[k], M.w1[o * 32 + k], acc); a[o] = fmaxf(acc, 0.f); }
     for (int o = 0; o < 6; o++) {
         float acc = 0.f; for (int k = 0; k < 32; k++) acc = fmaf(a[k], M.w2[o * 32 + k], acc);
-        float s = 1.0f / (1.0f + expf(-acc));
+        float s = mrf_sigmoid(acc);
         out[o] = s * (M.mx[o] - M.mn[o]) + M.mn[o];
     }
 }

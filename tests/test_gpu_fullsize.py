@@ -3,6 +3,8 @@
 import numpy as np
 import pytest
 
+from util import pixel_parity
+
 pytestmark = pytest.mark.gpu
 
 
@@ -129,8 +131,7 @@ def test_one_sample_frame_matches_the_oracle_at_full_size(big, scene_mod, oracle
                         c(g["pos"]), mat=None)
     for o_, n_ in zip(outs, ["final_color", "diffuse", "spec", "indirect", "indirect_diff", "indirect_spec"]):
         a, r = c(o_), ref[n_]
-        frac = float((np.abs(a - r).max(axis=1) <= 1e-3).mean())
-        assert frac >= 0.98, "%s: %.4f of pixels within 1e-3" % (n_, frac)
+        pixel_parity(a, r, "full-size one-sample frame / " + n_)
         mse = float(np.mean((np.clip(a, 0, 1) - np.clip(r, 0, 1)) ** 2))
         assert mse == 0 or -10 * np.log10(mse) >= 35.0, n_
 

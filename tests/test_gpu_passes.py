@@ -9,7 +9,7 @@ import pytest
 from util import SmallFrame, match_fraction
 
 pytestmark = pytest.mark.gpu
-MIN_MATCH = 0.995
+MIN_MATCH = 1.0
 
 
 @pytest.fixture(scope="module")
