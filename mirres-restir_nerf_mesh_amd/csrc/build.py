@@ -32,7 +32,7 @@ def _newer(a, deps):
 
 def build(force=False, verbose=True):
     srcs = sorted(f for f in os.listdir(HERE) if f.endswith(".hip"))
-    hdrs = [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith(".hpp")] + [os.path.join(HERE, "..", "..", "include", "mirres.h")]
+    hdrs = [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith(".hpp")] + [os.path.join(HERE, "..", "..", "include", f) for f in os.listdir(os.path.join(HERE, "..", "..", "include")) if f.endswith(".h")]
     objdir = os.path.join(HERE, "obj")
     os.makedirs(objdir, exist_ok=True)
     jobs = []

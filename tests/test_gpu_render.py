@@ -28,23 +28,22 @@ def _run(F, W, mods, RR, torch, spp, mlp, seed=4242):
 
 
 def test_one_spp_frame_matches_oracle(oracle, scene_mod):
-    """1 spp: per-pixel agreement. A flipped discrete decision changes single pixels, so the bar is: >= 98 % of pixels within 1e-3 abs on
-    every output buffer (denoising spreads a flipped pixel over its 5x5 / 9x9 footprint) and PSNR(HIP, oracle) >= 35 dB."""
+    """1 spp, constant material at the indirect vertices: every output buffer of the frame equals the oracle's BIT FOR BIT (shared FP policy and
+    shared transcendental arithmetic, include/mirres_fmath.h) — the north-star's 1e-3 per channel met with zero error in every pixel."""
     F, W, mods, RR, torch = _setup(oracle, scene_mod)
     got = _run(F, W, mods, RR, torch, 1, None)
     ref = oracle.render(F.fx, F.fy, 1, 4242, (F.info, F.aabb), F.vert, F.tri, F.env, F.occ, F.normal, F.depth, F.kd, F.rm, F.ray_dir_raw, F.pos, mat=None)
     names = ["final_color", "diffuse", "spec", "indirect", "indirect_diff", "indirect_spec"]
     for g, n in zip(got, names):
         r = ref[n]
-        pixel_parity(g, r, "one-sample frame / " + n)
-        assert psnr(np.clip(g, 0, 1), np.clip(r, 0, 1)) >= 35.0, n
+        pixel_parity(g, r, "one-sample frame / " + n, tol=0.0)
     assert np.array_equal(got[0][F.occ < 0.5], np.ones_like(got[0][F.occ < 0.5]))    # background := 1 (:546-547)
 
 
 def test_frame_matches_the_reference_loop(oracle, scene_mod):
     """The HIP frame (one mirres_render call, hash-grid + MFMA material field, 3 samples) against tests/golden/ref_loop.npz: the REFERENCE's own
-    Python frame loop executed over the oracle's kernels (tests/golden/gen_reference_loop.py). Per-pixel agreement as in the 1-spp test (a flipped
-    discrete decision changes single pixels and the denoiser spreads it)."""
+    Python frame loop executed over the oracle's kernels (tests/golden/gen_reference_loop.py). EVERY pixel within 1e-4 (observed 2.6e-5: the reference
+    builds the importance tables with torch.cumsum, the engine sequentially; the MFMA material field is 3e-6 from the fp32 chain of torch.nn.Linear)."""
     import os
     if os.environ.get("MIRRES_TEST_SEED", "0") != "0":
         pytest.skip("the fixture holds the default frame (view / materials of sweep 0)")
@@ -62,8 +61,7 @@ def test_frame_matches_the_reference_loop(oracle, scene_mod):
     got = _run(F, W, mods, RR, torch, int(g["spp"]), mlp, seed=int(g["random_offset"]))
     for k, n in enumerate(["final_color", "diffuse", "spec", "indirect", "indirect_diff", "indirect_spec"]):
         r = g["outs"][k]
-        pixel_parity(got[k], r, "reference loop frame / " + n)
-        assert psnr(np.clip(got[k], 0, 1), np.clip(r, 0, 1)) >= 35.0, n
+        pixel_parity(got[k], r, "reference loop frame / " + n, tol=1e-4)
 
 
 def test_load_m_for_restir_matches_the_reference(oracle, scene_mod):
@@ -120,8 +118,7 @@ def test_three_indirect_bounces_and_albedo_scale(oracle, scene_mod):
     assert np.abs(ref["indirect"] - two["indirect"]).max() > 1e-3          # the third bounce contributes
     for g_, n in zip(outs, ["final_color", "diffuse", "spec", "indirect", "indirect_diff", "indirect_spec"]):
         g_ = g_.cpu().numpy(); r = ref[n]
-        pixel_parity(g_, r, "three bounces + albedo scale / " + n)
-        assert psnr(np.clip(g_, 0, 1), np.clip(r, 0, 1)) >= 35.0, n
+        pixel_parity(g_, r, "three bounces + albedo scale / " + n, tol=1e-5)      # MFMA material field (hi / lo split operands): observed 3e-7
 
 
 def test_fused_equals_stepwise(oracle, scene_mod, monkeypatch):
@@ -401,7 +398,7 @@ def test_degenerate_frames(oracle, scene_mod):
     got, ref = both(F, W, F.env, F.occ, F.kd, F.rm, spp=2)
     for g_, n_ in zip(got, names):
         assert np.isfinite(g_).all()
-        pixel_parity(g_, ref[n_], "ragged 7x5 frame / " + n_)
+        pixel_parity(g_, ref[n_], "ragged 7x5 frame / " + n_, tol=0.0)
     # (b) nothing but background
     got, ref = both(F, W, F.env, np.zeros_like(F.occ), F.kd, F.rm)
     assert all(np.isfinite(g_).all() for g_ in got) and (got[0] == 1.0).all() and (ref["final_color"] == 1.0).all() and all((g_ == 0).all() for g_ in got[1:])
@@ -417,7 +414,7 @@ def test_degenerate_frames(oracle, scene_mod):
     got, ref = both(F2, W2, F2.env, F2.occ, kd, rm)
     for g_, n_ in zip(got, names):
         assert np.isfinite(g_).all()
-        pixel_parity(g_, ref[n_], "material extremes / " + n_)
+        pixel_parity(g_, ref[n_], "material extremes / " + n_, tol=0.0)
 
 
 def test_stage1_loop_with_reference_losses(scene_mod):

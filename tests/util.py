@@ -191,3 +191,18 @@ def pixel_parity(got, ref, what, tol=1e-3, min_frac=1.0):
             f.write("%s: %d of %d rows beyond %g (max abs err %.3e, exact-equal rows %.4f)\n" % (what, int(bad.sum()), len(err), tol, mx, float((err == 0).mean())))
     assert frac >= min_frac, "%s: %d of %d pixels beyond %g (max abs err %.3e)" % (what, int(bad.sum()), len(err), tol, mx)
     return frac, int(bad.sum()), mx
+
+
+def same_bits(got, ref, what):
+    """Bit-for-bit equality of two float arrays (NaNs compare by payload): what the shared arithmetic of product and oracle buys for everything that does not
+    pass through the MFMA material field."""
+    import os
+    g = np.ascontiguousarray(np.asarray(got, np.float32)).reshape(-1); r = np.ascontiguousarray(np.asarray(ref, np.float32)).reshape(-1)
+    assert g.shape == r.shape, (what, g.shape, r.shape)
+    bad = g.view(np.uint32) != r.view(np.uint32)
+    rep = os.environ.get("MIRRES_PARITY_REPORT")
+    if rep:
+        with open(rep, "a") as f:
+            f.write("%s: %d of %d values differ in bits (max abs diff %.3e)\n" % (what, int(bad.sum()), bad.size, float(np.nanmax(np.abs(g - r))) if bad.any() else 0.0))
+    assert not bad.any(), "%s: %d of %d values differ (first at %d: %r vs %r, max abs diff %.3e)" % (
+        what, int(bad.sum()), bad.size, int(np.argmax(bad)), g[np.argmax(bad)], r[np.argmax(bad)], float(np.nanmax(np.abs(g - r))))
