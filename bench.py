@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — headline metric of BASELINE.json on MI355X: Msamples/s (pixels x spp) of the ReSTIR + path-tracing forward render.
 
-    python bench.py [--gpus N --steps K --warmup W] [--res 800 --ssaa 2 --spp 128 --bounces 2]
+    python bench.py [--gpus N --steps K --warmup W] [--res 800 --ssaa 2 --spp 512 --bounces 2]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 One "step" = one frame of the hot path: LBVH rebuild (restirbvhWorker.update_mesh, as render_stage1 does every frame) + run_restir_di_with_pt
@@ -9,8 +9,9 @@ One "step" = one frame of the hot path: LBVH rebuild (restirbvhWorker.update_mes
 denoise, composite) over a synthetic scene of BASELINE config 2's shape, with every input already resident in HBM. The G-buffer (primary
 visibility, nvdiffrast's job in the reference) is built once outside the timed region.
 
-N > 1: the frame's spp range is split across ranks (mirres-restir_nerf_mesh_amd/dist.py), one all-reduce (RCCL) of the accumulators, then
-the replicated finish — total work is fixed, i.e. STRONG scaling of the one frame, as BASELINE's "at 1/2/4/8 GPU".
+N > 1: the one frame is shared by the ranks (mirres-restir_nerf_mesh_amd/dist.py) — total work is fixed, i.e. STRONG scaling, as BASELINE's "at
+1/2/4/8 GPU" — and BOTH sharding schemes are timed in the same run: `value` = spp slices + one all-reduce (RCCL) of the accumulators, and the
+`strips` sub-record = the north-star's pixel split (row strips, per-sample reservoir halo exchange, all-gather of radiance rows; bit-identical to one GPU).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (traversal kernel, measured live with HIP events on the
 launch stream) and `cpu_baseline` (the CPU oracle on a bounded sample; rank 0, N=1 only).
@@ -32,10 +33,12 @@ def parse():
     p.add_argument("--warmup", type=int, default=1)
     p.add_argument("--res", type=int, default=800, help="output resolution (BASELINE config 2: 800)")
     p.add_argument("--ssaa", type=int, default=2, help="reference default --ssaa 2 -> internal 1600x1600 (main.py:140)")
-    p.add_argument("--spp", type=int, default=128)
+    p.add_argument("--spp", type=int, default=512, help="BASELINE.json metric: 800x800, 512 spp, 3-bounce (configs[1] quotes the same frame at 128 spp)")
     p.add_argument("--bounces", type=int, default=2, help="indirect bounces (MAX_Bounce, FinalShading.slang:7) -> 3 path vertices")
     p.add_argument("--subdiv", type=int, default=7, help="icosphere subdivisions (7 -> 327 680 + 8 192 ground triangles)")
-    p.add_argument("--shard", choices=("strips", "spp"), default="spp", help="N > 1: exact row strips with halo exchange, or spp slices + all-reduce")
+    p.add_argument("--shard", choices=("both", "strips", "spp"), default="both",
+                   help="N > 1: `spp` = sample slices + one all-reduce (the timed `value`), `strips` = exact row strips + per-sample halo exchange + all-gather (the north-star's "
+                        "tile split, reported as the `strips` sub-record), `both` = time the two schemes one after the other")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-roofline", action="store_true")
     p.add_argument("--const-material", action="store_true", help="constant material instead of the hash-grid + MLP field")
@@ -78,6 +81,12 @@ def cpu_baseline(S, args):
     return {"value": round(N * spp / dt / 1e6, 6), "unit": "Msamples/s", "cores": O.num_threads(), "kind": "port",
             "sample": "%dx%d px, %d spp, same mesh (T=%d) / env / material, LBVH build + full frame (CPU restatement of the reference kernels, not reference code); "
                       "%.1f s of CPU work" % (fx, fy, spp, len(t), dt)}, frame
+
+
+# MFMA roofline of the material MLP: the instruction the kernel issues decides the peak it is priced against (MI355X_MICROARCH.md)
+MLP_ROOF = {"bound": "mfma", "peak": 157.3, "instruction": "v_mfma_f32_32x32x2_f32 (fp32 in / fp32 accumulate: the reference's fp32 Linear layers as fmaf chains, bit for bit)",
+            "note": "algorithmic flops (4 480 per point) / event-timed duration against the fp32 MFMA peak (157.3 TFLOP/s); the kernel issues 6 144 flop per point "
+                    "(the 6-row output layer occupies a 32-row tile): issued_frac = that rate against the same peak"}
 
 
 def main():
@@ -126,9 +135,9 @@ def main():
     ctx = get_ctx(fx, fy, max_bounce=args.bounces)
     N = fx * fy
 
-    def step():
+    def step(scheme):
         W.update_mesh(W.vrt, W.v_ind)                                   # LBVH rebuilt every frame (nerf/renderer.py:975)
-        if world > 1 and args.shard == "strips":      # exact: row strips + per-sample halo exchange + all-gather of the raw sums (dist.py)
+        if world > 1 and scheme == "strips":          # exact: row strips + per-sample halo exchange + all-gather of the raw sums (dist.py)
             return MD.render_strips(ctx, W, mlp, env, g, args.spp, 12345, rank, world, max_bounce=args.bounces)
         return MD.render_sharded(ctx, W, mlp, env, g, args.spp, 12345, rank, world)
 
@@ -137,22 +146,33 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    def timed(scheme):
+        """W untimed warm-up steps, then exactly K steps between barrier + synchronize on both sides; MAX over ranks."""
+        for _ in range(args.warmup):
+            step(scheme)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            o = step(scheme)
+        barrier()
+        d = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([d], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            d = float(tt.item())
+        return d, o
+
     samples = float(N) * args.spp * args.steps
+    schemes = ["spp"] if world == 1 else (["spp", "strips"] if args.shard == "both" else [args.shard])
+    results = {}
+    for sc in schemes:
+        results[sc] = timed(sc)
+    primary = schemes[0]
+    dt, out = results[primary]
     value = samples / dt / 1e6
 
-    # ---- roofline of the dominant kernel (any-hit traversal), measured live with HIP events on the launch stream (rank 0)
+    # ---- rooflines, measured live with HIP events on the launch stream (rank 0): the dominant kernel (shadow-ray traversal), the ordered
+    #      closest-hit traversal, and the material MLP's GEMM phase
     roof = None
     if rank == 0 and not args.no_roofline:
         b, e = MD.spp_slice(args.spp, rank, world)
@@ -160,43 +180,65 @@ def main():
         def frame(n):
             occ = g["occ"].clone()
             RR.render_fused(ctx, W, mlp, False, (1, 1, 1), env, occ, g["normal"], g["depth"], g["kd"], g["rm"], g["ray_dir"], g["pos"], n, 2, 2, 2.0, 0.1, 0.001, 12345)
-        # (a) visit counts of exactly these rays (deterministic; untimed): the reference traversal's own counts ("the reference node
-        #     layout as the accounting basis regardless of the build's internal layout", counts of bvh_hit's order on the same ray set) and the
-        #     production kernel's (64-byte records it fetches from global memory)
+        # (a) visit counts of exactly these rays (deterministic; untimed): the production kernels' own (64-byte records they fetch) and, for the
+        #     reference-equivalent figure, the reference traversal's (bvh_hit's order, no early exit) on the same ray set
         ctx.set_instrument(5); ctx.stats(reset=True); frame(prof_spp); st = ctx.stats(reset=True)
         ctx.set_instrument(1); ctx.stats(reset=True); frame(prof_spp); own = ctx.stats(reset=True)
         # (b) event-timed launches of the production kernels on the same rays
         ctx.set_instrument(2); ctx.trace_time(); frame(prof_spp); ms_any, n_any, ms_cl, n_cl = ctx.trace_time()
         ctx.set_instrument(0)
         rays_any, rays_cl = st["rays_any"], st["rays_closest"]
-        # algorithmic bytes: per ray 24 (o,d) + 12 (root info) + result, 24 per popped node (aabb) + 24 per entered internal node
-        # (two child infos) + 48 per tested leaf (indices + vertices), with the reference traversal's counts.
         total_rays = rays_any + rays_cl
-        bytes_any = 24.0 * st["popped"] + 24.0 * st["entered"] + 48.0 * st["leaves"] + rays_any * (24 + 12 + 4)
-        bytes_cl = 24.0 * st["cl_popped"] + 24.0 * st["cl_entered"] + 48.0 * st["cl_leaves"] + rays_cl * (24 + 12 + 28)
-        own_bytes_any = 64.0 * own["entered"] + rays_any * (32 + 4)      # compressed 64-byte node / leaf records + the 32-byte ray + result
-        ms_launch = ms_any / max(1, n_any)
-        achieved = bytes_any / (ms_any * 1e-3) / 1e9 if ms_any > 0 else 0.0
-        own_achieved = own_bytes_any / (ms_any * 1e-3) / 1e9 if ms_any > 0 else 0.0
-        roof = {"bound": "hbm", "kernel": "k_trace_any4q (shadow-ray BVH traversal)", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(achieved / 8000.0, 5), "traffic": None,
-                "launch_ms": round(ms_launch, 4), "launches": n_any, "rays_per_launch": round(rays_any / max(1, n_any)),
-                "bytes_per_ray": round(bytes_any / max(1, rays_any), 1), "grays_per_s": round(rays_any / (ms_any * 1e-3) / 1e9, 3) if ms_any > 0 else 0.0,
-                "own_bytes_per_ray": round(own_bytes_any / max(1, rays_any), 1), "own_achieved": round(own_achieved, 2), "own_frac": round(own_achieved / 8000.0, 5),
-                "note": "achieved = SURVEY 8d algorithmic bytes (reference layout, reference traversal's visit counts on the same rays) / event-timed duration; "
-                        "it exceeds the HBM peak because the production kernel stops at the first occluder, walks a 4-wide tree near-first and fetches 64-byte compressed "
-                        "records (own_*: the bytes it actually requests), and the 43 MB layout is cache resident (traffic = HBM bytes from PMC); the kernel is bound by issue slots and the "
-                        "dependent chain of a traversal step, not by memory: fetching every record twice costs +1.5 % (DESIGN.md section 5, round 2)",
-                "closest_launch_ms": round(ms_cl / max(1, n_cl), 4), "closest_achieved": round(bytes_cl / (ms_cl * 1e-3) / 1e9, 2) if ms_cl > 0 else 0.0, "rays_per_pixel_sample": round(total_rays / (float(N) * prof_spp), 3),
-                "per_ray": {"any_reference": [round(st[k] / max(1, rays_any), 2) for k in ("popped", "entered", "leaves")], "any_production": [round(own[k] / max(1, rays_any), 2) for k in ("popped", "entered", "leaves")],
-                            "closest": [round(st[k] / max(1, rays_cl), 2) for k in ("cl_popped", "cl_entered", "cl_leaves")]},
-                "traversal_share_of_step": round((ms_any + ms_cl) / prof_spp * args.spp / (dt / args.steps * 1e3) * (world if world > 1 else 1), 3)}
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
+        # ALGORITHMIC bytes of the kernel as built: every 64-byte node / leaf record the traversal has to read for its answer
+        # (counted by the instrumented kernel on these very rays) + the 32-byte ray + the result (4 B hit flag; 28 B hit record for the closest hit).
+        own_bytes_any = 64.0 * own["entered"] + rays_any * (32 + 4)
+        own_bytes_cl = 64.0 * own["cl_entered"] + rays_cl * (32 + 28)
+        # SURVEY section 8d's accounting (reference node layout, reference traversal's visit counts): what the REFERENCE's bvh_hit would have to move
+        # for the same rays — kept as `reference_equiv`, not as the roofline (the production kernel does not do that work: early exit, 4-wide tree)
+        ref_bytes_any = 24.0 * st["popped"] + 24.0 * st["entered"] + 48.0 * st["leaves"] + rays_any * (24 + 12 + 4)
+        sec_any, sec_cl = ms_any * 1e-3, ms_cl * 1e-3
+        achieved = own_bytes_any / sec_any / 1e9 if sec_any > 0 else 0.0
+        achieved_cl = own_bytes_cl / sec_cl / 1e9 if sec_cl > 0 else 0.0
+        HBM, L2 = 8000.0, 34500.0       # GB/s: MI355X_MICROARCH.md (HBM3E spec peak; aggregate L2 of the eight XCDs)
+        pmc = {}
+        for fn_ in ("r03_pmc_any4q_summary.json", "pmc_traffic.json"):
             try:
-                roof["traffic"] = json.load(open(pmc)).get("k_trace_any_hbm_bytes_per_launch")
+                pmc.update(json.load(open(os.path.join(ROOT, "profiles", fn_))))
             except Exception:
                 pass
+        roof = {"bound": "hbm", "kernel": "k_trace_any4q (shadow-ray BVH traversal)", "achieved": round(achieved, 2), "peak": HBM, "unit": "GB/s",
+                "frac": round(achieved / HBM, 5), "traffic": pmc.get("k_trace_any_hbm_bytes_per_launch"),
+                "bytes_per_ray": round(own_bytes_any / max(1, rays_any), 1), "launch_ms": round(ms_any / max(1, n_any), 4), "launches": n_any,
+                "rays_per_launch": round(rays_any / max(1, n_any)), "grays_per_s": round(rays_any / sec_any / 1e9, 3) if sec_any > 0 else 0.0,
+                "l2_peak": L2, "l2_frac": round(achieved / L2, 5),
+                "binding": "valu-issue", "valu_busy": pmc.get("valu_busy"), "lane_util": pmc.get("lane_util"), "l1_hit": pmc.get("l1_hit"),
+                "reference_equiv": {"bytes_per_ray": round(ref_bytes_any / max(1, rays_any), 1), "tbps": round(ref_bytes_any / sec_any / 1e12, 2) if sec_any > 0 else 0.0,
+                                    "note": "SURVEY 8d accounting: reference node layout x the reference traversal's visit counts on the same rays / this kernel's time"},
+                "note": "achieved = bytes the kernel's own algorithm has to move (64-B records visited + ray + result, counted on the timed rays) / event-timed duration, against the HBM "
+                        "peak as the contract asks; the 43 MB layout is cache resident (traffic = HBM bytes per launch from PMC, 6 % of the requested bytes; 88 % L1 hits), so the "
+                        "binding resource is VALU issue, not bandwidth: valu_busy = SQ_ACTIVE_INST_VALU / SIMD cycles, lane_util = active lanes per issued VALU instruction "
+                        "(profiles/r03_pmc_any4q_summary.json)",
+                "closest": {"kernel": "k_trace_closest4 (+ reference-order redo)", "achieved": round(achieved_cl, 2), "peak": HBM, "unit": "GB/s", "frac": round(achieved_cl / HBM, 5),
+                            "bytes_per_ray": round(own_bytes_cl / max(1, rays_cl), 1), "launch_ms": round(ms_cl / max(1, n_cl), 4), "launches": n_cl,
+                            "grays_per_s": round(rays_cl / sec_cl / 1e9, 3) if sec_cl > 0 else 0.0},
+                "rays_per_pixel_sample": round(total_rays / (float(N) * prof_spp), 3),
+                "per_ray": {"any_reference": [round(st[k] / max(1, rays_any), 2) for k in ("popped", "entered", "leaves")], "any_production": [round(own[k] / max(1, rays_any), 2) for k in ("popped", "entered", "leaves")],
+                            "closest": [round(own[k] / max(1, rays_cl), 2) for k in ("cl_popped", "cl_entered", "cl_leaves")]},
+                "traversal_share_of_step": round((ms_any + ms_cl) / prof_spp * args.spp / (dt / args.steps * 1e3) * (world if world > 1 else 1), 3)}
+        if mlp is not None:
+            # material MLP, GEMM phase alone (mirres_matnet_mlp on precomputed encodings of N points): 4 480 flop per point
+            gen = torch.Generator(device=dev).manual_seed(0)
+            enc = mlp.encode(torch.rand((N, 3), device=dev, generator=gen) * 1.2 - 0.6)
+            mlp.mlp_on_encoding(enc); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                mlp.mlp_on_encoding(enc)
+            e1.record(); torch.cuda.synchronize()
+            ms_mlp = e0.elapsed_time(e1) / 20
+            tf = 4480.0 * N / (ms_mlp * 1e-3) / 1e12
+            roof["mlp"] = dict(MLP_ROOF, kernel="k_mlp_mfma (material MLP, GEMM phase)", achieved=round(tf, 2), unit="TFLOP/s", frac=round(tf / MLP_ROOF["peak"], 5),
+                               issued_frac=round(tf * 6144.0 / 4480.0 / MLP_ROOF["peak"], 5), launch_ms=round(ms_mlp, 4), points=N, mfma_busy=pmc.get("mlp_mfma_busy"))
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu, cf = cpu_baseline(S, args)
@@ -204,22 +246,33 @@ def main():
         cu = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
         small, _, _ = RR.render_fused(get_ctx(cf["fx"], cf["fy"], max_bounce=args.bounces), W, mlp, False, (1, 1, 1), cu(cf["env"]), cu(cf["occ"][:, None]), cu(cf["normal"]),
                                       cu(cf["depth"][:, None]), cu(cf["kd"]), cu(cf["rm"]), cu(cf["ray_dir"]), cu(cf["pos"]), cf["spp"], 2, 2, 2.0, 0.1, 0.001, 12345)
-        mse = float(((small[0].clamp(0, 1) - cu(cf["final_color"]).clamp(0, 1)) ** 2).mean().item())
+        got_small = small[0].detach().cpu().numpy(); want_small = cf["final_color"]
+        err = np.abs(got_small - want_small).max(axis=1)
+        mse = float(np.mean((np.clip(got_small, 0, 1) - np.clip(want_small, 0, 1)) ** 2))
         cpu["psnr_hip_vs_oracle_db"] = round(-10.0 * float(np.log10(max(mse, 1e-20))), 2)
+        cpu["max_abs_err"] = float(err.max()); cpu["frac_within_1e-3"] = float((err <= 1e-3).mean()); cpu["frac_bit_equal"] = float((err == 0).mean())
+        # the north-star's parity bar on the benched workload: every pixel of the small frame within 1e-3 per channel of the CPU oracle
+        assert cpu["max_abs_err"] <= 1e-3, "bench: HIP frame differs from the CPU oracle by %.3e (> 1e-3)" % cpu["max_abs_err"]
 
     if rank == 0:
         fc = out[0]
+        par = {"spp": "sample slices + one all-reduce of the six accumulators (statistically equivalent frame)",
+               "strips": "row strips + per-sample reservoir halo exchange + all-gather of radiance rows (bit-identical to one GPU)"}
         line = {"metric": "Msamples/s (pixels x spp), ReSTIR-DI + %d-bounce path tracing forward render" % (args.bounces + 1),
                 "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
                 "data": "synthetic",
-                "config": {"workload": "BASELINE configs[1]: TensoIR-lego-shaped synthetic mesh (T=%d), %dx%d output, ssaa %d (internal %dx%d), %d spp, "
-                                       "%d indirect bounces + ReSTIR (initial/temporal/spatial), LBVH rebuild per frame, %s, EAW denoise"
+                "config": {"workload": "BASELINE metric frame (configs[1] geometry at the metric's 512 spp): TensoIR-lego-shaped synthetic mesh (T=%d), %dx%d output, ssaa %d (internal %dx%d), "
+                                       "%d spp, %d indirect bounces (3-bounce paths) + ReSTIR (initial/temporal/spatial), LBVH rebuild per frame, %s, EAW denoise"
                                        % (len(t), args.res, args.res, args.ssaa, fx, fy, args.spp, args.bounces, "constant material" if args.const_material else "hash-grid+MLP material field"),
-                           "internal_pixels": N, "spp": args.spp, "triangles": int(len(t)), "parallelism": ("%s x%d" % ("row strips + halo exchange + all-gather" if args.shard == "strips" else "spp-sharded + all-reduce", world)) if world > 1 else "single GPU",
+                           "internal_pixels": N, "spp": args.spp, "triangles": int(len(t)),
+                           "parallelism": ("%s x%d" % (par[primary], world)) if world > 1 else "single GPU",
                            "output_pixel_msamples_per_s": round(args.res * args.res * args.spp * args.steps / dt / 1e6, 3),
                            "finite": bool(torch.isfinite(fc).all().item()), "mean_radiance": round(float(fc[g["occ"][:, 0] > 0.5].mean().item()), 5)},
                 "roofline": roof, "cpu_baseline": cpu}
+        for sc in schemes[1:]:            # the other sharding scheme, timed the same way in the same run
+            d2, _ = results[sc]
+            line[sc] = {"value": round(samples / d2 / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(d2 / args.steps * 1e3, 2), "parallelism": "%s x%d" % (par[sc], world)}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

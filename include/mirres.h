@@ -214,7 +214,7 @@ int mirres_matnet_pack_grid(const float* params_f32, uint16_t* grid_f16, int64_t
 /* MLPTexture3D.sample / sample_no_di: pos f32[n,3] -> out f32[n,6]; enc_out (fp16 bits [n,32]) may be NULL.     */
 int mirres_matnet_fwd(const mirres_matnet_t* m, const float* pos, int n, float* out, uint16_t* enc_out, void* stream);
 /* _MLP.forward on precomputed encodings (render_helper.py:43-44, 100-104): enc fp16 bits [n,32] -> out f32[n,6] (sigmoid + range applied).
- * The MFMA-tiled kernel (v_mfma_f32_32x32x16_f16 with hi/lo operand splitting, fp32-accurate).                                          */
+ * The MFMA-tiled kernel (v_mfma_f32_32x32x2_f32, sixteen K = 2 steps per layer in ascending k: the fp32 fmaf chain of mirres_matnet_fwd, bit for bit). */
 int mirres_matnet_mlp(const mirres_matnet_t* m, const uint16_t* enc, int n, float* out, void* stream);
 /* renderer_restir.py:398-408 fused: evaluate where occ>=0.5 and scatter kd / (roughness, metallic) in place.    */
 int mirres_matnet_scatter(const mirres_matnet_t* m, const float* occ, const float* pos, int n, float* kd, float* rough_metal,

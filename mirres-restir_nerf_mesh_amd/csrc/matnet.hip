@@ -6,7 +6,7 @@
 // 5-15 hashed with primes (1, 2654435761, 805459861); pos = fmaf(scale, x, 0.5); fp16 table, fp16 accumulation of the
 // 8-corner interpolation; features level-major. The MLP runs in fp32 like the reference's torch.nn.Linear stack: the
 // per-lane kernels (k_matnet_fwd / k_matnet_scatter) evaluate each output as a k-ordered fmaf chain; the MFMA-tiled kernel
-// (k_mlp_mfma, the production path) reproduces it to ~1e-6 with hi/lo-split fp16 operands on the matrix pipe.
+// (k_mlp_mfma, the production path) runs the SAME chains on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32, K = 2 per step in ascending k): same bits.
 #include "engine.hpp"
 #include "device_math.hpp"
 #include "device_grid.hpp"
@@ -117,54 +117,40 @@ __global__ void __launch_bounds__(MR_BLOCK) k_matnet_scatter(MatNetD M, GridLeve
 
 
 // ---------------------------------------------------------------- MFMA-tiled MLP (the one dense contraction of the path)
-// 64 points per wave, v_mfma_f32_32x32x16_f16: M = 32 points, N = 32 neurons, K = 16 features per instruction.
-// fp32-accurate on the f16 matrix pipe: every fp32 operand is split x = xh + xl (two fp16 numbers, |x - xh - xl| <= 2^-22 |x|) and the
-// product is evaluated as xh*wh + xh*wl + xl*wh with fp32 accumulation inside the MFMA (f16 x f16 products are exact in fp32); the layer-0
-// inputs are fp16 already (hash-grid features), so layer 0 needs two terms. Result: the reference's fp32 torch.nn.Linear stack to ~1e-6,
-// at 32 MFMAs per 64 points instead of 2 240 VALU FMAs per point.
-// LDS staging: feature rows padded to 40 halfs and hidden rows to 36 floats so that the 16-byte fragment reads of 32 consecutive points
-// fall on distinct bank groups (MI355X guide, LDS section: b128 reads are served in 16-lane groups over 64 banks).
+// LDS staging (MODE 1): feature rows padded to 40 halfs so that the 16-byte fragment reads of 32 consecutive points fall on distinct bank
+// groups (MI355X guide, LDS section: b128 reads are served in 16-lane groups over 64 banks).
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 #define MR_FROW 40
-#define MR_HROW 36
 
-MR_DEV void split8(const float* __restrict__ x, half8_t& hi, half8_t& lo) {
-#pragma unroll
-    for (int t = 0; t < 8; t++) { _Float16 h = (_Float16)x[t]; hi[t] = h; lo[t] = (_Float16)(x[t] - (float)h); }
+// 64 points per wave on the fp32 matrix pipe: bit-equal to an fp32 fmaf chain.
+// v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate): D[i][j] = fma(A[i][1], B[1][j], fma(A[i][0], B[0][j], C[i][j])) — an fmaf chain in k order, bit for bit
+// (MI355X_MICROARCH.md, MFMA table; checked against the per-lane kernel in tests/test_gpu_matnet.py).  The reference evaluates the layers in fp32
+// (torch.nn.Linear on fp32 activations, nerf/render_helper.py:28-51); with sixteen K = 2 steps per layer in ascending k the accumulator of output neuron i
+// goes through exactly the chain  acc = fmaf(x[k], W[i][k], acc), k = 0 .. 31  of the per-lane kernel above — the material values, and with them every
+// lobe choice at an indirect vertex, are the same bits whichever kernel (or host restatement) produced them.
+// Layout: the product is computed transposed, C[neuron][point] = W X^T, so that a layer's accumulator turns into the next layer's B operand without
+// leaving registers.  A = weights, lane (i = lane & 31, kh = lane >> 5) holds W[i][2 s + kh] of step s; B = activations, lane
+// (kh, j) holds x[2 s + kh] of point j; D: lane (j, half) holds neurons (r & 3) + 8 (r >> 2) + 4 half in register r.  Between layers the B operand of step
+// s needs neurons 2 s and 2 s + 1 of point j in the two halves of ONE register: v_permlane32_swap_b32 on the register pairs (r, r + 1), r even, turns
+// D into exactly that — register r then holds neurons (n, n + 1), n = (r & 3) + 8 (r >> 2) + 4 (r & 1) - (r & 1), i.e. step s lives in register
+// (s & ~3) | ((s & 1) << 1) | ((s >> 1) & 1).  Activations never leave registers; 8 swaps and 16 ReLUs per layer and tile.
+// MODE 0: features given (enc_in fp16 [n,32]) -> out6[n,6];  MODE 1: positions of the compacted pixel list -> scatter kd / (rough, metal).
+// NT = 32-point tiles per wave, processed in lock-step (NT independent accumulator chains).
+// Cost: 48 MFMAs of 64 cycles per 32 points.  Round 2 ran this MLP on the f16 pipe with hi / lo split operands (32 MFMAs of 32 cycles per 64 points,
+// 3e-6 from the fmaf chain): the GEMM phase alone took 57 us per 2.56 M points against 201 us now, the FRAME is unchanged (1075 vs 1077 Msamples/s:
+// inside it the kernel is bound by its 128 hash-grid gathers per point) — and every frame with the material field is now bit-equal to the CPU
+// restatement, which is what the exchange bought (profiles/r03_mlp_ab.txt).
+MR_DEV int step_reg(int s) { return (s & ~3) | ((s & 1) << 1) | ((s >> 1) & 1); }
+MR_DEV void swap_halves(float& a, float& b) {     // a.upper <-> b.lower
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    a = __uint_as_float(r[0]); b = __uint_as_float(r[1]);
 }
-MR_DEV int mfma_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
-
-// Register-resident layer chaining: the product is computed transposed, C[neuron][point] = W[neuron][k] * X^T[k][point], so the accumulator
-// a lane holds after layer l (point = lane & 31, neurons (r&3) + 8(r>>2) + 4(lane>>5)) IS the B-operand fragment of layer l+1 — an MFMA is a
-// dot product over k, so any assignment of k to (lane>>5, slot) is valid as long as the A fragment (weights) uses the same one. Activations
-// never leave registers between layers: ReLU + hi/lo split on the accumulator, no LDS transpose.
-// MODE 0: features given (enc_in fp16 [n,32]) -> out6[n,6];  MODE 1: positions of the compacted pixel list -> scatter kd / (rough, metal)
-// NT = 32-point tiles per wave, processed in lock-step so that NT independent accumulator chains keep the matrix pipe busy while the
-// previous MFMA of the same chain drains (a dependent 32x32x16 MFMA cannot issue back-to-back).
-// ReLU + hi/lo split of eight accumulator values, four VALU ops per value and none of them packed-fp32 (hazard note):
-//   r  = max_i32(bits(x), 0)      ReLU on the bit pattern: a negative float is a negative integer (one v_max_i32, no canonicalising max);
-//   hi = r & 0xffffe000           the value truncated to an 11-bit significand: exactly representable in fp16 (normal range);
-//   lo = r - hi                   exact in fp32 (< 2^-10 r, 13 significant bits), rounded to fp16 by the packing conversion: |x - hi - lo| <= 2^-21 |x|;
-// both halves leave through v_cvt_pk_f16_f32 (two values per instruction).
-MR_DEV void relu_split8(const f32x16_t& acc, int first, half8_t& hi, half8_t& lo) {
-#pragma unroll
-    for (int t = 0; t < 8; t++) {
-        const int r = max(__float_as_int(acc[first + t]), 0);
-        const float h = __int_as_float(r & (int)0xffffe000u);
-        hi[t] = (_Float16)h; lo[t] = (_Float16)(__int_as_float(r) - h);
-    }
-}
-
-// sigmoid of the MFMA kernels: v_exp_f32 + v_rcp_f32 (each 1 ulp; the scaled argument adds |x| * 6e-8 relative) instead of libm expf and an
-// IEEE division — 6 instead of ~30 VALU instructions per output, |error| < 2e-6 relative against the per-lane kernel's 1 / (1 + expf(-x)).
-// The outputs are continuous shading parameters (no decision hangs on the last bits), three orders of magnitude inside the 1e-3 parity bar.
-#define MR_SIGMOID(x) __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * (x)))
 template <int MODE, int NT>
 __global__ void __launch_bounds__(MR_BLOCK) k_mlp_mfma(MatNetD M, GridLevels L, const uint16_t* __restrict__ enc_in, const float* __restrict__ pos,
-                                                       const int32_t* __restrict__ index, const uint32_t* __restrict__ d_count, int n_fixed,
-                                                       float* __restrict__ out6, float* __restrict__ kd, float* __restrict__ rm, int use_scale,
-                                                       float sx, float sy, float sz) {
+                                                         const int32_t* __restrict__ index, const uint32_t* __restrict__ d_count, int n_fixed,
+                                                         float* __restrict__ out6, float* __restrict__ kd, float* __restrict__ rm, int use_scale,
+                                                         float sx, float sy, float sz) {
     constexpr int PTS = (MR_BLOCK / 64) * NT * 32;   // points per block iteration
     __shared__ __attribute__((aligned(16))) _Float16 sF[MODE == 1 ? MR_BLOCK * MR_FROW : 8];
     __shared__ float sW[2240];
@@ -173,37 +159,26 @@ __global__ void __launch_bounds__(MR_BLOCK) k_mlp_mfma(MatNetD M, GridLevels L, 
     const int j = lane & 31, half = lane >> 5;
     for (int i = threadIdx.x; i < 2240; i += MR_BLOCK) sW[i] = i < 1024 ? M.w0[i] : (i < 2048 ? M.w1[i - 1024] : M.w2[i - 2048]);   // coalesced
     __syncthreads();
-    // A fragments (weights): lane (neuron j, half) holds W[j][k(kk, half, t)], with k() matching what the B fragment of that layer carries
-    half8_t wh[3][2], wl[3][2];
+    float wa[3][16];                                  // A fragments: W_l[j][2 s + half]
 #pragma unroll
     for (int l = 0; l < 3; l++) {
 #pragma unroll
-        for (int kk = 0; kk < 2; kk++) {
-            float w8[8];
-#pragma unroll
-            for (int t = 0; t < 8; t++) {
-                const int k = (l == 0) ? (kk * 16 + half * 8 + t) : mfma_row(kk * 8 + t, lane);
-                w8[t] = (l == 2 && j >= 6) ? 0.f : sW[l * 1024 + j * 32 + k];
-            }
-            split8(w8, wh[l][kk], wl[l][kk]);
-        }
+        for (int st = 0; st < 16; st++) wa[l][st] = (l == 2 && j >= 6) ? 0.f : sW[l * 1024 + j * 32 + 2 * st + half];
     }
     int prow[NT];
-    half8_t f[NT][2];
 #pragma unroll
-    for (int mt = 0; mt < NT; mt++) prow[mt] = wave * NT * 32 + mt * 32 + j;       // the point this lane carries in the B operand / accumulator column
-    // MODE 0 streams the features from HBM: the fragments of the next batch are requested as soon as layer 0 has consumed the current ones,
-    // so the load latency hides behind layers 1, 2 and the epilogue
+    for (int mt = 0; mt < NT; mt++) prow[mt] = wave * NT * 32 + mt * 32 + j;
+    half8_t f[NT][4];                                 // the 32 features of this lane's point (both halves of the wave hold the row; each picks its k parity)
     auto fetch = [&](int base_) {
 #pragma unroll
         for (int mt = 0; mt < NT; mt++) {
             const int q = base_ + prow[mt];
 #pragma unroll
-            for (int kk = 0; kk < 2; kk++) {
-                if (q < n) f[mt][kk] = *reinterpret_cast<const half8_t*>(enc_in + 32 * (size_t)q + kk * 16 + half * 8);
+            for (int c = 0; c < 4; c++) {
+                if (q < n) f[mt][c] = *reinterpret_cast<const half8_t*>(enc_in + 32 * (size_t)q + c * 8);
                 else {
 #pragma unroll
-                    for (int t = 0; t < 8; t++) f[mt][kk][t] = (_Float16)0.f;
+                    for (int t = 0; t < 8; t++) f[mt][c][t] = (_Float16)0.f;
                 }
             }
         }
@@ -228,50 +203,46 @@ __global__ void __launch_bounds__(MR_BLOCK) k_mlp_mfma(MatNetD M, GridLevels L, 
             p[mt] = base + prow[mt];
             if (MODE == 1) {
 #pragma unroll
-                for (int kk = 0; kk < 2; kk++) f[mt][kk] = *reinterpret_cast<const half8_t*>(sF + (size_t)prow[mt] * MR_FROW + kk * 16 + half * 8);
+                for (int c = 0; c < 4; c++) f[mt][c] = *reinterpret_cast<const half8_t*>(sF + (size_t)prow[mt] * MR_FROW + c * 8);
             }
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[mt][r] = 0.f;
         }
-        // ---- layer 0: B = fp16 features (exact), two weight terms
+        // ---- layer 0: B = features 2 s + half of the point (fp16 values, exact in fp32)
 #pragma unroll
-        for (int kk = 0; kk < 2; kk++) {
+        for (int st = 0; st < 16; st++) {
 #pragma unroll
-            for (int mt = 0; mt < NT; mt++) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[0][kk], f[mt][kk], acc[mt], 0, 0, 0);
-#pragma unroll
-            for (int mt = 0; mt < NT; mt++) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[0][kk], f[mt][kk], acc[mt], 0, 0, 0);
+            for (int mt = 0; mt < NT; mt++) {
+                const _Float16 e = half ? f[mt][st >> 2][2 * (st & 3) + 1] : f[mt][st >> 2][2 * (st & 3)];
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[0][st], (float)e, acc[mt], 0, 0, 0);
+            }
         }
         if (MODE == 0) fetch(base + gridDim.x * PTS);
-        // ---- layers 1, 2: ReLU + hi/lo split of the accumulator = next B operand
+        // ---- layers 1, 2: ReLU, halves swapped into (k, k + 1) pairs = next B operand
 #pragma unroll
         for (int l = 1; l < 3; l++) {
-            half8_t xh[NT][2], xl[NT][2];
+            float x[NT][16];
 #pragma unroll
             for (int mt = 0; mt < NT; mt++) {
 #pragma unroll
-                for (int kk = 0; kk < 2; kk++) {
-                    relu_split8(acc[mt], kk * 8, xh[mt][kk], xl[mt][kk]);
-                }
+                for (int r = 0; r < 16; r++) x[mt][r] = __int_as_float(max(__float_as_int(acc[mt][r]), 0));    // ReLU on the bit pattern (integer op: no read hazard games with the MFMA result)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) swap_halves(x[mt][r], x[mt][r + 1]);
 #pragma unroll
                 for (int r = 0; r < 16; r++) acc[mt][r] = 0.f;
             }
 #pragma unroll
-            for (int kk = 0; kk < 2; kk++) {
+            for (int st = 0; st < 16; st++) {
 #pragma unroll
-                for (int mt = 0; mt < NT; mt++) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[l][kk], xh[mt][kk], acc[mt], 0, 0, 0);
-#pragma unroll
-                for (int mt = 0; mt < NT; mt++) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[l][kk], xh[mt][kk], acc[mt], 0, 0, 0);
-#pragma unroll
-                for (int mt = 0; mt < NT; mt++) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[l][kk], xl[mt][kk], acc[mt], 0, 0, 0);
+                for (int mt = 0; mt < NT; mt++) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[l][st], x[mt][step_reg(st)], acc[mt], 0, 0, 0);
             }
         }
-        // ---- epilogue: rows 0..5 are the outputs: lanes 0-31 hold rows 0-3 (regs 0-3), lanes 32-63 rows 4,5 (regs 0,1). Three sigmoids per
-        // lane and tile: the lower half takes channels 0-2 (kd), the upper half channels 3-5 (channel 3 comes over from lane j; MODE 1 has no
-        // use for it and skips the shuffle)
+        // ---- epilogue: rows 0..5 are the outputs: lanes 0-31 hold rows 0-3 (regs 0-3), lanes 32-63 rows 4,5 (regs 0,1); sigmoid = the shared
+        // fixed arithmetic (include/mirres_fmath.h), the same bits as the per-lane kernel's
 #pragma unroll
         for (int mt = 0; mt < NT; mt++) {
             int px = 0;
-            if (MODE == 1) px = __shfl(pix, mt * 32 + j, 64);   // pixel id lives in the thread that encoded the point (same wave, lane mt*32+j)
+            if (MODE == 1) px = __shfl(pix, mt * 32 + j, 64);
             float a3 = 0.f;
             if (MODE == 0) a3 = __shfl(acc[mt][3], j, 64);
             const float a[3] = {half ? a3 : acc[mt][0], half ? acc[mt][0] : acc[mt][1], half ? acc[mt][1] : acc[mt][2]};
@@ -280,8 +251,7 @@ __global__ void __launch_bounds__(MR_BLOCK) k_mlp_mfma(MatNetD M, GridLevels L, 
 #pragma unroll
                 for (int r = 0; r < 3; r++) {
                     const float lo_ = half ? M.mn[3 + r] : M.mn[r], hi_ = half ? M.mx[3 + r] : M.mx[r];
-                    float sg = MR_SIGMOID(a[r]);
-                    o[r] = sg * (hi_ - lo_) + lo_;
+                    o[r] = mrf_sigmoid(a[r]) * (hi_ - lo_) + lo_;
                 }
                 if (MODE == 0) {
 #pragma unroll
@@ -296,7 +266,6 @@ __global__ void __launch_bounds__(MR_BLOCK) k_mlp_mfma(MatNetD M, GridLevels L, 
         if (MODE == 1) __syncthreads();
     }
 }
-
 // compacted list of pixels whose vertex needs a material lookup (occ >= 0.5): replaces torch.where (renderer_restir.py:398).
 // One queue-head word takes ~88 atomics per microsecond, so the list is built with ONE atomic per 4096 slots: a thread looks at 16 consecutive
 // slots (four 16-byte loads), the block scans the per-thread counts, and the indices go out in slot order (680 -> ~200 us for 82 M slots; with one
