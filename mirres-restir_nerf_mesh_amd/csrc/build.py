@@ -31,9 +31,15 @@ def _newer(a, deps):
 
 
 def build(force=False, verbose=True):
+    # MIRRES_BUILD_TAG=<tag>: an experiment variant (with MIRRES_*_FLAGS) into ab/libmirres_<tag>.so with its own objects; load it with MIRRES_LIB
+    tag = os.environ.get("MIRRES_BUILD_TAG", "")
+    global OUT
+    if tag:
+        os.makedirs(os.path.join(HERE, "..", "..", "ab"), exist_ok=True)
+        OUT = os.path.abspath(os.path.join(HERE, "..", "..", "ab", "libmirres_%s.so" % tag))
     srcs = sorted(f for f in os.listdir(HERE) if f.endswith(".hip"))
     hdrs = [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith(".hpp")] + [os.path.join(HERE, "..", "..", "include", f) for f in os.listdir(os.path.join(HERE, "..", "..", "include")) if f.endswith(".h")]
-    objdir = os.path.join(HERE, "obj")
+    objdir = os.path.join(HERE, "obj" + ("_" + tag if tag else ""))
     os.makedirs(objdir, exist_ok=True)
     jobs = []
     for s in srcs:

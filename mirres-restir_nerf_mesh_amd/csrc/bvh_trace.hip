@@ -538,8 +538,13 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const
         if (need && !exhausted) {
             if (chunk_next >= chunk_end) exhausted = !grab_chunk(work_head, n, q_per, chunk, q_cur, q_fail, chunk_next, chunk_end, lane);
             if (!exhausted) {
-                const uint32_t idx = chunk_next + (uint32_t)__popcll(need & lt_mask);
-                if (!have && idx < chunk_end) {
+                const uint32_t idx0 = chunk_next + (uint32_t)__popcll(need & lt_mask);
+#ifdef MR_EXP_PERMUTE   // experiment: queue position -> ray through a multiplicative permutation, i.e. a wave's lanes hold rays from all over the frame
+                const uint32_t idx = idx0 < n ? (uint32_t)(((unsigned long long)idx0 * 2654435761ull) % n) : idx0;
+#else
+                const uint32_t idx = idx0;
+#endif
+                if (!have && idx0 < chunk_end) {
                     const float4 a = reinterpret_cast<const float4*>(rays + idx)[0], b = reinterpret_cast<const float4*>(rays + idx)[1];
                     ridx = idx; ro = V3(a.x, a.y, a.z); t_min = a.w; t_max = b.w;
                     d = normalize(V3(b.x, b.y, b.z));

@@ -12,8 +12,15 @@ swap the border rows of their packed reservoirs (30 rows x fx x 32 B per directi
 neighbours). RNG streams are seeded with global pixel coordinates, so the rows a rank owns are bit-identical to the single-GPU frame; the six
 raw sums are all-gathered by rows and the (cheap) average + EAW + composite runs replicated on the whole frame."""
 import ctypes as C
+import os
 
 import torch
+
+
+def _forced():
+    """MIRRES_DIST_FORCE=1: run every collective even in a group of one rank (they degenerate to copies, but RCCL is loaded, the communicator is
+    built and its kernels are enqueued on the render's streams) — how the RCCL code path is exercised on a single-GPU box (tests/test_gpu_rccl.py)."""
+    return os.environ.get("MIRRES_DIST_FORCE", "0") == "1"
 
 
 def spp_slice(spp, rank, world):
@@ -26,7 +33,7 @@ def spp_slice(spp, rank, world):
 def allreduce_sums(sums, group=None):
     """Sum the six accumulators over ranks as ONE flat collective (184 MB at 1600x1600: large enough to be link-bandwidth bound)."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not _forced()):
         return sums
     flat = torch.cat([s.reshape(-1) for s in sums])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
@@ -47,7 +54,7 @@ def render_sharded(ctx, worker, mlp_mat, env_map, g, spp, random_offset, rank, w
     from .renderer_restir import render_fused
     b, e = spp_slice(spp, rank, world)
     occ = g["occ"].clone()
-    if world == 1:
+    if world == 1 and not _forced():
         outs, _, _ = render_fused(ctx, worker, mlp_mat, use_scale, scale, env_map, occ, g["normal"], g["depth"], g["kd"], g["rm"], g["ray_dir"], g["pos"], spp,
                                   denoise_iter, step_width, c_phi, n_phi, p_phi, random_offset)
         return outs
@@ -182,7 +189,7 @@ def render_strips(ctx_full, worker, mlp_mat, env_map, g, spp, random_offset, ran
     from ._ops import get_ctx
     from .renderer_restir import render_fused
     fx, fy = int(g["fx"]), int(g["fy"])
-    if world == 1:
+    if world == 1 and not _forced():
         outs, _, _ = render_fused(ctx_full, worker, mlp_mat, use_scale, scale, env_map, g["occ"].clone(), g["normal"], g["depth"], g["kd"], g["rm"], g["ray_dir"],
                                   g["pos"], spp, denoise_iter, step_width, c_phi, n_phi, p_phi, random_offset)
         return outs
@@ -253,7 +260,7 @@ def allreduce_gradients(tensors, group=None, average=True):
     by the per-link bandwidth of xGMI, so one large collective instead of one per tensor). `tensors` = parameters (their .grad is used; missing
     grads count as zero) or plain gradient tensors; updated in place."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not _forced()):
         return
     grads = []
     for t in tensors:

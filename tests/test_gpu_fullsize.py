@@ -189,3 +189,36 @@ def test_schedule_does_not_change_the_frame_at_full_size(big, scene_mod, monkeyp
         got = frame()
         for a, b in zip(ref, got):
             assert torch.equal(a, b)
+
+
+def test_configs4_shape_1024_512spp_three_indirect_bounces(big, scene_mod):
+    """BASELINE configs[4] on the one GPU of a test box: 336 k triangles, 1024 x 1024, 512 spp, THREE indirect bounces (4-vertex paths; the reference unrolls two,
+    here MAX_Bounce is a runtime parameter), hash-grid + MLP material field.  No oracle run at this size (hours): size-independent properties — finite, background
+    := 1, non-negative radiance, the same seed reproduces the frame bit for bit, and the third bounce adds energy to the indirect buffer without touching the
+    direct-lighting buffers (they do not depend on the path length: bit-equal between a 2- and a 3-bounce frame of the same seed)."""
+    v, t, W, RR, harness, torch = big
+    from mirres_restir_nerf_mesh_amd._ops import get_ctx
+    from mirres_restir_nerf_mesh_amd.render_helper import MLPTexture3D
+    params, w0, w1, w2 = scene_mod.make_matnet_params(seed=0)
+    mn, mx = scene_mod.material_min_max()
+    mlp = MLPTexture3D(torch.tensor([-1, -1, -1, 1, 1, 1], dtype=torch.float32), channels=6, min_max=(torch.from_numpy(mn).cuda(), torch.from_numpy(mx).cuda()), seed=1)
+    with torch.no_grad():
+        mlp.encoder.params.copy_(torch.from_numpy(params).cuda())
+        for i, w in zip((0, 2, 4), (w0, w1, w2)):
+            mlp.net.net[i].weight.copy_(torch.from_numpy(w).cuda())
+    g = harness.build_gbuffer(W, 1024, 1024, 1, mlp_mat=mlp)
+    env = torch.from_numpy(scene_mod.make_env(256, 512)).cuda()
+    def frame(bounces, spp, seed=2024):
+        ctx = get_ctx(g["fx"], g["fy"], max_bounce=bounces)
+        outs, _, _ = RR.render_fused(ctx, W, mlp, False, (1, 1, 1), env, g["occ"].clone(), g["normal"], g["depth"], g["kd"], g["rm"], g["ray_dir"], g["pos"], spp, 2, 2, 2.0, 0.1, 0.001, seed)
+        torch.cuda.synchronize()
+        return [o.clone() for o in outs]
+    three = frame(3, 512)
+    fg = g["occ"][:, 0] > 0.5
+    assert all(torch.isfinite(o).all() for o in three) and (three[0][~fg] == 1.0).all() and all((o >= 0).all() for o in three[1:])
+    again = frame(3, 512)
+    assert all(torch.equal(a, b) for a, b in zip(three, again))
+    two = frame(2, 512)
+    assert torch.equal(two[1], three[1]) and torch.equal(two[2], three[2])                      # direct diffuse / specular: independent of the path length
+    gain = float(three[3][fg].mean()) / float(two[3][fg].mean())
+    assert 1.005 < gain < 1.5, gain                                                            # the fourth vertex adds a few per cent of indirect light
