@@ -92,6 +92,7 @@ SIGNATURES = {
     "mirres_prepare_shading_normal_bwd": (C.c_int, [C.c_longlong, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]),
     "mirres_raster_raycast": (C.c_int, [vp, vp, C.c_int, vp, vp, vp, vp]),
     "mirres_interpolate": (C.c_int, [vp, C.c_int, vp, vp, C.c_int, vp, vp]),
+    "mirres_rasterize": (C.c_int, [vp, vp, vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_int, vp, vp, vp]),
     "mirres_interpolate_bwd": (C.c_int, [vp, C.c_int, vp, vp, C.c_int, vp, vp, vp, vp]),
     "mirres_texture2d": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, vp]),
     "mirres_texture2d_bwd": (C.c_int, [C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, vp, vp]),

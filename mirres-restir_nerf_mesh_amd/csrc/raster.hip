@@ -36,6 +36,71 @@ __global__ void __launch_bounds__(MR_BLOCK) k_rast_record(int n, const float* __
     reinterpret_cast<float4*>(rast)[i] = r;
 }
 
+// ---- dr.rasterize(glctx, pos_clip, tri, (H, W)) (nerf/renderer.py:983): the raster record of nvdiffrast for a clip-space vertex buffer.
+// Pixel (ix, iy) looks along the line NDC (x, y) = ((2 ix + 1) / W - 1, (2 iy + 1) / H - 1), z from -1 (near plane) to +1: its world-space pre-image
+// through the inverse model-view-projection matrix is the primary ray, cast through the path's BVH (world space: no second hierarchy over projected
+// vertices).  Record: perspective-correct barycentrics (u, v) = weights of v0, v1 — the world-space barycentrics of the hit —, z / w of the hit in clip
+// space (nvdiffrast's third channel), triangle id + 1.  rast_db = (du/dX, du/dY, dv/dX, dv/dY) per pixel step, central differences of the same
+// barycentrics on the hit triangle's plane half a pixel to either side (second-order accurate; nvdiffrast differentiates analytically).
+struct Mat4 { float m[16]; };   // row-major
+MR_DEV void mul4(const Mat4& M, float x, float y, float z, float w, float o[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) o[r] = ((M.m[4 * r] * x + M.m[4 * r + 1] * y) + M.m[4 * r + 2] * z) + M.m[4 * r + 3] * w;
+}
+MR_DEV void pixel_ray(const Mat4& Minv, float px, float py, int W, int H, v3& o, v3& d) {
+    const float x = (2.f * px) / W - 1.f, y = (2.f * py) / H - 1.f;
+    float a[4], b[4];
+    mul4(Minv, x, y, -1.f, 1.f, a); mul4(Minv, x, y, 1.f, 1.f, b);
+    o = V3(a[0] / a[3], a[1] / a[3], a[2] / a[3]);
+    d = V3(b[0] / b[3], b[1] / b[3], b[2] / b[3]) - o;
+}
+__global__ void __launch_bounds__(MR_BLOCK) k_rast_rays(Mat4 Minv, int W, int H, float* __restrict__ rays) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= W * H) return;
+    v3 o, d; pixel_ray(Minv, (i % W) + 0.5f, (i / W) + 0.5f, W, H, o, d);
+    float4 a, b; a.x = o.x; a.y = o.y; a.z = o.z; a.w = 0.f; b.x = d.x; b.y = d.y; b.z = d.z; b.w = 1e7f;
+    reinterpret_cast<float4*>(rays)[2 * (size_t)i] = a; reinterpret_cast<float4*>(rays)[2 * (size_t)i + 1] = b;
+}
+// barycentrics (weights of v0, v1) of the point where the line o + s d meets the plane of the triangle
+MR_DEV void plane_bary(v3 o, v3 d, v3 v0, v3 E1, v3 E2, float& b0, float& b1) {
+    const v3 P = cross(d, E2);
+    const float invDet = 1 / dot(E1, P);
+    const v3 Tv = o - v0;
+    const float u = dot(Tv, P) * invDet;
+    const float v = dot(d, cross(Tv, E1)) * invDet;
+    b0 = 1.f - u - v; b1 = u;
+}
+__global__ void __launch_bounds__(MR_BLOCK) k_rast_record_clip(Mat4 M, Mat4 Minv, int W, int H, const int32_t* __restrict__ hit, const float* __restrict__ t,
+                                                               const int32_t* __restrict__ prim, const float* __restrict__ vert, const int32_t* __restrict__ tri,
+                                                               float* __restrict__ rast, float* __restrict__ rast_db) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= W * H) return;
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f), db = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (hit[i] && t[i] > 0.f) {
+        const int p = prim[i];
+        const int32_t* ti = tri + 3 * (size_t)p;
+        const v3 v0 = ld3(vert, ti[0]), E1 = ld3(vert, ti[1]) - v0, E2 = ld3(vert, ti[2]) - v0;
+        const float px = (i % W) + 0.5f, py = (i / W) + 0.5f;
+        v3 o, d; pixel_ray(Minv, px, py, W, H, o, d);
+        float b0, b1; plane_bary(o, d, v0, E1, E2, b0, b1);
+        const v3 P = o + normalize(d) * t[i];                   // bvh_hit normalises the direction: t is a world-space distance
+        float c[4]; mul4(M, P.x, P.y, P.z, 1.f, c);
+        const float zw = c[2] / c[3];
+        if (zw <= 1.f) {                                        // beyond the far plane: clipped
+            r = make_float4(b0, b1, zw, (float)(p + 1));
+            float u0, v0_, u1, v1_;
+            pixel_ray(Minv, px - 0.5f, py, W, H, o, d); plane_bary(o, d, v0, E1, E2, u0, v0_);
+            pixel_ray(Minv, px + 0.5f, py, W, H, o, d); plane_bary(o, d, v0, E1, E2, u1, v1_);
+            db.x = u1 - u0; db.z = v1_ - v0_;
+            pixel_ray(Minv, px, py - 0.5f, W, H, o, d); plane_bary(o, d, v0, E1, E2, u0, v0_);
+            pixel_ray(Minv, px, py + 0.5f, W, H, o, d); plane_bary(o, d, v0, E1, E2, u1, v1_);
+            db.y = u1 - u0; db.w = v1_ - v0_;
+        }
+    }
+    reinterpret_cast<float4*>(rast)[i] = r;
+    if (rast_db) reinterpret_cast<float4*>(rast_db)[i] = db;
+}
+
 __global__ void __launch_bounds__(MR_BLOCK) k_interpolate(const float* __restrict__ attr, int C, const float* __restrict__ rast, const int32_t* __restrict__ tri, int n,
                                                           float* __restrict__ out) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -140,6 +205,29 @@ extern "C" int mirres_raster_raycast(mirres_bvh_t* bvh, const float* rays, int n
     int rc = mirres_bvh_trace(bvh, rays, n, 2, hit, t, nullptr, nullptr, prim, nullptr, stream); if (rc) return rc;
     k_rast_record<<<grid_for(n, MR_BLOCK), MR_BLOCK, 0, s>>>(n, rays, hit, t, prim, vert, tri, rast);
     MR_LAUNCH_CHECK("raster_raycast");
+    return MIRRES_OK;
+}
+
+extern "C" int mirres_rasterize(mirres_bvh_t* bvh, const float* vert, const int32_t* tri, const float* h_mvp, const float* h_mvp_inv, int W, int H,
+                                float* rast, float* rast_db, void* stream) {
+    if (!bvh || !vert || !tri || !h_mvp || !h_mvp_inv || W <= 0 || H <= 0 || !rast) { set_error("mirres_rasterize: bad argument"); return MIRRES_E_ARG; }
+    if (bvh->T < 2) { set_error("mirres_rasterize: BVH not built"); return MIRRES_E_STATE; }
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n = (size_t)W * H;
+    const size_t need = n * (32 + 12) + 256;           // rays + hit, t, prim of the frame (kept in the BVH object's scratch pool)
+    if (bvh->dump_pool_bytes < need) {
+        if (bvh->dump_pool) { MR_HIP(hipDeviceSynchronize()); MR_HIP(hipFree(bvh->dump_pool)); bvh->dump_pool = nullptr; bvh->dump_pool_bytes = 0; }
+        MR_HIP(hipMalloc(&bvh->dump_pool, need));
+        bvh->dump_pool_bytes = need;
+    }
+    float* rays = reinterpret_cast<float*>(bvh->dump_pool);
+    int32_t* hit = reinterpret_cast<int32_t*>(rays + 8 * n); float* t = reinterpret_cast<float*>(hit + n); int32_t* prim = reinterpret_cast<int32_t*>(t + n);
+    Mat4 M, Mi;
+    for (int k = 0; k < 16; k++) { M.m[k] = h_mvp[k]; Mi.m[k] = h_mvp_inv[k]; }
+    k_rast_rays<<<grid_for(n, MR_BLOCK), MR_BLOCK, 0, s>>>(Mi, W, H, rays);
+    int rc = mirres_bvh_trace(bvh, rays, (int)n, 2, hit, t, nullptr, nullptr, prim, nullptr, stream); if (rc) return rc;
+    k_rast_record_clip<<<grid_for(n, MR_BLOCK), MR_BLOCK, 0, s>>>(M, Mi, W, H, hit, t, prim, vert, tri, rast, rast_db);
+    MR_LAUNCH_CHECK("rasterize");
     return MIRRES_OK;
 }
 

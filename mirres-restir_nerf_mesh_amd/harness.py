@@ -34,8 +34,8 @@ def build_gbuffer(worker, H, W, ssaa=1, azimuth_deg=30.0, elevation_deg=30.0, kd
 
 
 def build_gbuffer_stage1(worker, vertices, triangles, H, W, ssaa=1, azimuth_deg=30.0, elevation_deg=30.0, mlp_mat=None, pose=None, intrinsics=None):
-    """The front half of render_stage1 (nerf/renderer.py:978-1022, 1083-1094) on the engine's own operators: raster record by casting the primary rays
-    (raster.rasterize_raycast, for dr.rasterize), xyzs / smooth normal / geometric normal by raster.interpolate (dr.interpolate), auto_normals,
+    """The front half of render_stage1 (nerf/renderer.py:978-1022, 1083-1094) on the engine's own operators: raster record by dr.rasterize's own call shape
+    (raster.dr.rasterize(glctx, vertices_clip, triangles, (h, w)) for a dataset camera; raster.rasterize_raycast for the synthetic orbit view), xyzs / smooth normal / geometric normal by raster.interpolate (dr.interpolate), auto_normals,
     renderutils.prepare_shading_normal, safe_normalize, material field. Differentiable w.r.t. `vertices` through the interpolations and the material
     field's position gradient. Returns the dict build_gbuffer returns, plus `rast`.  Camera: the synthetic orbit view (azimuth / elevation), or a
     dataset camera (`pose` [4,4] cam2world + `intrinsics` (fx, fy, cx, cy) at H x W) — then the dict also carries `mvp` (mvp_from_pose at the internal
@@ -52,12 +52,16 @@ def build_gbuffer_stage1(worker, vertices, triangles, H, W, ssaa=1, azimuth_deg=
         eye_t = pose[:3, 3].to(torch.float32).contiguous(); eye = eye_t.detach().cpu().numpy()
         mvp = mvp_from_pose(pose, (fx_, fy_, cx_, cy_), h, w)
         cam = dict(mvp=mvp, vertices_clip=torch.cat((vertices, torch.ones_like(vertices[:, :1])), dim=1) @ mvp.t())      # :981
+        # rast, rast_out_deriv_s = dr.rasterize(self.glctx, vertices_clip, self.triangles, (h, w))                          # :983 — the reference's call, unchanged
+        rast4, rast_db = raster.dr.rasterize(raster.RasterizeContext(worker), cam["vertices_clip"].unsqueeze(0), triangles, (h, w))
+        rast = rast4.view(h * w, 4)
+        cam["rast_db"] = rast_db
     else:
         eye, rd = scene.camera_rays(h, w, azimuth_deg, elevation_deg)
         rays_d = torch.from_numpy(rd).to(dev)
         eye_t = torch.from_numpy(eye).to(dev)
         rays_o = eye_t[None].expand(h * w, 3).contiguous()
-    rast = raster.rasterize_raycast(worker, rays_o, rays_d)
+        rast = raster.rasterize_raycast(worker, rays_o, rays_d)      # the synthetic orbit view has no projection matrix: the same record from explicit rays
     tri = triangles.to(torch.int32)
     xyzs = raster.interpolate(vertices, rast, tri)                                                         # :985
     v_nrm, t_nrm_idx = raster.auto_normals(vertices, tri)                                                  # :978

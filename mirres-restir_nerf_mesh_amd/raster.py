@@ -10,6 +10,8 @@ interpolation with gradients to the vertex attributes, smooth vertex normals —
 
     topo = antialias_topology(triangles)                      # once per index buffer
     img = antialias(img.view(1, h, w, 3), rast.view(1, h, w, 4), vertices_clip, triangles, topology_hash=topo, pos_gradient_boost=...)   # dr.antialias (:1184-1206)"""
+import ctypes as C
+
 import torch
 
 from ._lib import lib, check, stream_ptr
@@ -25,6 +27,44 @@ def rasterize_raycast(worker, rays_o, rays_d):
     vert = worker.vrt.detach().float().contiguous(); tri = worker.v_ind.detach().to(torch.int32).contiguous()
     check(lib().mirres_raster_raycast(worker.h, rays.data_ptr(), n, vert.data_ptr(), tri.data_ptr(), rast.data_ptr(), stream_ptr()), "mirres_raster_raycast")
     return rast
+
+
+class RasterizeContext:
+    """What the reference creates as `dr.RasterizeGLContext()` / `dr.RasterizeCudaContext()` (nerf/renderer.py:186-190) and passes to dr.rasterize as
+    `glctx`: here it names the restirbvhWorker whose BVH (world space, rebuilt by update_mesh at :975 just before) the primary rays are cast through."""
+    def __init__(self, worker=None):
+        self.worker = worker
+
+
+@torch.no_grad()
+def rasterize(glctx, pos, tri, resolution, ranges=None, grad_db=True, mvp=None):
+    """dr.rasterize(glctx, pos, tri, resolution) (nerf/renderer.py:983): pos f32[1,V,4] (or [V,4]) clip-space vertices = pad(vertices, 1) @ mvp^T, tri
+    i32[T,3], resolution (h, w) -> (rast [1,h,w,4], rast_db [1,h,w,4]) in nvdiffrast's layout: (u, v, z/w, triangle_id + 1) with perspective-correct
+    barycentrics, and (du/dX, du/dY, dv/dX, dv/dY).  `glctx` = RasterizeContext(worker) whose worker holds the same mesh in world space (worker.vrt);
+    the model-view-projection matrix is `mvp` [4,4] if given, else recovered from (worker.vrt, pos) — pos is an exact linear image of the vertices, so
+    a float64 least-squares fit returns the matrix to rounding.  Not differentiable (neither is nvdiffrast's: gradients enter through dr.interpolate
+    and dr.antialias).  Triangles crossing the near plane are not clipped: a hit nearer than the near plane hides what lies behind it."""
+    if ranges is not None:
+        raise NotImplementedError("rasterize: range mode (instanced minibatches) is not used by the path")
+    worker = glctx.worker if isinstance(glctx, RasterizeContext) else glctx
+    if worker is None or not hasattr(worker, "vrt"):
+        raise ValueError("rasterize: glctx must be a RasterizeContext holding the restirbvhWorker of this mesh")
+    p = pos.detach().reshape(-1, 4)
+    vert = worker.vrt.detach().float().contiguous(); t32 = tri.detach().to(torch.int32).contiguous()
+    if p.shape[0] != vert.shape[0]:
+        raise ValueError("rasterize: %d clip-space vertices for a BVH over %d vertices" % (p.shape[0], vert.shape[0]))
+    h, w = int(resolution[0]), int(resolution[1])
+    if mvp is None:
+        A = torch.cat((vert, torch.ones_like(vert[:, :1])), dim=1).double()
+        step = max(1, A.shape[0] // 4096)
+        mvp = torch.linalg.lstsq(A[::step], p[::step].double()).solution.t()            # p = A @ mvp^T
+    M = mvp.detach().double().cpu()
+    Mi = torch.linalg.inv(M)
+    cm = (C.c_float * 16)(*[float(x) for x in M.reshape(-1)]); cmi = (C.c_float * 16)(*[float(x) for x in Mi.reshape(-1)])
+    rast = torch.empty((h * w, 4), dtype=torch.float32, device=vert.device)
+    rast_db = torch.empty((h * w, 4), dtype=torch.float32, device=vert.device) if grad_db else None
+    check(lib().mirres_rasterize(worker.h, vert.data_ptr(), t32.data_ptr(), cm, cmi, w, h, rast.data_ptr(), rast_db.data_ptr() if grad_db else None, stream_ptr()), "mirres_rasterize")
+    return rast.view(1, h, w, 4), (rast_db.view(1, h, w, 4) if grad_db else torch.zeros((1, h, w, 0), device=vert.device))
 
 
 class _Interpolate(torch.autograd.Function):
@@ -56,6 +96,36 @@ class _Interpolate(torch.autograd.Function):
 def interpolate(attr, rast, tri):
     """dr.interpolate(attr[None], rast, tri)[0] for one image flattened to [n,4] / [n,C]: attr f32[V,C] -> f32[n,C]; zeros where rast's triangle id is 0."""
     return _Interpolate.apply(attr, rast, tri)
+
+
+def dr_interpolate(attr, rast, tri, rast_db=None, diff_attrs=None):
+    """dr.interpolate(attr, rast, tri, rast_db=None, diff_attrs=None) with nvdiffrast's shapes: attr [1,V,C] (or [V,C]), rast [1,h,w,4] -> (out [1,h,w,C],
+    out_db).  out_db = image-space derivatives [1,h,w,2 C'] = (da/dX, da/dY) per selected attribute when `rast_db` is given AND `diff_attrs` selects
+    attributes ('all' or a list of indices); with diff_attrs=None it is an EMPTY tensor, as in nvdiffrast — which is what nerf/renderer.py:1074 receives
+    (it passes rast_db but no diff_attrs, and :1078-1079 then substitutes ones for the empty gradient)."""
+    a = attr.reshape(-1, attr.shape[-1])
+    shp = rast.shape[:-1]
+    r = rast.reshape(-1, 4)
+    out = interpolate(a, r, tri).view(*shp, a.shape[1])
+    if rast_db is None or diff_attrs is None:
+        return out, torch.zeros((*shp, 0), dtype=out.dtype, device=out.device)
+    sel = list(range(a.shape[1])) if diff_attrs == "all" else [int(i) for i in diff_attrs]
+    idx = (r[:, 3].long() - 1).clamp(min=0)
+    t = tri.to(torch.int64)[idx]
+    a0, a1, a2 = a[t[:, 0]][:, sel], a[t[:, 1]][:, sel], a[t[:, 2]][:, sel]
+    db = rast_db.reshape(-1, 4)
+    on = (r[:, 3:4] > 0).to(a.dtype)
+    dX = (db[:, 0:1] * (a0 - a2) + db[:, 2:3] * (a1 - a2)) * on
+    dY = (db[:, 1:2] * (a0 - a2) + db[:, 3:4] * (a1 - a2)) * on
+    return out, torch.stack((dX, dY), dim=-1).reshape(*shp, 2 * len(sel))
+
+
+def dr_texture(tex, uv, filter_mode="linear", boundary_mode="clamp"):
+    """dr.texture(tex [1,H,W,C], uv [1,h,w,2], filter_mode='linear', boundary_mode='clamp') -> [1,h,w,C] (nerf/renderer.py:1003-1008)."""
+    if filter_mode != "linear" or boundary_mode != "clamp":
+        raise NotImplementedError("texture: the path uses filter_mode='linear', boundary_mode='clamp' only")
+    t = tex.reshape(tex.shape[-3], tex.shape[-2], tex.shape[-1])
+    return texture(t, uv).view(*uv.shape[:-1], t.shape[-1])
 
 
 def auto_normals(v_pos, t_pos_idx):
@@ -168,3 +238,17 @@ def antialias(color, rast, pos, tri, topology_hash=None, pos_gradient_boost=1.0)
         raise ValueError("antialias: topology_hash must be antialias_topology(tri) (i32[T,3])")
     out = _Antialias.apply(color.reshape(H * W, C_), rast.reshape(H * W, 4), p, tri, topology_hash.contiguous(), int(H), int(W), float(pos_gradient_boost))
     return out.view(shape)
+
+
+class _Dr:
+    """`import nvdiffrast.torch as dr` of nerf/renderer.py, on the engine's own operators: dr.RasterizeCudaContext / RasterizeGLContext, dr.rasterize,
+    dr.interpolate, dr.texture, dr.antialias with nvdiffrast's argument order and tensor shapes."""
+    RasterizeCudaContext = RasterizeContext
+    RasterizeGLContext = RasterizeContext
+    rasterize = staticmethod(rasterize)
+    interpolate = staticmethod(dr_interpolate)
+    texture = staticmethod(dr_texture)
+    antialias = staticmethod(antialias)
+
+
+dr = _Dr()

@@ -21,6 +21,10 @@ What can be imported of the hot path: everything else is Slang->CU
   * meshutils.py:auto_normals (+ length / dot / safe_normalize) — smooth vertex normals of the G-buffer front end, by AST
     (the module imports pymeshlab); `device='cuda'` of its fallback normal redirected to CPU.
   * nerf/utils.py:linear2srgb_torch (+ _clip_0to1_warn_torch) — the tone curve of the harness (SURVEY §8 a-H), taken by AST like above.
+  * nerf/renderutils/ops.py:prepare_shading_normal(..., use_python=True) — the reference's own pure-torch validation path of its CUDA plugin
+    (bsdf_prepare_shading_normal, :84-121; the module imports without building anything, _get_plugin() is never called): forward for the four flag
+    combinations incl. zero-length inputs, and autograd gradients of all six inputs -> tests/golden/ref_shading_normal.npz, which pins the numpy
+    restatement (oracle.prepare_shading_normal) and the HIP operator (csrc/normal.hip) — SURVEY §8 f-3.
 The fixtures are data (inputs + outputs); no reference source text is stored.
 
     python tests/golden/gen_from_reference.py
@@ -52,6 +56,38 @@ def load_function(path, name, namespace):
     code = compile(ast.Module(body=[fn], type_ignores=[]), os.path.join(REF, path), "exec")
     exec(code, namespace)
     return namespace[name]
+
+
+def shading_normal():
+    """nerf/renderutils/ops.py through its use_python=True path (never _get_plugin()): forward (four flag combinations) + autograd gradients."""
+    ops = load("nerf/renderutils/ops.py", "ref_renderutils_ops")
+    rng = np.random.default_rng(2)
+    shape = (1, 12, 17, 3)
+    mk = lambda: rng.normal(size=shape).astype(np.float32)
+    pos, sn, st, gn, pn = mk(), mk(), mk(), mk(), mk()
+    pn[..., 2] = np.abs(pn[..., 2]); pn[0, 0, :4, 2] = -0.3                  # some negative z (clamped)
+    sn[0, 1, 0] = 0; st[0, 1, 1] = 0                                          # zero-length inputs: F.normalize returns 0
+    view = np.array([0.5, -2.0, 3.0], np.float32).reshape(1, 1, 1, 3)
+    t = lambda a: torch.from_numpy(a.copy())
+    out = {"pos": pos, "view": view, "perturbed": pn, "smooth_nrm": sn, "smooth_tng": st, "geom_nrm": gn}
+    for two_sided in (True, False):
+        for opengl in (True, False):
+            o = ops.prepare_shading_normal(t(pos), t(view), t(pn), t(sn), t(st), t(gn), two_sided, opengl, use_python=True)
+            out["fwd_%d%d" % (two_sided, opengl)] = o.numpy()
+    default_p = np.array([0, 0, 1], np.float32).reshape(1, 1, 1, 3)            # what perturbed_nrm=None stands for (:148-149 builds it on 'cuda')
+    out["fwd_default_perturbation"] = ops.prepare_shading_normal(t(pos), t(view), t(default_p), t(sn), t(st), t(gn), True, True, use_python=True).numpy()
+    # gradients (rows 2.. : away from the zero-length rows, whose derivative torch defines through the eps clamp of F.normalize)
+    w = rng.normal(size=(1, 10, 17, 3)).astype(np.float32)
+    sl = (slice(None), slice(2, None))
+    for two_sided, opengl in ((True, True), (False, False)):
+        ins = [t(a[sl] if a.shape[1] > 1 else a).requires_grad_(True) for a in (pos, view, pn, sn, st, gn)]
+        o = ops.prepare_shading_normal(*ins, two_sided, opengl, use_python=True)
+        (o * t(w)).sum().backward()
+        for name, a in zip(("pos", "view", "perturbed", "smooth_nrm", "smooth_tng", "geom_nrm"), ins):
+            out["grad_%d%d_%s" % (two_sided, opengl, name)] = a.grad.numpy()
+    out["grad_weight"] = w
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "ref_shading_normal.npz"), **out)
+    print("wrote ref_shading_normal.npz")
 
 
 def config1(O, rd):
@@ -114,6 +150,9 @@ def config1(O, rd):
 
 
 def main():
+    if "--only-shading-normal" in sys.argv:
+        shading_normal()
+        return
     from oracle import oracle as O
     rd = load("nerf/render_dump.py", "ref_render_dump")
     glt = load("nerf/ScreenSpaceReSTIR/GenerateLightTiles.py", "ref_glt")
@@ -244,6 +283,7 @@ def main():
                         eaw_dims=np.array([fx, fy], np.int32), eaw_occ=occ, eaw_col=col, eaw_nrm=nrm, eaw_pos=pos, eaw_di=eaw_di, eaw_nodi=eaw_nodi,
                         eaw_steps=np.array(launches, np.int32))
     print("wrote ref_python.npz")
+    shading_normal()
     if "--skip-config1" not in sys.argv:
         config1(O, rd)   # ~4 min: 800 k rays against 1 408 triangles by brute force
 

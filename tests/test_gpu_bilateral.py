@@ -121,3 +121,30 @@ def test_prepare_shading_normal_forward_and_backward(oracle):
     (formula(*ins64, True, True) * torch.from_numpy(w.astype(np.float64))).sum().backward()
     for name, a, b in zip(("pos", "view_pos", "perturbed", "smooth_nrm", "smooth_tng", "geom_nrm"), ins32, ins64):
         np.testing.assert_allclose(a.grad.cpu().numpy(), b.grad.numpy(), rtol=2e-3, atol=2e-4, err_msg=name)
+
+
+def test_prepare_shading_normal_matches_the_reference_python_path():
+    """csrc/normal.hip through renderutils.ops.prepare_shading_normal (the reference's call shape) against tests/golden/ref_shading_normal.npz: outputs AND
+    gradients of the REFERENCE's own pure-torch implementation (nerf/renderutils/ops.py, use_python=True; tests/golden/gen_from_reference.py) — forward for the
+    four flag combinations incl. zero-length inputs and the default perturbation, backward for every input under both flag settings."""
+    import os
+    import torch
+    from mirres_restir_nerf_mesh_amd.renderutils.ops import prepare_shading_normal
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_shading_normal.npz"))
+    names = ("pos", "view", "perturbed", "smooth_nrm", "smooth_tng", "geom_nrm")
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    args = [g[k] for k in names]
+    for two_sided in (True, False):
+        for opengl in (True, False):
+            got = prepare_shading_normal(*[cu(a) for a in args], two_sided, opengl).cpu().numpy()
+            np.testing.assert_allclose(got, g["fwd_%d%d" % (two_sided, opengl)], rtol=1e-5, atol=1e-6)   # torch.lerp vs normal.cu's a (1 - t) + b t: last-bit differences
+    got = prepare_shading_normal(cu(args[0]), cu(args[1]), None, *[cu(a) for a in args[3:]]).cpu().numpy()
+    np.testing.assert_allclose(got, g["fwd_default_perturbation"], rtol=1e-5, atol=1e-6)
+    sl = (slice(None), slice(2, None))
+    for two_sided, opengl in ((True, True), (False, False)):
+        ins = [cu(a[sl] if a.shape[1] > 1 else a).requires_grad_(True) for a in args]
+        out = prepare_shading_normal(*ins, two_sided, opengl)
+        (out * cu(g["grad_weight"])).sum().backward()
+        for name, a in zip(names, ins):
+            ref = g["grad_%d%d_%s" % (two_sided, opengl, name)]
+            np.testing.assert_allclose(a.grad.cpu().numpy(), ref, rtol=2e-4, atol=2e-5 * max(1.0, float(np.abs(ref).max())), err_msg="%s %d%d" % (name, two_sided, opengl))

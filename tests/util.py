@@ -206,3 +206,39 @@ def same_bits(got, ref, what):
             f.write("%s: %d of %d values differ in bits (max abs diff %.3e)\n" % (what, int(bad.sum()), bad.size, float(np.nanmax(np.abs(g - r))) if bad.any() else 0.0))
     assert not bad.any(), "%s: %d of %d values differ (first at %d: %r vs %r, max abs diff %.3e)" % (
         what, int(bad.sum()), bad.size, int(np.argmax(bad)), g[np.argmax(bad)], r[np.argmax(bad)], float(np.nanmax(np.abs(g - r))))
+
+
+def rasterize_ref(pos_clip, tri, H, W):
+    """Software rasteriser in numpy float64 (test reference for raster.rasterize, written from nvdiffrast's published output contract): for every pixel centre
+    NDC ((2 ix + 1) / W - 1, (2 iy + 1) / H - 1) the front-most triangle (smallest z/w in [-1, 1]) among those whose projected 2-D triangle contains it;
+    record (u, v, z/w, id + 1) with perspective-correct barycentrics u, v = weights of v0, v1.  Also returns `margin`: the smallest absolute screen-space
+    barycentric of the winner and the z/w gap to the runner-up (pixels with tiny margins may legitimately resolve differently in float32)."""
+    p = np.asarray(pos_clip, np.float64); t = np.asarray(tri, np.int64)
+    ndc = p[:, :3] / p[:, 3:4]; wv = p[:, 3]
+    xs = (2 * np.arange(W) + 1) / W - 1; ys = (2 * np.arange(H) + 1) / H - 1
+    px, py = np.meshgrid(xs, ys); px = px.ravel(); py = py.ravel()
+    n = H * W
+    best_z = np.full(n, np.inf); second_z = np.full(n, np.inf); rast = np.zeros((n, 4)); edge = np.full(n, np.inf)
+    a, b, c = ndc[t[:, 0]], ndc[t[:, 1]], ndc[t[:, 2]]
+    area = (b[:, 0] - a[:, 0]) * (c[:, 1] - a[:, 1]) - (b[:, 1] - a[:, 1]) * (c[:, 0] - a[:, 0])
+    for k in range(len(t)):
+        if area[k] == 0 or (wv[t[k]] <= 0).any():
+            continue
+        w0 = ((b[k, 0] - px) * (c[k, 1] - py) - (b[k, 1] - py) * (c[k, 0] - px)) / area[k]
+        w1 = ((c[k, 0] - px) * (a[k, 1] - py) - (c[k, 1] - py) * (a[k, 0] - px)) / area[k]
+        w2 = 1 - w0 - w1
+        inside = (w0 >= 0) & (w1 >= 0) & (w2 >= 0)
+        if not inside.any():
+            continue
+        z = w0 * a[k, 2] + w1 * b[k, 2] + w2 * c[k, 2]
+        ok = inside & (z >= -1) & (z <= 1)
+        closer = ok & (z < best_z)
+        second_z = np.where(closer, best_z, np.where(ok & (z < second_z), z, second_z))
+        q0, q1, q2 = w0 / wv[t[k, 0]], w1 / wv[t[k, 1]], w2 / wv[t[k, 2]]
+        s = q0 + q1 + q2
+        rast[closer] = np.stack([q0 / s, q1 / s, z, np.full(n, k + 1.0)], 1)[closer]
+        edge = np.where(closer, np.minimum(np.minimum(w0, w1), w2), edge)
+        best_z = np.where(closer, z, best_z)
+    with np.errstate(invalid="ignore"):
+        gap = second_z - best_z
+    return rast, edge, gap
