@@ -177,12 +177,13 @@ int mirres_dump_render(mirres_bvh_t* bvh, int n, int L, const float* pos, const 
  * :998): out f32[n,C] = u a[i0] + v a[i1] + (1-u-v) a[i2] (0 where triangle_id = 0); the backward ACCUMULATES into g_attr f32[V,C] and writes
  * g_uv f32[n,2] (either may be NULL). dr.texture and dr.antialias are not provided.                                                      */
 int mirres_raster_raycast(mirres_bvh_t* bvh, const float* rays, int n, const float* vert, const int32_t* tri, float* rast, void* stream);
-/* dr.rasterize(glctx, pos_clip, tri, (H, W)) itself (nerf/renderer.py:983; with rast_db as :1074 hands it to dr.interpolate): h_mvp / h_mvp_inv = HOST
- * float[16], row-major, clip = mvp * (world, 1) — the matrix behind pos_clip = pad(vertices) @ mvp^T (:981) and its inverse.  Pixel (ix, iy) of the W x H
+/* dr.rasterize(glctx, pos_clip, tri, (H, W)) itself (nerf/renderer.py:983; with rast_db as :1074 hands it to dr.interpolate): h_mvp = HOST float[16],
+ * row-major, clip = mvp * (world, 1) — the matrix behind pos_clip = pad(vertices) @ mvp^T (:981), a perspective projection; h_eye = HOST float[3], the
+ * world-space point with x_c = y_c = w_c = 0 (the eye: every pixel's line passes through it).  Pixel (ix, iy) of the W x H
  * image looks along NDC ((2 ix + 1) / W - 1, (2 iy + 1) / H - 1); its world-space line is cast through the BVH (the world-space vert / tri it was built
  * from).  rast f32[H*W,4] = (u, v, z/w, triangle_id + 1) with perspective-correct barycentrics (weights of v0, v1) and the clip-space depth of the hit;
  * rast_db f32[H*W,4] = (du/dX, du/dY, dv/dX, dv/dY) per pixel, or NULL.  Hits behind the near plane or beyond the far plane give an empty record.   */
-int mirres_rasterize(mirres_bvh_t* bvh, const float* vert, const int32_t* tri, const float* h_mvp, const float* h_mvp_inv, int W, int H,
+int mirres_rasterize(mirres_bvh_t* bvh, const float* vert, const int32_t* tri, const float* h_mvp, const float* h_eye, int W, int H,
                      float* rast, float* rast_db, void* stream);
 int mirres_interpolate(const float* attr, int C, const float* rast, const int32_t* tri, int n, float* out, void* stream);
 int mirres_interpolate_bwd(const float* attr, int C, const float* rast, const int32_t* tri, int n, const float* g_out, float* g_attr, float* g_uv, void* stream);

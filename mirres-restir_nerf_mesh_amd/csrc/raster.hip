@@ -37,8 +37,8 @@ __global__ void __launch_bounds__(MR_BLOCK) k_rast_record(int n, const float* __
 }
 
 // ---- dr.rasterize(glctx, pos_clip, tri, (H, W)) (nerf/renderer.py:983): the raster record of nvdiffrast for a clip-space vertex buffer.
-// Pixel (ix, iy) looks along the line NDC (x, y) = ((2 ix + 1) / W - 1, (2 iy + 1) / H - 1), z from -1 (near plane) to +1: its world-space pre-image
-// through the inverse model-view-projection matrix is the primary ray, cast through the path's BVH (world space: no second hierarchy over projected
+// Pixel (ix, iy) looks along the line NDC (x, y) = ((2 ix + 1) / W - 1, (2 iy + 1) / H - 1): its world-space pre-image, a line through the eye, is the
+// primary ray, cast through the path's BVH (world space: no second hierarchy over projected
 // vertices).  Record: perspective-correct barycentrics (u, v) = weights of v0, v1 — the world-space barycentrics of the hit —, z / w of the hit in clip
 // space (nvdiffrast's third channel), triangle id + 1.  rast_db = (du/dX, du/dY, dv/dX, dv/dY) per pixel step, central differences of the same
 // barycentrics on the hit triangle's plane half a pixel to either side (second-order accurate; nvdiffrast differentiates analytically).
@@ -47,17 +47,22 @@ MR_DEV void mul4(const Mat4& M, float x, float y, float z, float w, float o[4]) 
 #pragma unroll
     for (int r = 0; r < 4; r++) o[r] = ((M.m[4 * r] * x + M.m[4 * r + 1] * y) + M.m[4 * r + 2] * z) + M.m[4 * r + 3] * w;
 }
-MR_DEV void pixel_ray(const Mat4& Minv, float px, float py, int W, int H, v3& o, v3& d) {
+// The line a pixel looks along needs only the x, y and w rows of the matrix: NDC x = x_c / w_c means (row_x - x row_w) . (P, 1) = 0, likewise for y — two planes
+// through the eye (the point where x_c = y_c = w_c = 0, solved on the host in double precision); the direction is the cross product of their normals, turned
+// towards increasing w.  The z row — ill-conditioned for far / near = 2 10^4, and through the inverse matrix it would spoil the directions too — enters the z / w
+// output only.  `eye` travels in Mat4::m[12..14] of the second argument, rows x, y, w in m[0..11].
+MR_DEV void pixel_ray(const Mat4& R, float px, float py, int W, int H, v3& o, v3& d) {
     const float x = (2.f * px) / W - 1.f, y = (2.f * py) / H - 1.f;
-    float a[4], b[4];
-    mul4(Minv, x, y, -1.f, 1.f, a); mul4(Minv, x, y, 1.f, 1.f, b);
-    o = V3(a[0] / a[3], a[1] / a[3], a[2] / a[3]);
-    d = V3(b[0] / b[3], b[1] / b[3], b[2] / b[3]) - o;
+    const v3 rx = V3(R.m[0], R.m[1], R.m[2]), ry = V3(R.m[4], R.m[5], R.m[6]), rw = V3(R.m[8], R.m[9], R.m[10]);
+    const v3 n1 = rx - rw * x, n2 = ry - rw * y;
+    d = cross(n1, n2);
+    if (dot(rw, d) < 0.f) d = -d;
+    o = V3(R.m[12], R.m[13], R.m[14]);
 }
-__global__ void __launch_bounds__(MR_BLOCK) k_rast_rays(Mat4 Minv, int W, int H, float* __restrict__ rays) {
+__global__ void __launch_bounds__(MR_BLOCK) k_rast_rays(Mat4 R, int W, int H, float* __restrict__ rays) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= W * H) return;
-    v3 o, d; pixel_ray(Minv, (i % W) + 0.5f, (i / W) + 0.5f, W, H, o, d);
+    v3 o, d; pixel_ray(R, (i % W) + 0.5f, (i / W) + 0.5f, W, H, o, d);
     float4 a, b; a.x = o.x; a.y = o.y; a.z = o.z; a.w = 0.f; b.x = d.x; b.y = d.y; b.z = d.z; b.w = 1e7f;
     reinterpret_cast<float4*>(rays)[2 * (size_t)i] = a; reinterpret_cast<float4*>(rays)[2 * (size_t)i + 1] = b;
 }
@@ -70,7 +75,7 @@ MR_DEV void plane_bary(v3 o, v3 d, v3 v0, v3 E1, v3 E2, float& b0, float& b1) {
     const float v = dot(d, cross(Tv, E1)) * invDet;
     b0 = 1.f - u - v; b1 = u;
 }
-__global__ void __launch_bounds__(MR_BLOCK) k_rast_record_clip(Mat4 M, Mat4 Minv, int W, int H, const int32_t* __restrict__ hit, const float* __restrict__ t,
+__global__ void __launch_bounds__(MR_BLOCK) k_rast_record_clip(Mat4 M, Mat4 R, int W, int H, const int32_t* __restrict__ hit, const float* __restrict__ t,
                                                                const int32_t* __restrict__ prim, const float* __restrict__ vert, const int32_t* __restrict__ tri,
                                                                float* __restrict__ rast, float* __restrict__ rast_db) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -81,19 +86,19 @@ __global__ void __launch_bounds__(MR_BLOCK) k_rast_record_clip(Mat4 M, Mat4 Minv
         const int32_t* ti = tri + 3 * (size_t)p;
         const v3 v0 = ld3(vert, ti[0]), E1 = ld3(vert, ti[1]) - v0, E2 = ld3(vert, ti[2]) - v0;
         const float px = (i % W) + 0.5f, py = (i / W) + 0.5f;
-        v3 o, d; pixel_ray(Minv, px, py, W, H, o, d);
+        v3 o, d; pixel_ray(R, px, py, W, H, o, d);
         float b0, b1; plane_bary(o, d, v0, E1, E2, b0, b1);
         const v3 P = o + normalize(d) * t[i];                   // bvh_hit normalises the direction: t is a world-space distance
         float c[4]; mul4(M, P.x, P.y, P.z, 1.f, c);
         const float zw = c[2] / c[3];
-        if (zw <= 1.f) {                                        // beyond the far plane: clipped
+        if (zw >= -1.f && zw <= 1.f) {                          // nearer than the near plane / beyond the far plane: clipped
             r = make_float4(b0, b1, zw, (float)(p + 1));
             float u0, v0_, u1, v1_;
-            pixel_ray(Minv, px - 0.5f, py, W, H, o, d); plane_bary(o, d, v0, E1, E2, u0, v0_);
-            pixel_ray(Minv, px + 0.5f, py, W, H, o, d); plane_bary(o, d, v0, E1, E2, u1, v1_);
+            pixel_ray(R, px - 0.5f, py, W, H, o, d); plane_bary(o, d, v0, E1, E2, u0, v0_);
+            pixel_ray(R, px + 0.5f, py, W, H, o, d); plane_bary(o, d, v0, E1, E2, u1, v1_);
             db.x = u1 - u0; db.z = v1_ - v0_;
-            pixel_ray(Minv, px, py - 0.5f, W, H, o, d); plane_bary(o, d, v0, E1, E2, u0, v0_);
-            pixel_ray(Minv, px, py + 0.5f, W, H, o, d); plane_bary(o, d, v0, E1, E2, u1, v1_);
+            pixel_ray(R, px, py - 0.5f, W, H, o, d); plane_bary(o, d, v0, E1, E2, u0, v0_);
+            pixel_ray(R, px, py + 0.5f, W, H, o, d); plane_bary(o, d, v0, E1, E2, u1, v1_);
             db.y = u1 - u0; db.w = v1_ - v0_;
         }
     }
@@ -208,9 +213,9 @@ extern "C" int mirres_raster_raycast(mirres_bvh_t* bvh, const float* rays, int n
     return MIRRES_OK;
 }
 
-extern "C" int mirres_rasterize(mirres_bvh_t* bvh, const float* vert, const int32_t* tri, const float* h_mvp, const float* h_mvp_inv, int W, int H,
+extern "C" int mirres_rasterize(mirres_bvh_t* bvh, const float* vert, const int32_t* tri, const float* h_mvp, const float* h_eye, int W, int H,
                                 float* rast, float* rast_db, void* stream) {
-    if (!bvh || !vert || !tri || !h_mvp || !h_mvp_inv || W <= 0 || H <= 0 || !rast) { set_error("mirres_rasterize: bad argument"); return MIRRES_E_ARG; }
+    if (!bvh || !vert || !tri || !h_mvp || !h_eye || W <= 0 || H <= 0 || !rast) { set_error("mirres_rasterize: bad argument"); return MIRRES_E_ARG; }
     if (bvh->T < 2) { set_error("mirres_rasterize: BVH not built"); return MIRRES_E_STATE; }
     hipStream_t s = (hipStream_t)stream;
     const size_t n = (size_t)W * H;
@@ -222,11 +227,13 @@ extern "C" int mirres_rasterize(mirres_bvh_t* bvh, const float* vert, const int3
     }
     float* rays = reinterpret_cast<float*>(bvh->dump_pool);
     int32_t* hit = reinterpret_cast<int32_t*>(rays + 8 * n); float* t = reinterpret_cast<float*>(hit + n); int32_t* prim = reinterpret_cast<int32_t*>(t + n);
-    Mat4 M, Mi;
-    for (int k = 0; k < 16; k++) { M.m[k] = h_mvp[k]; Mi.m[k] = h_mvp_inv[k]; }
-    k_rast_rays<<<grid_for(n, MR_BLOCK), MR_BLOCK, 0, s>>>(Mi, W, H, rays);
+    Mat4 M, R;
+    for (int k = 0; k < 16; k++) M.m[k] = h_mvp[k];
+    for (int k = 0; k < 4; k++) { R.m[k] = h_mvp[k]; R.m[4 + k] = h_mvp[4 + k]; R.m[8 + k] = h_mvp[12 + k]; }     // rows x, y, w
+    R.m[12] = h_eye[0]; R.m[13] = h_eye[1]; R.m[14] = h_eye[2]; R.m[15] = 0.f;
+    k_rast_rays<<<grid_for(n, MR_BLOCK), MR_BLOCK, 0, s>>>(R, W, H, rays);
     int rc = mirres_bvh_trace(bvh, rays, (int)n, 2, hit, t, nullptr, nullptr, prim, nullptr, stream); if (rc) return rc;
-    k_rast_record_clip<<<grid_for(n, MR_BLOCK), MR_BLOCK, 0, s>>>(M, Mi, W, H, hit, t, prim, vert, tri, rast, rast_db);
+    k_rast_record_clip<<<grid_for(n, MR_BLOCK), MR_BLOCK, 0, s>>>(M, R, W, H, hit, t, prim, vert, tri, rast, rast_db);
     MR_LAUNCH_CHECK("rasterize");
     return MIRRES_OK;
 }

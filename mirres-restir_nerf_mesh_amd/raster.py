@@ -43,7 +43,7 @@ def rasterize(glctx, pos, tri, resolution, ranges=None, grad_db=True, mvp=None):
     barycentrics, and (du/dX, du/dY, dv/dX, dv/dY).  `glctx` = RasterizeContext(worker) whose worker holds the same mesh in world space (worker.vrt);
     the model-view-projection matrix is `mvp` [4,4] if given, else recovered from (worker.vrt, pos) — pos is an exact linear image of the vertices, so
     a float64 least-squares fit returns the matrix to rounding.  Not differentiable (neither is nvdiffrast's: gradients enter through dr.interpolate
-    and dr.antialias).  Triangles crossing the near plane are not clipped: a hit nearer than the near plane hides what lies behind it."""
+    and dr.antialias).  Triangles crossing the near plane are not clipped: a hit nearer than the near plane is discarded, and hides what lies behind it."""
     if ranges is not None:
         raise NotImplementedError("rasterize: range mode (instanced minibatches) is not used by the path")
     worker = glctx.worker if isinstance(glctx, RasterizeContext) else glctx
@@ -59,8 +59,11 @@ def rasterize(glctx, pos, tri, resolution, ranges=None, grad_db=True, mvp=None):
         step = max(1, A.shape[0] // 4096)
         mvp = torch.linalg.lstsq(A[::step], p[::step].double()).solution.t()            # p = A @ mvp^T
     M = mvp.detach().double().cpu()
-    Mi = torch.linalg.inv(M)
-    cm = (C.c_float * 16)(*[float(x) for x in M.reshape(-1)]); cmi = (C.c_float * 16)(*[float(x) for x in Mi.reshape(-1)])
+    A = M[[0, 1, 3]]                                             # rows x, y, w: the eye is where all three vanish
+    if abs(float(torch.linalg.det(A[:, :3]))) < 1e-12 * float(A[:, :3].abs().max()) ** 3:
+        raise NotImplementedError("rasterize: the matrix is not a perspective projection (no eye point); the path's cameras are")
+    eye = torch.linalg.solve(A[:, :3], -A[:, 3])
+    cm = (C.c_float * 16)(*[float(x) for x in M.reshape(-1)]); cmi = (C.c_float * 3)(*[float(x) for x in eye])
     rast = torch.empty((h * w, 4), dtype=torch.float32, device=vert.device)
     rast_db = torch.empty((h * w, 4), dtype=torch.float32, device=vert.device) if grad_db else None
     check(lib().mirres_rasterize(worker.h, vert.data_ptr(), t32.data_ptr(), cm, cmi, w, h, rast.data_ptr(), rast_db.data_ptr() if grad_db else None, stream_ptr()), "mirres_rasterize")
