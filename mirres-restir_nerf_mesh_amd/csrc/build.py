@@ -21,7 +21,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # bisected to exactly this: no MFMA -> clean, no v_pk_* in the neighbour kernels -> clean). DESIGN.md §Two streams.
 # -fno-vectorize as well: the LOOP vectoriser packs too (round 2 found v_pk_mul / v_pk_add / v_pk_fma_f32 in matnet, backward, bvh_build and eaw built with
 # -fno-slp-vectorize alone — unrolled level / tap loops vectorised by two); with both switches no object of the library contains a packed-fp32 instruction.
-PER_FILE = {f: ["-fno-slp-vectorize", "-fno-vectorize"] for f in ("passes.hip", "shading.hip", "bvh_trace.hip", "bvh_build.hip", "eaw.hip", "render.hip", "backward.hip", "normal.hip", "matnet.hip", "dump.hip", "raster.hip", "antialias.hip", "selfcheck.hip")}
+# MIRRES_ALLOW_PK=1 (experiments only, with MIRRES_BUILD_TAG): leaves both vectorisers on, i.e. lets packed-fp32 instructions into the kernels again
+PER_FILE = {f: ([] if os.environ.get("MIRRES_ALLOW_PK") == "1" else ["-fno-slp-vectorize", "-fno-vectorize"]) for f in ("passes.hip", "shading.hip", "bvh_trace.hip", "bvh_build.hip", "eaw.hip", "render.hip", "backward.hip", "normal.hip", "matnet.hip", "dump.hip", "raster.hip", "antialias.hip", "selfcheck.hip")}
 # matnet.hip: MFMA accumulators in VGPRs (no v_accvgpr_read between the layers of the register-chained MLP: -15 % VALU in k_mlp_mfma)
 PER_FILE["matnet.hip"] += ["-mllvm", "-amdgpu-mfma-vgpr-form"]
 

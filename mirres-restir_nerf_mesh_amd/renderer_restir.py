@@ -159,111 +159,117 @@ def load_m_for_restir(framedim_x, framedim_y):
     return mods + (light_data, light_uv, light_inv_pdf, reservoirs, prev_reservoirs, final_samples, neighborOffsets, light_tile_count, light_tile_size)
 
 
+class _PassClock:
+    """Frame-index bookkeeping of the sample loop.  Every pass seeds its per-pixel RNG streams with `offset + STRIDE * sample + tick`, where the tick advances
+    by a fixed amount after each pass (renderer_restir.py:314-456: tiles +2, initial +1, temporal +1 — skipped for the first sample, which is why the spatial
+    pass of sample 0 runs one tick earlier —, spatial +1, new direction +5, every indirect vertex +5) and STRIDE = 5 + 15 ticks separate two samples (:316)."""
+    STRIDE = 5 + 15
+    TICKS = {"tiles": 2, "initial": 1, "temporal": 1, "spatial": 1, "direct": 0, "new_dir": 5, "vertex": 5}
+
+    def __init__(self, offset):
+        self.offset, self.sample, self.tick = int(offset), 0, 0
+
+    @property
+    def index(self):
+        return self.offset + self.STRIDE * self.sample + self.tick
+
+    def done(self, stage):
+        self.tick += self.TICKS[stage]
+
+    def next_sample(self):
+        self.sample += 1
+        self.tick = 0
+
+
+def _target_function_inputs(normal_map, depth_map, diffuse_map, roughness_specular):
+    """What the reservoir passes see of the material (renderer_restir.py:279-287): (n, depth) and the three scalars of the target function — diffuse weight =
+    luminance of kd, specular weight = `metallic` weighted by the three luminance coefficients (they sum to one), GGX alpha = clamp(roughness, 0.01, 1)^2."""
+    lum = diffuse_map.new_tensor([0.2126, 0.7152, 0.0722])
+    wd = diffuse_map[:, 0:1] * lum[0] + diffuse_map[:, 1:2] * lum[1] + diffuse_map[:, 2:3] * lum[2]
+    m = roughness_specular[:, 1:2]
+    ws = m * lum[0] + m * lum[1] + m * lum[2]
+    alpha = roughness_specular[:, 0:1].clamp(min=0.01, max=1)
+    return torch.cat((normal_map, depth_map), dim=-1).detach(), torch.cat((wd, ws, alpha * alpha), dim=-1).detach().contiguous()
+
+
 def restir_di_with_pt(use_scale, scale_x, scale_y, scale_z, mlp_mat, bvh_restir_worker, spp, framedim_x, framedim_y, make_sampleable_m, generateLightTiles_m,
                       InitialResampling_m, TemporalResampling_m, SpatialResampling_m, EvaluateFinalSamples_m, FinalShading_m, light_data, light_uv, light_inv_pdf,
                       reservoirs, prev_reservoirs, final_samples, neighborOffsets, light_tile_count, light_tile_size, env_map_init, occ_map, pos_map, normal_map,
                       depth_map, diffuse_map, roughness_specular, ray_dir_map, prev_occ_map, prev_normal_depth, prev_brdf_map, prev_ray_dir, motionVectors, color):
-    """renderer_restir.py:230-471 (stepwise path): the spp loop in Python over the engine's passes; supports autograd through
-    EvaluateFinalSamples_di / FinalShading exactly where the reference does."""
-    mTotalRISPasses = 5 + 15
-    mFrameIndex = 0
-    random_offset = np.random.randint(2**20) if _FIXED_RANDOM_OFFSET is None else int(_FIXED_RANDOM_OFFSET)
-    N = framedim_x * framedim_y
-    dev = 'cuda'
-    z3 = lambda: torch.zeros((N, 3), dtype=torch.float, device=dev)
-    total_color, total_diff_light, total_spec_light, total_indirect_light = z3(), z3(), z3(), z3()
-    total_color_1, color_1, color_diff_1, color_spec_1, total_diff_light_1, total_spec_light_1 = z3(), z3(), z3(), z3(), z3(), z3()
-    prd = torch.zeros((N, 5), dtype=torch.float, device=dev)
-    new_pos_map, new_ray_d, new_normal_map = z3(), z3(), z3()
-    new_occ_map = torch.zeros((N, 1), dtype=torch.float, device=dev)
-    new_diffuse_map = torch.zeros((N, 3), dtype=torch.float, device=dev)
-    new_roughness_specular = torch.zeros((N, 2), dtype=torch.float, device=dev)
-    new_pos_map_temp, new_ray_d_temp, new_normal_map_temp = z3(), z3(), z3()
-    new_occ_map_temp = torch.zeros((N, 1), dtype=torch.float, device=dev)
-
-    normal_depth = torch.cat((normal_map, depth_map), dim=-1).detach()
-    brdf_map = torch.cat((diffuse_map[:, 0:1] * 0.2126 + diffuse_map[:, 1:2] * 0.7152 + diffuse_map[:, 2:3] * 0.0722,
-                          roughness_specular[:, 1:2] * 0.2126 + roughness_specular[:, 1:2] * 0.7152 + roughness_specular[:, 1:2] * 0.0722,
-                          roughness_specular[:, 0:1]), dim=-1).detach()
-    brdf_map[:, 2].clamp_(min=0.01, max=1)
-    brdf_map[:, 2] = brdf_map[:, 2] * brdf_map[:, 2]
-    brdf_map = brdf_map.contiguous()
-    eva_vis_map = torch.ones((N, 1), dtype=torch.float, device=dev)
-    prev_reservoirs = (torch.zeros((N, 3), dtype=torch.float, device=dev), torch.zeros((N, 1), dtype=torch.float, device=dev),
-                       torch.zeros((N, 1), dtype=torch.int, device=dev), torch.zeros((N, 1), dtype=torch.float, device=dev))
-    prev_occ_map = torch.zeros(occ_map.shape, dtype=torch.float, device=dev)
-    prev_normal_depth = torch.zeros((N, 4), dtype=torch.float, device=dev)
-    prev_brdf_map = torch.zeros(brdf_map.shape, dtype=torch.float, device=dev)
-    prev_ray_dir = torch.zeros(ray_dir_map.shape, dtype=torch.float, device=dev)
-
-    env_map = env_map_init.detach()
-    width, height = env_map.shape[1], env_map.shape[0]
-    env_map_init = torch.flip(env_map_init, dims=[0]).reshape(-1, env_map_init.shape[2])
-    debug_out = None
-    env_map = torch.flip(env_map, dims=[0]).reshape(-1, env_map.shape[2]).contiguous()
-    pdf_, cdf_, mpdf_, mcdf_ = make_sampleable(make_sampleable_m, env_map, width, height)
-    ctx = InitialResampling_m.ctx
-    max_bounce = ctx.cfg.max_bounce
+    """renderer_restir.py:230-471, the sample-by-sample path (signature and return tuple are the reference's; the one-call path is render_fused).  Used when a
+    caller asks for the reference-shaped loop under autograd (MIRRES_TRAIN_FUSED=0): EvaluateFinalSamples_di and FinalShading are autograd Functions exactly
+    where the reference has them; everything else runs on detached inputs.  The caller's prev_* arguments are ignored and history starts empty, as in the
+    reference (:291-302)."""
+    fx, fy = int(framedim_x), int(framedim_y)
+    N = fx * fy
+    dev = occ_map.device
+    buf = lambda c: torch.zeros((N, c), dtype=torch.float32, device=dev)
     W = bvh_restir_worker
-    bvh_args = lambda: (W.LBVHNode_info, W.LBVHNode_aabb, W.vrt, W.v_ind)
-
-    for i in range(0, spp):
-        mCurRISPass = 0
-        frameIndex = random_offset + mTotalRISPasses * mFrameIndex + mCurRISPass
-        GenerateLightTiles(generateLightTiles_m, debug_out, env_map, pdf_, cdf_, mpdf_, mcdf_, width, height, frameIndex, light_data, light_uv, light_inv_pdf,
+    mesh = lambda: (W.LBVHNode_info, W.LBVHNode_aabb, W.vrt, W.v_ind)
+    geo, target = _target_function_inputs(normal_map, depth_map, diffuse_map, roughness_specular)
+    # the environment as the kernels index it: rows flipped, flattened; the differentiable copy feeds EvaluateFinalSamples_di only
+    Hc, Wc = env_map_init.shape[0], env_map_init.shape[1]
+    env_grad = torch.flip(env_map_init, dims=[0]).reshape(-1, env_map_init.shape[2])
+    env = env_grad.detach().contiguous()
+    tables = make_sampleable(make_sampleable_m, env, Wc, Hc)
+    # two reservoir sets with fixed roles: `fresh` receives a sample's initial candidates and its merge with the history; `merged` receives the spatial pass's
+    # output, is what the sample is shaded with, and is the next sample's history (the reference reaches the same hand-over with two swaps per sample, :358 / :460)
+    fresh = reservoirs
+    merged = (buf(3), buf(1), torch.zeros((N, 1), dtype=torch.int32, device=dev), buf(1))            # empty history
+    hist_gbuf = (torch.zeros_like(occ_map), buf(4), torch.zeros_like(target), torch.zeros_like(ray_dir_map))
+    visible = torch.ones((N, 1), dtype=torch.float32, device=dev)
+    # sums over samples: direct (colour, diffuse, specular) and indirect (colour, diffuse, specular); the seventh output of the reference stays zero (:298)
+    direct = [buf(3), buf(3), buf(3)]
+    indirect = [buf(3), buf(3), buf(3)]
+    throughput = buf(5)
+    kd_v, rm_v = buf(3), buf(2)                                                                       # material at the current path vertex
+    vertex = [dict(occ=buf(1), pos=buf(3), normal=buf(3), dir=buf(3)) for _ in range(2)]               # ping-pong of path vertices
+    contrib = [buf(3), buf(3), buf(3)]
+    bounces = InitialResampling_m.ctx.cfg.max_bounce
+    clock = _PassClock(np.random.randint(2**20) if _FIXED_RANDOM_OFFSET is None else int(_FIXED_RANDOM_OFFSET))
+    for s_ in range(int(spp)):
+        GenerateLightTiles(generateLightTiles_m, None, env, *tables, Wc, Hc, clock.index, light_data, light_uv, light_inv_pdf,
                            light_tile_count=light_tile_count, light_tile_size=light_tile_size)
-        mCurRISPass += 2
-        frameIndex = random_offset + mTotalRISPasses * mFrameIndex + mCurRISPass
-        W.InitialResampling_(InitialResampling_m, pos_map, reservoirs, env_map, width, height, framedim_x, framedim_y, frameIndex, occ_map, normal_depth, brdf_map,
-                             ray_dir_map, pdf_, cdf_, mpdf_, mcdf_, light_data, light_uv, light_inv_pdf)
-        mCurRISPass += 1
-        frameIndex = random_offset + mTotalRISPasses * mFrameIndex + mCurRISPass
-        if i > 0:
-            TemporalResampling(TemporalResampling_m, reservoirs, prev_reservoirs, env_map, width, height, framedim_x, framedim_y, frameIndex, occ_map, normal_depth,
-                               brdf_map, ray_dir_map, prev_occ_map, prev_normal_depth, prev_brdf_map, prev_ray_dir, motionVectors)
-            mCurRISPass += 1
-        frameIndex = random_offset + mTotalRISPasses * mFrameIndex + mCurRISPass
-        reservoirs, prev_reservoirs = prev_reservoirs, reservoirs
-        W.SpatialResampling_(SpatialResampling_m, pos_map, reservoirs, prev_reservoirs, neighborOffsets, env_map, width, height, framedim_x, framedim_y, frameIndex,
-                             occ_map, normal_depth, brdf_map, ray_dir_map)
-        mCurRISPass += 1
-        W.EvaluateFinalSamples_get_vis(EvaluateFinalSamples_m, pos_map, reservoirs, framedim_x, framedim_y, eva_vis_map)
-        final_Li = EvaluateFinalSamples_di.apply(EvaluateFinalSamples_m, reservoirs[0], reservoirs[1], reservoirs[2], reservoirs[3], env_map_init, width, height,
-                                                 framedim_x, framedim_y, final_samples[0], final_samples[1], eva_vis_map)
-        color, color_diff, color_spec = FinalShading.apply(FinalShading_m, final_samples[0], final_samples[1], final_Li, env_map, width, height, framedim_x,
-                                                           framedim_y, occ_map, normal_map, ray_dir_map, diffuse_map, roughness_specular)
-        frameIndex = random_offset + mTotalRISPasses * mFrameIndex + mCurRISPass
-        process_new_dir_for_pt(FinalShading_m, *bvh_args(), frameIndex, 0, framedim_x, framedim_y, occ_map, pos_map, normal_map.detach(), ray_dir_map, prd,
-                               diffuse_map.detach(), roughness_specular.detach(), new_pos_map, new_ray_d, new_occ_map, new_normal_map)
-        mCurRISPass += 5
-        cur = (new_occ_map, new_pos_map, new_normal_map, new_ray_d)
-        nxt = (new_occ_map_temp, new_pos_map_temp, new_normal_map_temp, new_ray_d_temp)
-        for b in range(1, max_bounce + 1):   # the reference unrolls b = 1, 2 (:396-454)
-            indices = torch.where(cur[0] >= 0.5)
-            kd_ks = mlp_mat.sample_no_di(cur[1][indices[0]])
-            new_diffuse_map[indices[0]] = kd_ks[..., 0:3]
-            new_roughness_specular[indices[0]] = torch.cat((kd_ks[..., 4:5], kd_ks[..., 5:6]), dim=-1)
-            if use_scale:
-                new_diffuse_map[indices[0], 0] = new_diffuse_map[indices[0], 0] * scale_x
-                new_diffuse_map[indices[0], 1] = new_diffuse_map[indices[0], 1] * scale_y
-                new_diffuse_map[indices[0], 2] = new_diffuse_map[indices[0], 2] * scale_z
-                new_diffuse_map = torch.clamp(new_diffuse_map, min=0.0, max=1.0)
-            frameIndex = random_offset + mTotalRISPasses * mFrameIndex + mCurRISPass
-            indirect_one_hit_divided_no_grad(FinalShading_m, *bvh_args(), frameIndex, b, framedim_x, framedim_y, env_map, width, height, pdf_, cdf_, mpdf_, mcdf_,
-                                             cur[0], cur[1], cur[2], cur[3], prd, new_diffuse_map, new_roughness_specular, color_1, color_diff_1, color_spec_1,
-                                             nxt[1], nxt[3], nxt[0], nxt[2])
-            total_color_1 += color_1
-            total_diff_light_1 += color_diff_1
-            total_spec_light_1 += color_spec_1
-            mCurRISPass += 5
-            cur, nxt = nxt, cur
-        mFrameIndex = mFrameIndex + 1
-        reservoirs, prev_reservoirs = prev_reservoirs, reservoirs
-        prev_occ_map, prev_normal_depth, prev_brdf_map, prev_ray_dir = occ_map, normal_depth, brdf_map, ray_dir_map
-        total_color = total_color + color
-        total_diff_light = total_diff_light + color_diff
-        total_spec_light = total_spec_light + color_spec
-    return total_color, total_color_1, total_diff_light, total_spec_light, total_diff_light_1, total_spec_light_1, total_indirect_light, mFrameIndex
+        clock.done("tiles")
+        W.InitialResampling_(InitialResampling_m, pos_map, fresh, env, Wc, Hc, fx, fy, clock.index, occ_map, geo, target, ray_dir_map, *tables,
+                             light_data, light_uv, light_inv_pdf)
+        clock.done("initial")
+        if s_ > 0:
+            TemporalResampling(TemporalResampling_m, fresh, merged, env, Wc, Hc, fx, fy, clock.index, occ_map, geo, target, ray_dir_map, *hist_gbuf, motionVectors)
+            clock.done("temporal")
+        W.SpatialResampling_(SpatialResampling_m, pos_map, merged, fresh, neighborOffsets, env, Wc, Hc, fx, fy, clock.index, occ_map, geo, target, ray_dir_map)
+        clock.done("spatial")
+        # direct lighting of the selected sample: visibility, W * Le, shading (the two differentiable stages)
+        W.EvaluateFinalSamples_get_vis(EvaluateFinalSamples_m, pos_map, merged, fx, fy, visible)
+        Li = EvaluateFinalSamples_di.apply(EvaluateFinalSamples_m, merged[0], merged[1], merged[2], merged[3], env_grad, Wc, Hc, fx, fy,
+                                           final_samples[0], final_samples[1], visible)
+        shaded = FinalShading.apply(FinalShading_m, final_samples[0], final_samples[1], Li, env, Wc, Hc, fx, fy, occ_map, normal_map, ray_dir_map, diffuse_map,
+                                    roughness_specular)
+        for k in range(3):
+            direct[k] = direct[k] + shaded[k]
+        # indirect lighting: a direction at the primary hit, then `bounces` path vertices with the material field looked up at each
+        here, there = vertex
+        process_new_dir_for_pt(FinalShading_m, *mesh(), clock.index, 0, fx, fy, occ_map, pos_map, normal_map.detach(), ray_dir_map, throughput,
+                               diffuse_map.detach(), roughness_specular.detach(), here["pos"], here["dir"], here["occ"], here["normal"])
+        clock.done("new_dir")
+        for depth in range(1, bounces + 1):         # the reference writes depth = 1, 2 out by hand (:396-454)
+            hit = torch.where(here["occ"] >= 0.5)[0]
+            looked_up = mlp_mat.sample_no_di(here["pos"][hit])
+            kd_v[hit] = looked_up[..., 0:3]
+            rm_v[hit] = looked_up[..., 4:6]
+            if use_scale:                           # relighting: albedo scaled per channel, then the WHOLE map clamped (:404-408)
+                kd_v[hit] = kd_v[hit] * kd_v.new_tensor([scale_x, scale_y, scale_z])
+                kd_v = torch.clamp(kd_v, min=0.0, max=1.0)
+            indirect_one_hit_divided_no_grad(FinalShading_m, *mesh(), clock.index, depth, fx, fy, env, Wc, Hc, *tables, here["occ"], here["pos"], here["normal"],
+                                             here["dir"], throughput, kd_v, rm_v, contrib[0], contrib[1], contrib[2], there["pos"], there["dir"], there["occ"],
+                                             there["normal"])
+            for k in range(3):
+                indirect[k] += contrib[k]
+            clock.done("vertex")
+            here, there = there, here
+        hist_gbuf = (occ_map, geo, target, ray_dir_map)      # from the second sample on the history's G-buffer is the frame's own
+        clock.next_sample()
+    return direct[0], indirect[0], direct[1], direct[2], indirect[1], indirect[2], buf(3), clock.sample
 
 
 def _needs_grad(*ts):
