@@ -70,16 +70,17 @@ def psnr(a, b, peak=1.0):
     return 99.0 if mse == 0 else 10.0 * np.log10(peak * peak / mse)
 
 
-def torch_material_field(O, params_f32, w0, w1, w2, aabb_min, aabb_max, mn, mx, pos, dtype=None):
+def torch_material_field(O, params_f32, w0, w1, w2, aabb_min, aabb_max, mn, mx, pos, dtype=None, table=None):
     """Plain-torch reference of MLPTexture3D.sample (render_helper.py:93-104) with autograd: position normalisation + clamp, the hash-grid encoding
     (tcnn's published algorithm: `fmaf(scale, x, 0.5)`, floor, 8-corner trilinear weights, dense / coherent-prime-hash index; the table holds the
     fp16-rounded parameters but the interpolation is carried out in `dtype`, not fp16), the bias-free 32-32-32-6 ReLU MLP, sigmoid and range.
-    `pos` may require grad; everything stays on pos.device.  The level layout comes from the oracle (`hashgrid_layout`)."""
+    `pos` may require grad; everything stays on pos.device.  The level layout comes from the oracle (`hashgrid_layout`).  `table`: the (fp16-valued) parameter
+    table as a flat tensor that may require grad (then params_f32 is not read) — for the table's own gradient."""
     import torch
     dtype = dtype or torch.float64
     dev = pos.device
     total, off, res, sc = O.hashgrid_layout()
-    tab = torch.from_numpy(O.to_f16_bits(params_f32).view(np.float16).astype(np.float64).reshape(-1, 2)).to(dev, dtype)
+    tab = table.reshape(-1, 2) if table is not None else torch.from_numpy(O.to_f16_bits(params_f32).view(np.float16).astype(np.float64).reshape(-1, 2)).to(dev, dtype)
     lo = torch.tensor(aabb_min, dtype=dtype, device=dev); hi = torch.tensor(aabb_max, dtype=dtype, device=dev)
     x = torch.clamp((pos.to(dtype) - lo) / (hi - lo), 0, 1)
     feats = []
