@@ -22,7 +22,8 @@ def _schlick3(f0, c):
 
 
 def _lambda_ggx(a2, c):
-    c2 = c * c
+    cs = torch.where(c <= 0, torch.ones_like(c), c)          # the untaken branch must stay finite for autograd (0 * inf = NaN otherwise)
+    c2 = cs * cs
     tan2 = torch.clamp(1.0 - c2, min=0.0) / c2
     return torch.where(c <= 0, torch.zeros_like(c), 0.5 * (-1.0 + torch.sqrt(1.0 + a2 * tan2)))
 
@@ -36,6 +37,8 @@ def final_shading(occ, normal, ray_dir, kd, rm, fdir, fdist, Li):
     fx = torch.cat((1.0 + sign * n[:, 0:1] * n[:, 0:1] * a, sign * b, -sign * n[:, 0:1]), 1)
     fy = torch.cat((b, sign + n[:, 1:2] * n[:, 1:2] * a, -n[:, 1:2]), 1)
     loc = lambda v: torch.cat((_dot(fx, v), _dot(fy, v), _dot(n, v)), 1)
+    valid = (occ > 0.1) & (fdist > 0)
+    fdir = torch.where(valid, fdir, n.detach())           # pixels without a sample: any finite direction (their outputs are masked to zero below)
     A, B = loc(-ray_dir), loc(fdir)                       # the view direction and the light direction in the shading frame
     rough, metal = rm[:, 0:1], rm[:, 1:2]
     spec_albedo = 0.04 * (1.0 - metal) + kd * metal
@@ -44,16 +47,15 @@ def final_shading(occ, normal, ray_dir, kd, rm, fdir, fdist, Li):
     pD = _lum(kd) * (1.0 - metal)
     pS = _lum(_schlick3(spec_albedo, _dot(-ray_dir, n))) * (metal + (1.0 - metal))
     low = torch.minimum(A[:, 2:3], B[:, 2:3]) < 1e-6
-    valid = (occ > 0.1) & (fdist > 0)
     diff = torch.where(low | ~(pD > 0) | ~valid, torch.zeros_like(Li), torch.clamp(0.31830988 * B[:, 2:3], min=0.0) * Li)
     h = A + B
-    h = h / torch.sqrt(_dot(h, h))
+    h = h / torch.sqrt(torch.where(low, torch.ones_like(low, dtype=h.dtype), _dot(h, h)))
     a2 = alpha * alpha
     d = (h[:, 2:3] * a2 - h[:, 2:3]) * h[:, 2:3] + 1.0
     D = a2 / (d * d * math.pi)
     G = 1.0 / (1.0 + _lambda_ggx(a2, A[:, 2:3]) + _lambda_ggx(a2, B[:, 2:3]))
     F = _schlick3(spec_albedo, _dot(A, h))
-    spec = torch.where(low | (alpha == 0) | ~(pS > 0) | ~valid, torch.zeros_like(Li), F * D * G * 0.25 / A[:, 2:3] * Li)
+    spec = torch.where(low | (alpha == 0) | ~(pS > 0) | ~valid, torch.zeros_like(Li), F * D * G * 0.25 / torch.where(low, torch.ones_like(A[:, 2:3]), A[:, 2:3]) * Li)
     return kd * (1.0 - metal) * diff + spec, diff, spec
 
 

@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 def env(oracle, scene_mod):
     import torch
     from mirres_restir_nerf_mesh_amd import renderer_restir as RR
-    F = SmallFrame(oracle, scene_mod, fx=48, fy=40)
+    F = SmallFrame(oracle, scene_mod, fx=72, fy=60)        # ~1 900 foreground pixels
     W = RR.restirbvhWorker(torch.from_numpy(F.vert).cuda(), torch.from_numpy(F.tri).cuda()); W.update_mesh(W.vrt, W.v_ind)
     mods = RR.load_m_for_restir(F.fx, F.fy)
     O = oracle
@@ -56,7 +56,7 @@ def test_final_shading_adjoint_element_by_element(env, oracle):
     oc, od, os_ = oracle.final_shading(F.frame, F.normal, F.kd, F.rm, st["fdir"], st["fdist"], st["fLi"])
     fg = F.occ > 0.5
     for a, b in ((c64, oc), (d64, od), (s64, os_)):
-        np.testing.assert_allclose(a.detach().cpu().numpy()[fg], b[fg], rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(a.detach().cpu().numpy()[fg], b[fg], rtol=5e-4, atol=2e-6)       # fp64 against fp32: (c a^2 - c) c + 1 of the GGX lobe cancels for small alpha near the highlight
     ((c64 * wts[0].double()).sum() + (d64 * wts[1].double()).sum() + (s64 * wts[2].double()).sum()).backward()
     assert int(fg.sum()) >= 1000
     fgt = torch.from_numpy(fg).cuda()
