@@ -209,7 +209,7 @@ def read_checkpoint(path, map_location="cpu"):
     top = ck if isinstance(ck, dict) and "model" in ck else {}
     return dict(vertices_offsets=f32(model.get("vertices_offsets")), grid_params=f32(grid), mlp_weights=[f32(w) for w in ws] if all(have) else None,
                 light_base=f32(top.get("light_base")), epoch=top.get("epoch"), global_step=top.get("global_step"), stage=top.get("stage"),
-                material_config=top.get("material_config"))
+                material_config=top.get("material_config"), train_state={k: top[k] for k in TRAIN_STATE_KEYS if k in top})
 
 
 def apply_checkpoint(ck, mlp_mat=None, n_vertices=None, device="cuda"):
@@ -233,10 +233,16 @@ def apply_checkpoint(ck, mlp_mat=None, n_vertices=None, device="cuda"):
     return to(voff), to(ck["light_base"])
 
 
-def save_checkpoint(path, mlp_mat, vertices_offsets, light_base, epoch=0, global_step=0, stage=1, material_config=None):
-    """The same file layout, written from this engine's objects (Trainer.save_checkpoint with full=False, :1843-1854, 1912-1920), plus one extra
+TRAIN_STATE_KEYS = ("optimizer", "lr_scheduler", "optimizer_mat", "optimizer_light", "lr_scheduler_mat", "lr_scheduler_light")
+
+
+def save_checkpoint(path, mlp_mat, vertices_offsets, light_base, epoch=0, global_step=0, stage=1, material_config=None, train_state=None):
+    """The same file layout, written from this engine's objects (Trainer.save_checkpoint, :1843-1854, 1912-1920), plus one extra
     top-level key the reference's loader ignores: `material_config` (the AABB / output-range constants the field was trained with, read back from the
-    module when not given) so that an evaluation of this file cannot silently decode it with another run's `--bound` / `--me_max`."""
+    module when not given) so that an evaluation of this file cannot silently decode it with another run's `--bound` / `--me_max`.
+    `train_state` (a `full=True` checkpoint, :1856-1866): state dicts under the reference's keys `optimizer`, `lr_scheduler`, `optimizer_mat`,
+    `optimizer_light` (+ `lr_scheduler_mat` / `lr_scheduler_light`: the reference keeps those two schedules in closures that it rebuilds from the step
+    count; here they are LambdaLR objects) so that a resumed run continues the Adam moments and the learning-rate schedules where they were."""
     if material_config is None:
         lo, hi = (t.detach().cpu().tolist() for t in mlp_mat.AABB)
         mn, mx = (t.detach().cpu().tolist() for t in mlp_mat.min_max)
@@ -246,5 +252,10 @@ def save_checkpoint(path, mlp_mat, vertices_offsets, light_base, epoch=0, global
     model = {"vertices_offsets": vertices_offsets.detach().cpu(), _MAT + "encoder.params": mlp_mat.encoder.params.detach().cpu()}
     for i in (0, 2, 4):
         model[_MAT + "net.net.%d.weight" % i] = mlp_mat.net.net[i].weight.detach().cpu()
-    torch.save({"epoch": epoch, "global_step": global_step, "stats": {}, "stage": stage, "light_base": light_base.detach().cpu(), "model": model,
-                "material_config": dict(material_config)}, path)
+    state = {"epoch": epoch, "global_step": global_step, "stats": {}, "stage": stage, "light_base": light_base.detach().cpu(), "model": model,
+             "material_config": dict(material_config)}
+    for k, v in (train_state or {}).items():
+        if k not in TRAIN_STATE_KEYS:
+            raise KeyError("train_state: unknown entry %r (expected %s)" % (k, ", ".join(TRAIN_STATE_KEYS)))
+        state[k] = v
+    torch.save(state, path)

@@ -137,6 +137,25 @@ def main():
     s_geo = torch.optim.lr_scheduler.LambdaLR(o_geo, lambda it: 0.01 + 0.99 * (it / 500) if it <= 500 else 0.1 ** ((it - 500) / max(1, a.iters - 500)))
     brdf_sched = lambda it: max(0.0, 10 ** (-it * 0.0002))
     s_mat = torch.optim.lr_scheduler.LambdaLR(o_mat, brdf_sched); s_lgt = torch.optim.lr_scheduler.LambdaLR(o_lgt, brdf_sched)
+    # resume (load_checkpoint, utils.py:1966-1990): optimiser moments and schedules continue where the checkpoint left them; a checkpoint without them
+    # (the reference's default full=False files) still gets the SCHEDULES of its step — they are functions of the step count — and only the Adam moments restart
+    scheds = {"lr_scheduler": s_geo, "lr_scheduler_mat": s_mat, "lr_scheduler_light": s_lgt}
+    optims = {"optimizer": o_geo, "optimizer_mat": o_mat, "optimizer_light": o_lgt}
+    if ck is not None:
+        ts = ck.get("train_state") or {}
+        for k_, o_ in optims.items():
+            if k_ in ts:
+                o_.load_state_dict(ts[k_])
+        for k_, s_ in scheds.items():
+            if k_ in ts:
+                s_.load_state_dict(ts[k_])
+            else:                                       # fast-forward: LambdaLR's rate is base_lr * lambda(step)
+                s_.last_epoch = step0
+                for g_, base, fn in zip(s_.optimizer.param_groups, s_.base_lrs, s_.lr_lambdas):
+                    g_["lr"] = base * fn(step0)
+                s_._last_lr = [g_["lr"] for g_ in s_.optimizer.param_groups]
+        if rank == 0 and not all(k_ in ts for k_ in optims):
+            print("[resume] %s holds no optimiser state: Adam moments restart at step %d (learning-rate schedules continue)" % (a.ckpt, step0), flush=True)
     opt = types.SimpleNamespace(use_brdf=True, lambda_extra_kd=a.lambda_extra_kd)
     sync = (lambda: MD.allreduce_gradients([voff] + list(mlp.parameters()) + [env])) if world > 1 else None
 
@@ -163,7 +182,8 @@ def main():
             print("[%5d/%d] loss %.5f  lr vert %.2e mat %.2e light %.2e" % (it, a.iters, val, o_geo.param_groups[0]["lr"], o_mat.param_groups[0]["lr"], o_lgt.param_groups[0]["lr"]), flush=True)
         if rank == 0 and a.save_interval > 0 and ((it + 1) % a.save_interval == 0 or it == a.iters - 1):
             os.makedirs(os.path.join(a.workspace, "checkpoints"), exist_ok=True)
-            CK.save_checkpoint(os.path.join(a.workspace, "checkpoints", "ngp_stage1_ep%04d.pth" % (it + 1)), mlp, voff, env, epoch=it + 1, global_step=it + 1, material_config=cfg)
+            CK.save_checkpoint(os.path.join(a.workspace, "checkpoints", "ngp_stage1_ep%04d.pth" % (it + 1)), mlp, voff, env, epoch=it + 1, global_step=it + 1, material_config=cfg,
+                               train_state={**{k_: o_.state_dict() for k_, o_ in optims.items()}, **{k_: s_.state_dict() for k_, s_ in scheds.items()}})
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     Wk.update_mesh((verts + voff.detach()).contiguous(), tris)
     psnr1 = psnr_of(0)

@@ -139,3 +139,41 @@ def test_reads_a_checkpoint_written_by_the_reference_code():
     assert bool(want["package_file_loads_in_reference"])
     voff, light = CK.apply_checkpoint(r, None, n_vertices=12, device="cpu")
     assert torch.equal(voff, r["vertices_offsets"]) and torch.equal(light, r["light_base"])
+
+
+def test_train_state_round_trip_and_schedule_fast_forward(tmp_path):
+    """A resumable checkpoint (Trainer.save_checkpoint full=True, nerf/utils.py:1856-1866) carries the three optimisers and their schedules under the reference's
+    keys; read_checkpoint hands them back, and an optimiser restored from them takes the same next step as the one that was saved.  A checkpoint without them
+    (the reference's default) still lets a resumed run continue the learning-rate SCHEDULE: it is a function of the step count (scripts/train_stage1.py)."""
+    import types
+    from mirres_restir_nerf_mesh_amd import checkpoint as CK
+    torch.manual_seed(0)
+    w = torch.nn.Parameter(torch.randn(8)); env = torch.nn.Parameter(torch.rand(4, 8, 3))
+    sched = lambda it: max(0.0, 10 ** (-it * 0.0002))
+    def make():
+        o = torch.optim.Adam([{"params": [w], "lr": 0.03}]); return o, torch.optim.lr_scheduler.LambdaLR(o, sched)
+    o, s = make()
+    for it in range(40):
+        o.zero_grad(); (w * w).sum().backward(); o.step(); s.step()
+    mlp = types.SimpleNamespace(encoder=types.SimpleNamespace(params=torch.zeros(16)), net=types.SimpleNamespace(net={i: types.SimpleNamespace(weight=torch.zeros(2, 2)) for i in (0, 2, 4)}))
+    cfg = CK.material_config(bound=1.0, roughness_min=0.08, me_max=0.0)
+    p = str(tmp_path / "resume.pth")
+    CK.save_checkpoint(p, mlp, torch.zeros(5, 3), env, epoch=40, global_step=40, material_config=cfg, train_state={"optimizer_mat": o.state_dict(), "lr_scheduler_mat": s.state_dict()})
+    with pytest.raises(KeyError):
+        CK.save_checkpoint(p + "x", mlp, torch.zeros(5, 3), env, material_config=cfg, train_state={"optimiser": {}})
+    ck = CK.read_checkpoint(p)
+    assert set(ck["train_state"]) == {"optimizer_mat", "lr_scheduler_mat"} and ck["global_step"] == 40
+    w_saved = w.detach().clone()
+    o.zero_grad(); (w * w).sum().backward(); o.step(); s.step(); after = w.detach().clone(); lr_after = o.param_groups[0]["lr"]
+    with torch.no_grad():
+        w.copy_(w_saved)
+    o2, s2 = make()
+    o2.load_state_dict(ck["train_state"]["optimizer_mat"]); s2.load_state_dict(ck["train_state"]["lr_scheduler_mat"])
+    o2.zero_grad(); (w * w).sum().backward(); o2.step(); s2.step()
+    assert torch.equal(w.detach(), after) and o2.param_groups[0]["lr"] == lr_after
+    # no saved state: the schedule alone is fast-forwarded to the checkpoint's step
+    o3, s3 = make()
+    s3.last_epoch = 40
+    for g_, base, fn in zip(s3.optimizer.param_groups, s3.base_lrs, s3.lr_lambdas):
+        g_["lr"] = base * fn(40)
+    assert o3.param_groups[0]["lr"] == pytest.approx(0.03 * sched(40)) and CK.read_checkpoint(p)["train_state"] is not None
