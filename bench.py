@@ -133,6 +133,7 @@ def main():
     env = torch.from_numpy(S.make_env(256, 512)).to(dev)
     fx, fy = g["fx"], g["fy"]
     ctx = get_ctx(fx, fy, max_bounce=args.bounces)
+    ctx.reserve()                       # the batch pool is sized here, not inside the first frame
     N = fx * fy
 
     def step(scheme):

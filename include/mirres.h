@@ -269,6 +269,12 @@ int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args
  * (accumulated). The indirect sums carry no gradient (process_path_tracing_divided_no_grad). `a` = the forward call's arguments.       */
 int mirres_render_bwd(mirres_ctx_t* ctx, const mirres_render_args_t* a, int samples, const float* g_color, const float* g_diff,
                       const float* g_spec, float* g_normal, float* g_kd, float* g_rough_metal, float* g_env, void* stream);
+/* Sizes the context's batch pool ahead of the first frame (no reference counterpart: load_m_for_restir allocates the reference's persistent buffers at
+ * start-up, renderer_restir.py:189-217; here the K-sample pool — ~670 B per sample slot, 55 GB for 32 samples of a 1600 x 1600 frame — would otherwise
+ * be allocated inside the first mirres_render of a frame size, a device synchronisation and a multi-GB hipMalloc + clear in the middle of the first
+ * timed frame).  samples_per_batch = 0: the default batch (MIRRES_PT_BATCH, 32).  Returns the batch size actually reserved (smaller when the device
+ * cannot spare the request) or a negative error code.                                                                                        */
+int mirres_ctx_reserve(mirres_ctx_t* ctx, int samples_per_batch);
 /* second half of run_restir_di_with_pt (:507-549) on already-summed accumulators (after an all-reduce).         */
 int mirres_render_finish(mirres_ctx_t* ctx, const mirres_render_args_t* a, float* sums[6], void* stream);
 

@@ -109,6 +109,7 @@ SIGNATURES = {
     "mirres_matnet_mlp": (C.c_int, [PMAT, vp, C.c_int, vp, vp]),
     "mirres_matnet_scatter": (C.c_int, [PMAT, vp, vp, C.c_int, vp, vp, C.c_int, C.POINTER(C.c_float), vp]),
     "mirres_matnet_bwd": (C.c_int, [PMAT, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp]),
+    "mirres_ctx_reserve": (C.c_int, [vp, C.c_int]),
     "mirres_render": (C.c_int, [vp, vp, PARGS, vp]),
     "mirres_render_bwd": (C.c_int, [vp, PARGS, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]),
     "mirres_render_finish": (C.c_int, [vp, PARGS, C.POINTER(vp), vp]),

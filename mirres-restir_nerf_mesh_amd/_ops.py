@@ -65,6 +65,13 @@ class Context:
     def set_instrument(self, on):
         check(lib().mirres_ctx_set_instrument(self.h, int(on)), "mirres_ctx_set_instrument")
 
+    def reserve(self, samples_per_batch=0):
+        """Allocate the K-sample batch pool now (mirres_ctx_reserve) instead of inside the first frame; returns the batch size that fitted."""
+        k = lib().mirres_ctx_reserve(self.h, int(samples_per_batch))
+        if k < 0:
+            check(k, "mirres_ctx_reserve")
+        return k
+
 
 _CTX_CACHE = collections.OrderedDict()      # (device, fx, fy, max_bounce) -> Context, least recently used first
 

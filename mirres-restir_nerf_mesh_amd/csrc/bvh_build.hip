@@ -237,117 +237,6 @@ __global__ void __launch_bounds__(256) k_pack(int T, const int32_t* __restrict__
     }
 }
 
-// ---------------------------------------------------------------- PLOC: a higher-quality binary tree over the same leaves, for shadow rays only
-// Parallel locally-ordered clustering (Meister & Bittner 2018) over the Morton-sorted leaves: every cluster looks R positions left and right
-// for the partner that minimises the surface area of the merged box; mutual nearest neighbours merge; the cluster array is compacted; repeat.
-// Why it is allowed: the any-hit bit depends on the leaves' own boxes only (bvh_trace.hip), so the shadow-ray kernel may walk any hierarchy
-// over them — and a hierarchy built by area instead of by Morton prefix tests far fewer boxes per ray. The closest-hit kernel keeps the LBVH
-// (its result depends on the reference's visiting order). Node ids are handed out deterministically (exclusive scan, counting down to 0 =
-// root); the tree is emitted in the LBVH arrays' convention (pl_info / pl_aabb) so the 4-wide collapse + quantisation (k_pack4q) is shared.
-#define MR_PLOC_R 16
-#define MR_PLOC_ITERS 72
-MR_DEV float box_area_union(const float* a, const float* b) {
-    const float dx = fmaxf(a[3], b[3]) - fminf(a[0], b[0]), dy = fmaxf(a[4], b[4]) - fminf(a[1], b[1]), dz = fmaxf(a[5], b[5]) - fminf(a[2], b[2]);
-    return dx * dy + dy * dz + dz * dx;
-}
-__global__ void __launch_bounds__(256) k_ploc_init(int T, const int32_t* __restrict__ info, const float* __restrict__ aabb, int32_t* __restrict__ pinfo,
-                                                   float* __restrict__ paabb, int32_t* __restrict__ cid, float* __restrict__ cbox, int32_t* __restrict__ state) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) { state[0] = T; state[1] = T - 2; }
-    if (i >= T) return;
-    const size_t L = (size_t)(T - 1) + i;
-#pragma unroll
-    for (int k = 0; k < 3; k++) pinfo[3 * L + k] = info[3 * L + k];
-#pragma unroll
-    for (int k = 0; k < 6; k++) { const float v = aabb[6 * L + k]; paabb[6 * L + k] = v; cbox[6 * (size_t)i + k] = v; }
-    cid[i] = (int32_t)L;
-}
-__global__ void __launch_bounds__(256) k_ploc_nn(const int32_t* __restrict__ state, const float* __restrict__ cbox, int32_t* __restrict__ nn) {
-    __shared__ float sb[(256 + 2 * MR_PLOC_R) * 6];
-    const int n = state[0];
-    const int base = blockIdx.x * 256 - MR_PLOC_R;
-    if (blockIdx.x * 256 >= n) return;
-    for (int t = threadIdx.x; t < 256 + 2 * MR_PLOC_R; t += 256) {
-        const int j = base + t;
-        if (j >= 0 && j < n) {
-#pragma unroll
-            for (int k = 0; k < 6; k++) sb[6 * t + k] = cbox[6 * (size_t)j + k];
-        }
-    }
-    __syncthreads();
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const float* me = sb + 6 * (threadIdx.x + MR_PLOC_R);
-    float best = 3.0e38f; int bj = -1;
-    for (int d = -MR_PLOC_R; d <= MR_PLOC_R; d++) {
-        const int j = i + d;
-        if (d == 0 || j < 0 || j >= n) continue;
-        const float a = box_area_union(me, sb + 6 * (threadIdx.x + MR_PLOC_R + d));
-        if (a < best) { best = a; bj = j; }          // ties: the leftmost candidate
-    }
-    nn[i] = bj;
-}
-// flag word per array position: low 32 bits = 1 if the cluster stays in the array, high 32 bits = 1 if it creates a new node (the left partner)
-__global__ void __launch_bounds__(256) k_ploc_flag(int T, const int32_t* __restrict__ state, const int32_t* __restrict__ nn, unsigned long long* __restrict__ flag) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= T) return;
-    const int n = state[0];
-    unsigned long long f = 0ull;
-    if (i < n) {
-        const int j = nn[i];
-        const bool mutual = n > 1 && j >= 0 && nn[j] == i;
-        if (!mutual) f = 1ull;
-        else if (i < j) f = 1ull | (1ull << 32);
-    }
-    flag[i] = f;
-}
-__global__ void __launch_bounds__(256) k_ploc_merge(int T, int32_t* __restrict__ state, const int32_t* __restrict__ nn, const unsigned long long* __restrict__ flag,
-                                                    const unsigned long long* __restrict__ scan, const int32_t* __restrict__ cid_in, const float* __restrict__ box_in,
-                                                    int32_t* __restrict__ cid_out, float* __restrict__ box_out, int32_t* __restrict__ pinfo, float* __restrict__ paabb) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int n = state[0];
-    if (i >= n) return;
-    const unsigned long long f = flag[i], sc = scan[i];
-    if (!(f & 1ull)) return;                                   // merged into its left partner
-    const int dst = (int)(sc & 0xffffffffull);
-    int id = cid_in[i];
-    float b[6];
-#pragma unroll
-    for (int k = 0; k < 6; k++) b[k] = box_in[6 * (size_t)i + k];
-    if (f >> 32) {
-        const int j = nn[i];
-        id = state[1] - (int)(sc >> 32);                       // next free node id minus this merge's rank
-#pragma unroll
-        for (int k = 0; k < 3; k++) { b[k] = fminf(b[k], box_in[6 * (size_t)j + k]); b[3 + k] = fmaxf(b[3 + k], box_in[6 * (size_t)j + 3 + k]); }
-        pinfo[3 * (size_t)id] = cid_in[i]; pinfo[3 * (size_t)id + 1] = cid_in[j]; pinfo[3 * (size_t)id + 2] = -1;
-#pragma unroll
-        for (int k = 0; k < 6; k++) paabb[6 * (size_t)id + k] = b[k];
-    }
-    cid_out[dst] = id;
-#pragma unroll
-    for (int k = 0; k < 6; k++) box_out[6 * (size_t)dst + k] = b[k];
-}
-__global__ void k_ploc_advance(int T, int32_t* __restrict__ state, const unsigned long long* __restrict__ flag, const unsigned long long* __restrict__ scan) {
-    const int n = state[0];
-    if (n <= 1) return;
-    const unsigned long long tot = scan[n - 1] + flag[n - 1];
-    state[0] = (int)(tot & 0xffffffffull);
-    state[1] -= (int)(tot >> 32);
-}
-// safety net (never needed on the meshes seen: PLOC merges at least the globally closest pair per iteration): merge what is left, left to right
-__global__ void k_ploc_finish(int32_t* __restrict__ state, int32_t* __restrict__ cid, float* __restrict__ box, int32_t* __restrict__ pinfo, float* __restrict__ paabb) {
-    int n = state[0];
-    while (n > 1) {
-        const int id = state[1]--;
-        float b[6];
-        for (int k = 0; k < 3; k++) { b[k] = fminf(box[k], box[6 * (size_t)(n - 1) + k]); b[3 + k] = fmaxf(box[3 + k], box[6 * (size_t)(n - 1) + 3 + k]); }
-        pinfo[3 * (size_t)id] = cid[0]; pinfo[3 * (size_t)id + 1] = cid[n - 1]; pinfo[3 * (size_t)id + 2] = -1;
-        for (int k = 0; k < 6; k++) { paabb[6 * (size_t)id + k] = b[k]; box[k] = b[k]; }
-        cid[0] = id; n--;
-    }
-    state[0] = n;
-}
-
 // ---- compressed 4-wide layout for shadow rays (engine.hpp Node4q / LeafRec)
 // step 2^(E-127) per axis: the smallest power of two (E >= 67) for which the decode expression of q = 255 still reaches the node's max corner
 MR_DEV float q_step(uint32_t E) { return __uint_as_float(E << 23); }
@@ -484,21 +373,6 @@ void mirres_default_config(mirres_config_t* c) {
     c->gather_radius = 30.f; c->max_bounce = 2; c->vis_near = 0.01f;
 }
 
-// MIRRES_PLOC=1: collapse the shadow-ray layout from a PLOC tree instead of the LBVH. Off by default: on uniformly tessellated meshes (the
-// bench scene; marching-cubes extractions like the reference's) the Morton-prefix splits of the LBVH are already area-balanced — measured
-// 43.0 (LBVH) vs 43.9 (PLOC) box tests per shadow ray, and the 72 iterations cost more than they save. Results are identical either way.
-static bool use_ploc() { const char* e = getenv("MIRRES_PLOC"); return e && e[0] == '1'; }
-static int ploc_alloc(mirres_bvh* b) {
-    if (b->pl_info) return 0;
-    const size_t T = (size_t)b->max_tris;
-    MR_HIP(hipMalloc(&b->pl_info, sizeof(int32_t) * 3 * (2 * T))); MR_HIP(hipMalloc(&b->pl_aabb, sizeof(float) * 6 * (2 * T)));
-    for (int k = 0; k < 2; k++) { MR_HIP(hipMalloc(&b->pl_cid[k], sizeof(int32_t) * T)); MR_HIP(hipMalloc(&b->pl_box[k], sizeof(float) * 6 * T)); }
-    MR_HIP(hipMalloc(&b->pl_nn, sizeof(int32_t) * T)); MR_HIP(hipMalloc(&b->pl_flag, sizeof(unsigned long long) * T)); MR_HIP(hipMalloc(&b->pl_scan, sizeof(unsigned long long) * T));
-    MR_HIP(hipMalloc(&b->pl_state, sizeof(int32_t) * 4));
-    { size_t pt = 0; MR_HIP(rocprim::exclusive_scan(nullptr, pt, b->pl_flag, b->pl_scan, 0ull, T, rocprim::plus<unsigned long long>(), 0)); b->pl_tmp_bytes = pt; MR_HIP(hipMalloc(&b->pl_tmp, pt ? pt : 16)); }
-    return 0;
-}
-
 int mirres_bvh_create(mirres_bvh_t** out, int max_tris) {
     if (!out || max_tris < 2) { set_error("mirres_bvh_create: need max_tris >= 2"); return MIRRES_E_ARG; }
     mirres_bvh* b = new mirres_bvh();
@@ -532,8 +406,7 @@ int mirres_bvh_create(mirres_bvh_t** out, int max_tris) {
 void mirres_bvh_destroy(mirres_bvh_t* b) {
     if (!b) return;
     void* ptrs[] = {b->ele_aabb, b->extent, b->keys_in, b->keys_out, b->vals_in, b->vals_out, b->parent, b->flags, b->own_info,
-                    b->own_aabb, b->nodes, b->tris, b->root_box, b->sort_tmp, b->work, b->redo[0], b->redo[1], b->dump_pool, b->lvl, b->nodes4q, b->leaves, b->top85q, b->top341q, b->pl_info, b->pl_aabb, b->pl_cid[0], b->pl_cid[1], b->pl_box[0], b->pl_box[1],
-                    b->pl_nn, b->pl_flag, b->pl_scan, b->pl_state, b->pl_tmp};
+                    b->own_aabb, b->nodes, b->tris, b->root_box, b->sort_tmp, b->work, b->redo[0], b->redo[1], b->dump_pool, b->lvl, b->nodes4q, b->leaves, b->top85q, b->top341q};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete b;
 }
@@ -564,24 +437,8 @@ int mirres_bvh_build(mirres_bvh_t* b, const float* vert, int V, const int32_t* t
         k_refit_ranges<<<grd, blk, 0, s>>>(T, b->flags, Lv, aabb);
     }
     k_pack<<<grd, blk, 0, s>>>(T, info, aabb, vert, tri, b->nodes, b->tris, b->root_box);
-    const int32_t* hinfo = info; const float* haabb = aabb;          // the hierarchy the shadow-ray layout is collapsed from
-    if (use_ploc() && T >= 64) {
-        { int rc = ploc_alloc(b); if (rc) return rc; }
-        k_ploc_init<<<grd, blk, 0, s>>>(T, info, aabb, b->pl_info, b->pl_aabb, b->pl_cid[0], b->pl_box[0], b->pl_state);
-        int cur = 0;
-        for (int it = 0; it < MR_PLOC_ITERS; it++) {
-            k_ploc_nn<<<grd, 256, 0, s>>>(b->pl_state, b->pl_box[cur], b->pl_nn);
-            k_ploc_flag<<<grd, blk, 0, s>>>(T, b->pl_state, b->pl_nn, b->pl_flag);
-            size_t pt = b->pl_tmp_bytes;
-            MR_HIP(rocprim::exclusive_scan(b->pl_tmp, pt, b->pl_flag, b->pl_scan, 0ull, (size_t)T, rocprim::plus<unsigned long long>(), s));
-            k_ploc_merge<<<grd, blk, 0, s>>>(T, b->pl_state, b->pl_nn, b->pl_flag, b->pl_scan, b->pl_cid[cur], b->pl_box[cur], b->pl_cid[cur ^ 1], b->pl_box[cur ^ 1], b->pl_info, b->pl_aabb);
-            k_ploc_advance<<<1, 1, 0, s>>>(T, b->pl_state, b->pl_flag, b->pl_scan);
-            cur ^= 1;
-        }
-        k_ploc_finish<<<1, 1, 0, s>>>(b->pl_state, b->pl_cid[cur], b->pl_box[cur], b->pl_info, b->pl_aabb);
-        hinfo = b->pl_info; haabb = b->pl_aabb;
-    }
-    k_pack4q<<<grd, blk, 0, s>>>(T, hinfo, haabb, vert, tri, b->nodes4q, b->leaves);
+    // the shadow-ray layout is collapsed from the LBVH itself (a PLOC hierarchy over the same leaves tested 43.9 boxes per shadow ray against 43.0: DESIGN.md section 5, round 1)
+    k_pack4q<<<grd, blk, 0, s>>>(T, info, aabb, vert, tri, b->nodes4q, b->leaves);
     if (T - 1 >= 341 * 4) { k_top4q<<<1, 256, 0, s>>>(T, b->nodes4q, b->top85q, 85); k_top4q<<<1, 256, 0, s>>>(T, b->nodes4q, b->top341q, 341); }
     MR_LAUNCH_CHECK("bvh_build");
     return MIRRES_OK;

@@ -18,7 +18,11 @@ namespace mr {
 //            against the compiler's 11 / ~46 (two v_div_scale, a second correction, v_div_fmas). Proved on the hardware by exhaustion
 //            (scripts/ubench/div_exhaustive.hip): all 2^46 pairs of significands agree with `a / b`, i.e. every pair of normal operands with a normal
 //            quotient while no intermediate leaves the normal range — operands and quotient within 2^-102 .. 2^102; zeros, infinities and NaNs by
-//            v_div_fixup_f32 exactly as in the compiler's sequence. Beyond 2^+-102 (nothing in a frame: radiances, pdfs, cosines) it can be off.
+//            v_div_fixup_f32 exactly as in the compiler's sequence. Beyond 2^+-102 (nothing in a frame: radiances, pdfs, cosines) it can be off:
+//            v_rcp_f32 flushes a denormal divisor to zero, so a / denormal comes out as what a / 0 gives (inf, or NaN for 0 / denormal) where IEEE division
+//            returns a large finite number. Where such a quotient could reach a reservoir it is harmless by construction of the callers: a NaN or inf
+//            weight zeroes the reservoir (store_ris, as InitialResampling.slang:285-293 does), and a pdf below 1.2e-38 belongs to a sample that is
+//            never selected. The traversal kernels, whose hostile-geometry tests do feed denormal reciprocals, keep the compiler's division.
 //   mr_sqrt: v_rsq_f32, s = x * y, one residual correction with y / 2; +-0 and +inf passed through — 7 instructions / ~28 cycles against 17 / ~60.
 //            All 2^24 significand / exponent-parity cases agree with sqrtf; a denormal argument is returned as it is (sqrtf would give ~1e-20).
 #ifndef MR_LEAN_FP

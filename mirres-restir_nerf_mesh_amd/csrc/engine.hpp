@@ -30,7 +30,7 @@ struct __attribute__((aligned(64))) Node4q {
     float org[3]; float step_x;           // quantisation steps (powers of two) as floats: no unpacking in the traversal (an `and` + a shift per axis and
     uint32_t qlo[3], qhi[3];              // visit otherwise); byte k of qlo[a] / qhi[a] = child k's min / max along axis a
     float step_y, step_z;
-    int32_t ref[4];                       // >=0 node id, <0 ~leaf slot, 0x7fffffff = unused entry; inside an LDS-staged prefix: MR_TOPBIT | index
+    int32_t ref[4];                       // >=0 node id, <0 ~leaf slot; an unused entry refers to the null leaf ~T (leaves[T]: an inverted box no ray passes); inside an LDS-staged prefix: MR_TOPBIT | index
 };
 struct __attribute__((aligned(64))) LeafRec {  // 64 B: triangle (v0, e1, e2) + the leaf's exact LBVH box + primitive id
     float v0[3], e1[3], e2[3];
@@ -73,13 +73,6 @@ struct mirres_bvh {
     // traversal layout
     mr::WideNode* nodes = nullptr;  // [T-1]
     mr::TriRec* tris = nullptr;     // [T]
-    // PLOC tree for the shadow-ray hierarchy (bvh_build.hip): any hierarchy over the same leaf boxes gives the same any-hit bit, so the shadow rays
-    // get a higher-quality tree than the LBVH the closest-hit kernel must walk in the reference's order
-    int32_t* pl_info = nullptr; float* pl_aabb = nullptr;               // [2T-1,3], [2T-1,6] in the LBVH arrays' convention (leaves copied)
-    int32_t* pl_cid[2] = {nullptr, nullptr}; float* pl_box[2] = {nullptr, nullptr};   // cluster ids / boxes, ping-pong
-    int32_t* pl_nn = nullptr; unsigned long long* pl_flag = nullptr; unsigned long long* pl_scan = nullptr;
-    int32_t* pl_state = nullptr;    // [4]: n (clusters), next node id, scratch
-    void* pl_tmp = nullptr; size_t pl_tmp_bytes = 0;
     mr::Node4q* nodes4q = nullptr;  // [T-1] compressed 4-wide nodes (shadow rays)
     mr::LeafRec* leaves = nullptr;  // [T]
     mr::Node4q* top85q = nullptr, *top341q = nullptr;   // [85], [341] breadth-first prefixes of nodes4q, children inside tagged MR_TOPBIT
@@ -115,7 +108,7 @@ struct mirres_ctx {
     // frame buffers of the fused loop (mirres_render)
     float* pool = nullptr; size_t pool_floats = 0;
     // K-sample batch of the path-tracing stages (mirres_render): queues + per-slot state for K * N sample slots
-    char* ptb = nullptr; size_t ptb_bytes = 0; int ptb_kcap = 0;   // ptb_kcap: largest batch the device could hold when an allocation last fell back (0 = never)
+    char* ptb = nullptr; size_t ptb_bytes = 0; int ptb_kcap = 0, ptb_kcap_age = 0;   // ptb_kcap: largest batch the device could hold when an allocation last fell back (0 = never)
     int y_off = 0, full_fy = 0;     // strip sharding (mirres_render): global row of local row 0 and the global height; full_fy == 0: the frame is the whole image
     const float* occ_own = nullptr; // strip sharding: occupancy with the halo rows zeroed (own-pixel tests of the spatial pass); NULL otherwise
     const float* grec = nullptr;    // set by mirres_render for the duration of a frame: packed 64-byte G records for the neighbour gathers of k_spatial_resolve

@@ -275,7 +275,7 @@ __global__ void __launch_bounds__(MR_BLOCK) k_active_list(const float* __restric
                                                           float* __restrict__ kd, int clamp_all) {
     const size_t base = ((size_t)blockIdx.x * MR_BLOCK + threadIdx.x) * MR_AL_PER;
     uint32_t bits = 0;
-    if (base + MR_AL_PER <= (size_t)n) {
+    if (base + MR_AL_PER <= (size_t)n && (reinterpret_cast<uintptr_t>(occ) & 15) == 0) {   // 16-byte loads only from a 16-byte aligned map (a sliced view may start anywhere)
 #pragma unroll
         for (int j = 0; j < MR_AL_PER; j += 4) {
             const float4 o = *reinterpret_cast<const float4*>(occ + base + j);

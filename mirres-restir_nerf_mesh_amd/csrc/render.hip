@@ -216,7 +216,14 @@ static int carve_batch(mirres_ctx* ctx, int N, int K, int max_bounce, size_t TS,
     };
     // A request the device could not hold last time is not repeated every frame (each retry costs a device synchronisation, a free of the working
     // pool and a failing multi-GB hipMalloc): the batch size that fitted is remembered and later requests are clamped to it.
-    if (ctx->ptb_kcap > 0 && K > ctx->ptb_kcap) K = ctx->ptb_kcap;
+    // The clamp is not for ever: a transient shortage (another tenant of the HBM) must not pin a long run to small batches, so every 64th clamped
+    // request — or as soon as hipMemGetInfo shows the full request would fit beside the working pool — the full size is tried again.
+    if (ctx->ptb_kcap > 0 && K > ctx->ptb_kcap) {
+        size_t fr = 0, tot = 0;
+        const bool roomy = hipMemGetInfo(&fr, &tot) == hipSuccess && fr + ctx->ptb_bytes > bytes_for(K) + (1ull << 30);
+        if (roomy || ++ctx->ptb_kcap_age >= 64) { ctx->ptb_kcap = 0; ctx->ptb_kcap_age = 0; }
+        else K = ctx->ptb_kcap;
+    }
     size_t need = bytes_for(K);
     if (ctx->ptb_bytes < need) {
         // ~670 bytes per slot: 55 GB for 32 samples of a 1600^2 frame. The larger pool is allocated BEFORE the working one is given up, so that a
@@ -311,6 +318,16 @@ static int finish(mirres_ctx* ctx, const mirres_render_args_t* a, float* tot[6],
 }
 
 extern "C" {
+
+int mirres_ctx_reserve(mirres_ctx_t* ctx, int samples_per_batch) {
+    if (!ctx || samples_per_batch < 0) { set_error("mirres_ctx_reserve: bad argument"); return MIRRES_E_ARG; }
+    int K = samples_per_batch > 0 ? samples_per_batch : pt_batch_size();
+    if (K > 64) K = 64;
+    PtBatch PB;
+    const size_t TS = (size_t)ctx->cfg.light_tile_count * ctx->cfg.light_tile_size;
+    const int rc = carve_batch(ctx, ctx->fx * ctx->fy, K, ctx->cfg.max_bounce, TS, PB);
+    return rc ? rc : PB.K;
+}
 
 int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args_t* a, void* stream) {
     if (!ctx || !bvh || !a || !a->env_map || !a->occ || !a->normal || !a->depth || !a->kd || !a->rough_metal || !a->ray_dir || !a->pos || a->spp <= 0) {

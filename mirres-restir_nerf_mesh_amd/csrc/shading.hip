@@ -25,7 +25,6 @@ int trace_closest_queue_counted(const mirres_bvh* bvh, const Ray* rays, const ui
 #ifndef MR_BGEN_BLOCK
 #define MR_BGEN_BLOCK MR_GEN_BLOCK
 #endif
-#define MR_SGEN_BLOCK 1024  // k_spatial_gen: one 32 x 32 pixel tile per block
 
 MR_DEV void put_ray(Ray* q, uint32_t slot, v3 pos, v3 dir, float vis_near) {
     v3 o = pos + vis_near * dir;

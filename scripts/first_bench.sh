@@ -1,6 +1,6 @@
 #!/bin/bash
 # first GPU pass: gpu tests, smoke, small bench, full bench, rocprof kernel trace
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:?}" || exit 1
 mkdir -p gpurun_out
 python -m pytest tests -m gpu -x -q 2>&1 | tail -5 > gpurun_out/gpu_tests.log
 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1

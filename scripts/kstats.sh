@@ -1,5 +1,5 @@
 #!/bin/bash
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:?}" || exit 1
 rm -rf gpurun_out/kt; mkdir -p gpurun_out/kt
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/kt -o kt -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline "$@" > gpurun_out/kt/bench.log 2>&1
 grep '^{' gpurun_out/kt/bench.log | tail -1 | cut -c1-220

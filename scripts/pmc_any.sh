@@ -2,7 +2,7 @@
 # PMC passes (separate runs, counters only, each under its own timeout: a counter set rocprofv3 rejects must not hang the box) over
 # scripts/dev_any_pmc.py: per-kernel averages per launch for the traversal kernels
 # usage: scripts/pmc_any.sh <tag> [res K launches mode]
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:?}" || exit 1
 tag=${1:-any}; shift
 out=gpurun_out/pmc_$tag; rm -rf $out; mkdir -p $out
 python3 scripts/dev_any_pmc.py "$@" > $out/plain.txt 2>&1

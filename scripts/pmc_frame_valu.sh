@@ -1,6 +1,6 @@
 #!/bin/bash
 # VALU issue share of every kernel in the frame loop: SQ_INSTS_VALU summed per kernel over one serialised (MIRRES_STREAMS=1) 16-spp frame
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:?}" || exit 1
 export MIRRES_STREAMS=1
 rm -rf gpurun_out/pv; mkdir -p gpurun_out/pv gpurun_out/out
 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAIT_INST_ANY --output-format csv -d gpurun_out/pv -o p -- python3 bench.py --spp 16 --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > gpurun_out/pv/log 2>&1

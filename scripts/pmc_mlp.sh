@@ -1,6 +1,6 @@
 #!/bin/bash
 # SQ counters of the MLP GEMM-phase kernel (scripts/dev_mlp_bench.py), averages per launch
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:?}" || exit 1
 rm -rf gpurun_out/pm; mkdir -p gpurun_out/pm gpurun_out/out
 timeout -k 5 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_SALU --output-format csv -d gpurun_out/pm -o p -- python3 scripts/dev_mlp_bench.py > gpurun_out/pm/log 2>&1
 timeout -k 5 300 rocprofv3 --pmc SQ_INST_CYCLES_VMEM SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS GRBM_GUI_ACTIVE SQ_WAVES --output-format csv -d gpurun_out/pm/b -o p -- python3 scripts/dev_mlp_bench.py > gpurun_out/pm/log2 2>&1

@@ -1,5 +1,5 @@
 #!/bin/bash
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:?}" || exit 1
 mkdir -p gpurun_out/pmc1 gpurun_out/pmc2 gpurun_out/pmc3
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_VMEM_RD --output-format csv -d gpurun_out/pmc1 -o p -- python3 scripts/dev_trace_bench.py > gpurun_out/pmc1/log 2>&1
 rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum --output-format csv -d gpurun_out/pmc2 -o p -- python3 scripts/dev_trace_bench.py > gpurun_out/pmc2/log 2>&1

@@ -1,6 +1,6 @@
 #!/bin/bash
 # SQ counters of the backward kernels of the stage-1 training step (scripts/train_step_bench.py), averages per launch
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:?}" || exit 1
 rm -rf gpurun_out/pt; mkdir -p gpurun_out/pt
 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAVES --output-format csv -d gpurun_out/pt -o p -- python3 scripts/train_step_bench.py --steps 2 > gpurun_out/pt/log 2>&1
 python3 - <<'PY'

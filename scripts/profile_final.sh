@@ -1,6 +1,6 @@
 #!/bin/bash
 # profiles for the round: kernel trace of the default bench command, PMC HBM traffic of the dominant kernel, MLP GEMM-phase kernel
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:?}" || exit 1
 R=${1:-r02}
 RP="timeout -k 5 600 rocprofv3"     # every profiler pass under its own limit: a counter set the tool rejects must not hold the box
 rm -rf gpurun_out/pf; mkdir -p gpurun_out/pf/kt gpurun_out/pf/fetch gpurun_out/pf/write gpurun_out/pf/mlp gpurun_out/pf/tr gpurun_out/out

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round-1 profiles: kernel trace of the default bench command + PMC passes (HBM traffic) on a short run
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:?}" || exit 1
 mkdir -p gpurun_out/prof_kt gpurun_out/prof_fetch gpurun_out/prof_write
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_kt -o kt -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/prof_kt/bench.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof_fetch -o fetch -- python3 bench.py --spp 4 --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > gpurun_out/prof_fetch/bench.log 2>&1

@@ -1,6 +1,6 @@
 #!/bin/bash
 # kernel timeline of one frame: per-queue busy time and how many queues are busy over the frame (which stream is the critical path?)
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:?}" || exit 1
 rm -rf gpurun_out/tl; mkdir -p gpurun_out/tl gpurun_out/out
 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tl -o t -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > gpurun_out/tl/log 2>&1
 python3 - <<'PY'
