@@ -78,7 +78,12 @@ static int tile_grid(int fx, int fy, int tw) {
 
 // G-buffer / reservoir views. The ABI layout is the reference's SoA (one array per field). mirres_render's internal buffers use packed records so
 // that a neighbour gather touches one or two cache lines instead of seven:  GBufD::rec = 64 B per pixel {n.xyz depth | ray_dir.xyz occ | brdf.xyz 0 |
-// pos.xyz 0};  ResD::rec = 32 B per slot {light_data.xyz inv_pdf | M(int bits) weight 0 0}. Same values, same arithmetic — only the addresses differ.
+// pos.xyz 0};  ResD::rec = 32 B per slot {light_data.xyz inv_pdf | M(int bits) weight vcode lum}. Same values, same arithmetic — only the addresses differ.
+// lum (packed records only, round 3) = luminance of the environment radiance along the stored light sample, luminance(env_radiance(E, oct_decode(light_data.yz))):
+// a pure function of the sample, evaluated once when the sample enters a reservoir (the initial pass has it anyway) and carried with it through the temporal and
+// spatial merges, instead of being recomputed (acos, atan2, sin, four texel gathers) by every pass that evaluates a target function for the sample — the temporal
+// merge thrice, the spatial merge six times per pixel. The target function only ever needs that luminance (res.slang:70-77), and a carried value has the bits of a
+// recomputed one.  Empty reservoirs (weight 0) carry 0: every product their luminance enters is multiplied by that weight.
 struct GBufD { const float *occ, *pos, *normal_depth, *brdf, *ray_dir; const float4* rec; };
 struct ResD { float* light_data; float* light_pdf; int32_t* M; float* weight; float4* rec; };
 struct GPix { v3 n; float depth; v3 rd; float occ; v3 brdf; };
@@ -99,18 +104,18 @@ MR_DEV v3 load_gpos(const GBufD& G, size_t i) { if (G.rec) { const float4 d = G.
 // an earlier stage traced for it — the initial candidate's ray, or the spatial pass's "canonical pixel towards the neighbour's light" ray —
 // so that stage's answer is carried along with the sample (through the temporal merge only when history comes from the same pixel) and the
 // final stage traces only what is still unknown: one shadow ray in five disappears, results unchanged by construction.
-struct ResV { v3 light_data; float light_pdf; int M; float weight; int vcode; };
-struct Ris { v3 light_data; float inv_pdf, weightSum, M, weight, canonicalWeight; int vcode; };
+struct ResV { v3 light_data; float light_pdf; int M; float weight; int vcode; float lum; bool has_lum; };
+struct Ris { v3 light_data; float inv_pdf, weightSum, M, weight, canonicalWeight; int vcode; float lum; };
 
-MR_DEV Ris empty_ris() { Ris s; s.light_data = V3(0.f); s.inv_pdf = 0.f; s.weightSum = 0.f; s.M = 0.f; s.weight = 0.f; s.canonicalWeight = 0.f; s.vcode = 0; return s; }
+MR_DEV Ris empty_ris() { Ris s; s.light_data = V3(0.f); s.inv_pdf = 0.f; s.weightSum = 0.f; s.M = 0.f; s.weight = 0.f; s.canonicalWeight = 0.f; s.vcode = 0; s.lum = 0.f; return s; }
 MR_DEV ResV load_res(const ResD& R, size_t i) {
     ResV r;
-    if (R.rec) { const float4 a = R.rec[2 * i], b = R.rec[2 * i + 1]; r.light_data = V3(a.x, a.y, a.z); r.light_pdf = a.w; r.M = __float_as_int(b.x); r.weight = b.y; r.vcode = __float_as_int(b.z); }
-    else { r.light_data = ld3(R.light_data, i); r.light_pdf = R.light_pdf[i]; r.M = R.M[i]; r.weight = R.weight[i]; r.vcode = 0; }
+    if (R.rec) { const float4 a = R.rec[2 * i], b = R.rec[2 * i + 1]; r.light_data = V3(a.x, a.y, a.z); r.light_pdf = a.w; r.M = __float_as_int(b.x); r.weight = b.y; r.vcode = __float_as_int(b.z); r.lum = b.w; r.has_lum = true; }
+    else { r.light_data = ld3(R.light_data, i); r.light_pdf = R.light_pdf[i]; r.M = R.M[i]; r.weight = R.weight[i]; r.vcode = 0; r.lum = 0.f; r.has_lum = false; }
     return r;
 }
-MR_DEV void store_res(const ResD& R, size_t i, v3 ld, float ipdf, int M, float w, int vcode = 0) {
-    if (R.rec) { float4 a, b; a.x = ld.x; a.y = ld.y; a.z = ld.z; a.w = ipdf; b.x = __int_as_float(M); b.y = w; b.z = __int_as_float(vcode); b.w = 0.f; R.rec[2 * i] = a; R.rec[2 * i + 1] = b; }
+MR_DEV void store_res(const ResD& R, size_t i, v3 ld, float ipdf, int M, float w, int vcode = 0, float lum = 0.f) {
+    if (R.rec) { float4 a, b; a.x = ld.x; a.y = ld.y; a.z = ld.z; a.w = ipdf; b.x = __int_as_float(M); b.y = w; b.z = __int_as_float(vcode); b.w = lum; R.rec[2 * i] = a; R.rec[2 * i + 1] = b; }
     else { st3(R.light_data, i, ld); R.light_pdf[i] = ipdf; R.M[i] = M; R.weight[i] = w; }
 }
 MR_DEV v3 res_light(const ResD& R, size_t i) { if (R.rec) { const float4 a = R.rec[2 * i]; return V3(a.x, a.y, a.z); } return ld3(R.light_data, i); }
@@ -120,8 +125,11 @@ MR_DEV int res_vcode(const ResD& R, size_t i) { return R.rec ? __float_as_int(R.
 MR_DEV void store_zero(const ResD& R, size_t i) { store_res(R, i, V3(0.f), 0.f, 0, 0.f); }
 MR_DEV void store_ris(const ResD& R, size_t i, const Ris& s) {
     if (isinf(s.weight) || isnan(s.weight)) { store_zero(R, i); return; }
-    store_res(R, i, s.light_data, s.inv_pdf, (int)s.M, s.weight, s.vcode);
+    store_res(R, i, s.light_data, s.inv_pdf, (int)s.M, s.weight, s.vcode, s.lum);
 }
+// luminance of the radiance along a loaded reservoir's sample: the carried value (packed records) or the evaluation itself (the reference's SoA layout)
+MR_DEV float sample_lum(const EnvD& E, const ResV& r, v3 dir) { return r.has_lum ? r.lum : luminance(env_radiance(E, dir)); }
+MR_DEV float target_lum(const rtarget::Ctx& c, float lum, v3 L) { return fmaxf(0.f, lum * rtarget::eval_brdf(c, L)); }   // rtarget::target with the luminance given
 MR_DEV void put_ray(Ray* q, uint32_t slot, v3 pos, v3 dir, float vis_near) {
     v3 o = pos + vis_near * dir;  // origin offset along the RAY direction (VIS_near, e.g. InitialResampling.slang:264-265)
     float4 a, b;
@@ -262,7 +270,7 @@ __global__ void __launch_bounds__(MR_IGEN_BLOCK) k_initial_gen(mirres_config_t C
                 float sourcePdf = lerpf(lpdf, rtarget::pdf_brdf(ctx, ldir), ratio);  // res.slang:79-91
                 float w = mr_div(targetPdf, sourcePdf);                                // res.slang:93-113
                 s.weightSum += w; s.M += 1.f;
-                if (rnd(sg) * s.weightSum < w) { s.light_data = ld; s.inv_pdf = lpdf; s.weight = targetPdf; }
+                if (rnd(sg) * s.weightSum < w) { s.light_data = ld; s.inv_pdf = lpdf; s.weight = targetPdf; s.lum = ax.w; }
             }
             for (int i = 0; i < C.initial_brdf_samples; ++i) {
                 float xa = rnd(sg), xb = rnd(sg), xc = rnd(sg);
@@ -273,12 +281,13 @@ __global__ void __launch_bounds__(MR_IGEN_BLOCK) k_initial_gen(mirres_config_t C
                     ld = V3(1.0f, o.x, o.y);
                 }
                 if (ld.x < 0.1f) { s.M += 1.f; continue; }
-                v3 em = env_radiance(E, dir);
-                float targetPdf = rtarget::target(ctx, em, dir);
+                const float elum = luminance(env_radiance(E, dir));
+                float targetPdf = target_lum(ctx, elum, dir);
                 float sourcePdf = lerpf(lpdf, rtarget::pdf_brdf(ctx, dir), ratio);
                 float w = mr_div(targetPdf, sourcePdf);
                 s.weightSum += w; s.M += 1.f;
-                if (rnd(sg) * s.weightSum < w) { s.light_data = ld; s.inv_pdf = lpdf; s.weight = targetPdf; }
+                // the carried luminance is that of the direction later passes will SEE — the octahedral code decoded again —, not of `dir` itself
+                if (rnd(sg) * s.weightSum < w) { s.light_data = ld; s.inv_pdf = lpdf; s.weight = targetPdf; s.lum = luminance(env_radiance(E, oct_decode(V2(ld.y, ld.z)))); }
             }
             if (s.light_data.x > 0.1f) { want = true; rpos = load_gpos(G, pi); rdir = oct_decode(V2(s.light_data.y, s.light_data.z)); }
             // reservoir as if the sample is visible; k_initial_resolve empties it when the shadow ray hits (:269-281)
@@ -325,25 +334,28 @@ __global__ void __launch_bounds__(MR_BLOCK) k_temporal(mirres_config_t C, EnvD E
     const rtarget::Ctx pctx = rtarget::make_ctx(pn, gq.rd, gq.brdf);
     Ris s = empty_ris();
     v3 ldir = oct_decode(V2(cur.light_data.y, cur.light_data.z));
-    float targetPdf = rtarget::target(ctx, env_radiance(E, ldir), ldir);
+    const float clum = sample_lum(E, cur, ldir);
+    float targetPdf = target_lum(ctx, clum, ldir);
     {
         float w = targetPdf * cur.weight * cur.M;  // res.slang:116-134
         s.weightSum += w; s.M += cur.M;
-        if (rnd(sg) * s.weightSum < w) { s.light_data = cur.light_data; s.inv_pdf = cur.light_pdf; s.weight = targetPdf; s.vcode = cur.vcode; }
+        if (rnd(sg) * s.weightSum < w) { s.light_data = cur.light_data; s.inv_pdf = cur.light_pdf; s.weight = targetPdf; s.vcode = cur.vcode; s.lum = clum; }
     }
     v3 pldir = oct_decode(V2(prev.light_data.y, prev.light_data.z));
-    float preTarget = rtarget::target(ctx, env_radiance(E, pldir), pldir);
+    const float plum = sample_lum(E, prev, pldir);
+    float preTarget = target_lum(ctx, plum, pldir);
     bool usedPrev;
     {
         float w = preTarget * prev.weight * prev.M;
         s.weightSum += w; s.M += prev.M;
         usedPrev = rnd(sg) * s.weightSum < w;
-        if (usedPrev) { s.light_data = prev.light_data; s.inv_pdf = prev.light_pdf; s.weight = preTarget; s.vcode = (qi == (size_t)pi) ? prev.vcode : 0; }
+        if (usedPrev) { s.light_data = prev.light_data; s.inv_pdf = prev.light_pdf; s.weight = preTarget; s.vcode = (qi == (size_t)pi) ? prev.vcode : 0; s.lum = plum; }
     }
     v3 sdir = oct_decode(V2(s.light_data.y, s.light_data.z));
-    v3 sem = env_radiance(E, sdir);
-    float currentPdf = rtarget::target(ctx, sem, sdir);
-    float prevPdf = rtarget::target(pctx, sem, sdir);
+    // the selected sample is the current one, the history's, or none (nothing selected: s.weight = 0 and the result is the empty reservoir whatever this luminance is)
+    const float slum = cur.has_lum ? s.lum : luminance(env_radiance(E, sdir));
+    float currentPdf = target_lum(ctx, slum, sdir);
+    float prevPdf = target_lum(pctx, slum, sdir);
     float normalization = mr_div(usedPrev ? prevPdf : currentPdf, cur.M * currentPdf + prev.M * prevPdf);
     s.weight = s.weight > 0.f ? mr_div(s.weightSum * normalization, s.weight) : 0.f;
     store_ris(R, pi, s);
@@ -452,8 +464,8 @@ __global__ void __launch_bounds__(MR_SRES_TILE * MR_SRES_TILE) k_spatial_resolve
     const uint32_t startIndex = (uint32_t)(rnd(sg) * C.neighbor_offset_count);
     ResV cur = load_res(PR, pi);
     const v3 cdir = oct_decode(V2(cur.light_data.y, cur.light_data.z));
-    const v3 cem = env_radiance(E, cdir);
-    const float curTarget = rtarget::target(ctx, cem, cdir);
+    const float clum = sample_lum(E, cur, cdir);
+    const float curTarget = target_lum(ctx, clum, cdir);
     s.canonicalWeight = 1.f;
     uint32_t validNeighbors = 1;
     const uint32_t k = (uint32_t)C.neighbor_count;
@@ -478,13 +490,13 @@ __global__ void __launch_bounds__(MR_SRES_TILE * MR_SRES_TILE) k_spatial_resolve
         const rtarget::Ctx nctx = rtarget::make_ctx(nn, gnb[i].rd, gnb[i].brdf);
         ++validNeighbors;
         const v3 ndir = oct_decode(V2(nbr.light_data.y, nbr.light_data.z));
-        const v3 nem = env_radiance(E, ndir);
+        const float nlum = sample_lum(E, nbr, ndir);
         const float canonicalVis = hit[hs] ? 0.f : 1.f, candidateVis = hit[hs + 1] ? 0.f : 1.f;
         hs += 2;
         // streamingResampleStepMisUnbiased (res.slang:173-213)
-        float candTarget = rtarget::target(nctx, nem, ndir);
-        float candAtOther = rtarget::target(ctx, nem, ndir);
-        float canonAtOther = rtarget::target(nctx, cem, cdir);
+        float candTarget = target_lum(nctx, nlum, ndir);
+        float candAtOther = target_lum(ctx, nlum, ndir);
+        float canonAtOther = target_lum(nctx, clum, cdir);
         candAtOther *= canonicalVis;
         canonAtOther *= candidateVis;
         float N0 = (float)((uint32_t)nbr.M * k), N1 = (float)cur.M;
@@ -494,12 +506,12 @@ __global__ void __launch_bounds__(MR_SRES_TILE * MR_SRES_TILE) k_spatial_resolve
         // state.M (+= M_j * min(mFactor..)) is overwritten with M_canonical below (:302), so it is not tracked
         s.weightSum += w;
         s.canonicalWeight += m1;
-        if (rnd(sg) * s.weightSum < w) { s.light_data = nbr.light_data; s.inv_pdf = nbr.light_pdf; s.weight = candAtOther; s.vcode = canonicalVis > 0.f ? 1 : 2; }
+        if (rnd(sg) * s.weightSum < w) { s.light_data = nbr.light_data; s.inv_pdf = nbr.light_pdf; s.weight = candAtOther; s.vcode = canonicalVis > 0.f ? 1 : 2; s.lum = nlum; }
     }
     {   // streamingResampleFinalizeMis (res.slang:215-232)
         float w = curTarget * cur.weight * s.canonicalWeight;
         s.weightSum += w;
-        if (rnd(sg) * s.weightSum < w) { s.light_data = cur.light_data; s.inv_pdf = cur.light_pdf; s.weight = curTarget; s.vcode = cur.vcode; }
+        if (rnd(sg) * s.weightSum < w) { s.light_data = cur.light_data; s.inv_pdf = cur.light_pdf; s.weight = curTarget; s.vcode = cur.vcode; s.lum = clum; }
     }
     s.M = (float)cur.M;
     s.weight = s.weight > 0.f ? mr_div(mr_div(s.weightSum, (float)validNeighbors), s.weight) : 0.f;
