@@ -441,8 +441,16 @@ __global__ void __launch_bounds__(MR_SGEN_BLOCK) k_spatial_gen(mirres_config_t C
     if (pi < N) { slot_out[pi] = cnt ? (int32_t)base : -1; mask_out[pi] = mask; }
 }
 
+#ifndef MR_SRES_WAVES
+#define MR_SRES_WAVES 0      // experiment: waves per SIMD the register allocator must make room for (0 = its own choice: 140 VGPRs, three waves)
+#endif
+#if MR_SRES_WAVES
+#define MR_SRES_ATTR __attribute__((amdgpu_waves_per_eu(MR_SRES_WAVES, MR_SRES_WAVES)))
+#else
+#define MR_SRES_ATTR
+#endif
 template <int MR_MAX_NB>
-__global__ void __launch_bounds__(MR_SRES_TILE * MR_SRES_TILE) k_spatial_resolve(mirres_config_t C, EnvD E, GBufD G, ResD R, ResD PR, const float* __restrict__ noff,
+__global__ void MR_SRES_ATTR __launch_bounds__(MR_SRES_TILE * MR_SRES_TILE) k_spatial_resolve(mirres_config_t C, EnvD E, GBufD G, ResD R, ResD PR, const float* __restrict__ noff,
                                                               uint32_t frameIndex, int fx, int fy, int N, int y_off, const float* __restrict__ occ_own,
                                                               const int32_t* __restrict__ slot, const uint32_t* __restrict__ mask_in, const int32_t* __restrict__ hit,
                                                               uint32_t* __restrict__ reset_counter, uint32_t* __restrict__ reset_heads) {
