@@ -104,7 +104,7 @@ struct mirres_ctx {
     int32_t* slot_c = nullptr;      // [N] closest-ray slot (or -1)
     float* pend = nullptr;          // [N,18] pending NEE / BSDF contributions of the bounce pass
     float* noff = nullptr;          // [neighbor_offset_count,2]
-    float* tile_aux = nullptr;      // [tiles,4] per tile sample: light direction xyz + luminance of its radiance
+    float* tile_aux = nullptr;      // [tiles,8] per tile sample: {light direction xyz, luminance of its radiance | pdf, light_data xyz}
     // frame buffers of the fused loop (mirres_render)
     float* pool = nullptr; size_t pool_floats = 0;
     // K-sample batch of the path-tracing stages (mirres_render): queues + per-slot state for K * N sample slots
