@@ -142,6 +142,10 @@ struct PtQueues {
     int N, NV;                          // pixels, sample slots (K * N)
     int lane;                           // stream of mirres_render the queue is worked on (0 chain, 1 bulk, 2 / 4 path tracing, 3 final stages): own traversal head sets
     int first_sample_is_zero;           // sample 0 of the frame has one pass fewer before the path-tracing stages (no temporal pass)
+    // Live-slot lists of the batched path-tracing stages (mirres_render; NULL = every slot, the stepwise ABI): the slots whose path is still going after a
+    // resolve stage — a hit, or a specular miss that picks up the environment at the next vertex — in two ping-pong buffers; counters[3 + b] counts list b.
+    // Of a K-sample batch's 82 M slots a few million survive the first indirect vertex; the bounce kernels run over the list instead of over all slots.
+    int32_t* live[2]; int live_cur;
 };
 int launch_initial_batch(mirres_ctx* ctx, mirres_bvh* bvh, const mirres_env_t* env, const mirres_gbuf_t* g, const mirres_res_t* res, float* tile_data,
                          float* tile_pdf, float* tile_aux, uint32_t frame0, int K, const PtQueues* q, hipStream_t s);

@@ -26,7 +26,7 @@ int launch_eaw5(int fx, int fy, int step, float c_phi, float n_phi, float p_phi,
 int launch_matnet_scatter(const mirres_matnet_t* m, const float* occ, const float* pos, int n, float* kd, float* rm, int use_scale, const float* scale3,
                           const float* const_kd, const float* const_rm, hipStream_t s);
 int launch_matnet_scatter_mfma(const mirres_matnet_t* m, const float* occ, const float* pos, int n, float* kd, float* rm, int use_scale, const float* scale3,
-                               int32_t* index, uint32_t* count, hipStream_t s);
+                               int32_t* index, uint32_t* count, hipStream_t s, const int32_t* live, const uint32_t* live_count);
 
 // run_restir_di_with_pt :484-486 + restir_di_with_pt :279-287
 __global__ void __launch_bounds__(MR_BLOCK) k_prep(int N, float* __restrict__ occ, const float* __restrict__ ray_dir_in, const float* __restrict__ normal,
@@ -190,6 +190,7 @@ static PtSet pt_set(const PtBatch& PB, int h, size_t cap, int nb) {
     S.q.any_rays = PB.q.any_rays + 2 * o; S.q.any_hit = PB.q.any_hit + 2 * o; S.q.cl_rays = PB.q.cl_rays + o; S.q.cl_hit = PB.q.cl_hit + o;
     S.q.counters = PB.q.counters + 8 * h;
     S.q.slot_a = PB.q.slot_a + o; S.q.mask_a = PB.q.mask_a + o; S.q.slot_c = PB.q.slot_c + o; S.q.pend = PB.q.pend + 18 * o;
+    S.q.live[0] = PB.q.live[0] + o; S.q.live[1] = PB.q.live[1] + o; S.q.live_cur = 0;
     S.prd = PB.prd + 5 * o;
     for (int k = 0; k < 2; k++) { S.pos[k] = PB.pos[k] + 3 * o; S.rd[k] = PB.rd[k] + 3 * o; S.n[k] = PB.n[k] + 3 * o; S.occ[k] = PB.occ[k] + o; }
     S.kd = PB.kd + 3 * o; S.rm = PB.rm + 2 * o;
@@ -209,7 +210,7 @@ static int carve_batch(mirres_ctx* ctx, int N, int K, int max_bounce, size_t TS,
     const int nb = max_bounce > 0 ? max_bounce : 1;
     auto bytes_for = [&](int k) {
         const size_t NV = (size_t)k * (size_t)N;
-        return al(sizeof(Ray) * 2 * NV) + al(4 * 2 * NV) + al(sizeof(Ray) * NV) + al(sizeof(HitRec) * NV) + al(64) + 3 * al(4 * NV) + al(4 * 18 * NV)
+        return al(sizeof(Ray) * 2 * NV) + al(4 * 2 * NV) + al(sizeof(Ray) * NV) + al(sizeof(HitRec) * NV) + al(64) + 5 * al(4 * NV) + al(4 * 18 * NV)
              + al(4 * 5 * NV) + 2 * (3 * al(4 * 3 * NV) + al(4 * NV)) + al(4 * 3 * NV) + al(4 * 2 * NV) + al(4 * 9 * NV * (size_t)nb) + al(4 * NV * (size_t)nb)
              + 4 * al(4 * 8 * NV) + al(4 * 3 * (size_t)k * TS) + al(4 * (size_t)k * TS) + al(32 * (size_t)k * TS)
              + 2 * (al(sizeof(Ray) * NV) + 2 * al(4 * NV) + al(64));
@@ -261,6 +262,7 @@ static int carve_batch(mirres_ctx* ctx, int N, int K, int max_bounce, size_t TS,
     PB.q.cl_rays = (Ray*)take(sizeof(Ray) * NV); PB.q.cl_hit = (HitRec*)take(sizeof(HitRec) * NV);
     PB.q.counters = (uint32_t*)take(64);
     PB.q.slot_a = (int32_t*)take(4 * NV); PB.q.mask_a = (uint32_t*)take(4 * NV); PB.q.slot_c = (int32_t*)take(4 * NV);
+    PB.q.live[0] = (int32_t*)take(4 * NV); PB.q.live[1] = (int32_t*)take(4 * NV); PB.q.live_cur = 0;
     PB.q.pend = (float*)take(4 * 18 * NV);
     PB.q.N = N; PB.q.NV = (int)NV; PB.q.first_sample_is_zero = 0; PB.q.lane = 0;
     PB.prd = (float*)take(4 * 5 * NV);
@@ -275,7 +277,7 @@ static int carve_batch(mirres_ctx* ctx, int N, int K, int max_bounce, size_t TS,
     PB.tile_data = (float*)take(4 * 3 * (size_t)K * TS); PB.tile_pdf = (float*)take(4 * (size_t)K * TS); PB.tile_aux = (float*)take(32 * (size_t)K * TS);
     PB.qf = PB.q;
     PB.qf.any_rays = (Ray*)take(sizeof(Ray) * NV); PB.qf.any_hit = (int32_t*)take(4 * NV); PB.qf.slot_a = (int32_t*)take(4 * NV); PB.qf.counters = (uint32_t*)take(64);
-    PB.qf.cl_rays = nullptr; PB.qf.cl_hit = nullptr; PB.qf.mask_a = nullptr; PB.qf.slot_c = nullptr; PB.qf.pend = nullptr;
+    PB.qf.cl_rays = nullptr; PB.qf.cl_hit = nullptr; PB.qf.mask_a = nullptr; PB.qf.slot_c = nullptr; PB.qf.pend = nullptr; PB.qf.live[0] = PB.qf.live[1] = nullptr; PB.qf.live_cur = 0;
     PB.qv = PB.qf;
     PB.qv.any_rays = (Ray*)take(sizeof(Ray) * NV); PB.qv.any_hit = (int32_t*)take(4 * NV); PB.qv.slot_a = (int32_t*)take(4 * NV); PB.qv.counters = (uint32_t*)take(64);
     return 0;
@@ -516,12 +518,15 @@ int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args
             PtQueues Q = T.q; Q.NV = ks * N; Q.first_sample_is_zero = (is == 0); if (h) Q.lane = 4;
             uint32_t fi = a->random_offset + passes * (uint32_t)is + 5;   // pass number of new_dir for a sample with a temporal pass before it
             mirres_path_t P0 = {occ, a->pos, a->normal, B.ray_dir, a->kd, a->rough_metal, T.prd, T.pos[0], T.rd[0], T.occ[0], T.n[0]};
+            // the bounce kernels run over live-slot lists and leave the other slots alone: the per-bounce masks k_pt_reduce reads must say "nothing" there
+            if (max_bounce > 0) MR_HIP(hipMemsetAsync(T.maskb, 0, sizeof(uint32_t) * (size_t)nbq * (size_t)Q.NV, sq));
+            Q.live_cur = 0;
             rc = launch_new_dir(ctx, bvh, &P0, fi, 0, sq, &Q); if (rc) return rc;
             fi += 5;
             int src = 0;
             for (int bo = 1; bo <= max_bounce; bo++) {
                 // material lookup at the new vertices: compacted slot list -> hash-grid gather -> MFMA MLP -> scatter (slot_c is free between passes)
-                if (a->mat && !(getenv("MIRRES_MATNET") && getenv("MIRRES_MATNET")[0] == 'v')) rc = launch_matnet_scatter_mfma(a->mat, T.occ[src], T.pos[src], Q.NV, T.kd, T.rm, a->use_scale, a->scale, Q.slot_c, &Q.counters[2], sq);
+                if (a->mat && !(getenv("MIRRES_MATNET") && getenv("MIRRES_MATNET")[0] == 'v')) rc = launch_matnet_scatter_mfma(a->mat, T.occ[src], T.pos[src], Q.NV, T.kd, T.rm, a->use_scale, a->scale, Q.slot_c, &Q.counters[2], sq, Q.live[Q.live_cur], &Q.counters[3 + Q.live_cur]);
                 else rc = launch_matnet_scatter(a->mat, T.occ[src], T.pos[src], Q.NV, T.kd, T.rm, a->use_scale, a->scale, a->const_kd, a->const_rm, sq);
                 if (rc) return rc;
                 mirres_path_t Pb = {T.occ[src], T.pos[src], T.n[src], T.rd[src], T.kd, T.rm, T.prd, T.pos[src ^ 1], T.rd[src ^ 1], T.occ[src ^ 1], T.n[src ^ 1]};
@@ -529,7 +534,7 @@ int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args
                 Q.mask_a = T.maskb + (size_t)(bo - 1) * (size_t)Q.NV;      // kept per bounce for k_pt_reduce
                 rc = launch_bounce(ctx, bvh, &E, &Pb, fi, (uint32_t)bo, cb, cb + 3 * (size_t)Q.NV, cb + 6 * (size_t)Q.NV, nullptr, nullptr, nullptr, sq, &Q); if (rc) return rc;
                 fi += 5;
-                src ^= 1;
+                src ^= 1; Q.live_cur ^= 1;
             }
             if (max_bounce > 0) {
                 // totals 3..5 take the sub-batches in sample order whatever stream they ran on (fp32 sums: the order is part of the result)
