@@ -302,16 +302,19 @@ __global__ void __launch_bounds__(MR_BLOCK) k_active_list(const float* __restric
 // the same list from a live-slot list (mirres_render's batches): only the slots whose path is still going are looked at
 __global__ void __launch_bounds__(MR_BLOCK) k_active_from_live(const float* __restrict__ occ, const int32_t* __restrict__ live, const uint32_t* __restrict__ live_count,
                                                                int32_t* __restrict__ index, uint32_t* __restrict__ count) {
-    const uint32_t t0 = blockIdx.x * (MR_BLOCK * 8u) + threadIdx.x, nl = *live_count;   // eight entries per thread (t0 + j * MR_BLOCK: coalesced): one queue atomic per 2048
-    int sl[8]; uint32_t n = 0;
+    const uint32_t nl = *live_count;
+    for (uint32_t b0 = blockIdx.x * (MR_BLOCK * 8u); b0 < nl; b0 += gridDim.x * (MR_BLOCK * 8u)) {   // a fixed grid strides over the list
+        const uint32_t t0 = b0 + threadIdx.x;   // eight entries per thread (t0 + j * MR_BLOCK: coalesced): one queue atomic per 2048
+        int sl[8]; uint32_t n = 0;
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        sl[j] = -1;
-        if (t0 + j * MR_BLOCK < nl) { const int sv = live[t0 + j * MR_BLOCK]; if (occ[sv] >= 0.5f) { sl[j] = sv; n++; } }
+        for (int j = 0; j < 8; j++) {
+            sl[j] = -1;
+            if (t0 + j * MR_BLOCK < nl) { const int sv = live[t0 + j * MR_BLOCK]; if (occ[sv] >= 0.5f) { sl[j] = sv; n++; } }
+        }
+        uint32_t o = block_append(count, n > 0, n);
+#pragma unroll
+        for (int j = 0; j < 8; j++) if (sl[j] >= 0) index[o++] = sl[j];
     }
-    uint32_t o = block_append(count, n > 0, n);
-#pragma unroll
-    for (int j = 0; j < 8; j++) if (sl[j] >= 0) index[o++] = sl[j];
 }
 
 __global__ void __launch_bounds__(MR_BLOCK) k_pack_grid(const float* __restrict__ in, uint16_t* __restrict__ out, int64_t n) {
@@ -332,7 +335,7 @@ int launch_matnet_scatter_mfma(const mirres_matnet_t* m, const float* occ, const
     float sx = scale3 ? scale3[0] : 1.f, sy = scale3 ? scale3[1] : 1.f, sz = scale3 ? scale3[2] : 1.f;
     MR_HIP(hipMemsetAsync(count, 0, sizeof(uint32_t), s));
     // (with a live list the whole-map clamp of use_scale is not applied to slots without a vertex: nothing reads their albedo)
-    if (live) k_active_from_live<<<grid_for(n, MR_BLOCK * 8), MR_BLOCK, 0, s>>>(occ, live, live_count, index, count);
+    if (live) { int ga = grid_for(n, MR_BLOCK * 8); if (ga > 256 * 8) ga = 256 * 8; k_active_from_live<<<ga, MR_BLOCK, 0, s>>>(occ, live, live_count, index, count); }
     else k_active_list<<<grid_for(n, MR_BLOCK * MR_AL_PER), MR_BLOCK, 0, s>>>(occ, n, index, count, kd, use_scale);
     int g = grid_for(n, MR_BLOCK); if (g > 256 * 8) g = 256 * 8;
     k_mlp_mfma<1, 2><<<g, MR_BLOCK, 0, s>>>(matd(m), host_levels(nullptr), nullptr, pos, index, count, 0, nullptr, kd, rm, use_scale, sx, sy, sz);

@@ -168,8 +168,12 @@ __global__ void __launch_bounds__(MR_BGEN_BLOCK) k_bounce_gen(mirres_path_t P, E
                                                          int32_t* __restrict__ slot_a, uint32_t* __restrict__ mask_out, int32_t* __restrict__ slot_c,
                                                          float* __restrict__ pend, const int32_t* __restrict__ live_in, const uint32_t* __restrict__ live_in_count) {
     // sample slot (all vertex data of a bounce is per slot): every slot, or the entries of the live list (then the dead slots are not touched at all: their
-    // masks were cleared for the whole batch, nothing else of theirs is read again)
-    const int pi = live_slot(live_in, live_in_count, blockIdx.x * blockDim.x + threadIdx.x, NV);
+    // masks were cleared for the whole batch, nothing else of theirs is read again). The list's length is known on the device only, so the grid is a fixed
+    // number of blocks that stride over it (no launch of 320 k blocks of which 14 k find work); without a list the loop runs once.
+    const int n_items = live_in ? (int)*live_in_count : NV;
+    for (int t0 = blockIdx.x * blockDim.x; t0 < n_items; t0 += gridDim.x * blockDim.x) {
+    const int t_ = t0 + (int)threadIdx.x;
+    const int pi = live_in ? (t_ < n_items ? live_in[t_] : NV) : t_;
     uint32_t mask = 0;  // bit0 NEE shadow ray, bit1 BSDF shadow ray, bit2 continuation ray
     v3 sp = V3(0.f), nee_dir = V3(0.f), bsdf_dir = V3(0.f), next_dir = V3(0.f);
     if (pi < NV) {
@@ -271,6 +275,7 @@ __global__ void __launch_bounds__(MR_BGEN_BLOCK) k_bounce_gen(mirres_path_t P, E
     if (mask & 2u) put_ray(qa, base + (mask & 1u), sp, bsdf_dir, vis_near);
     if (mask & 4u) put_ray(qc, cs, sp, next_dir, vis_near);
     if (pi < NV) { slot_a[pi] = na ? (int32_t)base : -1; mask_out[pi] = mask; slot_c[pi] = (mask & 4u) ? (int32_t)cs : -1; }
+    }
 }
 
 template <bool ACC>
@@ -307,12 +312,16 @@ __global__ void __launch_bounds__(MR_BLOCK) k_bounce_resolve(mirres_path_t P, in
                                                              float* __restrict__ spec_color, float* __restrict__ acc_c, float* __restrict__ acc_d, float* __restrict__ acc_s, int sparse,
                                                              const int32_t* __restrict__ live_in, const uint32_t* __restrict__ live_in_count,
                                                              int32_t* __restrict__ live_out, uint32_t* __restrict__ live_out_count) {
-    const int pi = live_slot(live_in, live_in_count, blockIdx.x * blockDim.x + threadIdx.x, N);
-    bool alive = false;
-    if (pi < N) alive = bounce_resolve_slot<ACC>(P, pi, slot_a, mask_in, slot_c, hit, rec, pend, color, diff_color, spec_color, acc_c, acc_d, acc_s, sparse);
-    if (live_out) {
-        const uint32_t o = block_append(live_out_count, alive);
-        if (alive) live_out[o] = pi;
+    const int n_items = live_in ? (int)*live_in_count : N;
+    for (int t0 = blockIdx.x * blockDim.x; t0 < n_items; t0 += gridDim.x * blockDim.x) {     // a fixed grid strides over the live list (see k_bounce_gen)
+        const int t_ = t0 + (int)threadIdx.x;
+        const int pi = live_in ? (t_ < n_items ? live_in[t_] : N) : t_;
+        bool alive = false;
+        if (pi < N) alive = bounce_resolve_slot<ACC>(P, pi, slot_a, mask_in, slot_c, hit, rec, pend, color, diff_color, spec_color, acc_c, acc_d, acc_s, sparse);
+        if (live_out) {
+            const uint32_t o = block_append(live_out_count, alive);
+            if (alive) live_out[o] = pi;
+        }
     }
 }
 
@@ -355,13 +364,15 @@ int launch_bounce(mirres_ctx* ctx, mirres_bvh* bvh, const mirres_env_t* env, con
     const int32_t* lin = Q.live[0] ? Q.live[Q.live_cur] : nullptr; const uint32_t* lin_n = &Q.counters[3 + Q.live_cur];
     int32_t* lout = Q.live[0] ? Q.live[Q.live_cur ^ 1] : nullptr; uint32_t* lout_n = &Q.counters[3 + (Q.live_cur ^ 1)];
     MR_HIP(hipMemsetAsync(&Q.counters[0], 0, 2 * sizeof(uint32_t), s));
-    k_bounce_gen<<<grid_for(NV, MR_BGEN_BLOCK), MR_BGEN_BLOCK, 0, s>>>(*p, envh(env), ctx->cfg.max_bounce, ctx->cfg.vis_near, frameIndex, bounce_count, ctx->fx, Q.N, NV, Q.first_sample_is_zero, ctx->y_off, qq ? 1 : 0,
+    // list mode: 16 blocks per CU stride over the device-side list; otherwise one thread per slot
+    const int ggen = lin ? min(grid_for(NV, MR_BGEN_BLOCK), 256 * 16) : grid_for(NV, MR_BGEN_BLOCK), gres = lin ? min(grd, 256 * 16) : grd;
+    k_bounce_gen<<<ggen, MR_BGEN_BLOCK, 0, s>>>(*p, envh(env), ctx->cfg.max_bounce, ctx->cfg.vis_near, frameIndex, bounce_count, ctx->fx, Q.N, NV, Q.first_sample_is_zero, ctx->y_off, qq ? 1 : 0,
                                                                       color, dc, sc, Q.any_rays, &Q.counters[0], Q.cl_rays, &Q.counters[1], Q.slot_a, Q.mask_a, Q.slot_c, Q.pend, lin, lin_n);
     int rc = trace_any_q(ctx, bvh, Q.any_rays, &Q.counters[0], 2 * (size_t)NV, Q.any_hit, s, Q.lane); if (rc) return rc;
     rc = trace_closest_q(ctx, bvh, Q.cl_rays, &Q.counters[1], (size_t)NV, Q.cl_hit, s, Q.lane); if (rc) return rc;
     if (lout) MR_HIP(hipMemsetAsync(lout_n, 0, sizeof(uint32_t), s));
-    if (acc_c) k_bounce_resolve<true><<<grd, MR_BLOCK, 0, s>>>(*p, NV, Q.slot_a, Q.mask_a, Q.slot_c, Q.any_hit, Q.cl_hit, Q.pend, color, dc, sc, acc_c, acc_d, acc_s, qq ? 1 : 0, lin, lin_n, lout, lout_n);
-    else k_bounce_resolve<false><<<grd, MR_BLOCK, 0, s>>>(*p, NV, Q.slot_a, Q.mask_a, Q.slot_c, Q.any_hit, Q.cl_hit, Q.pend, color, dc, sc, nullptr, nullptr, nullptr, qq ? 1 : 0, lin, lin_n, lout, lout_n);
+    if (acc_c) k_bounce_resolve<true><<<gres, MR_BLOCK, 0, s>>>(*p, NV, Q.slot_a, Q.mask_a, Q.slot_c, Q.any_hit, Q.cl_hit, Q.pend, color, dc, sc, acc_c, acc_d, acc_s, qq ? 1 : 0, lin, lin_n, lout, lout_n);
+    else k_bounce_resolve<false><<<gres, MR_BLOCK, 0, s>>>(*p, NV, Q.slot_a, Q.mask_a, Q.slot_c, Q.any_hit, Q.cl_hit, Q.pend, color, dc, sc, nullptr, nullptr, nullptr, qq ? 1 : 0, lin, lin_n, lout, lout_n);
     MR_LAUNCH_CHECK("pt_bounce");
     return 0;
 }
