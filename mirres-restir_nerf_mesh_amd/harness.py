@@ -148,10 +148,10 @@ def build_gbuffer_from_pose(worker, pose, intrinsics, H, W, ssaa=1, mlp_mat=None
 
 
 def test_view(worker, mlp_mat, env_map, pose, intrinsics, H, W, spp, ssaa=1, random_offset=0, de=2, c=2.0, n=0.1, p=0.001, max_bounce=None,
-              albedo_scale=None, shard=None, rank=0, world=1, group=None):
+              albedo_scale=None, shard=None, rank=0, world=1, group=None, return_maps=False):
     """One `--test --spp N` frame of the BRDF branch (Trainer.test_step -> render_stage1(is_test=True), nerf/renderer.py:1083-1129, 1162-1164,
     1208-1209, 1265-1302): G-buffer for the dataset camera, the fused frame (mirres_render), tone curve, alpha, SSAA down-scale, white background.
-    Returns the [H, W, 3] image in [0, 1].
+    Returns the [H, W, 3] image in [0, 1]; with `return_maps` also the dict of float maps that Trainer.test saves as EXR files (meters.write_test_maps).
     Relighting (`--envmap_path`, :1025-1026, 1086-1089, 1109-1111): pass the external map as `env_map` and `albedo_scale` = (--albedo_scale_x, _y,
     _z): the primary albedo is scaled here and `use_scale` does the same at the indirect hits.
     One view on several GPUs: `shard` = "strips" (exact row strips + halo exchange + all-gather of radiance rows, dist.render_strips) or "spp"
@@ -172,7 +172,17 @@ def test_view(worker, mlp_mat, env_map, pose, intrinsics, H, W, spp, ssaa=1, ran
     else:
         out = RR.render_fused(ctx, worker, mlp_mat, use_scale, scale, env_map, g["occ"].clone(), g["normal"], g["depth"], g["kd"], g["rm"], g["ray_dir"], g["pos"],
                               spp, de, 2 ** (de - 1), c, n, p, random_offset)[0]
-    return postprocess(torch.nan_to_num(out[0], 0.0), g["occ"], H, W, ssaa)
+    img = postprocess(torch.nan_to_num(out[0], 0.0), g["occ"], H, W, ssaa)
+    if not return_maps:
+        return img
+    # the float maps Trainer.test writes next to the image (preds_brdf_list of render_stage1, nerf/renderer.py:1310-1330; utils.py:1372-1377): albedo, (0, roughness,
+    # metallic), shading normal, environment map, denoised diffuse / specular light — at the internal (ssaa) resolution, background zero
+    h, w = g["fy"], g["fx"]
+    on = g["occ"]
+    m3 = lambda x: (x * on).view(h, w, 3)
+    ks = torch.cat((torch.zeros_like(g["rm"][:, :1]), g["rm"]), dim=1)
+    maps = dict(kd=m3(g["kd"]), ks=m3(ks), normal=m3(g["normal"]), env_map=env_map.detach(), rgb_diffuse_light=m3(out[1]), rgb_specular_light=m3(out[2]))
+    return img, maps
 
 
 test_view.__test__ = False      # not a pytest case

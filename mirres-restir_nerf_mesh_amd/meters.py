@@ -116,3 +116,81 @@ def write_test_frame(save_path, name, index, image_brdf, depth=None):
         out.append(os.path.join(save_path, "%s_%04d_depth.png" % (name, index)))
         write_png(out[1], (d * 255).astype(np.uint8))
     return out
+
+
+# ---------------------------------------------------------------------------------------------- OpenEXR (the material / light maps of Trainer.test)
+def write_exr(path, img):
+    """What `pyexr.write(path, array)` produces for the maps Trainer.test saves next to the BRDF image (nerf/utils.py:1372-1377: kd, ks, normal, env_map and
+    the diffuse / specular light, float32): a single-part scan-line OpenEXR file, channels R, G, B (A) — or Y for one channel — stored as 32-bit floats, no
+    compression (pyexr compresses; any EXR reader decodes either).  img: [H, W], [H, W, 1], [H, W, 3] or [H, W, 4]."""
+    a = img.detach().cpu().numpy() if torch.is_tensor(img) else np.asarray(img)
+    a = np.ascontiguousarray(a, np.float32)
+    if a.ndim == 2:
+        a = a[:, :, None]
+    if a.ndim != 3 or a.shape[2] not in (1, 3, 4):
+        raise ValueError("write_exr: expected [H, W], [H, W, 1], [H, W, 3] or [H, W, 4]")
+    h, w, c = a.shape
+    names = {1: ["Y"], 3: ["R", "G", "B"], 4: ["R", "G", "B", "A"]}[c]
+    order = sorted(range(c), key=lambda k: names[k])                     # channels are stored in alphabetical order, per scan line
+    attr = lambda name, typ, data: name.encode() + b"\0" + typ.encode() + b"\0" + struct.pack("<i", len(data)) + data
+    chlist = b"".join(names[k].encode() + b"\0" + struct.pack("<iBBBBii", 2, 0, 0, 0, 0, 1, 1) for k in order) + b"\0"   # pixel type 2 = FLOAT
+    box = struct.pack("<iiii", 0, 0, w - 1, h - 1)
+    head = (struct.pack("<ii", 20000630, 2) + attr("channels", "chlist", chlist) + attr("compression", "compression", b"\0") + attr("dataWindow", "box2i", box)
+            + attr("displayWindow", "box2i", box) + attr("lineOrder", "lineOrder", b"\0") + attr("pixelAspectRatio", "float", struct.pack("<f", 1.0))
+            + attr("screenWindowCenter", "v2f", struct.pack("<ff", 0.0, 0.0)) + attr("screenWindowWidth", "float", struct.pack("<f", 1.0)) + b"\0")
+    line_bytes = 4 * w * c
+    table_at = len(head)
+    first = table_at + 8 * h
+    offsets = struct.pack("<%dQ" % h, *[first + y * (8 + line_bytes) for y in range(h)])
+    planar = np.ascontiguousarray(a[:, :, order].transpose(0, 2, 1))     # [H, C, W]: one scan line = its channels one after the other
+    with open(path, "wb") as fh:
+        fh.write(head + offsets)
+        for y in range(h):
+            fh.write(struct.pack("<ii", y, line_bytes) + planar[y].tobytes())
+    return path
+
+
+def read_exr(path):
+    """Reads back what write_exr wrote (uncompressed scan lines, FLOAT channels) -> float32 [H, W, C] in R, G, B (A) / Y order."""
+    b = open(path, "rb").read()
+    if struct.unpack_from("<i", b, 0)[0] != 20000630:
+        raise ValueError("%s: not an OpenEXR file" % path)
+    p, attrs = 8, {}
+    while b[p] != 0:
+        e = b.index(b"\0", p); name = b[p:e].decode(); p = e + 1
+        e = b.index(b"\0", p); typ = b[p:e].decode(); p = e + 1
+        n = struct.unpack_from("<i", b, p)[0]; p += 4
+        attrs[name] = (typ, b[p:p + n]); p += n
+    p += 1
+    if attrs["compression"][1] != b"\0":
+        raise ValueError("%s: only uncompressed files (as write_exr makes them)" % path)
+    x0, y0, x1, y1 = struct.unpack("<iiii", attrs["dataWindow"][1]); w, h = x1 - x0 + 1, y1 - y0 + 1
+    ch, q, cl = [], 0, attrs["channels"][1]
+    while cl[q] != 0:
+        e = cl.index(b"\0", q); nm = cl[q:e].decode(); q = e + 1
+        if struct.unpack_from("<i", cl, q)[0] != 2:
+            raise ValueError("%s: only FLOAT channels" % path)
+        ch.append(nm); q += 16
+    offs = struct.unpack_from("<%dQ" % h, b, p)
+    out = np.zeros((h, w, len(ch)), np.float32)
+    for y in range(h):
+        yy, nb = struct.unpack_from("<ii", b, offs[y])
+        out[yy - y0] = np.frombuffer(b, np.float32, w * len(ch), offs[y] + 8).reshape(len(ch), w).T
+    want = [n for n in ("R", "G", "B", "A", "Y") if n in ch]
+    return out[:, :, [ch.index(n) for n in want]]
+
+
+def write_test_maps(save_path, name, index, maps):
+    """The float maps of Trainer.test's BRDF branch (:1372-1377): `<name>_<i>_{kd,ks,normal,env_map,netrgb_diffuse,netrgb_specular}.png` — OpenEXR content
+    under a .png name, as the reference writes them; `normal` is stored as n / 2 + 1 / 2.  maps: dict with any of kd, ks, normal, env_map, rgb_diffuse_light,
+    rgb_specular_light ([H, W, 3] each)."""
+    os.makedirs(save_path, exist_ok=True)
+    files = []
+    for key, stem, f in (("kd", "kd", None), ("ks", "ks", None), ("normal", "normal", lambda x: x * 0.5 + 0.5), ("env_map", "env_map", None),
+                         ("rgb_diffuse_light", "netrgb_diffuse", None), ("rgb_specular_light", "netrgb_specular", None)):
+        if key not in maps or maps[key] is None:
+            continue
+        m = maps[key]
+        m = m.detach().cpu().numpy() if torch.is_tensor(m) else np.asarray(m)
+        files.append(write_exr(os.path.join(save_path, "%s_%04d_%s.png" % (name, index, stem)), f(m) if f else m))
+    return files

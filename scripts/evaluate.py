@@ -70,6 +70,7 @@ def main():
     p.add_argument("--me_max", type=float, default=None, help="main.py --me_max (default 0.0)")
     p.add_argument("--kd_min", type=float, nargs=3, default=None); p.add_argument("--kd_max", type=float, nargs=3, default=None)
     p.add_argument("--limit", type=int, default=0); p.add_argument("--H", type=int, default=800); p.add_argument("--W", type=int, default=800)
+    p.add_argument("--save_maps", action="store_true", help="also write kd / ks / normal / env_map / diffuse and specular light as EXR files, like Trainer.test (nerf/utils.py:1372-1377)")
     p.add_argument("--scale", type=float, default=1.0); p.add_argument("--offset", type=float, nargs=3, default=[0.0, 0.0, 0.0]); p.add_argument("--synthetic", action="store_true")
     p.add_argument("--envmap_path", default="None", help="main.py --envmap_path: Radiance .hdr environment map for relighting")
     p.add_argument("--albedo_scale_x", type=float, default=1.0); p.add_argument("--albedo_scale_y", type=float, default=1.0); p.add_argument("--albedo_scale_z", type=float, default=1.0)
@@ -123,11 +124,16 @@ def main():
         pose = nerf_pose(fr["transform_matrix"], a.scale, a.offset)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         img = harness.test_view(W, mlp, light, torch.from_numpy(pose), intr, Hh, Ww, a.spp, a.ssaa, random_offset=i * 7919, albedo_scale=albedo_scale,
-                                shard=a.shard if world > 1 and a.shard != "views" else None, rank=rank, world=world)
+                                shard=a.shard if world > 1 and a.shard != "views" else None, rank=rank, world=world, return_maps=a.save_maps)
+        maps = None
+        if a.save_maps:
+            img, maps = img
         torch.cuda.synchronize(); t_render += time.perf_counter() - t0
         if world > 1 and a.shard != "views" and rank != 0:
             continue                                                       # every rank holds the whole frame; rank 0 writes and scores it
         files = meters.write_test_frame(out_dir, name, i, img)
+        if maps is not None:                                               # kd / ks / normal / env_map / diffuse + specular light as EXR (utils.py:1372-1377)
+            files += meters.write_test_maps(out_dir, name, i, maps)
         gt_path = os.path.join(base, fr["file_path"] + ".png")
         note = ""
         if os.path.exists(gt_path):

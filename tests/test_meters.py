@@ -73,3 +73,25 @@ def test_png_files_read_back(tmp_path):
     assert np.array_equal(np.asarray(Image.open(str(tmp_path / "a.png"))), rgba)
     with pytest.raises(ValueError):
         meters.write_png(str(tmp_path / "b.png"), rgba.astype(np.float32))
+
+
+def test_exr_maps_round_trip(tmp_path):
+    """meters.write_exr / read_exr / write_test_maps: the float maps Trainer.test saves with pyexr (nerf/utils.py:1372-1377) — header fields of a scan-line
+    OpenEXR file, channels in alphabetical order on disk and R, G, B in memory, values bit-exact through the round trip, the reference's file names."""
+    import struct
+    from mirres_restir_nerf_mesh_amd import meters
+    rng = np.random.default_rng(3)
+    img = (rng.random((7, 11, 3)) * 4 - 1).astype(np.float32); img[0, 0] = [np.inf, -0.0, 1e-40]
+    p = meters.write_exr(str(tmp_path / "a.exr"), img)
+    raw = open(p, "rb").read()
+    assert struct.unpack_from("<ii", raw, 0) == (20000630, 2) and b"channels\0chlist\0" in raw and raw.index(b"B\0") < raw.index(b"G\0") < raw.index(b"R\0")
+    back = meters.read_exr(p)
+    assert back.shape == img.shape and np.array_equal(back.view(np.uint32), img.view(np.uint32))
+    for c in (1, 4):
+        a = rng.random((5, 6, c)).astype(np.float32)
+        assert np.array_equal(meters.read_exr(meters.write_exr(str(tmp_path / ("c%d.exr" % c)), a)), a)
+    files = meters.write_test_maps(str(tmp_path / "brdf"), "ngp_ep0010", 3, {"kd": img, "normal": np.zeros((7, 11, 3), np.float32), "env_map": img[:4, :8]})
+    assert [os.path.basename(f) for f in files] == ["ngp_ep0010_0003_kd.png", "ngp_ep0010_0003_normal.png", "ngp_ep0010_0003_env_map.png"]
+    assert np.array_equal(meters.read_exr(files[1]), np.full((7, 11, 3), 0.5, np.float32))        # normal * 0.5 + 0.5
+    with pytest.raises(ValueError):
+        meters.write_exr(str(tmp_path / "bad.exr"), np.zeros((4, 4, 2), np.float32))
