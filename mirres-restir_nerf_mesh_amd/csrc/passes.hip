@@ -371,17 +371,45 @@ MR_DEV float pairwise_mis(float q0, float q1, float N0, float N1) { return (q1 =
 // neighbour acceptance in the reference's order of `continue`s (:236-258): in bounds -> normal / depth similar -> neighbour reservoir M != 0 ->
 // neighbour is foreground. The loads of all candidate neighbours are issued before any test is looked at (a runtime loop with early-outs made
 // each of the ~15 gathers of a pixel wait for the previous one: the kernel spent its time on dependent L2 round trips); the tests are unchanged.
+// MR_SGEN_PX pixels per thread (rows of a MR_SGEN_TILE x MR_SGEN_TILE tile, MR_SGEN_TILE^2 / MR_SGEN_PX threads per block): the block still reserves its rays with ONE
+// queue atomic, i.e. MR_SGEN_PX times fewer atomics per launch on the one head word (a word takes ~88 returning atomics per microsecond; a 1600 x 1600 frame in
+// 256-pixel blocks is 10 000 of them in a 235 us kernel).
+#ifndef MR_SGEN_PX
+#define MR_SGEN_PX 1
+#endif
+MR_DEV int tile_pixel_v(int fx, int fy, int tw, int N, int vt) {   // tile_pixel for a virtual thread index vt in [0, tw * tw)
+    const int tiles_x = (fx + tw - 1) / tw, tiles_y = (fy + tw - 1) / tw;
+    int tx, ty;
+#if MR_TILE_MAP == 0
+    tx = blockIdx.x % tiles_x; ty = blockIdx.x / tiles_x;
+#elif MR_TILE_MAP == 1
+    const int t = (int)(blockIdx.x & 7u) * ((tiles_x * tiles_y + 7) >> 3) + (int)(blockIdx.x >> 3);
+    if (t >= tiles_x * tiles_y) return N;
+    tx = t % tiles_x; ty = t / tiles_x;
+#else
+    const int ch = MR_CHUNK_PX / tw, chunks_x = (tiles_x + ch - 1) / ch;
+    const int j = (int)(blockIdx.x >> 3), chunk = (int)(blockIdx.x & 7u) + 8 * (j / (ch * ch)), w = j % (ch * ch);
+    tx = (chunk % chunks_x) * ch + w % ch; ty = (chunk / chunks_x) * ch + w / ch;
+    if (tx >= tiles_x || ty >= tiles_y) return N;
+#endif
+    const int x = tx * tw + (vt % tw), y = ty * tw + (vt / tw);
+    return (x < fx && y < fy) ? y * fx + x : N;   // N = "no pixel"
+}
 template <int MR_MAX_NB>   // 5 (the reference's neighbour count) or 8: bounds the unrolled gathers, i.e. the registers held
-__global__ void __launch_bounds__(MR_SGEN_BLOCK) k_spatial_gen(mirres_config_t C, GBufD G, ResD PR, const float* __restrict__ noff, uint32_t frameIndex,
+__global__ void __launch_bounds__(MR_SGEN_BLOCK / MR_SGEN_PX) k_spatial_gen(mirres_config_t C, GBufD G, ResD PR, const float* __restrict__ noff, uint32_t frameIndex,
                                                           int fx, int fy, int N, int y_off, const float* __restrict__ occ_own, Ray* __restrict__ q,
                                                           uint32_t* __restrict__ q_count, int32_t* __restrict__ slot_out, uint32_t* __restrict__ mask_out) {
     // strip sharding: y_off = global row of local row 0 (seeds), occ_own = occupancy with the halo rows zeroed (which pixels this rank merges);
     // neighbours are tested against the true G-buffer, halo rows included
-    const int pi = tile_pixel(fx, fy, MR_SGEN_TILE, N);
+    const int k = min(C.neighbor_count, MR_MAX_NB);
+    int pis[MR_SGEN_PX]; uint32_t masks[MR_SGEN_PX]; int nbs[MR_SGEN_PX][MR_MAX_NB]; uint32_t cnt_all = 0;
+#pragma unroll
+    for (int px = 0; px < MR_SGEN_PX; px++) {
+    const int pi = tile_pixel_v(fx, fy, MR_SGEN_TILE, N, (int)threadIdx.x + px * (MR_SGEN_BLOCK / MR_SGEN_PX));
     uint32_t mask = 0, cnt = 0;
     int nb[MR_MAX_NB];
-    v3 cpos = V3(0.f), cdir = V3(0.f);
-    const int k = min(C.neighbor_count, MR_MAX_NB);
+#pragma unroll
+    for (int i = 0; i < MR_MAX_NB; i++) nb[i] = -1;
     GPix gc; gc.occ = 0.f;
     if (pi < N) { gc = load_gpix(G, pi); if (occ_own) gc.occ = occ_own[pi]; }
     if (pi < N && !(gc.occ < 0.1f)) {
@@ -392,7 +420,6 @@ __global__ void __launch_bounds__(MR_SGEN_BLOCK) k_spatial_gen(mirres_config_t C
         float4 nd[MR_MAX_NB]; float nocc[MR_MAX_NB]; int nM[MR_MAX_NB];
 #pragma unroll
         for (int i = 0; i < MR_MAX_NB; i++) {
-            nb[i] = -1;
             if (i < k) {
                 const uint32_t ni = (startIndex + (uint32_t)i) & (uint32_t)(C.neighbor_offset_count - 1);
                 const int nx = x + (int)(noff[2 * ni] * C.gather_radius), ny = y + (int)(noff[2 * ni + 1] * C.gather_radius);
@@ -424,24 +451,32 @@ __global__ void __launch_bounds__(MR_SGEN_BLOCK) k_spatial_gen(mirres_config_t C
             }
             if (ok) { mask |= 1u << i; cnt++; } else nb[i] = -1;
         }
-        if (cnt) { cpos = load_gpos(G, pi); const v3 cl = res_light(PR, pi); cdir = oct_decode(V2(cl.y, cl.z)); }
     }
-    uint32_t base = block_append(q_count, cnt > 0, 2 * cnt);
-    if (cnt) {
-        v3 nl[MR_MAX_NB], np[MR_MAX_NB];
+    pis[px] = pi; masks[px] = mask; cnt_all += cnt;
 #pragma unroll
-        for (int i = 0; i < MR_MAX_NB; i++) if (mask & (1u << i)) { nl[i] = res_light(PR, (size_t)nb[i]); np[i] = load_gpos(G, (size_t)nb[i]); }
-        uint32_t s = base;
-#pragma unroll
-        for (int i = 0; i < MR_MAX_NB; i++) {
-            if (!(mask & (1u << i))) continue;
-            const v3 ndir = oct_decode(V2(nl[i].y, nl[i].z));
-            put_ray(q, s, cpos, ndir, C.vis_near);        // canonical pixel towards the neighbour's light
-            put_ray(q, s + 1, np[i], cdir, C.vis_near);   // neighbour towards the canonical light
-            s += 2;
-        }
+    for (int i = 0; i < MR_MAX_NB; i++) nbs[px][i] = nb[i];
     }
-    if (pi < N) { slot_out[pi] = cnt ? (int32_t)base : -1; mask_out[pi] = mask; }
+    uint32_t s = block_append(q_count, cnt_all > 0, 2 * cnt_all);
+#pragma unroll
+    for (int px = 0; px < MR_SGEN_PX; px++) {
+        const int pi = pis[px]; const uint32_t mask = masks[px];
+        if (mask) {
+            const v3 cpos = load_gpos(G, pi); const v3 cl = res_light(PR, pi); const v3 cdir = oct_decode(V2(cl.y, cl.z));
+            v3 nl[MR_MAX_NB], np[MR_MAX_NB];
+#pragma unroll
+            for (int i = 0; i < MR_MAX_NB; i++) if (mask & (1u << i)) { nl[i] = res_light(PR, (size_t)nbs[px][i]); np[i] = load_gpos(G, (size_t)nbs[px][i]); }
+            if (pi < N) slot_out[pi] = (int32_t)s;
+#pragma unroll
+            for (int i = 0; i < MR_MAX_NB; i++) {
+                if (!(mask & (1u << i))) continue;
+                const v3 ndir = oct_decode(V2(nl[i].y, nl[i].z));
+                put_ray(q, s, cpos, ndir, C.vis_near);        // canonical pixel towards the neighbour's light
+                put_ray(q, s + 1, np[i], cdir, C.vis_near);   // neighbour towards the canonical light
+                s += 2;
+            }
+        } else if (pi < N) slot_out[pi] = -1;
+        if (pi < N) mask_out[pi] = mask;
+    }
 }
 
 #ifndef MR_SRES_WAVES
@@ -830,9 +865,9 @@ int mirres_restir_spatial(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_env
     if (!(fold && ctx->chain_clean)) MR_HIP(hipMemsetAsync(&ctx->counters[0], 0, sizeof(uint32_t), s));
     uint32_t* const rc_ = fold ? &ctx->counters[0] : nullptr; uint32_t* const rh_ = fold ? bvh->work : nullptr;   // lane 0 = head set 0
     const bool nb5 = ctx->cfg.neighbor_count <= 5;
-    if (nb5) k_spatial_gen<5><<<tile_grid(ctx->fx, ctx->fy, MR_SGEN_TILE), MR_SGEN_BLOCK, 0, s>>>(ctx->cfg, gbufd(g), resd(prev_res), noff, frameIndex, ctx->fx, ctx->fy, N, ctx->y_off, ctx->occ_own, ctx->any_rays, &ctx->counters[0],
+    if (nb5) k_spatial_gen<5><<<tile_grid(ctx->fx, ctx->fy, MR_SGEN_TILE), MR_SGEN_BLOCK / MR_SGEN_PX, 0, s>>>(ctx->cfg, gbufd(g), resd(prev_res), noff, frameIndex, ctx->fx, ctx->fy, N, ctx->y_off, ctx->occ_own, ctx->any_rays, &ctx->counters[0],
                                                                                    ctx->slot_a, ctx->mask_a);
-    else k_spatial_gen<8><<<tile_grid(ctx->fx, ctx->fy, MR_SGEN_TILE), MR_SGEN_BLOCK, 0, s>>>(ctx->cfg, gbufd(g), resd(prev_res), noff, frameIndex, ctx->fx, ctx->fy, N, ctx->y_off, ctx->occ_own, ctx->any_rays, &ctx->counters[0],
+    else k_spatial_gen<8><<<tile_grid(ctx->fx, ctx->fy, MR_SGEN_TILE), MR_SGEN_BLOCK / MR_SGEN_PX, 0, s>>>(ctx->cfg, gbufd(g), resd(prev_res), noff, frameIndex, ctx->fx, ctx->fy, N, ctx->y_off, ctx->occ_own, ctx->any_rays, &ctx->counters[0],
                                                                                ctx->slot_a, ctx->mask_a);
     int rc = trace_any(ctx, bvh, ctx->any_cap, s); if (rc) return rc;
     GBufD gr = gbufd(g);
