@@ -78,7 +78,7 @@ MR_DEV float eval_brdf(const Ctx& c, v3 L) {
     // No specular weight (metallic = 0: the reference's default --me_max 0, main.py:110, makes brdf_map.y = 0 in every pixel): F is the constant 0, so
     // `specular` = max(0, (D G 0) / (4 NdotV)) is +0 whatever D and G are (they are finite or NaN, never infinite: D = a2 / (d d pi) with d > 0 for a2 > 0, and a
     // NaN — a2 = 0 at NdotH = 1, or 0 / 0 at NdotV = 0 — is dropped by fmaxf), and lerp(+0, diffuse, mix) = (diffuse - 0) mix exactly. The six divisions and two
-    // square roots of D, G, F and the quotient are skipped; the result has the same bits (the oracle takes the long way; full-size frames compare bit for bit).
+    // square roots of D, G, F and the quotient are skipped; the result has the same bits (the CPU checker takes the long way; full-size frames compare bit for bit).
     if (c.ws < 1e-8f) return NdotL > 0.f ? lerpf(0.f, NdotL * 0.31830988f, c.mix) : 0.f;
     v3 H = normalize(c.V + L);
     float NdotH = saturate(dot(c.N, H)), LdotH = saturate(dot(L, H));
