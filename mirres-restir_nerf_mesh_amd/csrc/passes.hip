@@ -487,9 +487,6 @@ __global__ void __launch_bounds__(MR_SGEN_BLOCK / MR_SGEN_PX) k_spatial_gen(mirr
 #else
 #define MR_SRES_ATTR
 #endif
-#ifdef MR_EXP_CULLSTAT   // experiment: how many of the spatial pass's shadow rays cannot change the merge
-__device__ unsigned long long g_cullstat[8];
-#endif
 template <int MR_MAX_NB>
 __global__ void MR_SRES_ATTR __launch_bounds__(MR_SRES_TILE * MR_SRES_TILE) k_spatial_resolve(mirres_config_t C, EnvD E, GBufD G, ResD R, ResD PR, const float* __restrict__ noff,
                                                               uint32_t frameIndex, int fx, int fy, int N, int y_off, const float* __restrict__ occ_own,
@@ -546,13 +543,6 @@ __global__ void MR_SRES_ATTR __launch_bounds__(MR_SRES_TILE * MR_SRES_TILE) k_sp
         float candTarget = target_lum(nctx, nlum, ndir);
         float candAtOther = target_lum(ctx, nlum, ndir);
         float canonAtOther = target_lum(nctx, clum, cdir);
-#ifdef MR_EXP_CULLSTAT
-        {   const bool a0 = candAtOther == 0.f, a1 = nbr.weight == 0.f, b0 = canonAtOther == 0.f, b1 = curTarget == 0.f || cur.weight == 0.f;
-            atomicAdd(&g_cullstat[0], 1ull); if (a0) atomicAdd(&g_cullstat[1], 1ull); if (a0 || a1) atomicAdd(&g_cullstat[2], 1ull);
-            if (b0) atomicAdd(&g_cullstat[3], 1ull); if (b0 || b1) atomicAdd(&g_cullstat[4], 1ull);
-            if (!(dot(n, ndir) > 0.f)) atomicAdd(&g_cullstat[5], 1ull); if (!(dot(nn, cdir) > 0.f)) atomicAdd(&g_cullstat[6], 1ull);
-            if (hit[hs - 2]) atomicAdd(&g_cullstat[7], 1ull); }
-#endif
         candAtOther *= canonicalVis;
         canonAtOther *= candidateVis;
         float N0 = (float)((uint32_t)nbr.M * k), N1 = (float)cur.M;
@@ -921,10 +911,3 @@ int mirres_restir_eval_final_bwd(mirres_ctx_t* ctx, const mirres_env_t* env, con
 }
 
 }  // extern "C"
-#ifdef MR_EXP_CULLSTAT
-extern "C" int mirres_dev_cullstat(unsigned long long* out, int reset) {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(mr::g_cullstat), sizeof(unsigned long long) * 8) != hipSuccess) return 1;
-    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(mr::g_cullstat), z, sizeof z) != hipSuccess) return 1; }
-    return 0;
-}
-#endif
