@@ -100,35 +100,6 @@ def test_trace_bit_exact(torch_cuda, oracle, scene_mod, subdiv, ground, hw):
     assert lib().mirres_bvh_trace(w.h, dr.data_ptr(), 4, 7, None, None, None, None, None, None, None) < 0
 
 
-def test_shadow_rays_on_a_ploc_hierarchy(torch_cuda, oracle, scene_mod, monkeypatch):
-    """MIRRES_PLOC=1 collapses the shadow-ray layout from a PLOC tree (area-driven clustering) instead of the LBVH: a completely different
-    hierarchy over the same leaf boxes must give the same any-hit bits (the result depends on the leaves' own boxes only), and every leaf must
-    still be reachable — both checked against the oracle's reference-order traversal on the LBVH."""
-    torch = torch_cuda
-    from mirres_restir_nerf_mesh_amd.renderer_restir import restirbvhWorker
-    from mirres_restir_nerf_mesh_amd._lib import lib, check
-    v, t = scene_mod.make_mesh(5, 32)
-    info, aabb, _, _ = oracle.bvh_build(v, t)
-    hw = 160
-    eye, rd = scene_mod.camera_rays(hw, hw)
-    n = hw * hw
-    prim = oracle.trace(info, aabb, v, t, oracle.make_rays(np.repeat(eye[None], n, 0), rd), True)
-    rng = np.random.default_rng(11)
-    d2 = rng.normal(size=(n, 3)).astype(np.float32)
-    o2 = (prim["pos"] + 0.01 * d2).astype(np.float32)
-    sets = {"primary": oracle.make_rays(np.repeat(eye[None], n, 0), rd), "secondary": oracle.make_rays(o2[prim["hit"] > 0], d2[prim["hit"] > 0]),
-            "short": oracle.make_rays(o2[prim["hit"] > 0], d2[prim["hit"] > 0], 0.0, 0.3)}
-    monkeypatch.setenv("MIRRES_PLOC", "1")
-    w = restirbvhWorker(torch.from_numpy(v).cuda(), torch.from_numpy(t).cuda()); w.update_mesh(w.vrt, w.v_ind)
-    for name, rays in sets.items():
-        ref = oracle.trace(info, aabb, v, t, rays, True, True)
-        dr = torch.from_numpy(rays).cuda()
-        hit0 = torch.zeros(len(rays), dtype=torch.int32, device="cuda")
-        check(lib().mirres_bvh_trace(w.h, dr.data_ptr(), len(rays), 0, hit0.data_ptr(), None, None, None, None, None, None), name)
-        torch.cuda.synchronize()
-        assert np.array_equal(hit0.cpu().numpy(), ref["hit"]), name
-
-
 def test_traversal_quirks_on_a_hand_made_mesh(torch_cuda, oracle):
     """The edge cases of SURVEY §8 a-7..a-9 on a mesh built for them, every trace mode against the oracle bit for bit: axis-aligned flat triangles (their
     boxes have zero thickness and can never be entered: `tmax <= tmin`), duplicated triangles (exact distance ties: the ordered fast path must hand them
