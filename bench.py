@@ -166,8 +166,21 @@ def main():
     samples = float(N) * args.spp * args.steps
     schemes = ["spp"] if world == 1 else (["spp", "strips"] if args.shard == "both" else [args.shard])
     results = {}
-    for sc in schemes:
-        results[sc] = timed(sc)
+    for i, sc in enumerate(schemes):
+        if i == 0:
+            results[sc] = timed(sc)
+            continue
+        # the second scheme must not take the line of the first one with it: an error that every rank raises (the likely kind: an API the backend refuses)
+        # is caught, agreed on by all ranks and reported in the sub-record
+        err = None
+        try:
+            results[sc] = timed(sc)
+        except Exception as e:      # noqa: BLE001
+            err = "%s: %s" % (type(e).__name__, e)
+        bad = torch.tensor([1.0 if err else 0.0], device=dev)
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        if float(bad.item()) > 0:
+            results[sc] = (None, err or "failed on another rank")
     primary = schemes[0]
     dt, out = results[primary]
     value = samples / dt / 1e6
@@ -272,7 +285,10 @@ def main():
                            "finite": bool(torch.isfinite(fc).all().item()), "mean_radiance": round(float(fc[g["occ"][:, 0] > 0.5].mean().item()), 5)},
                 "roofline": roof, "cpu_baseline": cpu}
         for sc in schemes[1:]:            # the other sharding scheme, timed the same way in the same run
-            d2, _ = results[sc]
+            d2, e2 = results[sc]
+            if d2 is None:
+                line[sc] = {"value": None, "error": str(e2)[:300], "parallelism": "%s x%d" % (par[sc], world)}
+                continue
             line[sc] = {"value": round(samples / d2 / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(d2 / args.steps * 1e3, 2), "parallelism": "%s x%d" % (par[sc], world)}
         print(json.dumps(line), flush=True)
     if world > 1:
