@@ -2,7 +2,7 @@
 // Behaviour contract: node arrays identical to the reference's 7-kernel build (nerf/bvhworkers/*.slang driven by
 // restirbvhWorker.update_bvh, nerf/renderer_restir.py:25-89). MI355X redesign:
 //   * scene extent by wave reduction + order-preserving atomics instead of 6 host-synchronising torch reductions;
-//   * device-wide stable radix sort (rocPRIM, multi-workgroup) instead of the single-256-thread-block sort
+//   * device-wide stable radix sort (k_rs_*: multi-workgroup, wave64 digit matching) instead of the single-256-thread-block sort
 //     (lbvh_single_radixsort.slang, hard-coded 32-wide subgroups) — same stable ascending order;
 //   * one-launch bottom-up refit with agent-scope arrival counters instead of tree_height launches + a host sync
 //     (fmin/fmax unions are exact and order independent, so the boxes are bit-identical);
@@ -10,7 +10,6 @@
 #include "engine.hpp"
 #include "device_math.hpp"
 #include <cstring>
-#include <rocprim/rocprim.hpp>
 #include <cstdarg>
 #include <cstdio>
 
@@ -101,6 +100,113 @@ __global__ void __launch_bounds__(256) k_morton(const float* __restrict__ ele, c
     }
     keys[g] = q[0] * 4 + q[1] * 2 + q[2];
     vals[g] = (uint32_t)g;
+}
+
+// ---------------------------------------------------------------- a-3: stable radix sort of (Morton code, element) pairs (lbvh_single_radixsort.slang)
+// The reference sorts with ONE 256-thread workgroup (8-bit digits, least significant first, 32-wide subgroup ballots). The contract is the order: ascending
+// codes, equal codes in ascending element order (the hierarchy's delta() breaks ties by position, so stability is part of the node arrays). Here: four
+// 8-bit passes, each  histogram per 2048-key tile -> per digit: exclusive scan over the tiles + total -> stable scatter.  Inside a tile a wave owns 512 consecutive keys
+// and takes them 64 at a time: the lanes holding the same digit find each other with eight ballots (wave64 match), the lowest of them bumps the wave's own
+// LDS counter of that digit, and a key's rank is  tile base of its digit + its digit's count in the waves before + in this wave's earlier rounds + in lower lanes.
+#define MR_RS_BLOCK 256
+#define MR_RS_ITEMS 8
+#define MR_RS_TILE (MR_RS_BLOCK * MR_RS_ITEMS)
+__global__ void __launch_bounds__(MR_RS_BLOCK) k_rs_hist(const uint32_t* __restrict__ keys, int n, int shift, uint32_t* __restrict__ hist, int nb) {
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0u;
+    __syncthreads();
+    const int base = blockIdx.x * MR_RS_TILE;
+#pragma unroll
+    for (int i = 0; i < MR_RS_ITEMS; i++) {
+        const int idx = base + i * MR_RS_BLOCK + (int)threadIdx.x;
+        if (idx < n) atomicAdd(&h[(keys[idx] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    hist[(size_t)threadIdx.x * nb + blockIdx.x] = h[threadIdx.x];      // digit-major: the scan below yields, per digit, the tiles in order
+}
+// per digit (one workgroup each): exclusive scan of its tile counters in place + the digit's total; the scatter kernel adds the totals of the smaller digits
+__global__ void __launch_bounds__(256) k_rs_scan(uint32_t* __restrict__ hist, int nb, uint32_t* __restrict__ totals) {
+    __shared__ uint32_t wsum[4];
+    uint32_t* h = hist + (size_t)blockIdx.x * nb;
+    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
+    uint32_t running = 0u;
+    for (int c0 = 0; c0 < nb; c0 += 256) {
+        const int i = c0 + (int)threadIdx.x;
+        const uint32_t x = i < nb ? h[i] : 0u;
+        uint32_t inc = x;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        uint32_t before = 0u, all = 0u;
+#pragma unroll
+        for (int w = 0; w < 4; w++) { const uint32_t t = wsum[w]; if (w < wave) before += t; all += t; }
+        if (i < nb) h[i] = running + before + inc - x;
+        running += all;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) totals[blockIdx.x] = running;
+}
+__global__ void __launch_bounds__(MR_RS_BLOCK) k_rs_scatter(const uint32_t* __restrict__ kin, const uint32_t* __restrict__ vin, uint32_t* __restrict__ kout,
+                                                            uint32_t* __restrict__ vout, int n, int shift, const uint32_t* __restrict__ offs, int nb,
+                                                            const uint32_t* __restrict__ totals) {
+    __shared__ uint32_t wh[MR_RS_BLOCK / 64][256];
+    __shared__ uint32_t dsum[MR_RS_BLOCK / 64];
+    const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (int w = 0; w < MR_RS_BLOCK / 64; w++) wh[w][threadIdx.x] = 0u;
+    __syncthreads();
+    const int base = blockIdx.x * MR_RS_TILE + wave * (64 * MR_RS_ITEMS);
+    uint32_t k[MR_RS_ITEMS], v[MR_RS_ITEMS], r[MR_RS_ITEMS];
+#pragma unroll
+    for (int i = 0; i < MR_RS_ITEMS; i++) {
+        const int idx = base + i * 64 + lane;
+        const bool valid = idx < n;
+        k[i] = valid ? kin[idx] : 0xffffffffu; v[i] = valid ? vin[idx] : 0u;
+        const uint32_t d = (k[i] >> shift) & 255u;
+        uint64_t m = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; b++) { const bool bit = (d >> b) & 1u; const uint64_t bal = __ballot(bit); m &= bit ? bal : ~bal; }
+        // m = the valid lanes of this round with the same digit (this lane included when it is valid)
+        const int leader = valid ? __builtin_ctzll(m) : lane;
+        uint32_t prev = 0u;
+        if (valid && lane == leader) { prev = wh[wave][d]; wh[wave][d] = prev + (uint32_t)__popcll(m); }
+        prev = (uint32_t)__shfl((int)prev, leader, 64);
+        r[i] = prev + (uint32_t)__popcll(m & lt_mask);
+        __syncthreads();                                                  // the next round's leaders read what this round's leaders wrote
+    }
+    {   // per digit (thread d = digit d): where each wave's keys start in the output = all keys with smaller digits + this digit's keys in the tiles before
+        // + its counts in the waves before
+        const uint32_t tot = totals[threadIdx.x];
+        uint32_t inc = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+        if (lane == 63) dsum[wave] = inc;
+        __syncthreads();
+        uint32_t run = inc - tot + offs[(size_t)threadIdx.x * nb + blockIdx.x];
+        for (int w = 0; w < wave; w++) run += dsum[w];
+#pragma unroll
+        for (int w = 0; w < MR_RS_BLOCK / 64; w++) { const uint32_t t = wh[w][threadIdx.x]; wh[w][threadIdx.x] = run; run += t; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MR_RS_ITEMS; i++) {
+        if (base + i * 64 + lane < n) {
+            const uint32_t pos = wh[wave][(k[i] >> shift) & 255u] + r[i];
+            kout[pos] = k[i]; vout[pos] = v[i];
+        }
+    }
+}
+// keys / vals hold the input and receive the sorted pairs (four passes: back in place); tmp_k / tmp_v = the other half of the ping-pong, hist = 256 * tiles + 256 words
+static void radix_sort_pairs_u32(uint32_t* keys, uint32_t* vals, uint32_t* tmp_k, uint32_t* tmp_v, uint32_t* hist, int n, hipStream_t s) {
+    const int nb = (n + MR_RS_TILE - 1) / MR_RS_TILE;
+    uint32_t *ka = keys, *va = vals, *kb = tmp_k, *vb = tmp_v;
+    for (int shift = 0; shift < 32; shift += 8) {
+        k_rs_hist<<<nb, MR_RS_BLOCK, 0, s>>>(ka, n, shift, hist, nb);
+        k_rs_scan<<<256, 256, 0, s>>>(hist, nb, hist + (size_t)256 * nb);
+        k_rs_scatter<<<nb, MR_RS_BLOCK, 0, s>>>(ka, va, kb, vb, n, shift, hist, nb, hist + (size_t)256 * nb);
+        uint32_t* t = ka; ka = kb; kb = t; t = va; va = vb; vb = t;
+    }
 }
 
 // delta / determineRange / findSplit (lbvh_hierarchy.slang:40-109)
@@ -395,10 +501,8 @@ int mirres_bvh_create(mirres_bvh_t** out, int max_tris) {
     MR_HIP(hipMalloc(&b->top341q, sizeof(Node4q) * 341));
     MR_HIP(hipMalloc(&b->root_box, sizeof(float) * 8));
     MR_HIP(hipMalloc(&b->work, sizeof(uint32_t) * MR_WSETS * MR_WSET));
-    size_t tmp = 0;
-    MR_HIP(rocprim::radix_sort_pairs(nullptr, tmp, b->keys_in, b->keys_out, b->vals_in, b->vals_out, T, 0, 32, 0));
-    b->sort_tmp_bytes = tmp;
-    MR_HIP(hipMalloc(&b->sort_tmp, tmp ? tmp : 16));
+    b->sort_tmp_bytes = sizeof(uint32_t) * 256 * ((T + MR_RS_TILE - 1) / MR_RS_TILE + 1);     // (digit, tile) counters of the radix sort + the digit totals
+    MR_HIP(hipMalloc(&b->sort_tmp, b->sort_tmp_bytes));
     *out = b;
     return MIRRES_OK;
 }
@@ -422,9 +526,8 @@ int mirres_bvh_build(mirres_bvh_t* b, const float* vert, int V, const int32_t* t
     const int blk = 256, grd = grid_for(T, blk);
     k_init_extent<<<1, 64, 0, s>>>(b->extent);
     k_elements<<<(grd < 256 ? grd : 256), blk, 0, s>>>(vert, tri, T, b->ele_aabb, b->extent);
-    k_morton<<<grd, blk, 0, s>>>(b->ele_aabb, b->extent, T, b->keys_in, b->vals_in);
-    size_t tmp = b->sort_tmp_bytes;
-    MR_HIP(rocprim::radix_sort_pairs(b->sort_tmp, tmp, b->keys_in, b->keys_out, b->vals_in, b->vals_out, (size_t)T, 0, 32, s));
+    k_morton<<<grd, blk, 0, s>>>(b->ele_aabb, b->extent, T, b->keys_out, b->vals_out);
+    radix_sort_pairs_u32(b->keys_out, b->vals_out, b->keys_in, b->vals_in, (uint32_t*)b->sort_tmp, T, s);
     k_hierarchy<<<grd, blk, 0, s>>>(T, b->keys_out, b->vals_out, b->ele_aabb, info, aabb, b->parent, b->flags, sorted_codes);
     {
         RefitLevels Lv; Lv.n = 1; Lv.a[0] = aabb + 6 * (size_t)(T - 1);

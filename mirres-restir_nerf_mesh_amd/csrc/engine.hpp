@@ -64,11 +64,11 @@ struct mirres_bvh {
     // build workspace
     float* ele_aabb = nullptr;      // [T,6]
     uint32_t* extent = nullptr;     // [6] order-preserving uint encoding of min xyz / max xyz
-    uint32_t *keys_in = nullptr, *keys_out = nullptr, *vals_in = nullptr, *vals_out = nullptr;  // [T]
+    uint32_t *keys_in = nullptr, *keys_out = nullptr, *vals_in = nullptr, *vals_out = nullptr;  // [T] Morton codes / element ids: *_out = k_morton output and, after the sort, the sorted pairs; *_in = the other half of the ping-pong
     int32_t* parent = nullptr;      // [2T-1]
     uint32_t* flags = nullptr;      // [2T] (first, last) sorted-leaf range of every internal node (k_hierarchy -> k_refit_ranges)
     float* lvl = nullptr;           // 64-ary union pyramid over the sorted leaf boxes (k_refit_level)
-    void* sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
+    void* sort_tmp = nullptr; size_t sort_tmp_bytes = 0;   // radix sort: (digit, tile) counters
     int32_t* own_info = nullptr; float* own_aabb = nullptr;  // used when the caller passes NULL
     // traversal layout
     mr::WideNode* nodes = nullptr;  // [T-1]

@@ -35,6 +35,40 @@ def test_build_bit_exact(torch_cuda, oracle, scene_mod, subdiv, ground):
     assert sorted(i[T - 1:, 2].tolist()) == list(range(T))
 
 
+@pytest.mark.parametrize("T", [2, 3, 64, 65, 511, 512, 513, 2047, 2048, 2049, 4103, 10000, 70001])
+def test_radix_sort_is_stable_across_wave_and_tile_boundaries(torch_cuda, oracle, T):
+    """a-3 (lbvh_single_radixsort.slang): ascending Morton codes, equal codes in ascending element order. The hand-written sort works on 2048-key tiles of four
+    512-key wave chunks taken 64 keys at a time; sizes around those boundaries, with few distinct cells so that every tile holds long runs of equal codes.
+    Checked through the C ABI's `sorted_codes` output against the oracle's build and against numpy's stable sort of the codes themselves."""
+    torch = torch_cuda
+    import ctypes as C
+    from mirres_restir_nerf_mesh_amd._lib import lib, check
+    rng = np.random.default_rng(T)
+    cells = rng.random((max(2, T // 40), 3)).astype(np.float32) * 1.8 - 0.9          # ~40 triangles per Morton cell
+    c = cells[rng.integers(0, len(cells), T)]
+    tri0 = np.array([[0, 0, 0], [3e-5, 1e-5, 2e-5], [1e-5, 3e-5, 2e-5]], np.float32)
+    v = (c[:, None, :] + tri0[None] + rng.random((T, 1, 3)).astype(np.float32) * 1e-6).reshape(-1, 3).astype(np.float32)
+    v[0] = (-1, -1, -1); v[-1] = (1, 1, 1)                                            # the scene extent
+    t = np.arange(3 * T, dtype=np.int32).reshape(-1, 3)
+    h = C.c_void_p()
+    check(lib().mirres_bvh_create(C.byref(h), T), "create")
+    try:
+        dv, dt = torch.from_numpy(v).cuda(), torch.from_numpy(t).cuda()
+        srt = torch.full((T, 2), -1, dtype=torch.int32, device="cuda")
+        for _ in range(2):                                                            # a second build reuses the ping-pong buffers and counters
+            check(lib().mirres_bvh_build(h, dv.data_ptr(), 3 * T, dt.data_ptr(), T, None, None, srt.data_ptr(), None), "build")
+        torch.cuda.synchronize()
+        got = srt.cpu().numpy()
+    finally:
+        lib().mirres_bvh_destroy(h)
+    _, _, ref, _ = oracle.bvh_build(v, t)
+    assert np.array_equal(got, ref)
+    codes = np.empty(T, np.int64); codes[ref[:, 1]] = ref[:, 0]                       # code of every element
+    order = np.argsort(codes, kind="stable")
+    assert np.array_equal(got[:, 1], order) and np.array_equal(got[:, 0], codes[order])
+    assert T < 100 or len(np.unique(codes)) < T // 8                                  # long runs of equal codes
+
+
 def test_duplicate_morton_codes(torch_cuda, oracle):
     """Many triangles in one Morton cell: ties are broken by sorted position (lbvh_hierarchy.slang:47-48), so the sort must be stable."""
     torch = torch_cuda
