@@ -205,6 +205,7 @@ def main():
         total_rays = rays_any + rays_cl
         # ALGORITHMIC bytes of the kernel as built: every 64-byte node / leaf record the traversal has to read for its answer
         # (counted by the instrumented kernel on these very rays) + the 32-byte ray + the result (4 B hit flag; 28 B hit record for the closest hit).
+        # (the spatial pass's rays reach the kernel as 8-byte pixel pairs and are formed there from two 16-byte gathers: 40 B requested, accounted as 32 B like the others)
         own_bytes_any = 64.0 * own["entered"] + rays_any * (32 + 4)
         own_bytes_cl = 64.0 * own["cl_entered"] + rays_cl * (32 + 28)
         # SURVEY section 8d's accounting (reference node layout, reference traversal's visit counts): what the REFERENCE's bvh_hit would have to move

@@ -470,11 +470,12 @@ MR_DEV bool tri_accepts_regs(float4 a, float4 b, float4 c, v3 ro, v3 d) {
 #define MR_PH(x)
 #endif
 // TIMED = 2: front-only occlusion (nerf/render_dump.py's external `intersector`, a conventional ray tracer) — the same traversal with t > 0 required
-template <bool COUNT, int TOPN, int TIMED = 0>   // TIMED: identical code under a second name, launched by bench.py's event-timed frame so that a rocprofv3
-                                                 // kernel trace of the same command shows those launches as their own row
+// SRC = 1: the queue holds (origin pixel, light pixel) pairs and the ray is formed here (engine.hpp RaySrc)
+template <bool COUNT, int TOPN, int TIMED = 0, int SRC = 0>   // TIMED: identical code under a second name, launched by bench.py's event-timed frame so that a rocprofv3
+                                                              // kernel trace of the same command shows those launches as their own row
 __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const Ray* __restrict__ rays, const uint32_t* __restrict__ d_count,
                                                                uint32_t n_fixed, uint32_t* __restrict__ work_head, int32_t* __restrict__ hit_out,
-                                                               unsigned long long* __restrict__ stats) {
+                                                               unsigned long long* __restrict__ stats, RaySrc src = RaySrc{nullptr, nullptr, 0.f}) {
     __shared__ uint32_t lds[MR_ANY_LDS * MR_TRACE_BLOCK];
     __shared__ __attribute__((aligned(16))) uint4 s_top[TOPN > 0 ? TOPN * 4 : 1];
     if (TOPN > 0) {
@@ -545,7 +546,14 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const
                 const uint32_t idx = idx0;
 #endif
                 if (!have && idx0 < chunk_end) {
-                    const float4 a = reinterpret_cast<const float4*>(rays + idx)[0], b = reinterpret_cast<const float4*>(rays + idx)[1];
+                    float4 a, b;
+                    if (SRC == 1) {
+                        const uint2 it = reinterpret_cast<const uint2*>(rays)[idx];
+                        const float4 P = src.grec[4 * (size_t)it.x + 3], L = src.rrec[2 * (size_t)it.y];
+                        const v3 dir = oct_decode(V2(L.y, L.z));
+                        const v3 o = V3(P.x, P.y, P.z) + src.vis_near * dir;          // put_ray (passes.hip): the same two expressions
+                        a.x = o.x; a.y = o.y; a.z = o.z; a.w = 0.f; b.x = dir.x; b.y = dir.y; b.z = dir.z; b.w = 1e7f;
+                    } else { a = reinterpret_cast<const float4*>(rays + idx)[0]; b = reinterpret_cast<const float4*>(rays + idx)[1]; }
                     ridx = idx; ro = V3(a.x, a.y, a.z); t_min = a.w; t_max = b.w;
                     d = normalize(V3(b.x, b.y, b.z));
                     ox = ro.x; oy = ro.y; oz = ro.z;
@@ -909,6 +917,21 @@ static int trace_grid(size_t capacity) {
     return (int)(want < 1 ? 1 : (want > cap ? cap : want));
 }
 
+// the spatial pass's queue of (origin pixel, light pixel) pairs: same kernel, rays formed at the refill (head set of lane 0 ... 4 as below)
+int trace_any_items_queue(const mirres_bvh* bvh, const uint2* items, const RaySrc& src, const uint32_t* d_count, size_t capacity, int32_t* hit,
+                          unsigned long long* stats, hipStream_t s, int lane, int timed, bool heads_clean) {
+    static const int set_of_lane[5] = {0, 7, 9, 11, 15};
+    uint32_t* const heads = bvh->work + set_of_lane[lane] * MR_WSET;
+    if (!heads_clean) MR_HIP(hipMemsetAsync(heads, 0, MR_WSET * sizeof(uint32_t), s));
+    const Ray* q = reinterpret_cast<const Ray*>(items);
+    const int grid = persist_grid(capacity); const uint32_t cap = (uint32_t)capacity;
+    const int top = (bvh->T - 1 >= 341 * 4) ? 85 : 0;
+    if (top == 85 && timed) k_trace_any4q<false, 85, 1, 1><<<grid, MR_TRACE_BLOCK, 0, s>>>(bvh->view(), q, d_count, cap, heads, hit, stats, src);
+    else if (top == 85) k_trace_any4q<false, 85, 0, 1><<<grid, MR_TRACE_BLOCK, 0, s>>>(bvh->view(), q, d_count, cap, heads, hit, stats, src);
+    else k_trace_any4q<false, 0, 0, 1><<<grid, MR_TRACE_BLOCK, 0, s>>>(bvh->view(), q, d_count, cap, heads, hit, stats, src);
+    MR_LAUNCH_CHECK("trace_any_items_queue");
+    return 0;
+}
 int trace_any_queue(const mirres_bvh* bvh, const Ray* rays, const uint32_t* d_count, size_t capacity, int32_t* hit,
                     unsigned long long* stats, hipStream_t s, int lane, int timed, bool heads_clean) {
     g_timed_tag = timed;

@@ -57,6 +57,11 @@ struct BvhView {
     unsigned long long* dbg;   // optional [2 * waves]: wall-clock start / end of every traversal wave (mirres_debug_wave_times)
 };
 
+// Shadow rays given as (origin pixel, light pixel) pairs instead of 32-byte rays (the spatial pass of mirres_render): the traversal kernel forms the ray when a
+// lane takes it from the queue — origin = pos[origin pixel] + vis_near * dir, dir = oct_decode(light sample of `light pixel`) — with the expressions the
+// generating kernel would have used (put_ray), so the traced ray has the same bits and the queue carries 8 bytes per ray instead of 32.
+struct RaySrc { const float4* grec; const float4* rrec; float vis_near; };   // grec: 64-B pixel records (pos in the fourth quarter), rrec: 32-B packed reservoirs
+
 }  // namespace mr
 
 struct mirres_bvh {
@@ -126,6 +131,8 @@ int check_hip(hipError_t e, const char* what);
 #define MR_LAUNCH_CHECK(name) MR_HIP(hipGetLastError())
 
 // queue tracing (bvh_trace.hip). count is read on the device; capacity bounds the grid-stride loop.
+int trace_any_items_queue(const mirres_bvh* bvh, const uint2* items, const RaySrc& src, const uint32_t* d_count, size_t capacity, int32_t* hit,
+                          unsigned long long* stats, hipStream_t s, int lane, int timed, bool heads_clean);
 int trace_any_queue(const mirres_bvh* bvh, const Ray* rays, const uint32_t* d_count, size_t capacity, int32_t* hit,
                     unsigned long long* stats, hipStream_t s, int lane = 0, int timed = 0, bool heads_clean = false);
 int trace_any_front_queue(const mirres_bvh* bvh, const Ray* rays, const uint32_t* d_count, size_t capacity, int32_t* hit, hipStream_t s);

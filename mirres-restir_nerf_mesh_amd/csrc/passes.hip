@@ -395,7 +395,10 @@ MR_DEV int tile_pixel_v(int fx, int fy, int tw, int N, int vt) {   // tile_pixel
     const int x = tx * tw + (vt % tw), y = ty * tw + (vt / tw);
     return (x < fx && y < fy) ? y * fx + x : N;   // N = "no pixel"
 }
-template <int MR_MAX_NB>   // 5 (the reference's neighbour count) or 8: bounds the unrolled gathers, i.e. the registers held
+// ITEMS (mirres_render's chain: packed pixel records and reservoirs exist): the queue receives one (origin pixel, light pixel) pair per ray — 16 bytes per
+// accepted neighbour instead of two 32-byte rays — and k_trace_any4q<.., SRC = 1> forms the rays (engine.hpp RaySrc). Forming and writing the rays was 135 of
+// this kernel's 214 us per sample (five position / light gathers per pixel, 290 MB of ray records per launch).
+template <int MR_MAX_NB, bool ITEMS = false>   // 5 (the reference's neighbour count) or 8: bounds the unrolled gathers, i.e. the registers held
 __global__ void __launch_bounds__(MR_SGEN_BLOCK / MR_SGEN_PX) k_spatial_gen(mirres_config_t C, GBufD G, ResD PR, const float* __restrict__ noff, uint32_t frameIndex,
                                                           int fx, int fy, int N, int y_off, const float* __restrict__ occ_own, Ray* __restrict__ q,
                                                           uint32_t* __restrict__ q_count, int32_t* __restrict__ slot_out, uint32_t* __restrict__ mask_out) {
@@ -460,6 +463,22 @@ __global__ void __launch_bounds__(MR_SGEN_BLOCK / MR_SGEN_PX) k_spatial_gen(mirr
 #pragma unroll
     for (int px = 0; px < MR_SGEN_PX; px++) {
         const int pi = pis[px]; const uint32_t mask = masks[px];
+        if (ITEMS) {
+            if (mask) {
+                slot_out[pi] = (int32_t)s;
+                uint4* const qi = reinterpret_cast<uint4*>(reinterpret_cast<uint2*>(q) + s);     // s is even: 16-byte aligned
+                int j = 0;
+#pragma unroll
+                for (int i = 0; i < MR_MAX_NB; i++) {
+                    if (!(mask & (1u << i))) continue;
+                    // ray s + 2j: canonical pixel towards the neighbour's light; ray s + 2j + 1: neighbour towards the canonical light
+                    qi[j++] = make_uint4((uint32_t)pi, (uint32_t)nbs[px][i], (uint32_t)nbs[px][i], (uint32_t)pi);
+                }
+                s += 2 * (uint32_t)j;
+            } else if (pi < N) slot_out[pi] = -1;
+            if (pi < N) mask_out[pi] = mask;
+            continue;
+        }
         if (mask) {
             const v3 cpos = load_gpos(G, pi); const v3 cl = res_light(PR, pi); const v3 cdir = oct_decode(V2(cl.y, cl.z));
             v3 nl[MR_MAX_NB], np[MR_MAX_NB];
@@ -865,11 +884,26 @@ int mirres_restir_spatial(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_env
     if (!(fold && ctx->chain_clean)) MR_HIP(hipMemsetAsync(&ctx->counters[0], 0, sizeof(uint32_t), s));
     uint32_t* const rc_ = fold ? &ctx->counters[0] : nullptr; uint32_t* const rh_ = fold ? bvh->work : nullptr;   // lane 0 = head set 0
     const bool nb5 = ctx->cfg.neighbor_count <= 5;
-    if (nb5) k_spatial_gen<5><<<tile_grid(ctx->fx, ctx->fy, MR_SGEN_TILE), MR_SGEN_BLOCK / MR_SGEN_PX, 0, s>>>(ctx->cfg, gbufd(g), resd(prev_res), noff, frameIndex, ctx->fx, ctx->fy, N, ctx->y_off, ctx->occ_own, ctx->any_rays, &ctx->counters[0],
-                                                                                   ctx->slot_a, ctx->mask_a);
-    else k_spatial_gen<8><<<tile_grid(ctx->fx, ctx->fy, MR_SGEN_TILE), MR_SGEN_BLOCK / MR_SGEN_PX, 0, s>>>(ctx->cfg, gbufd(g), resd(prev_res), noff, frameIndex, ctx->fx, ctx->fy, N, ctx->y_off, ctx->occ_own, ctx->any_rays, &ctx->counters[0],
-                                                                               ctx->slot_a, ctx->mask_a);
-    int rc = trace_any(ctx, bvh, ctx->any_cap, s); if (rc) return rc;
+    // mirres_render's chain (packed pixel records + packed reservoirs, no per-ray counters wanted): the queue carries pixel pairs and the traversal kernel forms the rays
+    static const bool force_rays = [] { const char* e = getenv("MIRRES_SPATIAL_RAYS"); return e && e[0] == '1'; }();   // A/B: 32-byte rays as before
+    const bool items = ctx->grec && resd(prev_res).rec && !(ctx->instrument & 1) && !force_rays;
+    const dim3 sg_grid(tile_grid(ctx->fx, ctx->fy, MR_SGEN_TILE)), sg_block(MR_SGEN_BLOCK / MR_SGEN_PX);
+#define MR_SGEN_ARGS ctx->cfg, gbufd(g), resd(prev_res), noff, frameIndex, ctx->fx, ctx->fy, N, ctx->y_off, ctx->occ_own, ctx->any_rays, &ctx->counters[0], ctx->slot_a, ctx->mask_a
+    if (nb5 && items) k_spatial_gen<5, true><<<sg_grid, sg_block, 0, s>>>(MR_SGEN_ARGS);
+    else if (nb5) k_spatial_gen<5><<<sg_grid, sg_block, 0, s>>>(MR_SGEN_ARGS);
+    else if (items) k_spatial_gen<8, true><<<sg_grid, sg_block, 0, s>>>(MR_SGEN_ARGS);
+    else k_spatial_gen<8><<<sg_grid, sg_block, 0, s>>>(MR_SGEN_ARGS);
+#undef MR_SGEN_ARGS
+    int rc;
+    if (items) {
+        hipEvent_t *e0 = nullptr, *e1 = nullptr;
+        if (ctx->instrument & 2) { rc = ev_pair(ctx->ev_any, ctx->ev_any_used, &e0, &e1); if (rc) return rc; MR_HIP(hipEventRecord(*e0, s)); }
+        const RaySrc src = {reinterpret_cast<const float4*>(ctx->grec), resd(prev_res).rec, ctx->cfg.vis_near};
+        rc = trace_any_items_queue(bvh, reinterpret_cast<const uint2*>(ctx->any_rays), src, &ctx->counters[0], ctx->any_cap, ctx->any_hit, ctx->stats, s, 0, (ctx->instrument & 2) != 0,
+                                   ctx->chain_reset && ctx->chain_clean);
+        if (e1) MR_HIP(hipEventRecord(*e1, s));
+    } else rc = trace_any(ctx, bvh, ctx->any_cap, s);
+    if (rc) return rc;
     GBufD gr = gbufd(g);
     if (ctx->grec) gr.rec = reinterpret_cast<const float4*>(ctx->grec);   // mirres_render: same values, one 64-byte record per neighbour instead of three arrays
     if (nb5) k_spatial_resolve<5><<<tile_grid(ctx->fx, ctx->fy, MR_SRES_TILE), MR_SRES_TILE * MR_SRES_TILE, 0, s>>>(ctx->cfg, envh(env), gr, resd(res), resd(prev_res), noff, frameIndex, ctx->fx, ctx->fy, N, ctx->y_off, ctx->occ_own,
