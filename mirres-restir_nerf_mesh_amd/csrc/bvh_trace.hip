@@ -470,7 +470,7 @@ MR_DEV bool tri_accepts_regs(float4 a, float4 b, float4 c, v3 ro, v3 d) {
 #define MR_PH(x)
 #endif
 // TIMED = 2: front-only occlusion (nerf/render_dump.py's external `intersector`, a conventional ray tracer) — the same traversal with t > 0 required
-// SRC = 1: the queue holds (origin pixel, light pixel) pairs and the ray is formed here (engine.hpp RaySrc)
+// SRC = 1: the queue holds one pixel pair per two rays and the ray is formed here (engine.hpp RaySrc)
 template <bool COUNT, int TOPN, int TIMED = 0, int SRC = 0>   // TIMED: identical code under a second name, launched by bench.py's event-timed frame so that a rocprofv3
                                                               // kernel trace of the same command shows those launches as their own row
 __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const Ray* __restrict__ rays, const uint32_t* __restrict__ d_count,
@@ -548,8 +548,9 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const
                 if (!have && idx0 < chunk_end) {
                     float4 a, b;
                     if (SRC == 1) {
-                        const uint2 it = reinterpret_cast<const uint2*>(rays)[idx];
-                        const float4 P = src.grec[4 * (size_t)it.x + 3], L = src.rrec[2 * (size_t)it.y];
+                        const uint2 it = reinterpret_cast<const uint2*>(rays)[idx >> 1];      // pair (a, b): even ray a -> b's light, odd ray b -> a's light
+                        const uint32_t op = (idx & 1u) ? it.y : it.x, lp = (idx & 1u) ? it.x : it.y;
+                        const float4 P = src.grec[4 * (size_t)op + 3], L = src.rrec[2 * (size_t)lp];
                         const v3 dir = oct_decode(V2(L.y, L.z));
                         const v3 o = V3(P.x, P.y, P.z) + src.vis_near * dir;          // put_ray (passes.hip): the same two expressions
                         a.x = o.x; a.y = o.y; a.z = o.z; a.w = 0.f; b.x = dir.x; b.y = dir.y; b.z = dir.z; b.w = 1e7f;

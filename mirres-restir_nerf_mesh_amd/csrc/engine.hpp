@@ -57,9 +57,10 @@ struct BvhView {
     unsigned long long* dbg;   // optional [2 * waves]: wall-clock start / end of every traversal wave (mirres_debug_wave_times)
 };
 
-// Shadow rays given as (origin pixel, light pixel) pairs instead of 32-byte rays (the spatial pass of mirres_render): the traversal kernel forms the ray when a
-// lane takes it from the queue — origin = pos[origin pixel] + vis_near * dir, dir = oct_decode(light sample of `light pixel`) — with the expressions the
-// generating kernel would have used (put_ray), so the traced ray has the same bits and the queue carries 8 bytes per ray instead of 32.
+// Shadow rays given as pixel pairs instead of 32-byte rays (the spatial pass of mirres_render): queue entry j = (pixel a, pixel b) stands for ray 2j — from a's
+// position towards b's light sample — and ray 2j + 1 — from b's position towards a's. The traversal kernel forms the ray when a lane takes it from the queue:
+// origin = pos + vis_near * dir, dir = oct_decode(light sample), the expressions the generating kernel would have used (put_ray), so the traced ray has the
+// same bits and the queue carries 4 bytes per ray instead of 32.
 struct RaySrc { const float4* grec; const float4* rrec; float vis_near; };   // grec: 64-B pixel records (pos in the fourth quarter), rrec: 32-B packed reservoirs
 
 }  // namespace mr

@@ -395,8 +395,8 @@ MR_DEV int tile_pixel_v(int fx, int fy, int tw, int N, int vt) {   // tile_pixel
     const int x = tx * tw + (vt % tw), y = ty * tw + (vt / tw);
     return (x < fx && y < fy) ? y * fx + x : N;   // N = "no pixel"
 }
-// ITEMS (mirres_render's chain: packed pixel records and reservoirs exist): the queue receives one (origin pixel, light pixel) pair per ray — 16 bytes per
-// accepted neighbour instead of two 32-byte rays — and k_trace_any4q<.., SRC = 1> forms the rays (engine.hpp RaySrc). Forming and writing the rays was 135 of
+// ITEMS (mirres_render's chain: packed pixel records and reservoirs exist): the queue receives one (canonical pixel, neighbour pixel) pair per accepted
+// neighbour — 8 bytes instead of two 32-byte rays — and k_trace_any4q<.., SRC = 1> forms the rays (engine.hpp RaySrc). Forming and writing the rays was 135 of
 // this kernel's 214 us per sample (five position / light gathers per pixel, 290 MB of ray records per launch).
 template <int MR_MAX_NB, bool ITEMS = false>   // 5 (the reference's neighbour count) or 8: bounds the unrolled gathers, i.e. the registers held
 __global__ void __launch_bounds__(MR_SGEN_BLOCK / MR_SGEN_PX) k_spatial_gen(mirres_config_t C, GBufD G, ResD PR, const float* __restrict__ noff, uint32_t frameIndex,
@@ -466,13 +466,13 @@ __global__ void __launch_bounds__(MR_SGEN_BLOCK / MR_SGEN_PX) k_spatial_gen(mirr
         if (ITEMS) {
             if (mask) {
                 slot_out[pi] = (int32_t)s;
-                uint4* const qi = reinterpret_cast<uint4*>(reinterpret_cast<uint2*>(q) + s);     // s is even: 16-byte aligned
+                uint2* const qi = reinterpret_cast<uint2*>(q) + (s >> 1);     // s is even: one pair per two rays
                 int j = 0;
 #pragma unroll
                 for (int i = 0; i < MR_MAX_NB; i++) {
                     if (!(mask & (1u << i))) continue;
-                    // ray s + 2j: canonical pixel towards the neighbour's light; ray s + 2j + 1: neighbour towards the canonical light
-                    qi[j++] = make_uint4((uint32_t)pi, (uint32_t)nbs[px][i], (uint32_t)nbs[px][i], (uint32_t)pi);
+                    // pair (a, b) = rays s + 2j: pixel a towards pixel b's light (canonical towards the neighbour's), and s + 2j + 1: b towards a's light
+                    qi[j++] = make_uint2((uint32_t)pi, (uint32_t)nbs[px][i]);
                 }
                 s += 2 * (uint32_t)j;
             } else if (pi < N) slot_out[pi] = -1;
@@ -708,6 +708,21 @@ int trace_any_q(mirres_ctx* ctx, mirres_bvh* bvh, const Ray* rays, const uint32_
     if (e1) MR_HIP(hipEventRecord(*e1, s));
     return rc;
 }
+// queue of (origin pixel, light pixel) pairs instead of rays (engine.hpp RaySrc); never in the counting mode (callers fall back to rays there).
+// Only the spatial pass uses it: the initial pass's ray must follow the candidate's direction even when its reservoir is stored empty (non-finite weight), and
+// one ray per pixel is a small part of that kernel anyway.
+int trace_any_items_q(mirres_ctx* ctx, mirres_bvh* bvh, const Ray* queue, const RaySrc& src, const uint32_t* count, size_t cap, int32_t* hit, hipStream_t s, int lane) {
+    hipEvent_t *e0 = nullptr, *e1 = nullptr;
+    if (ctx->instrument & 2) { int rc = ev_pair(ctx->ev_any, ctx->ev_any_used, &e0, &e1); if (rc) return rc; MR_HIP(hipEventRecord(*e0, s)); }
+    int rc = trace_any_items_queue(bvh, reinterpret_cast<const uint2*>(queue), src, count, cap, hit, ctx->stats, s, lane, (ctx->instrument & 2) != 0,
+                                   lane == 0 && ctx->chain_reset && ctx->chain_clean);
+    if (e1) MR_HIP(hipEventRecord(*e1, s));
+    return rc;
+}
+static bool ray_items_allowed(const mirres_ctx* ctx) {
+    static const bool force_rays = [] { const char* e = getenv("MIRRES_SPATIAL_RAYS"); return e && e[0] == '1'; }();   // A/B: 32-byte rays everywhere, as before
+    return ctx->grec && !(ctx->instrument & 1) && !force_rays;
+}
 int trace_closest_q(mirres_ctx* ctx, mirres_bvh* bvh, const Ray* rays, const uint32_t* count, size_t cap, HitRec* out, hipStream_t s, int lane) {
     hipEvent_t *e0 = nullptr, *e1 = nullptr;
     if (ctx->instrument & 2) { int rc = ev_pair(ctx->ev_cl, ctx->ev_cl_used, &e0, &e1); if (rc) return rc; MR_HIP(hipEventRecord(*e0, s)); }
@@ -885,8 +900,7 @@ int mirres_restir_spatial(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_env
     uint32_t* const rc_ = fold ? &ctx->counters[0] : nullptr; uint32_t* const rh_ = fold ? bvh->work : nullptr;   // lane 0 = head set 0
     const bool nb5 = ctx->cfg.neighbor_count <= 5;
     // mirres_render's chain (packed pixel records + packed reservoirs, no per-ray counters wanted): the queue carries pixel pairs and the traversal kernel forms the rays
-    static const bool force_rays = [] { const char* e = getenv("MIRRES_SPATIAL_RAYS"); return e && e[0] == '1'; }();   // A/B: 32-byte rays as before
-    const bool items = ctx->grec && resd(prev_res).rec && !(ctx->instrument & 1) && !force_rays;
+    const bool items = ray_items_allowed(ctx) && resd(prev_res).rec;
     const dim3 sg_grid(tile_grid(ctx->fx, ctx->fy, MR_SGEN_TILE)), sg_block(MR_SGEN_BLOCK / MR_SGEN_PX);
 #define MR_SGEN_ARGS ctx->cfg, gbufd(g), resd(prev_res), noff, frameIndex, ctx->fx, ctx->fy, N, ctx->y_off, ctx->occ_own, ctx->any_rays, &ctx->counters[0], ctx->slot_a, ctx->mask_a
     if (nb5 && items) k_spatial_gen<5, true><<<sg_grid, sg_block, 0, s>>>(MR_SGEN_ARGS);
@@ -896,12 +910,8 @@ int mirres_restir_spatial(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_env
 #undef MR_SGEN_ARGS
     int rc;
     if (items) {
-        hipEvent_t *e0 = nullptr, *e1 = nullptr;
-        if (ctx->instrument & 2) { rc = ev_pair(ctx->ev_any, ctx->ev_any_used, &e0, &e1); if (rc) return rc; MR_HIP(hipEventRecord(*e0, s)); }
         const RaySrc src = {reinterpret_cast<const float4*>(ctx->grec), resd(prev_res).rec, ctx->cfg.vis_near};
-        rc = trace_any_items_queue(bvh, reinterpret_cast<const uint2*>(ctx->any_rays), src, &ctx->counters[0], ctx->any_cap, ctx->any_hit, ctx->stats, s, 0, (ctx->instrument & 2) != 0,
-                                   ctx->chain_reset && ctx->chain_clean);
-        if (e1) MR_HIP(hipEventRecord(*e1, s));
+        rc = trace_any_items_q(ctx, bvh, ctx->any_rays, src, &ctx->counters[0], ctx->any_cap, ctx->any_hit, s, 0);
     } else rc = trace_any(ctx, bvh, ctx->any_cap, s);
     if (rc) return rc;
     GBufD gr = gbufd(g);
