@@ -225,12 +225,14 @@ def main():
                 "frac": round(achieved / HBM, 5), "traffic": pmc.get("k_trace_any_hbm_bytes_per_launch"),
                 "bytes_per_ray": round(own_bytes_any / max(1, rays_any), 1), "launch_ms": round(ms_any / max(1, n_any), 4), "launches": n_any,
                 "rays_per_launch": round(rays_any / max(1, n_any)), "grays_per_s": round(rays_any / sec_any / 1e9, 3) if sec_any > 0 else 0.0,
+                "traffic_over_own_bytes": (round(pmc["k_trace_any_hbm_bytes_per_launch"] / (own_bytes_any / max(1, n_any)), 3) if pmc.get("k_trace_any_hbm_bytes_per_launch") else None),
                 "l2_peak": L2, "l2_frac": round(achieved / L2, 5),
                 "binding": "valu-issue", "valu_busy": pmc.get("valu_busy"), "lane_util": pmc.get("lane_util"), "l1_hit": pmc.get("l1_hit"),
                 "reference_equiv": {"bytes_per_ray": round(ref_bytes_any / max(1, rays_any), 1), "tbps": round(ref_bytes_any / sec_any / 1e12, 2) if sec_any > 0 else 0.0,
                                     "note": "SURVEY 8d accounting: reference node layout x the reference traversal's visit counts on the same rays / this kernel's time"},
                 "note": "achieved = bytes the kernel's own algorithm has to move (64-B records visited + ray + result, counted on the timed rays) / event-timed duration, against the HBM "
-                        "peak as the contract asks; the 43 MB layout is cache resident (traffic = HBM bytes per launch from PMC, 6 % of the requested bytes; 88 % L1 hits), so the "
+                        "peak as the contract asks; the 43 MB layout is cache resident (traffic = HBM bytes per launch from PMC — the spatial pass's pixel records and reservoirs gathered at the refill, "
+                        "ray queues, results — `traffic_over_own_bytes` of the accounted bytes; 88 % L1 hits), so the "
                         "binding resource is VALU issue, not bandwidth: valu_busy = SQ_ACTIVE_INST_VALU / SIMD cycles, lane_util = active lanes per issued VALU instruction "
                         "(profiles/r03_pmc_any4q_summary.json)",
                 "closest": {"kernel": "k_trace_closest4 (+ reference-order redo)", "achieved": round(achieved_cl, 2), "peak": HBM, "unit": "GB/s", "frac": round(achieved_cl / HBM, 5),
