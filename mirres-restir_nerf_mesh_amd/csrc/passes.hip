@@ -536,17 +536,10 @@ __global__ void MR_SRES_ATTR __launch_bounds__(MR_SRES_TILE * MR_SRES_TILE) k_sp
     const uint32_t k = (uint32_t)C.neighbor_count;
     const uint32_t mask = mask_in[pi];
     int hs = slot[pi];
-    // the accepted neighbours' pixel data and reservoirs are fetched together (independent gathers in flight), then merged in order — in TWO groups (three
-    // neighbours, then the rest; the compiler barrier keeps the second group's gathers behind the first merge): 111 VGPRs instead of 139, i.e. four waves per SIMD
-    // instead of three. Alone the kernel is slower that way (173 -> 189 us: two gather round trips per thread), beside the other streams' kernels the frame is
-    // 0.9 % faster (1246 -> 1257 Msamples/s at 128 spp, interleaved runs): the registers it leaves are worth more than the round trip.
+    // the accepted neighbours' pixel data and reservoirs are fetched up front (independent gathers in flight together), then merged in order
     GPix gnb[MR_MAX_NB]; ResV rnb[MR_MAX_NB];
-    constexpr int SPLIT = MR_MAX_NB <= 5 ? 3 : 4;
 #pragma unroll
-    for (int grp = 0; grp < 2; grp++) {
-    const int g_lo = grp ? SPLIT : 0, g_hi = grp ? MR_MAX_NB : SPLIT;
-#pragma unroll
-    for (int i = g_lo; i < g_hi; i++) {
+    for (int i = 0; i < MR_MAX_NB; i++) {
         if ((uint32_t)i < k && (mask & (1u << i))) {
             const uint32_t ni = (startIndex + (uint32_t)i) & (uint32_t)(C.neighbor_offset_count - 1);
             const int nx = x + (int)(noff[2 * ni] * C.gather_radius), ny = y + (int)(noff[2 * ni + 1] * C.gather_radius);
@@ -555,7 +548,7 @@ __global__ void MR_SRES_ATTR __launch_bounds__(MR_SRES_TILE * MR_SRES_TILE) k_sp
         }
     }
 #pragma unroll
-    for (int i = g_lo; i < g_hi; i++) {
+    for (int i = 0; i < MR_MAX_NB; i++) {
         if (!((uint32_t)i < k && (mask & (1u << i)))) continue;
         const v3 nn = gnb[i].n;
         const ResV nbr = rnb[i];
@@ -579,8 +572,6 @@ __global__ void MR_SRES_ATTR __launch_bounds__(MR_SRES_TILE * MR_SRES_TILE) k_sp
         s.weightSum += w;
         s.canonicalWeight += m1;
         if (rnd(sg) * s.weightSum < w) { s.light_data = nbr.light_data; s.inv_pdf = nbr.light_pdf; s.weight = candAtOther; s.vcode = canonicalVis > 0.f ? 1 : 2; s.lum = nlum; }
-    }
-    asm volatile("" ::: "memory");
     }
     {   // streamingResampleFinalizeMis (res.slang:215-232)
         float w = curTarget * cur.weight * s.canonicalWeight;
