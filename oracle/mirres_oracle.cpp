@@ -320,9 +320,18 @@ static void accumulate(std::vector<float>& a, const std::vector<float>& b) {
     for (long long i = 0; i < (long long)a.size(); i++) a[i] += b[i];
 }
 
+// ReSTIR constants of the NEXT orc_render calls (0 = the reference's value): the reference fixes them at compile time, the product takes them as runtime
+// configuration (mirres_config_t) — frame-level tests of that configuration set the same numbers here
+static int g_render_neighbor_count = 0, g_render_initial_light_samples = 0, g_render_max_history = 0;
+void orc_set_render_constants(int neighbor_count, int initial_light_samples, int max_history) {
+    g_render_neighbor_count = neighbor_count; g_render_initial_light_samples = initial_light_samples; g_render_max_history = max_history;
+}
 int orc_render(const OrcRenderArgs* A) {
     const int fx = A->fx, fy = A->fy; const size_t N = (size_t)fx * fy;
     Config C; if (A->max_bounce > 0) C.max_bounce = A->max_bounce;
+    if (g_render_neighbor_count > 0) C.neighbor_count = g_render_neighbor_count;
+    if (g_render_initial_light_samples > 0) C.initial_light_samples = g_render_initial_light_samples;
+    if (g_render_max_history > 0) C.max_history = g_render_max_history;
     // run_restir_di_with_pt :484-486
     for (size_t i = 0; i < N; i++) if (A->occ[i] <= 0.5f) A->occ[i] = 0.f;
     std::vector<float> ray_dir(3 * N);

@@ -356,6 +356,11 @@ def matnet(mat, pos):
 
 
 # ------------------------------------------------------------------ whole frame
+def set_render_constants(neighbor_count=0, initial_light_samples=0, max_history=0):
+    """ReSTIR constants of the following render() calls (0 = the reference's compile-time value); reset with no arguments."""
+    lib().orc_set_render_constants(int(neighbor_count), int(initial_light_samples), int(max_history))
+
+
 def render(fx, fy, spp, random_offset, bvh, vert, tri, env_map, occ, normal, depth, kd, rs, ray_dir, pos, mat=None, max_bounce=2,
            use_scale=False, scale=(1, 1, 1), denoise_iter=2, step_width=2, c_phi=2.0, n_phi=0.1, p_phi=0.001, want_avg=False,
            const_kd=(0.6, 0.6, 0.6), const_rs=(0.5, 0.0)):

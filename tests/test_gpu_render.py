@@ -121,6 +121,33 @@ def test_three_indirect_bounces_and_albedo_scale(oracle, scene_mod):
         pixel_parity(g_, r, "three bounces + albedo scale / " + n, tol=0.0)        # the fp32-MFMA material field is an fmaf chain: bit-equal frame
 
 
+def test_frame_with_other_restir_constants_matches_the_oracle(oracle, scene_mod):
+    """The ReSTIR constants are runtime configuration (mirres_config_t): a frame with SEVEN spatial neighbours, 16 light candidates and a history cap of 7
+    goes through the second instantiations of the spatial kernels inside mirres_render — k_spatial_gen<8, pixel pairs>, the traversal kernel's pair queue,
+    k_spatial_resolve<8> on packed records — which the stepwise test of these constants (test_gpu_passes.py) does not reach. Bit for bit against the oracle's
+    frame with the same constants, and different from the default constants' frame."""
+    import torch
+    from mirres_restir_nerf_mesh_amd import _lib, _ops
+    F, W, mods, RR, torch = _setup(oracle, scene_mod)
+    cfg = _lib.default_config(); cfg.neighbor_count, cfg.initial_light_samples, cfg.max_history = 7, 16, 7
+    ctx = _ops.Context(F.fx, F.fy, cfg)
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    outs, _, _ = RR.render_fused(ctx, W, None, False, (1, 1, 1), cu(F.env), cu(F.occ[:, None].copy()), cu(F.normal), cu(F.depth[:, None]), cu(F.kd), cu(F.rm), cu(F.ray_dir_raw), cu(F.pos),
+                                 4, 2, 2, 2.0, 0.1, 0.001, 4242)
+    got = [o.cpu().numpy() for o in outs]
+    args = (F.fx, F.fy, 4, 4242, (F.info, F.aabb), F.vert, F.tri, F.env, F.occ, F.normal, F.depth, F.kd, F.rm, F.ray_dir_raw, F.pos)
+    oracle.set_render_constants(7, 16, 7)
+    try:
+        ref = oracle.render(*args, mat=None)
+    finally:
+        oracle.set_render_constants()
+    names = ["final_color", "diffuse", "spec", "indirect", "indirect_diff", "indirect_spec"]
+    for g, n in zip(got, names):
+        pixel_parity(g, ref[n], "frame with 7 neighbours / 16 candidates / history 7 / " + n, tol=0.0)
+    dflt = oracle.render(*args, mat=None)
+    assert not np.array_equal(dflt["diffuse"], ref["diffuse"])          # the constants reach the oracle's frame
+
+
 def test_fused_equals_stepwise(oracle, scene_mod, monkeypatch):
     """The one-call fused loop and the reference-shaped Python loop run the same kernels; the only difference is that the stepwise path
     prepares ray_dir / brdf_map with torch ops (F.normalize rounds differently from the fused prep kernel by an ulp), so results agree to
