@@ -276,3 +276,18 @@ def test_configs2_training_step_800x800_32spp(big, scene_mod, monkeypatch):
     for a, b, nm in zip(res["1"], res["0"], ("env", "W2", "hash grid")):
         cos = float((a * b).sum() / (a.norm() * b.norm() + 1e-30))
         assert cos > 0.999, (nm, cos)
+
+
+def test_pixel_pair_queue_and_ray_queue_render_the_same_frame_at_full_size():
+    """The spatial pass hands its shadow rays to the traversal kernel as pixel pairs (the kernel forms the rays) or, with MIRRES_SPATIAL_RAYS=1, as 32-byte rays
+    formed by the generator — the same expressions on the same inputs, so a 1600 x 1600 frame with the material field must come out with the same bits. The
+    switch is read once per process: two processes (scripts/dev_frame_hash.py prints a SHA-256 of every output buffer)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for rays in ("0", "1"):
+        env = dict(os.environ, MIRRES_SPATIAL_RAYS=rays); env.pop("MIRRES_PARITY_REPORT", None)
+        r = subprocess.run([sys.executable, os.path.join(root, "scripts", "dev_frame_hash.py"), "6"], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout.strip().splitlines()[-1])
+    assert outs[0] == outs[1] and len(outs[0].split()) >= 7, outs
