@@ -36,6 +36,10 @@ def parse():
     p.add_argument("--spp", type=int, default=512, help="BASELINE.json metric: 800x800, 512 spp, 3-bounce (configs[1] quotes the same frame at 128 spp)")
     p.add_argument("--bounces", type=int, default=2, help="indirect bounces (MAX_Bounce, FinalShading.slang:7) -> 3 path vertices")
     p.add_argument("--subdiv", type=int, default=7, help="icosphere subdivisions (7 -> 327 680 + 8 192 ground triangles)")
+    p.add_argument("--mesh", choices=("icosphere", "clustered"), default="icosphere",
+                   help="icosphere: SURVEY 8d's synthetic mesh (uniform tessellation); clustered: the lego-like assembly of scene.make_mesh_clustered (studs, cavities, "
+                        "thin plates, triangle areas spread > 1e5 : 1). The default run reports the other mesh as a sub-record")
+    p.add_argument("--no-extras", action="store_true", help="skip the sub-records of the default single-GPU run (the other mesh, the configs[2] training step)")
     p.add_argument("--shard", choices=("both", "strips", "spp"), default="both",
                    help="N > 1: `spp` = sample slices + one all-reduce (the timed `value`), `strips` = exact row strips + per-sample halo exchange + all-gather (the north-star's "
                         "tile split, reported as the `strips` sub-record), `both` = time the two schemes one after the other")
@@ -49,7 +53,7 @@ def cpu_baseline(S, args):
     """The CPU oracle (restatement of the reference kernels — NOT reference code, which is CUDA-only) on a bounded sample of the same workload."""
     import numpy as np
     from oracle import oracle as O
-    v, t = S.make_mesh(args.subdiv, 64 if args.subdiv >= 6 else 16)
+    v, t = S.mesh_by_name(args.mesh, args.subdiv)
     info, aabb, _, _ = O.bvh_build(v, t)
     fx = fy = 320
     eye, rd = S.camera_rays(fy, fx)
@@ -89,6 +93,150 @@ MLP_ROOF = {"bound": "mfma", "peak": 157.3, "instruction": "v_mfma_f32_32x32x2_f
                     "(the 6-row output layer occupies a 32-row tile): issued_frac = that rate against the same peak"}
 
 
+def csrc_sha():
+    """Identity of the native sources a counter snapshot belongs to: sha256 over csrc/*.hip, csrc/*.hpp and include/*.h (the GPU box has no .git)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "mirres-restir_nerf_mesh_amd", "csrc")
+    files = sorted(os.path.join(d, f) for f in os.listdir(d) if f.endswith((".hip", ".hpp"))) + sorted(os.path.join(ROOT, "include", f) for f in os.listdir(os.path.join(ROOT, "include")) if f.endswith(".h"))
+    for f in files:
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()[:12]
+
+
+def pmc_snapshot():
+    """Hardware-counter figures cannot be collected inside this process (rocprofv3 --pmc runs are separate, scripts/pmc_*.sh); the committed summaries are
+    reported ONLY while they belong to the sources the library was built from (the snapshot records csrc_sha at collection time). Otherwise: stale, no numbers."""
+    snap = {}
+    for fn_ in ("pmc_any4q_summary.json", "pmc_traffic.json"):
+        path = os.path.join(ROOT, "profiles", fn_)
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        d["_file"] = "profiles/" + fn_
+        snap[fn_] = d
+    cur = csrc_sha()
+    out = {"csrc_sha_now": cur}
+    for fn_, d in snap.items():
+        fresh = d.get("csrc_sha") == cur
+        key = "counters" if "any4q" in fn_ else "traffic"
+        if fresh:
+            out[key] = dict({k: v for k, v in d.items() if not k.startswith("_")}, source="static:%s@%s" % (d["_file"], d.get("csrc_sha")))
+        else:
+            out[key] = {"stale": True, "source": "static:%s@%s" % (d["_file"], d.get("csrc_sha")), "note": "collected on other kernel sources: not reported"}
+    return out
+
+
+def make_field(S, torch, dev):
+    from mirres_restir_nerf_mesh_amd.render_helper import MLPTexture3D
+    params, w0, w1, w2 = S.make_matnet_params(seed=0)
+    mn, mx = S.material_min_max()
+    mlp = MLPTexture3D(torch.tensor([-1, -1, -1, 1, 1, 1], dtype=torch.float32), channels=6, min_max=(torch.from_numpy(mn).to(dev), torch.from_numpy(mx).to(dev)))
+    with torch.no_grad():
+        mlp.encoder.params.copy_(torch.from_numpy(params).to(dev))
+        for i, w in zip((0, 2, 4), (w0, w1, w2)):
+            mlp.net.net[i].weight.copy_(torch.from_numpy(w).to(dev))
+    return mlp
+
+
+def traversal_roofline(args, ctx, W, mlp, env, g, prof_spp, step_ms, world, pmc):
+    """Live measurement (HIP events on the launch stream + the instrumented kernels' visit counts on the same rays) of the dominant kernel, k_trace_any4q."""
+    import torch
+    from mirres_restir_nerf_mesh_amd import renderer_restir as RR
+    N = g["fx"] * g["fy"]
+    def frame(n):
+        occ = g["occ"].clone()
+        RR.render_fused(ctx, W, mlp, False, (1, 1, 1), env, occ, g["normal"], g["depth"], g["kd"], g["rm"], g["ray_dir"], g["pos"], n, 2, 2, 2.0, 0.1, 0.001, 12345)
+    # (a) visit counts of exactly these rays (deterministic; untimed): the production kernels' own (64-byte records they fetch) and, for the
+    #     reference-equivalent figure, the reference traversal's (bvh_hit's order, no early exit) on the same ray set
+    ctx.set_instrument(5); ctx.stats(reset=True); frame(prof_spp); st = ctx.stats(reset=True)
+    ctx.set_instrument(1); ctx.stats(reset=True); frame(prof_spp); own = ctx.stats(reset=True)
+    # (b) event-timed launches of the production kernels on the same rays
+    ctx.set_instrument(2); ctx.trace_time(); frame(prof_spp); ms_any, n_any, ms_cl, n_cl = ctx.trace_time()
+    ctx.set_instrument(0)
+    rays_any, rays_cl = st["rays_any"], st["rays_closest"]
+    total_rays = rays_any + rays_cl
+    # ALGORITHMIC bytes of the kernel as built (DESIGN.md section 5): every 64-byte node / leaf record the traversal has to read for its answer
+    # (counted by the instrumented kernel on these very rays) + the 32-byte ray + the result (4 B hit flag; 28 B hit record for the closest hit).
+    # (the spatial pass's rays reach the kernel as 8-byte pixel pairs and are formed there from two 16-byte gathers: 40 B requested, accounted as 32 B like the others)
+    own_bytes_any = 64.0 * own["entered"] + rays_any * (32 + 4)
+    own_bytes_cl = 64.0 * own["cl_entered"] + rays_cl * (32 + 28)
+    # SURVEY section 8d's accounting (reference node layout, reference traversal's visit counts): what the REFERENCE's bvh_hit would have to move
+    # for the same rays — kept as `reference_equiv`, not as the roofline (the production kernel does not do that work: early exit, 4-wide tree)
+    ref_bytes_any = 24.0 * st["popped"] + 24.0 * st["entered"] + 48.0 * st["leaves"] + rays_any * (24 + 12 + 4)
+    sec_any, sec_cl = ms_any * 1e-3, ms_cl * 1e-3
+    achieved = own_bytes_any / sec_any / 1e9 if sec_any > 0 else 0.0
+    achieved_cl = own_bytes_cl / sec_cl / 1e9 if sec_cl > 0 else 0.0
+    HBM, L2 = 8000.0, 34500.0       # GB/s: MI355X_MICROARCH.md (HBM3E spec peak; aggregate L2 of the eight XCDs)
+    cnt = (pmc or {}).get("counters") or {}; trf = (pmc or {}).get("traffic") or {}
+    valu_busy = None if cnt.get("stale") else cnt.get("valu_busy")
+    traffic = None if trf.get("stale") else trf.get("k_trace_any_hbm_bytes_per_launch")
+    launch_s = sec_any / max(1, n_any)
+    roof = {"bound": "valu-issue", "kernel": "k_trace_any4q (shadow-ray BVH traversal)",
+            # the binding resource is VALU issue (the 43 MB node / leaf layout is cache resident): frac = SQ_ACTIVE_INST_VALU / SIMD cycles of the kernel, a hardware-counter
+            # figure from the snapshot below (null when the snapshot does not belong to the built sources); everything else in this record is measured in this run
+            "achieved": valu_busy, "peak": 1.0, "unit": "VALU-busy cycles per SIMD cycle", "frac": valu_busy,
+            "traffic": traffic,
+            "own_bytes": {"achieved": round(achieved, 2), "peak": HBM, "unit": "GB/s", "frac": round(achieved / HBM, 5), "bytes_per_ray": round(own_bytes_any / max(1, rays_any), 1),
+                          "l2_peak": L2, "l2_frac": round(achieved / L2, 5),
+                          "note": "bytes the kernel's own algorithm requests (64-B records visited, counted on the timed rays, + ray + result) / event-timed duration; mostly L1 / L2 hits, "
+                                  "i.e. NOT an HBM utilisation"},
+            "hbm_counter": ({"bytes_per_launch": traffic, "achieved": round(traffic / launch_s / 1e9, 1), "peak": HBM, "unit": "GB/s", "frac": round(traffic / launch_s / 1e9 / HBM, 4),
+                             "over_own_bytes": round(traffic / (own_bytes_any / max(1, n_any)), 3),
+                             "note": "FETCH_SIZE + WRITE_SIZE per launch (snapshot, on the default workload) / this run's launch time"} if traffic and launch_s > 0 and args.mesh == "icosphere" else None),
+            "launch_ms": round(ms_any / max(1, n_any), 4), "launches": n_any,
+            "rays_per_launch": round(rays_any / max(1, n_any)), "grays_per_s": round(rays_any / sec_any / 1e9, 3) if sec_any > 0 else 0.0,
+            "pmc_snapshot": pmc,
+            "reference_equiv": {"bytes_per_ray": round(ref_bytes_any / max(1, rays_any), 1), "tbps": round(ref_bytes_any / sec_any / 1e12, 2) if sec_any > 0 else 0.0,
+                                "note": "SURVEY 8d accounting: reference node layout x the reference traversal's visit counts on the same rays / this kernel's time"},
+            "closest": {"kernel": "k_trace_closest4 (+ reference-order redo)", "own_bytes_gbps": round(achieved_cl, 2), "own_bytes_frac_of_hbm": round(achieved_cl / HBM, 5),
+                        "bytes_per_ray": round(own_bytes_cl / max(1, rays_cl), 1), "launch_ms": round(ms_cl / max(1, n_cl), 4), "launches": n_cl,
+                        "grays_per_s": round(rays_cl / sec_cl / 1e9, 3) if sec_cl > 0 else 0.0, "redo_frac": round(own["cl_redo"] / max(1, rays_cl), 6)},
+            "rays_per_pixel_sample": round(total_rays / (float(N) * prof_spp), 3),
+            "per_ray": {"any_reference": [round(st[k] / max(1, rays_any), 2) for k in ("popped", "entered", "leaves")], "any_production": [round(own[k] / max(1, rays_any), 2) for k in ("popped", "entered", "leaves")],
+                        "closest": [round(own[k] / max(1, rays_cl), 2) for k in ("cl_popped", "cl_entered", "cl_leaves")],
+                        "legend": "reference: nodes popped / internal nodes entered / leaves tested by bvh_hit's own order; production: box tests / 64-B records fetched / leaves tested"},
+            "private_stack_deepest": {"shadow": own["any_max_stack"], "ordered_closest": own["cl_max_stack"], "overflows": own["any_stack_overflow"]},
+            "traversal_share_of_step": round((ms_any + ms_cl) / prof_spp * args.spp / step_ms * (world if world > 1 else 1), 3)}
+    return roof
+
+
+def train_step_record(S, torch, dev, W, steps=3):
+    """BASELINE configs[2]: one stage-1 inverse-rendering step — forward + backward through FinalShading / EvaluateFinalSamples_di / EAW / the material field,
+    Adam step on field + environment — at 800 x 800, 32 spp (main.py:108), LBVH rebuild per step, on the benched mesh."""
+    from mirres_restir_nerf_mesh_amd import renderer_restir as RR, harness
+    mlp = make_field(S, torch, dev)
+    g = harness.build_gbuffer(W, 800, 800, 1)
+    fx, fy = g["fx"], g["fy"]; N = fx * fy
+    mods = RR.load_m_for_restir(fx, fy)
+    env = torch.full((256, 512, 3), 0.5, device=dev, requires_grad=True)
+    opt = torch.optim.Adam([{"params": mlp.parameters(), "lr": 1e-3}, {"params": [env], "lr": 1e-2}])
+    target = torch.rand((N, 3), device=dev, generator=torch.Generator(device=dev).manual_seed(5)) * 0.5 + 0.25
+    fg = g["occ"][:, 0] > 0.5
+    z = lambda *s_: torch.zeros(s_, device=dev)
+    def step():
+        opt.zero_grad(set_to_none=True)
+        W.update_mesh(W.vrt, W.v_ind)
+        kdks = mlp.sample(g["pos"])
+        kd = kdks[:, 0:3].contiguous(); rm = torch.cat((kdks[:, 4:5], kdks[:, 5:6]), -1).contiguous()
+        out = RR.run_restir_di_with_pt(False, 1.0, 1.0, 1.0, mlp, None, W, *mods[:8], *mods[8:17], env, g["occ"].clone(), g["normal"], g["depth"], kd, rm, g["ray_dir"], g["pos"],
+                                       z(N, 1), z(N, 4), z(N, 3), z(N, 3), fx, fy, 32, 2, 2, 2.0, 0.1, 0.001)
+        loss = (torch.clamp(out[0][fg], 0, 1) - target[fg]).abs().mean()
+        loss.backward(); opt.step()
+        with torch.no_grad():
+            env.clamp_(min=0.01)
+        return loss
+    step(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        last = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"config": "BASELINE configs[2]: stage-1 training step, 800x800, 32 spp, forward + backward (direct-lighting terms) + Adam, LBVH rebuild per step",
+            "ms_per_step": round(dt * 1e3, 2), "steps": steps, "warmup": 1, "msamples_per_s": round(N * 32 / dt / 1e6, 1), "loss_finite": bool(torch.isfinite(last).item())}
+
+
 def main():
     args = parse()
     import numpy as np
@@ -112,49 +260,47 @@ def main():
     import mirres_restir_nerf_mesh_amd as M
     from mirres_restir_nerf_mesh_amd import renderer_restir as RR, harness, dist as MD
     from mirres_restir_nerf_mesh_amd._ops import get_ctx
-    from mirres_restir_nerf_mesh_amd.render_helper import MLPTexture3D
     S = M.scene
     dev = torch.device("cuda", local)
 
-    # ---- synthetic scene of BASELINE config 2's shape
-    v, t = S.make_mesh(args.subdiv, 64 if args.subdiv >= 6 else 16)
-    W = RR.restirbvhWorker(torch.from_numpy(v).to(dev), torch.from_numpy(t).to(dev))
-    W.update_mesh(W.vrt, W.v_ind)
-    mlp = None
-    if not args.const_material:
-        params, w0, w1, w2 = S.make_matnet_params(seed=0)
-        mn, mx = S.material_min_max()
-        mlp = MLPTexture3D(torch.tensor([-1, -1, -1, 1, 1, 1], dtype=torch.float32), channels=6, min_max=(torch.from_numpy(mn).to(dev), torch.from_numpy(mx).to(dev)))
-        with torch.no_grad():
-            mlp.encoder.params.copy_(torch.from_numpy(params).to(dev))
-            for i, w in zip((0, 2, 4), (w0, w1, w2)):
-                mlp.net.net[i].weight.copy_(torch.from_numpy(w).to(dev))
-    g = harness.build_gbuffer(W, args.res, args.res, args.ssaa, mlp_mat=mlp)
+    # ---- synthetic scene of BASELINE config 2's size
+    def scene_for(mesh_name):
+        v, t = S.mesh_by_name(mesh_name, args.subdiv)
+        W = RR.restirbvhWorker(torch.from_numpy(v).to(dev), torch.from_numpy(t).to(dev))
+        W.update_mesh(W.vrt, W.v_ind)
+        mlp = None if args.const_material else make_field(S, torch, dev)
+        g = harness.build_gbuffer(W, args.res, args.res, args.ssaa, mlp_mat=mlp)
+        return t, W, mlp, g
+    t, W, mlp, g = scene_for(args.mesh)
     env = torch.from_numpy(S.make_env(256, 512)).to(dev)
     fx, fy = g["fx"], g["fy"]
     ctx = get_ctx(fx, fy, max_bounce=args.bounces)
     ctx.reserve()                       # the batch pool is sized here, not inside the first frame
     N = fx * fy
 
-    def step(scheme):
-        W.update_mesh(W.vrt, W.v_ind)                                   # LBVH rebuilt every frame (nerf/renderer.py:975)
-        if world > 1 and scheme == "strips":          # exact: row strips + per-sample halo exchange + all-gather of the raw sums (dist.py)
-            return MD.render_strips(ctx, W, mlp, env, g, args.spp, 12345, rank, world, max_bounce=args.bounces)
-        return MD.render_sharded(ctx, W, mlp, env, g, args.spp, 12345, rank, world)
+    def make_step(W_, mlp_, g_):
+        def step(scheme):
+            W_.update_mesh(W_.vrt, W_.v_ind)                                   # LBVH rebuilt every frame (nerf/renderer.py:975)
+            if world > 1 and scheme == "strips":          # exact: row strips + per-sample halo exchange + all-gather of the raw sums (dist.py)
+                return MD.render_strips(ctx, W_, mlp_, env, g_, args.spp, 12345, rank, world, max_bounce=args.bounces)
+            return MD.render_sharded(ctx, W_, mlp_, env, g_, args.spp, 12345, rank, world)
+        return step
+    step = make_step(W, mlp, g)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(scheme):
+    def timed(scheme, step_fn=None, warmup=None, steps=None):
         """W untimed warm-up steps, then exactly K steps between barrier + synchronize on both sides; MAX over ranks."""
-        for _ in range(args.warmup):
-            step(scheme)
+        step_fn = step_fn or step
+        for _ in range(args.warmup if warmup is None else warmup):
+            step_fn(scheme)
         barrier()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            o = step(scheme)
+        for _ in range(args.steps if steps is None else steps):
+            o = step_fn(scheme)
         barrier()
         d = time.perf_counter() - t0
         if world > 1:
@@ -184,64 +330,16 @@ def main():
     primary = schemes[0]
     dt, out = results[primary]
     value = samples / dt / 1e6
+    step_ms = dt / args.steps * 1e3
 
     # ---- rooflines, measured live with HIP events on the launch stream (rank 0): the dominant kernel (shadow-ray traversal), the ordered
     #      closest-hit traversal, and the material MLP's GEMM phase
     roof = None
+    pmc = pmc_snapshot() if rank == 0 else None
     if rank == 0 and not args.no_roofline:
         b, e = MD.spp_slice(args.spp, rank, world)
         prof_spp = max(1, min(8, e - b))
-        def frame(n):
-            occ = g["occ"].clone()
-            RR.render_fused(ctx, W, mlp, False, (1, 1, 1), env, occ, g["normal"], g["depth"], g["kd"], g["rm"], g["ray_dir"], g["pos"], n, 2, 2, 2.0, 0.1, 0.001, 12345)
-        # (a) visit counts of exactly these rays (deterministic; untimed): the production kernels' own (64-byte records they fetch) and, for the
-        #     reference-equivalent figure, the reference traversal's (bvh_hit's order, no early exit) on the same ray set
-        ctx.set_instrument(5); ctx.stats(reset=True); frame(prof_spp); st = ctx.stats(reset=True)
-        ctx.set_instrument(1); ctx.stats(reset=True); frame(prof_spp); own = ctx.stats(reset=True)
-        # (b) event-timed launches of the production kernels on the same rays
-        ctx.set_instrument(2); ctx.trace_time(); frame(prof_spp); ms_any, n_any, ms_cl, n_cl = ctx.trace_time()
-        ctx.set_instrument(0)
-        rays_any, rays_cl = st["rays_any"], st["rays_closest"]
-        total_rays = rays_any + rays_cl
-        # ALGORITHMIC bytes of the kernel as built: every 64-byte node / leaf record the traversal has to read for its answer
-        # (counted by the instrumented kernel on these very rays) + the 32-byte ray + the result (4 B hit flag; 28 B hit record for the closest hit).
-        # (the spatial pass's rays reach the kernel as 8-byte pixel pairs and are formed there from two 16-byte gathers: 40 B requested, accounted as 32 B like the others)
-        own_bytes_any = 64.0 * own["entered"] + rays_any * (32 + 4)
-        own_bytes_cl = 64.0 * own["cl_entered"] + rays_cl * (32 + 28)
-        # SURVEY section 8d's accounting (reference node layout, reference traversal's visit counts): what the REFERENCE's bvh_hit would have to move
-        # for the same rays — kept as `reference_equiv`, not as the roofline (the production kernel does not do that work: early exit, 4-wide tree)
-        ref_bytes_any = 24.0 * st["popped"] + 24.0 * st["entered"] + 48.0 * st["leaves"] + rays_any * (24 + 12 + 4)
-        sec_any, sec_cl = ms_any * 1e-3, ms_cl * 1e-3
-        achieved = own_bytes_any / sec_any / 1e9 if sec_any > 0 else 0.0
-        achieved_cl = own_bytes_cl / sec_cl / 1e9 if sec_cl > 0 else 0.0
-        HBM, L2 = 8000.0, 34500.0       # GB/s: MI355X_MICROARCH.md (HBM3E spec peak; aggregate L2 of the eight XCDs)
-        pmc = {}
-        for fn_ in ("r03_pmc_any4q_summary.json", "pmc_traffic.json"):
-            try:
-                pmc.update(json.load(open(os.path.join(ROOT, "profiles", fn_))))
-            except Exception:
-                pass
-        roof = {"bound": "hbm", "kernel": "k_trace_any4q (shadow-ray BVH traversal)", "achieved": round(achieved, 2), "peak": HBM, "unit": "GB/s",
-                "frac": round(achieved / HBM, 5), "traffic": pmc.get("k_trace_any_hbm_bytes_per_launch"),
-                "bytes_per_ray": round(own_bytes_any / max(1, rays_any), 1), "launch_ms": round(ms_any / max(1, n_any), 4), "launches": n_any,
-                "rays_per_launch": round(rays_any / max(1, n_any)), "grays_per_s": round(rays_any / sec_any / 1e9, 3) if sec_any > 0 else 0.0,
-                "traffic_over_own_bytes": (round(pmc["k_trace_any_hbm_bytes_per_launch"] / (own_bytes_any / max(1, n_any)), 3) if pmc.get("k_trace_any_hbm_bytes_per_launch") else None),
-                "l2_peak": L2, "l2_frac": round(achieved / L2, 5),
-                "binding": "valu-issue", "valu_busy": pmc.get("valu_busy"), "lane_util": pmc.get("lane_util"), "l1_hit": pmc.get("l1_hit"),
-                "reference_equiv": {"bytes_per_ray": round(ref_bytes_any / max(1, rays_any), 1), "tbps": round(ref_bytes_any / sec_any / 1e12, 2) if sec_any > 0 else 0.0,
-                                    "note": "SURVEY 8d accounting: reference node layout x the reference traversal's visit counts on the same rays / this kernel's time"},
-                "note": "achieved = bytes the kernel's own algorithm has to move (64-B records visited + ray + result, counted on the timed rays) / event-timed duration, against the HBM "
-                        "peak as the contract asks; the 43 MB layout is cache resident (traffic = HBM bytes per launch from PMC — the spatial pass's pixel records and reservoirs gathered at the refill, "
-                        "ray queues, results — `traffic_over_own_bytes` of the accounted bytes; 88 % L1 hits), so the "
-                        "binding resource is VALU issue, not bandwidth: valu_busy = SQ_ACTIVE_INST_VALU / SIMD cycles, lane_util = active lanes per issued VALU instruction "
-                        "(profiles/r03_pmc_any4q_summary.json)",
-                "closest": {"kernel": "k_trace_closest4 (+ reference-order redo)", "achieved": round(achieved_cl, 2), "peak": HBM, "unit": "GB/s", "frac": round(achieved_cl / HBM, 5),
-                            "bytes_per_ray": round(own_bytes_cl / max(1, rays_cl), 1), "launch_ms": round(ms_cl / max(1, n_cl), 4), "launches": n_cl,
-                            "grays_per_s": round(rays_cl / sec_cl / 1e9, 3) if sec_cl > 0 else 0.0},
-                "rays_per_pixel_sample": round(total_rays / (float(N) * prof_spp), 3),
-                "per_ray": {"any_reference": [round(st[k] / max(1, rays_any), 2) for k in ("popped", "entered", "leaves")], "any_production": [round(own[k] / max(1, rays_any), 2) for k in ("popped", "entered", "leaves")],
-                            "closest": [round(own[k] / max(1, rays_cl), 2) for k in ("cl_popped", "cl_entered", "cl_leaves")]},
-                "traversal_share_of_step": round((ms_any + ms_cl) / prof_spp * args.spp / (dt / args.steps * 1e3) * (world if world > 1 else 1), 3)}
+        roof = traversal_roofline(args, ctx, W, mlp, env, g, prof_spp, step_ms, world, pmc)
         if mlp is not None:
             # material MLP, GEMM phase alone (mirres_matnet_mlp on precomputed encodings of N points): 4 480 flop per point
             gen = torch.Generator(device=dev).manual_seed(0)
@@ -254,9 +352,37 @@ def main():
             e1.record(); torch.cuda.synchronize()
             ms_mlp = e0.elapsed_time(e1) / 20
             tf = 4480.0 * N / (ms_mlp * 1e-3) / 1e12
+            cnt = (pmc or {}).get("counters") or {}
             roof["mlp"] = dict(MLP_ROOF, kernel="k_mlp_mfma (material MLP, GEMM phase)", achieved=round(tf, 2), unit="TFLOP/s", frac=round(tf / MLP_ROOF["peak"], 5),
-                               issued_frac=round(tf * 6144.0 / 4480.0 / MLP_ROOF["peak"], 5), launch_ms=round(ms_mlp, 4), points=N, mfma_busy=pmc.get("mlp_mfma_busy"))
+                               issued_frac=round(tf * 6144.0 / 4480.0 / MLP_ROOF["peak"], 5), launch_ms=round(ms_mlp, 4), points=N,
+                               mfma_busy=None if cnt.get("stale") else cnt.get("mlp_mfma_busy"))
+
+    # ---- sub-records of the default single-GPU run: the other mesh (same frame, same counters), the configs[2] training step
+    extras = {}
+    if rank == 0 and world == 1 and not args.no_extras:
+        other = "clustered" if args.mesh == "icosphere" else "icosphere"
+        try:
+            t2, W2, mlp2, g2 = scene_for(other)
+            d2, o2 = timed("spp", make_step(W2, mlp2, g2), warmup=1, steps=1)
+            fg2 = float((g2["occ"][:, 0] > 0.5).float().mean().item())
+            rec = {"mesh": other, "triangles": int(len(t2)), "value": round(float(N) * args.spp / d2 / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(d2 * 1e3, 2), "steps": 1, "warmup": 1,
+                   "foreground_frac": round(fg2, 4), "foreground_msamples_per_s": round(float(N) * args.spp * fg2 / d2 / 1e6, 3), "finite": bool(torch.isfinite(o2[0]).all().item())}
+            if not args.no_roofline:
+                args_o = argparse.Namespace(**vars(args)); args_o.mesh = other
+                r2 = traversal_roofline(args_o, ctx, W2, mlp2, env, g2, 8 if args.spp >= 8 else args.spp, d2 * 1e3, 1, None)
+                rec["traversal"] = {k: r2[k] for k in ("launch_ms", "launches", "rays_per_launch", "grays_per_s", "per_ray", "rays_per_pixel_sample", "private_stack_deepest", "traversal_share_of_step")}
+                rec["traversal"]["own_bytes_per_ray"] = r2["own_bytes"]["bytes_per_ray"]; rec["traversal"]["closest"] = r2["closest"]
+            extras[other] = rec
+            del W2, mlp2, g2
+        except Exception as e_:      # noqa: BLE001 — a sub-record must not take the line with it
+            extras[other] = {"error": "%s: %s" % (type(e_).__name__, str(e_)[:300])}
+        try:
+            extras["train_step"] = train_step_record(S, torch, dev, W)
+        except Exception as e_:      # noqa: BLE001
+            extras["train_step"] = {"error": "%s: %s" % (type(e_).__name__, str(e_)[:300])}
+
     cpu = None
+    parity_failed = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu, cf = cpu_baseline(S, args)
         # the same small frame (same inputs, seed and sample count) through the HIP path: the PSNR half of BASELINE's metric, against the CPU oracle
@@ -268,25 +394,36 @@ def main():
         mse = float(np.mean((np.clip(got_small, 0, 1) - np.clip(want_small, 0, 1)) ** 2))
         cpu["psnr_hip_vs_oracle_db"] = round(-10.0 * float(np.log10(max(mse, 1e-20))), 2)
         cpu["max_abs_err"] = float(err.max()); cpu["frac_within_1e-3"] = float((err <= 1e-3).mean()); cpu["frac_bit_equal"] = float((err == 0).mean())
-        # the north-star's parity bar on the benched workload: every pixel of the small frame within 1e-3 per channel of the CPU oracle
-        assert cpu["max_abs_err"] <= 1e-3, "bench: HIP frame differs from the CPU oracle by %.3e (> 1e-3)" % cpu["max_abs_err"]
+        # the north-star's parity bar on the benched workload: every pixel of the small frame within 1e-3 per channel of the CPU oracle. A failure is
+        # reported IN the line (and by the exit code), not instead of it
+        if not cpu["max_abs_err"] <= 1e-3:
+            parity_failed = "HIP frame differs from the CPU oracle by %.3e (> 1e-3) on the %dx%d x %d spp sample" % (cpu["max_abs_err"], cf["fx"], cf["fy"], cf["spp"])
 
     if rank == 0:
         fc = out[0]
+        fgm = g["occ"][:, 0] > 0.5
+        fg_frac = float(fgm.float().mean().item())
         par = {"spp": "sample slices + one all-reduce of the six accumulators (statistically equivalent frame)",
                "strips": "row strips + per-sample reservoir halo exchange + all-gather of radiance rows (bit-identical to one GPU)"}
+        mesh_words = {"icosphere": "lego-SIZED synthetic mesh (noise-displaced icosphere + ground, uniformly tessellated: SURVEY 8d)",
+                      "clustered": "lego-LIKE synthetic mesh (brick assembly: studs, cavities, thin plates, triangle areas spread > 1e5 : 1)"}[args.mesh]
         line = {"metric": "Msamples/s (pixels x spp), ReSTIR-DI + %d-bounce path tracing forward render" % (args.bounces + 1),
                 "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+                "ms_per_step": round(step_ms, 2), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
                 "data": "synthetic",
-                "config": {"workload": "BASELINE metric frame (configs[1] geometry at the metric's 512 spp): TensoIR-lego-shaped synthetic mesh (T=%d), %dx%d output, ssaa %d (internal %dx%d), "
+                "config": {"workload": "BASELINE metric frame (configs[1] geometry at the metric's 512 spp): %s, T=%d, %dx%d output, ssaa %d (internal %dx%d), "
                                        "%d spp, %d indirect bounces (3-bounce paths) + ReSTIR (initial/temporal/spatial), LBVH rebuild per frame, %s, EAW denoise"
-                                       % (len(t), args.res, args.res, args.ssaa, fx, fy, args.spp, args.bounces, "constant material" if args.const_material else "hash-grid+MLP material field"),
-                           "internal_pixels": N, "spp": args.spp, "triangles": int(len(t)),
+                                       % (mesh_words, len(t), args.res, args.res, args.ssaa, fx, fy, args.spp, args.bounces, "constant material" if args.const_material else "hash-grid+MLP material field"),
+                           "mesh": args.mesh, "internal_pixels": N, "spp": args.spp, "triangles": int(len(t)),
                            "parallelism": ("%s x%d" % (par[primary], world)) if world > 1 else "single GPU",
                            "output_pixel_msamples_per_s": round(args.res * args.res * args.spp * args.steps / dt / 1e6, 3),
-                           "finite": bool(torch.isfinite(fc).all().item()), "mean_radiance": round(float(fc[g["occ"][:, 0] > 0.5].mean().item()), 5)},
+                           # the metric counts every pixel of the frame; background pixels cost almost nothing, so the number scales with coverage:
+                           "foreground_frac": round(fg_frac, 4), "foreground_msamples_per_s": round(value * fg_frac, 3),
+                           "finite": bool(torch.isfinite(fc).all().item()), "mean_radiance": round(float(fc[fgm].mean().item()), 5)},
                 "roofline": roof, "cpu_baseline": cpu}
+        line.update(extras)
+        if parity_failed:
+            line["parity_failed"] = parity_failed
         for sc in schemes[1:]:            # the other sharding scheme, timed the same way in the same run
             d2, e2 = results[sc]
             if d2 is None:
@@ -296,6 +433,8 @@ def main():
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    if parity_failed:
+        raise SystemExit("bench: " + parity_failed)
 
 
 if __name__ == "__main__":

@@ -209,7 +209,7 @@ def read_checkpoint(path, map_location="cpu"):
     top = ck if isinstance(ck, dict) and "model" in ck else {}
     return dict(vertices_offsets=f32(model.get("vertices_offsets")), grid_params=f32(grid), mlp_weights=[f32(w) for w in ws] if all(have) else None,
                 light_base=f32(top.get("light_base")), epoch=top.get("epoch"), global_step=top.get("global_step"), stage=top.get("stage"),
-                material_config=top.get("material_config"), train_state={k: top[k] for k in TRAIN_STATE_KEYS if k in top})
+                material_config=top.get("material_config"), train_state=_train_state_of(top))
 
 
 def apply_checkpoint(ck, mlp_mat=None, n_vertices=None, device="cuda"):
@@ -233,7 +233,19 @@ def apply_checkpoint(ck, mlp_mat=None, n_vertices=None, device="cuda"):
     return to(voff), to(ck["light_base"])
 
 
-TRAIN_STATE_KEYS = ("optimizer", "lr_scheduler", "optimizer_mat", "optimizer_light", "lr_scheduler_mat", "lr_scheduler_light")
+# Trainer.save_checkpoint(full=True) writes exactly these names (nerf/utils.py:1856-1867) and load_checkpoint reads them back (:1966-2022);
+# `scaler` / `ema` are not produced here (no AMP scaler, no EMA on this path) and are ignored on read.
+def _train_state_of(top):
+    ts = {k: top[k] for k in TRAIN_STATE_KEYS if k in top}
+    for old, new in _LEGACY_TRAIN_STATE_KEYS.items():
+        if old in top and new not in ts:
+            ts[new] = top[old]
+    return ts
+
+
+TRAIN_STATE_KEYS = ("optimizer", "lr_scheduler", "optimizer_mat", "optimizer_light", "scheduler_mat", "scheduler_light")
+# names this package wrote before round 4 (never understood by the reference); accepted on read only
+_LEGACY_TRAIN_STATE_KEYS = {"lr_scheduler_mat": "scheduler_mat", "lr_scheduler_light": "scheduler_light"}
 
 
 def save_checkpoint(path, mlp_mat, vertices_offsets, light_base, epoch=0, global_step=0, stage=1, material_config=None, train_state=None):
@@ -241,8 +253,8 @@ def save_checkpoint(path, mlp_mat, vertices_offsets, light_base, epoch=0, global
     top-level key the reference's loader ignores: `material_config` (the AABB / output-range constants the field was trained with, read back from the
     module when not given) so that an evaluation of this file cannot silently decode it with another run's `--bound` / `--me_max`.
     `train_state` (a `full=True` checkpoint, :1856-1866): state dicts under the reference's keys `optimizer`, `lr_scheduler`, `optimizer_mat`,
-    `optimizer_light` (+ `lr_scheduler_mat` / `lr_scheduler_light`: the reference keeps those two schedules in closures that it rebuilds from the step
-    count; here they are LambdaLR objects) so that a resumed run continues the Adam moments and the learning-rate schedules where they were."""
+    `optimizer_light`, `scheduler_mat`, `scheduler_light` (LambdaLR state dicts, :1863-1867) so that a resumed run — here or through the reference's own
+    `load_checkpoint` (:2003-2022) — continues the Adam moments and the learning-rate schedules where they were."""
     if material_config is None:
         lo, hi = (t.detach().cpu().tolist() for t in mlp_mat.AABB)
         mn, mx = (t.detach().cpu().tolist() for t in mlp_mat.min_max)

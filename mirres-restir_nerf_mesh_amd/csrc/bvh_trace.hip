@@ -373,7 +373,7 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_persist(BvhView B, con
             }
         } while (__popcll(__ballot(have)) >= MR_REFILL || (exhausted && __ballot(have)));
     }
-    if (stats && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[ANY ? 0 : 1], (unsigned long long)n);
+    if (stats && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[redo ? 10 : (ANY ? 0 : 1)], (unsigned long long)n);   // [10]: rays the ordered fast path handed back
 }
 
 
@@ -383,6 +383,14 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_persist(BvhView B, con
 // fmin/fmax unions and (b - o) * inv is monotone in b under IEEE rounding), hence (2) any visiting order and any pruning by ancestor
 // boxes yields the same boolean. The stack holds bare 4-byte references in LDS (16 per lane, scratch beyond); no pop-time re-test is needed.
 #define MR_ANY_LDS 16
+// Depth of the shadow-ray kernel's private stack (LDS part + scratch). A 4-wide node defers at most three references and the 4-wide collapse is never
+// deeper than the LBVH it was collapsed from, whose depth is bounded by the bits of the augmented sort key: 30 Morton bits + ceil(log2 T) position bits
+// (lbvh_hierarchy.slang:40-60: every internal node splits its range at the highest differing bit of (code, position)). Hence at most
+// 3 * (30 + ceil(log2 T)) entries: 147 for T < 2^19, 183 for any T < 2^31 — MR_ANY_STACK = 192 cannot overflow ("Stack bounds").
+// (The reference's own stack of 64 {index, left, right, prim} entries, helperDi.slang:136, holds at most depth + 1 <= 62 entries: it cannot overflow either.)
+#ifndef MR_ANY_STACK
+#define MR_ANY_STACK 192
+#endif
 #define MR_TOPBIT 0x20000000
 // ---------------------------------------------------------------- shadow rays on the COMPRESSED 4-wide collapse (engine.hpp Node4q / LeafRec)
 // The any-hit bit is the OR over leaves whose own box passes the slab test (above); interior boxes only steer the search and may be any
@@ -501,8 +509,8 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const
     RayCons rc; rc.mx = rc.my = rc.mz = 0.f;
     const float scene_bs = scene_bound(B.root_box);
     int cur = 0, sp = 0, sbase = 0; uint32_t ridx = 0;   // the lane's deferred entries live in [sbase, sp)
-    uint32_t spill[MR_STACK - MR_ANY_LDS];
-    unsigned long long c_boxes = 0, c_nodes = 0, c_leaves = 0;
+    uint32_t spill[MR_ANY_STACK - MR_ANY_LDS];
+    unsigned long long c_boxes = 0, c_nodes = 0, c_leaves = 0; int c_maxsp = 0;
     MR_PH(long long ph_refill = 0; long long ph_mem = 0; long long ph_cmp = 0; long long ph_iters = 0; const long long ph_begin = MR_PH_NOW();)
     while (true) {
         MR_PH(const long long ph_a = MR_PH_NOW();)
@@ -646,8 +654,9 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const
                                 int far = ref[k];
                                 if (tn < next_tn) { far = next; next = ref[k]; next_tn = tn; }   // keep the nearest (node or leaf) for the immediate descent
                                 if (sp < MR_ANY_LDS) lds_stack[sp * MR_TRACE_BLOCK] = (uint32_t)far;
-                                else if (sp < MR_STACK) spill[sp - MR_ANY_LDS] = (uint32_t)far;
-                                if (sp < MR_STACK) sp++;
+                                else if (sp < MR_ANY_STACK) spill[sp - MR_ANY_LDS] = (uint32_t)far;
+                                if (sp < MR_ANY_STACK) sp++;
+                                else if (stats) atomicAdd(&stats[11], 1ull);    // cannot happen (bound above); were it to, it is not silent: mirres_ctx_stats()[11]
                             }
                         }
                     }
@@ -659,6 +668,7 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const
                     else if (sp > sbase) { --sp; cur = (int)((sp < MR_ANY_LDS) ? lds_stack[sp * MR_TRACE_BLOCK] : spill[sp - MR_ANY_LDS]); }
                     else done = true;
                 }
+                if (COUNT) c_maxsp = sp > c_maxsp ? sp : c_maxsp;
                 if (done) { have = false; if (hit) hit_out[ridx] = 1; }
             }
             MR_PH(ph_mem += ph_1 - ph_0; ph_cmp += MR_PH_NOW() - ph_1;)
@@ -670,7 +680,7 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const
 #endif
     MR_PH(if (B.dbg && (threadIdx.x & 63) == 0) { unsigned long long* o = B.dbg + 5 * (blockIdx.x * (MR_TRACE_BLOCK / 64) + (threadIdx.x >> 6));
             o[0] = (unsigned long long)(MR_PH_NOW() - ph_begin); o[1] = (unsigned long long)ph_refill; o[2] = (unsigned long long)ph_mem; o[3] = (unsigned long long)ph_cmp; o[4] = (unsigned long long)ph_iters; })
-    if (COUNT && stats) { atomicAdd(&stats[2], c_boxes); atomicAdd(&stats[3], c_nodes); atomicAdd(&stats[4], c_leaves); }
+    if (COUNT && stats) { atomicAdd(&stats[2], c_boxes); atomicAdd(&stats[3], c_nodes); atomicAdd(&stats[4], c_leaves); atomicMax(&stats[8], (unsigned long long)c_maxsp); }
     if (stats && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[0], (unsigned long long)n);
 }
 
@@ -713,7 +723,7 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_closest4(BvhView B, co
     const int NONE = 0x7fffffff;
     int cur = NONE, sp = 0, best_slot = -1; uint32_t ridx = 0; bool any_hit = false, need_redo = false;
     uint2 spill[MR_STACK - MR_LDS_STACK];
-    unsigned long long c_boxes = 0, c_nodes = 0, c_leaves = 0;
+    unsigned long long c_boxes = 0, c_nodes = 0, c_leaves = 0; int c_maxsp = 0;
     while (true) {
         const uint64_t need = __ballot(!have);
         if (need && !exhausted) {
@@ -830,9 +840,10 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_closest4(BvhView B, co
                                     uint2 e; e.x = (uint32_t)nref[q]; e.y = __float_as_uint(ntn[q]);
                                     if (sp < MR_LDS_STACK) lds_stack[sp * MR_TRACE_BLOCK] = e;
                                     else if (sp < MR_STACK) spill[sp - MR_LDS_STACK] = e;
-                                    if (sp < MR_STACK) sp++; else need_redo = true;
+                                    if (sp < MR_STACK) sp++; else need_redo = true;   // a full stack hands the ray to the reference-order kernel, whose stack cannot overflow
                                 }
                             }
+                            if (COUNT) c_maxsp = sp > c_maxsp ? sp : c_maxsp;
                         }
                     }
                 }
@@ -858,7 +869,7 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_closest4(BvhView B, co
             if (prim_out) prim_out[ridx] = pr;
         }
     }
-    if (COUNT && stats) { atomicAdd(&stats[5], c_boxes); atomicAdd(&stats[6], c_nodes); atomicAdd(&stats[7], c_leaves); }
+    if (COUNT && stats) { atomicAdd(&stats[5], c_boxes); atomicAdd(&stats[6], c_nodes); atomicAdd(&stats[7], c_leaves); atomicMax(&stats[9], (unsigned long long)c_maxsp); }
     if (stats && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[1], (unsigned long long)n);
 }
 
@@ -881,7 +892,7 @@ static int closest_fast(mirres_bvh* bvh, const Ray* rays, const uint32_t* d_coun
     MR_HIP(hipMemsetAsync(w, 0, 3 * MR_WSET * sizeof(uint32_t), s));
     k_trace_closest4<COUNT><<<persist_grid(capacity), MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, d_count, (uint32_t)capacity, w, rec, hit, t, pos, nrm, prim,
                                                                                bvh->redo[alt], w + MR_WSET, stats);
-    k_trace_persist<false><<<256, MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, w + MR_WSET, 0u, w + 2 * MR_WSET, hit, rec, t, pos, nrm, prim, nullptr, bvh->redo[alt]);
+    k_trace_persist<false><<<256, MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, w + MR_WSET, 0u, w + 2 * MR_WSET, hit, rec, t, pos, nrm, prim, COUNT ? stats : nullptr, bvh->redo[alt]);
     MR_LAUNCH_CHECK("closest_fast");
     return 0;
 }
@@ -1018,6 +1029,22 @@ extern "C" int mirres_bvh_trace(mirres_bvh_t* bvh, const float* rays, int n, int
         }
     }
     MR_LAUNCH_CHECK("mirres_bvh_trace");
+    return MIRRES_OK;
+}
+
+// development aid (not part of include/mirres.h): the PRODUCTION shadow-ray kernel in its counting build on n rays -> hit[n] and h_stats u64[12] in the layout of
+// mirres_ctx_stats ([0] rays, [2..4] box tests / 64-byte records fetched / leaves tested, [8] deepest private stack, [11] stack overflows). Synchronises.
+extern "C" int mirres_debug_any_stats(mirres_bvh_t* bvh, const float* rays, int n, int32_t* hit, unsigned long long* h_stats, void* stream) {
+    if (!bvh || !rays || !hit || !h_stats || n <= 0 || bvh->T < 2) return MIRRES_E_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    unsigned long long* d = nullptr;
+    MR_HIP(hipMalloc(&d, 12 * sizeof(unsigned long long)));
+    MR_HIP(hipMemsetAsync(d, 0, 12 * sizeof(unsigned long long), s));
+    MR_HIP(hipMemsetAsync(bvh->work + 2 * MR_WSET, 0, MR_WSET * sizeof(uint32_t), s));
+    launch_any4q<true>(bvh, persist_grid((size_t)n), reinterpret_cast<const Ray*>(rays), nullptr, (uint32_t)n, bvh->work + 2 * MR_WSET, hit, d, s);
+    MR_HIP(hipStreamSynchronize(s));
+    MR_HIP(hipMemcpy(h_stats, d, 12 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    MR_HIP(hipFree(d));
     return MIRRES_OK;
 }
 

@@ -114,7 +114,7 @@ struct mirres_ctx {
     // frame buffers of the fused loop (mirres_render)
     float* pool = nullptr; size_t pool_floats = 0;
     // K-sample batch of the path-tracing stages (mirres_render): queues + per-slot state for K * N sample slots
-    char* ptb = nullptr; size_t ptb_bytes = 0; int ptb_kcap = 0, ptb_kcap_age = 0;   // ptb_kcap: largest batch the device could hold when an allocation last fell back (0 = never)
+    char* ptb = nullptr; size_t ptb_bytes = 0; int ptb_kcap = 0, ptb_kcap_age = 0, ptb_retry_wait = 64;   // ptb_kcap: largest batch the device could hold when an allocation last fell back (0 = never); clamped frames between speculative retries
     int y_off = 0, full_fy = 0;     // strip sharding (mirres_render): global row of local row 0 and the global height; full_fy == 0: the frame is the whole image
     const float* occ_own = nullptr; // strip sharding: occupancy with the halo rows zeroed (own-pixel tests of the spatial pass); NULL otherwise
     const float* grec = nullptr;    // set by mirres_render for the duration of a frame: packed 64-byte G records for the neighbour gathers of k_spatial_resolve

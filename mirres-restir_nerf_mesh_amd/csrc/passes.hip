@@ -784,9 +784,9 @@ int mirres_ctx_create(mirres_ctx_t** out, int fx, int fy, const mirres_config_t*
     MR_HIP(hipMalloc(&c->cl_rays, sizeof(Ray) * c->cl_cap));
     MR_HIP(hipMalloc(&c->cl_hit, sizeof(HitRec) * c->cl_cap));
     MR_HIP(hipMalloc(&c->counters, sizeof(uint32_t) * 8));
-    MR_HIP(hipMalloc(&c->stats, sizeof(unsigned long long) * 8));
+    MR_HIP(hipMalloc(&c->stats, sizeof(unsigned long long) * 12));
     MR_HIP(hipMemset(c->counters, 0, sizeof(uint32_t) * 8));
-    MR_HIP(hipMemset(c->stats, 0, sizeof(unsigned long long) * 8));
+    MR_HIP(hipMemset(c->stats, 0, sizeof(unsigned long long) * 12));
     MR_HIP(hipMalloc(&c->slot_a, sizeof(int32_t) * N));
     MR_HIP(hipMalloc(&c->mask_a, sizeof(uint32_t) * N));
     MR_HIP(hipMalloc(&c->slot_c, sizeof(int32_t) * N));
@@ -828,8 +828,8 @@ int mirres_neighbor_offsets(mirres_ctx_t* ctx, float* out, void* stream) {
 int mirres_ctx_stats(mirres_ctx_t* ctx, uint64_t* h_out, int reset) {
     if (!ctx || !h_out) { set_error("mirres_ctx_stats: null"); return MIRRES_E_ARG; }
     MR_HIP(hipDeviceSynchronize());
-    MR_HIP(hipMemcpy(h_out, ctx->stats, sizeof(unsigned long long) * 8, hipMemcpyDeviceToHost));
-    if (reset) MR_HIP(hipMemset(ctx->stats, 0, sizeof(unsigned long long) * 8));
+    MR_HIP(hipMemcpy(h_out, ctx->stats, sizeof(unsigned long long) * 12, hipMemcpyDeviceToHost));
+    if (reset) MR_HIP(hipMemset(ctx->stats, 0, sizeof(unsigned long long) * 12));
     return MIRRES_OK;
 }
 int mirres_ctx_set_instrument(mirres_ctx_t* ctx, int on) { if (!ctx) return MIRRES_E_ARG; ctx->instrument = on; return MIRRES_OK; }

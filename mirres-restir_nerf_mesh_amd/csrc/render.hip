@@ -215,15 +215,32 @@ static int carve_batch(mirres_ctx* ctx, int N, int K, int max_bounce, size_t TS,
              + 4 * al(4 * 8 * NV) + al(4 * 3 * (size_t)k * TS) + al(4 * (size_t)k * TS) + al(32 * (size_t)k * TS)
              + 2 * (al(sizeof(Ray) * NV) + 2 * al(4 * NV) + al(64));
     };
-    // A request the device could not hold last time is not repeated every frame (each retry costs a device synchronisation, a free of the working
-    // pool and a failing multi-GB hipMalloc): the batch size that fitted is remembered and later requests are clamped to it.
-    // The clamp is not for ever: a transient shortage (another tenant of the HBM) must not pin a long run to small batches, so every 64th clamped
-    // request — or as soon as hipMemGetInfo shows the full request would fit beside the working pool — the full size is tried again.
+    // A request the device could not hold last time is not repeated every frame (a failing multi-GB hipMalloc per frame): the batch size that fitted is
+    // remembered and later requests are clamped to it. The clamp is not for ever — a transient shortage (another tenant of the HBM) must not pin a long
+    // run to small batches — but a retry is SPECULATIVE: after `ptb_retry_wait` clamped frames, and only if hipMemGetInfo says the full request fits
+    // BESIDE the working pool (and under MIRRES_POOL_LIMIT_MB), the larger pool is allocated next to the working one, which is given up only once the
+    // new one exists. A retry that fails anyway (fragmentation) doubles the wait (64, 128, ... 4096 frames), so a device that stays full costs one
+    // failed hipMalloc per ever-longer interval, never a synchronisation, a free or a memset of the working pool.
+    const char* lim_s0 = getenv("MIRRES_POOL_LIMIT_MB"); const size_t lim0 = lim_s0 ? (size_t)atoll(lim_s0) << 20 : 0;
     if (ctx->ptb_kcap > 0 && K > ctx->ptb_kcap) {
-        size_t fr = 0, tot = 0;
-        const bool roomy = hipMemGetInfo(&fr, &tot) == hipSuccess && fr + ctx->ptb_bytes > bytes_for(K) + (1ull << 30);
-        if (roomy || ++ctx->ptb_kcap_age >= 64) { ctx->ptb_kcap = 0; ctx->ptb_kcap_age = 0; }
-        else K = ctx->ptb_kcap;
+        const size_t want = bytes_for(K);
+        bool grown = false;
+        if (++ctx->ptb_kcap_age >= ctx->ptb_retry_wait) {
+            ctx->ptb_kcap_age = 0;
+            size_t fr = 0, tot = 0;
+            const bool roomy = !(lim0 && want > lim0) && hipMemGetInfo(&fr, &tot) == hipSuccess && fr > want + (1ull << 30);
+            char* fresh = nullptr;
+            if (roomy && hipMalloc(&fresh, want) == hipSuccess) {
+                if (ctx->ptb) { MR_HIP(hipDeviceSynchronize()); MR_HIP(hipFree(ctx->ptb)); }
+                ctx->ptb = fresh; ctx->ptb_bytes = want;
+                MR_HIP(hipMemset(ctx->ptb, 0, want));
+                ctx->ptb_kcap = 0; ctx->ptb_retry_wait = 64; grown = true;
+            } else {
+                (void)hipGetLastError();
+                ctx->ptb_retry_wait = ctx->ptb_retry_wait >= 2048 ? 4096 : 2 * ctx->ptb_retry_wait;
+            }
+        }
+        if (!grown) K = ctx->ptb_kcap;
     }
     size_t need = bytes_for(K);
     if (ctx->ptb_bytes < need) {

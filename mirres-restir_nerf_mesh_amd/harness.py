@@ -53,7 +53,8 @@ def build_gbuffer_stage1(worker, vertices, triangles, H, W, ssaa=1, azimuth_deg=
         mvp = mvp_from_pose(pose, (fx_, fy_, cx_, cy_), h, w)
         cam = dict(mvp=mvp, vertices_clip=torch.cat((vertices, torch.ones_like(vertices[:, :1])), dim=1) @ mvp.t())      # :981
         # rast, rast_out_deriv_s = dr.rasterize(self.glctx, vertices_clip, self.triangles, (h, w))                          # :983 — the reference's call, unchanged
-        rast4, rast_db = raster.dr.rasterize(raster.RasterizeContext(worker), cam["vertices_clip"].unsqueeze(0), triangles, (h, w))
+        # (the exact camera is in hand: `mvp=` spares rasterize the float64 re-fit of the matrix — a host synchronisation per view)
+        rast4, rast_db = raster.dr.rasterize(raster.RasterizeContext(worker), cam["vertices_clip"].unsqueeze(0), triangles, (h, w), mvp=mvp)
         rast = rast4.view(h * w, 4)
         cam["rast_db"] = rast_db
     else:

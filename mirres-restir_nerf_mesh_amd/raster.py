@@ -58,6 +58,11 @@ def rasterize(glctx, pos, tri, resolution, ranges=None, grad_db=True, mvp=None):
         A = torch.cat((vert, torch.ones_like(vert[:, :1])), dim=1).double()
         step = max(1, A.shape[0] // 4096)
         mvp = torch.linalg.lstsq(A[::step], p[::step].double()).solution.t()            # p = A @ mvp^T
+        # the fit is only meaningful when `pos` really is a linear image of THIS worker's vertices (a BVH built over another mesh of the same vertex
+        # count would otherwise rasterise silently wrong): the residual of an exact image is float32 rounding of the clip coordinates
+        resid = float((A[::step] @ mvp.t() - p[::step].double()).abs().max()); scale = max(1.0, float(p[::step].abs().max()))
+        if not resid <= 1e-4 * scale:
+            raise ValueError("rasterize: clip-space vertices are not a projective image of the worker's mesh (fit residual %.3e): wrong BVH for `pos`?" % resid)
     M = mvp.detach().double().cpu()
     A = M[[0, 1, 3]]                                             # rows x, y, w: the eye is where all three vanish
     if abs(float(torch.linalg.det(A[:, :3]))) < 1e-12 * float(A[:, :3].abs().max()) ** 3:

@@ -127,3 +127,190 @@ def make_matnet_params(seed=0, scale=1e-4 * 1e3, n_params=12599920):
 # main.py:167-170 / network.py:119-125 : min=(0,0,0, 0,roughness_min,0)  max=(1,1,1, 0,1,me_max)
 def material_min_max(roughness_min=0.08, me_max=0.0):
     return (np.array([0, 0, 0, 0, roughness_min, 0], np.float32), np.array([1, 1, 1, 0, 1, me_max], np.float32))
+
+
+# ---------------------------------------------------------------- a lego-LIKE workload ("What's missing" 1)
+# BASELINE's scene is TensoIR-lego: marching cubes of a density field + decimation to 3e5 triangles (main.py:133, configs/tensoir_synthetic/lego.txt).
+# No such mesh exists offline, and the icosphere of make_mesh() is the LBVH's best case (uniform tessellation, depth complexity 1-2). This builder
+# makes the features that move traversal cost: a brick assembly with studs (many small cylinders), hollow bricks with inner tubes (cavities), thin
+# plates a few hundredths apart (near occluders), a slatted grille, wheels and track links (clusters of tiny triangles) next to faces tessellated
+# from 1 x 1 to 48 x 48 cells (triangle areas spread > 1000 : 1), all turned out of the axes by a fixed rotation — plus a few EXACTLY axis-aligned
+# plates, whose zero-thickness leaf boxes the reference's slab test can never enter (helperDi.slang:165).
+class _MeshBuf:
+    def __init__(self):
+        self.v, self.f, self.nv = [], [], 0
+
+    def add(self, v, f):
+        self.v.append(np.asarray(v, np.float64)); self.f.append(np.asarray(f, np.int64) + self.nv); self.nv += len(v)
+
+    def grid(self, p0, du, dv, nu, nv, bump=None):
+        """Parallelogram p0 + s du + t dv as nu x nv cells (2 nu nv triangles), counter-clockwise seen against du x dv."""
+        nu, nv = max(1, int(nu)), max(1, int(nv))
+        s, t = np.meshgrid(np.linspace(0, 1, nu + 1), np.linspace(0, 1, nv + 1), indexing="xy")
+        p = np.asarray(p0, np.float64)[None] + s.reshape(-1, 1) * np.asarray(du, np.float64)[None] + t.reshape(-1, 1) * np.asarray(dv, np.float64)[None]
+        if bump is not None and nu * nv >= 16:          # marching-cubes surfaces are not flat: a smooth normal displacement on the finely tessellated faces
+            n = np.cross(du, dv); n = n / max(np.linalg.norm(n), 1e-30)
+            inner = ((s > 0) & (s < 1) & (t > 0) & (t < 1)).reshape(-1)     # borders stay put so that neighbouring faces still meet
+            p = p + (inner * bump[0] * (_value_noise(np.clip(p * 0.9, -0.999, 0.999), bump[1], res=32) - 0.5))[:, None] * n[None]
+        idx = np.arange((nu + 1) * (nv + 1)).reshape(nv + 1, nu + 1)
+        a, b, c, d = idx[:-1, :-1].ravel(), idx[:-1, 1:].ravel(), idx[1:, 1:].ravel(), idx[1:, :-1].ravel()
+        self.add(p, np.concatenate([np.stack([a, b, c], 1), np.stack([a, c, d], 1)], 0))
+
+    def box(self, c, size, res=(1, 1, 1), skip=(), bump=None):
+        """Axis-parallel box (model space) with per-axis cell counts; `skip` names faces left open: '+x', '-z', ..."""
+        c = np.asarray(c, np.float64); h = 0.5 * np.asarray(size, np.float64)
+        ex, ey, ez = np.array([2 * h[0], 0, 0]), np.array([0, 2 * h[1], 0]), np.array([0, 0, 2 * h[2]])
+        lo = c - h
+        faces = {"-z": (lo, ey, ex, res[1], res[0]), "+z": (lo + ez, ex, ey, res[0], res[1]), "-y": (lo, ex, ez, res[0], res[2]),
+                 "+y": (lo + ey, ez, ex, res[2], res[0]), "-x": (lo, ez, ey, res[2], res[1]), "+x": (lo + ex, ey, ez, res[1], res[2])}
+        for name, (p0, du, dv, nu, nv) in faces.items():
+            if name not in skip:
+                self.grid(p0, du, dv, nu, nv, bump)
+
+    def cylinder(self, base, axis, radius, height, seg, rings=1, cap0=False, cap1=True, inward=False):
+        """Cylinder side (seg x rings quads) around `axis` (0/1/2) from `base`, with optional fan caps (seg slivers each)."""
+        seg, rings = max(5, int(seg)), max(1, int(rings))
+        th = np.linspace(0, 2 * np.pi, seg, endpoint=False)
+        u, w = [(1, 2), (2, 0), (0, 1)][axis]
+        ring = np.zeros((seg, 3)); ring[:, u] = np.cos(th) * radius; ring[:, w] = np.sin(th) * radius
+        ax = np.zeros(3); ax[axis] = 1.0
+        pts = np.concatenate([np.asarray(base, np.float64)[None] + ring + ax[None] * (height * k / rings) for k in range(rings + 1)], 0)
+        i = np.arange(seg); j = (i + 1) % seg
+        f = []
+        for k in range(rings):
+            a, b, c, d = k * seg + i, k * seg + j, (k + 1) * seg + j, (k + 1) * seg + i
+            f += [np.stack([a, b, c], 1), np.stack([a, c, d], 1)]
+        f = np.concatenate(f, 0)
+        if inward:
+            f = f[:, ::-1]
+        self.add(pts, f)
+        for on, k in ((cap0, 0), (cap1, rings)):
+            if on:
+                ctr = np.asarray(base, np.float64) + ax * (height * k / rings)
+                p = np.concatenate([pts[k * seg:(k + 1) * seg], ctr[None]], 0)
+                fan = np.stack([i, j, np.full(seg, seg)], 1)
+                self.add(p, fan if k else fan[:, ::-1])
+
+
+def _clustered_parts(B, s, rng):
+    """The assembly in model space (z up, roughly [-1, 1] x [-0.75, 0.75] x [-0.6, 0.62]); s scales every tessellation count."""
+    r = lambda n: max(1, int(round(n * s)))
+    seg = lambda n: max(6, int(round(n * min(1.0, 0.35 + 0.65 * s))))
+    bump = (0.004, 7)
+    def studs(x0, x1, y0, y1, z, pitch=0.1, rad=0.03, h=0.024):
+        xs = np.arange(x0 + pitch / 2, x1, pitch); ys = np.arange(y0 + pitch / 2, y1, pitch)
+        for x in xs:
+            for y in ys:
+                B.cylinder((x, y, z), 2, rad, h, seg(16), 1, cap0=False, cap1=True)
+    def brick(c, size, res, stud=True, skip=(), tubes=False):
+        B.box(c, size, (r(res[0]), r(res[1]), r(res[2])), skip=skip, bump=bump)
+        c = np.asarray(c, float); h = 0.5 * np.asarray(size, float)
+        if stud:
+            studs(c[0] - h[0], c[0] + h[0], c[1] - h[1], c[1] + h[1], c[2] + h[2])
+        if tubes:   # a hollow brick seen from its open side: inner walls one plate thickness inside, and the tubes between the studs' undersides
+            t = 0.02
+            B.box(c, (size[0] - 2 * t, size[1] - 2 * t, size[2] - 2 * t), (r(res[0]), r(res[1]), r(res[2])), skip=skip, bump=None)
+            for x in np.arange(c[0] - h[0] + 0.1, c[0] + h[0] - 0.05, 0.1):
+                B.cylinder((x, c[1], c[2] - h[2] + t), 2, 0.032, size[2] - 2 * t, seg(14), r(3), cap0=False, cap1=False)
+                B.cylinder((x, c[1], c[2] - h[2] + t), 2, 0.024, size[2] - 2 * t, seg(14), r(3), cap0=False, cap1=False, inward=True)
+    # base plate: huge coarse underside and rim, finely tessellated top between the studs
+    B.box((0, 0, -0.56), (2.0, 1.9, 0.06), (r(40), r(38), 1), skip=("-z",), bump=bump)
+    B.grid((-1.0, -0.95, -0.59), (0, 1.9, 0), (2.0, 0, 0), 1, 1)                     # two triangles of area 1.9 each
+    studs(-1.0, 1.0, -0.95, 0.95, -0.53)
+    # chassis and body: bricks of assorted sizes and tessellations (decimation keeps flat faces coarse and detailed regions fine)
+    brick((-0.05, 0, -0.43), (1.5, 0.8, 0.2), (24, 12, 4), stud=False)
+    brick((-0.35, 0, -0.23), (0.8, 0.7, 0.2), (40, 36, 10))
+    brick((0.35, 0.0, -0.26), (0.5, 0.6, 0.14), (6, 6, 2))
+    brick((-0.45, 0.0, -0.03), (0.5, 0.5, 0.2), (48, 48, 20), skip=("+y",), tubes=True)      # hollow brick open towards +y: an interior cavity
+    brick((0.3, -0.18, -0.12), (0.3, 0.2, 0.14), (3, 2, 1))
+    brick((0.3, 0.18, -0.12), (0.3, 0.2, 0.14), (30, 20, 14))
+    # cab: thin pillars, a roof plate with studs, a seat
+    for sx in (-0.68, -0.24):
+        for sy in (-0.22, 0.22):
+            B.box((sx, sy, 0.27), (0.035, 0.035, 0.4), (r(2), r(2), r(24)), bump=None)
+    brick((-0.46, 0, 0.49), (0.56, 0.56, 0.04), (28, 28, 2))
+    brick((-0.5, 0, 0.12), (0.2, 0.3, 0.1), (10, 14, 5), stud=False)
+    # exhaust and levers: thin tall cylinders
+    B.cylinder((0.42, 0.2, -0.05), 2, 0.035, 0.45, seg(20), r(30), cap1=True)
+    B.cylinder((0.42, 0.2, 0.40), 2, 0.05, 0.06, seg(20), r(4), cap0=True, cap1=True)
+    for k in range(3):
+        B.cylinder((-0.3 + 0.05 * k, -0.1 + 0.1 * k, 0.07), 2, 0.008, 0.2, seg(8), r(10), cap1=True)
+    # blade: three thin plates 0.02 apart (near occluders), finely and coarsely tessellated in turn, on two slanted arms
+    for k, (res_x, res_z) in enumerate(((64, 24), (2, 1), (32, 12))):
+        B.box((0.86 + 0.035 * k, 0, -0.3), (0.015, 1.3, 0.36), (1, r(res_x), r(res_z)), bump=None)
+    for sy in (-0.45, 0.45):
+        p0 = np.array([0.5, sy - 0.03, -0.42]); L = np.array([0.36, 0.0, 0.1]); Wd = np.array([0, 0.06, 0]); Hh = np.cross(L, Wd); Hh = Hh / np.linalg.norm(Hh) * 0.05
+        for (a, du, dv, nu, nv) in ((p0, L, Wd, 12, 2), (p0 + Hh, Wd, L, 2, 12), (p0, Hh, L, 2, 12), (p0 + Wd, L, Hh, 12, 2)):
+            B.grid(a, du, dv, r(nu), r(nv))
+    # grille: thin slats 0.012 apart in front of a back plate — many near occluders and tiny triangles in one place
+    for k in range(36):
+        B.box((0.615, -0.21 + 0.012 * k, -0.04), (0.05, 0.004, 0.26), (r(3), 1, r(14)), bump=None)
+    B.box((0.57, 0, -0.04), (0.01, 0.46, 0.28), (1, r(20), r(12)), bump=None)
+    # tracks: wheels (cylinder + hub tube) and links on both sides
+    for sy in (-0.62, 0.62):
+        for k in range(9):
+            x = -0.8 + 0.2 * k
+            B.cylinder((x, sy - 0.06, -0.4), 1, 0.085, 0.12, seg(28), r(4), cap0=True, cap1=True)
+            B.cylinder((x, sy - 0.07, -0.4), 1, 0.03, 0.14, seg(12), r(2), cap0=True, cap1=True)
+        for k in range(44):
+            x = -0.92 + 0.042 * k
+            B.box((x, sy, -0.3), (0.034, 0.15, 0.016), (r(2), r(8), 1), bump=None)
+            B.box((x, sy, -0.5), (0.034, 0.15, 0.016), (r(2), r(8), 1), bump=None)
+    # two towers of stacked bricks behind the vehicle (fine and coarse tessellation alternating, two of them hollow and open to one side), joined at
+    # the top by a long thin beam; an antenna on one of them
+    for ti, (tx, ty) in enumerate(((-0.78, -0.55), (-0.78, 0.55), (0.05, 0.72), (0.62, 0.74))):
+        z = -0.53; nb = (7, 6, 6, 4)[ti]
+        for k in range(nb):
+            hgt = 0.2 if (k + ti) % 3 else 0.12
+            fine = (k + ti) % 2 == 0
+            hollow = (k == 2 and ti < 2)
+            brick((tx, ty, z + hgt / 2), (0.44 if ti < 2 else 0.5, 0.44 if ti < 2 else 0.3, hgt), (36, 36, 16) if fine else (2, 2, 1), stud=(k == nb - 1), skip=(("+x",) if hollow else ()), tubes=hollow)
+            z += hgt
+        if ti == 1:
+            B.cylinder((tx, ty, z + 0.024), 2, 0.01, 0.14, seg(8), r(12), cap1=True)
+    B.box((-0.78, 0.0, 0.5), (0.1, 1.3, 0.03), (r(4), r(60), r(2)), bump=None)
+    # loose small parts scattered on the plate (seeded): clusters of small bricks at random places / sizes
+    for _ in range(40):
+        cx, cy = rng.uniform(-0.4, 0.9), rng.choice([-1, 1]) * rng.uniform(0.95, 1.1)
+        sz = rng.uniform(0.03, 0.09, 3)
+        B.box((cx, cy * 0.78, -0.53 + sz[2] / 2 + 0.26), sz, tuple(r(int(q)) for q in rng.integers(1, 12, 3)), bump=None)
+
+
+MODEL_SCALE = (0.8, 0.8, 1.3, 0.05)
+
+
+def make_mesh_clustered(target_tris=300000, seed=0, axis_aligned_plates=3):
+    """Lego-like synthetic mesh, ~target_tris triangles (default 3e5 = main.py:133's decimation target), deterministic for (target_tris, seed).
+    Returns (verts f32[V,3], tris i32[T,3]) inside [-1,1]^3 (`--bound 1`). See the comment above for what it contains and why."""
+    s = float(np.sqrt(max(target_tris, 2000) / 3.0e5))
+    for _ in range(6):           # tessellation counts are integers: a few fixed-point steps land within a few per cent of the target
+        B = _MeshBuf(); _clustered_parts(B, s, np.random.default_rng(seed))
+        T = sum(len(f) for f in B.f)
+        if abs(T - target_tris) <= 0.03 * target_tris:
+            break
+        s *= float(np.sqrt(target_tris / T)) if T > 0.2 * target_tris else 1.3
+    v = np.concatenate(B.v, 0); f = np.concatenate(B.f, 0)
+    # out of the axes: no edge of the assembly stays axis-parallel (the reference's slab test cannot enter zero-thickness boxes, a-7)
+    def rot(axis, deg):
+        a = np.deg2rad(deg); c, s_ = np.cos(a), np.sin(a)
+        R = np.eye(3); i, j = [(1, 2), (2, 0), (0, 1)][axis]
+        R[i, i] = c; R[i, j] = -s_; R[j, i] = s_; R[j, j] = c
+        return R
+    # (stretched first — taller than wide, studs slightly elliptical — so that from the benchmark camera the model covers more than half the frame)
+    v = (v * np.array([MODEL_SCALE[0], MODEL_SCALE[1], MODEL_SCALE[2]])) @ (rot(2, 14.0) @ rot(0, 5.0) @ rot(1, -3.0)).T + np.array([0.0, 0.0, MODEL_SCALE[3]])
+    # ... and a few plates that ARE axis-aligned (after the rotation), floating beside the model: every triangle of theirs has a zero-thickness box
+    P = _MeshBuf()
+    for k in range(axis_aligned_plates):
+        P.box((-0.1 + 0.4 * k, -0.6 - 0.03 * k, 0.3 + 0.06 * k), (0.3, 0.2, 0.02), (4, 3, 1))
+    if axis_aligned_plates:
+        pv = np.concatenate(P.v, 0); pf = np.concatenate(P.f, 0) + len(v)
+        v = np.concatenate([v, pv], 0); f = np.concatenate([f, pf], 0)
+    assert np.abs(v).max() < 1.0, "clustered mesh leaves the unit bound"
+    return np.ascontiguousarray(v.astype(np.float32)), np.ascontiguousarray(f.astype(np.int32))
+
+
+def mesh_by_name(name, subdiv=7):
+    """bench.py / scripts: 'icosphere' (SURVEY 8d's synthetic mesh) or 'clustered' (lego-like); both ~3.3e5 triangles at full size."""
+    if name == "clustered":
+        return make_mesh_clustered(335872 if subdiv >= 7 else max(2000, 20 * 4 ** subdiv + 512))
+    return make_mesh(subdiv, 64 if subdiv >= 6 else 16)

@@ -91,6 +91,18 @@ void orc_trace(const int32_t* info, const float* aabb, const float* vert, const 
     }
 }
 
+// deepest the reference's 64-entry traversal stack gets for each ray (bvh_hit, helperDi.slang:197-274), and the depth of the LBVH itself
+void orc_trace_stack_depth(const int32_t* info, const float* aabb, const float* vert, const int32_t* tri, const float* rays, int n, int want_normal, uint32_t* max_count) {
+    Bvh B = {info, aabb, vert, tri};
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int i = 0; i < n; i++) {
+        const float* r = rays + 8 * (size_t)i;
+        TraceCounters tc = {0, 0, 0, 0, 1};
+        (void)bvh_hit(B, mk3(r[0], r[1], r[2]), mk3(r[4], r[5], r[6]), r[3], r[7], want_normal != 0, &tc);
+        max_count[i] = tc.max_count;
+    }
+}
+
 // ---- environment
 void orc_make_sampleable(const float* tex, int W, int H, float* pdf, float* cdf, float* mpdf, float* mcdf) { make_sampleable(tex, W, H, pdf, cdf, mpdf, mcdf); }
 void orc_neighbor_offsets(int count, float* out) { neighbor_offsets(count, out); }

@@ -143,6 +143,27 @@ def trace(info, aabb, vert, tri, rays, want_normal=True, counters=False):
     return out
 
 
+def trace_stack_depth(info, aabb, vert, tri, rays, want_normal=False):
+    """Most entries the reference's 64-entry stack holds for each ray (helperDi.slang:136, :197-274)."""
+    rays = _c(rays, np.float32); n = rays.shape[0]
+    out = np.zeros(n, np.uint32)
+    lib().orc_trace_stack_depth(_p(info, i32p), _p(aabb, f32p), _p(_c(vert, np.float32), f32p), _p(_c(tri, np.int32), i32p), _p(rays, f32p), n, int(want_normal), _p(out, u32p))
+    return out
+
+
+def tree_depth(info):
+    """Depth (edges on the longest root-to-leaf path) of the LBVH in the reference's `info` layout (left, right, prim per node; root 0)."""
+    info = np.asarray(info).reshape(-1, 3)
+    depth = np.zeros(len(info), np.int32)
+    front = np.array([0]); d = 0
+    while len(front):
+        depth[front] = d
+        kids = info[front, :2].reshape(-1)
+        front = kids[kids != 0]
+        d += 1
+    return int(depth.max())
+
+
 # ------------------------------------------------------------------ environment
 def flip_env(env_map):
     """renderer_restir.py:305-311: vertical flip + flatten to [Hc*Wc,3]."""

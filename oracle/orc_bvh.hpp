@@ -212,7 +212,7 @@ static inline void bvh_build(const float* vert, int V, const int32_t* tri, int T
 struct Bvh {
     const int32_t* info; const float* aabb; const float* vert; const int32_t* tri;
 };
-struct TraceCounters { uint32_t popped, entered, leaves, overflow; };
+struct TraceCounters { uint32_t popped, entered, leaves, overflow, max_count; };   // max_count: most entries the 64-entry stack ever held (helperDi.slang:136)
 
 // helperDi.slang:149-170
 static inline bool aabb_hit(f3 o, f3 d, float t_min, float t_max, const float* bb) {
@@ -279,6 +279,7 @@ static inline HitResult bvh_hit(const Bvh& B, f3 o, f3 d, float t_min, float t_m
             Node l = {n.left, B.info[3 * n.left], B.info[3 * n.left + 1], (uint32_t)B.info[3 * n.left + 2]};
             Node rr = {n.right, B.info[3 * n.right], B.info[3 * n.right + 1], (uint32_t)B.info[3 * n.right + 2]};
             stack[count++] = l; stack[count++] = rr;
+            if (tc && (uint32_t)count > tc->max_count) tc->max_count = (uint32_t)count;
         } else if (n.left == 0 && n.right == 0) {
             if (tc) tc->leaves++;
             const int32_t* ti = B.tri + 3 * (size_t)n.prim;

@@ -139,7 +139,7 @@ def main():
     s_mat = torch.optim.lr_scheduler.LambdaLR(o_mat, brdf_sched); s_lgt = torch.optim.lr_scheduler.LambdaLR(o_lgt, brdf_sched)
     # resume (load_checkpoint, utils.py:1966-1990): optimiser moments and schedules continue where the checkpoint left them; a checkpoint without them
     # (the reference's default full=False files) still gets the SCHEDULES of its step — they are functions of the step count — and only the Adam moments restart
-    scheds = {"lr_scheduler": s_geo, "lr_scheduler_mat": s_mat, "lr_scheduler_light": s_lgt}
+    scheds = {"lr_scheduler": s_geo, "scheduler_mat": s_mat, "scheduler_light": s_lgt}      # the reference's key names (nerf/utils.py:1863-1867)
     optims = {"optimizer": o_geo, "optimizer_mat": o_mat, "optimizer_light": o_lgt}
     if ck is not None:
         ts = ck.get("train_state") or {}

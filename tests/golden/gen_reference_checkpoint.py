@@ -103,6 +103,43 @@ def main():
         same = all(torch.equal(a, b) for a, b in zip(fresh.state_dict().values(), mine.state_dict().values())) and torch.equal(fresh.lgt.base, mine.lgt.base.detach())
         assert same, "a file written by checkpoint.save_checkpoint does not load into the reference's model"
         out["package_file_loads_in_reference"] = np.bool_(same)
+        # ---- a resumable file: the reference's save_checkpoint(full=True) (:1856-1867) over real optimisers / LambdaLR schedules that took 9 steps
+        def train_objs(m, steps):
+            sched = lambda it: max(0.0, 10 ** (-it * 0.0002))
+            o_g = torch.optim.Adam([{"params": [m.vertices_offsets], "lr": 1e-3}]); s_g = torch.optim.lr_scheduler.LambdaLR(o_g, lambda it: 0.5 ** (it / 10))
+            o_m = torch.optim.Adam([{"params": list(m.mlp_mat_opt.parameters()), "lr": 1e-2}]); s_m = torch.optim.lr_scheduler.LambdaLR(o_m, sched)
+            o_l = torch.optim.Adam([{"params": [m.lgt.base], "lr": 3e-2}]); s_l = torch.optim.lr_scheduler.LambdaLR(o_l, sched)
+            for _ in range(steps):
+                for o_ in (o_g, o_m, o_l):
+                    o_.zero_grad()
+                (m.vertices_offsets.square().sum() + sum(p_.square().sum() for p_ in m.mlp_mat_opt.parameters()) + m.lgt.base.square().sum()).backward()
+                for o_, s_ in ((o_g, s_g), (o_m, s_m), (o_l, s_l)):
+                    o_.step(); s_.step()
+            return o_g, s_g, o_m, s_m, o_l, s_l
+        full_model = build_model(21)
+        trf = trainer_for(full_model, tmp)
+        trf.optimizer, trf.lr_scheduler, trf.optimizer_mat, trf.scheduler_mat, trf.optimizer_light, trf.scheduler_light = train_objs(full_model, 9)
+        trf.scaler = torch.amp.GradScaler("cpu", enabled=False)
+        trf.epoch = 9; trf.global_step = 9
+        save_checkpoint(trf, full=True)
+        srcf = os.path.join(tmp, "ngp_stage1_ep0009.pth")
+        shutil.copy(srcf, os.path.join(HERE, "ref_checkpoint_stage1_full.pth"))
+        top = torch.load(srcf, map_location="cpu", weights_only=False)
+        out["full_top_keys"] = np.array(sorted(top.keys()))
+        out["full_sched_mat_last_epoch"] = np.int64(top["scheduler_mat"]["last_epoch"]); out["full_sched_light_last_epoch"] = np.int64(top["scheduler_light"]["last_epoch"])
+        out["full_lr_mat"] = np.float64(trf.optimizer_mat.param_groups[0]["lr"])
+        # and the other direction with train state: this package writes, the reference's load_checkpoint (model_only=False) restores optimisers AND schedules
+        ck_f = CK.read_checkpoint(srcf)
+        p3 = os.path.join(tmp, "from_package_full.pth")
+        holder_f = types.SimpleNamespace(encoder=full_model.mlp_mat_opt.encoder, net=full_model.mlp_mat_opt.net, AABB=full_model.mlp_mat_opt.AABB, min_max=full_model.mlp_mat_opt.min_max)
+        CK.save_checkpoint(p3, holder_f, full_model.vertices_offsets, full_model.lgt.base, epoch=9, global_step=9, train_state=ck_f["train_state"])
+        fresh_f = build_model(6); tr3 = trainer_for(fresh_f, tmp)
+        tr3.optimizer, tr3.lr_scheduler, tr3.optimizer_mat, tr3.scheduler_mat, tr3.optimizer_light, tr3.scheduler_light = train_objs(fresh_f, 0)
+        load_checkpoint(tr3, p3)
+        ok_full = (tr3.scheduler_mat.last_epoch == 9 and tr3.scheduler_light.last_epoch == 9 and tr3.lr_scheduler.last_epoch == 9
+                   and tr3.optimizer_mat.state_dict()["state"][0]["step"] == trf.optimizer_mat.state_dict()["state"][0]["step"] and tr3.global_step == 9)
+        assert ok_full, "the reference's load_checkpoint did not restore the schedules / optimisers from a package-written full checkpoint"
+        out["package_full_file_resumes_in_reference"] = np.bool_(ok_full)
         np.savez_compressed(os.path.join(HERE, "ref_checkpoint_stage1.npz"), **out)
         print("wrote ref_checkpoint_stage1.pth (%d bytes); keys: %s; package-written file loads in the reference: %s" % (os.path.getsize(src), list(sd.keys()), same))
     finally:

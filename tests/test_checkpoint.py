@@ -11,6 +11,8 @@ import torch
 from mirres_restir_nerf_mesh_amd import checkpoint as CK
 from mirres_restir_nerf_mesh_amd import scene
 
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
 
 def test_ply_round_trip_and_variants(tmp_path):
     v, t = scene.make_mesh(2, 4)
@@ -158,17 +160,17 @@ def test_train_state_round_trip_and_schedule_fast_forward(tmp_path):
     mlp = types.SimpleNamespace(encoder=types.SimpleNamespace(params=torch.zeros(16)), net=types.SimpleNamespace(net={i: types.SimpleNamespace(weight=torch.zeros(2, 2)) for i in (0, 2, 4)}))
     cfg = CK.material_config(bound=1.0, roughness_min=0.08, me_max=0.0)
     p = str(tmp_path / "resume.pth")
-    CK.save_checkpoint(p, mlp, torch.zeros(5, 3), env, epoch=40, global_step=40, material_config=cfg, train_state={"optimizer_mat": o.state_dict(), "lr_scheduler_mat": s.state_dict()})
+    CK.save_checkpoint(p, mlp, torch.zeros(5, 3), env, epoch=40, global_step=40, material_config=cfg, train_state={"optimizer_mat": o.state_dict(), "scheduler_mat": s.state_dict()})
     with pytest.raises(KeyError):
         CK.save_checkpoint(p + "x", mlp, torch.zeros(5, 3), env, material_config=cfg, train_state={"optimiser": {}})
     ck = CK.read_checkpoint(p)
-    assert set(ck["train_state"]) == {"optimizer_mat", "lr_scheduler_mat"} and ck["global_step"] == 40
+    assert set(ck["train_state"]) == {"optimizer_mat", "scheduler_mat"} and ck["global_step"] == 40
     w_saved = w.detach().clone()
     o.zero_grad(); (w * w).sum().backward(); o.step(); s.step(); after = w.detach().clone(); lr_after = o.param_groups[0]["lr"]
     with torch.no_grad():
         w.copy_(w_saved)
     o2, s2 = make()
-    o2.load_state_dict(ck["train_state"]["optimizer_mat"]); s2.load_state_dict(ck["train_state"]["lr_scheduler_mat"])
+    o2.load_state_dict(ck["train_state"]["optimizer_mat"]); s2.load_state_dict(ck["train_state"]["scheduler_mat"])
     o2.zero_grad(); (w * w).sum().backward(); o2.step(); s2.step()
     assert torch.equal(w.detach(), after) and o2.param_groups[0]["lr"] == lr_after
     # no saved state: the schedule alone is fast-forwarded to the checkpoint's step
@@ -177,3 +179,31 @@ def test_train_state_round_trip_and_schedule_fast_forward(tmp_path):
     for g_, base, fn in zip(s3.optimizer.param_groups, s3.base_lrs, s3.lr_lambdas):
         g_["lr"] = base * fn(40)
     assert o3.param_groups[0]["lr"] == pytest.approx(0.03 * sched(40)) and CK.read_checkpoint(p)["train_state"] is not None
+
+
+def test_reference_full_checkpoint_train_state():
+    """tests/golden/ref_checkpoint_stage1_full.pth was written by the reference's own Trainer.save_checkpoint(full=True) (nerf/utils.py:1856-1867) over real
+    optimisers / LambdaLR schedules after nine steps.  read_checkpoint must hand back all six state dicts under the reference's key names — in particular
+    `scheduler_mat` / `scheduler_light`, which load_checkpoint (:2003-2022) reads — and save_checkpoint must accept those names; the generator also verified
+    that a package-written full file resumes in the reference's load_checkpoint (recorded in the npz).  Names this package wrote before round 4 are read too."""
+    import types
+    from mirres_restir_nerf_mesh_amd import checkpoint as CK
+    g = np.load(os.path.join(GOLD, "ref_checkpoint_stage1.npz"))
+    assert bool(g["package_full_file_resumes_in_reference"])
+    assert {"optimizer", "lr_scheduler", "optimizer_mat", "scheduler_mat", "optimizer_light", "scheduler_light"} <= set(g["full_top_keys"].tolist())
+    ck = CK.read_checkpoint(os.path.join(GOLD, "ref_checkpoint_stage1_full.pth"))
+    ts = ck["train_state"]
+    assert set(ts) == set(CK.TRAIN_STATE_KEYS)
+    assert ts["scheduler_mat"]["last_epoch"] == int(g["full_sched_mat_last_epoch"]) == 9 and ts["scheduler_light"]["last_epoch"] == int(g["full_sched_light_last_epoch"])
+    # a LambdaLR restored from it continues the reference's learning rate
+    w = torch.nn.Parameter(torch.zeros(3)); o = torch.optim.Adam([{"params": [w], "lr": 1e-2}])
+    s = torch.optim.lr_scheduler.LambdaLR(o, lambda it: max(0.0, 10 ** (-it * 0.0002)))
+    s.load_state_dict(ts["scheduler_mat"])
+    assert s.last_epoch == 9 and s.get_last_lr()[0] == pytest.approx(float(g["full_lr_mat"]), rel=1e-12)
+    # legacy names (rounds 1-3 of this package) are mapped on read
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        p = os.path.join(d, "old.pth")
+        torch.save({"model": {"vertices_offsets": torch.zeros(4, 3)}, "epoch": 1, "global_step": 5, "stage": 1, "lr_scheduler_mat": {"last_epoch": 5}, "lr_scheduler_light": {"last_epoch": 5}}, p)
+        old = CK.read_checkpoint(p)["train_state"]
+        assert set(old) == {"scheduler_mat", "scheduler_light"} and old["scheduler_mat"]["last_epoch"] == 5

@@ -263,3 +263,52 @@ def test_worker_is_released_when_dropped(torch_cuda, scene_mod):
     from mirres_restir_nerf_mesh_amd._lib import MirresError
     with pytest.raises(MirresError, match="live restirbvhWorker"):
         Resampling._owner(info)
+
+
+def test_deep_tree_private_stack_and_reference_stack(torch_cuda, oracle):
+    """The adversarial mesh of tests/test_oracle_invariants.py (a 27-deep right-running Morton chain + 65 536 triangles of ONE Morton code, every leaf box around
+    one common line, no triangle on it): the LBVH is ~43 deep, the reference's stack holds depth + 1 entries (< 64: it cannot overflow for any int32 T), and the
+    4-wide private stack of the shadow-ray kernel — up to three deferred references per 4-wide level — goes DEEPER than the reference's 64 would allow: the
+    kernel's stack is 192 entries = 3 x (30 + 31) rounded up (bvh_trace.hip MR_ANY_STACK), so nothing is dropped.  Every mode of mirres_bvh_trace equals
+    the oracle on the line itself and on rays jittered around it (hits and misses)."""
+    torch = torch_cuda
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_oracle_invariants import adversarial_chain_mesh
+    from mirres_restir_nerf_mesh_amd.renderer_restir import restirbvhWorker
+    from mirres_restir_nerf_mesh_amd._lib import lib, check
+    v, t, (lx, ly) = adversarial_chain_mesh(65536)
+    w = restirbvhWorker(torch.from_numpy(v).cuda(), torch.from_numpy(t).cuda()); w.update_mesh(w.vrt, w.v_ind)
+    info, aabb, _, _ = oracle.bvh_build(v, t)
+    assert np.array_equal(w.LBVHNode_info.cpu().numpy(), info) and np.array_equal(_bits(w.LBVHNode_aabb.cpu().numpy()), _bits(aabb))
+    rng = np.random.default_rng(5)
+    n = 4096
+    o = np.tile(np.array([[1.0 - lx, 1.0 - ly, -1.5]], np.float32), (n, 1)); d = np.tile(np.array([[0.0, 0.0, 1.0]], np.float32), (n, 1))
+    o[1:, :2] += (rng.random((n - 1, 2)).astype(np.float32) - 0.5) * np.float32(0.004)        # around the line: inside and outside the triangles' half
+    d[n // 2:, :2] += (rng.random((n - n // 2, 2)).astype(np.float32) - 0.5) * np.float32(0.002)
+    rays = oracle.make_rays(o, d)
+    ref = oracle.trace(info, aabb, v, t, rays, True, counters=True)
+    assert ref["hit"][0] == 0 and ref["counters"][0, 2] > 60000 and ref["counters"][:, 3].sum() == 0 and 0.05 < ref["hit"].mean() < 0.95
+    depth = oracle.tree_depth(info); deepest_ref = int(oracle.trace_stack_depth(info, aabb, v, t, rays).max())
+    assert 40 <= depth <= 30 + int(np.ceil(np.log2(len(t)))) and deepest_ref == depth + 1 < 64
+    dr = torch.from_numpy(rays).cuda()
+    for mode in (0, 1, 2):
+        hit = torch.zeros(n, dtype=torch.int32, device="cuda"); tt = torch.zeros(n, device="cuda"); p = torch.zeros((n, 3), device="cuda")
+        nn = torch.zeros((n, 3), device="cuda"); pr = torch.zeros(n, dtype=torch.int32, device="cuda")
+        check(lib().mirres_bvh_trace(w.h, dr.data_ptr(), n, mode, hit.data_ptr(), tt.data_ptr(), p.data_ptr(), nn.data_ptr(), pr.data_ptr(), None, None), "trace")
+        torch.cuda.synchronize()
+        assert np.array_equal(hit.cpu().numpy(), ref["hit"]), mode
+        if mode:
+            m = ref["hit"] > 0
+            assert np.array_equal(pr.cpu().numpy(), ref["prim"]) and np.array_equal(_bits(tt.cpu().numpy()[m]), _bits(ref["t"][m])) and np.array_equal(_bits(nn.cpu().numpy()[m]), _bits(ref["normal"][m]))
+    L = lib(); L.mirres_debug_any_stats.argtypes = [C.c_void_p] * 6; L.mirres_debug_any_stats.restype = C.c_int
+    st = (C.c_uint64 * 12)(); hit = torch.zeros(n, dtype=torch.int32, device="cuda")
+    check(L.mirres_debug_any_stats(w.h, dr.data_ptr(), n, hit.data_ptr(), st, None), "any stats")
+    assert np.array_equal(hit.cpu().numpy(), ref["hit"])
+    bound = 3 * (30 + int(np.ceil(np.log2(len(t)))))
+    assert st[11] == 0 and 27 <= st[8] <= bound <= 192, (st[8], bound)
+    rep = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(rep):
+        open(os.path.join(rep, "deep_tree_stack.txt"), "w").write(
+            "adversarial chain mesh T=%d: LBVH depth %d; reference stack deepest %d of 64; shadow-ray kernel's private stack deepest %d (bound 3 x (30 + ceil(log2 T)) = %d, capacity 192); overflows %d; "
+            "64-byte records per ray %.1f\n" % (len(t), depth, deepest_ref, st[8], bound, st[11], st[3] / n))

@@ -1,0 +1,132 @@
+"""GPU: the lego-LIKE workload (scene.make_mesh_clustered: studs, hollow bricks, thin plates 0.02 apart, a slatted grille, wheels; triangle areas spread
+> 10^5 : 1; a few exactly axis-aligned plates) at BASELINE size — LBVH arrays, the traversal kernels with their visit counters, and whole frames (one sample at
+1600 x 1600, 24 samples at 400 x 400, material field at every vertex) against the oracle, bit for bit.  Also what the reference's fixed-size stack needs on it."""
+import os
+
+import numpy as np
+import pytest
+
+from util import pixel_parity
+
+pytestmark = pytest.mark.gpu
+NAMES = ["final_color", "diffuse", "spec", "indirect", "indirect_diff", "indirect_spec"]
+
+
+def _report(line):
+    rep = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(rep):
+        with open(os.path.join(rep, "clustered_mesh_report.txt"), "a") as f:
+            f.write(line + "\n")
+
+
+def _field(scene_mod, torch):
+    from mirres_restir_nerf_mesh_amd.render_helper import MLPTexture3D
+    params, w0, w1, w2 = scene_mod.make_matnet_params(seed=0)
+    mn, mx = scene_mod.material_min_max()
+    mlp = MLPTexture3D(torch.tensor([-1, -1, -1, 1, 1, 1], dtype=torch.float32), channels=6, min_max=(torch.from_numpy(mn).cuda(), torch.from_numpy(mx).cuda()), seed=1)
+    with torch.no_grad():
+        mlp.encoder.params.copy_(torch.from_numpy(params).cuda())
+        for i, w in zip((0, 2, 4), (w0, w1, w2)):
+            mlp.net.net[i].weight.copy_(torch.from_numpy(w).cuda())
+    return mlp
+
+
+@pytest.fixture(scope="module")
+def lego(scene_mod, oracle):
+    import torch
+    from mirres_restir_nerf_mesh_amd import renderer_restir as RR, harness
+    v, t = scene_mod.mesh_by_name("clustered")
+    W = RR.restirbvhWorker(torch.from_numpy(v).cuda(), torch.from_numpy(t).cuda()); W.update_mesh(W.vrt, W.v_ind)
+    info, aabb, _, _ = oracle.bvh_build(v, t)
+    return v, t, W, RR, harness, torch, info, aabb
+
+
+def test_clustered_lbvh_and_traversal_match_the_oracle(lego, oracle):
+    """LBVHNode_info / LBVHNode_aabb bit-equal; 40 000 shadow-like rays: every mode of mirres_bvh_trace (shadow 4-wide kernel, reference-order kernel,
+    ordered fast path + redo, front-only occlusion) equals the oracle's bvh_hit in hit bit, primitive, t, point and normal, and the reference-order
+    counted kernels visit exactly the nodes the oracle visits (popped / entered / leaves per ray)."""
+    v, t, W, RR, harness, torch, info, aabb = lego
+    from mirres_restir_nerf_mesh_amd._lib import lib, check
+    assert np.array_equal(W.LBVHNode_info.cpu().numpy(), info) and np.array_equal(W.LBVHNode_aabb.cpu().numpy(), aabb)
+    g = harness.build_gbuffer(W, 800, 800, 1)
+    fg = g["occ"][:, 0] > 0.5
+    frac = float(fg.float().mean())
+    assert frac >= 0.5, frac
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    n = int(fg.sum())
+    d = g["normal"][fg] + 0.95 * torch.nn.functional.normalize(torch.randn((n, 3), device="cuda", generator=gen), dim=1)
+    o = g["pos"][fg] + 0.01 * torch.nn.functional.normalize(d, dim=1)
+    rays = torch.zeros((n, 8), device="cuda"); rays[:, 0:3] = o; rays[:, 4:7] = d; rays[:, 7] = 1e7
+    sel = torch.randperm(n, generator=torch.Generator().manual_seed(3))[:40000].cuda()
+    rs = rays[sel].contiguous(); m = rs.shape[0]
+    ref = oracle.trace(info, aabb, v, t, rs.cpu().numpy(), True, counters=True)
+    assert ref["counters"][:, 3].sum() == 0
+    mm = ref["hit"] > 0
+    assert 0.3 < mm.mean() < 0.9
+    for mode in (0, 1, 2, 3):
+        hit = torch.zeros(m, dtype=torch.int32, device="cuda"); tt = torch.zeros(m, device="cuda"); p = torch.zeros((m, 3), device="cuda")
+        nn = torch.zeros((m, 3), device="cuda"); pr = torch.zeros(m, dtype=torch.int32, device="cuda")
+        for counted in ((False, True) if mode < 2 else (False,)):
+            cnt = torch.zeros((m, 4), dtype=torch.int32, device="cuda") if counted else None
+            check(lib().mirres_bvh_trace(W.h, rs.data_ptr(), m, mode, hit.data_ptr(), tt.data_ptr(), p.data_ptr(), nn.data_ptr(), pr.data_ptr(), cnt.data_ptr() if counted else None, None), "trace")
+            torch.cuda.synchronize()
+            if mode == 3:
+                assert np.array_equal(hit.cpu().numpy(), oracle.occluded_front(info, aabb, v, t, rs.cpu().numpy()))
+                continue
+            assert np.array_equal(hit.cpu().numpy(), ref["hit"]), (mode, counted)
+            if mode == 0:
+                if counted:   # the shadow query in the reference's order, exhaustive: the reference's own visit counts
+                    assert np.array_equal(cnt.cpu().numpy()[:, :3].astype(np.uint32), ref["counters"][:, :3])
+                continue
+            assert np.array_equal(pr.cpu().numpy(), ref["prim"]), (mode, counted)
+            assert np.array_equal(tt.cpu().numpy()[mm], ref["t"][mm]) and np.array_equal(p.cpu().numpy()[mm], ref["pos"][mm]) and np.array_equal(nn.cpu().numpy()[mm], ref["normal"][mm])
+            if counted:
+                assert np.array_equal(cnt.cpu().numpy()[:, :3].astype(np.uint32), ref["counters"][:, :3])
+    # what the reference's 64-entry stack (helperDi.slang:136) needs here: depth + 1 <= 30 + ceil(log2 T) + 1
+    depth = oracle.tree_depth(info); deepest = int(oracle.trace_stack_depth(info, aabb, v, t, rs.cpu().numpy()).max())
+    assert deepest <= depth + 1 <= 30 + int(np.ceil(np.log2(len(t)))) + 1 < 64
+    _report("clustered T=%d: LBVH depth %d, deepest reference stack on 40 000 shadow rays %d of 64; reference visits per shadow ray: popped %.1f entered %.1f leaves %.2f; occluded %.3f; foreground %.3f"
+            % (len(t), depth, deepest, *ref["counters"][:, :3].mean(0), mm.mean(), frac))
+
+
+def _frame_vs_oracle(lego, scene_mod, oracle, res, ssaa, spp, seed, what, bounces=2):
+    v, t, W, RR, harness, torch, info, aabb = lego
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from gen_reference_loop import matnet_for
+    from mirres_restir_nerf_mesh_amd._ops import get_ctx
+    mlp = _field(scene_mod, torch)
+    g = harness.build_gbuffer(W, res, res, ssaa, mlp_mat=mlp)
+    env_np = scene_mod.make_env(256, 512)
+    mat, keep, _ = matnet_for(oracle, scene_mod)
+    ctx = get_ctx(g["fx"], g["fy"], max_bounce=bounces)
+    ctx.set_instrument(1); ctx.stats(reset=True)          # counted kernels: same results, plus the private-stack / redo statistics
+    outs, _, _ = RR.render_fused(ctx, W, mlp, False, (1, 1, 1), torch.from_numpy(env_np).cuda(), g["occ"].clone(), g["normal"], g["depth"], g["kd"], g["rm"], g["ray_dir"],
+                                 g["pos"], spp, 2, 2, 2.0, 0.1, 0.001, seed)
+    torch.cuda.synchronize()
+    st = ctx.stats(reset=True); ctx.set_instrument(0)
+    outs2, _, _ = RR.render_fused(ctx, W, mlp, False, (1, 1, 1), torch.from_numpy(env_np).cuda(), g["occ"].clone(), g["normal"], g["depth"], g["kd"], g["rm"], g["ray_dir"],
+                                  g["pos"], spp, 2, 2, 2.0, 0.1, 0.001, seed)
+    c = lambda x: x.detach().cpu().numpy()
+    ref = oracle.render(g["fx"], g["fy"], spp, seed, (info, aabb), v, t, env_np, c(g["occ"])[:, 0], c(g["normal"]), c(g["depth"])[:, 0], c(g["kd"]), c(g["rm"]), c(g["ray_dir"]),
+                        c(g["pos"]), mat=mat, max_bounce=bounces)
+    assert np.abs(ref["indirect"]).max() > 0
+    for o_, o2, n_ in zip(outs, outs2, NAMES):
+        pixel_parity(c(o_), ref[n_], "%s (counted kernels) / %s" % (what, n_), tol=0.0)
+        pixel_parity(c(o2), ref[n_], "%s / %s" % (what, n_), tol=0.0)
+    assert st["any_stack_overflow"] == 0 and st["any_max_stack"] < 64 and st["cl_max_stack"] < 64
+    _report("%s: rays any %d closest %d; production visits per shadow ray: boxes %.1f records %.2f leaves %.2f; deepest private stack: shadow %d, ordered closest %d; "
+            "ordered closest rays handed to the reference-order kernel: %d (%.4f %%)" % (what, st["rays_any"], st["rays_closest"], st["popped"] / max(1, st["rays_any"]),
+            st["entered"] / max(1, st["rays_any"]), st["leaves"] / max(1, st["rays_any"]), st["any_max_stack"], st["cl_max_stack"], st["cl_redo"], 100.0 * st["cl_redo"] / max(1, st["rays_closest"])))
+    return st
+
+
+def test_clustered_one_sample_frame_at_full_size(lego, scene_mod, oracle):
+    """1600 x 1600 internal pixels (800^2, ssaa 2), one sample, two indirect bounces, material field: all 2 560 000 pixels of the six outputs bit-equal."""
+    _frame_vs_oracle(lego, scene_mod, oracle, 800, 2, 1, 2468, "clustered 1600x1600 x 1 spp")
+
+
+def test_clustered_24_sample_frame(lego, scene_mod, oracle):
+    """400 x 400, 24 samples (temporal history, the M cap of 20, ragged batches), material field: bit-equal in every pixel."""
+    st = _frame_vs_oracle(lego, scene_mod, oracle, 400, 1, 24, 97531, "clustered 400x400 x 24 spp")
+    assert st["cl_redo"] < 0.02 * st["rays_closest"]          # the ordered fast path keeps (nearly) all rays

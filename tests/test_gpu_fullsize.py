@@ -165,6 +165,47 @@ def test_one_sample_frame_with_the_material_field_matches_the_oracle_at_full_siz
         pixel_parity(c(o_), ref[n_], "full-size one-sample frame with the material field / " + n_, tol=0.0)
 
 
+def _many_samples_vs_oracle(big, scene_mod, oracle, res, ssaa, spp, bounces, seed, what):
+    v, t, W, RR, harness, torch = big
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from gen_reference_loop import matnet_for
+    from mirres_restir_nerf_mesh_amd._ops import get_ctx
+    from mirres_restir_nerf_mesh_amd.render_helper import MLPTexture3D
+    params, w0, w1, w2 = scene_mod.make_matnet_params(seed=0)
+    mn, mx = scene_mod.material_min_max()
+    mlp = MLPTexture3D(torch.tensor([-1, -1, -1, 1, 1, 1], dtype=torch.float32), channels=6, min_max=(torch.from_numpy(mn).cuda(), torch.from_numpy(mx).cuda()), seed=1)
+    with torch.no_grad():
+        mlp.encoder.params.copy_(torch.from_numpy(params).cuda())
+        for i, w in zip((0, 2, 4), (w0, w1, w2)):
+            mlp.net.net[i].weight.copy_(torch.from_numpy(w).cuda())
+    mat, keep, _ = matnet_for(oracle, scene_mod)
+    g = harness.build_gbuffer(W, res, res, ssaa, mlp_mat=mlp)            # primary-hit materials from the field too, as bench.py renders it
+    env_np = scene_mod.make_env(256, 512)
+    ctx = get_ctx(g["fx"], g["fy"], max_bounce=bounces)
+    outs, _, _ = RR.render_fused(ctx, W, mlp, False, (1, 1, 1), torch.from_numpy(env_np).cuda(), g["occ"].clone(), g["normal"], g["depth"], g["kd"], g["rm"], g["ray_dir"],
+                                 g["pos"], spp, 2, 2, 2.0, 0.1, 0.001, seed)
+    c = lambda x: x.detach().cpu().numpy()
+    info, aabb, _, _ = oracle.bvh_build(v, t)
+    ref = oracle.render(g["fx"], g["fy"], spp, seed, (info, aabb), v, t, env_np, c(g["occ"])[:, 0], c(g["normal"]), c(g["depth"])[:, 0], c(g["kd"]), c(g["rm"]), c(g["ray_dir"]),
+                        c(g["pos"]), mat=mat, max_bounce=bounces)
+    assert np.abs(ref["indirect"]).max() > 0
+    for o_, n_ in zip(outs, ["final_color", "diffuse", "spec", "indirect", "indirect_diff", "indirect_spec"]):
+        pixel_parity(c(o_), ref[n_], what + " / " + n_, tol=0.0)
+
+
+def test_24_sample_frame_800x800_with_the_material_field_matches_the_oracle(big, scene_mod, oracle):
+    """Many samples at (output) size under the driver's signature: 800 x 800 (ssaa 1), 24 spp — temporal history, the M cap (20 x), the batch schedule —
+    material field at every vertex, two indirect bounces: every pixel of the six outputs BIT-EQUAL to the oracle's frame (~40 s of oracle on the box's cores)."""
+    _many_samples_vs_oracle(big, scene_mod, oracle, 800, 1, 24, 2, 8642, "800x800 x 24 spp frame with the material field")
+
+
+def test_configs4_shape_1024_8spp_three_bounces_matches_the_oracle(big, scene_mod, oracle):
+    """BASELINE configs[4]'s shape (1024 x 1024, THREE indirect bounces: MAX_Bounce as a runtime parameter on both sides, material field) at 8 spp against the oracle:
+    bit-equal in every pixel (the 512-spp property test below covers the full sample count)."""
+    _many_samples_vs_oracle(big, scene_mod, oracle, 1024, 1, 8, 3, 1123, "configs[4] shape 1024x1024 x 8 spp x 3 indirect bounces")
+
+
 def test_schedule_does_not_change_the_frame_at_full_size(big, scene_mod, monkeypatch):
     """The frame loop's scheduling choices — K samples per batched launch, the stages spread over 1 to 5 streams — must not change a single bit
     of any output: 1600 x 1600, 6 samples, K = 1 on one stream against K = 4 / 3 / 2 (ragged batches, uneven path-tracing halves) on 2 .. 5 streams."""

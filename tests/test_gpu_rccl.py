@@ -54,9 +54,16 @@ if world == 1:
     plan = [(0, send, recv) for peer, send, recv in D.halo_plan(fy, fx, 0, 2)]
     loc = {k: g[k][lo * fx:hi * fx].contiguous() for k in ("occ", "normal", "depth", "kd", "rm", "ray_dir", "pos")}
     calls = {"rccl": 0, "copy": 0}
+    moved = {"ok": True, "nonzero": False}
     def via_rccl(user, records, sample, stream):
         calls["rccl"] += 1
-        D.exchange_halos(D.device_view(records, (hi - lo, fx, 8)), plan)
+        view = D.device_view(records, (hi - lo, fx, 8))
+        sent = [view[sa:sb].clone() for _, (sa, sb), _ in plan]
+        D.exchange_halos(view, plan)
+        torch.cuda.synchronize()
+        for (_, _, (ra, rb)), s_ in zip(plan, sent):      # the halo rows now hold exactly the rows that were sent (self exchange)
+            moved["ok"] = moved["ok"] and bool(torch.equal(view[ra:rb], s_))
+            moved["nonzero"] = moved["nonzero"] or bool((s_ != 0).any())
         return 0
     def via_copy(user, records, sample, stream):
         calls["copy"] += 1
@@ -71,7 +78,7 @@ if world == 1:
         torch.cuda.synchronize()
         frames.append([s_.clone() for s_ in sums])
     res["p2p_in_callback_equal"] = all(torch.equal(a, b) for a, b in zip(*frames)) and calls == {"rccl": 3, "copy": 3}
-    res["p2p_moved_something"] = bool(frames[0][0][(y1 - lo) * fx:].abs().sum() >= 0)
+    res["p2p_moved_something"] = moved["ok"] and moved["nonzero"]     # received halo rows == sent rows, and those rows carried reservoirs (not all zero)
 torch.cuda.synchronize()
 dist.barrier()
 dist.destroy_process_group()
@@ -123,7 +130,9 @@ def test_two_ranks_over_rccl_on_the_same_gpu_or_its_documented_refusal(tmp_path)
         assert r0["grad_bucket"][:2] == [1.5, 1.5]
         return
     text = "\n".join(o for _, o in outs).lower()
-    refusal = any(k in text for k in ("duplicate gpu", "invalid usage", "invalid device", "same device", "nccl_invalid", "ncclinvalid", "unhandled", "timeout"))
+    # only RCCL's explicit refusal counts; a hang (the harness appends "[timeout]") or any other error is a failure of the exchange code
+    assert "[timeout]" not in text, "two ranks on one GPU hung (a deadlock in the halo exchange / collectives is a bug, not a refusal):\n" + text[-3000:]
+    refusal = any(k in text for k in ("duplicate gpu", "invalid usage", "ncclinvalidusage"))
     rep = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(rep):
         open(os.path.join(rep, "rccl_two_ranks_one_gpu.txt"), "w").write("\n----\n".join(o[-2000:] for _, o in outs))

@@ -47,6 +47,95 @@ def test_bvh_structure_and_bruteforce(oracle, scene_mod):
     assert np.array_equal(anyr["hit"], r["hit"])
 
 
+def test_clustered_mesh_is_what_it_claims(scene_mod):
+    """scene.make_mesh_clustered (the lego-like workload): ~3.3e5 triangles inside the unit bound, seeded, triangle areas spread far beyond 100 : 1,
+    and a few hundred exactly axis-aligned triangles (zero-thickness leaf boxes, helperDi.slang:165)."""
+    v, t = scene_mod.mesh_by_name("clustered")
+    assert 300000 <= len(t) <= 345000 and np.abs(v).max() < 1.0
+    a, b, c = v[t[:, 0]], v[t[:, 1]], v[t[:, 2]]
+    area = 0.5 * np.linalg.norm(np.cross((b - a).astype(np.float64), (c - a).astype(np.float64)), axis=1)
+    assert (area > 0).all() and area.max() / area.min() > 1e4
+    flat = (np.maximum(np.maximum(a, b), c) - np.minimum(np.minimum(a, b), c)).min(axis=1) == 0
+    assert 100 < int(flat.sum()) < 2000
+    v2, t2 = scene_mod.mesh_by_name("clustered")
+    assert np.array_equal(v, v2) and np.array_equal(t, t2)
+    small_v, small_t = scene_mod.make_mesh_clustered(13000)
+    assert 10000 <= len(small_t) <= 20000          # the floor: stud and part counts do not scale, only tessellations do
+
+
+def test_clustered_mesh_bvh_against_brute_force_and_the_flat_box_quirk(oracle, scene_mod):
+    """On the small clustered mesh: every BVH hit is a triangle brute force accepts; where brute force accepts nothing the BVH misses; and a triangle whose
+    leaf box has zero thickness (the axis-aligned plates) is NEVER reported although brute force accepts it — aabb_hit rejects t_max <= t_min (helperDi.slang:165)."""
+    v, t = scene_mod.make_mesh_clustered(13000)
+    info, aabb, srt, h = oracle.bvh_build(v, t)
+    T = len(t)
+    L, R = info[:T - 1, 0], info[:T - 1, 1]
+    assert np.array_equal(aabb[:T - 1, :3], np.minimum(aabb[L, :3], aabb[R, :3])) and np.array_equal(aabb[:T - 1, 3:], np.maximum(aabb[L, 3:], aabb[R, 3:]))
+    tv = v[t]
+    flat = (tv.max(1) - tv.min(1)).min(axis=1) == 0
+    assert flat.sum() > 100
+    eye, rd = scene_mod.camera_rays(28, 28)
+    n = 28 * 28
+    o = np.repeat(eye[None], n, 0)
+    # a second bundle straight down onto the axis-aligned plates
+    ctr = tv[flat].mean(1)[::max(1, int(flat.sum()) // 60)]
+    o2 = ctr + np.array([0.003, 0.002, 0.5], np.float32); d2 = np.repeat(np.array([[0.0, 0.0, -1.0]], np.float32), len(o2), 0)
+    o = np.concatenate([o, o2]).astype(np.float32); dd = np.concatenate([rd, d2]).astype(np.float32)
+    r = oracle.trace(info, aabb, v, t, oracle.make_rays(o, dd), True, True)
+    dn = dd / np.linalg.norm(dd, axis=1, keepdims=True)
+    br = _brute(v, t, o, dn.astype(np.float32))
+    saw_flat_only = 0
+    for i, (m, tt) in enumerate(br):
+        if r["hit"][i]:
+            assert m[r["prim"][i]] and not flat[r["prim"][i]]
+        if not m.any():
+            assert not r["hit"][i]
+        if m.any() and not (m & ~flat).any():
+            saw_flat_only += 1
+            assert not r["hit"][i], "only zero-thickness-box triangles on this line: the reference can never enter their leaves"
+    assert saw_flat_only > 0 and r["counters"][:, 3].sum() == 0
+
+
+def adversarial_chain_mesh(dups=64):
+    """Deep LBVH + a line through every leaf box that misses every triangle.  The scene extent is [-1, 1]^3; triangle k (k = 1..27) has its box centre in the
+    cell whose Morton code has the top bit of every axis and the next k bits set (x, y, z cells 1024 - 2^(9-j)): sorted, every split peels ONE leaf off to the
+    left and the chain continues to the right — bvh_hit pushes left then right (helperDi.slang:245-246), so the lefts pile up.  `dups` more triangles share
+    the deepest cell (identical codes: told apart by sorted position only).  Every box is [2c - 1, 1] per axis, hence contains the line (1 - lx, 1 - ly, .);
+    each triangle covers the half of its x / y rectangle the line does not pass.  Returns (verts, tris, (lx, ly))."""
+    tris = []
+    lx, ly = 0.0004, 0.0014
+    def add(cell_x, cell_y, cell_z, jitter=0.0):
+        c = [2.0 * (q + 0.5) / 1024.0 - 1.0 for q in (cell_x, cell_y, cell_z)]
+        x0, y0, z0 = 2 * c[0] - 1, 2 * c[1] - 1, 2 * c[2] - 1
+        tris.append([[1.0, 1.0, 1.0 + jitter], [x0, y0, z0], [x0, 1.0, 0.5 * (1 + z0)]])
+    hb = lambda n: 1024 - (1 << (9 - n))
+    for k in range(1, 28):       # bit 3i+2 of the code is x's bit i, 3i+1 y's, 3i z's: the next k bits set = x, then y, then z cells
+        j, r_ = divmod(k, 3)
+        add(hb(j + (1 if r_ >= 1 else 0)), hb(j + (1 if r_ >= 2 else 0)), hb(j))
+    for q in range(dups):
+        add(1023, 1023, 1023, jitter=-1e-7 * q)
+    tris.append([[1, 1, 1], [-1, -1, -1], [-1, 1, 0]])                # fixes the scene extent at [-1, 1]^3
+    v = np.asarray(tris, np.float32).reshape(-1, 3); t = np.arange(len(v), dtype=np.int32).reshape(-1, 3)
+    return v, t, (lx, ly)
+
+
+def test_reference_stack_cannot_overflow(oracle):
+    """The 64-entry stack of bvh_hit (helperDi.slang:136) holds at most depth + 1 entries, and the LBVH's depth is bounded by the bits of its sort key:
+    30 Morton bits + ceil(log2 T) position bits (lbvh_hierarchy.slang:40-60) <= 61 for any int32 T.  An adversarial mesh — a 30-deep Morton chain
+    (box centres at cells 1024 - 2^(10-j): codes with their k high bits set, so that the chain runs through RIGHT children and the left ones pile up on the stack) with 64 identical-code triangles hanging off the deepest cell, every box containing one common line — and a
+    ray along that line that misses every triangle: the deepest the stack gets is depth + 1, far below 64, nothing overflows, and the answer is a miss."""
+    v, t, (lx, ly) = adversarial_chain_mesh()
+    info, aabb, srt, h = oracle.bvh_build(v, t)
+    depth = oracle.tree_depth(info)
+    assert depth <= 30 + int(np.ceil(np.log2(len(t)))) and depth >= 27          # the chain is there
+    rays = oracle.make_rays(np.array([[1.0 - lx, 1.0 - ly, -0.5]], np.float32), np.array([[0.0, 0.0, 1.0]], np.float32))
+    r = oracle.trace(info, aabb, v, t, rays, True, True)
+    deepest = int(oracle.trace_stack_depth(info, aabb, v, t, rays)[0])
+    assert r["hit"][0] == 0 and r["counters"][0, 3] == 0
+    assert r["counters"][0, 2] >= 60, r["counters"][0]                          # the ray really goes through (nearly) every leaf box
+    assert depth // 2 < deepest <= depth + 1 < 64, (depth, deepest)
+
+
 def test_negative_t_quirk_is_preserved(oracle):
     """triangle_hit ignores the t interval (helperDi.slang:172-195): a triangle BEHIND the origin whose box contains the origin is a hit."""
     v = np.array([[-1, -1, 0.3], [1, -1.1, -0.3], [0, 1, 0.1], [5, 5, 5], [6, 5, 5.2], [5, 6, 5.1]], np.float32)
