@@ -386,10 +386,11 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_persist(BvhView B, con
 // Depth of the shadow-ray kernel's private stack (LDS part + scratch). A 4-wide node defers at most three references and the 4-wide collapse is never
 // deeper than the LBVH it was collapsed from, whose depth is bounded by the bits of the augmented sort key: 30 Morton bits + ceil(log2 T) position bits
 // (lbvh_hierarchy.slang:40-60: every internal node splits its range at the highest differing bit of (code, position)). Hence at most
-// 3 * (30 + ceil(log2 T)) entries: 147 for T < 2^19, 183 for any T < 2^31 — MR_ANY_STACK = 192 cannot overflow ("Stack bounds").
+// 3 * (30 + ceil(log2 T)) entries for the collapsed reference LBVH; the private extended-Morton hierarchy (bvh_build.hip) has 32 + 6 key bits that can differ:
+// 3 * (38 + ceil(log2 T)) = 171 for T < 2^19, 207 for any T < 2^31 — MR_ANY_STACK = 224 cannot overflow ("Stack bounds").
 // (The reference's own stack of 64 {index, left, right, prim} entries, helperDi.slang:136, holds at most depth + 1 <= 62 entries: it cannot overflow either.)
 #ifndef MR_ANY_STACK
-#define MR_ANY_STACK 192
+#define MR_ANY_STACK 224
 #endif
 #define MR_TOPBIT 0x20000000
 // ---------------------------------------------------------------- shadow rays on the COMPRESSED 4-wide collapse (engine.hpp Node4q / LeafRec)
@@ -687,9 +688,17 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const
 
 // ---------------------------------------------------------------- closest hit: ordered 4-wide fast path + exact fallback
 // The reference's closest-hit result depends on its (unordered, right-first) visiting order only in two situations:
-//   (a) a triangle is accepted with t <= 0 (triangle_hit ignores the t interval, helperDi.slang:172-195): `closest` drops to <= t_min and the
+//   (a) a triangle is accepted with t <= t_min (triangle_hit ignores the t interval, helperDi.slang:172-195): `closest` drops to <= t_min and the
 //       rest of the search is culled, so WHICH behind-the-origin triangle is found first matters;
 //   (b) two different triangles are accepted with exactly the same t (the later one in visiting order provides prim / normal).
+// Case (a) is common on real meshes (46 % of the indirect rays of the lego-like scene: a large triangle's box contains the origins of the rays leaving the
+// faces around it) and it has an order-free answer (round 4). bvh_hit pushes left then right and pops the right child first, and leaf slots are the
+// sorted Morton positions, so the reference reaches leaves in DESCENDING slot order. A triangle accepted behind the origin has the origin inside its
+// leaf box along the line: its entry distance is t_min itself, smaller than any `closest` that positive hits can have produced, so it is never culled —
+// neither by the reference before it gets there nor by this kernel. Hence: if any triangle is accepted with t <= t_min, the reference's search ends at the
+// one with the HIGHEST slot, and reports that triangle (t = closest = its t, prim, normal: `now_t <= closest`). This kernel keeps the highest such slot
+// (`neg_t` set), does not let those hits shrink `closest`, and from the first of them on only looks into boxes that contain the origin. The rare leaf whose
+// computed entry distance is not exactly t_min although its triangle's t is <= t_min (rounding of two different expressions) still goes to the redo list.
 // Otherwise every traversal that culls with `closest > tn` finds the same minimum: the minimum triangle's boxes all contain its hit point,
 // so their entry distance tn <= t_min_hit <= closest and they are never culled (DESIGN.md §Traversal exactness). This kernel therefore walks
 // the 4-wide collapse front to back (far more culling than the reference order), watches for (a) and (b), and appends the few affected rays
@@ -722,6 +731,8 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_closest4(BvhView B, co
     const float scene_bs = scene_bound(B.root_box);
     const int NONE = 0x7fffffff;
     int cur = NONE, sp = 0, best_slot = -1; uint32_t ridx = 0; bool any_hit = false, need_redo = false;
+    const float NO_NEG = 3.0e38f;
+    float neg_t = NO_NEG;      // case (a): t of the accepted triangle with t <= t_min and the highest slot (then best_slot / best_u / best_v are that triangle's); NO_NEG: none yet
     uint2 spill[MR_STACK - MR_LDS_STACK];
     unsigned long long c_boxes = 0, c_nodes = 0, c_leaves = 0; int c_maxsp = 0;
     while (true) {
@@ -738,7 +749,7 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_closest4(BvhView B, co
                     { float dx = d.x, dy = d.y, dz = d.z;
                       if (dx == 0.f) dx = 0.000001f; if (dy == 0.f) dy = 0.000001f; if (dz == 0.f) dz = 0.000001f;
                       ix = 1.0f / dx; iy = 1.0f / dy; iz = 1.0f / dz; }
-                    sp = 0; any_hit = false; need_redo = false; best_u = 0.f; best_v = 0.f; best_slot = -1;
+                    sp = 0; any_hit = false; need_redo = false; best_u = 0.f; best_v = 0.f; best_slot = -1; neg_t = NO_NEG;
                     rc = ray_margins(scene_bs, ox, oy, oz, ix, iy, iz);
                     const float o3[3] = {ox, oy, oz}, i3[3] = {ix, iy, iz};
                     Slab s0 = slab(B.root_box, B.root_box + 3, o3, i3, t_min);
@@ -801,8 +812,14 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_closest4(BvhView B, co
                                     if (!(v < 0 || u + v > 1)) {
                                         const float t = dot(E2, Q) * invDet;
                                         any_hit = true;
-                                        if (!(t > 0.f)) need_redo = true;                                               // case (a) (also NaN)
-                                        if (t <= closest) {
+                                        if (t <= t_min) {                                                               // case (a): see the head comment
+                                            if (etn != t_min) need_redo = true;                                         // entry distance and t disagree about the origin: let the reference order decide
+                                            if (neg_t == NO_NEG || slot > best_slot) { best_slot = slot; best_u = u; best_v = v; neg_t = t; }
+                                            // nothing in front of the origin matters any more: only boxes that contain the origin (entry distance t_min) can hold
+                                            // another such triangle. (`closest` is no longer a hit distance and positive hits are no longer recorded.)
+                                            closest = fminf(closest, fmaxf(t_min, 0.f) + 1.17549435e-38f);
+                                        } else if (!(t > 0.f)) need_redo = true;                                        // NaN (or t_min < t <= 0 for a caller's negative t_min)
+                                        else if (neg_t == NO_NEG && t <= closest) {
                                             if (t == closest && best_slot >= 0 && best_slot != slot) need_redo = true;    // case (b)
                                             closest = t; best_u = u; best_v = v; best_slot = slot;
                                         }
@@ -854,6 +871,7 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_closest4(BvhView B, co
             fin = false;
             if (need_redo) redo[atomicAdd(redo_count, 1u)] = ridx;
             TraceOut r; r.hit = any_hit; r.t = any_hit ? closest : 0.f; r.u = best_u; r.v = best_v; r.slot = best_slot; r.d = d;
+            if (neg_t != NO_NEG) r.t = neg_t;      // case (a): the reference's search ended at that triangle
             v3 p, nn_; int pr;
             finish_closest(B, r, ro, p, nn_, pr);
             if (rec) {

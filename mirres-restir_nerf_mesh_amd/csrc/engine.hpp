@@ -82,6 +82,8 @@ struct mirres_bvh {
     mr::Node4q* nodes4q = nullptr;  // [T-1] compressed 4-wide nodes (shadow rays)
     mr::LeafRec* leaves = nullptr;  // [T]
     mr::Node4q* top85q = nullptr, *top341q = nullptr;   // [85], [341] breadth-first prefixes of nodes4q, children inside tagged MR_TOPBIT
+    // private steering hierarchy (bvh_build.hip k_emc_*): extended-Morton keys / slots, 64-bit keys, node arrays in the reference's own layout (leaf info[.][2] = slot)
+    uint32_t *p_keys = nullptr, *p_vals = nullptr, *p_range = nullptr; unsigned long long* p_key64 = nullptr; int32_t* p_info = nullptr; float* p_aabb = nullptr;
     float* root_box = nullptr;      // [6]
     uint32_t* work = nullptr;       // [MR_WSETS * MR_WSET] head sets of the persistent traversal kernels: 0/1 chain, 2/3 API, 4-6 ordered closest + redo, 7/8 bulk stream, 9/10 path-tracing stream,
                                     // 11 final-stage stream, 12-14 ordered closest + redo and 15/16 any / closest of the second path-tracing stream

@@ -14,7 +14,7 @@ res = int(sys.argv[1]) if len(sys.argv) > 1 else 1600
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 7
 L = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 mode = int(sys.argv[4]) if len(sys.argv) > 4 else 0
-v, t = S.make_mesh(7, 64)
+v, t = S.mesh_by_name(os.environ.get("MIRRES_MESH", "icosphere"))
 W = RR.restirbvhWorker(torch.from_numpy(v).cuda(), torch.from_numpy(t).cuda()); W.update_mesh(W.vrt, W.v_ind)
 g = harness.build_gbuffer(W, res, res, 1)
 fg = g["occ"][:, 0] > 0.5

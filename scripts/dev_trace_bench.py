@@ -7,7 +7,7 @@ from mirres_restir_nerf_mesh_amd import renderer_restir as RR, harness
 from mirres_restir_nerf_mesh_amd._lib import lib, check
 S = M.scene
 res = int(sys.argv[1]) if len(sys.argv) > 1 else 1600
-v, t = S.make_mesh(7, 64)
+v, t = S.mesh_by_name(os.environ.get("MIRRES_MESH", "icosphere"))
 W = RR.restirbvhWorker(torch.from_numpy(v).cuda(), torch.from_numpy(t).cuda()); W.update_mesh(W.vrt, W.v_ind)
 g = harness.build_gbuffer(W, res, res, 1)
 fg = g["occ"][:, 0] > 0.5
