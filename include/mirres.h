@@ -263,6 +263,12 @@ typedef struct mirres_render_args {
     int strip_full_fy, strip_y_off, own_y0, own_y1;
     int (*halo)(void* user, float* records, int sample, void* stream);
     void* halo_user;
+    /* strip_overlap != 0 (round 4; needs `halo`): the spatial pass of every sample runs in two parts. `halo` is called with a SIDE stream (ordered after the
+     * temporal pass) and must enqueue the exchange there; meanwhile the caller's stream does the spatial pass of the INTERIOR rows — the own rows at least
+     * gather_radius away from a strip edge with a neighbouring rank, whose neighbours are all own rows — and only then waits for the exchange and does the border
+     * rows. Same results bit for bit; the exchange leaves the per-sample critical chain at the price of three more launches per sample (and the next sample's
+     * temporal merge is not fused into the resolve kernel). Strips too short to have interior rows fall back to the in-line exchange.                       */
+    int strip_overlap;
 } mirres_render_args_t;
 int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args_t* a, void* stream);
 /* Backward of the frame's DIRECT lighting sums w.r.t. what the reference differentiates (EvaluateFinalSamples_di.backward +

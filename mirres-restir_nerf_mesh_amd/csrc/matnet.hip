@@ -395,4 +395,11 @@ int mirres_matnet_scatter(const mirres_matnet_t* m, const float* occ, const floa
     return launch_matnet_scatter(m, occ, pos, n, kd, rough_metal, use_scale, h_scale3, nullptr, nullptr, (hipStream_t)stream);
 }
 
+// development aid (not part of include/mirres.h): the PRODUCTION material lookup of mirres_render's indirect vertices — compacted slot list -> fused hash-grid gather + MFMA MLP
+// (k_mlp_mfma<1, 2>) -> scatter into kd / rough_metal — on caller-given points, for scripts/dev_grid_locality.py. index: int32[n] scratch, count: uint32[1] scratch.
+int mirres_debug_matnet_scatter_mfma(const mirres_matnet_t* m, const float* occ, const float* pos, int n, float* kd, float* rough_metal, int32_t* index, uint32_t* count, void* stream) {
+    if (!m || !occ || !pos || !kd || !rough_metal || !index || !count || n <= 0) return MIRRES_E_ARG;
+    return launch_matnet_scatter_mfma(m, occ, pos, n, kd, rough_metal, 0, nullptr, index, count, (hipStream_t)stream, nullptr, nullptr);
+}
+
 }  // extern "C"

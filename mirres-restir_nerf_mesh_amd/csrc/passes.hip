@@ -312,30 +312,16 @@ __global__ void __launch_bounds__(MR_BLOCK) k_initial_resolve(ResD R, int N, con
 }
 
 // ---------------------------------------------------------------- temporal resampling (TemporalResampling.slang:23-135)
-__global__ void __launch_bounds__(MR_BLOCK) k_temporal(mirres_config_t C, EnvD E, GBufD G, GBufD P, ResD R, ResD PR, const float* __restrict__ motion,
-                                                       uint32_t frameIndex, int fx, int fy, int N, int y_off) {
-    const int pi = blockIdx.x * blockDim.x + threadIdx.x;
-    if (pi >= N) return;
-    const GPix gc = load_gpix(G, pi);
-    if (gc.occ < 0.1f) return;
-    const uint32_t x = (uint32_t)(pi % fx), y = (uint32_t)(pi / fx);
-    uint32_t sg = seed_generator(x, y + (uint32_t)y_off, frameIndex);
-    float mvx = motion ? motion[2 * (size_t)pi] : 0.f, mvy = motion ? motion[2 * (size_t)pi + 1] : 0.f;
-    float jx = rnd(sg), jy = rnd(sg);
-    int ppx = (int)(((float)x + mvx * (float)(uint32_t)fx) + (jx * 1.f - 0.f));
-    int ppy = (int)(((float)y + mvy * (float)(uint32_t)fy) + (jy * 1.f - 0.f));
-    if (ppx >= fx || ppx < 0 || ppy >= fy || ppy < 0) return;
-    const size_t qi = (size_t)ppy * fx + ppx;
-    const GPix gq = load_gpix(P, qi);
-    if (gq.occ < 0.1f) return;
+// the merge itself (TemporalResampling.slang:60-135) for one pixel: current reservoir `cur`, history `prev` taken from pixel q (G-buffer entry gq; `same` = q is this pixel).
+// Returns false when the neighbour is rejected (the current reservoir stays as it is); sg = the pixel's generator after the two jitter draws.
+MR_DEV bool temporal_merge(const mirres_config_t& C, const EnvD& E, const GPix& gc, const GPix& gq, ResV cur, ResV prev, bool same, uint32_t& sg, Ris& s) {
     const v3 n = gc.n; const float depth = gc.depth;
     const v3 pn = gq.n; const float pdepth = gq.depth;
-    ResV cur = load_res(R, pi), prev = load_res(PR, qi);
     prev.M = min(prev.M, cur.M * C.max_history);
-    if (!(dot(n, pn) >= 0.5f && fabsf(depth - pdepth) <= 0.1f * depth)) return;  // isValidNeighbor res.slang:63-68
+    if (!(dot(n, pn) >= 0.5f && fabsf(depth - pdepth) <= 0.1f * depth)) return false;  // isValidNeighbor res.slang:63-68
     const rtarget::Ctx ctx = rtarget::make_ctx(n, gc.rd, gc.brdf);
     const rtarget::Ctx pctx = rtarget::make_ctx(pn, gq.rd, gq.brdf);
-    Ris s = empty_ris();
+    s = empty_ris();
     v3 ldir = oct_decode(V2(cur.light_data.y, cur.light_data.z));
     const float clum = sample_lum(E, cur, ldir);
     float targetPdf = target_lum(ctx, clum, ldir);
@@ -352,7 +338,7 @@ __global__ void __launch_bounds__(MR_BLOCK) k_temporal(mirres_config_t C, EnvD E
         float w = preTarget * prev.weight * prev.M;
         s.weightSum += w; s.M += prev.M;
         usedPrev = rnd(sg) * s.weightSum < w;
-        if (usedPrev) { s.light_data = prev.light_data; s.inv_pdf = prev.light_pdf; s.weight = preTarget; s.vcode = (qi == (size_t)pi) ? prev.vcode : 0; s.lum = plum; }
+        if (usedPrev) { s.light_data = prev.light_data; s.inv_pdf = prev.light_pdf; s.weight = preTarget; s.vcode = same ? prev.vcode : 0; s.lum = plum; }
     }
     v3 sdir = oct_decode(V2(s.light_data.y, s.light_data.z));
     // the selected sample is the current one, the history's, or none (nothing selected: s.weight = 0 and the result is the empty reservoir whatever this luminance is)
@@ -361,7 +347,32 @@ __global__ void __launch_bounds__(MR_BLOCK) k_temporal(mirres_config_t C, EnvD E
     float prevPdf = target_lum(pctx, slum, sdir);
     float normalization = mr_div(usedPrev ? prevPdf : currentPdf, cur.M * currentPdf + prev.M * prevPdf);
     s.weight = s.weight > 0.f ? mr_div(s.weightSum * normalization, s.weight) : 0.f;
-    store_ris(R, pi, s);
+    return true;
+}
+// the history pixel of (x, y): the jitter int2(pixel + rnd) (TemporalResampling.slang:40-52; motion vectors optional) — almost always the pixel itself, but
+// (float)x + u rounds up to x + 1 for the largest u. Returns false when it leaves the frame.
+MR_DEV bool temporal_history_pixel(uint32_t x, uint32_t y, float mvx, float mvy, int fx, int fy, uint32_t& sg, int& ppx, int& ppy) {
+    float jx = rnd(sg), jy = rnd(sg);
+    ppx = (int)(((float)x + mvx * (float)(uint32_t)fx) + (jx * 1.f - 0.f));
+    ppy = (int)(((float)y + mvy * (float)(uint32_t)fy) + (jy * 1.f - 0.f));
+    return !(ppx >= fx || ppx < 0 || ppy >= fy || ppy < 0);
+}
+__global__ void __launch_bounds__(MR_BLOCK) k_temporal(mirres_config_t C, EnvD E, GBufD G, GBufD P, ResD R, ResD PR, const float* __restrict__ motion,
+                                                       uint32_t frameIndex, int fx, int fy, int N, int y_off) {
+    const int pi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pi >= N) return;
+    const GPix gc = load_gpix(G, pi);
+    if (gc.occ < 0.1f) return;
+    const uint32_t x = (uint32_t)(pi % fx), y = (uint32_t)(pi / fx);
+    uint32_t sg = seed_generator(x, y + (uint32_t)y_off, frameIndex);
+    float mvx = motion ? motion[2 * (size_t)pi] : 0.f, mvy = motion ? motion[2 * (size_t)pi + 1] : 0.f;
+    int ppx, ppy;
+    if (!temporal_history_pixel(x, y, mvx, mvy, fx, fy, sg, ppx, ppy)) return;
+    const size_t qi = (size_t)ppy * fx + ppx;
+    const GPix gq = load_gpix(P, qi);
+    if (gq.occ < 0.1f) return;
+    Ris s;
+    if (temporal_merge(C, E, gc, gq, load_res(R, pi), load_res(PR, qi), qi == (size_t)pi, sg, s)) store_ris(R, pi, s);
 }
 
 // ---------------------------------------------------------------- spatial resampling (SpatialResampling.slang:178-322)
@@ -398,17 +409,20 @@ MR_DEV int tile_pixel_v(int fx, int fy, int tw, int N, int vt) {   // tile_pixel
 // ITEMS (mirres_render's chain: packed pixel records and reservoirs exist): the queue receives one (canonical pixel, neighbour pixel) pair per accepted
 // neighbour — 8 bytes instead of two 32-byte rays — and k_trace_any4q<.., SRC = 1> forms the rays (engine.hpp RaySrc). Forming and writing the rays was 135 of
 // this kernel's 214 us per sample (five position / light gathers per pixel, 290 MB of ray records per launch).
+struct RowSet { int a, b, mode; };    // mode 0: every row; 1: rows in [a, b); 2: rows outside [a, b)  (the interior / border parts of a strip's spatial pass)
+MR_DEV bool row_in(const RowSet& r, int pi, int fx) { if (r.mode == 0) return true; const int y = pi / fx; const bool in = y >= r.a && y < r.b; return r.mode == 1 ? in : !in; }
 template <int MR_MAX_NB, bool ITEMS = false>   // 5 (the reference's neighbour count) or 8: bounds the unrolled gathers, i.e. the registers held
 __global__ void __launch_bounds__(MR_SGEN_BLOCK / MR_SGEN_PX) k_spatial_gen(mirres_config_t C, GBufD G, ResD PR, const float* __restrict__ noff, uint32_t frameIndex,
                                                           int fx, int fy, int N, int y_off, const float* __restrict__ occ_own, Ray* __restrict__ q,
-                                                          uint32_t* __restrict__ q_count, int32_t* __restrict__ slot_out, uint32_t* __restrict__ mask_out) {
+                                                          uint32_t* __restrict__ q_count, int32_t* __restrict__ slot_out, uint32_t* __restrict__ mask_out, RowSet rows) {
     // strip sharding: y_off = global row of local row 0 (seeds), occ_own = occupancy with the halo rows zeroed (which pixels this rank merges);
     // neighbours are tested against the true G-buffer, halo rows included
     const int k = min(C.neighbor_count, MR_MAX_NB);
     int pis[MR_SGEN_PX]; uint32_t masks[MR_SGEN_PX]; int nbs[MR_SGEN_PX][MR_MAX_NB]; uint32_t cnt_all = 0;
 #pragma unroll
     for (int px = 0; px < MR_SGEN_PX; px++) {
-    const int pi = tile_pixel_v(fx, fy, MR_SGEN_TILE, N, (int)threadIdx.x + px * (MR_SGEN_BLOCK / MR_SGEN_PX));
+    int pi = tile_pixel_v(fx, fy, MR_SGEN_TILE, N, (int)threadIdx.x + px * (MR_SGEN_BLOCK / MR_SGEN_PX));
+    if (pi < N && !row_in(rows, pi, fx)) pi = N;       // not this launch's rows: no pixel (nothing read, nothing written)
     uint32_t mask = 0, cnt = 0;
     int nb[MR_MAX_NB];
 #pragma unroll
@@ -506,26 +520,19 @@ __global__ void __launch_bounds__(MR_SGEN_BLOCK / MR_SGEN_PX) k_spatial_gen(mirr
 #else
 #define MR_SRES_ATTR
 #endif
+// the spatial merge of ONE pixel (SpatialResampling.slang:200-322) from the generator's acceptance mask and the traced hit bits; false: the pixel is background (or,
+// under strip sharding, not this rank's): its output reservoir is empty
 template <int MR_MAX_NB>
-__global__ void MR_SRES_ATTR __launch_bounds__(MR_SRES_TILE * MR_SRES_TILE) k_spatial_resolve(mirres_config_t C, EnvD E, GBufD G, ResD R, ResD PR, const float* __restrict__ noff,
-                                                              uint32_t frameIndex, int fx, int fy, int N, int y_off, const float* __restrict__ occ_own,
-                                                              const int32_t* __restrict__ slot, const uint32_t* __restrict__ mask_in, const int32_t* __restrict__ hit,
-                                                              uint32_t* __restrict__ reset_counter, uint32_t* __restrict__ reset_heads) {
-    // mirres_render's chain: the shadow-ray launch of this pass has finished (stream order), so the ray counter and the traversal work heads it used
-    // are zeroed here for the next sample's pass instead of by two separate fill launches per sample
-    if (reset_heads && blockIdx.x == 0) {
-        for (int i = threadIdx.x; i < MR_WSET; i += MR_SRES_TILE * MR_SRES_TILE) reset_heads[i] = 0u;
-        if (threadIdx.x == 0) *reset_counter = 0u;
-    }
-    const int pi = tile_pixel(fx, fy, MR_SRES_TILE, N);
-    if (pi >= N) return;
+MR_DEV bool spatial_pixel(const mirres_config_t& C, const EnvD& E, const GBufD& G, const ResD& PR, const float* __restrict__ noff, uint32_t frameIndex, int fx, int y_off,
+                          const float* __restrict__ occ_own, const int32_t* __restrict__ slot, const uint32_t* __restrict__ mask_in, const int32_t* __restrict__ hit,
+                          int pi, Ris& s) {
     const GPix gc = load_gpix(G, pi);
-    if ((occ_own ? occ_own[pi] : gc.occ) < 0.1f) { store_zero(R, pi); return; }
+    if ((occ_own ? occ_own[pi] : gc.occ) < 0.1f) return false;
     const int x = pi % fx, y = pi / fx;
     uint32_t sg = seed_generator((uint32_t)x, (uint32_t)(y + y_off), frameIndex);
     const v3 n = gc.n;
     const rtarget::Ctx ctx = rtarget::make_ctx(n, gc.rd, gc.brdf);
-    Ris s = empty_ris();
+    s = empty_ris();
     const uint32_t startIndex = (uint32_t)(rnd(sg) * C.neighbor_offset_count);
     ResV cur = load_res(PR, pi);
     const v3 cdir = oct_decode(V2(cur.light_data.y, cur.light_data.z));
@@ -580,7 +587,55 @@ __global__ void MR_SRES_ATTR __launch_bounds__(MR_SRES_TILE * MR_SRES_TILE) k_sp
     }
     s.M = (float)cur.M;
     s.weight = s.weight > 0.f ? mr_div(mr_div(s.weightSum, (float)validNeighbors), s.weight) : 0.f;
+    return true;
+}
+// what store_ris leaves in memory for a merge result, as the next pass would load it (packed records)
+MR_DEV ResV stored_res(const Ris& s, bool fg) {
+    ResV r; r.has_lum = true;
+    if (!fg || isinf(s.weight) || isnan(s.weight)) { r.light_data = V3(0.f); r.light_pdf = 0.f; r.M = 0; r.weight = 0.f; r.vcode = 0; r.lum = 0.f; return r; }
+    r.light_data = s.light_data; r.light_pdf = s.inv_pdf; r.M = (int)s.M; r.weight = s.weight; r.vcode = s.vcode; r.lum = s.lum;
+    return r;
+}
+// FUSE (mirres_render's chain, round 4): the temporal merge of the NEXT sample (TemporalResampling.slang:23-135) runs in the same thread right after this sample's
+// spatial merge. Its history is the spatial output of the pixel the jitter selects — the pixel itself (in registers: no reservoir round trip, no G-buffer
+// re-read, no launch) or, when (float)x + u rounds up (a few hundred pixels of a 1600 x 1600 frame per sample), its right / lower neighbour, whose spatial merge this
+// thread then recomputes from the same inputs (the neighbour's own thread may not have stored it yet). NR = the next sample's initial reservoirs, merged in place.
+template <int MR_MAX_NB, bool FUSE>
+__global__ void MR_SRES_ATTR __launch_bounds__(MR_SRES_TILE * MR_SRES_TILE) k_spatial_resolve(mirres_config_t C, EnvD E, GBufD G, ResD R, ResD PR, const float* __restrict__ noff,
+                                                              uint32_t frameIndex, int fx, int fy, int N, int y_off, const float* __restrict__ occ_own,
+                                                              const int32_t* __restrict__ slot, const uint32_t* __restrict__ mask_in, const int32_t* __restrict__ hit,
+                                                              uint32_t* __restrict__ reset_counter, uint32_t* __restrict__ reset_heads, ResD NR, uint32_t next_frame, RowSet rows) {
+    // mirres_render's chain: the shadow-ray launch of this pass has finished (stream order), so the ray counter and the traversal work heads it used
+    // are zeroed here for the next sample's pass instead of by two separate fill launches per sample
+    if (reset_heads && blockIdx.x == 0) {
+        for (int i = threadIdx.x; i < MR_WSET; i += MR_SRES_TILE * MR_SRES_TILE) reset_heads[i] = 0u;
+        if (threadIdx.x == 0) *reset_counter = 0u;
+    }
+    const int pi = tile_pixel(fx, fy, MR_SRES_TILE, N);
+    if (pi >= N || !row_in(rows, pi, fx)) return;
+    Ris s;
+    const bool fg = spatial_pixel<MR_MAX_NB>(C, E, G, PR, noff, frameIndex, fx, y_off, occ_own, slot, mask_in, hit, pi, s);
+    if (!fg) { store_zero(R, pi); return; }
     store_ris(R, pi, s);
+    if (FUSE) {
+        const uint32_t x = (uint32_t)(pi % fx), y = (uint32_t)(pi / fx);
+        uint32_t sg = seed_generator(x, y + (uint32_t)y_off, next_frame);
+        int ppx, ppy;
+        if (!temporal_history_pixel(x, y, 0.f, 0.f, fx, fy, sg, ppx, ppy)) return;
+        const int qi = ppy * fx + ppx;
+        GPix gc = load_gpix(G, pi); if (occ_own) gc.occ = occ_own[pi];
+        GPix gq = gc; ResV prev;
+        if (qi == pi) prev = stored_res(s, true);
+        else {
+            gq = load_gpix(G, qi); if (occ_own) gq.occ = occ_own[qi];
+            if (gq.occ < 0.1f) return;
+            Ris sq;
+            const bool qfg = spatial_pixel<MR_MAX_NB>(C, E, G, PR, noff, frameIndex, fx, y_off, occ_own, slot, mask_in, hit, qi, sq);
+            prev = stored_res(sq, qfg);
+        }
+        Ris t;
+        if (temporal_merge(C, E, gc, gq, load_res(NR, pi), prev, qi == pi, sg, t)) store_ris(NR, pi, t);
+    }
 }
 
 // ---------------------------------------------------------------- final-sample visibility + evaluation (EvaluateFinalSamples.slang:84-188)
@@ -762,6 +817,48 @@ int launch_final_batch(mirres_ctx* ctx, mirres_bvh* bvh, const mirres_env_t* env
     return 0;
 }
 
+// spatial pass; next_res != NULL (mirres_render's chain, packed reservoirs): the temporal merge of the next sample is fused into the resolve kernel (k_spatial_resolve<., true>)
+int launch_spatial(mirres_ctx* ctx, mirres_bvh* bvh, const mirres_env_t* env, const mirres_gbuf_t* g, const mirres_res_t* res, const mirres_res_t* prev_res,
+                   const float* neighbor_offsets, uint32_t frameIndex, hipStream_t s, const mirres_res_t* next_res, uint32_t next_frame) {
+    if (!ctx || !bvh || !env || !g || !res || !prev_res) { set_error("mirres_restir_spatial: null"); return MIRRES_E_ARG; }
+    const int N = (int)ctx->N;
+    const float* noff = neighbor_offsets ? neighbor_offsets : ctx->noff;
+    const bool fold = ctx->chain_reset;                         // inside mirres_render's chain (its own stream, its own work heads)
+    if (!(fold && ctx->chain_clean)) MR_HIP(hipMemsetAsync(&ctx->counters[0], 0, sizeof(uint32_t), s));
+    uint32_t* const rc_ = fold ? &ctx->counters[0] : nullptr; uint32_t* const rh_ = fold ? bvh->work : nullptr;   // lane 0 = head set 0
+    const bool nb5 = ctx->cfg.neighbor_count <= 5;
+    const RowSet rows = {ctx->row_a, ctx->row_b, ctx->row_mode};
+    // mirres_render's chain (packed pixel records + packed reservoirs, no per-ray counters wanted): the queue carries pixel pairs and the traversal kernel forms the rays
+    const bool items = ray_items_allowed(ctx) && resd(prev_res).rec;
+    const dim3 sg_grid(tile_grid(ctx->fx, ctx->fy, MR_SGEN_TILE)), sg_block(MR_SGEN_BLOCK / MR_SGEN_PX);
+#define MR_SGEN_ARGS ctx->cfg, gbufd(g), resd(prev_res), noff, frameIndex, ctx->fx, ctx->fy, N, ctx->y_off, ctx->occ_own, ctx->any_rays, &ctx->counters[0], ctx->slot_a, ctx->mask_a, rows
+    if (nb5 && items) k_spatial_gen<5, true><<<sg_grid, sg_block, 0, s>>>(MR_SGEN_ARGS);
+    else if (nb5) k_spatial_gen<5><<<sg_grid, sg_block, 0, s>>>(MR_SGEN_ARGS);
+    else if (items) k_spatial_gen<8, true><<<sg_grid, sg_block, 0, s>>>(MR_SGEN_ARGS);
+    else k_spatial_gen<8><<<sg_grid, sg_block, 0, s>>>(MR_SGEN_ARGS);
+#undef MR_SGEN_ARGS
+    int rc;
+    if (items) {
+        const RaySrc src = {reinterpret_cast<const float4*>(ctx->grec), resd(prev_res).rec, ctx->cfg.vis_near};
+        rc = trace_any_items_q(ctx, bvh, ctx->any_rays, src, &ctx->counters[0], ctx->any_cap, ctx->any_hit, s, 0);
+    } else rc = trace_any(ctx, bvh, ctx->any_cap, s);
+    if (rc) return rc;
+    GBufD gr = gbufd(g);
+    if (ctx->grec) gr.rec = reinterpret_cast<const float4*>(ctx->grec);   // mirres_render: same values, one 64-byte record per neighbour instead of three arrays
+    const bool fuse = next_res && resd(next_res).rec && resd(res).rec && gr.rec;
+    const ResD NR = fuse ? resd(next_res) : resd(res);
+    const int rg = tile_grid(ctx->fx, ctx->fy, MR_SRES_TILE), rb = MR_SRES_TILE * MR_SRES_TILE;
+#define MR_SRES_ARGS ctx->cfg, envh(env), gr, resd(res), resd(prev_res), noff, frameIndex, ctx->fx, ctx->fy, N, ctx->y_off, ctx->occ_own, ctx->slot_a, ctx->mask_a, ctx->any_hit, rc_, rh_, NR, next_frame, rows
+    if (nb5 && fuse) k_spatial_resolve<5, true><<<rg, rb, 0, s>>>(MR_SRES_ARGS);
+    else if (nb5) k_spatial_resolve<5, false><<<rg, rb, 0, s>>>(MR_SRES_ARGS);
+    else if (fuse) k_spatial_resolve<8, true><<<rg, rb, 0, s>>>(MR_SRES_ARGS);
+    else k_spatial_resolve<8, false><<<rg, rb, 0, s>>>(MR_SRES_ARGS);
+#undef MR_SRES_ARGS
+    if (fold) ctx->chain_clean = true;
+    MR_LAUNCH_CHECK("restir_spatial");
+    return MIRRES_OK;
+}
+
 }  // namespace mr
 
 using namespace mr;
@@ -892,37 +989,7 @@ int mirres_restir_temporal(mirres_ctx_t* ctx, const mirres_env_t* env, const mir
 
 int mirres_restir_spatial(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_env_t* env, const mirres_gbuf_t* g, const mirres_res_t* res,
                           const mirres_res_t* prev_res, const float* neighbor_offsets, uint32_t frameIndex, void* stream) {
-    if (!ctx || !bvh || !env || !g || !res || !prev_res) { set_error("mirres_restir_spatial: null"); return MIRRES_E_ARG; }
-    hipStream_t s = (hipStream_t)stream; const int N = (int)ctx->N; const int grd = grid_for(N, MR_BLOCK);
-    const float* noff = neighbor_offsets ? neighbor_offsets : ctx->noff;
-    const bool fold = ctx->chain_reset;                         // inside mirres_render's chain (its own stream, its own work heads)
-    if (!(fold && ctx->chain_clean)) MR_HIP(hipMemsetAsync(&ctx->counters[0], 0, sizeof(uint32_t), s));
-    uint32_t* const rc_ = fold ? &ctx->counters[0] : nullptr; uint32_t* const rh_ = fold ? bvh->work : nullptr;   // lane 0 = head set 0
-    const bool nb5 = ctx->cfg.neighbor_count <= 5;
-    // mirres_render's chain (packed pixel records + packed reservoirs, no per-ray counters wanted): the queue carries pixel pairs and the traversal kernel forms the rays
-    const bool items = ray_items_allowed(ctx) && resd(prev_res).rec;
-    const dim3 sg_grid(tile_grid(ctx->fx, ctx->fy, MR_SGEN_TILE)), sg_block(MR_SGEN_BLOCK / MR_SGEN_PX);
-#define MR_SGEN_ARGS ctx->cfg, gbufd(g), resd(prev_res), noff, frameIndex, ctx->fx, ctx->fy, N, ctx->y_off, ctx->occ_own, ctx->any_rays, &ctx->counters[0], ctx->slot_a, ctx->mask_a
-    if (nb5 && items) k_spatial_gen<5, true><<<sg_grid, sg_block, 0, s>>>(MR_SGEN_ARGS);
-    else if (nb5) k_spatial_gen<5><<<sg_grid, sg_block, 0, s>>>(MR_SGEN_ARGS);
-    else if (items) k_spatial_gen<8, true><<<sg_grid, sg_block, 0, s>>>(MR_SGEN_ARGS);
-    else k_spatial_gen<8><<<sg_grid, sg_block, 0, s>>>(MR_SGEN_ARGS);
-#undef MR_SGEN_ARGS
-    int rc;
-    if (items) {
-        const RaySrc src = {reinterpret_cast<const float4*>(ctx->grec), resd(prev_res).rec, ctx->cfg.vis_near};
-        rc = trace_any_items_q(ctx, bvh, ctx->any_rays, src, &ctx->counters[0], ctx->any_cap, ctx->any_hit, s, 0);
-    } else rc = trace_any(ctx, bvh, ctx->any_cap, s);
-    if (rc) return rc;
-    GBufD gr = gbufd(g);
-    if (ctx->grec) gr.rec = reinterpret_cast<const float4*>(ctx->grec);   // mirres_render: same values, one 64-byte record per neighbour instead of three arrays
-    if (nb5) k_spatial_resolve<5><<<tile_grid(ctx->fx, ctx->fy, MR_SRES_TILE), MR_SRES_TILE * MR_SRES_TILE, 0, s>>>(ctx->cfg, envh(env), gr, resd(res), resd(prev_res), noff, frameIndex, ctx->fx, ctx->fy, N, ctx->y_off, ctx->occ_own,
-                                                                                   ctx->slot_a, ctx->mask_a, ctx->any_hit, rc_, rh_);
-    else k_spatial_resolve<8><<<tile_grid(ctx->fx, ctx->fy, MR_SRES_TILE), MR_SRES_TILE * MR_SRES_TILE, 0, s>>>(ctx->cfg, envh(env), gr, resd(res), resd(prev_res), noff, frameIndex, ctx->fx, ctx->fy, N, ctx->y_off, ctx->occ_own,
-                                                                               ctx->slot_a, ctx->mask_a, ctx->any_hit, rc_, rh_);
-    if (fold) ctx->chain_clean = true;
-    MR_LAUNCH_CHECK("restir_spatial");
-    return MIRRES_OK;
+    return mr::launch_spatial(ctx, bvh, env, g, res, prev_res, neighbor_offsets, frameIndex, (hipStream_t)stream, nullptr, 0u);
 }
 
 int mirres_restir_final_vis(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const float* pos, const mirres_res_t* res, float* vis_map, void* stream) {

@@ -390,7 +390,7 @@ int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args
     }
     mirres_gbuf_t G = {occ, a->pos, B.nd, B.brdf, B.ray_dir};          // own-pixel stages (initial, temporal)
     mirres_gbuf_t Gt = {a->occ, a->pos, B.nd, B.brdf, B.ray_dir};      // spatial reuse: neighbours in the halo rows are real pixels
-    struct GrecGuard { mirres_ctx* c; ~GrecGuard() { c->grec = nullptr; c->chain_reset = false; c->chain_clean = false; } } grec_guard{ctx};
+    struct GrecGuard { mirres_ctx* c; ~GrecGuard() { c->grec = nullptr; c->chain_reset = false; c->chain_clean = false; c->row_mode = 0; } } grec_guard{ctx};
     ctx->grec = B.grec;   // packed copy for the neighbour gathers of the spatial merge; cleared when this call returns (the launches captured the pointer)
     const uint32_t passes = 20;  // mTotalRISPasses (:242)
     const int max_bounce = ctx->cfg.max_bounce;
@@ -502,25 +502,60 @@ int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args
         // ---- chain: temporal + spatial reuse of samples ib .. ib+kk-1
         if (two_streams) MR_HIP(hipStreamWaitEvent(s, ev_bulk(b - 1), 0));
         if (sf != sp && b >= 2) MR_HIP(hipStreamWaitEvent(s, ev_fin(b - 2), 0));   // C(b) overwrites the spatial reservoirs F(b-2) evaluates
+        // The temporal merge of sample i + 1 is fused into the spatial resolve of sample i (k_spatial_resolve<., true>: same pixel, the spatial output still in
+        // registers) whenever sample i + 1 belongs to the same batch — its initial reservoirs are then complete (I(b) precedes C(b)). The first sample of a batch
+        // merges in a launch of its own (its initial reservoirs come from the bulk stream's I(b), which the previous batch's last resolve cannot wait for).
+        static const bool fuse_temporal = [] { const char* e = getenv("MIRRES_FUSE_TEMPORAL"); return !(e && e[0] == '0'); }();
+        // strip_overlap: interior rows = own rows at least gather_radius away from every strip edge that has a neighbouring rank behind it
+        int in_a = a->own_y0, in_b = a->own_y1; bool overlap = false;
+        if (strip && a->halo && a->strip_overlap) {
+            const int r = (int)ctx->cfg.gather_radius;
+            if (a->strip_y_off + a->own_y0 > 0) in_a += r;
+            if (a->strip_y_off + a->own_y1 < a->strip_full_fy) in_b -= r;
+            overlap = in_b > in_a;
+            if (overlap && !ctx->halo_stream) {
+                MR_HIP(hipStreamCreateWithFlags(&ctx->halo_stream, hipStreamNonBlocking));
+                MR_HIP(hipEventCreateWithFlags(&ctx->ev_halo[0], hipEventDisableTiming)); MR_HIP(hipEventCreateWithFlags(&ctx->ev_halo[1], hipEventDisableTiming));
+            }
+        }
+        bool merged_already = false;     // this sample's temporal merge ran inside the previous sample's resolve
         for (int k = 0; k < kk; k++) {
             const int i = ib + k;
             const uint32_t base = a->random_offset + passes * (uint32_t)i;
             uint32_t pass = 3;
             mirres_res_t rt = res_slot(PB.rinit[b & 1], k, (size_t)N), rs = res_slot(PB.rspat[b & 1], k, (size_t)N);
-            csum(rt.light_data, 8 * (size_t)N);
+            if (!merged_already) csum(rt.light_data, 8 * (size_t)N);
             if (i > 0) {
                 // prev_* G-buffers alias the current ones from the second sample on (:462-465); a rank that starts in the middle of the sample
                 // range (spp sharding) has no history yet and skips the merge but keeps the pass numbering
-                if (i > i0) {
+                if (i > i0 && !merged_already) {
                     mirres_res_t rp = (k > 0) ? res_slot(PB.rspat[b & 1], k - 1, (size_t)N) : res_slot(PB.rspat[(b - 1) & 1], PB.K - 1, (size_t)N);
                     rc = mirres_restir_temporal(ctx, &E, &G, &G, &rt, &rp, nullptr, base + pass, s); if (rc) return rc;
                 }
                 pass += 1;
             }
+            if (a->halo && overlap) {
+                // strip sharding with the exchange off the chain: the callback enqueues it on the side stream (after this sample's temporal output), the chain does the
+                // interior rows meanwhile, then waits and does the border rows
+                MR_HIP(hipEventRecord(ctx->ev_halo[0], s)); MR_HIP(hipStreamWaitEvent(ctx->halo_stream, ctx->ev_halo[0], 0));
+                if (a->halo(a->halo_user, rt.light_data, i, (void*)ctx->halo_stream)) { set_error("mirres_render: halo exchange callback failed at sample %d", i); return MIRRES_E_STATE; }
+                MR_HIP(hipEventRecord(ctx->ev_halo[1], ctx->halo_stream));
+                ctx->row_a = in_a; ctx->row_b = in_b; ctx->row_mode = 1;
+                rc = launch_spatial(ctx, bvh, &E, &Gt, &rs, &rt, nullptr, base + pass, s, nullptr, 0u);
+                if (!rc) { MR_HIP(hipStreamWaitEvent(s, ctx->ev_halo[1], 0)); ctx->row_mode = 2; rc = launch_spatial(ctx, bvh, &E, &Gt, &rs, &rt, nullptr, base + pass, s, nullptr, 0u); }
+                ctx->row_mode = 0;
+                if (rc) return rc;
+                merged_already = false;
+                csum(rs.light_data, 8 * (size_t)N);
+                continue;
+            }
             if (a->halo) {   // strip sharding: the neighbouring ranks' border rows of the temporal output -> this rank's halo rows (and vice versa)
                 if (a->halo(a->halo_user, rt.light_data, i, (void*)s)) { set_error("mirres_render: halo exchange callback failed at sample %d", i); return MIRRES_E_STATE; }
             }
-            rc = mirres_restir_spatial(ctx, bvh, &E, &Gt, &rs, &rt, nullptr, base + pass, s); if (rc) return rc;
+            const bool fuse_next = fuse_temporal && !dbg_sum && k + 1 < kk;      // (sample i + 1 > i0 >= 0: it always has a temporal pass)
+            mirres_res_t rn = res_slot(PB.rinit[b & 1], fuse_next ? k + 1 : k, (size_t)N);
+            rc = launch_spatial(ctx, bvh, &E, &Gt, &rs, &rt, nullptr, base + pass, s, fuse_next ? &rn : nullptr, a->random_offset + passes * (uint32_t)(i + 1) + 3u); if (rc) return rc;
+            merged_already = fuse_next;
             csum(rs.light_data, 8 * (size_t)N);
         }
         if (two_streams) MR_HIP(hipEventRecord(ev_chain(b), s));

@@ -121,6 +121,15 @@ def device_view(ptr, shape):
     return torch.as_tensor(_DevMem(ptr, shape), device="cuda")
 
 
+def on_stream(stream):
+    """Context manager that makes the raw HIP stream `stream` (an integer handle, as mirres_render's halo callback receives it) torch's current stream, so
+    that copies and collectives enqueued inside are ordered on it. With strip_overlap the callback gets the engine's side stream, not the caller's."""
+    if not stream or int(stream) == torch.cuda.current_stream().cuda_stream:
+        import contextlib
+        return contextlib.nullcontext()
+    return torch.cuda.stream(torch.cuda.ExternalStream(int(stream)))
+
+
 def halo_plan(fy, fx, rank, world, halo=HALO_ROWS, bounds=None):
     """What the per-sample exchange moves, in LOCAL row numbers of `rank`'s frame: a list of (peer, send_rows, recv_rows) with row ranges
     [a, b). The rank above receives our first own rows (its bottom halo) and sends its last own rows (our top halo); same below."""
@@ -181,7 +190,7 @@ def gather_rows(own, fy, fx, world, group=None, bounds=None):
 
 
 def render_strips(ctx_full, worker, mlp_mat, env_map, g, spp, random_offset, rank, world, denoise_iter=2, step_width=2, c_phi=2.0, n_phi=0.1, p_phi=0.001,
-                  use_scale=False, scale=(1.0, 1.0, 1.0), group=None, max_bounce=None, balanced=True):
+                  use_scale=False, scale=(1.0, 1.0, 1.0), group=None, max_bounce=None, balanced=True, overlap=None):
     """Exact multi-GPU frame: this rank renders its strip (all spp) with per-sample halo exchange, the raw sums are all-gathered by rows and
     finished on every rank. `g` is the full-frame G-buffer dict (harness.build_gbuffer); `ctx_full` a context of the full frame (finish only)."""
     from . import _lib
@@ -213,9 +222,13 @@ def render_strips(ctx_full, worker, mlp_mat, env_map, g, spp, random_offset, ran
     ctx_loc = get_ctx(fx, rows_pad, max_bounce)
     plan = halo_plan(fy, fx, rank, world, bounds=bounds)
 
+    if overlap is None:      # MIRRES_STRIP_OVERLAP=1: exchange on a side stream behind the interior rows' spatial pass (mirres_render_args_t.strip_overlap)
+        overlap = os.environ.get("MIRRES_STRIP_OVERLAP", "0") == "1"
+
     def _halo(user, records, sample, stream):
         try:
-            exchange_halos(device_view(records, (rows_pad, fx, 8)), plan, group)
+            with on_stream(stream):
+                exchange_halos(device_view(records, (rows_pad, fx, 8)), plan, group)
             return 0
         except Exception as e:      # surfaced by mirres_render as MIRRES_E_STATE
             import sys
@@ -223,7 +236,7 @@ def render_strips(ctx_full, worker, mlp_mat, env_map, g, spp, random_offset, ran
             return 1
     cb = _lib.HALO_FN(_halo)
     sums, a, keep = render_fused(ctx_loc, worker, mlp_mat, use_scale, scale, env_map, loc["occ"], loc["normal"], loc["depth"], loc["kd"], loc["rm"], loc["ray_dir"],
-                                 loc["pos"], spp, denoise_iter, step_width, c_phi, n_phi, p_phi, random_offset, strip=(fy, lo, y0 - lo, y1 - lo), halo=cb)
+                                 loc["pos"], spp, denoise_iter, step_width, c_phi, n_phi, p_phi, random_offset, strip=(fy, lo, y0 - lo, y1 - lo), halo=cb, strip_overlap=overlap)
     own = [s_[(y0 - lo) * fx:(y1 - lo) * fx].contiguous() for s_ in sums]
     full = gather_rows(own, fy, fx, world, group, bounds)
     # replicated finish on the whole frame (average, EAW, composite)

@@ -278,7 +278,7 @@ def _needs_grad(*ts):
 
 def render_fused(ctx, bvh_restir_worker, mlp_mat, use_scale, scale, env_map, occ_map, normal_map, depth_map, diffuse_map, roughness_specular, ray_dir_map, pos_map,
                  spp, denoise_iter, stepWidth, c_phi, n_phi, p_phi, random_offset, spp_range=None, const_kd=(0.6, 0.6, 0.6), const_rm=(0.5, 0.0),
-                 strip=None, halo=None, gb_depth=None, tape=None):
+                 strip=None, halo=None, gb_depth=None, tape=None, strip_overlap=False):
     """One C call for the whole frame (mirres_render). Returns the 6 output buffers [N,3] (raw sums when spp_range or strip is given).
     strip = (full_fy, y_off, own_y0, own_y1): `ctx` and all per-pixel inputs describe a rank's LOCAL frame (own rows + halo rows, dist.py);
     halo = a _lib.HALO_FN called once per sample to exchange the halo rows of the packed reservoirs."""
@@ -323,6 +323,7 @@ def render_fused(ctx, bvh_restir_worker, mlp_mat, use_scale, scale, env_map, occ
         if halo is not None:
             keep.append(halo)
             a.halo = C.cast(halo, C.c_void_p)
+            a.strip_overlap = 1 if strip_overlap else 0
     check(lib().mirres_render(ctx.h, bvh_restir_worker.h, C.byref(a), stream_ptr()), "mirres_render")
     return outs, a, keep
 

@@ -1,4 +1,6 @@
 """GPU parity: whole frames through run_restir_di_with_pt (fused C path and the stepwise Python path) against the oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -324,6 +326,22 @@ def test_strip_sharding_is_exact(oracle, scene_mod):
         got = render(get_ctx(fx, hi - lo), loc, strip=(fy, lo, y0 - lo, y1 - lo), halo=_lib.HALO_FN(replay))
         for a, b in zip(ref, got):
             assert torch.equal(a[y0 * fx:y1 * fx], b[(y0 - lo) * fx:(y1 - lo) * fx]), "rank %d" % rank
+        # the same strip with the exchange off the chain (strip_overlap): the callback is handed the engine's side stream, the interior rows' spatial pass runs
+        # before the halo rows have arrived, the border rows after — and not a bit changes
+        seen = []
+        def replay_side(user, records, sample, stream, lo=lo, hi=hi, plan=plan):
+            seen.append(int(stream or 0))
+            with D.on_stream(stream):
+                view = D.device_view(records, (hi - lo, fx, 8))
+                for peer, send, (ra, rb) in plan:
+                    view[ra:rb].fill_(float("nan"))                       # whatever the interior pass may read too early would poison the frame
+                    torch.cuda._sleep(200000)                           # a slow exchange: ~0.1 ms on the side stream
+                    view[ra:rb].copy_(rec[sample][lo + ra:lo + rb])
+            return 0
+        got2 = render(get_ctx(fx, hi - lo), loc, strip=(fy, lo, y0 - lo, y1 - lo), halo=_lib.HALO_FN(replay_side), strip_overlap=True)
+        assert len(seen) == spp and all(st != torch.cuda.current_stream().cuda_stream for st in seen)
+        for a, b in zip(ref, got2):
+            assert torch.equal(a[y0 * fx:y1 * fx], b[(y0 - lo) * fx:(y1 - lo) * fx]), "rank %d with strip_overlap" % rank
 
 
 def _strip_rank(rank, world, port, out):
@@ -347,6 +365,8 @@ def _strip_rank(rank, world, port, out):
     ctx = get_ctx(g["fx"], g["fy"])
     outs = D.render_strips(ctx, W, None, env, g, 3, 4321, rank, world)
     res = {"outs": [o.cpu() for o in outs]}
+    over = D.render_strips(ctx, W, None, env, g, 3, 4321, rank, world, overlap=True)      # the exchange on the engine's side stream, interior rows first
+    res["overlap"] = [o.cpu() for o in over]
     if rank == 0:
         ref = D.render_strips(ctx, W, None, env, g, 3, 4321, 0, 1)      # world == 1: the ordinary single-GPU frame
         res["ref"] = [o.cpu() for o in ref]
@@ -367,6 +387,7 @@ def test_two_rank_strip_render_equals_single_gpu(tmp_path):
     for k in range(6):
         assert torch.equal(r0["outs"][k], r0["ref"][k]), "rank 0 buffer %d" % k
         assert torch.equal(r1["outs"][k], r0["ref"][k]), "rank 1 buffer %d" % k
+        assert torch.equal(r0["overlap"][k], r0["ref"][k]) and torch.equal(r1["overlap"][k], r0["ref"][k]), "strip_overlap, buffer %d" % k
 
 
 def test_fused_training_gradients_match_the_stepwise_loop(oracle, scene_mod, monkeypatch):
@@ -442,6 +463,64 @@ def test_degenerate_frames(oracle, scene_mod):
     for g_, n_ in zip(got, names):
         assert np.isfinite(g_).all()
         pixel_parity(g_, ref[n_], "material extremes / " + n_, tol=0.0)
+
+
+def test_hostile_shading_inputs_match_the_oracle(oracle, scene_mod):
+    """Shading-side hostile inputs against the oracle, bit for bit (NaNs must sit in the same places): the shading translation units divide
+    and take square roots with short sequences (device_math.hpp mr_div / mr_sqrt) that equal IEEE division only inside 2^-102 .. 2^102 — these frames leave that
+    comfort zone on purpose: (e) an HDR environment spanning 1e-30 .. 1e6 with exact zeros; (f) the same with NaN and +inf texels; (g) roughness on both sides of
+    the alpha < 1e-4 switch (brdfDi.slang:169-199) and of the 0.01 clamp; (h) grazing shading normals (n.v ~ 1e-7) and normals facing away; (i) an environment
+    whose importance pdfs underflow (radiance 1e-38 next to 1e-3)."""
+    import torch
+    from mirres_restir_nerf_mesh_amd import renderer_restir as RR
+    from mirres_restir_nerf_mesh_amd._ops import get_ctx
+    names = ["final_color", "diffuse", "spec", "indirect", "indirect_diff", "indirect_spec"]
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+    F = SmallFrame(oracle, scene_mod, fx=24, fy=20, subdiv=2, ground=4, env_hw=(8, 16))
+    W = RR.restirbvhWorker(torch.from_numpy(F.vert).cuda(), torch.from_numpy(F.tri).cuda()); W.update_mesh(W.vrt, W.v_ind)
+
+    def check(what, env, normal, kd, rm, spp=2, seed=77):
+        outs, _, _ = RR.render_fused(get_ctx(F.fx, F.fy), W, None, False, (1, 1, 1), cu(env), cu(F.occ[:, None].copy()), cu(normal), cu(F.depth[:, None]), cu(kd), cu(rm),
+                                     cu(F.ray_dir_raw), cu(F.pos), spp, 2, 2, 2.0, 0.1, 0.001, seed)
+        ref = oracle.render(F.fx, F.fy, spp, seed, (F.info, F.aabb), F.vert, F.tri, env, F.occ, normal, F.depth, kd, rm, F.ray_dir_raw, F.pos, mat=None)
+        rep = os.environ.get("MIRRES_PARITY_REPORT")
+        for o_, n_ in zip(outs, names):
+            g_ = np.ascontiguousarray(o_.cpu().numpy(), dtype=np.float32); r_ = np.ascontiguousarray(ref[n_], dtype=np.float32)
+            same = (g_.view(np.uint32) == r_.view(np.uint32)) | (np.isnan(g_) & np.isnan(r_))
+            if rep:
+                with open(rep, "a") as f:
+                    f.write("hostile shading inputs / %s / %s: %d of %d values differ (NaN in the oracle: %d, inf: %d)\n" % (what, n_, int((~same).sum()), same.size, int(np.isnan(r_).sum()), int(np.isinf(r_).sum())))
+            assert same.all(), "%s / %s: %d of %d values differ; first: got %r want %r" % (what, n_, int((~same).sum()), same.size, g_[~same][:4], r_[~same][:4])
+        return ref
+    rng = np.random.default_rng(12)
+    Hc, Wc = 8, 16
+    # (e) radiance over 36 decades, a tenth of the texels exactly zero
+    env = (10.0 ** rng.uniform(-30, 6, (Hc, Wc, 3))).astype(np.float32)
+    env[rng.random((Hc, Wc)) < 0.1] = 0.0
+    ref = check("HDR 1e-30..1e6 with zeros", env, F.normal, F.kd, F.rm)
+    assert np.isfinite(ref["final_color"]).all()
+    # (f) + NaN and +inf texels
+    env2 = env.copy(); env2[1, 3] = np.nan; env2[5, 9, 1] = np.inf; env2[6, 2] = np.inf
+    check("HDR with NaN and +inf texels", env2, F.normal, F.kd, F.rm)
+    # (g) roughness around the alpha = r^2 < 1e-4 switch and the 0.01 clamp; metallic extremes
+    rm = F.rm.copy()
+    vals = np.array([0.0, 0.0099, 0.0099999, 0.01, 0.0100001, 0.010001, 0.02, 1.0, 1e-30, 0.999999], np.float32)
+    rm[:, 0] = vals[np.arange(F.N) % len(vals)]; rm[::7, 1] = 1.0; rm[3::7, 1] = 0.0
+    check("roughness at the alpha switch", F.env, F.normal, F.kd, rm)
+    # (h) grazing and back-facing shading normals
+    v = -F.ray_dir
+    t = np.cross(v, np.array([0.3, 0.5, 0.8], np.float32)); t /= np.maximum(np.linalg.norm(t, axis=1, keepdims=True), 1e-20)
+    nrm = F.normal.copy()
+    sel = (np.arange(F.N) % 3 == 0) & (F.occ > 0.5)
+    eps = np.where(np.arange(F.N) % 2 == 0, 1e-7, -1e-7).astype(np.float32)[:, None]
+    g = t + eps * v; g /= np.linalg.norm(g, axis=1, keepdims=True)
+    nrm[sel] = g[sel].astype(np.float32)
+    back = (np.arange(F.N) % 11 == 5) & (F.occ > 0.5)
+    nrm[back] = (-F.normal[back]).astype(np.float32)
+    check("grazing and back-facing normals", F.env, nrm, F.kd, F.rm)
+    # (i) importance pdfs that underflow: 1e-38 next to 1e-3 (the dark texels' pdf is a denormal)
+    env3 = np.full((Hc, Wc, 3), 1e-38, np.float32); env3[2, 4] = 1e-3; env3[6, 11] = 7e-4
+    check("underflowing pdfs", env3, F.normal, F.kd, F.rm)
 
 
 def test_stage1_loop_with_reference_losses(scene_mod):
