@@ -147,6 +147,8 @@ int trace_any(mirres_ctx* ctx, mirres_bvh* bvh, size_t cap, hipStream_t s);     
 int trace_closest(mirres_ctx* ctx, mirres_bvh* bvh, size_t cap, hipStream_t s);   // ctx->cl_rays  -> ctx->cl_hit
 // queues and per-slot scratch of the path-tracing stages: the context's own (one sample per pixel — the stepwise ABI) or a K-sample batch
 // (mirres_render): slot v = k * N + pixel holds sample k of the batch, so one launch carries K samples' rays.
+// scratch of the position bucket sort in front of the material lookup (matnet.hip): a key per listed slot, the sorted list, 2^15 bucket counters
+struct GridSort { uint32_t* keys; int32_t* sorted; uint32_t* buckets; };
 struct PtQueues {
     Ray* any_rays; int32_t* any_hit; Ray* cl_rays; HitRec* cl_hit;
     uint32_t* counters;                 // [0] shadow rays, [1] continuation rays, [2] material-net list
@@ -158,6 +160,7 @@ struct PtQueues {
     // resolve stage — a hit, or a specular miss that picks up the environment at the next vertex — in two ping-pong buffers; counters[3 + b] counts list b.
     // Of a K-sample batch's 82 M slots a few million survive the first indirect vertex; the bounce kernels run over the list instead of over all slots.
     int32_t* live[2]; int live_cur;
+    GridSort gs;
 };
 int launch_initial_batch(mirres_ctx* ctx, mirres_bvh* bvh, const mirres_env_t* env, const mirres_gbuf_t* g, const mirres_res_t* res, float* tile_data,
                          float* tile_pdf, float* tile_aux, uint32_t frame0, int K, const PtQueues* q, hipStream_t s);

@@ -26,7 +26,7 @@ int launch_eaw5(int fx, int fy, int step, float c_phi, float n_phi, float p_phi,
 int launch_matnet_scatter(const mirres_matnet_t* m, const float* occ, const float* pos, int n, float* kd, float* rm, int use_scale, const float* scale3,
                           const float* const_kd, const float* const_rm, hipStream_t s);
 int launch_matnet_scatter_mfma(const mirres_matnet_t* m, const float* occ, const float* pos, int n, float* kd, float* rm, int use_scale, const float* scale3,
-                               int32_t* index, uint32_t* count, hipStream_t s, const int32_t* live, const uint32_t* live_count);
+                               int32_t* index, uint32_t* count, hipStream_t s, const int32_t* live, const uint32_t* live_count, const GridSort* gs);
 
 // run_restir_di_with_pt :484-486 + restir_di_with_pt :279-287
 __global__ void __launch_bounds__(MR_BLOCK) k_prep(int N, float* __restrict__ occ, const float* __restrict__ ray_dir_in, const float* __restrict__ normal,
@@ -191,6 +191,7 @@ static PtSet pt_set(const PtBatch& PB, int h, size_t cap, int nb) {
     S.q.counters = PB.q.counters + 8 * h;
     S.q.slot_a = PB.q.slot_a + o; S.q.mask_a = PB.q.mask_a + o; S.q.slot_c = PB.q.slot_c + o; S.q.pend = PB.q.pend + 18 * o;
     S.q.live[0] = PB.q.live[0] + o; S.q.live[1] = PB.q.live[1] + o; S.q.live_cur = 0;
+    S.q.gs.keys = PB.q.gs.keys + o; S.q.gs.sorted = PB.q.gs.sorted + o; S.q.gs.buckets = PB.q.gs.buckets + 32768 * (size_t)h;
     S.prd = PB.prd + 5 * o;
     for (int k = 0; k < 2; k++) { S.pos[k] = PB.pos[k] + 3 * o; S.rd[k] = PB.rd[k] + 3 * o; S.n[k] = PB.n[k] + 3 * o; S.occ[k] = PB.occ[k] + o; }
     S.kd = PB.kd + 3 * o; S.rm = PB.rm + 2 * o;
@@ -213,7 +214,8 @@ static int carve_batch(mirres_ctx* ctx, int N, int K, int max_bounce, size_t TS,
         return al(sizeof(Ray) * 2 * NV) + al(4 * 2 * NV) + al(sizeof(Ray) * NV) + al(sizeof(HitRec) * NV) + al(64) + 5 * al(4 * NV) + al(4 * 18 * NV)
              + al(4 * 5 * NV) + 2 * (3 * al(4 * 3 * NV) + al(4 * NV)) + al(4 * 3 * NV) + al(4 * 2 * NV) + al(4 * 9 * NV * (size_t)nb) + al(4 * NV * (size_t)nb)
              + 4 * al(4 * 8 * NV) + al(4 * 3 * (size_t)k * TS) + al(4 * (size_t)k * TS) + al(32 * (size_t)k * TS)
-             + 2 * (al(sizeof(Ray) * NV) + 2 * al(4 * NV) + al(64));
+             + 2 * (al(sizeof(Ray) * NV) + 2 * al(4 * NV) + al(64))
+             + 2 * al(4 * NV) + 2 * al(4 * 32768);      // bucket sort in front of the material lookup: keys + sorted list, two sets of counters (one per half)
     };
     // A request the device could not hold last time is not repeated every frame (a failing multi-GB hipMalloc per frame): the batch size that fitted is
     // remembered and later requests are clamped to it. The clamp is not for ever — a transient shortage (another tenant of the HBM) must not pin a long
@@ -292,6 +294,7 @@ static int carve_batch(mirres_ctx* ctx, int N, int K, int max_bounce, size_t TS,
         r.light_data = (float*)take(4 * 8 * NV); r.light_pdf = nullptr; r.M = nullptr; r.weight = nullptr;
     }
     PB.tile_data = (float*)take(4 * 3 * (size_t)K * TS); PB.tile_pdf = (float*)take(4 * (size_t)K * TS); PB.tile_aux = (float*)take(32 * (size_t)K * TS);
+    PB.q.gs.keys = (uint32_t*)take(4 * NV); PB.q.gs.sorted = (int32_t*)take(4 * NV); PB.q.gs.buckets = (uint32_t*)take(2 * 4 * 32768);
     PB.qf = PB.q;
     PB.qf.any_rays = (Ray*)take(sizeof(Ray) * NV); PB.qf.any_hit = (int32_t*)take(4 * NV); PB.qf.slot_a = (int32_t*)take(4 * NV); PB.qf.counters = (uint32_t*)take(64);
     PB.qf.cl_rays = nullptr; PB.qf.cl_hit = nullptr; PB.qf.mask_a = nullptr; PB.qf.slot_c = nullptr; PB.qf.pend = nullptr; PB.qf.live[0] = PB.qf.live[1] = nullptr; PB.qf.live_cur = 0;
@@ -578,7 +581,7 @@ int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args
             int src = 0;
             for (int bo = 1; bo <= max_bounce; bo++) {
                 // material lookup at the new vertices: compacted slot list -> hash-grid gather -> MFMA MLP -> scatter (slot_c is free between passes)
-                if (a->mat && !(getenv("MIRRES_MATNET") && getenv("MIRRES_MATNET")[0] == 'v')) rc = launch_matnet_scatter_mfma(a->mat, T.occ[src], T.pos[src], Q.NV, T.kd, T.rm, a->use_scale, a->scale, Q.slot_c, &Q.counters[2], sq, Q.live[Q.live_cur], &Q.counters[3 + Q.live_cur]);
+                if (a->mat && !(getenv("MIRRES_MATNET") && getenv("MIRRES_MATNET")[0] == 'v')) rc = launch_matnet_scatter_mfma(a->mat, T.occ[src], T.pos[src], Q.NV, T.kd, T.rm, a->use_scale, a->scale, Q.slot_c, &Q.counters[2], sq, Q.live[Q.live_cur], &Q.counters[3 + Q.live_cur], &Q.gs);
                 else rc = launch_matnet_scatter(a->mat, T.occ[src], T.pos[src], Q.NV, T.kd, T.rm, a->use_scale, a->scale, a->const_kd, a->const_rm, sq);
                 if (rc) return rc;
                 mirres_path_t Pb = {T.occ[src], T.pos[src], T.n[src], T.rd[src], T.kd, T.rm, T.prd, T.pos[src ^ 1], T.rd[src ^ 1], T.occ[src ^ 1], T.n[src ^ 1]};

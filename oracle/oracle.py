@@ -26,6 +26,29 @@ def build(force=False):
     return so
 
 
+def build_ref(force=False):
+    """oracle/_ref: the reference's own bilateral-denoiser kernels compiled by hipcc from /root/reference (oracle/Makefile `ref`). Only possible where the
+    reference tree exists (the build container); the GPU box uses the prebuilt oracle/_ref/libref_denoise.so that travelled with the snapshot."""
+    if not os.path.isdir(os.environ.get("MIRRES_REF", "/root/reference")):
+        return None
+    out = os.path.join(_HERE, "_ref", "libref_denoise.so")
+    if force or not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(os.path.join(_HERE, "ref_denoise_driver.hip")):
+        subprocess.run(["make", "-C", _HERE, "ref"] + (["-B"] if force else []), check=True, capture_output=True)
+    return out
+
+
+def ref_denoise_lib():
+    """ctypes handle of oracle/_ref/libref_denoise.so (GPU code: ref_bilateral_fwd / ref_bilateral_bwd take device pointers), or None when it was not built."""
+    p = os.path.join(_HERE, "_ref", "libref_denoise.so")
+    if not os.path.exists(p):
+        return None
+    L = C.CDLL(p)
+    vp = C.c_void_p
+    L.ref_bilateral_fwd.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, vp]; L.ref_bilateral_fwd.restype = C.c_int
+    L.ref_bilateral_bwd.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, vp]; L.ref_bilateral_bwd.restype = C.c_int
+    return L
+
+
 def lib():
     global _LIB
     if _LIB is None:

@@ -43,6 +43,40 @@ def test_bilateral_forward_backward_match_oracle(oracle):
     assert torch.isfinite(c2.grad).all() and float(c2.grad.abs().sum()) > 0
 
 
+def test_bilateral_against_the_reference_kernels(oracle):
+    """oracle/_ref/libref_denoise.so = the reference's OWN bilateral_denoiser_fwd_kernel / _bwd_kernel (nerf/renderutils/c_src/denoising.cu) compiled by hipcc from
+    the reference tree (oracle/Makefile `ref`; built where the tree exists, travels as a .so). The product's kernels (csrc/eaw.hip) and the CPU oracle are both held to
+    what the reference's code computes on this GPU: forward (weighted colour sums and weight sum) and backward (colour gradient), 43 x 43 taps. Tolerance: the
+    reference build contracts a * b + c into fma and calls the vendor's expf / powf, the product does neither (rtol 2e-5 on sums of ~10^3 weighted taps)."""
+    import torch
+    from mirres_restir_nerf_mesh_amd.renderutils.ops import _bilateral_denoiser_func
+    L = oracle.ref_denoise_lib()
+    if L is None:
+        pytest.skip("oracle/_ref/libref_denoise.so was not built (no reference tree at build time)")
+    fx, fy = 40, 28
+    col, nrm, zdz = _inputs(fx, fy)
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    d_col, d_nrm, d_zdz = cu(col), cu(nrm), cu(zdz)
+    # the reference normalises the guide normals in Python before its kernel (safe_normalize, ops.py:168-169, 194); the product's op does it inside
+    d_nrm_unit = (d_nrm / torch.sqrt(torch.clamp((d_nrm * d_nrm).sum(-1, keepdim=True), min=1e-20))).contiguous()
+    ref_out = torch.zeros((fy * fx, 4), device="cuda")
+    assert L.ref_bilateral_fwd(d_col.data_ptr(), d_nrm_unit.data_ptr(), d_zdz.data_ptr(), ref_out.data_ptr(), 1, fy, fx, 4.0, None) == 0
+    torch.cuda.synchronize()
+    got = _bilateral_denoiser_func.apply(d_col, d_nrm, d_zdz, 4.0, fy, fx)
+    np.testing.assert_allclose(got.cpu().numpy(), ref_out.cpu().numpy(), rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(oracle.bilateral(fx, fy, 4.0, col, nrm, zdz), ref_out.cpu().numpy(), rtol=2e-5, atol=1e-6)
+    g4 = np.random.default_rng(9).normal(size=(fx * fy, 4)).astype(np.float32)
+    ref_g = torch.zeros((fy * fx, 3), device="cuda")
+    d_g4 = cu(g4)
+    assert L.ref_bilateral_bwd(d_col.data_ptr(), d_nrm_unit.data_ptr(), d_zdz.data_ptr(), d_g4.data_ptr(), ref_g.data_ptr(), 1, fy, fx, 4.0, None) == 0
+    torch.cuda.synchronize()
+    c = cu(col).requires_grad_(True)
+    out4 = _bilateral_denoiser_func.apply(c, d_nrm, d_zdz, 4.0, fy, fx)
+    out4.backward(cu(g4))
+    np.testing.assert_allclose(c.grad.cpu().numpy(), ref_g.cpu().numpy(), rtol=5e-5, atol=2e-5)
+    np.testing.assert_allclose(oracle.bilateral(fx, fy, 4.0, None, nrm, zdz, grad4=g4), ref_g.cpu().numpy(), rtol=5e-5, atol=2e-5)
+
+
 def test_use_bi_de_branch_of_the_frame(oracle, scene_mod):
     """run_restir_di_with_pt with gb_depth (--use_bi_de, renderer_restir.py:529-541): the fused loop's bilateral finish equals the oracle's
     filter applied to the frame's own averaged sums, and final_color composes the three denoised buffers (:543-549)."""
