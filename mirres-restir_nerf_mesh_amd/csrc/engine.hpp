@@ -147,8 +147,8 @@ int trace_any(mirres_ctx* ctx, mirres_bvh* bvh, size_t cap, hipStream_t s);     
 int trace_closest(mirres_ctx* ctx, mirres_bvh* bvh, size_t cap, hipStream_t s);   // ctx->cl_rays  -> ctx->cl_hit
 // queues and per-slot scratch of the path-tracing stages: the context's own (one sample per pixel — the stepwise ABI) or a K-sample batch
 // (mirres_render): slot v = k * N + pixel holds sample k of the batch, so one launch carries K samples' rays.
-// scratch of the position bucket sort in front of the material lookup (matnet.hip): a key per listed slot, the sorted list, 2^15 bucket counters
-struct GridSort { uint32_t* keys; int32_t* sorted; uint32_t* buckets; };
+// scratch of the position bucket sort in front of the material lookup (matnet.hip): two key buffers and a second list (ping-pong of the two radix passes), digit counters
+struct GridSort { uint32_t *keys, *keys2; int32_t* sorted; uint32_t* hist; };     // hist: 256 x 1024 workgroup counters + 256 digit totals
 struct PtQueues {
     Ray* any_rays; int32_t* any_hit; Ray* cl_rays; HitRec* cl_hit;
     uint32_t* counters;                 // [0] shadow rays, [1] continuation rays, [2] material-net list

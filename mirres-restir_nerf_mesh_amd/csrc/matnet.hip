@@ -300,8 +300,8 @@ __global__ void __launch_bounds__(MR_BLOCK) k_active_list(const float* __restric
 }
 
 // the same list from a live-slot list (mirres_render's batches): only the slots whose path is still going are looked at.
-// SORT (round 4): every listed slot also gets a 15-bit Morton key of its position (5 bits per axis of the field's box) and is counted into that key's bucket — the
-// first pass of a one-pass bucket sort of the list (k_bucket_scan, k_bucket_scatter below). The indirect vertices of a batch reach the material field in slot
+// SORT (round 4): every listed slot also gets a 15-bit Morton key of its position (5 bits per axis of the field's box); the list is then sorted by that key
+// (k_ls_* below). The indirect vertices of a batch reach the material field in slot
 // order (sample-major, pixel-minor): consecutive slots hold hit points of scattered bounce rays, and every point gathers 128 table entries (512 B) of which the
 // eleven hashed levels (2 MB each) miss the 4 MB L2 of the XCD. Ordered by position the fused gather + MLP kernel runs 23 / 33 / 36 % faster for 12- / 18- /
 // 30-bit keys (scripts/dev_grid_locality.py, profiles/r04_grid_locality.txt); outputs are scattered by slot, so not a bit changes.
@@ -311,7 +311,7 @@ MR_DEV uint32_t spread5(uint32_t v) { v &= 0x1fu; v = (v | (v << 8)) & 0x100fu; 
 template <bool SORT>
 __global__ void __launch_bounds__(MR_BLOCK) k_active_from_live(const float* __restrict__ occ, const int32_t* __restrict__ live, const uint32_t* __restrict__ live_count,
                                                                int32_t* __restrict__ index, uint32_t* __restrict__ count, MatNetD M, const float* __restrict__ pos,
-                                                               uint32_t* __restrict__ keys, uint32_t* __restrict__ buckets) {
+                                                               uint32_t* __restrict__ keys) {
     const uint32_t nl = *live_count;
     for (uint32_t b0 = blockIdx.x * (MR_BLOCK * 8u); b0 < nl; b0 += gridDim.x * (MR_BLOCK * 8u)) {   // a fixed grid strides over the list
         const uint32_t t0 = b0 + threadIdx.x;   // eight entries per thread (t0 + j * MR_BLOCK: coalesced): one queue atomic per 2048
@@ -332,30 +332,110 @@ __global__ void __launch_bounds__(MR_BLOCK) k_active_from_live(const float* __re
                     q[a] = (uint32_t)fminf(fmaxf(u * (float)(1 << MR_GS_BITS), 0.f), (float)((1 << MR_GS_BITS) - 1));      // (NaN -> 0: any bucket will do)
                 }
                 const uint32_t key = (spread5(q[0]) << 2) | (spread5(q[1]) << 1) | spread5(q[2]);
-                keys[o] = key; atomicAdd(&buckets[key], 1u);
+                keys[o] = key;
             }
             index[o++] = sl[j];
         }
     }
 }
-// exclusive scan of the bucket counters in place (one workgroup: 32 768 counters, 128 per thread)
-__global__ void __launch_bounds__(MR_BLOCK) k_bucket_scan(uint32_t* __restrict__ buckets) {
-    __shared__ uint32_t part[MR_BLOCK];
-    constexpr int PER = MR_GS_BUCKETS / MR_BLOCK;
-    uint32_t sum = 0;
-    for (int i = 0; i < PER; i++) sum += buckets[threadIdx.x * PER + i];
-    part[threadIdx.x] = sum;
-    __syncthreads();
-    if (threadIdx.x == 0) { uint32_t run = 0; for (int i = 0; i < MR_BLOCK; i++) { const uint32_t t = part[i]; part[i] = run; run += t; } }
-    __syncthreads();
-    uint32_t run = part[threadIdx.x];
-    for (int i = 0; i < PER; i++) { const uint32_t t = buckets[threadIdx.x * PER + i]; buckets[threadIdx.x * PER + i] = run; run += t; }
+// ---- two-pass LSD radix sort (8-bit digits) of (key, slot) pairs whose count lives on the device. No global atomics (a first version that counted and
+// scattered with one atomic per element cost 2.9 ms per launch for 7.5 M entries, more than the ordered gathers saved): a fixed grid of MR_LS_GRID workgroups,
+// each owning a contiguous run of 2048-key tiles — digit histogram of its run -> per digit: exclusive scan over the workgroups -> stable scatter walking the run
+// tile by tile with the wave64 digit matching of bvh_build.hip's sort (a key's rank = running base of its digit in this workgroup + the digit's count in the waves
+// before + in this wave's earlier rounds + in lower lanes).
+#define MR_LS_GRID 1024
+#define MR_LS_TILE 2048
+MR_DEV void ls_run(uint32_t n, uint32_t& t0, uint32_t& t1) {      // tiles [t0, t1) of this workgroup
+    const uint32_t tiles = (n + MR_LS_TILE - 1) / MR_LS_TILE, per = (tiles + MR_LS_GRID - 1) / MR_LS_GRID;
+    t0 = blockIdx.x * per; t1 = t0 + per < tiles ? t0 + per : tiles; if (t0 > tiles) t0 = tiles;
 }
-// every listed slot to its bucket's next free place (the order inside a bucket is whatever the atomics give: the field's outputs do not depend on it)
-__global__ void __launch_bounds__(MR_BLOCK) k_bucket_scatter(const int32_t* __restrict__ index, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ count,
-                                                             uint32_t* __restrict__ buckets, int32_t* __restrict__ sorted) {
-    const uint32_t n = *count;
-    for (uint32_t i = blockIdx.x * MR_BLOCK + threadIdx.x; i < n; i += gridDim.x * MR_BLOCK) sorted[atomicAdd(&buckets[keys[i]], 1u)] = index[i];
+__global__ void __launch_bounds__(MR_BLOCK) k_ls_hist(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ d_count, int shift, uint32_t* __restrict__ hist) {
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t n = *d_count; uint32_t t0, t1; ls_run(n, t0, t1);
+    for (uint32_t t = t0; t < t1; t++)
+#pragma unroll
+        for (int i = 0; i < 8; i++) { const uint32_t idx = t * MR_LS_TILE + i * MR_BLOCK + threadIdx.x; if (idx < n) atomicAdd(&h[(keys[idx] >> shift) & 255u], 1u); }
+    __syncthreads();
+    hist[(size_t)threadIdx.x * MR_LS_GRID + blockIdx.x] = h[threadIdx.x];      // digit-major
+}
+// per digit (one workgroup each): exclusive scan over the MR_LS_GRID workgroup counters in place + the digit's total
+__global__ void __launch_bounds__(MR_BLOCK) k_ls_scan(uint32_t* __restrict__ hist, uint32_t* __restrict__ totals) {
+    __shared__ uint32_t wsum[4];
+    uint32_t* h = hist + (size_t)blockIdx.x * MR_LS_GRID;
+    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
+    uint32_t running = 0u;
+    for (int c0 = 0; c0 < MR_LS_GRID; c0 += MR_BLOCK) {
+        const int i = c0 + (int)threadIdx.x;
+        const uint32_t x = h[i];
+        uint32_t inc = x;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        uint32_t before = 0u, all = 0u;
+#pragma unroll
+        for (int w = 0; w < 4; w++) { const uint32_t t = wsum[w]; if (w < wave) before += t; all += t; }
+        h[i] = running + before + inc - x;
+        running += all;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) totals[blockIdx.x] = running;
+}
+__global__ void __launch_bounds__(MR_BLOCK) k_ls_scatter(const uint32_t* __restrict__ kin, const int32_t* __restrict__ vin, uint32_t* __restrict__ kout, int32_t* __restrict__ vout,
+                                                         const uint32_t* __restrict__ d_count, int shift, const uint32_t* __restrict__ offs, const uint32_t* __restrict__ totals) {
+    __shared__ uint32_t wh[MR_BLOCK / 64][256];
+    __shared__ uint32_t dsum[MR_BLOCK / 64];
+    __shared__ uint32_t base[256];
+    const int wave = (int)(threadIdx.x >> 6), lane = lane_id();
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const uint32_t n = *d_count; uint32_t t0, t1; ls_run(n, t0, t1);
+    {   // where this workgroup's keys of digit d (= thread d) start: all keys with smaller digits + this digit's keys in the workgroups before
+        const uint32_t tot = totals[threadIdx.x];
+        uint32_t inc = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+        if (lane == 63) dsum[wave] = inc;
+        __syncthreads();
+        uint32_t run = inc - tot + offs[(size_t)threadIdx.x * MR_LS_GRID + blockIdx.x];
+        for (int w = 0; w < wave; w++) run += dsum[w];
+        base[threadIdx.x] = run;
+    }
+    for (uint32_t t = t0; t < t1; t++) {
+        for (int w = 0; w < MR_BLOCK / 64; w++) wh[w][threadIdx.x] = 0u;
+        __syncthreads();
+        const uint32_t first = t * MR_LS_TILE + wave * 512u;
+        uint32_t k[8], r[8]; int32_t v[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const uint32_t idx = first + i * 64 + lane;
+            const bool valid = idx < n;
+            k[i] = valid ? kin[idx] : 0xffffffffu; v[i] = valid ? vin[idx] : 0;
+            const uint32_t d = (k[i] >> shift) & 255u;
+            uint64_t m = __ballot(valid);
+#pragma unroll
+            for (int b = 0; b < 8; b++) { const bool bit = (d >> b) & 1u; const uint64_t bal = __ballot(bit); m &= bit ? bal : ~bal; }
+            const int leader = valid ? __builtin_ctzll(m) : lane;
+            uint32_t prev = 0u;
+            if (valid && lane == leader) { prev = wh[wave][d]; wh[wave][d] = prev + (uint32_t)__popcll(m); }
+            prev = (uint32_t)__shfl((int)prev, leader, 64);
+            r[i] = prev + (uint32_t)__popcll(m & lt_mask);
+            __syncthreads();
+        }
+        {   // per digit: the waves' starting places in this tile, and the workgroup's running base moves past the tile
+            uint32_t run = base[threadIdx.x];
+#pragma unroll
+            for (int w = 0; w < MR_BLOCK / 64; w++) { const uint32_t c = wh[w][threadIdx.x]; wh[w][threadIdx.x] = run; run += c; }
+            base[threadIdx.x] = run;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            if (first + i * 64 + lane < n) { const uint32_t pos = wh[wave][(k[i] >> shift) & 255u] + r[i]; kout[pos] = k[i]; vout[pos] = v[i]; }
+        }
+        __syncthreads();
+    }
 }
 
 __global__ void __launch_bounds__(MR_BLOCK) k_pack_grid(const float* __restrict__ in, uint16_t* __restrict__ out, int64_t n) {
@@ -376,17 +456,21 @@ int launch_matnet_scatter_mfma(const mirres_matnet_t* m, const float* occ, const
     float sx = scale3 ? scale3[0] : 1.f, sy = scale3 ? scale3[1] : 1.f, sz = scale3 ? scale3[2] : 1.f;
     MR_HIP(hipMemsetAsync(count, 0, sizeof(uint32_t), s));
     static const bool sort_on = [] { const char* e = getenv("MIRRES_GRID_SORT"); return !(e && e[0] == '0'); }();
-    const bool sort = sort_on && live && gs && gs->keys && gs->sorted && gs->buckets;
+    const bool sort = sort_on && live && gs && gs->keys && gs->keys2 && gs->sorted && gs->hist;
     // (with a live list the whole-map clamp of use_scale is not applied to slots without a vertex: nothing reads their albedo)
     if (live) {
         int ga = grid_for(n, MR_BLOCK * 8); if (ga > 256 * 8) ga = 256 * 8;
         if (sort) {
-            MR_HIP(hipMemsetAsync(gs->buckets, 0, sizeof(uint32_t) * MR_GS_BUCKETS, s));
-            k_active_from_live<true><<<ga, MR_BLOCK, 0, s>>>(occ, live, live_count, index, count, matd(m), pos, gs->keys, gs->buckets);
-            k_bucket_scan<<<1, MR_BLOCK, 0, s>>>(gs->buckets);
-            k_bucket_scatter<<<256 * 4, MR_BLOCK, 0, s>>>(index, gs->keys, count, gs->buckets, gs->sorted);
-            index = gs->sorted;
-        } else k_active_from_live<false><<<ga, MR_BLOCK, 0, s>>>(occ, live, live_count, index, count, MatNetD(), nullptr, nullptr, nullptr);
+            k_active_from_live<true><<<ga, MR_BLOCK, 0, s>>>(occ, live, live_count, index, count, matd(m), pos, gs->keys);
+            uint32_t* const hist = gs->hist; uint32_t* const totals = hist + 256 * MR_LS_GRID;
+            // pass 1 (low byte): (keys, index) -> (keys2, sorted); pass 2 (high byte): (keys2, sorted) -> (keys, index): the sorted list ends up where the unsorted one was
+            k_ls_hist<<<MR_LS_GRID, MR_BLOCK, 0, s>>>(gs->keys, count, 0, hist);
+            k_ls_scan<<<256, MR_BLOCK, 0, s>>>(hist, totals);
+            k_ls_scatter<<<MR_LS_GRID, MR_BLOCK, 0, s>>>(gs->keys, index, gs->keys2, gs->sorted, count, 0, hist, totals);
+            k_ls_hist<<<MR_LS_GRID, MR_BLOCK, 0, s>>>(gs->keys2, count, 8, hist);
+            k_ls_scan<<<256, MR_BLOCK, 0, s>>>(hist, totals);
+            k_ls_scatter<<<MR_LS_GRID, MR_BLOCK, 0, s>>>(gs->keys2, gs->sorted, gs->keys, index, count, 8, hist, totals);
+        } else k_active_from_live<false><<<ga, MR_BLOCK, 0, s>>>(occ, live, live_count, index, count, MatNetD(), nullptr, nullptr);
     }
     else k_active_list<<<grid_for(n, MR_BLOCK * MR_AL_PER), MR_BLOCK, 0, s>>>(occ, n, index, count, kd, use_scale);
     int g = grid_for(n, MR_BLOCK); if (g > 256 * 8) g = 256 * 8;

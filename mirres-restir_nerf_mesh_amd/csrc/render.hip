@@ -191,7 +191,8 @@ static PtSet pt_set(const PtBatch& PB, int h, size_t cap, int nb) {
     S.q.counters = PB.q.counters + 8 * h;
     S.q.slot_a = PB.q.slot_a + o; S.q.mask_a = PB.q.mask_a + o; S.q.slot_c = PB.q.slot_c + o; S.q.pend = PB.q.pend + 18 * o;
     S.q.live[0] = PB.q.live[0] + o; S.q.live[1] = PB.q.live[1] + o; S.q.live_cur = 0;
-    S.q.gs.keys = PB.q.gs.keys + o; S.q.gs.sorted = PB.q.gs.sorted + o; S.q.gs.buckets = PB.q.gs.buckets + 32768 * (size_t)h;
+    S.q.gs.keys = PB.q.gs.keys + o; S.q.gs.keys2 = PB.q.gs.keys2 + o; S.q.gs.sorted = PB.q.gs.sorted + o;
+    S.q.gs.hist = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(PB.q.gs.hist) + (h ? (((size_t)4 * (256 * 1024 + 256) + 255) & ~(size_t)255) : 0));
     S.prd = PB.prd + 5 * o;
     for (int k = 0; k < 2; k++) { S.pos[k] = PB.pos[k] + 3 * o; S.rd[k] = PB.rd[k] + 3 * o; S.n[k] = PB.n[k] + 3 * o; S.occ[k] = PB.occ[k] + o; }
     S.kd = PB.kd + 3 * o; S.rm = PB.rm + 2 * o;
@@ -215,7 +216,7 @@ static int carve_batch(mirres_ctx* ctx, int N, int K, int max_bounce, size_t TS,
              + al(4 * 5 * NV) + 2 * (3 * al(4 * 3 * NV) + al(4 * NV)) + al(4 * 3 * NV) + al(4 * 2 * NV) + al(4 * 9 * NV * (size_t)nb) + al(4 * NV * (size_t)nb)
              + 4 * al(4 * 8 * NV) + al(4 * 3 * (size_t)k * TS) + al(4 * (size_t)k * TS) + al(32 * (size_t)k * TS)
              + 2 * (al(sizeof(Ray) * NV) + 2 * al(4 * NV) + al(64))
-             + 2 * al(4 * NV) + 2 * al(4 * 32768);      // bucket sort in front of the material lookup: keys + sorted list, two sets of counters (one per half)
+             + 3 * al(4 * NV) + 2 * al(4 * (256 * 1024 + 256));      // radix sort in front of the material lookup: two key buffers + second list, two sets of digit counters (one per half)
     };
     // A request the device could not hold last time is not repeated every frame (a failing multi-GB hipMalloc per frame): the batch size that fitted is
     // remembered and later requests are clamped to it. The clamp is not for ever — a transient shortage (another tenant of the HBM) must not pin a long
@@ -294,7 +295,8 @@ static int carve_batch(mirres_ctx* ctx, int N, int K, int max_bounce, size_t TS,
         r.light_data = (float*)take(4 * 8 * NV); r.light_pdf = nullptr; r.M = nullptr; r.weight = nullptr;
     }
     PB.tile_data = (float*)take(4 * 3 * (size_t)K * TS); PB.tile_pdf = (float*)take(4 * (size_t)K * TS); PB.tile_aux = (float*)take(32 * (size_t)K * TS);
-    PB.q.gs.keys = (uint32_t*)take(4 * NV); PB.q.gs.sorted = (int32_t*)take(4 * NV); PB.q.gs.buckets = (uint32_t*)take(2 * 4 * 32768);
+    PB.q.gs.keys = (uint32_t*)take(4 * NV); PB.q.gs.keys2 = (uint32_t*)take(4 * NV); PB.q.gs.sorted = (int32_t*)take(4 * NV);
+    PB.q.gs.hist = (uint32_t*)take(4 * (256 * 1024 + 256)); (void)take(4 * (256 * 1024 + 256));
     PB.qf = PB.q;
     PB.qf.any_rays = (Ray*)take(sizeof(Ray) * NV); PB.qf.any_hit = (int32_t*)take(4 * NV); PB.qf.slot_a = (int32_t*)take(4 * NV); PB.qf.counters = (uint32_t*)take(64);
     PB.qf.cl_rays = nullptr; PB.qf.cl_hit = nullptr; PB.qf.mask_a = nullptr; PB.qf.slot_c = nullptr; PB.qf.pend = nullptr; PB.qf.live[0] = PB.qf.live[1] = nullptr; PB.qf.live_cur = 0;

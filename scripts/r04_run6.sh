@@ -15,7 +15,7 @@ for f in 0 1; do
 import csv,sys
 for r in csv.DictReader(open('{}')):
     n=r['Name']
-    if any(k in n for k in ('k_mlp_mfma','k_active_from_live','k_bucket','k_bounce_gen','k_trace_closest4')): print('%-60s calls %4s avg %9.1f us total %8.2f ms' % (n.replace('void mr::','')[:60], r['Calls'], float(r['AverageNs'])/1e3, float(r['TotalDurationNs'])/1e6))
+    if any(k in n for k in ('k_mlp_mfma','k_active_from_live','k_ls_','k_bounce_gen','k_trace_closest4')): print('%-60s calls %4s avg %9.1f us total %8.2f ms' % (n.replace('void mr::','')[:60], r['Calls'], float(r['AverageNs'])/1e3, float(r['TotalDurationNs'])/1e6))
 "
   rm -rf gpurun_out/ks$f
 done > gpurun_out/r04/grid_sort_kernels.txt 2>&1
