@@ -5,11 +5,11 @@ R=${1:-r02}
 RP="timeout -k 5 600 rocprofv3"     # every profiler pass under its own limit: a counter set the tool rejects must not hold the box
 rm -rf gpurun_out/pf; mkdir -p gpurun_out/pf/kt gpurun_out/pf/fetch gpurun_out/pf/write gpurun_out/pf/mlp gpurun_out/pf/tr gpurun_out/out
 python3 bench.py > gpurun_out/out/${R}_bench_default.json 2> gpurun_out/out/${R}_bench_default.err
-$RP --kernel-trace --stats --output-format csv -d gpurun_out/pf/kt -o kt -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/pf/kt/log 2>&1
+$RP --kernel-trace --stats --output-format csv -d gpurun_out/pf/kt -o kt -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras > gpurun_out/pf/kt/log 2>&1
 grep '^{' gpurun_out/pf/kt/log | tail -1 > gpurun_out/out/${R}_bench_under_rocprof.json
 cp gpurun_out/pf/kt/kt_kernel_stats.csv gpurun_out/out/${R}_kernel_stats.csv
-$RP --pmc FETCH_SIZE --output-format csv -d gpurun_out/pf/fetch -o f -- python3 bench.py --spp 8 --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > gpurun_out/pf/fetch/log 2>&1
-$RP --pmc WRITE_SIZE --output-format csv -d gpurun_out/pf/write -o w -- python3 bench.py --spp 8 --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > gpurun_out/pf/write/log 2>&1
+$RP --pmc FETCH_SIZE --output-format csv -d gpurun_out/pf/fetch -o f -- python3 bench.py --spp 8 --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-extras > gpurun_out/pf/fetch/log 2>&1
+$RP --pmc WRITE_SIZE --output-format csv -d gpurun_out/pf/write -o w -- python3 bench.py --spp 8 --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-extras > gpurun_out/pf/write/log 2>&1
 $RP --kernel-trace --stats --output-format csv -d gpurun_out/pf/mlp -o m -- python3 scripts/dev_mlp_bench.py > gpurun_out/pf/mlp/log 2>&1
 cp gpurun_out/pf/mlp/m_kernel_stats.csv gpurun_out/out/${R}_mlp_kernel_stats.csv
 grep -E '^(mlp_mfma|valu)' gpurun_out/pf/mlp/log > gpurun_out/out/${R}_mlp_bench.txt
