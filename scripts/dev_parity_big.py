@@ -15,7 +15,7 @@ p = argparse.ArgumentParser(); p.add_argument("--res", type=int, default=1600); 
 p.add_argument("--env", default="256x512", help="environment map HxW (BASELINE configs[3]: an external 1024x2048 map)"); p.add_argument("--albedo_scale", default="", help="x,y,z: use_scale on (relighting, renderer_restir.py:404-408)")
 a = p.parse_args()
 S = M.scene
-v, t = S.make_mesh(7, 64)
+v, t = S.mesh_by_name(os.environ.get("MIRRES_MESH", "icosphere"))
 info, aabb, _, _ = O.bvh_build(v, t)
 fx = fy = a.res; N = fx * fy
 eye, rd = S.camera_rays(fy, fx)
