@@ -15,12 +15,13 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-fgpu-rdc" if False else "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Wno-unused-variable", "-Wno-unused-but-set-variable",
          "-I", os.path.join(HERE, "..", "..", "include")]
 
-# No packed-fp32 VALU code (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32, formed by the SLP vectoriser) anywhere in the library: kernels may share
-# a SIMD with the MFMA material-net kernel when mirres_render runs its two streams, and on the MI355X boxes of this pool such waves occasionally got wrong results
-# for one 16-lane pass while another wave's v_mfma was in flight (found by tests/test_gpu_fullsize.py::test_schedule_does_not_change_the_frame;
-# bisected to exactly this: no MFMA -> clean, no v_pk_* in the neighbour kernels -> clean). DESIGN.md §Two streams.
-# -fno-vectorize as well: the LOOP vectoriser packs too (round 2 found v_pk_mul / v_pk_add / v_pk_fma_f32 in matnet, backward, bvh_build and eaw built with
-# -fno-slp-vectorize alone — unrolled level / tap loops vectorised by two); with both switches no object of the library contains a packed-fp32 instruction.
+# No packed-fp32 VALU code (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32, formed by the SLP and the loop vectoriser) anywhere in the library.
+# History, as far as it could be established (profiles/r03_pk_mfma_hazard.txt): in round 1, frames were corrupted when packed-fp32 kernels
+# shared SIMDs with the material-net kernel of that time (f16-split MFMA) on mirres_render's second stream; removing the packed instructions from the neighbouring
+# kernels made the frames clean. Round 3 could reproduce the corruption ONLY with that (since deleted) kernel: a stand-alone reproducer of packed fp32 beside MFMA
+# is clean (0 wrong results in 1e11), and a packed build beside today's fp32-MFMA kernel renders 32 of 32 frames identically. The root cause was never found.
+# The flags stay for a measured reason, not a hardware claim: a build WITH packed fp32 is 5-6 % slower on the frame (1014 vs 1070 Msamples/s, round 3), and the
+# hash-grid encoder's two-step fp16 rounding is pinned against contraction choices either way. tests/test_abi.py checks that no object contains v_pk_*_f32.
 # MIRRES_ALLOW_PK=1 (experiments only, with MIRRES_BUILD_TAG): leaves both vectorisers on, i.e. lets packed-fp32 instructions into the kernels again
 PER_FILE = {f: ([] if os.environ.get("MIRRES_ALLOW_PK") == "1" else ["-fno-slp-vectorize", "-fno-vectorize"]) for f in ("passes.hip", "shading.hip", "bvh_trace.hip", "bvh_build.hip", "eaw.hip", "render.hip", "backward.hip", "normal.hip", "matnet.hip", "dump.hip", "raster.hip", "antialias.hip", "selfcheck.hip")}
 # matnet.hip: MFMA accumulators in VGPRs (no v_accvgpr_read between the layers of the register-chained MLP: -15 % VALU in k_mlp_mfma)
