@@ -173,10 +173,20 @@ def traversal_roofline(args, ctx, W, mlp, env, g, prof_spp, step_ms, world, pmc)
     valu_busy = None if cnt.get("stale") else cnt.get("valu_busy")
     traffic = None if trf.get("stale") else trf.get("k_trace_any_hbm_bytes_per_launch")
     launch_s = sec_any / max(1, n_any)
-    roof = {"bound": "valu-issue", "kernel": "k_trace_any4q (shadow-ray BVH traversal)",
+    # which resource binds the kernel is read off the counters, not asserted: VALU pipes busy for most of the SIMD cycles while the HBM counters show a fraction of
+    # the peak -> "valu-issue"; without a counter snapshot that belongs to the built sources the record says so
+    hbm_frac = (traffic / launch_s / 1e9 / HBM) if (traffic and launch_s > 0) else None
+    if valu_busy is None:
+        bound = "unknown (no counter snapshot for these kernel sources: run scripts/profile_r04.sh)"
+    elif valu_busy >= 0.6 and (hbm_frac is None or hbm_frac < valu_busy):
+        bound = "valu-issue"
+    else:
+        bound = "hbm"
+    roof = {"bound": bound, "kernel": "k_trace_any4q (shadow-ray BVH traversal)",
             # the binding resource is VALU issue (the 43 MB node / leaf layout is cache resident): frac = SQ_ACTIVE_INST_VALU / SIMD cycles of the kernel, a hardware-counter
             # figure from the snapshot below (null when the snapshot does not belong to the built sources); everything else in this record is measured in this run
-            "achieved": valu_busy, "peak": 1.0, "unit": "VALU-busy cycles per SIMD cycle", "frac": valu_busy,
+            "achieved": (round(traffic / launch_s / 1e9, 1) if bound == "hbm" else valu_busy), "peak": (HBM if bound == "hbm" else 1.0),
+            "unit": ("GB/s" if bound == "hbm" else "VALU-busy cycles per SIMD cycle"), "frac": (round(hbm_frac, 4) if bound == "hbm" else valu_busy),
             "traffic": traffic,
             "own_bytes": {"achieved": round(achieved, 2), "peak": HBM, "unit": "GB/s", "frac": round(achieved / HBM, 5), "bytes_per_ray": round(own_bytes_any / max(1, rays_any), 1),
                           "l2_peak": L2, "l2_frac": round(achieved / L2, 5),
