@@ -8,7 +8,7 @@ from mirres_restir_nerf_mesh_amd import renderer_restir as RR, harness
 from mirres_restir_nerf_mesh_amd._ops import get_ctx
 from mirres_restir_nerf_mesh_amd.render_helper import MLPTexture3D
 S = M.scene
-v, t = S.make_mesh(7, 64)
+v, t = S.mesh_by_name(os.environ.get("MIRRES_MESH", "icosphere"))
 W = RR.restirbvhWorker(torch.from_numpy(v).cuda(), torch.from_numpy(t).cuda()); W.update_mesh(W.vrt, W.v_ind)
 mn, mx = S.material_min_max()
 params, w0, w1, w2 = S.make_matnet_params(seed=0)        # numpy-seeded: the same field in every process

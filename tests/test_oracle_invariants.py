@@ -136,6 +136,59 @@ def test_reference_stack_cannot_overflow(oracle):
     assert depth // 2 < deepest <= depth + 1 < 64, (depth, deepest)
 
 
+def test_behind_the_origin_hits_end_the_search_at_the_highest_slot(oracle, scene_mod):
+    """The order-free statement k_trace_closest4 relies on (bvh_trace.hip, round 4), checked against the oracle's bvh_hit on the lego-like mesh WITHOUT any
+    hierarchy: among the triangles that (1) Moller-Trumbore accepts with t <= t_min = 0 and (2) whose own leaf box passes aabb_hit against [0, anything > 0] — all of
+    it re-stated here in numpy float32 with the reference's operation order — the reference's right-first traversal reports the one with the HIGHEST sorted
+    position (slot), with that triangle's t. Rays: from surface points of the mesh, where large triangles' boxes contain the origins of many rays."""
+    f = np.float32
+    v, t = scene_mod.make_mesh_clustered(13000)
+    info, aabb, srt, h = oracle.bvh_build(v, t)
+    T = len(t)
+    slot_of = np.empty(T, np.int64); slot_of[srt[:, 1]] = np.arange(T)
+    eye, rd = scene_mod.camera_rays(30, 30)
+    prim0 = oracle.trace(info, aabb, v, t, oracle.make_rays(np.repeat(eye[None], 900, 0), rd), True)
+    fg = prim0["hit"] > 0
+    rng = np.random.default_rng(4)
+    g = rng.normal(size=(int(fg.sum()), 3)).astype(f); g /= np.linalg.norm(g, axis=1, keepdims=True)
+    d = (prim0["normal"][fg] + f(0.9) * g).astype(f)
+    o = (prim0["pos"][fg] + f(0.01) * d / np.linalg.norm(d, axis=1, keepdims=True)).astype(f)
+    r = oracle.trace(info, aabb, v, t, oracle.make_rays(o, d), True)
+    v0 = v[t[:, 0]]; E1 = (v[t[:, 1]] - v0).astype(f); E2 = (v[t[:, 2]] - v0).astype(f)
+    bmin = np.minimum(np.minimum(v[t[:, 0]], v[t[:, 1]]), v[t[:, 2]]); bmax = np.maximum(np.maximum(v[t[:, 0]], v[t[:, 1]]), v[t[:, 2]])
+    dot = lambda a, b: (a[:, 0] * b[:, 0] + a[:, 1] * b[:, 1]) + a[:, 2] * b[:, 2]
+    def cross(a, b):
+        return np.stack([a[:, 1] * b[:, 2] - a[:, 2] * b[:, 1], a[:, 2] * b[:, 0] - a[:, 0] * b[:, 2], a[:, 0] * b[:, 1] - a[:, 1] * b[:, 0]], 1).astype(f)
+    seen = 0
+    with np.errstate(all="ignore"):
+        for i in range(len(o)):
+            dn = d[i] * (f(1.0) / np.sqrt(f((d[i, 0] * d[i, 0] + d[i, 1] * d[i, 1]) + d[i, 2] * d[i, 2])))          # normalize (helperDi.slang:201)
+            dn = dn.astype(f)
+            D = np.repeat(dn[None], T, 0)
+            P = cross(D, E2); det = dot(E1, P)
+            ok = ~((det > f(-1e-15)) & (det < f(1e-15)))
+            inv = (f(1) / det).astype(f); Tv = (o[i][None] - v0).astype(f)
+            u = (dot(Tv, P) * inv).astype(f); ok &= ~((u < 0) | (u > 1))
+            Q = cross(Tv, E1); w = (dot(D, Q) * inv).astype(f); ok &= ~((w < 0) | ((u + w).astype(f) > 1))
+            tt = (dot(E2, Q) * inv).astype(f)
+            # aabb_hit of the triangle's own box against [t_min = 0, t_max = +inf) (helperDi.slang:149-170)
+            tmin = np.zeros(T, f); tmax = np.full(T, np.inf, f); passed = np.ones(T, bool)
+            for a in range(3):
+                da = dn[a] if dn[a] != 0 else f(1e-6)
+                ia = f(1.0) / da
+                t0 = ((bmin[:, a] - o[i, a]) * ia).astype(f); t1 = ((bmax[:, a] - o[i, a]) * ia).astype(f)
+                if ia < 0: t0, t1 = t1, t0
+                tmin = np.where(t0 > tmin, t0, tmin); tmax = np.where(t1 < tmax, t1, tmax)
+                passed &= ~(tmax <= tmin)
+            cand = ok & passed & (tt <= 0)
+            if not cand.any():
+                continue
+            seen += 1
+            best = np.flatnonzero(cand)[np.argmax(slot_of[cand])]
+            assert r["hit"][i] == 1 and r["prim"][i] == best and r["t"][i] == tt[best], (i, int(r["prim"][i]), int(best), float(r["t"][i]), float(tt[best]))
+    assert seen > 30, seen          # the situation is common on this mesh
+
+
 def test_negative_t_quirk_is_preserved(oracle):
     """triangle_hit ignores the t interval (helperDi.slang:172-195): a triangle BEHIND the origin whose box contains the origin is a hit."""
     v = np.array([[-1, -1, 0.3], [1, -1.1, -0.3], [0, 1, 0.1], [5, 5, 5], [6, 5, 5.2], [5, 6, 5.1]], np.float32)
