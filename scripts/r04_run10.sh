@@ -6,3 +6,5 @@ MIRRES_DIST_BACKEND=gloo timeout 900 python3 -m torch.distributed.run --nnodes=1
 tail -3 gpurun_out/r04/bench_two_ranks_gloo_dry_run.err | cut -c1-300
 python3 -c "
 import json; d=json.loads([l for l in open('gpurun_out/r04/bench_two_ranks_gloo_dry_run.json') if l.startswith('{')][-1]); print(d['value'], d['n_gpus'], d['config']['parallelism'], d.get('strips'))"
+( time timeout 1500 python3 -m pytest tests/test_gpu_fullsize.py -m gpu -q -k "round4_switches" ) > gpurun_out/r04/gpu_tests_switches.log 2>&1
+tail -5 gpurun_out/r04/gpu_tests_switches.log | cut -c1-300
