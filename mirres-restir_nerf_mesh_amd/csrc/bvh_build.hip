@@ -13,6 +13,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 namespace mr {
 
@@ -480,7 +481,7 @@ MR_DEV int delta64(int i, unsigned long long ki, int j, int n, const unsigned lo
     if (ki == kj) return 64 + __clz((uint32_t)i ^ (uint32_t)j);
     return __clzll(ki ^ kj);
 }
-__global__ void __launch_bounds__(256) k_hierarchy64(int T, const unsigned long long* __restrict__ keys, int32_t* __restrict__ info, uint32_t* __restrict__ range) {
+__global__ void __launch_bounds__(256) k_hierarchy64(int T, const unsigned long long* __restrict__ keys, int32_t* __restrict__ info, uint32_t* __restrict__ range, int32_t* __restrict__ parent) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= T - 1) return;
     const int LEAF = T - 1;
@@ -503,10 +504,176 @@ __global__ void __launch_bounds__(256) k_hierarchy64(int T, const unsigned long 
         const int ns = split + stride;
         if (ns < last && delta64(first, firstKey, ns, T, keys) > common) split = ns;
     } while (stride > 1);
-    info[3 * (size_t)g] = (split == first) ? LEAF + split : split;
-    info[3 * (size_t)g + 1] = (split + 1 == last) ? LEAF + split + 1 : split + 1;
-    info[3 * (size_t)g + 2] = 0;
+    const int cA = (split == first) ? LEAF + split : split, cB = (split + 1 == last) ? LEAF + split + 1 : split + 1;
+    info[3 * (size_t)g] = cA; info[3 * (size_t)g + 1] = cB; info[3 * (size_t)g + 2] = 0;
     range[2 * (size_t)g] = (uint32_t)first; range[2 * (size_t)g + 1] = (uint32_t)last;
+    parent[cA] = g; parent[cB] = g;
+    if (g == 0) parent[0] = -1;
+}
+
+// ---------------------------------------------------------------- SAH top over prefix clusters (round 4, MIRRES_PRIVATE_TREE=2)
+// The upper levels of the private hierarchy rebuilt top-down with a binned surface-area heuristic. Items = the maximal subtrees of the extended-Morton tree whose
+// leaves share a key prefix of MR_SAH_PREFIX bits (six (size, x, y, z) levels: ~10-20 k clusters for 3.3e5 triangles); everything above them is replaced: per level
+// every node bins its items' centroids into 8 bins per axis (box + count per bin, device atomics), picks the cheapest of the 21 candidate planes, and its items move
+// to the two children. The rebuilt nodes take over the ids of the nodes they replace (a cut through a binary tree with C subtrees below it has C - 1 nodes above it),
+// node 0 stays the root. scripts/treelab (CPU replay of the shadow-ray kernel's visiting order): records per ray -6 % on both meshes beyond the extended-Morton tree.
+// All or nothing: if anything is off — more clusters than the scratch holds, a level budget exceeded, counts that do not add up — nothing is installed and the
+// extended-Morton tree stays as it is (k_sah_install checks). Which ids the atomics hand out varies from run to run; the topology does not, and no result depends on either.
+#define MR_SAH_PREFIX 24
+#define MR_SAH_BINS 8
+#define MR_SAH_LEVELS 40
+#define MR_SAH_MAXC 65536
+struct SahNode { uint32_t count, cb[6], minidx; int32_t axis, bin; float lo, scale; int32_t cl, cr, iid, alias; float box[6]; };      // 24 words
+struct SahBin { uint32_t count, box[6]; };
+struct SahState { uint32_t n_items, n_top, n_nodes, n_internal, n_resolved, fail, first[MR_SAH_LEVELS + 3]; };
+MR_DEV int node_prefix(int n, int T, const unsigned long long* __restrict__ key64, const uint32_t* __restrict__ range) {
+    if (n >= T - 1) return 128;                                  // a leaf
+    const unsigned long long a = key64[range[2 * (size_t)n]], b = key64[range[2 * (size_t)n + 1]];
+    return a == b ? 64 : __clzll(a ^ b);
+}
+MR_DEV void sah_accumulate(SahNode* nodes, int k, const float* __restrict__ bx, uint32_t item) {
+    SahNode& N = nodes[k];
+    atomicAdd(&N.count, 1u); atomicMin(&N.minidx, item);
+#pragma unroll
+    for (int a = 0; a < 3; a++) { const uint32_t c = f2ord(bx[a] + 0.5f * (bx[3 + a] - bx[a])); atomicMin(&N.cb[a], c); atomicMax(&N.cb[3 + a], c); }
+}
+__global__ void __launch_bounds__(256) k_sah_reset(SahState* st, SahNode* nodes, int n_nodes) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) { st->n_items = 0; st->n_top = 1; st->n_nodes = 1; st->n_internal = 1; st->n_resolved = 0; st->fail = 0; st->first[0] = 0; st->first[1] = 1; st->first[2] = 1; }
+    if (i < n_nodes) { SahNode z; z.count = 0; z.minidx = 0xffffffffu; for (int a = 0; a < 3; a++) { z.cb[a] = 0xffffffffu; z.cb[3 + a] = 0u; } z.axis = -1; z.bin = 0; z.lo = 0.f; z.scale = 0.f; z.cl = z.cr = -1; z.iid = -1; z.alias = -1;
+                       for (int a = 0; a < 6; a++) z.box[a] = 0.f; nodes[i] = z; }
+}
+__global__ void __launch_bounds__(256) k_sah_clusters(int T, const unsigned long long* __restrict__ key64, const uint32_t* __restrict__ range, const int32_t* __restrict__ parent,
+                                                      const float* __restrict__ paabb, SahState* st, SahNode* nodes, int32_t* __restrict__ iref, int32_t* __restrict__ inode,
+                                                      int32_t* __restrict__ top_ids) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= 2 * T - 1) return;
+    const int cp = node_prefix(n, T, key64, range);
+    const int par = parent[n];
+    const int cpp = par < 0 ? -1 : node_prefix(par, T, key64, range);
+    if (cp >= MR_SAH_PREFIX && cpp < MR_SAH_PREFIX) {            // a cluster root (n == 0 here: the whole tree is one cluster, nothing to rebuild)
+        const uint32_t i = atomicAdd(&st->n_items, 1u);
+        if (i < MR_SAH_MAXC) { iref[i] = n; inode[i] = 0; sah_accumulate(nodes, 0, paabb + 6 * (size_t)n, i); }
+        else st->fail = 1;
+    } else if (cp < MR_SAH_PREFIX) {                             // an internal node above the cut: its id is reused
+        if (n == 0) top_ids[0] = 0; else { const uint32_t j = atomicAdd(&st->n_top, 1u); if (j < MR_SAH_MAXC) top_ids[j] = n; else st->fail = 1; }
+    }
+    if (n == 0) { for (int a = 0; a < 6; a++) nodes[0].box[a] = paabb[a]; nodes[0].iid = 0; }
+}
+MR_DEV int sah_bin_of(float c, float lo, float scale) { const int b = (int)((c - lo) * scale); return b < 0 ? 0 : (b > MR_SAH_BINS - 1 ? MR_SAH_BINS - 1 : b); }
+__global__ void __launch_bounds__(256) k_sah_bin(int level, const SahState* st, const SahNode* __restrict__ nodes, const int32_t* __restrict__ iref, const int32_t* __restrict__ inode,
+                                                 const float* __restrict__ paabb, SahBin* __restrict__ bins) {
+    const uint32_t C = st->n_items < MR_SAH_MAXC ? st->n_items : MR_SAH_MAXC;
+    const int f0 = (int)st->first[level];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < C; i += gridDim.x * blockDim.x) {
+        const int k = inode[i];
+        if (k < f0) continue;                                    // resolved (-1) — every live item sits in a node of the current level
+        const SahNode& N = nodes[k];
+        if (N.count < 2) continue;
+        const float* bx = paabb + 6 * (size_t)iref[i];
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const float lo = ord2f(N.cb[a]), hi = ord2f(N.cb[3 + a]);
+            if (!(hi > lo)) continue;
+            const int b = sah_bin_of(bx[a] + 0.5f * (bx[3 + a] - bx[a]), lo, (float)MR_SAH_BINS / (hi - lo));
+            SahBin& B = bins[((size_t)(k - f0) * 3 + a) * MR_SAH_BINS + b];
+            atomicAdd(&B.count, 1u);
+#pragma unroll
+            for (int q = 0; q < 3; q++) { atomicMin(&B.box[q], f2ord(bx[q])); atomicMax(&B.box[3 + q], f2ord(bx[3 + q])); }
+        }
+    }
+}
+__global__ void __launch_bounds__(256) k_sah_split(int level, SahState* st, SahNode* nodes, SahBin* __restrict__ bins) {
+    const int f0 = (int)st->first[level], f1 = (int)st->first[level + 1];
+    const int k = f0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= f1) return;
+    SahNode& N = nodes[k];
+    if (N.count < 2) return;                                     // a single item: resolved by k_sah_assign (count 0 cannot happen: both sides of a split are non-empty)
+    if (level >= MR_SAH_LEVELS) { st->fail = 1; return; }
+    float best = 3.0e38f; int best_axis = -1, best_bin = 0; uint32_t best_nl = 0; float lbox[6], rbox[6];
+    for (int a = 0; a < 3; a++) {
+        SahBin* B = bins + ((size_t)(k - f0) * 3 + a) * MR_SAH_BINS;
+        const float lo = ord2f(N.cb[a]), hi = ord2f(N.cb[3 + a]);
+        if (hi > lo) {
+            float racc[MR_SAH_BINS][6]; uint32_t rcnt[MR_SAH_BINS];
+            float acc[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY}; uint32_t c = 0;
+            for (int b = MR_SAH_BINS - 1; b >= 0; b--) {
+                if (B[b].count) { for (int q = 0; q < 3; q++) { acc[q] = fminf(acc[q], ord2f(B[b].box[q])); acc[3 + q] = fmaxf(acc[3 + q], ord2f(B[b].box[3 + q])); } c += B[b].count; }
+                for (int q = 0; q < 6; q++) racc[b][q] = acc[q]; rcnt[b] = c;
+            }
+            float l[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY}; uint32_t nl = 0;
+            for (int b = 0; b + 1 < MR_SAH_BINS; b++) {
+                if (B[b].count) { for (int q = 0; q < 3; q++) { l[q] = fminf(l[q], ord2f(B[b].box[q])); l[3 + q] = fmaxf(l[3 + q], ord2f(B[b].box[3 + q])); } nl += B[b].count; }
+                const uint32_t nr = rcnt[b + 1];
+                if (!nl || !nr) continue;
+                const float* r = racc[b + 1];
+                const float al = (l[3] - l[0]) * (l[4] - l[1]) + (l[4] - l[1]) * (l[5] - l[2]) + (l[5] - l[2]) * (l[3] - l[0]);
+                const float ar = (r[3] - r[0]) * (r[4] - r[1]) + (r[4] - r[1]) * (r[5] - r[2]) + (r[5] - r[2]) * (r[3] - r[0]);
+                const float cost = al * (float)nl + ar * (float)nr;
+                if (cost < best) { best = cost; best_axis = a; best_bin = b; best_nl = nl; for (int q = 0; q < 6; q++) { lbox[q] = l[q]; rbox[q] = r[q]; } }
+            }
+        }
+        for (int b = 0; b < MR_SAH_BINS; b++) { B[b].count = 0; for (int q = 0; q < 3; q++) { B[b].box[q] = 0xffffffffu; B[b].box[3 + q] = 0u; } }      // clean for the next level
+    }
+    const uint32_t base = atomicAdd(&st->n_nodes, 2u);
+    if (base + 2 > 2 * MR_SAH_MAXC) { st->fail = 1; return; }
+    N.cl = (int)base; N.cr = (int)base + 1;
+    if (best_axis >= 0) {
+        N.axis = best_axis; N.bin = best_bin; N.lo = ord2f(N.cb[best_axis]); N.scale = (float)MR_SAH_BINS / (ord2f(N.cb[3 + best_axis]) - N.lo);
+        for (int q = 0; q < 6; q++) { nodes[base].box[q] = lbox[q]; nodes[base + 1].box[q] = rbox[q]; }
+        if (best_nl >= 2) nodes[base].iid = (int)atomicAdd(&st->n_internal, 1u);
+        if (N.count - best_nl >= 2) nodes[base + 1].iid = (int)atomicAdd(&st->n_internal, 1u);
+    } else {
+        // all centroids coincide: peel off the item with the smallest index (the boxes of the two sides are formed by k_sah_assign)
+        N.axis = 3;
+        for (int q = 0; q < 3; q++) { nodes[base].box[q] = nodes[base + 1].box[q] = INFINITY; nodes[base].box[3 + q] = nodes[base + 1].box[3 + q] = -INFINITY; }
+        if (N.count - 1 >= 2) nodes[base + 1].iid = (int)atomicAdd(&st->n_internal, 1u);
+    }
+}
+MR_DEV void atomic_box_f(float* box, const float* bx) {   // float min / max through the order-preserving integer encoding would need a second array: CAS loops on the few degenerate nodes instead
+#pragma unroll
+    for (int q = 0; q < 6; q++) {
+        unsigned int* p = reinterpret_cast<unsigned int*>(box + q); unsigned int old = *p;
+        while (true) { const float cur = __uint_as_float(old); const float nv = q < 3 ? fminf(cur, bx[q]) : fmaxf(cur, bx[q]); if (nv == cur) break;
+                       const unsigned int prev = atomicCAS(p, old, __float_as_uint(nv)); if (prev == old) break; old = prev; }
+    }
+}
+__global__ void __launch_bounds__(256) k_sah_assign(int level, SahState* st, SahNode* nodes, const int32_t* __restrict__ iref, int32_t* __restrict__ inode, const float* __restrict__ paabb) {
+    const uint32_t C = st->n_items < MR_SAH_MAXC ? st->n_items : MR_SAH_MAXC;
+    const int f0 = (int)st->first[level];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < C; i += gridDim.x * blockDim.x) {
+        const int k = inode[i];
+        if (k < f0) continue;
+        SahNode& N = nodes[k];
+        if (N.count == 1) { N.alias = iref[i]; inode[i] = -1; atomicAdd(&st->n_resolved, 1u); continue; }
+        if (N.cl < 0) continue;                                  // not split (failure flagged by k_sah_split)
+        const float* bx = paabb + 6 * (size_t)iref[i];
+        int side;
+        if (N.axis == 3) side = (i == N.minidx) ? 0 : 1;
+        else side = sah_bin_of(bx[N.axis] + 0.5f * (bx[3 + N.axis] - bx[N.axis]), N.lo, N.scale) <= N.bin ? 0 : 1;
+        const int c = side ? N.cr : N.cl;
+        inode[i] = c;
+        sah_accumulate(nodes, c, bx, i);
+        if (N.axis == 3) atomic_box_f(nodes[c].box, bx);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) st->first[level + 2] = st->n_nodes;      // no allocation runs concurrently with this kernel
+}
+// the rebuilt upper levels into the private node arrays — or nothing at all when the counts do not add up
+__global__ void __launch_bounds__(256) k_sah_install(const SahState* st, const SahNode* __restrict__ nodes, const int32_t* __restrict__ top_ids, int32_t* __restrict__ pinfo, float* __restrict__ paabb) {
+    const uint32_t C = st->n_items;
+    if (st->fail || C < 2 || C > MR_SAH_MAXC || st->n_resolved != C || st->n_internal != C - 1 || st->n_top != C - 1) return;
+    const uint32_t n = st->n_nodes;
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        const SahNode& N = nodes[k];
+        if (N.count < 2) continue;
+        const int id = top_ids[N.iid];
+        const SahNode &L = nodes[N.cl], &R = nodes[N.cr];
+        pinfo[3 * (size_t)id] = L.count == 1 ? L.alias : top_ids[L.iid];
+        pinfo[3 * (size_t)id + 1] = R.count == 1 ? R.alias : top_ids[R.iid];
+        pinfo[3 * (size_t)id + 2] = 0;
+#pragma unroll
+        for (int q = 0; q < 6; q++) paabb[6 * (size_t)id + q] = N.box[q];
+    }
 }
 
 // Breadth-first prefix (TOPN = 85: levels 0..3, 341: levels 0..4) of the compressed 4-wide tree for the LDS-resident part of the shadow-ray
@@ -586,6 +753,17 @@ int mirres_bvh_create(mirres_bvh_t** out, int max_tris) {
     MR_HIP(hipMalloc(&b->p_key64, sizeof(unsigned long long) * T));
     MR_HIP(hipMalloc(&b->p_info, sizeof(int32_t) * 3 * (2 * T))); MR_HIP(hipMalloc(&b->p_aabb, sizeof(float) * 6 * (2 * T)));
     MR_HIP(hipMalloc(&b->p_range, sizeof(uint32_t) * 2 * T));
+    MR_HIP(hipMalloc(&b->p_parent, sizeof(int32_t) * 2 * T));
+    {   // scratch of the SAH top (k_sah_*): clusters, rebuilt nodes, one level's bins
+        const size_t C = MR_SAH_MAXC;
+        MR_HIP(hipMalloc(&b->sah_state, sizeof(SahState)));
+        MR_HIP(hipMalloc(&b->sah_nodes, sizeof(SahNode) * 2 * C));
+        MR_HIP(hipMalloc(&b->sah_bins, sizeof(SahBin) * C * 3 * MR_SAH_BINS));
+        MR_HIP(hipMalloc(&b->sah_iref, sizeof(int32_t) * C)); MR_HIP(hipMalloc(&b->sah_inode, sizeof(int32_t) * C)); MR_HIP(hipMalloc(&b->sah_top, sizeof(int32_t) * C));
+        std::vector<SahBin> z(C * 3 * MR_SAH_BINS);
+        for (auto& e : z) { e.count = 0; for (int q = 0; q < 3; q++) { e.box[q] = 0xffffffffu; e.box[3 + q] = 0u; } }
+        MR_HIP(hipMemcpy(b->sah_bins, z.data(), sizeof(SahBin) * z.size(), hipMemcpyHostToDevice));      // every split leaves its bins clean again
+    }
     MR_HIP(hipMalloc(&b->top85q, sizeof(Node4q) * 85));
     MR_HIP(hipMalloc(&b->top341q, sizeof(Node4q) * 341));
     MR_HIP(hipMalloc(&b->root_box, sizeof(float) * 8));
@@ -600,7 +778,7 @@ void mirres_bvh_destroy(mirres_bvh_t* b) {
     if (!b) return;
     void* ptrs[] = {b->ele_aabb, b->extent, b->keys_in, b->keys_out, b->vals_in, b->vals_out, b->parent, b->flags, b->own_info,
                     b->own_aabb, b->nodes, b->tris, b->root_box, b->sort_tmp, b->work, b->redo[0], b->redo[1], b->dump_pool, b->lvl, b->nodes4q, b->leaves, b->top85q, b->top341q,
-                    b->p_keys, b->p_vals, b->p_key64, b->p_info, b->p_aabb, b->p_range};
+                    b->p_keys, b->p_vals, b->p_key64, b->p_info, b->p_aabb, b->p_range, b->p_parent, b->sah_state, b->sah_nodes, b->sah_bins, b->sah_iref, b->sah_inode, b->sah_top};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete b;
 }
@@ -633,11 +811,11 @@ int mirres_bvh_build(mirres_bvh_t* b, const float* vert, int V, const int32_t* t
     // the 4-wide layout of the shadow-ray / ordered closest-hit kernels: collapsed from the private extended-Morton hierarchy (above), or
     // (MIRRES_PRIVATE_TREE=0) from the reference LBVH itself
     static const int private_tree = [] { const char* e = getenv("MIRRES_PRIVATE_TREE"); return e ? atoi(e) : 1; }();
-    if (private_tree == 1 && T >= 8) {
+    if (private_tree >= 1 && T >= 8) {
         k_emc_keys<<<grd, blk, 0, s>>>(T, aabb, b->extent, b->p_keys, b->p_vals);
         radix_sort_pairs_u32(b->p_keys, b->p_vals, b->keys_in, b->vals_in, (uint32_t*)b->sort_tmp, T, s);      // keys_in / vals_in: idle halves of the first sort's ping-pong
         k_emc_leaves<<<grd, blk, 0, s>>>(T, b->p_keys, b->p_vals, b->keys_out, aabb, b->p_key64, b->p_info, b->p_aabb);
-        k_hierarchy64<<<grd, blk, 0, s>>>(T, b->p_key64, b->p_info, b->p_range);
+        k_hierarchy64<<<grd, blk, 0, s>>>(T, b->p_key64, b->p_info, b->p_range, b->p_parent);
         RefitLevels Lv; Lv.n = 1; Lv.a[0] = b->p_aabb + 6 * (size_t)(T - 1);
         int n = T; float* dst = b->lvl;                                                                          // the pyramid of the reference refit is done with
         while (n > 64 && Lv.n < 5) {
@@ -646,6 +824,17 @@ int mirres_bvh_build(mirres_bvh_t* b, const float* vert, int V, const int32_t* t
             Lv.a[Lv.n++] = dst; dst += 6 * (size_t)nd; n = nd;
         }
         k_refit_ranges<<<grd, blk, 0, s>>>(T, b->p_range, Lv, b->p_aabb);
+        if (private_tree == 2) {
+            SahState* st = reinterpret_cast<SahState*>(b->sah_state); SahNode* sn = reinterpret_cast<SahNode*>(b->sah_nodes); SahBin* sb = reinterpret_cast<SahBin*>(b->sah_bins);
+            k_sah_reset<<<grid_for(2 * MR_SAH_MAXC, blk), blk, 0, s>>>(st, sn, 2 * MR_SAH_MAXC);
+            k_sah_clusters<<<grid_for(2 * (size_t)T, blk), blk, 0, s>>>(T, b->p_key64, b->p_range, b->p_parent, b->p_aabb, st, sn, b->sah_iref, b->sah_inode, b->sah_top);
+            for (int level = 0; level <= MR_SAH_LEVELS; level++) {
+                k_sah_bin<<<256, blk, 0, s>>>(level, st, sn, b->sah_iref, b->sah_inode, b->p_aabb, sb);
+                k_sah_split<<<grid_for(MR_SAH_MAXC, blk), blk, 0, s>>>(level, st, sn, sb);
+                k_sah_assign<<<256, blk, 0, s>>>(level, st, sn, b->sah_iref, b->sah_inode, b->p_aabb);
+            }
+            k_sah_install<<<256, blk, 0, s>>>(st, sn, b->sah_top, b->p_info, b->p_aabb);
+        }
         k_pack4q<true><<<grd, blk, 0, s>>>(T, b->p_info, b->p_aabb, info, aabb, vert, tri, b->nodes4q, b->leaves);
     } else k_pack4q<false><<<grd, blk, 0, s>>>(T, info, aabb, info, aabb, vert, tri, b->nodes4q, b->leaves);
     if (T - 1 >= 341 * 4) { k_top4q<<<1, 256, 0, s>>>(T, b->nodes4q, b->top85q, 85); k_top4q<<<1, 256, 0, s>>>(T, b->nodes4q, b->top341q, 341); }

@@ -387,10 +387,10 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_persist(BvhView B, con
 // deeper than the LBVH it was collapsed from, whose depth is bounded by the bits of the augmented sort key: 30 Morton bits + ceil(log2 T) position bits
 // (lbvh_hierarchy.slang:40-60: every internal node splits its range at the highest differing bit of (code, position)). Hence at most
 // 3 * (30 + ceil(log2 T)) entries for the collapsed reference LBVH; the private extended-Morton hierarchy (bvh_build.hip) has 32 + 6 key bits that can differ:
-// 3 * (38 + ceil(log2 T)) = 171 for T < 2^19, 207 for any T < 2^31 — MR_ANY_STACK = 224 cannot overflow ("Stack bounds").
-// (The reference's own stack of 64 {index, left, right, prim} entries, helperDi.slang:136, holds at most depth + 1 <= 62 entries: it cannot overflow either.)
+// 3 * (38 + ceil(log2 T)); with its upper levels rebuilt by the SAH top (at most 40 levels above clusters that share 24 key bits: 14 key bits + the position
+// bits left below) 3 * (40 + 14 + ceil(log2 T)) = 219 for T < 2^19, 255 for any T < 2^31 — MR_ANY_STACK = 256 cannot overflow ("Stack bounds").
 #ifndef MR_ANY_STACK
-#define MR_ANY_STACK 224
+#define MR_ANY_STACK 256
 #endif
 #define MR_TOPBIT 0x20000000
 // ---------------------------------------------------------------- shadow rays on the COMPRESSED 4-wide collapse (engine.hpp Node4q / LeafRec)

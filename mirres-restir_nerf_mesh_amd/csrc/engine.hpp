@@ -84,6 +84,7 @@ struct mirres_bvh {
     mr::Node4q* top85q = nullptr, *top341q = nullptr;   // [85], [341] breadth-first prefixes of nodes4q, children inside tagged MR_TOPBIT
     // private steering hierarchy (bvh_build.hip k_emc_*): extended-Morton keys / slots, 64-bit keys, node arrays in the reference's own layout (leaf info[.][2] = slot)
     uint32_t *p_keys = nullptr, *p_vals = nullptr, *p_range = nullptr; unsigned long long* p_key64 = nullptr; int32_t* p_info = nullptr; float* p_aabb = nullptr;
+    int32_t* p_parent = nullptr; void *sah_state = nullptr, *sah_nodes = nullptr, *sah_bins = nullptr; int32_t *sah_iref = nullptr, *sah_inode = nullptr, *sah_top = nullptr;   // SAH top over prefix clusters (k_sah_*)
     float* root_box = nullptr;      // [6]
     uint32_t* work = nullptr;       // [MR_WSETS * MR_WSET] head sets of the persistent traversal kernels: 0/1 chain, 2/3 API, 4-6 ordered closest + redo, 7/8 bulk stream, 9/10 path-tracing stream,
                                     // 11 final-stage stream, 12-14 ordered closest + redo and 15/16 any / closest of the second path-tracing stream

@@ -66,6 +66,7 @@ static BTree build_lbvh(const Mesh& M, int bits) {
 // extended Morton codes (Vinkler, Bittner, Havran 2017): the triangle's size is a fourth coordinate whose bits are interleaved every `every` position triples, so
 // that large triangles split off near the top instead of inflating the boxes of the small ones around them
 static std::vector<int> g_emc_order;
+static std::vector<uint64_t> g_emc_keys;
 static BTree build_emc(const Mesh& M, int every, int sbits, int first, int qmode = 0, int xyzbits = 20) {
     int T = M.T; std::vector<uint64_t> code(T); std::vector<int> idx(T); std::iota(idx.begin(), idx.end(), 0);
     float sd = 0; for (int a = 0; a < 3; a++) { float e = M.scene.hi[a] - M.scene.lo[a]; sd += e * e; } sd = std::sqrt(sd);
@@ -80,13 +81,72 @@ static BTree build_emc(const Mesh& M, int every, int sbits, int first, int qmode
         code[i] = k << (63 - nb); }
     std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return code[a] < code[b]; });
     std::vector<uint64_t> key(T); for (int i = 0; i < T; i++) key[i] = code[idx[i]];
-    g_emc_order = idx;
+    g_emc_order = idx; g_emc_keys = key;
     return karras(key, idx);
 }
 static BTree from_reference(const Mesh& M, const std::vector<int>& info) {   // reference LBVH arrays -> BTree (leaf = primitive id)
     int T = M.T; BTree B; B.l.assign(T - 1, 0); B.r.assign(T - 1, 0);
     for (int i = 0; i < T - 1; i++) { int L = info[3 * i], R = info[3 * i + 1]; B.l[i] = L >= T - 1 ? ~info[3 * L + 2] : L; B.r[i] = R >= T - 1 ? ~info[3 * R + 2] : R; }
     B.root = 0; return B;
+}
+// hybrid (HLBVH with a SAH top): the LBVH subtrees whose leaves share a Morton prefix of `bits` bits become items of a top-down binned SAH build
+static BTree build_sah_items(const std::vector<Box>& ib, const std::vector<int>& iref, BTree B, int nbins, int mode = 0);
+static BTree build_hybrid_keys(const Mesh& M, const std::vector<uint64_t>& key, const std::vector<int>& idx, int prefix_bits_from_top, int mode, int nbins);
+static BTree build_hybrid(const Mesh& M, int prefix_bits, int mode = 0, int nbins = 32) {
+    int T = M.T; std::vector<uint64_t> code(T); std::vector<int> idx(T); std::iota(idx.begin(), idx.end(), 0);
+    for (int i = 0; i < T; i++) { uint64_t c[3]; for (int a = 0; a < 3; a++) { float u = (M.cen[3 * i + a] - M.scene.lo[a]) / (M.scene.hi[a] - M.scene.lo[a]); c[a] = (uint64_t)std::min(std::max((double)u * 1024.0, 0.0), 1023.0); } code[i] = expand21(c[0]) << 2 | expand21(c[1]) << 1 | expand21(c[2]); }
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return code[a] < code[b]; });
+    std::vector<uint64_t> key(T); for (int i = 0; i < T; i++) key[i] = code[idx[i]] << 34;      // codes left-aligned: prefix lengths count from bit 63
+    return build_hybrid_keys(M, key, idx, prefix_bits, mode, nbins);
+}
+static BTree build_hybrid_keys(const Mesh& M, const std::vector<uint64_t>& key, const std::vector<int>& idx, int prefix_bits, int mode, int nbins) {
+    int T = M.T;
+    BTree B = karras(key, idx); refit(B, M);
+    // leaf range of every internal node (first, last sorted position) by a post-order pass
+    int n = T - 1; std::vector<int> first(n), last(n); std::vector<int> pos_of(T); for (int i = 0; i < T; i++) pos_of[idx[i]] = i;
+    std::vector<int> order; std::vector<int> st = {B.root};
+    while (!st.empty()) { int x = st.back(); st.pop_back(); order.push_back(x); if (B.l[x] >= 0) st.push_back(B.l[x]); if (B.r[x] >= 0) st.push_back(B.r[x]); }
+    for (int k = n - 1; k >= 0; k--) { int x = order[k]; int fl = B.l[x] >= 0 ? first[B.l[x]] : pos_of[~B.l[x]], lr = B.r[x] >= 0 ? last[B.r[x]] : pos_of[~B.r[x]]; first[x] = fl; last[x] = lr; }
+    std::vector<Box> ib; std::vector<int> iref; st = {B.root};
+    while (!st.empty()) { int x = st.back(); st.pop_back();
+        auto emit = [&](int ref) { ib.push_back(ref >= 0 ? B.box[ref] : M.tb[~ref]); iref.push_back(ref); };
+        int common = key[first[x]] == key[last[x]] ? 64 : __builtin_clzll(key[first[x]] ^ key[last[x]]);
+        if (common >= prefix_bits) { emit(x); continue; }
+        for (int ch : {B.l[x], B.r[x]}) { if (ch < 0) emit(ch); else st.push_back(ch); } }
+    printf("   hybrid %d bits: %zu clusters\n", prefix_bits, ib.size());
+    return build_sah_items(ib, iref, B, nbins, mode);
+}
+static BTree build_sah_items(const std::vector<Box>& ib, const std::vector<int>& iref, BTree B, int nbins, int mode) {
+    // new internal nodes are appended to B (the LBVH, whose subtrees the items refer to); the root moves to the top of the SAH tree
+    int n = (int)ib.size(); std::vector<int> idx(n); std::iota(idx.begin(), idx.end(), 0);
+    std::vector<float> cen(3 * (size_t)n); for (int i = 0; i < n; i++) for (int a = 0; a < 3; a++) cen[3 * i + a] = ib[i].lo[a] + 0.5f * (ib[i].hi[a] - ib[i].lo[a]);
+    struct Job { int lo, hi, parent, side; }; std::vector<Job> st = {{0, n, -1, 0}};
+    while (!st.empty()) {
+        Job j = st.back(); st.pop_back(); int m = j.hi - j.lo;
+        auto attach = [&](int ref) { if (j.parent >= 0) (j.side ? B.r : B.l)[j.parent] = ref; else B.root = ref; };
+        if (m == 1) { attach(iref[idx[j.lo]]); continue; }
+        int me = (int)B.l.size(); B.l.push_back(0); B.r.push_back(0); attach(me);
+        Box cb = empty_box(); for (int i = j.lo; i < j.hi; i++) for (int a = 0; a < 3; a++) { float c = cen[3 * idx[i] + a]; cb.lo[a] = std::min(cb.lo[a], c); cb.hi[a] = std::max(cb.hi[a], c); }
+        int best_axis = -1, best_bin = -1; double best = 1e300;
+        if (mode == 1 && m > 2) {   // spatial median of the centroid bounds on the largest axis
+            int a = 0; for (int k = 1; k < 3; k++) if (cb.hi[k] - cb.lo[k] > cb.hi[a] - cb.lo[a]) a = k;
+            if (cb.hi[a] - cb.lo[a] > 0) { best_axis = a; best_bin = nbins / 2 - 1; }
+        }
+        if (mode == 0 && m > 2) for (int a = 0; a < 3; a++) {
+            float ext = cb.hi[a] - cb.lo[a]; if (!(ext > 0)) continue;
+            std::vector<Box> bb(nbins, empty_box()); std::vector<int> cnt(nbins, 0);
+            for (int i = j.lo; i < j.hi; i++) { int b = std::min(nbins - 1, (int)((cen[3 * idx[i] + a] - cb.lo[a]) / ext * nbins)); bb[b] = merge(bb[b], ib[idx[i]]); cnt[b]++; }
+            std::vector<double> la(nbins), ra(nbins); std::vector<int> lc(nbins), rc(nbins); Box acc = empty_box(); int c = 0;
+            for (int b = 0; b < nbins; b++) { if (cnt[b]) acc = merge(acc, bb[b]); c += cnt[b]; la[b] = c ? area(acc) : 0; lc[b] = c; }
+            acc = empty_box(); c = 0; for (int b = nbins - 1; b >= 0; b--) { if (cnt[b]) acc = merge(acc, bb[b]); c += cnt[b]; ra[b] = c ? area(acc) : 0; rc[b] = c; }
+            for (int b = 0; b + 1 < nbins; b++) { if (!lc[b] || !rc[b + 1]) continue; double cost = la[b] * lc[b] + ra[b + 1] * rc[b + 1]; if (cost < best) { best = cost; best_axis = a; best_bin = b; } }
+        }
+        int mid;
+        if (best_axis < 0) { int a = 0; for (int k = 1; k < 3; k++) if (cb.hi[k] - cb.lo[k] > cb.hi[a] - cb.lo[a]) a = k; mid = j.lo + m / 2; std::nth_element(idx.begin() + j.lo, idx.begin() + mid, idx.begin() + j.hi, [&](int x, int y) { return cen[3 * x + a] < cen[3 * y + a]; }); }
+        else { float ext = cb.hi[best_axis] - cb.lo[best_axis]; mid = (int)(std::partition(idx.begin() + j.lo, idx.begin() + j.hi, [&](int x) { return std::min(nbins - 1, (int)((cen[3 * x + best_axis] - cb.lo[best_axis]) / ext * nbins)) <= best_bin; }) - idx.begin()); if (mid == j.lo || mid == j.hi) mid = j.lo + m / 2; }
+        st.push_back({j.lo, mid, me, 0}); st.push_back({mid, j.hi, me, 1});
+    }
+    return B;
 }
 // top-down binned SAH, one triangle per leaf
 static BTree build_sah(const Mesh& M, int nbins = 32) {
@@ -224,14 +284,17 @@ int main(int argc, char** argv) {
     if (argc > 3) { std::vector<int> info(3 * (size_t)(2 * M.T - 1)); FILE* g = fopen(argv[3], "rb"); if (g && fread(info.data(), 4, info.size(), g) == info.size()) trees.push_back({"reference LBVH (30-bit)", from_reference(M, info)}); if (g) fclose(g); }
     else trees.push_back({"LBVH 30-bit", build_lbvh(M, 10)});
     trees.push_back({"EMC lin s8 (32-bit: xyz8)", build_emc(M, 1, 8, 0, 0, 8)});
-    trees.push_back({"EMC lin s8 xyz20", build_emc(M, 1, 8, 0, 0, 20)});
-    { std::vector<int> ord = g_emc_order; trees.push_back({"PLOC r=8 on EMC order", build_ploc(M, 8, 21, &ord)}); }
-    trees.push_back({"EMC sqrt s8 xyz20", build_emc(M, 1, 8, 0, 1, 20)});
-    trees.push_back({"EMC log s8 xyz20", build_emc(M, 1, 8, 0, 2, 20)});
-    trees.push_back({"EMC log s4 xyz20", build_emc(M, 1, 4, 0, 2, 20)});
-    trees.push_back({"EMC sqrt s5 xyz20", build_emc(M, 1, 5, 0, 1, 20)});
-    trees.push_back({"PLOC r=8", build_ploc(M, 8)});
-    trees.push_back({"PLOC r=4", build_ploc(M, 4)});
+    { build_emc(M, 1, 8, 0, 0, 8); std::vector<uint64_t> ek = g_emc_keys; std::vector<int> eo = g_emc_order;
+      trees.push_back({"EMC cut 20 bits + SAH8 top", build_hybrid_keys(M, ek, eo, 20, 0, 8)});
+      trees.push_back({"EMC cut 24 bits + SAH8 top", build_hybrid_keys(M, ek, eo, 24, 0, 8)});
+      trees.push_back({"EMC cut 28 bits + SAH8 top", build_hybrid_keys(M, ek, eo, 28, 0, 8)}); }
+    trees.push_back({"hybrid 18: SAH 32 bins", build_hybrid(M, 18, 0, 32)});
+    trees.push_back({"hybrid 18: SAH 8 bins", build_hybrid(M, 18, 0, 8)});
+    trees.push_back({"hybrid 18: SAH 4 bins", build_hybrid(M, 18, 0, 4)});
+    trees.push_back({"hybrid 18: spatial median", build_hybrid(M, 18, 1, 32)});
+    trees.push_back({"hybrid 18: object median", build_hybrid(M, 18, 2, 32)});
+    trees.push_back({"hybrid 21: SAH 8 bins", build_hybrid(M, 21, 0, 8)});
+    trees.push_back({"binned SAH", build_sah(M)});
     std::vector<unsigned char> ref_hits(rays.size() / 8), hits(rays.size() / 8);
     printf("%-26s %-8s %9s %9s %7s %8s %8s %8s %9s %6s %6s\n", "binary hierarchy", "collapse", "SAH(bin)", "SAH(4w)", "depth4", "rec/ray", "box/ray", "tri/ray", "wave-it", "maxsp", "hit");
     bool first = true;
