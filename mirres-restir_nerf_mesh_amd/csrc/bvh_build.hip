@@ -546,49 +546,83 @@ __global__ void __launch_bounds__(256) k_sah_reset(SahState* st, SahNode* nodes,
 __global__ void __launch_bounds__(256) k_sah_clusters(int T, const unsigned long long* __restrict__ key64, const uint32_t* __restrict__ range, const int32_t* __restrict__ parent,
                                                       const float* __restrict__ paabb, SahState* st, SahNode* nodes, int32_t* __restrict__ iref, int32_t* __restrict__ inode,
                                                       int32_t* __restrict__ top_ids) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= 2 * T - 1) return;
-    const int cp = node_prefix(n, T, key64, range);
-    const int par = parent[n];
-    const int cpp = par < 0 ? -1 : node_prefix(par, T, key64, range);
-    if (cp >= MR_SAH_PREFIX && cpp < MR_SAH_PREFIX) {            // a cluster root (n == 0 here: the whole tree is one cluster, nothing to rebuild)
-        const uint32_t i = atomicAdd(&st->n_items, 1u);
-        if (i < MR_SAH_MAXC) { iref[i] = n; inode[i] = 0; sah_accumulate(nodes, 0, paabb + 6 * (size_t)n, i); }
-        else st->fail = 1;
-    } else if (cp < MR_SAH_PREFIX) {                             // an internal node above the cut: its id is reused
-        if (n == 0) top_ids[0] = 0; else { const uint32_t j = atomicAdd(&st->n_top, 1u); if (j < MR_SAH_MAXC) top_ids[j] = n; else st->fail = 1; }
+    // the root's item count and centroid bounds: one set of atomics per workgroup (every cluster would otherwise hit the same eight words)
+    __shared__ uint32_t s_count, s_min, s_cb[6];
+    if (threadIdx.x == 0) { s_count = 0; s_min = 0xffffffffu; for (int a = 0; a < 3; a++) { s_cb[a] = 0xffffffffu; s_cb[3 + a] = 0u; } }
+    __syncthreads();
+    for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < 2 * T - 1; n += gridDim.x * blockDim.x) {
+        const int cp = node_prefix(n, T, key64, range);
+        const int par = parent[n];
+        const int cpp = par < 0 ? -1 : node_prefix(par, T, key64, range);
+        if (cp >= MR_SAH_PREFIX && cpp < MR_SAH_PREFIX) {            // a cluster root (n == 0 here: the whole tree is one cluster, nothing to rebuild)
+            const uint32_t i = atomicAdd(&st->n_items, 1u);
+            if (i < MR_SAH_MAXC) {
+                iref[i] = n; inode[i] = 0;
+                const float* bx = paabb + 6 * (size_t)n;
+                atomicAdd(&s_count, 1u); atomicMin(&s_min, i);
+#pragma unroll
+                for (int a = 0; a < 3; a++) { const uint32_t c = f2ord(bx[a] + 0.5f * (bx[3 + a] - bx[a])); atomicMin(&s_cb[a], c); atomicMax(&s_cb[3 + a], c); }
+            } else st->fail = 1;
+        } else if (cp < MR_SAH_PREFIX) {                             // an internal node above the cut: its id is reused
+            if (n == 0) top_ids[0] = 0; else { const uint32_t j = atomicAdd(&st->n_top, 1u); if (j < MR_SAH_MAXC) top_ids[j] = n; else st->fail = 1; }
+        }
+        if (n == 0) { for (int a = 0; a < 6; a++) nodes[0].box[a] = paabb[a]; nodes[0].iid = 0; }
     }
-    if (n == 0) { for (int a = 0; a < 6; a++) nodes[0].box[a] = paabb[a]; nodes[0].iid = 0; }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_count) {
+        atomicAdd(&nodes[0].count, s_count); atomicMin(&nodes[0].minidx, s_min);
+        for (int a = 0; a < 3; a++) { atomicMin(&nodes[0].cb[a], s_cb[a]); atomicMax(&nodes[0].cb[3 + a], s_cb[3 + a]); }
+    }
 }
 MR_DEV int sah_bin_of(float c, float lo, float scale) { const int b = (int)((c - lo) * scale); return b < 0 ? 0 : (b > MR_SAH_BINS - 1 ? MR_SAH_BINS - 1 : b); }
+// Levels 0 .. MR_SAH_LDS_LEVELS - 1 have at most 32 nodes (64 children): thousands of items would hammer the same few words with device atomics (the first version
+// spent 4.4 of its 4.9 ms there), so every workgroup first accumulates in LDS and then sends one atomic per non-empty word. Deeper levels go straight to memory.
+#define MR_SAH_LDS_LEVELS 6
+#define MR_SAH_LDS_NODES 32
+// levels from MR_SAH_TAIL on are finished by ONE workgroup looping over the remaining levels (few items are still unplaced by then; a launch per level would
+// cost more than the work): k_sah_tail
+#define MR_SAH_TAIL 14
+MR_DEV void sah_bin_item(uint32_t i, int f0, const SahNode* __restrict__ nodes, const int32_t* __restrict__ iref, const int32_t* __restrict__ inode,
+                         const float* __restrict__ paabb, SahBin* bins) {      // bins: global, or the workgroup's LDS copy (same indexing)
+    const int k = inode[i];
+    if (k < f0) return;                                      // resolved (-1) — every live item sits in a node of the current level
+    const SahNode& N = nodes[k];
+    if (N.count < 2) return;
+    const float* bx = paabb + 6 * (size_t)iref[i];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const float lo = ord2f(N.cb[a]), hi = ord2f(N.cb[3 + a]);
+        if (!(hi > lo)) continue;
+        const int b = sah_bin_of(bx[a] + 0.5f * (bx[3 + a] - bx[a]), lo, (float)MR_SAH_BINS / (hi - lo));
+        SahBin& B = bins[((size_t)(k - f0) * 3 + a) * MR_SAH_BINS + b];
+        atomicAdd(&B.count, 1u);
+#pragma unroll
+        for (int q = 0; q < 3; q++) { atomicMin(&B.box[q], f2ord(bx[q])); atomicMax(&B.box[3 + q], f2ord(bx[3 + q])); }
+    }
+}
+template <bool LDS>
 __global__ void __launch_bounds__(256) k_sah_bin(int level, const SahState* st, const SahNode* __restrict__ nodes, const int32_t* __restrict__ iref, const int32_t* __restrict__ inode,
                                                  const float* __restrict__ paabb, SahBin* __restrict__ bins) {
+    __shared__ SahBin sb[LDS ? MR_SAH_LDS_NODES * 3 * MR_SAH_BINS : 1];
     const uint32_t C = st->n_items < MR_SAH_MAXC ? st->n_items : MR_SAH_MAXC;
     const int f0 = (int)st->first[level];
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < C; i += gridDim.x * blockDim.x) {
-        const int k = inode[i];
-        if (k < f0) continue;                                    // resolved (-1) — every live item sits in a node of the current level
-        const SahNode& N = nodes[k];
-        if (N.count < 2) continue;
-        const float* bx = paabb + 6 * (size_t)iref[i];
-#pragma unroll
-        for (int a = 0; a < 3; a++) {
-            const float lo = ord2f(N.cb[a]), hi = ord2f(N.cb[3 + a]);
-            if (!(hi > lo)) continue;
-            const int b = sah_bin_of(bx[a] + 0.5f * (bx[3 + a] - bx[a]), lo, (float)MR_SAH_BINS / (hi - lo));
-            SahBin& B = bins[((size_t)(k - f0) * 3 + a) * MR_SAH_BINS + b];
-            atomicAdd(&B.count, 1u);
-#pragma unroll
-            for (int q = 0; q < 3; q++) { atomicMin(&B.box[q], f2ord(bx[q])); atomicMax(&B.box[3 + q], f2ord(bx[3 + q])); }
+    if (LDS) {
+        for (int j = threadIdx.x; j < MR_SAH_LDS_NODES * 3 * MR_SAH_BINS; j += blockDim.x) { sb[j].count = 0; for (int q = 0; q < 3; q++) { sb[j].box[q] = 0xffffffffu; sb[j].box[3 + q] = 0u; } }
+        __syncthreads();
+    }
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < C; i += gridDim.x * blockDim.x) sah_bin_item(i, f0, nodes, iref, inode, paabb, LDS ? sb : bins);
+    if (LDS) {
+        __syncthreads();
+        for (int j = threadIdx.x; j < MR_SAH_LDS_NODES * 3 * MR_SAH_BINS; j += blockDim.x) {
+            if (!sb[j].count) continue;
+            atomicAdd(&bins[j].count, sb[j].count);
+            for (int q = 0; q < 3; q++) { atomicMin(&bins[j].box[q], sb[j].box[q]); atomicMax(&bins[j].box[3 + q], sb[j].box[3 + q]); }
         }
     }
 }
-__global__ void __launch_bounds__(256) k_sah_split(int level, SahState* st, SahNode* nodes, SahBin* __restrict__ bins) {
-    const int f0 = (int)st->first[level], f1 = (int)st->first[level + 1];
-    const int k = f0 + blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= f1) return;
+MR_DEV void sah_split_node(int k, int level, int f0, SahState* st, SahNode* nodes, SahBin* __restrict__ bins) {
     SahNode& N = nodes[k];
-    if (N.count < 2) return;                                     // a single item: resolved by k_sah_assign (count 0 cannot happen: both sides of a split are non-empty)
+    if (N.count < 2) return;                                     // a single item: resolved by the assign step (count 0 cannot happen: both sides of a split are non-empty)
     if (level >= MR_SAH_LEVELS) { st->fail = 1; return; }
     float best = 3.0e38f; int best_axis = -1, best_bin = 0; uint32_t best_nl = 0; float lbox[6], rbox[6];
     for (int a = 0; a < 3; a++) {
@@ -624,13 +658,18 @@ __global__ void __launch_bounds__(256) k_sah_split(int level, SahState* st, SahN
         if (best_nl >= 2) nodes[base].iid = (int)atomicAdd(&st->n_internal, 1u);
         if (N.count - best_nl >= 2) nodes[base + 1].iid = (int)atomicAdd(&st->n_internal, 1u);
     } else {
-        // all centroids coincide: peel off the item with the smallest index (the boxes of the two sides are formed by k_sah_assign)
+        // all centroids coincide: peel off the item with the smallest index (the boxes of the two sides are formed by the assign step)
         N.axis = 3;
         for (int q = 0; q < 3; q++) { nodes[base].box[q] = nodes[base + 1].box[q] = INFINITY; nodes[base].box[3 + q] = nodes[base + 1].box[3 + q] = -INFINITY; }
         if (N.count - 1 >= 2) nodes[base + 1].iid = (int)atomicAdd(&st->n_internal, 1u);
     }
 }
-MR_DEV void atomic_box_f(float* box, const float* bx) {   // float min / max through the order-preserving integer encoding would need a second array: CAS loops on the few degenerate nodes instead
+__global__ void __launch_bounds__(256) k_sah_split(int level, SahState* st, SahNode* nodes, SahBin* __restrict__ bins) {
+    const int f0 = (int)st->first[level], f1 = (int)st->first[level + 1];
+    const int k = f0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < f1) sah_split_node(k, level, f0, st, nodes, bins);
+}
+MR_DEV void atomic_box_f(float* box, const float* bx) {   // float min / max by compare-and-swap: only the few degenerate nodes come here
 #pragma unroll
     for (int q = 0; q < 6; q++) {
         unsigned int* p = reinterpret_cast<unsigned int*>(box + q); unsigned int old = *p;
@@ -638,25 +677,65 @@ MR_DEV void atomic_box_f(float* box, const float* bx) {   // float min / max thr
                        const unsigned int prev = atomicCAS(p, old, __float_as_uint(nv)); if (prev == old) break; old = prev; }
     }
 }
+// per-child accumulators of the assign step: {count, centroid bounds x 6, smallest item index} — in the nodes themselves, or in a workgroup's LDS copy
+struct SahAcc { uint32_t count, cb[6], minidx; };
+MR_DEV void sah_assign_item(uint32_t i, int f0, int c0, SahState* st, SahNode* nodes, const int32_t* __restrict__ iref, int32_t* __restrict__ inode, const float* __restrict__ paabb, SahAcc* lacc) {
+    const int k = inode[i];
+    if (k < f0) return;
+    SahNode& N = nodes[k];
+    if (N.count == 1) { N.alias = iref[i]; inode[i] = -1; atomicAdd(&st->n_resolved, 1u); return; }
+    if (N.cl < 0) return;                                    // not split (failure flagged by the split step)
+    const float* bx = paabb + 6 * (size_t)iref[i];
+    int side;
+    if (N.axis == 3) side = (i == N.minidx) ? 0 : 1;
+    else side = sah_bin_of(bx[N.axis] + 0.5f * (bx[3 + N.axis] - bx[N.axis]), N.lo, N.scale) <= N.bin ? 0 : 1;
+    const int c = side ? N.cr : N.cl;
+    inode[i] = c;
+    if (lacc) {
+        SahAcc& A = lacc[c - c0];
+        atomicAdd(&A.count, 1u); atomicMin(&A.minidx, i);
+#pragma unroll
+        for (int a = 0; a < 3; a++) { const uint32_t cc = f2ord(bx[a] + 0.5f * (bx[3 + a] - bx[a])); atomicMin(&A.cb[a], cc); atomicMax(&A.cb[3 + a], cc); }
+    } else sah_accumulate(nodes, c, bx, i);
+    if (N.axis == 3) atomic_box_f(nodes[c].box, bx);
+}
+template <bool LDS>
 __global__ void __launch_bounds__(256) k_sah_assign(int level, SahState* st, SahNode* nodes, const int32_t* __restrict__ iref, int32_t* __restrict__ inode, const float* __restrict__ paabb) {
+    __shared__ SahAcc sa[LDS ? 2 * MR_SAH_LDS_NODES : 1];
     const uint32_t C = st->n_items < MR_SAH_MAXC ? st->n_items : MR_SAH_MAXC;
-    const int f0 = (int)st->first[level];
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < C; i += gridDim.x * blockDim.x) {
-        const int k = inode[i];
-        if (k < f0) continue;
-        SahNode& N = nodes[k];
-        if (N.count == 1) { N.alias = iref[i]; inode[i] = -1; atomicAdd(&st->n_resolved, 1u); continue; }
-        if (N.cl < 0) continue;                                  // not split (failure flagged by k_sah_split)
-        const float* bx = paabb + 6 * (size_t)iref[i];
-        int side;
-        if (N.axis == 3) side = (i == N.minidx) ? 0 : 1;
-        else side = sah_bin_of(bx[N.axis] + 0.5f * (bx[3 + N.axis] - bx[N.axis]), N.lo, N.scale) <= N.bin ? 0 : 1;
-        const int c = side ? N.cr : N.cl;
-        inode[i] = c;
-        sah_accumulate(nodes, c, bx, i);
-        if (N.axis == 3) atomic_box_f(nodes[c].box, bx);
+    const int f0 = (int)st->first[level], c0 = (int)st->first[level + 1];      // this level's nodes start at f0, their children at c0
+    if (LDS) {
+        for (int j = threadIdx.x; j < 2 * MR_SAH_LDS_NODES; j += blockDim.x) { sa[j].count = 0; sa[j].minidx = 0xffffffffu; for (int q = 0; q < 3; q++) { sa[j].cb[q] = 0xffffffffu; sa[j].cb[3 + q] = 0u; } }
+        __syncthreads();
+    }
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < C; i += gridDim.x * blockDim.x) sah_assign_item(i, f0, c0, st, nodes, iref, inode, paabb, LDS ? sa : nullptr);
+    if (LDS) {
+        __syncthreads();
+        for (int j = threadIdx.x; j < 2 * MR_SAH_LDS_NODES; j += blockDim.x) {
+            if (!sa[j].count) continue;
+            SahNode& N = nodes[c0 + j];
+            atomicAdd(&N.count, sa[j].count); atomicMin(&N.minidx, sa[j].minidx);
+            for (int q = 0; q < 3; q++) { atomicMin(&N.cb[q], sa[j].cb[q]); atomicMax(&N.cb[3 + q], sa[j].cb[3 + q]); }
+        }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) st->first[level + 2] = st->n_nodes;      // no allocation runs concurrently with this kernel
+}
+// the remaining levels in one workgroup: bin -> split -> assign per level with workgroup barriers in between, until a level has no node left
+__global__ void __launch_bounds__(1024) k_sah_tail(int level0, SahState* st, SahNode* nodes, const int32_t* __restrict__ iref, int32_t* __restrict__ inode, const float* __restrict__ paabb,
+                                                   SahBin* __restrict__ bins) {
+    const uint32_t C = st->n_items < MR_SAH_MAXC ? st->n_items : MR_SAH_MAXC;
+    for (int level = level0; level <= MR_SAH_LEVELS; level++) {
+        const int f0 = (int)st->first[level], f1 = (int)st->first[level + 1];
+        if (f1 <= f0) break;                                  // uniform: every thread reads the same words after the barrier below
+        for (uint32_t i = threadIdx.x; i < C; i += blockDim.x) sah_bin_item(i, f0, nodes, iref, inode, paabb, bins);
+        __threadfence(); __syncthreads();
+        for (int k = f0 + (int)threadIdx.x; k < f1; k += blockDim.x) sah_split_node(k, level, f0, st, nodes, bins);
+        __threadfence(); __syncthreads();
+        for (uint32_t i = threadIdx.x; i < C; i += blockDim.x) sah_assign_item(i, f0, f1, st, nodes, iref, inode, paabb, nullptr);
+        __threadfence(); __syncthreads();
+        if (threadIdx.x == 0) st->first[level + 2] = st->n_nodes;
+        __threadfence(); __syncthreads();
+    }
 }
 // the rebuilt upper levels into the private node arrays — or nothing at all when the counts do not add up
 __global__ void __launch_bounds__(256) k_sah_install(const SahState* st, const SahNode* __restrict__ nodes, const int32_t* __restrict__ top_ids, int32_t* __restrict__ pinfo, float* __restrict__ paabb) {
@@ -827,18 +906,35 @@ int mirres_bvh_build(mirres_bvh_t* b, const float* vert, int V, const int32_t* t
         if (private_tree == 2) {
             SahState* st = reinterpret_cast<SahState*>(b->sah_state); SahNode* sn = reinterpret_cast<SahNode*>(b->sah_nodes); SahBin* sb = reinterpret_cast<SahBin*>(b->sah_bins);
             k_sah_reset<<<grid_for(2 * MR_SAH_MAXC, blk), blk, 0, s>>>(st, sn, 2 * MR_SAH_MAXC);
-            k_sah_clusters<<<grid_for(2 * (size_t)T, blk), blk, 0, s>>>(T, b->p_key64, b->p_range, b->p_parent, b->p_aabb, st, sn, b->sah_iref, b->sah_inode, b->sah_top);
-            for (int level = 0; level <= MR_SAH_LEVELS; level++) {
-                k_sah_bin<<<256, blk, 0, s>>>(level, st, sn, b->sah_iref, b->sah_inode, b->p_aabb, sb);
-                k_sah_split<<<grid_for(MR_SAH_MAXC, blk), blk, 0, s>>>(level, st, sn, sb);
-                k_sah_assign<<<256, blk, 0, s>>>(level, st, sn, b->sah_iref, b->sah_inode, b->p_aabb);
+            k_sah_clusters<<<256, blk, 0, s>>>(T, b->p_key64, b->p_range, b->p_parent, b->p_aabb, st, sn, b->sah_iref, b->sah_inode, b->sah_top);
+            for (int level = 0; level < MR_SAH_TAIL; level++) {
+                const bool lds = level < MR_SAH_LDS_LEVELS;                      // <= 2^level nodes in the level
+                const int nodes_max = level < 16 ? (1 << level) : MR_SAH_MAXC;
+                if (lds) k_sah_bin<true><<<64, blk, 0, s>>>(level, st, sn, b->sah_iref, b->sah_inode, b->p_aabb, sb);
+                else k_sah_bin<false><<<256, blk, 0, s>>>(level, st, sn, b->sah_iref, b->sah_inode, b->p_aabb, sb);
+                k_sah_split<<<grid_for(nodes_max < MR_SAH_MAXC ? nodes_max : MR_SAH_MAXC, blk), blk, 0, s>>>(level, st, sn, sb);
+                if (lds) k_sah_assign<true><<<64, blk, 0, s>>>(level, st, sn, b->sah_iref, b->sah_inode, b->p_aabb);
+                else k_sah_assign<false><<<256, blk, 0, s>>>(level, st, sn, b->sah_iref, b->sah_inode, b->p_aabb);
             }
+            k_sah_tail<<<1, 1024, 0, s>>>(MR_SAH_TAIL, st, sn, b->sah_iref, b->sah_inode, b->p_aabb, sb);
             k_sah_install<<<256, blk, 0, s>>>(st, sn, b->sah_top, b->p_info, b->p_aabb);
         }
         k_pack4q<true><<<grd, blk, 0, s>>>(T, b->p_info, b->p_aabb, info, aabb, vert, tri, b->nodes4q, b->leaves);
     } else k_pack4q<false><<<grd, blk, 0, s>>>(T, info, aabb, info, aabb, vert, tri, b->nodes4q, b->leaves);
     if (T - 1 >= 341 * 4) { k_top4q<<<1, 256, 0, s>>>(T, b->nodes4q, b->top85q, 85); k_top4q<<<1, 256, 0, s>>>(T, b->nodes4q, b->top341q, 341); }
     MR_LAUNCH_CHECK("bvh_build");
+    return MIRRES_OK;
+}
+
+// development aid (not part of include/mirres.h): counters of the last SAH-top build: clusters, nodes above the cut, rebuilt nodes, internal ones, resolved clusters, failure flag, levels used
+int mirres_debug_sah_state(mirres_bvh_t* b, uint32_t* h_out) {
+    if (!b || !h_out || !b->sah_state) return MIRRES_E_ARG;
+    SahState st;
+    MR_HIP(hipDeviceSynchronize());
+    MR_HIP(hipMemcpy(&st, b->sah_state, sizeof(st), hipMemcpyDeviceToHost));
+    h_out[0] = st.n_items; h_out[1] = st.n_top; h_out[2] = st.n_nodes; h_out[3] = st.n_internal; h_out[4] = st.n_resolved; h_out[5] = st.fail;
+    int lv = 0; while (lv + 1 < MR_SAH_LEVELS + 2 && st.first[lv + 1] > st.first[lv]) lv++;
+    h_out[6] = (uint32_t)lv; h_out[7] = 0;
     return MIRRES_OK;
 }
 

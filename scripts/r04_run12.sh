@@ -15,5 +15,5 @@ for mesh in icosphere clustered; do
     echo "mesh $mesh private_tree $pt frame: $(MIRRES_PRIVATE_TREE=$pt python3 bench.py --mesh $mesh --spp 128 --steps 3 --warmup 1 --no-cpu-baseline --no-extras 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; print(d['value'], 'Msamples/s', d['ms_per_step'], 'ms; any launch', r['launch_ms'], 'ms', r['grays_per_s'], 'Grays/s per_ray', r['per_ray']['any_production'], 'closest', r['closest']['launch_ms'], 'ms per_ray', r['per_ray']['closest'], 'stack', r['private_stack_deepest'])")" >> $out
   done
 done
-for pt in 1 2; do echo "build time private_tree $pt: $(MIRRES_PRIVATE_TREE=$pt python3 scripts/dev_build_time.py 2>&1 | tail -2 | tr '\n' ' ')" >> $out; done
+for mesh in icosphere clustered; do for pt in 1 2; do echo "build time $mesh private_tree $pt: $(MIRRES_MESH=$mesh MIRRES_PRIVATE_TREE=$pt python3 scripts/dev_build_time.py 2>&1 | tail -2 | tr "\n" " ")" >> $out; done; done
 cat $out
