@@ -511,12 +511,13 @@ __global__ void __launch_bounds__(256) k_hierarchy64(int T, const unsigned long 
     if (g == 0) parent[0] = -1;
 }
 
-// ---------------------------------------------------------------- SAH top over prefix clusters (round 4, MIRRES_PRIVATE_TREE=2)
+// ---------------------------------------------------------------- SAH top over prefix clusters (round 4; the default, MIRRES_PRIVATE_TREE=1 keeps the plain extended-Morton tree)
 // The upper levels of the private hierarchy rebuilt top-down with a binned surface-area heuristic. Items = the maximal subtrees of the extended-Morton tree whose
 // leaves share a key prefix of MR_SAH_PREFIX bits (six (size, x, y, z) levels: ~10-20 k clusters for 3.3e5 triangles); everything above them is replaced: per level
 // every node bins its items' centroids into 8 bins per axis (box + count per bin, device atomics), picks the cheapest of the 21 candidate planes, and its items move
 // to the two children. The rebuilt nodes take over the ids of the nodes they replace (a cut through a binary tree with C subtrees below it has C - 1 nodes above it),
-// node 0 stays the root. scripts/treelab (CPU replay of the shadow-ray kernel's visiting order): records per ray -6 % on both meshes beyond the extended-Morton tree.
+// node 0 stays the root. scripts/treelab (CPU replay of the shadow-ray kernel's visiting order): records per ray -6 % on both meshes beyond the extended-Morton tree;
+// measured (profiles/r04_ab_sah_top.txt): shadow-ray launch -4 % (icosphere) / -7 % (lego-like), 128-spp frame +2.5 % / +3.8 %, build +0.9 / +1.4 ms.
 // All or nothing: if anything is off — more clusters than the scratch holds, a level budget exceeded, counts that do not add up — nothing is installed and the
 // extended-Morton tree stays as it is (k_sah_install checks). Which ids the atomics hand out varies from run to run; the topology does not, and no result depends on either.
 #define MR_SAH_PREFIX 24
@@ -579,9 +580,9 @@ MR_DEV int sah_bin_of(float c, float lo, float scale) { const int b = (int)((c -
 // spent 4.4 of its 4.9 ms there), so every workgroup first accumulates in LDS and then sends one atomic per non-empty word. Deeper levels go straight to memory.
 #define MR_SAH_LDS_LEVELS 6
 #define MR_SAH_LDS_NODES 32
-// levels from MR_SAH_TAIL on are finished by ONE workgroup looping over the remaining levels (few items are still unplaced by then; a launch per level would
-// cost more than the work): k_sah_tail
-#define MR_SAH_TAIL 14
+// levels from MR_SAH_TAIL on are finished by ONE workgroup looping over the remaining levels (the trees of both test meshes are complete by level 18 / 21: the
+// tail usually finds nothing to do; started at level 14 it cost 2.4 ms on the lego-like mesh — a third of the items were still unplaced): k_sah_tail
+#define MR_SAH_TAIL 22
 MR_DEV void sah_bin_item(uint32_t i, int f0, const SahNode* __restrict__ nodes, const int32_t* __restrict__ iref, const int32_t* __restrict__ inode,
                          const float* __restrict__ paabb, SahBin* bins) {      // bins: global, or the workgroup's LDS copy (same indexing)
     const int k = inode[i];
@@ -887,9 +888,9 @@ int mirres_bvh_build(mirres_bvh_t* b, const float* vert, int V, const int32_t* t
         k_refit_ranges<<<grd, blk, 0, s>>>(T, b->flags, Lv, aabb);
     }
     k_pack<<<grd, blk, 0, s>>>(T, info, aabb, vert, tri, b->nodes, b->tris, b->root_box);
-    // the 4-wide layout of the shadow-ray / ordered closest-hit kernels: collapsed from the private extended-Morton hierarchy (above), or
-    // (MIRRES_PRIVATE_TREE=0) from the reference LBVH itself
-    static const int private_tree = [] { const char* e = getenv("MIRRES_PRIVATE_TREE"); return e ? atoi(e) : 1; }();
+    // the 4-wide layout of the shadow-ray / ordered closest-hit kernels: collapsed from the private hierarchy — extended-Morton tree with its upper levels rebuilt by
+    // the binned-SAH top (2, default), the plain extended-Morton tree (MIRRES_PRIVATE_TREE=1) — or (0) from the reference LBVH itself
+    static const int private_tree = [] { const char* e = getenv("MIRRES_PRIVATE_TREE"); return e ? atoi(e) : 2; }();
     if (private_tree >= 1 && T >= 8) {
         k_emc_keys<<<grd, blk, 0, s>>>(T, aabb, b->extent, b->p_keys, b->p_vals);
         radix_sort_pairs_u32(b->p_keys, b->p_vals, b->keys_in, b->vals_in, (uint32_t*)b->sort_tmp, T, s);      // keys_in / vals_in: idle halves of the first sort's ping-pong
@@ -909,7 +910,7 @@ int mirres_bvh_build(mirres_bvh_t* b, const float* vert, int V, const int32_t* t
             k_sah_clusters<<<256, blk, 0, s>>>(T, b->p_key64, b->p_range, b->p_parent, b->p_aabb, st, sn, b->sah_iref, b->sah_inode, b->sah_top);
             for (int level = 0; level < MR_SAH_TAIL; level++) {
                 const bool lds = level < MR_SAH_LDS_LEVELS;                      // <= 2^level nodes in the level
-                const int nodes_max = level < 16 ? (1 << level) : MR_SAH_MAXC;
+                const int nodes_max = level < 16 ? (1 << level) : MR_SAH_MAXC;                  // <= 2^level nodes, never more than clusters
                 if (lds) k_sah_bin<true><<<64, blk, 0, s>>>(level, st, sn, b->sah_iref, b->sah_inode, b->p_aabb, sb);
                 else k_sah_bin<false><<<256, blk, 0, s>>>(level, st, sn, b->sah_iref, b->sah_inode, b->p_aabb, sb);
                 k_sah_split<<<grid_for(nodes_max < MR_SAH_MAXC ? nodes_max : MR_SAH_MAXC, blk), blk, 0, s>>>(level, st, sn, sb);

@@ -132,7 +132,9 @@ static BTree build_sah_items(const std::vector<Box>& ib, const std::vector<int>&
             int a = 0; for (int k = 1; k < 3; k++) if (cb.hi[k] - cb.lo[k] > cb.hi[a] - cb.lo[a]) a = k;
             if (cb.hi[a] - cb.lo[a] > 0) { best_axis = a; best_bin = nbins / 2 - 1; }
         }
-        if (mode == 0 && m > 2) for (int a = 0; a < 3; a++) {
+        int amax = 0; for (int k2 = 1; k2 < 3; k2++) if (cb.hi[k2] - cb.lo[k2] > cb.hi[amax] - cb.lo[amax]) amax = k2;
+        if ((mode == 0 || mode == 3) && m > 2) for (int a = 0; a < 3; a++) {
+            if (mode == 3 && a != amax) continue;
             float ext = cb.hi[a] - cb.lo[a]; if (!(ext > 0)) continue;
             std::vector<Box> bb(nbins, empty_box()); std::vector<int> cnt(nbins, 0);
             for (int i = j.lo; i < j.hi; i++) { int b = std::min(nbins - 1, (int)((cen[3 * idx[i] + a] - cb.lo[a]) / ext * nbins)); bb[b] = merge(bb[b], ib[idx[i]]); cnt[b]++; }
@@ -287,6 +289,8 @@ int main(int argc, char** argv) {
     { build_emc(M, 1, 8, 0, 0, 8); std::vector<uint64_t> ek = g_emc_keys; std::vector<int> eo = g_emc_order;
       trees.push_back({"EMC cut 20 bits + SAH8 top", build_hybrid_keys(M, ek, eo, 20, 0, 8)});
       trees.push_back({"EMC cut 24 bits + SAH8 top", build_hybrid_keys(M, ek, eo, 24, 0, 8)});
+      trees.push_back({"EMC cut 24 + SAH8 largest axis", build_hybrid_keys(M, ek, eo, 24, 3, 8)});
+      trees.push_back({"EMC cut 24 + SAH16 largest axis", build_hybrid_keys(M, ek, eo, 24, 3, 16)});
       trees.push_back({"EMC cut 28 bits + SAH8 top", build_hybrid_keys(M, ek, eo, 28, 0, 8)}); }
     trees.push_back({"hybrid 18: SAH 32 bins", build_hybrid(M, 18, 0, 32)});
     trees.push_back({"hybrid 18: SAH 8 bins", build_hybrid(M, 18, 0, 8)});
