@@ -87,6 +87,28 @@ def test_clustered_lbvh_and_traversal_match_the_oracle(lego, oracle):
             % (len(t), depth, deepest, *ref["counters"][:, :3].mean(0), mm.mean(), frac))
 
 
+def test_private_hierarchy_is_installed(lego, scene_mod):
+    """The private hierarchy's SAH top is all-or-nothing (k_sah_install): a silent fall-back to the plain extended-Morton tree would cost speed, not correctness, and
+    no parity test would notice. Here: on both full-size meshes the counters of the last build say that every cluster was placed, that the rebuilt nodes are exactly
+    as many as the nodes they replace, and that nothing failed."""
+    import ctypes as C
+    import torch
+    from mirres_restir_nerf_mesh_amd import renderer_restir as RR
+    from mirres_restir_nerf_mesh_amd._lib import lib
+    if os.environ.get("MIRRES_PRIVATE_TREE", "2") != "2":
+        pytest.skip("the SAH top is switched off in this process")
+    L = lib(); L.mirres_debug_sah_state.argtypes = [C.c_void_p, C.c_void_p]; L.mirres_debug_sah_state.restype = C.c_int
+    v2, t2 = scene_mod.mesh_by_name("icosphere")
+    W2 = RR.restirbvhWorker(torch.from_numpy(v2).cuda(), torch.from_numpy(t2).cuda()); W2.update_mesh(W2.vrt, W2.v_ind)
+    for name, W in (("clustered", lego[2]), ("icosphere", W2)):
+        W.update_mesh(W.vrt, W.v_ind)
+        st = (C.c_uint32 * 8)()
+        assert L.mirres_debug_sah_state(W.h, st) == 0
+        clusters, above, rebuilt, internal, resolved, fail, levels = st[:7]
+        assert fail == 0 and 1000 < clusters <= 65536 and resolved == clusters and internal == clusters - 1 == above and rebuilt == 2 * clusters - 1 and 10 <= levels <= 40, (name, list(st))
+        _report("%s: SAH top over %d clusters, %d levels" % (name, clusters, levels))
+
+
 def _frame_vs_oracle(lego, scene_mod, oracle, res, ssaa, spp, seed, what, bounces=2):
     v, t, W, RR, harness, torch, info, aabb = lego
     import sys
