@@ -272,6 +272,17 @@ static Counts replay(const Tree4& Q, const Mesh& M, const std::vector<float>& ra
     double wi = 0; for (int w = 0; w + 64 <= n; w += 64) { int m = 0; for (int k = 0; k < 64; k++) m = std::max(m, recs[w + k]); wi += m; }
     C.rec = rec / n; C.box = box / n; C.tri = tri / n; C.hit = hit / n; C.wave_iter = wi / (n / 64); C.maxsp = maxsp; return C;
 }
+// child boxes as the GPU stores them (Node4q): offsets from the node's corner in power-of-two steps, `bits` bits per plane, rounded outward
+static Tree4 quantise(Tree4 Q, int bits) {
+    const float qmax = (float)((1 << bits) - 1);
+    for (auto& q : Q.nodes) for (int a = 0; a < 3; a++) {
+        float lo = 3e38f, hi = -3e38f; for (int k = 0; k < q.n; k++) { lo = std::min(lo, q.box[k].lo[a]); hi = std::max(hi, q.box[k].hi[a]); }
+        float r = (hi - lo) / qmax; int e; std::frexp(r > 0 ? r : 1e-30f, &e); float st = std::ldexp(1.0f, e);      // smallest power of two >= r
+        while (st * 0.5f >= r && st > 1e-30f) st *= 0.5f; while (lo + st * qmax < hi) st *= 2;
+        for (int k = 0; k < q.n; k++) { float ql = std::floor((q.box[k].lo[a] - lo) / st), qh = std::ceil((q.box[k].hi[a] - lo) / st); q.box[k].lo[a] = lo + std::min(std::max(ql, 0.f), qmax) * st; q.box[k].hi[a] = lo + std::min(std::max(qh, 0.f), qmax) * st; }
+    }
+    return Q;
+}
 static int depth4(const Tree4& Q) { int d = 0; std::vector<std::pair<int, int>> st = {{Q.root, 1}}; while (!st.empty()) { auto [x, dd] = st.back(); st.pop_back(); d = std::max(d, dd); for (int k = 0; k < Q.nodes[x].n; k++) if (Q.nodes[x].ref[k] >= 0) st.push_back({Q.nodes[x].ref[k], dd + 1}); } return d; }
 
 int main(int argc, char** argv) {
@@ -303,8 +314,8 @@ int main(int argc, char** argv) {
     printf("%-26s %-8s %9s %9s %7s %8s %8s %8s %9s %6s %6s\n", "binary hierarchy", "collapse", "SAH(bin)", "SAH(4w)", "depth4", "rec/ray", "box/ray", "tri/ray", "wave-it", "maxsp", "hit");
     bool first = true;
     for (auto& [name, B] : trees) { refit(B, M); double sb = sah_binary(B, M);
-        for (int c = 0; c < 2; c++) { Tree4 Q = c ? collapse_sah(B, M) : collapse_greedy(B, M); Counts C = replay(Q, M, rays, first ? &ref_hits : &hits);
+        for (int c = 0; c < 4; c++) { if (c == 1 && !getenv("TL_DP")) continue; Tree4 Q = c == 1 ? collapse_sah(B, M) : collapse_greedy(B, M); if (c == 2) Q = quantise(Q, 8); if (c == 3) Q = quantise(Q, 12); Counts C = replay(Q, M, rays, first ? &ref_hits : &hits);
             if (!first && hits != ref_hits) printf("!! hit bits differ from the first tree\n"); first = false;
-            printf("%-26s %-8s %9.2f %9.2f %7d %8.2f %8.2f %8.2f %9.1f %6d %6.3f\n", name.c_str(), c ? "sah-dp" : "greedy", sb, sah4(Q, M), depth4(Q), C.rec, C.box, C.tri, C.wave_iter, C.maxsp, C.hit); fflush(stdout); } }
+            printf("%-26s %-8s %9.2f %9.2f %7d %8.2f %8.2f %8.2f %9.1f %6d %6.3f\n", name.c_str(), c == 1 ? "sah-dp" : (c == 2 ? "greedy q8" : (c == 3 ? "greedy q12" : "greedy")), sb, sah4(Q, M), depth4(Q), C.rec, C.box, C.tri, C.wave_iter, C.maxsp, C.hit); fflush(stdout); } }
     return 0;
 }
