@@ -170,7 +170,9 @@ def traversal_roofline(args, ctx, W, mlp, env, g, prof_spp, step_ms, world, pmc)
     achieved_cl = own_bytes_cl / sec_cl / 1e9 if sec_cl > 0 else 0.0
     HBM, L2 = 8000.0, 34500.0       # GB/s: MI355X_MICROARCH.md (HBM3E spec peak; aggregate L2 of the eight XCDs)
     cnt = (pmc or {}).get("counters") or {}; trf = (pmc or {}).get("traffic") or {}
-    valu_busy = None if cnt.get("stale") else cnt.get("valu_busy")
+    # the snapshot holds one counter set per mesh (collected on that mesh's rays): report the one that belongs to THIS run's mesh
+    cnt_mesh = cnt if args.mesh == "icosphere" else (cnt.get(args.mesh) or {})
+    valu_busy = None if cnt.get("stale") else cnt_mesh.get("valu_busy")
     traffic = None if trf.get("stale") else trf.get("k_trace_any_hbm_bytes_per_launch")
     launch_s = sec_any / max(1, n_any)
     # which resource binds the kernel is read off the counters, not asserted: VALU pipes busy for most of the SIMD cycles while the HBM counters show a fraction of
