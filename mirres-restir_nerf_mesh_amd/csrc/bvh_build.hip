@@ -939,4 +939,15 @@ int mirres_debug_sah_state(mirres_bvh_t* b, uint32_t* h_out) {
     return MIRRES_OK;
 }
 
+// development aid (not part of include/mirres.h): the traversal layout as the kernels read it — nodes4q [T-1], leaves [T+1] (the null leaf last), top85q [85], 64 bytes per
+// record — for the structural check of tests/test_gpu_layout.py (every leaf reachable exactly once, every decoded child box around its subtree's exact leaf boxes)
+int mirres_debug_layout(mirres_bvh_t* b, void* h_nodes4q, void* h_leaves, void* h_top85q) {
+    if (!b || b->T < 2 || !h_nodes4q || !h_leaves) return MIRRES_E_ARG;
+    MR_HIP(hipDeviceSynchronize());
+    MR_HIP(hipMemcpy(h_nodes4q, b->nodes4q, sizeof(Node4q) * (size_t)(b->T - 1), hipMemcpyDeviceToHost));
+    MR_HIP(hipMemcpy(h_leaves, b->leaves, sizeof(LeafRec) * (size_t)(b->T + 1), hipMemcpyDeviceToHost));
+    if (h_top85q) MR_HIP(hipMemcpy(h_top85q, b->top85q, sizeof(Node4q) * 85, hipMemcpyDeviceToHost));
+    return MIRRES_OK;
+}
+
 }  // extern "C"
