@@ -88,7 +88,7 @@ def check_layout(nodes, leaves, top, T, vert, tri, info, aabb):
     assert np.all(seen_leaf[:T] == 1), "every leaf slot is reachable exactly once (missing %d, doubled %d)" % (int((seen_leaf[:T] == 0).sum()), int((seen_leaf[:T] > 1).sum()))
     # ---- (2) containment, bottom-up: exact union of the leaf boxes below every reachable node
     ex_lo = np.full((max(1, T - 1), 3), np.inf, np.float32); ex_hi = np.full((max(1, T - 1), 3), -np.inf, np.float32)
-    slack = 0.0; worst = 0.0
+    worst = 0.0
     for cur in reversed(levels):
         ref = nodes["ref"][cur].astype(np.int64)
         lo, hi, _, _ = decode(nodes, cur)
@@ -102,8 +102,8 @@ def check_layout(nodes, leaves, top, T, vert, tri, info, aabb):
         ex_lo[cur] = np.min(np.where(real[..., None], c_lo, np.inf), axis=1)
         ex_hi[cur] = np.max(np.where(real[..., None], c_hi, -np.inf), axis=1)
         # how loose the 8-bit boxes are (reported, not asserted): relative to the node's extent
-        ext = np.maximum((ex_hi[cur] - ex_lo[cur]).max(axis=1), 1e-30)[:, None, None]
-        loose = np.where(real[..., None], np.maximum(c_lo - lo, hi - c_hi) / ext, 0.0)
+        ext = np.maximum((ex_hi[cur] - ex_lo[cur]).max(axis=1).astype(np.float64), 1e-30)[:, None, None]
+        loose = np.where(real[..., None], np.maximum(c_lo.astype(np.float64) - lo, hi.astype(np.float64) - c_hi) / ext, 0.0)
         worst = max(worst, float(loose.max()))
     assert np.array_equal(ex_lo[0], aabb[0, 0:3]) and np.array_equal(ex_hi[0], aabb[0, 3:6]), "the union of everything below node 0 is the reference's root box"
     # ---- (5) the LDS prefix (built when T - 1 >= 1364): heap order, entry e's k-th child at 4e + 1 + k
