@@ -210,6 +210,9 @@ def traversal_roofline(args, ctx, W, mlp, env, g, prof_spp, step_ms, world, pmc)
                         "closest": [round(own[k] / max(1, rays_cl), 2) for k in ("cl_popped", "cl_entered", "cl_leaves")],
                         "legend": "reference: nodes popped / internal nodes entered / leaves tested by bvh_hit's own order; production: box tests / 64-B records fetched / leaves tested"},
             "private_stack_deepest": {"shadow": own["any_max_stack"], "ordered_closest": own["cl_max_stack"], "overflows": own["any_stack_overflow"]},
+            # queue entries of the spatial pass that are answered without a traversal (light reservoir with luminance 0: the merge cannot see the answer; the reference
+            # traces them). They ARE counted in rays_per_launch / grays_per_s / per_ray (as the one root-box test they cost); MIRRES_SKIP_DEAD=0 traces them
+            "rays_not_traced_frac": round(own.get("any_dead", 0) / max(1, rays_any), 4),
             "traversal_share_of_step": round((ms_any + ms_cl) / prof_spp * args.spp / step_ms * (world if world > 1 else 1), 3)}
     return roof
 
@@ -382,7 +385,7 @@ def main():
             if not args.no_roofline:
                 args_o = argparse.Namespace(**vars(args)); args_o.mesh = other
                 r2 = traversal_roofline(args_o, ctx, W2, mlp2, env, g2, 8 if args.spp >= 8 else args.spp, d2 * 1e3, 1, None)
-                rec["traversal"] = {k: r2[k] for k in ("launch_ms", "launches", "rays_per_launch", "grays_per_s", "per_ray", "rays_per_pixel_sample", "private_stack_deepest", "traversal_share_of_step")}
+                rec["traversal"] = {k: r2[k] for k in ("launch_ms", "launches", "rays_per_launch", "grays_per_s", "per_ray", "rays_per_pixel_sample", "private_stack_deepest", "rays_not_traced_frac", "traversal_share_of_step")}
                 rec["traversal"]["own_bytes_per_ray"] = r2["own_bytes"]["bytes_per_ray"]; rec["traversal"]["closest"] = r2["closest"]
             extras[other] = rec
             del W2, mlp2, g2

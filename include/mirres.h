@@ -69,11 +69,13 @@ int mirres_ctx_create(mirres_ctx_t** out, int fx, int fy, const mirres_config_t*
 void mirres_ctx_destroy(mirres_ctx_t* ctx);
 /* createNeighborOffsetTexture (make_sampleable.slang:186-205) / 127 -> f32[count,2]; ctx keeps a copy.      */
 int mirres_neighbor_offsets(mirres_ctx_t* ctx, float* out, void* stream);
-/* totals since the last reset (host; synchronises): u64[12] = rays_any, rays_closest, then (popped, entered, leaves) of the any-hit
+/* totals since the last reset (host; synchronises): u64[16] = rays_any, rays_closest, then (popped, entered, leaves) of the any-hit
  * kernel and (popped, entered, leaves) of the closest-hit kernel — the node counts only advance while instrument bit 0 is set —
  * [8] / [9] deepest private traversal stack seen by the shadow-ray / ordered closest-hit kernel (instrument bit 0), [10] rays the
  * ordered closest-hit kernel handed to the reference-order kernel (instrument bit 0), [11] private-stack overflows of the
- * shadow-ray kernel (always counted; provably 0, bvh_trace.hip MR_ANY_STACK).                                            */
+ * shadow-ray kernel (always counted; provably 0, bvh_trace.hip MR_ANY_STACK), [12] shadow rays of the spatial pass that were
+ * not traced because the merge cannot see their answer (light reservoir with luminance 0; instrument bit 0; they are
+ * included in rays_any), [13..15] reserved (0).                                                                           */
 int mirres_ctx_stats(mirres_ctx_t* ctx, uint64_t* h_out, int reset);
 /* instrument bit 0: traversal kernels count visited nodes into the stats (slower kernels); bit 1: every traversal launch is
  * bracketed by HIP events on its own stream so that mirres_ctx_trace_time can report per-kernel durations; bit 2 (with bit 0):

@@ -484,7 +484,7 @@ template <bool COUNT, int TOPN, int TIMED = 0, int SRC = 0>   // TIMED: identica
                                                               // kernel trace of the same command shows those launches as their own row
 __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const Ray* __restrict__ rays, const uint32_t* __restrict__ d_count,
                                                                uint32_t n_fixed, uint32_t* __restrict__ work_head, int32_t* __restrict__ hit_out,
-                                                               unsigned long long* __restrict__ stats, RaySrc src = RaySrc{nullptr, nullptr, 0.f}) {
+                                                               unsigned long long* __restrict__ stats, RaySrc src = RaySrc{nullptr, nullptr, 0.f, 0}) {
     __shared__ uint32_t lds[MR_ANY_LDS * MR_TRACE_BLOCK];
     __shared__ __attribute__((aligned(16))) uint4 s_top[TOPN > 0 ? TOPN * 4 : 1];
     if (TOPN > 0) {
@@ -555,11 +555,12 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const
                 const uint32_t idx = idx0;
 #endif
                 if (!have && idx0 < chunk_end) {
-                    float4 a, b;
+                    float4 a, b; bool dead = false;
                     if (SRC == 1) {
                         const uint2 it = reinterpret_cast<const uint2*>(rays)[idx >> 1];      // pair (a, b): even ray a -> b's light, odd ray b -> a's light
                         const uint32_t op = (idx & 1u) ? it.y : it.x, lp = (idx & 1u) ? it.x : it.y;
                         const float4 P = src.grec[4 * (size_t)op + 3], L = src.rrec[2 * (size_t)lp];
+                        dead = src.skip_dead && L.w == 0.f;   // engine.hpp RaySrc: the light sample's carried luminance is 0 — nobody can see this ray's answer
                         const v3 dir = oct_decode(V2(L.y, L.z));
                         const v3 o = V3(P.x, P.y, P.z) + src.vis_near * dir;          // put_ray (passes.hip): the same two expressions
                         a.x = o.x; a.y = o.y; a.z = o.z; a.w = 0.f; b.x = dir.x; b.y = dir.y; b.z = dir.z; b.w = 1e7f;
@@ -576,7 +577,7 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const
                     const float o3[3] = {ox, oy, oz}, i3[3] = {ix, iy, iz};
                     Slab s0 = slab(B.root_box, B.root_box + 3, o3, i3, t_min);
                     if (COUNT) c_boxes++;
-                    if (s0.tf > s0.tn && t_max > s0.tn) { cur = TOPN > 0 ? MR_TOPBIT : 0; have = true; }
+                    if (!dead && s0.tf > s0.tn && t_max > s0.tn) { cur = TOPN > 0 ? MR_TOPBIT : 0; have = true; }
                 }
                 const uint32_t want = (uint32_t)__popcll(need);
                 chunk_next = (chunk_next + want < chunk_end) ? chunk_next + want : chunk_end;

@@ -61,7 +61,13 @@ struct BvhView {
 // position towards b's light sample — and ray 2j + 1 — from b's position towards a's. The traversal kernel forms the ray when a lane takes it from the queue:
 // origin = pos + vis_near * dir, dir = oct_decode(light sample), the expressions the generating kernel would have used (put_ray), so the traced ray has the
 // same bits and the queue carries 4 bytes per ray instead of 32.
-struct RaySrc { const float4* grec; const float4* rrec; float vis_near; };   // grec: 64-B pixel records (pos in the fourth quarter), rrec: 32-B packed reservoirs
+// skip_dead (round 4): a ray whose LIGHT reservoir carries luminance 0 (the emptied reservoir of an occluded initial candidate; lum travels with the sample in the
+// packed record) is not traced. Its answer cannot reach the frame: the spatial merge multiplies it into target(lum = 0, .) = fmaxf(0, 0 * brdf) = 0, for any brdf
+// value incl. inf / NaN (k_spatial_resolve: candAtOther *= canonicalVis, canonAtOther *= candidateVis), and reads it nowhere else (vcode is taken from it only for a
+// SELECTED sample, which needs w > 0, i.e. lum > 0). The reference traces these rays and throws the answers away.
+// (The further rule "direction in or below the horizon of the origin pixel's shading normal" — eval_brdf is exactly 0 there — was measured too: 1.4 % / 0.3 % more
+// rays on the two bench meshes, nothing on the frame, one more 16-byte gather per ray: not kept. DESIGN.md Appendix A.)
+struct RaySrc { const float4* grec; const float4* rrec; float vis_near; int skip_dead; };   // grec: 64-B pixel records (pos in the fourth quarter), rrec: 32-B packed reservoirs {light_data.xyz, lum | M, weight, vcode, inv_pdf}
 
 }  // namespace mr
 

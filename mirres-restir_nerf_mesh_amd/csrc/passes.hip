@@ -78,7 +78,7 @@ static int tile_grid(int fx, int fy, int tw) {
 
 // G-buffer / reservoir views. The ABI layout is the reference's SoA (one array per field). mirres_render's internal buffers use packed records so
 // that a neighbour gather touches one or two cache lines instead of seven:  GBufD::rec = 64 B per pixel {n.xyz depth | ray_dir.xyz occ | brdf.xyz 0 |
-// pos.xyz 0};  ResD::rec = 32 B per slot {light_data.xyz inv_pdf | M(int bits) weight vcode lum}. Same values, same arithmetic — only the addresses differ.
+// pos.xyz 0};  ResD::rec = 32 B per slot {light_data.xyz lum | M(int bits) weight vcode inv_pdf} (lum in the first half: the shadow-ray kernel reads it with the direction). Same values, same arithmetic — only the addresses differ.
 // lum (packed records only, round 3) = luminance of the environment radiance along the stored light sample, luminance(env_radiance(E, oct_decode(light_data.yz))):
 // a pure function of the sample, evaluated once when the sample enters a reservoir (the initial pass has it anyway) and carried with it through the temporal and
 // spatial merges, instead of being recomputed (acos, atan2, sin, four texel gathers) by every pass that evaluates a target function for the sample — the temporal
@@ -110,18 +110,19 @@ struct Ris { v3 light_data; float inv_pdf, weightSum, M, weight, canonicalWeight
 MR_DEV Ris empty_ris() { Ris s; s.light_data = V3(0.f); s.inv_pdf = 0.f; s.weightSum = 0.f; s.M = 0.f; s.weight = 0.f; s.canonicalWeight = 0.f; s.vcode = 0; s.lum = 0.f; return s; }
 MR_DEV ResV load_res(const ResD& R, size_t i) {
     ResV r;
-    if (R.rec) { const float4 a = R.rec[2 * i], b = R.rec[2 * i + 1]; r.light_data = V3(a.x, a.y, a.z); r.light_pdf = a.w; r.M = __float_as_int(b.x); r.weight = b.y; r.vcode = __float_as_int(b.z); r.lum = b.w; r.has_lum = true; }
+    if (R.rec) { const float4 a = R.rec[2 * i], b = R.rec[2 * i + 1]; r.light_data = V3(a.x, a.y, a.z); r.lum = a.w; r.M = __float_as_int(b.x); r.weight = b.y; r.vcode = __float_as_int(b.z); r.light_pdf = b.w; r.has_lum = true; }
     else { r.light_data = ld3(R.light_data, i); r.light_pdf = R.light_pdf[i]; r.M = R.M[i]; r.weight = R.weight[i]; r.vcode = 0; r.lum = 0.f; r.has_lum = false; }
     return r;
 }
 MR_DEV void store_res(const ResD& R, size_t i, v3 ld, float ipdf, int M, float w, int vcode = 0, float lum = 0.f) {
-    if (R.rec) { float4 a, b; a.x = ld.x; a.y = ld.y; a.z = ld.z; a.w = ipdf; b.x = __int_as_float(M); b.y = w; b.z = __int_as_float(vcode); b.w = lum; R.rec[2 * i] = a; R.rec[2 * i + 1] = b; }
+    if (R.rec) { float4 a, b; a.x = ld.x; a.y = ld.y; a.z = ld.z; a.w = lum; b.x = __int_as_float(M); b.y = w; b.z = __int_as_float(vcode); b.w = ipdf; R.rec[2 * i] = a; R.rec[2 * i + 1] = b; }
     else { st3(R.light_data, i, ld); R.light_pdf[i] = ipdf; R.M[i] = M; R.weight[i] = w; }
 }
 MR_DEV v3 res_light(const ResD& R, size_t i) { if (R.rec) { const float4 a = R.rec[2 * i]; return V3(a.x, a.y, a.z); } return ld3(R.light_data, i); }
 MR_DEV int res_M(const ResD& R, size_t i) { return R.rec ? __float_as_int(R.rec[2 * i + 1].x) : R.M[i]; }
 MR_DEV float res_weight(const ResD& R, size_t i) { return R.rec ? R.rec[2 * i + 1].y : R.weight[i]; }
 MR_DEV int res_vcode(const ResD& R, size_t i) { return R.rec ? __float_as_int(R.rec[2 * i + 1].z) : 0; }
+MR_DEV float res_lum(const ResD& R, size_t i) { return R.rec ? R.rec[2 * i].w : 1.f; }   // carried luminance of the stored sample (packed records; SoA: unknown, never 0)
 MR_DEV void store_zero(const ResD& R, size_t i) { store_res(R, i, V3(0.f), 0.f, 0, 0.f); }
 MR_DEV void store_ris(const ResD& R, size_t i, const Ris& s) {
     if (isinf(s.weight) || isnan(s.weight)) { store_zero(R, i); return; }
@@ -130,11 +131,11 @@ MR_DEV void store_ris(const ResD& R, size_t i, const Ris& s) {
 // luminance of the radiance along a loaded reservoir's sample: the carried value (packed records) or the evaluation itself (the reference's SoA layout)
 MR_DEV float sample_lum(const EnvD& E, const ResV& r, v3 dir) { return r.has_lum ? r.lum : luminance(env_radiance(E, dir)); }
 MR_DEV float target_lum(const rtarget::Ctx& c, float lum, v3 L) { return fmaxf(0.f, lum * rtarget::eval_brdf(c, L)); }   // rtarget::target with the luminance given
-MR_DEV void put_ray(Ray* q, uint32_t slot, v3 pos, v3 dir, float vis_near) {
+MR_DEV void put_ray(Ray* q, uint32_t slot, v3 pos, v3 dir, float vis_near, float t_max = 1e7f) {
     v3 o = pos + vis_near * dir;  // origin offset along the RAY direction (VIS_near, e.g. InitialResampling.slang:264-265)
     float4 a, b;
     a.x = o.x; a.y = o.y; a.z = o.z; a.w = 0.f;
-    b.x = dir.x; b.y = dir.y; b.z = dir.z; b.w = 1e7f;
+    b.x = dir.x; b.y = dir.y; b.z = dir.z; b.w = t_max;
     reinterpret_cast<float4*>(q + slot)[0] = a; reinterpret_cast<float4*>(q + slot)[1] = b;
 }
 MR_DEV EnvD envd(const mirres_env_t& e) { EnvD E; E.tex = e.tex; E.W = e.Wc; E.H = e.Hc; E.pdf = e.pdf; E.cdf = e.cdf; E.mpdf = e.mpdf; E.mcdf = e.mcdf; return E; }
@@ -414,7 +415,7 @@ MR_DEV bool row_in(const RowSet& r, int pi, int fx) { if (r.mode == 0) return tr
 template <int MR_MAX_NB, bool ITEMS = false>   // 5 (the reference's neighbour count) or 8: bounds the unrolled gathers, i.e. the registers held
 __global__ void __launch_bounds__(MR_SGEN_BLOCK / MR_SGEN_PX) k_spatial_gen(mirres_config_t C, GBufD G, ResD PR, const float* __restrict__ noff, uint32_t frameIndex,
                                                           int fx, int fy, int N, int y_off, const float* __restrict__ occ_own, Ray* __restrict__ q,
-                                                          uint32_t* __restrict__ q_count, int32_t* __restrict__ slot_out, uint32_t* __restrict__ mask_out, RowSet rows) {
+                                                          uint32_t* __restrict__ q_count, int32_t* __restrict__ slot_out, uint32_t* __restrict__ mask_out, RowSet rows, unsigned long long* __restrict__ mark_dead) {
     // strip sharding: y_off = global row of local row 0 (seeds), occ_own = occupancy with the halo rows zeroed (which pixels this rank merges);
     // neighbours are tested against the true G-buffer, halo rows included
     const int k = min(C.neighbor_count, MR_MAX_NB);
@@ -495,17 +496,23 @@ __global__ void __launch_bounds__(MR_SGEN_BLOCK / MR_SGEN_PX) k_spatial_gen(mirr
         }
         if (mask) {
             const v3 cpos = load_gpos(G, pi); const v3 cl = res_light(PR, pi); const v3 cdir = oct_decode(V2(cl.y, cl.z));
-            v3 nl[MR_MAX_NB], np[MR_MAX_NB];
+            // mark_dead (the counting mode of mirres_render's chain): the rays the production queue does not trace (engine.hpp RaySrc::skip_dead: the light reservoir
+            // carries luminance 0) keep their slots but get an empty interval — the counted kernel then charges them one root-box test, as the production kernel does
+            const bool c_dead = mark_dead && res_lum(PR, pi) == 0.f;
+            v3 nl[MR_MAX_NB], np[MR_MAX_NB]; bool n_dead[MR_MAX_NB];
 #pragma unroll
-            for (int i = 0; i < MR_MAX_NB; i++) if (mask & (1u << i)) { nl[i] = res_light(PR, (size_t)nbs[px][i]); np[i] = load_gpos(G, (size_t)nbs[px][i]); }
+            for (int i = 0; i < MR_MAX_NB; i++) if (mask & (1u << i)) { nl[i] = res_light(PR, (size_t)nbs[px][i]); np[i] = load_gpos(G, (size_t)nbs[px][i]);
+                                                                       n_dead[i] = mark_dead && res_lum(PR, (size_t)nbs[px][i]) == 0.f; }
             if (pi < N) slot_out[pi] = (int32_t)s;
 #pragma unroll
             for (int i = 0; i < MR_MAX_NB; i++) {
                 if (!(mask & (1u << i))) continue;
                 const v3 ndir = oct_decode(V2(nl[i].y, nl[i].z));
-                put_ray(q, s, cpos, ndir, C.vis_near);        // canonical pixel towards the neighbour's light
-                put_ray(q, s + 1, np[i], cdir, C.vis_near);   // neighbour towards the canonical light
+                const bool da = n_dead[i], db = c_dead;
+                put_ray(q, s, cpos, ndir, C.vis_near, da ? -1.f : 1e7f);        // canonical pixel towards the neighbour's light
+                put_ray(q, s + 1, np[i], cdir, C.vis_near, db ? -1.f : 1e7f);   // neighbour towards the canonical light
                 s += 2;
+                if (mark_dead && (da || db)) atomicAdd(mark_dead, (unsigned long long)((int)da + (int)db));
             }
         } else if (pi < N) slot_out[pi] = -1;
         if (pi < N) mask_out[pi] = mask;
@@ -830,8 +837,12 @@ int launch_spatial(mirres_ctx* ctx, mirres_bvh* bvh, const mirres_env_t* env, co
     const RowSet rows = {ctx->row_a, ctx->row_b, ctx->row_mode};
     // mirres_render's chain (packed pixel records + packed reservoirs, no per-ray counters wanted): the queue carries pixel pairs and the traversal kernel forms the rays
     const bool items = ray_items_allowed(ctx) && resd(prev_res).rec;
+    // rays whose answer the merge cannot see (engine.hpp RaySrc::skip_dead) are not traced; MIRRES_SKIP_DEAD=0: trace them as the reference does (A/B). In the counting
+    // mode of the chain (32-byte rays, own counters) they are marked instead, so that the counters describe what production traces; never for the reference-order counts
+    static const int skip_dead = [] { const char* e = getenv("MIRRES_SKIP_DEAD"); return (e && e[0] == '0') ? 0 : 1; }();
+    unsigned long long* const mark_dead = (skip_dead && ctx->grec && resd(prev_res).rec && (ctx->instrument & 1) && !(ctx->instrument & 4)) ? &ctx->stats[12] : nullptr;
     const dim3 sg_grid(tile_grid(ctx->fx, ctx->fy, MR_SGEN_TILE)), sg_block(MR_SGEN_BLOCK / MR_SGEN_PX);
-#define MR_SGEN_ARGS ctx->cfg, gbufd(g), resd(prev_res), noff, frameIndex, ctx->fx, ctx->fy, N, ctx->y_off, ctx->occ_own, ctx->any_rays, &ctx->counters[0], ctx->slot_a, ctx->mask_a, rows
+#define MR_SGEN_ARGS ctx->cfg, gbufd(g), resd(prev_res), noff, frameIndex, ctx->fx, ctx->fy, N, ctx->y_off, ctx->occ_own, ctx->any_rays, &ctx->counters[0], ctx->slot_a, ctx->mask_a, rows, mark_dead
     if (nb5 && items) k_spatial_gen<5, true><<<sg_grid, sg_block, 0, s>>>(MR_SGEN_ARGS);
     else if (nb5) k_spatial_gen<5><<<sg_grid, sg_block, 0, s>>>(MR_SGEN_ARGS);
     else if (items) k_spatial_gen<8, true><<<sg_grid, sg_block, 0, s>>>(MR_SGEN_ARGS);
@@ -839,7 +850,7 @@ int launch_spatial(mirres_ctx* ctx, mirres_bvh* bvh, const mirres_env_t* env, co
 #undef MR_SGEN_ARGS
     int rc;
     if (items) {
-        const RaySrc src = {reinterpret_cast<const float4*>(ctx->grec), resd(prev_res).rec, ctx->cfg.vis_near};
+        const RaySrc src = {reinterpret_cast<const float4*>(ctx->grec), resd(prev_res).rec, ctx->cfg.vis_near, skip_dead};
         rc = trace_any_items_q(ctx, bvh, ctx->any_rays, src, &ctx->counters[0], ctx->any_cap, ctx->any_hit, s, 0);
     } else rc = trace_any(ctx, bvh, ctx->any_cap, s);
     if (rc) return rc;
@@ -881,9 +892,9 @@ int mirres_ctx_create(mirres_ctx_t** out, int fx, int fy, const mirres_config_t*
     MR_HIP(hipMalloc(&c->cl_rays, sizeof(Ray) * c->cl_cap));
     MR_HIP(hipMalloc(&c->cl_hit, sizeof(HitRec) * c->cl_cap));
     MR_HIP(hipMalloc(&c->counters, sizeof(uint32_t) * 8));
-    MR_HIP(hipMalloc(&c->stats, sizeof(unsigned long long) * 12));
+    MR_HIP(hipMalloc(&c->stats, sizeof(unsigned long long) * 16));
     MR_HIP(hipMemset(c->counters, 0, sizeof(uint32_t) * 8));
-    MR_HIP(hipMemset(c->stats, 0, sizeof(unsigned long long) * 12));
+    MR_HIP(hipMemset(c->stats, 0, sizeof(unsigned long long) * 16));
     MR_HIP(hipMalloc(&c->slot_a, sizeof(int32_t) * N));
     MR_HIP(hipMalloc(&c->mask_a, sizeof(uint32_t) * N));
     MR_HIP(hipMalloc(&c->slot_c, sizeof(int32_t) * N));
@@ -925,8 +936,8 @@ int mirres_neighbor_offsets(mirres_ctx_t* ctx, float* out, void* stream) {
 int mirres_ctx_stats(mirres_ctx_t* ctx, uint64_t* h_out, int reset) {
     if (!ctx || !h_out) { set_error("mirres_ctx_stats: null"); return MIRRES_E_ARG; }
     MR_HIP(hipDeviceSynchronize());
-    MR_HIP(hipMemcpy(h_out, ctx->stats, sizeof(unsigned long long) * 12, hipMemcpyDeviceToHost));
-    if (reset) MR_HIP(hipMemset(ctx->stats, 0, sizeof(unsigned long long) * 12));
+    MR_HIP(hipMemcpy(h_out, ctx->stats, sizeof(unsigned long long) * 16, hipMemcpyDeviceToHost));
+    if (reset) MR_HIP(hipMemset(ctx->stats, 0, sizeof(unsigned long long) * 16));
     return MIRRES_OK;
 }
 int mirres_ctx_set_instrument(mirres_ctx_t* ctx, int on) { if (!ctx) return MIRRES_E_ARG; ctx->instrument = on; return MIRRES_OK; }

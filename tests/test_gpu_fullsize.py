@@ -338,12 +338,15 @@ def test_round4_switches_do_not_change_the_frame_at_full_size():
     """Round 4's restructurings are each behind a switch that is read once per process; every one of them must leave all six output buffers of a 1600 x 1600 x 6 spp
     frame of the LEGO-LIKE mesh (material field on) with the same bits: the private hierarchy (extended-Morton tree + SAH top) vs the plain extended-Morton
     tree (MIRRES_PRIVATE_TREE=1) vs the collapsed reference LBVH (=0), the temporal merge fused into the spatial resolve vs its own launch (MIRRES_FUSE_TEMPORAL=0), the material lookup in position order
-    vs slot order (MIRRES_GRID_SORT=0), and the ordered closest-hit kernel vs the reference-order kernel for every ray (MIRRES_CLOSEST=2)."""
+    vs slot order (MIRRES_GRID_SORT=0), the ordered closest-hit kernel vs the reference-order kernel for every ray (MIRRES_CLOSEST=2), and the spatial pass with
+    the shadow rays nobody can see the answer of (light reservoirs carrying luminance 0) left untraced vs traced as the reference traces them
+    (MIRRES_SKIP_DEAD=0)."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = {}
     for name, extra in (("default", {}), ("collapsed LBVH", {"MIRRES_PRIVATE_TREE": "0"}), ("extended-Morton tree without the SAH top", {"MIRRES_PRIVATE_TREE": "1"}), ("separate temporal", {"MIRRES_FUSE_TEMPORAL": "0"}),
-                        ("slot-order material lookup", {"MIRRES_GRID_SORT": "0"}), ("reference-order closest hit", {"MIRRES_CLOSEST": "2"})):
+                        ("slot-order material lookup", {"MIRRES_GRID_SORT": "0"}), ("reference-order closest hit", {"MIRRES_CLOSEST": "2"}),
+                        ("every spatial shadow ray traced", {"MIRRES_SKIP_DEAD": "0"})):
         env = dict(os.environ, MIRRES_MESH="clustered", **extra); env.pop("MIRRES_PARITY_REPORT", None)
         r = subprocess.run([sys.executable, os.path.join(root, "scripts", "dev_frame_hash.py"), "6"], env=env, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, (name, r.stderr[-2000:])
