@@ -66,7 +66,8 @@ struct BvhView {
 // value incl. inf / NaN (k_spatial_resolve: candAtOther *= canonicalVis, canonAtOther *= candidateVis), and reads it nowhere else (vcode is taken from it only for a
 // SELECTED sample, which needs w > 0, i.e. lum > 0). The reference traces these rays and throws the answers away.
 // (The further rule "direction in or below the horizon of the origin pixel's shading normal" — eval_brdf is exactly 0 there — was measured too: 1.4 % / 0.3 % more
-// rays on the two bench meshes, nothing on the frame, one more 16-byte gather per ray: not kept. DESIGN.md Appendix A.)
+// rays on the two bench meshes, nothing on the frame, one more 16-byte gather per ray: not kept. Likewise "the origin pixel holds the same light sample and
+// already knows the answer (vcode)": 0.2 % of the rays. DESIGN.md Appendix A.)
 struct RaySrc { const float4* grec; const float4* rrec; float vis_near; int skip_dead; };   // grec: 64-B pixel records (pos in the fourth quarter), rrec: 32-B packed reservoirs {light_data.xyz, lum | M, weight, vcode, inv_pdf}
 
 }  // namespace mr
