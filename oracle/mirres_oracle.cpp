@@ -338,6 +338,7 @@ static int g_render_neighbor_count = 0, g_render_initial_light_samples = 0, g_re
 void orc_set_render_constants(int neighbor_count, int initial_light_samples, int max_history) {
     g_render_neighbor_count = neighbor_count; g_render_initial_light_samples = initial_light_samples; g_render_max_history = max_history;
 }
+long long orc_set_dead_ray_override(int mode) { g_dead_ray_override = mode; const long long n = g_dead_ray_count; g_dead_ray_count = 0; return n; }   // orc_kernels.hpp: test hook, -1 = off; returns the rays answered by the hook since the last call
 int orc_render(const OrcRenderArgs* A) {
     const int fx = A->fx, fy = A->fy; const size_t N = (size_t)fx * fy;
     Config C; if (A->max_bounce > 0) C.max_bounce = A->max_bounce;

@@ -405,6 +405,14 @@ def set_render_constants(neighbor_count=0, initial_light_samples=0, max_history=
     lib().orc_set_render_constants(int(neighbor_count), int(initial_light_samples), int(max_history))
 
 
+def set_dead_ray_override(mode=-1):
+    """Test hook (orc_kernels.hpp g_dead_ray_override): 0 / 1 = spatial shadow rays aimed at the sample of a zero-weight reservoir are not traced and report
+    free / occluded; 2 = control: every spatial shadow ray reports occluded; -1 = the reference's behaviour. Returns the number of rays the hook answered since the
+    previous call."""
+    f = lib().orc_set_dead_ray_override; f.restype = C.c_longlong
+    return int(f(int(mode)))
+
+
 def render(fx, fy, spp, random_offset, bvh, vert, tri, env_map, occ, normal, depth, kd, rs, ray_dir, pos, mat=None, max_bounce=2,
            use_scale=False, scale=(1, 1, 1), denoise_iter=2, step_width=2, c_phi=2.0, n_phi=0.1, p_phi=0.001, want_avg=False,
            const_kd=(0.6, 0.6, 0.6), const_rs=(0.5, 0.0)):

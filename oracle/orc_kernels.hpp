@@ -162,6 +162,18 @@ static inline void temporal_pixel(const Config& C, const Env& E, const GBuf& G, 
 static inline float m_factor(float q0, float q1) { return q0 == 0.f ? 1.f : clampf(mrf_pow2k(fminf(q1 / q0, 1.f), 3), 0.f, 1.f); }
 static inline float pairwise_mis(float q0, float q1, float N0, float N1) { return (q1 == 0.f) ? 0.f : (N0 * q0) / (q0 * N0 + q1 * N1); }
 
+// Test hook (tests/test_oracle_invariants.py): -1 = the reference's behaviour. 0 / 1: every spatial shadow ray aimed at the light sample of a reservoir with
+// weight == 0 (an emptied one) is not traced and reports "free" / "occluded". The claim under test: such a ray's answer cannot reach the output — it only ever
+// scales a term that is multiplied by that weight (w = candAtOther * nb.weight * m0; w_final = curTarget * cur.weight * canonicalWeight), res.slang:173-232.
+static int g_dead_ray_override = -1;
+static long long g_dead_ray_count = 0;        // rays the hook answered (0 / 1); mode 2 = control: EVERY spatial shadow ray reports "occluded" (the frame must change)
+static inline bool dead_ray_answer(bool dead, bool& hit) {
+    if (g_dead_ray_override < 0 || !(dead || g_dead_ray_override == 2)) return false;
+    hit = g_dead_ray_override != 0;
+    #pragma omp atomic
+    g_dead_ray_count++;
+    return true;
+}
 static inline void spatial_pixel(const Config& C, const Bvh& B, const Env& E, const GBuf& G, const Reservoirs& R,
                                  const Reservoirs& prevR, const float* neighborOffsets, uint32_t frameIndex, int x, int y, TraceCounters* tc) {
     size_t pi = (size_t)y * G.fx + x;
@@ -197,8 +209,9 @@ static inline void spatial_pixel(const Config& C, const Bvh& B, const Env& E, co
         f3 nem, ndir;
         get_light_info(E, mk2(nb.light_data.y, nb.light_data.z), nem, ndir);
         f3 npos = ld3(G.pos, qi);
-        bool canonical_hit = shadow_ray(B, cpos, ndir, C.vis_near, tc);
-        bool candidate_hit = shadow_ray(B, npos, cdir, C.vis_near, tc);
+        bool canonical_hit, candidate_hit;
+        if (!dead_ray_answer(nb.weight == 0.f, canonical_hit)) canonical_hit = shadow_ray(B, cpos, ndir, C.vis_near, tc);
+        if (!dead_ray_answer(cur.weight == 0.f, candidate_hit)) candidate_hit = shadow_ray(B, npos, cdir, C.vis_near, tc);
         float canonicalVis = canonical_hit ? 0.f : 1.f, candidateVis = candidate_hit ? 0.f : 1.f;
         // streamingResampleStepMisUnbiased res.slang:173-213
         float candTarget = rt::target(nem, ndir, nn, nrd, nbr);

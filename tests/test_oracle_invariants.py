@@ -314,3 +314,40 @@ def test_prepare_shading_normal_known_cases(oracle):
     o_gl = oracle.prepare_shading_normal(pos, view, np.array([[0, 1, 1]], f), up, tng, np.array([[0, 0, 1]], f), opengl=True)
     o_dx = oracle.prepare_shading_normal(pos, view, np.array([[0, 1, 1]], f), up, tng, np.array([[0, 0, 1]], f), opengl=False)
     assert o_gl[0, 1] * o_dx[0, 1] < 0 and abs(o_gl[0, 2] - o_dx[0, 2]) < 1e-6
+
+
+def test_shadow_rays_aimed_at_an_emptied_reservoirs_sample_cannot_be_seen(oracle, scene_mod):
+    """What the engine's spatial pass relies on when it does not trace part of its shadow rays (engine.hpp RaySrc::skip_dead; 25 % of them on the lego-like
+    mesh): in the REFERENCE's arithmetic (SpatialResampling.slang:262-322, res.slang:173-232) the answer of a shadow ray aimed at the light sample of a
+    reservoir with weight 0 only scales terms that are multiplied by that weight, so forcing those answers to "free" or to "occluded" must leave every
+    output buffer of a many-sample frame with the same bits.  Scene with large shadowed regions (the lego-like mesh from below its plates), 16 samples so that
+    emptied reservoirs travel through temporal and spatial reuse; the control (forcing ALL spatial shadow rays) is what shows the hook bites."""
+    v, t = scene_mod.make_mesh_clustered(target_tris=20000, seed=3)
+    info, aabb, _, _ = oracle.bvh_build(v, t)
+    fx = fy = 72
+    eye, rd = scene_mod.camera_rays(fy, fx)
+    r = oracle.trace(info, aabb, v, t, oracle.make_rays(np.repeat(eye[None], fx * fy, 0), rd), True)
+    occ = r["hit"].astype(np.float32)
+    nrm = np.where(occ[:, None] > 0, r["normal"], 0).astype(np.float32)
+    depth = np.linalg.norm(r["pos"] - eye, axis=1).astype(np.float32)
+    N = fx * fy
+    kd = np.full((N, 3), 0.6, np.float32); rm = np.zeros((N, 2), np.float32); rm[:, 0] = 0.5
+    env = scene_mod.make_env(64, 128)
+    names = ["final_color", "diffuse", "spec", "indirect", "indirect_diff", "indirect_spec"]
+    def frame():
+        return oracle.render(fx, fy, 16, 777, (info, aabb), v, t, env, occ, nrm, depth, kd, rm, rd, r["pos"], mat=None)
+    try:
+        oracle.set_dead_ray_override(-1); ref = frame()
+        outs, answered = {}, {}
+        for mode in (0, 1, 2):
+            oracle.set_dead_ray_override(mode); outs[mode] = frame(); answered[mode] = oracle.set_dead_ray_override(-1)
+    finally:
+        oracle.set_dead_ray_override(-1)
+    assert occ.mean() > 0.3 and float(ref["final_color"].mean()) > 0
+    for mode in (0, 1):
+        for k in names:
+            assert np.array_equal(outs[mode][k], ref[k]), (mode, k, int((outs[mode][k] != ref[k]).any(axis=1).sum()))
+    # the equality above says something: a good part of the spatial pass's shadow rays is of that kind (the same number in both modes: the reservoirs are the
+    # same), and the hook is live — with EVERY spatial shadow ray forced to "occluded" the frame changes
+    assert answered[0] == answered[1] and answered[0] > 0.05 * answered[2] > 0, answered
+    assert not np.array_equal(outs[2]["final_color"], ref["final_color"])
