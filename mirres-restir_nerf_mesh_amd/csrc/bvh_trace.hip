@@ -562,7 +562,10 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const
                         const float4 P = src.grec[4 * (size_t)op + 3], L = src.rrec[2 * (size_t)lp];
                         dead = src.skip_dead && L.w == 0.f;   // engine.hpp RaySrc: the light sample's carried luminance is 0 — nobody can see this ray's answer
                         const v3 dir = oct_decode(V2(L.y, L.z));
-                        const v3 o = V3(P.x, P.y, P.z) + src.vis_near * dir;          // put_ray (passes.hip): the same two expressions
+                        v3 o = V3(P.x, P.y, P.z) + src.vis_near * dir;          // put_ray (passes.hip): the same two expressions
+#ifdef MR_EXP_REFILL2X   // experiment: what the two dependent gathers of the refill cost — a second pair of them (the pair's other pixel), folded in with weight 0
+                        { const float4 P2 = src.grec[4 * (size_t)lp + 3], L2 = src.rrec[2 * (size_t)op]; o.x += 0.f * (P2.x + L2.y); }
+#endif
                         a.x = o.x; a.y = o.y; a.z = o.z; a.w = 0.f; b.x = dir.x; b.y = dir.y; b.z = dir.z; b.w = 1e7f;
                     } else { a = reinterpret_cast<const float4*>(rays + idx)[0]; b = reinterpret_cast<const float4*>(rays + idx)[1]; }
                     ridx = idx; ro = V3(a.x, a.y, a.z); t_min = a.w; t_max = b.w;
