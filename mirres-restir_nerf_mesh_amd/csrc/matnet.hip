@@ -300,18 +300,17 @@ __global__ void __launch_bounds__(MR_BLOCK) k_active_list(const float* __restric
 }
 
 // the same list from a live-slot list (mirres_render's batches): only the slots whose path is still going are looked at.
-// SORT (round 4): every listed slot also gets a 15-bit Morton key of its position (5 bits per axis of the field's box); the list is then sorted by that key
+// SORT (round 4): every listed slot also gets a Morton key of its position (8 bits per axis of the field's box; 5 in the first version); the list is then sorted by that key
 // (k_ls_* below). The indirect vertices of a batch reach the material field in slot
 // order (sample-major, pixel-minor): consecutive slots hold hit points of scattered bounce rays, and every point gathers 128 table entries (512 B) of which the
 // eleven hashed levels (2 MB each) miss the 4 MB L2 of the XCD. Ordered by position the fused gather + MLP kernel runs 23 / 33 / 36 % faster for 12- / 18- /
 // 30-bit keys (scripts/dev_grid_locality.py, profiles/r04_grid_locality.txt); outputs are scattered by slot, so not a bit changes.
-#define MR_GS_BITS 5
-#define MR_GS_BUCKETS (1 << (3 * MR_GS_BITS))
-MR_DEV uint32_t spread5(uint32_t v) { v &= 0x1fu; v = (v | (v << 8)) & 0x100fu; v = (v | (v << 4)) & 0x10c3u; v = (v | (v << 2)) & 0x1249u; return v; }
+#define MR_GS_BITS 8       // default: 24-bit keys, three 8-bit passes; MIRRES_GS_BITS = 1 .. 8 bits per axis (A/B: 5 bits = the two-pass sort of the first version)
+MR_DEV uint32_t spread10(uint32_t v) { v &= 0x3ffu; v = (v | (v << 16)) & 0x30000ffu; v = (v | (v << 8)) & 0x300f00fu; v = (v | (v << 4)) & 0x30c30c3u; v = (v | (v << 2)) & 0x9249249u; return v; }
 template <bool SORT>
 __global__ void __launch_bounds__(MR_BLOCK) k_active_from_live(const float* __restrict__ occ, const int32_t* __restrict__ live, const uint32_t* __restrict__ live_count,
                                                                int32_t* __restrict__ index, uint32_t* __restrict__ count, MatNetD M, const float* __restrict__ pos,
-                                                               uint32_t* __restrict__ keys) {
+                                                               uint32_t* __restrict__ keys, int bits) {
     const uint32_t nl = *live_count;
     for (uint32_t b0 = blockIdx.x * (MR_BLOCK * 8u); b0 < nl; b0 += gridDim.x * (MR_BLOCK * 8u)) {   // a fixed grid strides over the list
         const uint32_t t0 = b0 + threadIdx.x;   // eight entries per thread (t0 + j * MR_BLOCK: coalesced): one queue atomic per 2048
@@ -329,16 +328,16 @@ __global__ void __launch_bounds__(MR_BLOCK) k_active_from_live(const float* __re
 #pragma unroll
                 for (int a = 0; a < 3; a++) {
                     const float u = (pos[3 * (size_t)sl[j] + a] - M.aabb_min[a]) / (M.aabb_max[a] - M.aabb_min[a]);
-                    q[a] = (uint32_t)fminf(fmaxf(u * (float)(1 << MR_GS_BITS), 0.f), (float)((1 << MR_GS_BITS) - 1));      // (NaN -> 0: any bucket will do)
+                    q[a] = (uint32_t)fminf(fmaxf(u * (float)(1 << bits), 0.f), (float)((1 << bits) - 1));      // (NaN -> 0: any bucket will do)
                 }
-                const uint32_t key = (spread5(q[0]) << 2) | (spread5(q[1]) << 1) | spread5(q[2]);
+                const uint32_t key = (spread10(q[0]) << 2) | (spread10(q[1]) << 1) | spread10(q[2]);
                 keys[o] = key;
             }
             index[o++] = sl[j];
         }
     }
 }
-// ---- two-pass LSD radix sort (8-bit digits) of (key, slot) pairs whose count lives on the device. No global atomics (a first version that counted and
+// ---- LSD radix sort (8-bit digits, one pass per key byte) of (key, slot) pairs whose count lives on the device. No global atomics (a first version that counted and
 // scattered with one atomic per element cost 2.9 ms per launch for 7.5 M entries, more than the ordered gathers saved): a fixed grid of MR_LS_GRID workgroups,
 // each owning a contiguous run of 2048-key tiles — digit histogram of its run -> per digit: exclusive scan over the workgroups -> stable scatter walking the run
 // tile by tile with the wave64 digit matching of bvh_build.hip's sort (a key's rank = running base of its digit in this workgroup + the digit's count in the waves
@@ -457,24 +456,28 @@ int launch_matnet_scatter_mfma(const mirres_matnet_t* m, const float* occ, const
     MR_HIP(hipMemsetAsync(count, 0, sizeof(uint32_t), s));
     static const bool sort_on = [] { const char* e = getenv("MIRRES_GRID_SORT"); return !(e && e[0] == '0'); }();
     const bool sort = sort_on && live && gs && gs->keys && gs->keys2 && gs->sorted && gs->hist;
+    const int32_t* list = index;     // the list the lookup kernel walks
     // (with a live list the whole-map clamp of use_scale is not applied to slots without a vertex: nothing reads their albedo)
     if (live) {
         int ga = grid_for(n, MR_BLOCK * 8); if (ga > 256 * 8) ga = 256 * 8;
         if (sort) {
-            k_active_from_live<true><<<ga, MR_BLOCK, 0, s>>>(occ, live, live_count, index, count, matd(m), pos, gs->keys);
+            static const int bits = [] { const char* e = getenv("MIRRES_GS_BITS"); const int b = e ? atoi(e) : MR_GS_BITS; return b < 1 ? 1 : (b > 8 ? 8 : b); }();
+            k_active_from_live<true><<<ga, MR_BLOCK, 0, s>>>(occ, live, live_count, index, count, matd(m), pos, gs->keys, bits);
             uint32_t* const hist = gs->hist; uint32_t* const totals = hist + 256 * MR_LS_GRID;
-            // pass 1 (low byte): (keys, index) -> (keys2, sorted); pass 2 (high byte): (keys2, sorted) -> (keys, index): the sorted list ends up where the unsorted one was
-            k_ls_hist<<<MR_LS_GRID, MR_BLOCK, 0, s>>>(gs->keys, count, 0, hist);
-            k_ls_scan<<<256, MR_BLOCK, 0, s>>>(hist, totals);
-            k_ls_scatter<<<MR_LS_GRID, MR_BLOCK, 0, s>>>(gs->keys, index, gs->keys2, gs->sorted, count, 0, hist, totals);
-            k_ls_hist<<<MR_LS_GRID, MR_BLOCK, 0, s>>>(gs->keys2, count, 8, hist);
-            k_ls_scan<<<256, MR_BLOCK, 0, s>>>(hist, totals);
-            k_ls_scatter<<<MR_LS_GRID, MR_BLOCK, 0, s>>>(gs->keys2, gs->sorted, gs->keys, index, count, 8, hist, totals);
-        } else k_active_from_live<false><<<ga, MR_BLOCK, 0, s>>>(occ, live, live_count, index, count, MatNetD(), nullptr, nullptr);
+            // LSD passes over the key's bytes, ping-pong (keys, index) <-> (keys2, sorted); after an even number of passes the sorted list is where the unsorted one was
+            uint32_t *ka = gs->keys, *kb = gs->keys2; int32_t *va = index, *vb = gs->sorted;
+            for (int shift = 0; shift < 3 * bits; shift += 8) {
+                k_ls_hist<<<MR_LS_GRID, MR_BLOCK, 0, s>>>(ka, count, shift, hist);
+                k_ls_scan<<<256, MR_BLOCK, 0, s>>>(hist, totals);
+                k_ls_scatter<<<MR_LS_GRID, MR_BLOCK, 0, s>>>(ka, va, kb, vb, count, shift, hist, totals);
+                uint32_t* tk = ka; ka = kb; kb = tk; int32_t* tv = va; va = vb; vb = tv;
+            }
+            list = va;
+        } else k_active_from_live<false><<<ga, MR_BLOCK, 0, s>>>(occ, live, live_count, index, count, MatNetD(), nullptr, nullptr, 0);
     }
     else k_active_list<<<grid_for(n, MR_BLOCK * MR_AL_PER), MR_BLOCK, 0, s>>>(occ, n, index, count, kd, use_scale);
     int g = grid_for(n, MR_BLOCK); if (g > 256 * 8) g = 256 * 8;
-    k_mlp_mfma<1, 2><<<g, MR_BLOCK, 0, s>>>(matd(m), host_levels(nullptr), nullptr, pos, index, count, 0, nullptr, kd, rm, use_scale, sx, sy, sz);
+    k_mlp_mfma<1, 2><<<g, MR_BLOCK, 0, s>>>(matd(m), host_levels(nullptr), nullptr, pos, list, count, 0, nullptr, kd, rm, use_scale, sx, sy, sz);
     MR_LAUNCH_CHECK("matnet_scatter_mfma");
     return 0;
 }

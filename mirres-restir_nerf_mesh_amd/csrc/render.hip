@@ -204,7 +204,7 @@ static int pt_batch_size() {   // MIRRES_PT_BATCH = samples per batch (default 3
     int k = e ? atoi(e) : 32; if (k < 1) k = 1; if (k > 64) k = 64;
     return k;
 }
-static int stream_count() { const char* e = getenv("MIRRES_STREAMS"); const int n = e ? atoi(e) : 3; return n < 1 ? 1 : (n > 5 ? 5 : n); }   // 1: everything on the caller's stream; 2: + one bulk stream; 3 (default): + path tracing on its own; 4: + final stages on their own; 5: + a second path-tracing stream (4, 5: measured within noise of 3)
+static int stream_count() { const char* e = getenv("MIRRES_STREAMS"); const int n = e ? atoi(e) : 2; return n < 1 ? 1 : (n > 5 ? 5 : n); }   // 1: everything on the caller's stream; 2 (default since the end of round 4: equal on the icosphere, +0.7 % on the lego-like mesh, profiles/r04_ab_gs_bits.txt): + one bulk stream; 3 (rounds 1-4): + path tracing on its own; 4: + final stages on their own; 5: + a second path-tracing stream (4, 5: measured within noise of 3)
 static int carve_batch(mirres_ctx* ctx, int N, int K, int max_bounce, size_t TS, PtBatch& PB) {
     if (K < 1) K = 1;
     while ((size_t)K * (size_t)N > 0x30000000ull && K > 1) K--;   // slot indices are 32-bit
