@@ -920,15 +920,15 @@ static int closest_fast(mirres_bvh* bvh, const Ray* rays, const uint32_t* d_coun
 }
 
 static int g_timed_tag = 0;   // set by trace_any_queue for event-timed launches (mirres_ctx_set_instrument bit 1)
+static int any_top();
 template <bool COUNT>
 static void launch_any4q(const mirres_bvh* bvh, int grid, const Ray* rays, const uint32_t* d_count, uint32_t cap, uint32_t* head, int32_t* hit,
                          unsigned long long* stats, hipStream_t s) {
-    static int topq = -1;
-    if (topq < 0) { const char* e = getenv("MIRRES_TOPQ"); topq = e ? atoi(e) : 85; if (topq != 0 && topq != 85 && topq != 341) topq = 85; }
-    const int top = (bvh->T - 1 >= 341 * 4) ? topq : 0;
+    const int top = (bvh->T - 1 >= 341 * 4) ? any_top() : 0;
     if (top == 85 && !COUNT && g_timed_tag) k_trace_any4q<false, 85, 1><<<grid, MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, d_count, cap, head, hit, stats);
     else if (top == 85) k_trace_any4q<COUNT, 85><<<grid, MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, d_count, cap, head, hit, stats);
     else if (top == 341) k_trace_any4q<COUNT, 341><<<grid, MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, d_count, cap, head, hit, stats);
+    else if (!COUNT && g_timed_tag) k_trace_any4q<false, 0, 1><<<grid, MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, d_count, cap, head, hit, stats);
     else k_trace_any4q<COUNT, 0><<<grid, MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, d_count, cap, head, hit, stats);
 }
 static int closest_mode() {   // 4 (default): ordered compressed 4-wide fast path + reference-order redo of the flagged rays; MIRRES_CLOSEST=2: reference order for all
@@ -951,6 +951,14 @@ static int trace_grid(size_t capacity) {
     return (int)(want < 1 ? 1 : (want > cap ? cap : want));
 }
 
+// How many of the compressed tree's top nodes the shadow-ray kernel reads from LDS: 0 (default since the end of round 4), 85 (levels 0..3; the default of rounds
+// 1-4) or 341 (MIRRES_TOPQ). Round 1 measured the 85-node prefix as a gain on the collapsed reference LBVH; on the final kernel and the private hierarchy it is a
+// loss — launch -5 %, frame +3.5 % (icosphere) / +2.6 % (lego-like) without it (profiles/r04_ab_any_top.txt): two fetch paths in the hot loop cost more than the
+// L1 hits they replace. The ordered closest-hit kernel never had it (and loses 3-5 % with it: r04_ab_closest_top.txt).
+static int any_top() {
+    static const int topq = [] { const char* e = getenv("MIRRES_TOPQ"); const int v = e ? atoi(e) : 0; return (v == 85 || v == 341) ? v : 0; }();
+    return topq;
+}
 // the spatial pass's queue of (origin pixel, light pixel) pairs: same kernel, rays formed at the refill (head set of lane 0 ... 4 as below)
 int trace_any_items_queue(const mirres_bvh* bvh, const uint2* items, const RaySrc& src, const uint32_t* d_count, size_t capacity, int32_t* hit,
                           unsigned long long* stats, hipStream_t s, int lane, int timed, bool heads_clean) {
@@ -959,9 +967,10 @@ int trace_any_items_queue(const mirres_bvh* bvh, const uint2* items, const RaySr
     if (!heads_clean) MR_HIP(hipMemsetAsync(heads, 0, MR_WSET * sizeof(uint32_t), s));
     const Ray* q = reinterpret_cast<const Ray*>(items);
     const int grid = persist_grid(capacity); const uint32_t cap = (uint32_t)capacity;
-    const int top = (bvh->T - 1 >= 341 * 4) ? 85 : 0;
+    const int top = (bvh->T - 1 >= 341 * 4 && any_top() == 85) ? 85 : 0;
     if (top == 85 && timed) k_trace_any4q<false, 85, 1, 1><<<grid, MR_TRACE_BLOCK, 0, s>>>(bvh->view(), q, d_count, cap, heads, hit, stats, src);
     else if (top == 85) k_trace_any4q<false, 85, 0, 1><<<grid, MR_TRACE_BLOCK, 0, s>>>(bvh->view(), q, d_count, cap, heads, hit, stats, src);
+    else if (timed) k_trace_any4q<false, 0, 1, 1><<<grid, MR_TRACE_BLOCK, 0, s>>>(bvh->view(), q, d_count, cap, heads, hit, stats, src);
     else k_trace_any4q<false, 0, 0, 1><<<grid, MR_TRACE_BLOCK, 0, s>>>(bvh->view(), q, d_count, cap, heads, hit, stats, src);
     MR_LAUNCH_CHECK("trace_any_items_queue");
     return 0;
@@ -981,7 +990,7 @@ int trace_any_front_queue(const mirres_bvh* bvh, const Ray* rays, const uint32_t
     uint32_t* const heads = bvh->work + 2 * MR_WSET;
     MR_HIP(hipMemsetAsync(heads, 0, MR_WSET * sizeof(uint32_t), s));
     const int grid = persist_grid(capacity);
-    if (bvh->T - 1 >= 341 * 4) k_trace_any4q<false, 85, 2><<<grid, MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, d_count, (uint32_t)capacity, heads, hit, nullptr);
+    if (bvh->T - 1 >= 341 * 4 && any_top() == 85) k_trace_any4q<false, 85, 2><<<grid, MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, d_count, (uint32_t)capacity, heads, hit, nullptr);
     else k_trace_any4q<false, 0, 2><<<grid, MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, d_count, (uint32_t)capacity, heads, hit, nullptr);
     MR_LAUNCH_CHECK("trace_any_front_queue");
     return 0;
