@@ -382,7 +382,9 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_persist(BvhView B, con
 // whose OWN box passes the slab test of "triangle_hit accepts": a leaf's ancestors always pass when the leaf does (their boxes are
 // fmin/fmax unions and (b - o) * inv is monotone in b under IEEE rounding), hence (2) any visiting order and any pruning by ancestor
 // boxes yields the same boolean. The stack holds bare 4-byte references in LDS (16 per lane, scratch beyond); no pop-time re-test is needed.
+#ifndef MR_ANY_LDS
 #define MR_ANY_LDS 16
+#endif
 // Depth of the shadow-ray kernel's private stack (LDS part + scratch). A 4-wide node defers at most three references and the 4-wide collapse is never
 // deeper than the LBVH it was collapsed from, whose depth is bounded by the bits of the augmented sort key: 30 Morton bits + ceil(log2 T) position bits
 // (lbvh_hierarchy.slang:40-60: every internal node splits its range at the highest differing bit of (code, position)). Hence at most
@@ -938,9 +940,11 @@ static int closest_mode() {   // 4 (default): ordered compressed 4-wide fast pat
 }
 static int persist_grid(size_t capacity) {
     size_t want = (capacity + MR_TRACE_BLOCK - 1) / MR_TRACE_BLOCK;
-    static const size_t cap_blocks = [] { const char* e = getenv("MIRRES_TRACE_BLOCKS_PER_CU"); const int v = e ? atoi(e) : 6; return (size_t)(v >= 1 && v <= 16 ? v : 6); }();
-    size_t cap = 256 * cap_blocks;                                       // 6 resident blocks per CU: measured faster than 8 (forcing <= 64 VGPRs spills; the kernels are
-                                                                // VALU-issue bound while CUs hold waves — DESIGN.md §5 — so more occupancy buys nothing)
+    static const size_t cap_blocks = [] { const char* e = getenv("MIRRES_TRACE_BLOCKS_PER_CU"); const int v = e ? atoi(e) : 8; return (size_t)(v >= 1 && v <= 16 ? v : 8); }();
+    size_t cap = 256 * cap_blocks;      // workgroups launched per CU. Six are resident at once (75-79 VGPRs; forcing <= 64 spills, and the kernels are VALU-issue bound while CUs
+                                        // hold waves, so more occupancy buys nothing); launching eight lets a CU that finishes early pick up another workgroup's share of the
+                                        // queues' tails: +0.7 % (icosphere) / +0.9 % (lego-like) on the 512-spp frame against six, twelve and more lose on the icosphere
+                                        // (profiles/r04_ab_trace_blocks.txt; rounds 1-4 launched six)
     return (int)(want < 1 ? 1 : (want > cap ? cap : want));
 }
 

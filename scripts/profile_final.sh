@@ -37,7 +37,7 @@ def pick(d, key):      # all instantiations of the kernel (ray queue / pixel-pai
     return {'avg_KB': tot / n if n else 0.0, 'launches': n}
 f = pick(out['FETCH_SIZE'], 'k_trace_any4q<false'); w = pick(out['WRITE_SIZE'], 'k_trace_any4q<false')
 json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --spp 8 --steps 1 --warmup 0 --no-cpu-baseline --no-roofline",
-           "kernel": "mr::k_trace_any4q<false, 85, *> (all shadow-ray launches of the frame: ray queues and the spatial pass's pixel-pair queue)", "launches_sampled": f['launches'], "FETCH_SIZE_KB_avg": f['avg_KB'], "WRITE_SIZE_KB_avg": w['avg_KB'],
+           "kernel": "mr::k_trace_any4q<false, *> (all shadow-ray launches of the frame: ray queues and the spatial pass's pixel-pair queue)", "launches_sampled": f['launches'], "FETCH_SIZE_KB_avg": f['avg_KB'], "WRITE_SIZE_KB_avg": w['avg_KB'],
            "correction": "gfx950: FETCH_SIZE reports 1/2 of the bytes of 16-B/lane loads (MI355X_MICROARCH.md, HBM section) -> doubled; WRITE_SIZE as reported; the guide calibrates the factor on streaming reads, so for the traversal's dwordx4 gathers it is an extrapolation",
            "k_trace_any_hbm_bytes_per_launch": round((2 * f['avg_KB'] + w['avg_KB']) * 1024)}, open('gpurun_out/out/pmc_traffic.json', 'w'), indent=1)
 print(open('gpurun_out/out/pmc_traffic.json').read())
