@@ -23,7 +23,9 @@
 namespace mr {
 
 #define MR_STACK 64        // MAX_STACK_SIZE helperDi.slang:136
+#ifndef MR_LDS_STACK
 #define MR_LDS_STACK 12    // entries per lane kept in LDS before spilling to scratch
+#endif
 #define MR_TRACE_BLOCK 256
 
 struct Slab { float tn, tf; };
