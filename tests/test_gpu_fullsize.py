@@ -340,13 +340,15 @@ def test_round4_switches_do_not_change_the_frame_at_full_size():
     tree (MIRRES_PRIVATE_TREE=1) vs the collapsed reference LBVH (=0), the temporal merge fused into the spatial resolve vs its own launch (MIRRES_FUSE_TEMPORAL=0), the material lookup in position order
     vs slot order (MIRRES_GRID_SORT=0), the ordered closest-hit kernel vs the reference-order kernel for every ray (MIRRES_CLOSEST=2), and the spatial pass with
     the shadow rays nobody can see the answer of (light reservoirs carrying luminance 0) left untraced vs traced as the reference traces them
-    (MIRRES_SKIP_DEAD=0)."""
+    (MIRRES_SKIP_DEAD=0), the shadow-ray kernel reading the tree's first four levels from LDS (MIRRES_TOPQ=85, the default of rounds 1-4) vs from global memory, and
+    the launch / sort-key / stream defaults of before."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = {}
     for name, extra in (("default", {}), ("collapsed LBVH", {"MIRRES_PRIVATE_TREE": "0"}), ("extended-Morton tree without the SAH top", {"MIRRES_PRIVATE_TREE": "1"}), ("separate temporal", {"MIRRES_FUSE_TEMPORAL": "0"}),
                         ("slot-order material lookup", {"MIRRES_GRID_SORT": "0"}), ("reference-order closest hit", {"MIRRES_CLOSEST": "2"}),
-                        ("every spatial shadow ray traced", {"MIRRES_SKIP_DEAD": "0"})):
+                        ("every spatial shadow ray traced", {"MIRRES_SKIP_DEAD": "0"}), ("shadow-ray kernel with the LDS-staged top levels", {"MIRRES_TOPQ": "85"}),
+                        ("15-bit sort keys, three streams, six workgroups per CU (the defaults until the end of round 4)", {"MIRRES_GS_BITS": "5", "MIRRES_STREAMS": "3", "MIRRES_TRACE_BLOCKS_PER_CU": "6"})):
         env = dict(os.environ, MIRRES_MESH="clustered", **extra); env.pop("MIRRES_PARITY_REPORT", None)
         r = subprocess.run([sys.executable, os.path.join(root, "scripts", "dev_frame_hash.py"), "6"], env=env, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, (name, r.stderr[-2000:])
