@@ -190,10 +190,10 @@ def traversal_roofline(args, ctx, W, mlp, env, g, prof_spp, step_ms, world, pmc)
             "achieved": (round(traffic / launch_s / 1e9, 1) if bound == "hbm" else valu_busy), "peak": (HBM if bound == "hbm" else 1.0),
             "unit": ("GB/s" if bound == "hbm" else "VALU-busy cycles per SIMD cycle"), "frac": (round(hbm_frac, 4) if bound == "hbm" else valu_busy),
             "traffic": traffic,
-            "own_bytes": {"achieved": round(achieved, 2), "peak": HBM, "unit": "GB/s", "frac": round(achieved / HBM, 5), "bytes_per_ray": round(own_bytes_any / max(1, rays_any), 1),
-                          "l2_peak": L2, "l2_frac": round(achieved / L2, 5),
-                          "note": "bytes the kernel's own algorithm requests (64-B records visited, counted on the timed rays, + ray + result) / event-timed duration; mostly L1 / L2 hits, "
-                                  "i.e. NOT an HBM utilisation"},
+            "own_bytes": {"achieved": round(achieved, 2), "unit": "GB/s", "bytes_per_ray": round(own_bytes_any / max(1, rays_any), 1),
+                          "l2_peak": L2, "l2_frac": round(achieved / L2, 5), "hbm_peak": HBM, "over_hbm_peak": round(achieved / HBM, 5),
+                          "note": "bytes the kernel's own algorithm requests from global memory (64-B records visited, counted on the timed rays, + ray + result) / event-timed duration. "
+                                  "About 90 % of the requests are L1 hits: this is a request rate, NOT an HBM utilisation (it exceeds the HBM peak) — the DRAM side is hbm_counter"},
             "hbm_counter": ({"bytes_per_launch": traffic, "achieved": round(traffic / launch_s / 1e9, 1), "peak": HBM, "unit": "GB/s", "frac": round(traffic / launch_s / 1e9 / HBM, 4),
                              "over_own_bytes": round(traffic / (own_bytes_any / max(1, n_any)), 3),
                              "note": "FETCH_SIZE + WRITE_SIZE per launch (snapshot, on the default workload) / this run's launch time"} if traffic and launch_s > 0 and args.mesh == "icosphere" else None),
@@ -202,7 +202,7 @@ def traversal_roofline(args, ctx, W, mlp, env, g, prof_spp, step_ms, world, pmc)
             "pmc_snapshot": pmc,
             "reference_equiv": {"bytes_per_ray": round(ref_bytes_any / max(1, rays_any), 1), "tbps": round(ref_bytes_any / sec_any / 1e12, 2) if sec_any > 0 else 0.0,
                                 "note": "SURVEY 8d accounting: reference node layout x the reference traversal's visit counts on the same rays / this kernel's time"},
-            "closest": {"kernel": "k_trace_closest4 (+ reference-order redo)", "own_bytes_gbps": round(achieved_cl, 2), "own_bytes_frac_of_hbm": round(achieved_cl / HBM, 5),
+            "closest": {"kernel": "k_trace_closest4 (+ reference-order redo)", "own_bytes_gbps": round(achieved_cl, 2), "own_bytes_l2_frac": round(achieved_cl / L2, 5),
                         "bytes_per_ray": round(own_bytes_cl / max(1, rays_cl), 1), "launch_ms": round(ms_cl / max(1, n_cl), 4), "launches": n_cl,
                         "grays_per_s": round(rays_cl / sec_cl / 1e9, 3) if sec_cl > 0 else 0.0, "redo_frac": round(own["cl_redo"] / max(1, rays_cl), 6)},
             "rays_per_pixel_sample": round(total_rays / (float(N) * prof_spp), 3),
