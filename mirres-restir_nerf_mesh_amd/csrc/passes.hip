@@ -229,17 +229,26 @@ __global__ void __launch_bounds__(MR_BLOCK) k_light_tiles(EnvD E, uint32_t frame
 // pure functions of the same inputs, so the values are bit-identical to in-loop evaluation.
 // Round 3: the record is 32 bytes — {direction xyz, luminance | pdf, light_data xyz} — everything the candidate loop of k_initial_gen reads about a tile sample,
 // in one sector: two 16-byte gathers per candidate instead of five gathers from three arrays (the loop's 32 x 5 scattered loads per pixel were what it waited for).
+// COMPACT (mirres_render's batches, where the tiles come from k_light_tiles above; end of round 4): 16 bytes per sample — {oct code y z, luminance, pdf}. The candidate loop
+// is bound by these gathers (33 per pixel and sample out of a 4 MB table), not by arithmetic, so it re-derives what the other half of the record held: the direction
+// = oct_decode of the code (the very expression evaluated here) and light_data.x, which k_light_tiles sets to 1 exactly when sample_li succeeded, i.e. when the
+// stored pdf != 0 (device_light.hpp sample_li: `return !(pdf == 0)`; a failed sample is stored as all zeros). Arrays handed in through the stepwise ABI
+// (mirres_restir_initial) need not obey that relation: they keep the 32-byte record.
+template <bool COMPACT>
 __global__ void __launch_bounds__(MR_BLOCK) k_tile_aux(EnvD E, int total, const float* __restrict__ tile_data, const float* __restrict__ tile_pdf, float4* __restrict__ aux) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     v3 ld = ld3(tile_data, idx);
     v3 ldir = oct_decode(V2(ld.y, ld.z));
-    float4 a; a.x = ldir.x; a.y = ldir.y; a.z = ldir.z; a.w = luminance(env_radiance(E, ldir));
+    const float lum = luminance(env_radiance(E, ldir));
+    if (COMPACT) { float4 c; c.x = ld.y; c.y = ld.z; c.z = lum; c.w = tile_pdf[idx]; aux[idx] = c; return; }
+    float4 a; a.x = ldir.x; a.y = ldir.y; a.z = ldir.z; a.w = lum;
     float4 b; b.x = tile_pdf[idx]; b.y = ld.x; b.z = ld.y; b.w = ld.z;
     aux[2 * (size_t)idx] = a; aux[2 * (size_t)idx + 1] = b;
 }
 
 // ---------------------------------------------------------------- initial resampling (InitialResampling.slang:151-295)
+template <bool COMPACT>
 __global__ void __launch_bounds__(MR_IGEN_BLOCK) k_initial_gen(mirres_config_t C, EnvD E, GBufD G, ResD R, const float* __restrict__ tile_data,
                                                           const float* __restrict__ tile_pdf, const float4* __restrict__ tile_aux, uint32_t frameIndex0, int fx, int N,
                                                           int NV, int TS, int y_off, Ray* __restrict__ q, uint32_t* __restrict__ q_count, int32_t* __restrict__ slot_out) {
@@ -250,7 +259,7 @@ __global__ void __launch_bounds__(MR_IGEN_BLOCK) k_initial_gen(mirres_config_t C
     if (sv < NV) {
         const int ks = sv / N, pi = sv - ks * N;
         const uint32_t frameIndex = frameIndex0 + 20u * (uint32_t)ks;
-        tile_aux += 2 * (size_t)ks * TS;
+        tile_aux += (COMPACT ? 1 : 2) * (size_t)ks * TS;
         const GPix gp = load_gpix(G, pi);
         if (gp.occ < 0.1f) store_zero(R, sv);
         else {
@@ -267,14 +276,19 @@ __global__ void __launch_bounds__(MR_IGEN_BLOCK) k_initial_gen(mirres_config_t C
             Ris s = empty_ris();
             for (uint32_t i = 0; i < (uint32_t)C.initial_light_samples; ++i) {
                 uint32_t index = tileOffset + (offset + i * stride) % C.light_tile_size;
-                const float4 ax = tile_aux[2 * (size_t)index], bx = tile_aux[2 * (size_t)index + 1];
-                const v3 ld = V3(bx.y, bx.z, bx.w); const float lpdf = bx.x;
-                const v3 ldir = V3(ax.x, ax.y, ax.z);
-                float targetPdf = fmaxf(0.f, ax.w * rtarget::eval_brdf(ctx, ldir));   // rtarget::target with the precomputed luminance
+                v3 ld, ldir; float lpdf, llum;
+                if (COMPACT) {
+                    const float4 cx = tile_aux[index];
+                    lpdf = cx.w; llum = cx.z; ld = V3(cx.w != 0.f ? 1.f : 0.f, cx.x, cx.y); ldir = oct_decode(V2(cx.x, cx.y));
+                } else {
+                    const float4 ax = tile_aux[2 * (size_t)index], bx = tile_aux[2 * (size_t)index + 1];
+                    ld = V3(bx.y, bx.z, bx.w); lpdf = bx.x; ldir = V3(ax.x, ax.y, ax.z); llum = ax.w;
+                }
+                float targetPdf = fmaxf(0.f, llum * rtarget::eval_brdf(ctx, ldir));   // rtarget::target with the precomputed luminance
                 float sourcePdf = lerpf(lpdf, rtarget::pdf_brdf(ctx, ldir), ratio);  // res.slang:79-91
                 float w = mr_div(targetPdf, sourcePdf);                                // res.slang:93-113
                 s.weightSum += w; s.M += 1.f;
-                if (rnd(sg) * s.weightSum < w) { s.light_data = ld; s.inv_pdf = lpdf; s.weight = targetPdf; s.lum = ax.w; }
+                if (rnd(sg) * s.weightSum < w) { s.light_data = ld; s.inv_pdf = lpdf; s.weight = targetPdf; s.lum = llum; }
             }
             for (int i = 0; i < C.initial_brdf_samples; ++i) {
                 float xa = rnd(sg), xb = rnd(sg), xc = rnd(sg);
@@ -805,8 +819,10 @@ int launch_initial_batch(mirres_ctx* ctx, mirres_bvh* bvh, const mirres_env_t* e
     const int TS = ctx->cfg.light_tile_count * ctx->cfg.light_tile_size;
     MR_HIP(hipMemsetAsync(&q->counters[0], 0, sizeof(uint32_t), s));
     k_light_tiles<<<grid_for((size_t)K * TS, MR_BLOCK), MR_BLOCK, 0, s>>>(envh(env), frame0, K * TS, TS, tile_data, nullptr, tile_pdf);       // pass 0 (+1 inside)
-    k_tile_aux<<<grid_for((size_t)K * TS, MR_BLOCK), MR_BLOCK, 0, s>>>(envh(env), K * TS, tile_data, tile_pdf, reinterpret_cast<float4*>(tile_aux));
-    k_initial_gen<<<grid_for(NV, MR_IGEN_BLOCK), MR_IGEN_BLOCK, 0, s>>>(ctx->cfg, envh(env), gbufd(g), resd(res), tile_data, tile_pdf, reinterpret_cast<const float4*>(tile_aux),
+    static const bool compact = [] { const char* e = getenv("MIRRES_TILE_COMPACT"); return !(e && e[0] == '0'); }();
+    if (compact) k_tile_aux<true><<<grid_for((size_t)K * TS, MR_BLOCK), MR_BLOCK, 0, s>>>(envh(env), K * TS, tile_data, tile_pdf, reinterpret_cast<float4*>(tile_aux));
+    else k_tile_aux<false><<<grid_for((size_t)K * TS, MR_BLOCK), MR_BLOCK, 0, s>>>(envh(env), K * TS, tile_data, tile_pdf, reinterpret_cast<float4*>(tile_aux));
+    (compact ? k_initial_gen<true> : k_initial_gen<false>)<<<grid_for(NV, MR_IGEN_BLOCK), MR_IGEN_BLOCK, 0, s>>>(ctx->cfg, envh(env), gbufd(g), resd(res), tile_data, tile_pdf, reinterpret_cast<const float4*>(tile_aux),
                                                                        frame0 + 2, ctx->fx, N, NV, TS, ctx->y_off, q->any_rays, &q->counters[0], q->slot_a);       // pass 2
     int rc = trace_any_q(ctx, bvh, q->any_rays, &q->counters[0], (size_t)NV, q->any_hit, s, q->lane); if (rc) return rc;
     k_initial_resolve<<<grid_for(NV, MR_BLOCK), MR_BLOCK, 0, s>>>(resd(res), NV, q->slot_a, q->any_hit);
@@ -979,8 +995,8 @@ int mirres_restir_initial(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_env
     hipStream_t s = (hipStream_t)stream; const int N = (int)ctx->N; const int grd = grid_for(N, MR_BLOCK);
     MR_HIP(hipMemsetAsync(&ctx->counters[0], 0, sizeof(uint32_t), s));
     const int TS = ctx->cfg.light_tile_count * ctx->cfg.light_tile_size;
-    k_tile_aux<<<grid_for(TS, MR_BLOCK), MR_BLOCK, 0, s>>>(envh(env), TS, light_data, light_inv_pdf, reinterpret_cast<float4*>(ctx->tile_aux));
-    k_initial_gen<<<grid_for(N, MR_IGEN_BLOCK), MR_IGEN_BLOCK, 0, s>>>(ctx->cfg, envh(env), gbufd(g), resd(res), light_data, light_inv_pdf, reinterpret_cast<const float4*>(ctx->tile_aux), frameIndex, ctx->fx, N, N, TS, 0, ctx->any_rays,
+    k_tile_aux<false><<<grid_for(TS, MR_BLOCK), MR_BLOCK, 0, s>>>(envh(env), TS, light_data, light_inv_pdf, reinterpret_cast<float4*>(ctx->tile_aux));
+    k_initial_gen<false><<<grid_for(N, MR_IGEN_BLOCK), MR_IGEN_BLOCK, 0, s>>>(ctx->cfg, envh(env), gbufd(g), resd(res), light_data, light_inv_pdf, reinterpret_cast<const float4*>(ctx->tile_aux), frameIndex, ctx->fx, N, N, TS, 0, ctx->any_rays,
                                             &ctx->counters[0], ctx->slot_a);
     int rc = trace_any(ctx, bvh, (size_t)N, s); if (rc) return rc;
     k_initial_resolve<<<grd, MR_BLOCK, 0, s>>>(resd(res), N, ctx->slot_a, ctx->any_hit);

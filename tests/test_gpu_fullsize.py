@@ -347,7 +347,7 @@ def test_round4_switches_do_not_change_the_frame_at_full_size():
     outs = {}
     for name, extra in (("default", {}), ("collapsed LBVH", {"MIRRES_PRIVATE_TREE": "0"}), ("extended-Morton tree without the SAH top", {"MIRRES_PRIVATE_TREE": "1"}), ("separate temporal", {"MIRRES_FUSE_TEMPORAL": "0"}),
                         ("slot-order material lookup", {"MIRRES_GRID_SORT": "0"}), ("reference-order closest hit", {"MIRRES_CLOSEST": "2"}),
-                        ("every spatial shadow ray traced", {"MIRRES_SKIP_DEAD": "0"}), ("shadow-ray kernel with the LDS-staged top levels", {"MIRRES_TOPQ": "85"}),
+                        ("every spatial shadow ray traced", {"MIRRES_SKIP_DEAD": "0"}), ("shadow-ray kernel with the LDS-staged top levels", {"MIRRES_TOPQ": "85"}), ("32-byte light-tile records", {"MIRRES_TILE_COMPACT": "0"}),
                         ("15-bit sort keys, three streams, six workgroups per CU (the defaults until the end of round 4)", {"MIRRES_GS_BITS": "5", "MIRRES_STREAMS": "3", "MIRRES_TRACE_BLOCKS_PER_CU": "6"})):
         env = dict(os.environ, MIRRES_MESH="clustered", **extra); env.pop("MIRRES_PARITY_REPORT", None)
         r = subprocess.run([sys.executable, os.path.join(root, "scripts", "dev_frame_hash.py"), "6"], env=env, capture_output=True, text=True, timeout=900)
