@@ -274,21 +274,29 @@ __global__ void __launch_bounds__(MR_IGEN_BLOCK) k_initial_gen(mirres_config_t C
             const rtarget::Ctx ctx = rtarget::make_ctx(n, gp.rd, gp.brdf);
             const float ratio = (float)C.initial_brdf_samples / (float)(C.initial_light_samples + C.initial_brdf_samples);
             Ris s = empty_ris();
-            for (uint32_t i = 0; i < (uint32_t)C.initial_light_samples; ++i) {
-                uint32_t index = tileOffset + (offset + i * stride) % C.light_tile_size;
-                v3 ld, ldir; float lpdf, llum;
-                if (COMPACT) {
-                    const float4 cx = tile_aux[index];
-                    lpdf = cx.w; llum = cx.z; ld = V3(cx.w != 0.f ? 1.f : 0.f, cx.x, cx.y); ldir = oct_decode(V2(cx.x, cx.y));
-                } else {
-                    const float4 ax = tile_aux[2 * (size_t)index], bx = tile_aux[2 * (size_t)index + 1];
-                    ld = V3(bx.y, bx.z, bx.w); lpdf = bx.x; ldir = V3(ax.x, ax.y, ax.z); llum = ax.w;
-                }
+            auto candidate = [&](v3 ld, v3 ldir, float lpdf, float llum) {
                 float targetPdf = fmaxf(0.f, llum * rtarget::eval_brdf(ctx, ldir));   // rtarget::target with the precomputed luminance
                 float sourcePdf = lerpf(lpdf, rtarget::pdf_brdf(ctx, ldir), ratio);  // res.slang:79-91
                 float w = mr_div(targetPdf, sourcePdf);                                // res.slang:93-113
                 s.weightSum += w; s.M += 1.f;
                 if (rnd(sg) * s.weightSum < w) { s.light_data = ld; s.inv_pdf = lpdf; s.weight = targetPdf; s.lum = llum; }
+            };
+            {
+                // light_tile_size is 1024 in every configuration of the reference: the wrap is a mask then (a 32-bit modulo by a run-time value costs ~35 instructions, 32
+                // times per pixel and sample). Requesting several candidate records ahead of their use was measured too: no gain (profiles/r04_ab_igen_ahead.txt) — the
+                // loop is bound by its ~350 instructions per candidate (three IEEE divisions, a normalisation, the GGX pdf), not by its gathers.
+                const uint32_t ts_mask = (uint32_t)C.light_tile_size - 1u; const bool ts_pow2 = ((uint32_t)C.light_tile_size & ts_mask) == 0u;
+                for (uint32_t i = 0; i < (uint32_t)C.initial_light_samples; ++i) {
+                    const uint32_t v = offset + i * stride;
+                    const uint32_t index = tileOffset + (ts_pow2 ? (v & ts_mask) : v % (uint32_t)C.light_tile_size);
+                    if (COMPACT) {
+                        const float4 cx = tile_aux[index];
+                        candidate(V3(cx.w != 0.f ? 1.f : 0.f, cx.x, cx.y), oct_decode(V2(cx.x, cx.y)), cx.w, cx.z);
+                    } else {
+                        const float4 ax = tile_aux[2 * (size_t)index], bx = tile_aux[2 * (size_t)index + 1];
+                        candidate(V3(bx.y, bx.z, bx.w), V3(ax.x, ax.y, ax.z), bx.x, ax.w);
+                    }
+                }
             }
             for (int i = 0; i < C.initial_brdf_samples; ++i) {
                 float xa = rnd(sg), xb = rnd(sg), xc = rnd(sg);
