@@ -42,7 +42,8 @@ int trace_any_queue_counted(const mirres_bvh* bvh, const Ray* rays, const uint32
 #define MR_CHUNK_PX 128
 #endif
 #ifndef MR_SRES_TILE
-#define MR_SRES_TILE 16
+#define MR_SRES_TILE 8      // one wave per workgroup. 16 (rounds 2-4) was the better shape while the kernel held 140 registers without the fused temporal merge; at 159 (three waves
+                            // per SIMD) the finer granularity wins: +2.2 % (icosphere) / +0.7 % (lego-like) on the frame (profiles/r04_ab_spatial_shapes.txt)
 #endif
 // MR_TILE_MAP 0: row-major tiles. 1: eight contiguous bands of tile rows, one per XCD. 2: 128 x 128 px chunks of tiles dealt to the XCDs in turn.
 // (Workgroups go to the eight XCDs round-robin by block index and every XCD has its own L2.)
