@@ -26,7 +26,11 @@ namespace mr {
 #ifndef MR_LDS_STACK
 #define MR_LDS_STACK 12    // entries per lane kept in LDS before spilling to scratch
 #endif
-#define MR_TRACE_BLOCK 256
+#ifndef MR_TRACE_BLOCK
+#define MR_TRACE_BLOCK 64  // one wave per workgroup: nothing in the traversal kernels is shared between the waves of a workgroup any more (the LDS stack is per lane; the staged top
+                           // levels are off by default), and single-wave workgroups are placed and retired independently: lego-like frame +1.0 %, icosphere +- 0 against 256
+                           // (rounds 1-4), the same number of waves launched (profiles/r04_ab_trace_block.txt)
+#endif
 
 struct Slab { float tn, tf; };
 
@@ -943,7 +947,7 @@ static int closest_mode() {   // 4 (default): ordered compressed 4-wide fast pat
 static int persist_grid(size_t capacity) {
     size_t want = (capacity + MR_TRACE_BLOCK - 1) / MR_TRACE_BLOCK;
     static const size_t cap_blocks = [] { const char* e = getenv("MIRRES_TRACE_BLOCKS_PER_CU"); const int v = e ? atoi(e) : 8; return (size_t)(v >= 1 && v <= 16 ? v : 8); }();
-    size_t cap = 256 * cap_blocks;      // workgroups launched per CU. Six are resident at once (75-79 VGPRs; forcing <= 64 spills, and the kernels are VALU-issue bound while CUs
+    size_t cap = 256 * cap_blocks * (256 / MR_TRACE_BLOCK);      // workgroups (of 256 threads) launched per CU. Six are resident at once (75-79 VGPRs; forcing <= 64 spills, and the kernels are VALU-issue bound while CUs
                                         // hold waves, so more occupancy buys nothing); launching eight lets a CU that finishes early pick up another workgroup's share of the
                                         // queues' tails: +0.7 % (icosphere) / +0.9 % (lego-like) on the 512-spp frame against six, twelve and more lose on the icosphere
                                         // (profiles/r04_ab_trace_blocks.txt; rounds 1-4 launched six)
