@@ -520,9 +520,7 @@ __global__ void __launch_bounds__(256) k_hierarchy64(int T, const unsigned long 
 // measured (profiles/r04_ab_sah_top.txt): shadow-ray launch -4 % (icosphere) / -7 % (lego-like), 128-spp frame +2.5 % / +3.8 %, build +0.9 / +1.4 ms.
 // All or nothing: if anything is off — more clusters than the scratch holds, a level budget exceeded, counts that do not add up — nothing is installed and the
 // extended-Morton tree stays as it is (k_sah_install checks). Which ids the atomics hand out varies from run to run; the topology does not, and no result depends on either.
-#define MR_SAH_PREFIX 24
 #define MR_SAH_BINS 8
-#define MR_SAH_LEVELS 40
 #define MR_SAH_MAXC 65536
 struct SahNode { uint32_t count, cb[6], minidx; int32_t axis, bin; float lo, scale; int32_t cl, cr, iid, alias; float box[6]; };      // 24 words
 struct SahBin { uint32_t count, box[6]; };
@@ -848,6 +846,7 @@ int mirres_bvh_create(mirres_bvh_t** out, int max_tris) {
     MR_HIP(hipMalloc(&b->top341q, sizeof(Node4q) * 341));
     MR_HIP(hipMalloc(&b->root_box, sizeof(float) * 8));
     MR_HIP(hipMalloc(&b->work, sizeof(uint32_t) * MR_WSETS * MR_WSET));
+    MR_HIP(hipHostMalloc((void**)&b->err, 64, hipHostMallocMapped)); *b->err = 0u;
     b->sort_tmp_bytes = sizeof(uint32_t) * 256 * ((T + MR_RS_TILE - 1) / MR_RS_TILE + 1);     // (digit, tile) counters of the radix sort + the digit totals
     MR_HIP(hipMalloc(&b->sort_tmp, b->sort_tmp_bytes));
     *out = b;
@@ -860,6 +859,7 @@ void mirres_bvh_destroy(mirres_bvh_t* b) {
                     b->own_aabb, b->nodes, b->tris, b->root_box, b->sort_tmp, b->work, b->redo[0], b->redo[1], b->dump_pool, b->lvl, b->nodes4q, b->leaves, b->top85q, b->top341q,
                     b->p_keys, b->p_vals, b->p_key64, b->p_info, b->p_aabb, b->p_range, b->p_parent, b->sah_state, b->sah_nodes, b->sah_bins, b->sah_iref, b->sah_inode, b->sah_top};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (b->err) (void)hipHostFree(b->err);
     delete b;
 }
 

@@ -229,14 +229,37 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_closest(BvhView B, con
 // 36 k of them = 0.41 ms — the whole kernel. The ray queue is therefore cut into MR_NQ contiguous sub-queues with their own head words
 // (128 B apart: different L2 channels); a wave starts on sub-queue (wave id mod MR_NQ), takes chunks from it and moves to the next one when
 // it runs dry (each sub-queue is probed at most once after it emptied, so a wave stops after MR_NQ failed probes).
-MR_DEV bool grab_chunk(uint32_t* __restrict__ heads, uint32_t n, uint32_t per, uint32_t chunk, uint32_t& q, uint32_t& fails, uint32_t& c_next, uint32_t& c_end, int lane) {
+// The END of a launch (round 5). Every wave leaves through MR_NQ failed probes; as returning atomicAdds those are 8192 waves x 32 = 262 k read-modify-writes,
+// 8192 per word, ~11 ns each when they queue on one word: an EMPTY launch takes 108 us doing nothing else (profiles/r05_strip_fixed_cost.txt), and a strip of an
+// 8-GPU frame spends more time there than on its rays. What does NOT help, measured (profiles/r05_ab_grab_modes.txt): probing with a load of the head first
+// (0.67 -> 0.80 ms on 6.9 M rays), or every failing wave OR-ing "empty" into a shared mask word (1.10 ms) — same instruction counts, but TCP_TCR_TCP_STALL_CYCLES
+// 1.3 M -> 187 M and twice the L1 miss latency: a few hundred thousand atomics queued on ONE line (11 ns each, serial) saturate that line's L2 channel for the whole
+// launch, and every node fetch that maps to the channel waits behind them (profiles/r05_pmc_grab_modes.txt). The failed probes have to go, not get cheaper:
+// the wave whose atomicAdd lands in [end, end + chunk) — exactly one per sub-queue, chunks being equal — publishes the sub-queue's bit in a mask word on a line of
+// its own (32 atomics per launch), and a wave that has just failed reads the mask once and skips what is known to be empty. Sub-queues beyond n are never touched.
+// Which wave gets which rays does not change any ray's answer; a mask that lags only costs the atomic it would have saved.
+#ifndef MR_GRAB_MODE
+#define MR_GRAB_MODE 3     // 0: every probe is an atomicAdd (rounds 1-4); 3: + the mask of empty sub-queues, published once per sub-queue
+#endif
+MR_DEV bool grab_chunk(uint32_t* __restrict__ heads, uint32_t n, uint32_t per, uint32_t chunk, uint32_t& q, uint32_t& fails, uint32_t& known, uint32_t& c_next, uint32_t& c_end, int lane) {
+    uint32_t* const empty_mask = heads + MR_NQ * MR_QSTRIDE;
     while (fails < MR_NQ) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(heads + q * MR_QSTRIDE, chunk);
-        base = __builtin_amdgcn_readfirstlane(base);
         const uint32_t qb = q * per;
-        const uint32_t qe = (qb + per < n) ? qb + per : n;
-        if (qb < n && base < qe - qb) { c_next = qb + base; c_end = (c_next + chunk < qe) ? c_next + chunk : qe; return true; }
+        if (MR_GRAB_MODE == 0 || (qb < n && !((known >> q) & 1u))) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(heads + q * MR_QSTRIDE, chunk);
+            base = __builtin_amdgcn_readfirstlane(base);
+            const uint32_t qe = (qb + per < n) ? qb + per : n;
+            if (qb < n && base < qe - qb) { c_next = qb + base; c_end = (c_next + chunk < qe) ? c_next + chunk : qe; return true; }
+            if (MR_GRAB_MODE == 3) {
+                uint32_t m = 0;
+                if (lane == 0) {
+                    if (base - (qe - qb) < chunk) (void)__hip_atomic_fetch_or(empty_mask, 1u << q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    m = __hip_atomic_load(empty_mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                known |= __builtin_amdgcn_readfirstlane(m) | (1u << q);
+            }
+        }
         q = (q + 1 == MR_NQ) ? 0 : q + 1; fails++;
     }
     return false;
@@ -259,6 +282,7 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_persist(BvhView B, con
     chunk = chunk < 64 ? 64 : (chunk > MR_CHUNK_MAX ? MR_CHUNK_MAX : (chunk & ~63u));
     const uint32_t q_per = (((n + MR_NQ - 1) / MR_NQ) + 63u) & ~63u;                                  // rays per sub-queue
     uint32_t q_cur = (blockIdx.x * (MR_TRACE_BLOCK / 64) + (threadIdx.x >> 6)) % MR_NQ, q_fail = 0;   // wave-uniform
+    uint32_t q_known = 0;   // sub-queues this wave knows to be empty (grab_chunk)
     uint32_t chunk_next = 0, chunk_end = 0;  // wave-uniform
     bool exhausted = false;                  // wave-uniform: the global queue has no more chunks
     bool have = false;
@@ -271,7 +295,7 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_persist(BvhView B, con
         // ---- refill idle lanes from the wave's chunk
         const uint64_t need = __ballot(!have);
         if (need && !exhausted) {
-            if (chunk_next >= chunk_end) exhausted = !grab_chunk(work_head, n, q_per, chunk, q_cur, q_fail, chunk_next, chunk_end, lane);
+            if (chunk_next >= chunk_end) exhausted = !grab_chunk(work_head, n, q_per, chunk, q_cur, q_fail, q_known, chunk_next, chunk_end, lane);
             if (!exhausted) {
                 const uint32_t idx = chunk_next + (uint32_t)__popcll(need & lt_mask);
                 if (!have && idx < chunk_end) {
@@ -400,6 +424,9 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_persist(BvhView B, con
 #ifndef MR_ANY_STACK
 #define MR_ANY_STACK 256
 #endif
+// 3 deferred references per 4-wide level x (levels of the SAH top + key bits free below a cluster + position bits of an int32 triangle count)
+static_assert(MR_ANY_STACK >= 3 * (MR_SAH_LEVELS + (38 - MR_SAH_PREFIX) + 31), "MR_ANY_STACK must cover the deepest private hierarchy (DESIGN.md, stack bounds)");
+static_assert(MR_ANY_LDS >= 3 && MR_ANY_LDS <= MR_ANY_STACK, "the LDS part of the private stack holds at least one node's deferred references");
 #define MR_TOPBIT 0x20000000
 // ---------------------------------------------------------------- shadow rays on the COMPRESSED 4-wide collapse (engine.hpp Node4q / LeafRec)
 // The any-hit bit is the OR over leaves whose own box passes the slab test (above); interior boxes only steer the search and may be any
@@ -511,6 +538,7 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const
     chunk = chunk < 64 ? 64 : (chunk > MR_CHUNK_MAX ? MR_CHUNK_MAX : (chunk & ~63u));
     const uint32_t q_per = (((n + MR_NQ - 1) / MR_NQ) + 63u) & ~63u;                                  // rays per sub-queue
     uint32_t q_cur = (blockIdx.x * (MR_TRACE_BLOCK / 64) + (threadIdx.x >> 6)) % MR_NQ, q_fail = 0;   // wave-uniform
+    uint32_t q_known = 0;   // sub-queues this wave knows to be empty (grab_chunk)
     uint32_t chunk_next = 0, chunk_end = 0;
     bool exhausted = false, have = false;
     float ox = 0, oy = 0, oz = 0, ix = 0, iy = 0, iz = 0; v3 d = V3(0.f), ro = V3(0.f);
@@ -554,7 +582,7 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const
             }
         }
         if (need && !exhausted) {
-            if (chunk_next >= chunk_end) exhausted = !grab_chunk(work_head, n, q_per, chunk, q_cur, q_fail, chunk_next, chunk_end, lane);
+            if (chunk_next >= chunk_end) exhausted = !grab_chunk(work_head, n, q_per, chunk, q_cur, q_fail, q_known, chunk_next, chunk_end, lane);
             if (!exhausted) {
                 const uint32_t idx0 = chunk_next + (uint32_t)__popcll(need & lt_mask);
 #ifdef MR_EXP_PERMUTE   // experiment: queue position -> ray through a multiplicative permutation, i.e. a wave's lanes hold rays from all over the frame
@@ -669,7 +697,10 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const
                                 if (sp < MR_ANY_LDS) lds_stack[sp * MR_TRACE_BLOCK] = (uint32_t)far;
                                 else if (sp < MR_ANY_STACK) spill[sp - MR_ANY_LDS] = (uint32_t)far;
                                 if (sp < MR_ANY_STACK) sp++;
-                                else if (stats) atomicAdd(&stats[11], 1ull);    // cannot happen (bound above); were it to, it is not silent: mirres_ctx_stats()[11]
+                                else {    // cannot happen (bound above, static_assert); were it to, it is not silent: the sticky word makes mirres_render / mirres_bvh_trace fail, mirres_ctx_stats()[11] counts
+                                    if (B.err) __hip_atomic_store(B.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                    if (stats) atomicAdd(&stats[11], 1ull);
+                                }
                             }
                         }
                     }
@@ -735,6 +766,7 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_closest4(BvhView B, co
     chunk = chunk < 64 ? 64 : (chunk > MR_CHUNK_MAX ? MR_CHUNK_MAX : (chunk & ~63u));
     const uint32_t q_per = (((n + MR_NQ - 1) / MR_NQ) + 63u) & ~63u;                                  // rays per sub-queue
     uint32_t q_cur = (blockIdx.x * (MR_TRACE_BLOCK / 64) + (threadIdx.x >> 6)) % MR_NQ, q_fail = 0;   // wave-uniform
+    uint32_t q_known = 0;   // sub-queues this wave knows to be empty (grab_chunk)
     uint32_t chunk_next = 0, chunk_end = 0;
     bool exhausted = false, have = false, fin = false;
     float ox = 0, oy = 0, oz = 0, ix = 0, iy = 0, iz = 0; v3 d = V3(0.f), ro = V3(0.f);
@@ -750,7 +782,7 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_closest4(BvhView B, co
     while (true) {
         const uint64_t need = __ballot(!have);
         if (need && !exhausted) {
-            if (chunk_next >= chunk_end) exhausted = !grab_chunk(work_head, n, q_per, chunk, q_cur, q_fail, chunk_next, chunk_end, lane);
+            if (chunk_next >= chunk_end) exhausted = !grab_chunk(work_head, n, q_per, chunk, q_cur, q_fail, q_known, chunk_next, chunk_end, lane);
             if (!exhausted) {
                 const uint32_t idx = chunk_next + (uint32_t)__popcll(need & lt_mask);
                 if (!have && idx < chunk_end) {
@@ -922,7 +954,7 @@ static int closest_fast(mirres_bvh* bvh, const Ray* rays, const uint32_t* d_coun
     MR_HIP(hipMemsetAsync(w, 0, 3 * MR_WSET * sizeof(uint32_t), s));
     k_trace_closest4<COUNT><<<persist_grid(capacity), MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, d_count, (uint32_t)capacity, w, rec, hit, t, pos, nrm, prim,
                                                                                bvh->redo[alt], w + MR_WSET, stats);
-    k_trace_persist<false><<<256, MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, w + MR_WSET, 0u, w + 2 * MR_WSET, hit, rec, t, pos, nrm, prim, COUNT ? stats : nullptr, bvh->redo[alt]);
+    k_trace_persist<false><<<256 * (256 / MR_TRACE_BLOCK), MR_TRACE_BLOCK, 0, s>>>(bvh->view(), rays, w + MR_WSET, 0u, w + 2 * MR_WSET, hit, rec, t, pos, nrm, prim, COUNT ? stats : nullptr, bvh->redo[alt]);
     MR_LAUNCH_CHECK("closest_fast");
     return 0;
 }
@@ -955,9 +987,9 @@ static int persist_grid(size_t capacity) {
 }
 
 static int trace_grid(size_t capacity) {
-    // persistent-style launch: enough 256-thread blocks to fill 256 CUs several times over, grid-stride beyond
+    // persistent-style launch: enough workgroups (counted in 256 threads, whatever MR_TRACE_BLOCK is) to fill 256 CUs several times over, grid-stride beyond
     size_t want = (capacity + MR_TRACE_BLOCK - 1) / MR_TRACE_BLOCK;
-    size_t cap = 256 * 8;
+    size_t cap = 256 * 8 * (256 / MR_TRACE_BLOCK);
     return (int)(want < 1 ? 1 : (want > cap ? cap : want));
 }
 
@@ -1045,6 +1077,7 @@ extern "C" int mirres_bvh_trace(mirres_bvh_t* bvh, const float* rays, int n, int
                                 int32_t* prim, uint32_t* counters, void* stream) {
     if (!bvh || !rays || n < 0 || mode < 0 || mode > 3) { set_error("mirres_bvh_trace: bad argument"); return MIRRES_E_ARG; }
     if (bvh->T < 2) { set_error("mirres_bvh_trace: BVH not built"); return MIRRES_E_STATE; }
+    if (int e = bvh_sticky_error(bvh, "mirres_bvh_trace")) return e;
     if (n == 0) return MIRRES_OK;
     hipStream_t s = (hipStream_t)stream;
     const Ray* r = reinterpret_cast<const Ray*>(rays);

@@ -8,8 +8,12 @@
 // persistent-traversal work queue: MR_NQ sub-queue heads, one per 128-byte line (bvh_trace.hip grab_chunk); mirres_bvh::work holds MR_WSETS such sets
 #define MR_NQ 32
 #define MR_QSTRIDE 32
-#define MR_WSET (MR_NQ * MR_QSTRIDE)
+#define MR_WSET ((MR_NQ + 1) * MR_QSTRIDE)   // + one more line: word MR_NQ * MR_QSTRIDE = bit mask of the sub-queues found empty (grab_chunk)
 #define MR_WSETS 17
+// Binned-SAH top of the private steering hierarchy (bvh_build.hip): clusters = maximal subtrees whose leaves share MR_SAH_PREFIX key bits (of 38), at most
+// MR_SAH_LEVELS levels rebuilt above them. The shadow-ray kernel's private stack (bvh_trace.hip MR_ANY_STACK) is sized from these two.
+#define MR_SAH_PREFIX 24
+#define MR_SAH_LEVELS 40
 
 namespace mr {
 
@@ -55,6 +59,7 @@ struct BvhView {
     const Node4q* nodes4q; const LeafRec* leaves; const Node4q* top85q; const Node4q* top341q;   // compressed shadow-ray layout
     int T;
     unsigned long long* dbg;   // optional [2 * waves]: wall-clock start / end of every traversal wave (mirres_debug_wave_times)
+    uint32_t* err;             // host-mapped sticky word: set by a traversal kernel that had to drop a deferred subtree (provably never; mirres_render / mirres_bvh_trace refuse to go on once it is set)
 };
 
 // Shadow rays given as pixel pairs instead of 32-byte rays (the spatial pass of mirres_render): queue entry j = (pixel a, pixel b) stands for ray 2j — from a's
@@ -96,9 +101,10 @@ struct mirres_bvh {
     uint32_t* work = nullptr;       // [MR_WSETS * MR_WSET] head sets of the persistent traversal kernels: 0/1 chain, 2/3 API, 4-6 ordered closest + redo, 7/8 bulk stream, 9/10 path-tracing stream,
                                     // 11 final-stage stream, 12-14 ordered closest + redo and 15/16 any / closest of the second path-tracing stream
     unsigned long long* dbg = nullptr;   // see BvhView::dbg
+    uint32_t* err = nullptr;             // see BvhView::err (hipHostMalloc, mapped: the host reads it without a copy)
     char* dump_pool = nullptr; size_t dump_pool_bytes = 0;   // mirres_dump_render: shadow rays / results / slots of one pixel chunk
     uint32_t* redo[2] = {nullptr, nullptr}; size_t redo_cap[2] = {0, 0};   // ray ids handed back by the ordered closest-hit fast path (one list per path-tracing stream)
-    mr::BvhView view() const { mr::BvhView v; v.nodes = nodes; v.tris = tris; v.root_box = root_box; v.T = T; v.nodes4q = nodes4q; v.leaves = leaves; v.top85q = top85q; v.top341q = top341q; v.dbg = dbg; return v; }
+    mr::BvhView view() const { mr::BvhView v; v.nodes = nodes; v.tris = tris; v.root_box = root_box; v.T = T; v.nodes4q = nodes4q; v.leaves = leaves; v.top85q = top85q; v.top341q = top341q; v.dbg = dbg; v.err = err; return v; }
 };
 
 struct mirres_ctx {
@@ -142,6 +148,11 @@ const char* set_error(const char* fmt, ...);
 int check_hip(hipError_t e, const char* what);
 #define MR_HIP(x) do { int _rc = mr::check_hip((x), #x); if (_rc) return _rc; } while (0)
 #define MR_LAUNCH_CHECK(name) MR_HIP(hipGetLastError())
+// sticky traversal error (BvhView::err): checked where a caller can still be told
+inline int bvh_sticky_error(const mirres_bvh* bvh, const char* who) {
+    if (bvh && bvh->err && *(volatile uint32_t*)bvh->err) { set_error("%s: an earlier traversal launch overflowed its private stack (flag %u): results since then are not trustworthy", who, *(volatile uint32_t*)bvh->err); return MIRRES_E_STATE; }
+    return MIRRES_OK;
+}
 
 // queue tracing (bvh_trace.hip). count is read on the device; capacity bounds the grid-stride loop.
 int trace_any_items_queue(const mirres_bvh* bvh, const uint2* items, const RaySrc& src, const uint32_t* d_count, size_t capacity, int32_t* hit,

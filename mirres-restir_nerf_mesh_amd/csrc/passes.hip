@@ -949,6 +949,8 @@ void mirres_ctx_destroy(mirres_ctx_t* c) {
     if (c->pt_stream2) (void)hipStreamDestroy(c->pt_stream2);
     for (hipEvent_t e : c->ev_pt) (void)hipEventDestroy(e);
     if (c->fin_stream) (void)hipStreamDestroy(c->fin_stream);
+    for (hipEvent_t e : c->ev_halo) if (e) (void)hipEventDestroy(e);      // created on first use by mirres_render's strip_overlap path (render.hip)
+    if (c->halo_stream) (void)hipStreamDestroy(c->halo_stream);
     delete c;
 }
 

@@ -359,6 +359,7 @@ int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args
     }
     for (int k = 0; k < 6; k++) if (!a->outs[k]) { set_error("mirres_render: outs[%d] is null", k); return MIRRES_E_ARG; }
     if (bvh->T < 2) { set_error("mirres_render: BVH not built"); return MIRRES_E_STATE; }
+    if (int e = bvh_sticky_error(bvh, "mirres_render")) return e;
     hipStream_t s = (hipStream_t)stream;
     const int N = (int)ctx->N, fx = ctx->fx; const size_t n3 = 3 * (size_t)N;
     const int Wc = a->Wc, Hc = a->Hc;

@@ -463,6 +463,57 @@ int orc_render(const OrcRenderArgs* A) {
     return 0;
 }
 
+// ---- probes of the two BRDF libraries (orc_brdf.hpp), one call per array of inputs: what tests/test_brdf_invariants.py holds against the published formulas
+// (Walter et al. 2007 GGX, Heitz 2014 Smith masking, Schlick Fresnel, Falcor's lobe selection) written out independently in float64 numpy
+void orc_sh_lobes(int n, const float* kd, const float* rough, const float* metal, const float* ray_dir, const float* normal, float* pD, float* pS, float* alpha, float* specular) {
+    for (int i = 0; i < n; i++) {
+        sh::Lobes L = sh::lobes(ld3(kd, i), rough[i], metal[i], ld3(ray_dir, i), ld3(normal, i));
+        pD[i] = L.pD; pS[i] = L.pS; alpha[i] = L.alpha; st3(specular, i, L.specular);
+    }
+}
+// FalcorBRDF_eval / FalcorBRDF_evalPdf (activeLobes = true, allowDeltaEval = false) and the two lobes on their own, local frame (z = normal)
+void orc_sh_eval(int n, const float* pD, const float* pS, const float* alpha, const float* spec_albedo, const float* diff_albedo, const float* wo, const float* wi,
+                 float* f /*[n,3]*/, float* pdf /*[n]*/, float* spec_f /*[n,3]*/, float* spec_pdf /*[n]*/, float* diff_light /*[n]*/) {
+#pragma omp parallel for
+    for (int i = 0; i < n; i++) {
+        f3 o = ld3(wo, i), w = ld3(wi, i);
+        st3(f, i, sh::falcor_eval(pD[i], pS[i], alpha[i], ld3(spec_albedo, i), ld3(diff_albedo, i), o, w));
+        pdf[i] = sh::falcor_eval_pdf(pD[i], pS[i], o, w, alpha[i]);
+        st3(spec_f, i, sh::specular_eval(o, w, ld3(spec_albedo, i), alpha[i]));
+        spec_pdf[i] = sh::specular_eval_pdf(o, w, alpha[i]);
+        diff_light[i] = sh::diffuse_light(o, w).x;
+    }
+}
+// FalcorBRDF_sample (with_weight) / FalcorBRDF_sample_no_weight from generator state sg[i]; also returns the state afterwards (draw count) and the lobe choice u
+void orc_sh_sample(int n, const uint32_t* sg_in, float pD, float pS, float alpha, const float* spec_albedo, const float* diff_albedo, const float* wo, int with_weight,
+                   float* wi /*[n,3]*/, float* pdf, uint32_t* specular_bounce, float* weight /*[n,3]*/, int32_t* valid, uint32_t* sg_out, float* u_select) {
+    const f3 sa = mk3(spec_albedo[0], spec_albedo[1], spec_albedo[2]), da = mk3(diff_albedo[0], diff_albedo[1], diff_albedo[2]), o = mk3(wo[0], wo[1], wo[2]);
+#pragma omp parallel for
+    for (int i = 0; i < n; i++) {
+        uint32_t sg = sg_in[i], probe = sg_in[i];
+        u_select[i] = next1d(probe);
+        f3 w, wt; float p; uint32_t sb;
+        valid[i] = sh::falcor_sample(pD, pS, o, w, p, sb, wt, sg, alpha, sa, da, with_weight != 0) ? 1 : 0;
+        st3(wi, i, w); pdf[i] = p; specular_bounce[i] = sb; st3(weight, i, wt); sg_out[i] = sg;
+    }
+}
+// utils/brdf.slang (reservoir target function and candidate pdf): evalBRDF, evalPdfBRDF(specularOnly = false), sampleBRDF, world space
+void orc_rt_eval(int n, const float* L, const float* V, const float* N, const float* alpha, const float* wd, const float* ws, float* f, float* pdf) {
+#pragma omp parallel for
+    for (int i = 0; i < n; i++) {
+        f[i] = rt::eval_brdf(ld3(L, i), ld3(V, i), ld3(N, i), alpha[i], wd[i], ws[i]);
+        pdf[i] = rt::eval_pdf_brdf(ld3(L, i), ld3(V, i), ld3(N, i), alpha[i], wd[i], ws[i]);
+    }
+}
+void orc_rt_sample(int n, const float* xi /*[n,3]*/, const float* V, const float* N, float alpha, float wd, float ws, float* dir /*[n,3]*/, int32_t* valid) {
+    const f3 v = mk3(V[0], V[1], V[2]), nn = mk3(N[0], N[1], N[2]);
+#pragma omp parallel for
+    for (int i = 0; i < n; i++) {
+        f3 d; valid[i] = rt::sample_brdf(ld3(xi, i), d, v, nn, alpha, wd, ws) ? 1 : 0; st3(dir, i, d);
+    }
+}
+void orc_sh_frame(const float* n, float* x, float* y) { sh::Frame f = sh::create_frame(mk3(n[0], n[1], n[2])); x[0] = f.x.x; x[1] = f.x.y; x[2] = f.x.z; y[0] = f.y.x; y[1] = f.y.y; y[2] = f.y.z; }
+
 // ---- nerf/render_dump.py (BASELINE configs[0]: direct lighting over a fixed lat-long light set, no ReSTIR)
 void orc_occluded_front(const int32_t* info, const float* aabb, const float* vert, const int32_t* tri, const float* rays, int n, int32_t* hit) {
     Bvh B = {info, aabb, vert, tri};

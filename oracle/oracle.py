@@ -365,6 +365,60 @@ def bilateral(fx, fy, sigma, col, nrm, zdz, grad4=None):
     return out
 
 
+# ------------------------------------------------------------------ BRDF library probes (tests/test_brdf_invariants.py)
+def sh_lobes(kd, rough, metal, ray_dir, normal):
+    """Lobe probabilities, GGX alpha and F0 colour as FinalShading.slang:58-78 derives them: (pD, pS, alpha, specular[n,3])."""
+    kd = _c(kd, np.float32); n = kd.shape[0]
+    pD = np.zeros(n, np.float32); pS = np.zeros(n, np.float32); al = np.zeros(n, np.float32); sp = np.zeros((n, 3), np.float32)
+    lib().orc_sh_lobes(n, _p(kd, f32p), _p(_c(rough, np.float32), f32p), _p(_c(metal, np.float32), f32p), _p(_c(ray_dir, np.float32), f32p), _p(_c(normal, np.float32), f32p),
+                       _p(pD, f32p), _p(pS, f32p), _p(al, f32p), _p(sp, f32p))
+    return pD, pS, al, sp
+
+
+def sh_eval(pD, pS, alpha, spec_albedo, diff_albedo, wo, wi):
+    """utils/brdfDi.slang in the local frame: dict(f = FalcorBRDF_eval [n,3], pdf = FalcorBRDF_evalPdf, spec_f = SpecularReflection_eval, spec_pdf, diff_light = Diffuse_light)."""
+    wo = _c(wo, np.float32); n = wo.shape[0]
+    b = lambda a, w: _c(np.broadcast_to(np.asarray(a, np.float32), (n,) if w == 1 else (n, w)), np.float32)
+    f = np.zeros((n, 3), np.float32); pdf = np.zeros(n, np.float32); sf = np.zeros((n, 3), np.float32); spdf = np.zeros(n, np.float32); dl = np.zeros(n, np.float32)
+    lib().orc_sh_eval(n, _p(b(pD, 1), f32p), _p(b(pS, 1), f32p), _p(b(alpha, 1), f32p), _p(b(spec_albedo, 3), f32p), _p(b(diff_albedo, 3), f32p), _p(wo, f32p), _p(b(wi, 3), f32p),
+                      _p(f, f32p), _p(pdf, f32p), _p(sf, f32p), _p(spdf, f32p), _p(dl, f32p))
+    return dict(f=f, pdf=pdf, spec_f=sf, spec_pdf=spdf, diff_light=dl)
+
+
+def sh_sample(sg, pD, pS, alpha, spec_albedo, diff_albedo, wo, with_weight=True):
+    """FalcorBRDF_sample (with_weight) / FalcorBRDF_sample_no_weight for every generator state in `sg` (uint32): dict(wi, pdf, specular_bounce, weight, valid, sg_out, u_select)."""
+    sg = _c(sg, np.uint32); n = sg.shape[0]
+    wi = np.zeros((n, 3), np.float32); pdf = np.zeros(n, np.float32); sb = np.zeros(n, np.uint32); wt = np.zeros((n, 3), np.float32)
+    valid = np.zeros(n, np.int32); so = np.zeros(n, np.uint32); us = np.zeros(n, np.float32)
+    lib().orc_sh_sample(n, _p(sg, u32p), C.c_float(pD), C.c_float(pS), C.c_float(alpha), _p(_c(spec_albedo, np.float32), f32p), _p(_c(diff_albedo, np.float32), f32p),
+                        _p(_c(wo, np.float32), f32p), int(with_weight), _p(wi, f32p), _p(pdf, f32p), _p(sb, u32p), _p(wt, f32p), _p(valid, i32p), _p(so, u32p), _p(us, f32p))
+    return dict(wi=wi, pdf=pdf, specular_bounce=sb, weight=wt, valid=valid.astype(bool), sg_out=so, u_select=us)
+
+
+def rt_eval(L, V, N, alpha, wd, ws):
+    """utils/brdf.slang: (evalBRDF, evalPdfBRDF(specularOnly=false)) per row, world space."""
+    L = _c(L, np.float32); n = L.shape[0]
+    b = lambda a, w: _c(np.broadcast_to(np.asarray(a, np.float32), (n,) if w == 1 else (n, w)), np.float32)
+    f = np.zeros(n, np.float32); pdf = np.zeros(n, np.float32)
+    lib().orc_rt_eval(n, _p(L, f32p), _p(b(V, 3), f32p), _p(b(N, 3), f32p), _p(b(alpha, 1), f32p), _p(b(wd, 1), f32p), _p(b(ws, 1), f32p), _p(f, f32p), _p(pdf, f32p))
+    return f, pdf
+
+
+def rt_sample(xi, V, N, alpha, wd, ws):
+    """utils/brdf.slang sampleBRDF(specularOnly=false): (dir [n,3], valid)."""
+    xi = _c(xi, np.float32); n = xi.shape[0]
+    d = np.zeros((n, 3), np.float32); valid = np.zeros(n, np.int32)
+    lib().orc_rt_sample(n, _p(xi, f32p), _p(_c(V, np.float32), f32p), _p(_c(N, np.float32), f32p), C.c_float(alpha), C.c_float(wd), C.c_float(ws), _p(d, f32p), _p(valid, i32p))
+    return d, valid.astype(bool)
+
+
+def sh_frame(n):
+    """create_frame (helperDi.slang:18-30): tangent x, y of the shading frame around normal n."""
+    x = np.zeros(3, np.float32); y = np.zeros(3, np.float32)
+    lib().orc_sh_frame(_p(_c(n, np.float32), f32p), _p(x, f32p), _p(y, f32p))
+    return x, y
+
+
 # ------------------------------------------------------------------ material field
 def hashgrid_layout():
     off = np.zeros(17, np.uint32); res = np.zeros(16, np.uint32); sc = np.zeros(16, np.float32)

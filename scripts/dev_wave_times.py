@@ -12,6 +12,8 @@ g = harness.build_gbuffer(W, 1600, 1600, 1)
 fg = g["occ"][:, 0] > 0.5
 pos, nrm = g["pos"][fg], g["normal"][fg]
 gen = torch.Generator(device="cuda").manual_seed(0)
+K = int(sys.argv[1]) if len(sys.argv) > 1 else 1          # rays per foreground pixel (7 = the spatial pass's launch size)
+pos = pos.repeat_interleave(K, 0); nrm = nrm.repeat_interleave(K, 0)
 n = pos.shape[0]
 r = torch.randn((n, 3), device="cuda", generator=gen); r = r / r.norm(dim=1, keepdim=True)
 d = nrm + 0.98 * r; d = d / d.norm(dim=1, keepdim=True)
@@ -39,3 +41,7 @@ print("waves", len(tt), "span us", en.max())
 for q in (0, 1, 5, 25, 50, 75, 95, 99, 100):
     print(f"  pct {q:3d}: start {np.percentile(st, q):8.1f} us   end {np.percentile(en, q):8.1f} us   dur {np.percentile(en - st, q):8.1f}")
 print("mean alive fraction", float((en - st).sum() / (len(tt) * en.max())))
+edges = np.linspace(0, en.max(), 21)
+alive = [(int(((st <= a) & (en > a)).sum())) for a in edges]
+print("waves alive at 5 % steps of the launch:", alive)
+print("waves started after 50 us:", int((st > 50).sum()), " of them lasting < 20 us:", int(((st > 50) & (en - st < 20)).sum()))
