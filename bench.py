@@ -293,11 +293,13 @@ def main():
     ctx.reserve()                       # the batch pool is sized here, not inside the first frame
     N = fx * fy
 
+    balancer = MD.StripBalancer(fy, world) if world > 1 else None      # strip boundaries follow the strips' measured times from frame to frame (bit-identical for any partition)
+
     def make_step(W_, mlp_, g_):
         def step(scheme):
             W_.update_mesh(W_.vrt, W_.v_ind)                                   # LBVH rebuilt every frame (nerf/renderer.py:975)
             if world > 1 and scheme == "strips":          # exact: row strips + per-sample halo exchange + all-gather of the raw sums (dist.py)
-                return MD.render_strips(ctx, W_, mlp_, env, g_, args.spp, 12345, rank, world, max_bounce=args.bounces)
+                return MD.render_strips(ctx, W_, mlp_, env, g_, args.spp, 12345, rank, world, max_bounce=args.bounces, balancer=balancer)
             return MD.render_sharded(ctx, W_, mlp_, env, g_, args.spp, 12345, rank, world)
         return step
     step = make_step(W, mlp, g)

@@ -204,6 +204,16 @@ static int pt_batch_size() {   // MIRRES_PT_BATCH = samples per batch (default 3
     int k = e ? atoi(e) : 32; if (k < 1) k = 1; if (k > 64) k = 64;
     return k;
 }
+// The bulk stream at the LOWEST priority (MIRRES_BULK_PRIO=low): the sample-by-sample chain on the caller's stream is what bounds a small frame (a strip of a
+// multi-GPU frame: profiles/r05_strip_table.txt), and its small launches get the CUs first while the batched stages fill in behind them. Default: normal priority.
+static hipError_t create_side_stream(hipStream_t* out) {
+    static const int prio_mode = [] { const char* e = getenv("MIRRES_BULK_PRIO"); return (e && e[0] == 'l') ? 1 : 0; }();
+    if (prio_mode == 1) {
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest) return hipStreamCreateWithPriority(out, hipStreamNonBlocking, least);
+    }
+    return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
 static int stream_count() { const char* e = getenv("MIRRES_STREAMS"); const int n = e ? atoi(e) : 2; return n < 1 ? 1 : (n > 5 ? 5 : n); }   // 1: everything on the caller's stream; 2 (default since the end of round 4: equal on the icosphere, +0.7 % on the lego-like mesh, profiles/r04_ab_gs_bits.txt): + one bulk stream; 3 (rounds 1-4): + path tracing on its own; 4: + final stages on their own; 5: + a second path-tracing stream (4, 5: measured within noise of 3)
 static int carve_batch(mirres_ctx* ctx, int N, int K, int max_bounce, size_t TS, PtBatch& PB) {
     if (K < 1) K = 1;
@@ -449,7 +459,7 @@ int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args
     const int nbatch = (i1 - i0 + PB.K - 1) / PB.K;
     if (two_streams) {
         if (!ctx->aux_stream) {
-            MR_HIP(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+            MR_HIP(create_side_stream(&ctx->aux_stream));
             MR_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming)); MR_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
         }
         while ((int)ctx->ev_sync.size() < 3 * (nbatch + 1)) { hipEvent_t e; MR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ctx->ev_sync.push_back(e); }

@@ -71,27 +71,37 @@ def render_sharded(ctx, worker, mlp_mat, env_map, g, spp, random_offset, rank, w
 
 
 # ------------------------------------------------------------------------------------------------ exact strip sharding
+_WARNED_OVERLAP = False
 HALO_ROWS = 30   # = mirres_config_t.gather_radius (SpatialResampling.slang:33-39)
 STRIP_ROW_QUANTUM = 32   # local strip frames are padded (background rows) to a multiple of this many rows: see render_strips
 
 
-def strip_bounds(fy, world, occ=None, fx=None, halo=HALO_ROWS, bg_weight=0.2):
-    """Row boundaries [b_0 = 0, ..., b_world = fy] of the strips. Without `occ`: equal heights (differing by at most one row). With the full-frame
-    occupancy `occ` ([fy*fx] or [fy*fx,1], any device): cost-balanced — a foreground pixel costs 1, a background pixel `bg_weight` (measured on the
-    bench frame: a mostly-sky strip renders ~4.5x faster than a foreground one of the same height), boundaries at equal cost quantiles, every strip
-    at least `halo` rows high. Deterministic in `occ`, so every rank computes the same partition from the (replicated) G-buffer."""
+BG_WEIGHT = 0.03   # cost of a background pixel relative to a foreground one (measured, profiles/r05_strip_table.txt: T_strip = a + 1.7 .. 2.6 ns x foreground px + ~0 x background px)
+
+
+def row_cost(fy, fx, occ, bg_weight=BG_WEIGHT):
+    """Static cost model of the rows of a frame: a foreground pixel costs 1, a background pixel `bg_weight`. float64 [fy] on the CPU."""
+    o = occ.detach().reshape(int(fy), int(fx)).float()
+    return (bg_weight * o.shape[1] + (1.0 - bg_weight) * (o > 0.5).float().sum(dim=1)).double().cpu()
+
+
+def strip_bounds(fy, world, occ=None, fx=None, halo=HALO_ROWS, bg_weight=BG_WEIGHT, cost=None):
+    """Row boundaries [b_0 = 0, ..., b_world = fy] of the strips. Without `occ` / `cost`: equal heights (differing by at most one row). With the full-frame
+    occupancy `occ` ([fy*fx] or [fy*fx,1], any device): cost-balanced by the static model (row_cost) — boundaries at equal cost quantiles, every strip at least
+    `halo` rows high. `cost` ([fy], e.g. StripBalancer.cost) replaces the model. Deterministic in its inputs, so every rank computes the same partition from the
+    (replicated) G-buffer."""
     fy, world = int(fy), int(world)
     if world > 1 and fy // world < halo:
         raise ValueError("strip sharding needs at least %d rows per rank (fy=%d, world=%d)" % (halo, fy, world))
-    if occ is None or world == 1:
+    if (occ is None and cost is None) or world == 1:
         base, rem = divmod(fy, world)
         b = [0]
         for r in range(world):
             b.append(b[-1] + base + (1 if r < rem else 0))
         return b
-    o = occ.detach().reshape(fy, int(fx)).float()
-    cost = (bg_weight * o.shape[1] + (1.0 - bg_weight) * (o > 0.5).float().sum(dim=1)).double().cpu()
-    cum = torch.cumsum(cost, 0)
+    if cost is None:
+        cost = row_cost(fy, fx, occ, bg_weight)
+    cum = torch.cumsum(cost.double().cpu(), 0)
     total = float(cum[-1])
     b = [0]
     for r in range(1, world):
@@ -101,6 +111,77 @@ def strip_bounds(fy, world, occ=None, fx=None, halo=HALO_ROWS, bg_weight=0.2):
         b.append(y)
     b.append(fy)
     return b
+
+
+class StripBalancer:
+    """Measured load balancing of the exact strip scheme over successive frames (round 5). The static model (foreground pixel = 1) leaves the slowest of eight
+    strips 15-25 % above the mean (profiles/r05_strip_table.txt): what a foreground pixel costs depends on what its rays meet. The strips' own render times say
+    where: every frame each rank times its strip (stream events, read at the start of the next frame: no extra synchronisation), the times are all-gathered (one
+    tiny collective per frame), and a per-row correction of the static model is scaled by (t_r / mean)^damping over strip r's rows. The next frame's boundaries are
+    the cost quantiles of model x correction, computed identically on every rank. Boundaries never change a pixel (the scheme is exact for any partition), so this
+    only moves time. The correction is tied to rows of the image, not to a view: it carries over to a similar next view and washes out (towards 1) otherwise."""
+
+    def __init__(self, fy, world, damping=1.0, bg_weight=BG_WEIGHT, smooth=0.02):
+        self.fy, self.world, self.damping, self.bg_weight, self.smooth = int(fy), int(world), float(damping), float(bg_weight), float(smooth)
+        self.corr = torch.ones(self.fy, dtype=torch.float64)
+        self.last_bounds = None
+        self.pending = None        # (start event, end event) of this rank's last strip render
+        self.history = []          # (bounds, times) per update: what the table in profiles/ is printed from
+
+    def cost(self, fx, occ):
+        return row_cost(self.fy, fx, occ, self.bg_weight) * self.corr
+
+    def bounds(self, fx, occ):
+        self.last_bounds = strip_bounds(self.fy, self.world, cost=self.cost(fx, occ))
+        return self.last_bounds
+
+    def update(self, times):
+        """`times`: this frame's strip render times of ALL ranks (any unit), in rank order; the same list on every rank."""
+        t = torch.tensor([float(x) for x in times], dtype=torch.float64)
+        if self.last_bounds is None or len(t) != self.world or not bool((t > 0).all()):
+            return
+        self.history.append((list(self.last_bounds), [float(x) for x in t]))
+        rel = (t / t.mean()) ** self.damping
+        for r in range(self.world):
+            self.corr[self.last_bounds[r]:self.last_bounds[r + 1]] *= rel[r]
+        self.corr /= self.corr.mean()
+        if self.smooth > 0:            # relax towards 1: a correction learnt on one view fades on views that do not confirm it
+            self.corr = self.corr ** (1.0 - self.smooth)
+
+    # ---- timing of this rank's strip and the exchange of the times
+    def start(self):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        self.pending = (e0, e1)
+
+    def stop(self):
+        if self.pending is not None:
+            self.pending[1].record()
+
+    def exchange(self, rank, group=None):
+        """Called at the start of a frame: last frame's strip time of every rank -> update(). Returns the gathered times (None on the first frame)."""
+        import torch.distributed as dist
+        if self.pending is None:
+            return None
+        e0, e1 = self.pending
+        e1.synchronize()
+        mine = e0.elapsed_time(e1)
+        self.pending = None
+        times = gather_times(mine, rank, self.world, group)
+        self.update(times)
+        return times
+
+
+def gather_times(mine, rank, world, group=None):
+    """One float per rank -> the list of all of them, in rank order, on every rank (the balancer's only collective: 8 bytes per rank and frame)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return [float(mine)]
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    buf = torch.zeros(int(world), dtype=torch.float64, device=dev)
+    buf[rank] = float(mine)
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    return [float(x) for x in buf.cpu()]
 
 
 def strip_rows(fy, rank, world, halo=HALO_ROWS, bounds=None):
@@ -190,7 +271,7 @@ def gather_rows(own, fy, fx, world, group=None, bounds=None):
 
 
 def render_strips(ctx_full, worker, mlp_mat, env_map, g, spp, random_offset, rank, world, denoise_iter=2, step_width=2, c_phi=2.0, n_phi=0.1, p_phi=0.001,
-                  use_scale=False, scale=(1.0, 1.0, 1.0), group=None, max_bounce=None, balanced=True, overlap=None):
+                  use_scale=False, scale=(1.0, 1.0, 1.0), group=None, max_bounce=None, balanced=True, overlap=None, balancer=None):
     """Exact multi-GPU frame: this rank renders its strip (all spp) with per-sample halo exchange, the raw sums are all-gathered by rows and
     finished on every rank. `g` is the full-frame G-buffer dict (harness.build_gbuffer); `ctx_full` a context of the full frame (finish only)."""
     from . import _lib
@@ -202,7 +283,11 @@ def render_strips(ctx_full, worker, mlp_mat, env_map, g, spp, random_offset, ran
         outs, _, _ = render_fused(ctx_full, worker, mlp_mat, use_scale, scale, env_map, g["occ"].clone(), g["normal"], g["depth"], g["kd"], g["rm"], g["ray_dir"],
                                   g["pos"], spp, denoise_iter, step_width, c_phi, n_phi, p_phi, random_offset)
         return outs
-    bounds = strip_bounds(fy, world, g["occ"] if balanced else None, fx)      # cost-balanced strip heights (same on every rank)
+    if balancer is not None:      # measured balancing: last frame's strip times of all ranks move this frame's boundaries (StripBalancer)
+        balancer.exchange(rank, group)
+        bounds = balancer.bounds(fx, g["occ"])
+    else:
+        bounds = strip_bounds(fy, world, g["occ"] if balanced else None, fx)      # cost-balanced strip heights by the static model (same on every rank)
     y0, y1, lo, hi = strip_rows(fy, rank, world, bounds=bounds)
     sl = slice(lo * fx, hi * fx)
     # Balanced strip heights follow the view's occupancy, so every camera would ask for a context (and a multi-GB batch pool) of its own height.
@@ -224,6 +309,17 @@ def render_strips(ctx_full, worker, mlp_mat, env_map, g, spp, random_offset, ran
 
     if overlap is None:      # MIRRES_STRIP_OVERLAP=1: exchange on a side stream behind the interior rows' spatial pass (mirres_render_args_t.strip_overlap)
         overlap = os.environ.get("MIRRES_STRIP_OVERLAP", "0") == "1"
+    if overlap and world > 1:
+        import torch.distributed as dist
+        if dist.get_backend(group) != "nccl":
+            # the exchange of any other backend is staged through the host and blocks (exchange_halos): nothing overlaps, and the split costs three more launches per
+            # sample and the fused temporal merge — run the in-line exchange instead and say so once
+            global _WARNED_OVERLAP
+            if not _WARNED_OVERLAP:
+                import warnings
+                warnings.warn("strip_overlap needs stream-ordered point-to-point transfers (backend nccl = RCCL); backend %r exchanges through the host: overlap ignored" % dist.get_backend(group))
+                _WARNED_OVERLAP = True
+            overlap = False
 
     def _halo(user, records, sample, stream):
         try:
@@ -235,8 +331,12 @@ def render_strips(ctx_full, worker, mlp_mat, env_map, g, spp, random_offset, ran
             print("[mirres] halo exchange failed:", e, file=sys.stderr)
             return 1
     cb = _lib.HALO_FN(_halo)
+    if balancer is not None:
+        balancer.start()
     sums, a, keep = render_fused(ctx_loc, worker, mlp_mat, use_scale, scale, env_map, loc["occ"], loc["normal"], loc["depth"], loc["kd"], loc["rm"], loc["ray_dir"],
                                  loc["pos"], spp, denoise_iter, step_width, c_phi, n_phi, p_phi, random_offset, strip=(fy, lo, y0 - lo, y1 - lo), halo=cb, strip_overlap=overlap)
+    if balancer is not None:
+        balancer.stop()
     own = [s_[(y0 - lo) * fx:(y1 - lo) * fx].contiguous() for s_ in sums]
     full = gather_rows(own, fy, fx, world, group, bounds)
     # replicated finish on the whole frame (average, EAW, composite)

@@ -29,11 +29,12 @@ def build(force=False):
 def build_ref(force=False):
     """oracle/_ref: the reference's own bilateral-denoiser kernels compiled by hipcc from /root/reference (oracle/Makefile `ref`). Only possible where the
     reference tree exists (the build container); the GPU box uses the prebuilt oracle/_ref/libref_denoise.so that travelled with the snapshot."""
-    if not os.path.isdir(os.environ.get("MIRRES_REF", "/root/reference")):
+    ref = os.environ.get("MIRRES_REF", "/root/reference")
+    if not os.path.isdir(ref):
         return None
     out = os.path.join(_HERE, "_ref", "libref_denoise.so")
     if force or not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(os.path.join(_HERE, "ref_denoise_driver.hip")):
-        subprocess.run(["make", "-C", _HERE, "ref"] + (["-B"] if force else []), check=True, capture_output=True)
+        subprocess.run(["make", "-C", _HERE, "ref", "REF=" + ref] + (["-B"] if force else []), check=True, capture_output=True, text=True)   # the tree the isdir test looked at
     return out
 
 

@@ -8,7 +8,10 @@ dist.render_strips would hand to rank r: own rows + halo rows + padding, no exch
 Also prints each strip's pixel counts and fits T_r = a + b * foreground px + c * background px over all strips of the mesh (a = per-sample fixed cost of a strip,
 c / b = what dist.strip_bounds calls bg_weight).
 
-    python scripts/dev_strip_table.py [spp=64] [reps=2] [bg_weight=default] [worlds=2,4,8]
+With iters > 1 the boundaries are then moved by dist.StripBalancer from the measured T_r (what the ranks of a real run exchange after every frame), `iters` times,
+and the last round is the table's second line per N.
+
+    python scripts/dev_strip_table.py [spp=64] [reps=2] [bg_weight=default] [worlds=2,4,8] [iters=1]
     MIRRES_MESH=clustered python scripts/dev_strip_table.py ..."""
 import os, sys, time, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
@@ -23,6 +26,7 @@ spp = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 bgw = None if len(sys.argv) <= 3 or sys.argv[3] == "default" else float(sys.argv[3])
 worlds = [int(x) for x in (sys.argv[4] if len(sys.argv) > 4 else "2,4,8").split(",")]
+iters = int(sys.argv[5]) if len(sys.argv) > 5 else 1
 EXCH_US = 44.0
 mesh = os.environ.get("MIRRES_MESH", "icosphere")
 dev = torch.device("cuda", 0)
@@ -53,7 +57,9 @@ occ2 = (g["occ"].reshape(fy, fx) > 0.5)
 rows_fit, table = [], {}
 kw = {} if bgw is None else {"bg_weight": bgw}
 for world in worlds:
-    bounds = D.strip_bounds(fy, world, g["occ"], fx, **kw)
+  bal = D.StripBalancer(fy, world, **kw)
+  for it in range(iters):
+    bounds = bal.bounds(fx, g["occ"])
     Ts = []
     for rank in range(world):
         y0, y1, lo, hi = D.strip_rows(fy, rank, world, bounds=bounds)
@@ -73,15 +79,20 @@ for world in worlds:
                             strip=(fy, lo, y0 - lo, y1 - lo), halo=cb)
         T = timed(strip)
         fgp = int(occ2[y0:y1].sum().item()); bgp = (y1 - y0) * fx - fgp
-        Ts.append(T); rows_fit.append((1.0, fgp, bgp, T))
-        print("  N=%d strip %d: own rows [%4d,%4d) = %4d, local %4d (padded %4d), fg px %7d, bg px %7d: %8.1f us per sample" % (world, rank, y0, y1, y1 - y0, rows, rows_pad, fgp, bgp, T))
+        Ts.append(T)
+        if it == 0:
+            rows_fit.append((1.0, fgp, bgp, T))
+        if it in (0, iters - 1):
+            print("  N=%d round %d strip %d: own rows [%4d,%4d) = %4d, local %4d (padded %4d), fg px %7d, bg px %7d: %8.1f us per sample" % (world, it, rank, y0, y1, y1 - y0, rows, rows_pad, fgp, bgp, T))
         del ctx, loc
+    bal.update(Ts)
     mx, mean = max(Ts), sum(Ts) / len(Ts)
     pred = T_full / (mx + EXCH_US)
-    table[world] = {"bounds": [int(b) for b in bounds], "T_us": [round(x, 1) for x in Ts], "max_over_mean": round(mx / mean, 3), "sum_over_full": round(sum(Ts) / T_full, 3),
+    table["%d/%s" % (world, "static model" if it == 0 else "after %d measured rounds" % it)] = {
+                    "bounds": [int(b) for b in bounds], "T_us": [round(x, 1) for x in Ts], "max_over_mean": round(mx / mean, 3), "sum_over_full": round(sum(Ts) / T_full, 3),
                     "predicted_speedup": round(pred, 2), "predicted_speedup_no_exchange": round(T_full / mx, 2), "ideal_balanced_speedup": round(T_full / (mean + EXCH_US), 2)}
-    print("N=%d: max %.1f, mean %.1f (max/mean %.3f), sum/full %.3f -> predicted speed-up %.2fx (%.2fx without exchange; %.2fx if perfectly balanced)" %
-          (world, mx, mean, mx / mean, sum(Ts) / T_full, pred, T_full / mx, T_full / (mean + EXCH_US)))
+    print("N=%d round %d: max %.1f, mean %.1f (max/mean %.3f), sum/full %.3f -> predicted speed-up %.2fx (%.2fx without exchange; %.2fx if perfectly balanced)" %
+          (world, it, mx, mean, mx / mean, sum(Ts) / T_full, pred, T_full / mx, T_full / (mean + EXCH_US)))
 A = np.array([r[:3] for r in rows_fit], dtype=np.float64); y = np.array([r[3] for r in rows_fit])
 coef, res, _, _ = np.linalg.lstsq(A, y, rcond=None)
 fit = A @ coef

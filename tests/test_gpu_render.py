@@ -365,8 +365,20 @@ def _strip_rank(rank, world, port, out):
     ctx = get_ctx(g["fx"], g["fy"])
     outs = D.render_strips(ctx, W, None, env, g, 3, 4321, rank, world)
     res = {"outs": [o.cpu() for o in outs]}
-    over = D.render_strips(ctx, W, None, env, g, 3, 4321, rank, world, overlap=True)      # the exchange on the engine's side stream, interior rows first
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")      # gloo stages the exchange through the host: dist.render_strips says so once and runs the in-line exchange
+        over = D.render_strips(ctx, W, None, env, g, 3, 4321, rank, world, overlap=True)      # RCCL: the exchange on the engine's side stream, interior rows first
     res["overlap"] = [o.cpu() for o in over]
+    # measured balancing (round 5): three frames whose boundaries move with the strips' own times — any partition must give the same bits
+    bal = D.StripBalancer(g["fy"], world)
+    res["balanced"], res["bounds"] = [], []
+    for frame in range(3):
+        if frame == 1:
+            bal.corr[:g["fy"] // 2] *= 3.0; bal.corr /= bal.corr.mean()      # (and a deliberately lopsided correction, so that the boundary really moves)
+        o = D.render_strips(ctx, W, None, env, g, 3, 4321, rank, world, balancer=bal)
+        res["balanced"].append([x.cpu() for x in o]); res["bounds"].append(list(bal.last_bounds))
+    res["history"] = len(bal.history)
     if rank == 0:
         ref = D.render_strips(ctx, W, None, env, g, 3, 4321, 0, 1)      # world == 1: the ordinary single-GPU frame
         res["ref"] = [o.cpu() for o in ref]
@@ -388,6 +400,10 @@ def test_two_rank_strip_render_equals_single_gpu(tmp_path):
         assert torch.equal(r0["outs"][k], r0["ref"][k]), "rank 0 buffer %d" % k
         assert torch.equal(r1["outs"][k], r0["ref"][k]), "rank 1 buffer %d" % k
         assert torch.equal(r0["overlap"][k], r0["ref"][k]) and torch.equal(r1["overlap"][k], r0["ref"][k]), "strip_overlap, buffer %d" % k
+        for frame in range(3):
+            assert torch.equal(r0["balanced"][frame][k], r0["ref"][k]) and torch.equal(r1["balanced"][frame][k], r0["ref"][k]), "balanced frame %d, buffer %d" % (frame, k)
+    assert r0["bounds"] == r1["bounds"] and len(set(tuple(b) for b in r0["bounds"])) >= 2, r0["bounds"]      # same partition on both ranks, and it moved
+    assert r0["history"] == 2 and r1["history"] == 2                                                       # frames 2 and 3 used the times of frames 1 and 2
 
 
 def test_fused_training_gradients_match_the_stepwise_loop(oracle, scene_mod, monkeypatch):

@@ -106,12 +106,56 @@ def test_strip_partition_and_halo_plan():
     b = D.strip_bounds(fy, 4, occ.reshape(-1, 1), fx)
     assert b[0] == 0 and b[-1] == fy and all(y1 - y0 >= 30 for y0, y1 in zip(b, b[1:]))
     assert b[1] - b[0] > b[4] - b[3]                                                      # cheap rows -> taller strip
-    cost = 0.2 * fx + 0.8 * occ.sum(1)
+    cost = D.BG_WEIGHT * fx + (1 - D.BG_WEIGHT) * occ.sum(1)
     per = [float(cost[y0:y1].sum()) for y0, y1 in zip(b, b[1:])]
     assert max(per) < 1.35 * min(per)
     assert D.strip_bounds(fy, 4) == [0, 100, 200, 300, 400]
     with pytest.raises(ValueError):
         D.strip_rows(100, 0, 8)                                                            # 12 rows per rank < 30-row halo
+
+
+def test_strip_balancer_converges_on_a_cost_the_static_model_does_not_know():
+    """dist.StripBalancer: strips timed by a synthetic truth (per-row foreground cost that varies by a factor of nine over the image + a fixed cost per strip, which the
+    multiplicative update does not model) — the slowest strip starts 40-50 % above the mean under the static model and is within 4 % after three updates, for 2, 4 and 8
+    ranks; boundaries stay legal partitions throughout; a rank list of the wrong length or with a zero is ignored."""
+    import torch
+    from mirres_restir_nerf_mesh_amd import dist as D
+    torch.manual_seed(0)
+    fy, fx = 1600, 400
+    y = torch.arange(fy, dtype=torch.float64)
+    occ = (((y[:, None] - 900).abs() < 500).float().expand(fy, fx) * (torch.rand(fy, fx) < 0.6)).float()
+    rowc = (occ > 0.5).double().sum(1) * (1.0 + 0.8 * torch.sin(y / 150)) * 4e-3
+    for world in (2, 4, 8):
+        B = D.StripBalancer(fy, world)
+        ratios = []
+        for it in range(6):
+            b = B.bounds(fx, occ.reshape(-1, 1))
+            assert b[0] == 0 and b[-1] == fy and all(y1 - y0 >= D.HALO_ROWS for y0, y1 in zip(b, b[1:]))
+            t = [60.0 + float(rowc[b[r]:b[r + 1]].sum()) for r in range(world)]
+            ratios.append(max(t) / (sum(t) / world))
+            B.update(t)
+        assert ratios[0] > 1.3 and max(ratios[3:]) < 1.04, ratios
+        before = B.corr.clone()
+        B.update(t[:-1]); B.update([0.0] * world)
+        assert torch.equal(before, B.corr)
+        assert len(B.history) == 6
+
+
+def _times_worker(rank, world, port, out):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mirres_restir_nerf_mesh_amd import dist as D
+    out[rank] = D.gather_times(10.0 + rank, rank, world)
+    dist.destroy_process_group()
+
+
+def test_strip_times_are_gathered_in_rank_order_gloo_world2():
+    import torch.multiprocessing as mp
+    mgr = mp.Manager(); out = mgr.dict()
+    mp.spawn(_times_worker, args=(2, 29600 + (os.getpid() % 200), out), nprocs=2, join=True)
+    assert out[0] == [10.0, 11.0] and out[1] == [10.0, 11.0]
 
 
 def _strip_worker(rank, world, port, out):
