@@ -10,8 +10,10 @@ denoise, composite) over a synthetic scene of BASELINE config 2's shape, with ev
 visibility, nvdiffrast's job in the reference) is built once outside the timed region.
 
 N > 1: the one frame is shared by the ranks (mirres-restir_nerf_mesh_amd/dist.py) — total work is fixed, i.e. STRONG scaling, as BASELINE's "at
-1/2/4/8 GPU" — and BOTH sharding schemes are timed in the same run: `value` = spp slices + one all-reduce (RCCL) of the accumulators, and the
-`strips` sub-record = the north-star's pixel split (row strips, per-sample reservoir halo exchange, all-gather of radiance rows; bit-identical to one GPU).
+1/2/4/8 GPU" — and BOTH sharding schemes are timed in the same run: `strips` = the north-star's pixel split (row strips, per-sample reservoir halo exchange,
+all-gather of radiance rows; bit-identical to one GPU; boundaries balanced from the strips' measured times) and `spp` = sample slices + one all-reduce (RCCL) of the
+accumulators (statistically equivalent frame). `value` is the exact scheme's when it wins or is within 2 %, otherwise the faster one's; `config.value_scheme` says
+which, and the other scheme is reported beside it with its ratio.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (traversal kernel, measured live with HIP events on the
 launch stream) and `cpu_baseline` (the CPU oracle on a bounded sample; rank 0, N=1 only).
@@ -87,6 +89,12 @@ def cpu_baseline(S, args):
                       "%.1f s of CPU work" % (fx, fy, spp, len(t), dt)}, frame
 
 
+MESH_WORDS = {"icosphere": "lego-SIZED synthetic mesh (noise-displaced icosphere + ground, 335 872 uniformly tessellated triangles: the mesh SURVEY 8d prescribes; BASELINE's TensoIR-lego has "
+                           "this triangle COUNT but not this uniformity)",
+              "clustered": "lego-LIKE synthetic mesh (brick assembly: studs, cavities, thin plates, 331 274 triangles with areas spread > 1e5 : 1 — the closer of the two to BASELINE's TensoIR-lego "
+                           "in what a ray meets: 100 vs 63 reference node visits per shadow ray, 63 % vs 22 % occluded)"}
+
+
 # MFMA roofline of the material MLP: the instruction the kernel issues decides the peak it is priced against (MI355X_MICROARCH.md)
 MLP_ROOF = {"bound": "mfma", "peak": 157.3, "instruction": "v_mfma_f32_32x32x2_f32 (fp32 in / fp32 accumulate: the reference's fp32 Linear layers as fmaf chains, bit for bit)",
             "note": "algorithmic flops (4 480 per point) / event-timed duration against the fp32 MFMA peak (157.3 TFLOP/s); the kernel issues 6 144 flop per point "
@@ -108,7 +116,7 @@ def pmc_snapshot():
     """Hardware-counter figures cannot be collected inside this process (rocprofv3 --pmc runs are separate, scripts/pmc_*.sh); the committed summaries are
     reported ONLY while they belong to the sources the library was built from (the snapshot records csrc_sha at collection time). Otherwise: stale, no numbers."""
     snap = {}
-    for fn_ in ("pmc_any4q_summary.json", "pmc_traffic.json"):
+    for fn_ in ("pmc_any4q_summary.json", "pmc_traffic.json", "pmc_chain_summary.json"):
         path = os.path.join(ROOT, "profiles", fn_)
         try:
             d = json.load(open(path))
@@ -120,7 +128,7 @@ def pmc_snapshot():
     out = {"csrc_sha_now": cur}
     for fn_, d in snap.items():
         fresh = d.get("csrc_sha") == cur
-        key = "counters" if "any4q" in fn_ else "traffic"
+        key = "counters" if "any4q" in fn_ else ("chain" if "chain" in fn_ else "traffic")
         if fresh:
             out[key] = dict({k: v for k, v in d.items() if not k.startswith("_")}, source="static:%s@%s" % (d["_file"], d.get("csrc_sha")))
         else:
@@ -173,7 +181,11 @@ def traversal_roofline(args, ctx, W, mlp, env, g, prof_spp, step_ms, world, pmc)
     # the snapshot holds one counter set per mesh (collected on that mesh's rays): report the one that belongs to THIS run's mesh
     cnt_mesh = cnt if args.mesh == "icosphere" else (cnt.get(args.mesh) or {})
     valu_busy = None if cnt.get("stale") else cnt_mesh.get("valu_busy")
-    traffic = None if trf.get("stale") else trf.get("k_trace_any_hbm_bytes_per_launch")
+    lane_util = None if cnt.get("stale") else cnt_mesh.get("lane_util")
+    trf_mesh = trf if args.mesh == "icosphere" else (trf.get(args.mesh) or {})
+    traffic = None if trf.get("stale") else trf_mesh.get("k_trace_any_hbm_bytes_per_launch")
+    chain = (pmc or {}).get("chain") or {}
+    chain_mesh = None if (chain.get("stale") or not chain) else (chain.get(args.mesh) or None)
     launch_s = sec_any / max(1, n_any)
     # which resource binds the kernel is read off the counters, not asserted: VALU pipes busy for most of the SIMD cycles while the HBM counters show a fraction of
     # the peak -> "valu-issue"; without a counter snapshot that belongs to the built sources the record says so
@@ -189,6 +201,9 @@ def traversal_roofline(args, ctx, W, mlp, env, g, prof_spp, step_ms, world, pmc)
             # figure from the snapshot below (null when the snapshot does not belong to the built sources); everything else in this record is measured in this run
             "achieved": (round(traffic / launch_s / 1e9, 1) if bound == "hbm" else valu_busy), "peak": (HBM if bound == "hbm" else 1.0),
             "unit": ("GB/s" if bound == "hbm" else "VALU-busy cycles per SIMD cycle"), "frac": (round(hbm_frac, 4) if bound == "hbm" else valu_busy),
+            # frac is a BUSY fraction (the SIMDs issue a VALU instruction in that share of the kernel's cycles); the share of the VALU roof that does useful lane work is
+            # busy x lane utilisation (SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU)): divergence between node and leaf lanes and idle lanes between refills are in it
+            "valu_useful": (round(valu_busy * lane_util, 4) if (valu_busy is not None and lane_util is not None) else None), "lane_util": lane_util,
             "traffic": traffic,
             "own_bytes": {"achieved": round(achieved, 2), "unit": "GB/s", "bytes_per_ray": round(own_bytes_any / max(1, rays_any), 1),
                           "l2_peak": L2, "l2_frac": round(achieved / L2, 5), "hbm_peak": HBM, "over_hbm_peak": round(achieved / HBM, 5),
@@ -196,7 +211,7 @@ def traversal_roofline(args, ctx, W, mlp, env, g, prof_spp, step_ms, world, pmc)
                                   "About 90 % of the requests are L1 hits: this is a request rate, NOT an HBM utilisation (it exceeds the HBM peak) — the DRAM side is hbm_counter"},
             "hbm_counter": ({"bytes_per_launch": traffic, "achieved": round(traffic / launch_s / 1e9, 1), "peak": HBM, "unit": "GB/s", "frac": round(traffic / launch_s / 1e9 / HBM, 4),
                              "over_own_bytes": round(traffic / (own_bytes_any / max(1, n_any)), 3),
-                             "note": "FETCH_SIZE + WRITE_SIZE per launch (snapshot, on the default workload) / this run's launch time"} if traffic and launch_s > 0 and args.mesh == "icosphere" else None),
+                             "note": "FETCH_SIZE + WRITE_SIZE per launch (snapshot, collected on THIS mesh) / this run's launch time"} if traffic and launch_s > 0 else None),
             "launch_ms": round(ms_any / max(1, n_any), 4), "launches": n_any,
             "rays_per_launch": round(rays_any / max(1, n_any)), "grays_per_s": round(rays_any / sec_any / 1e9, 3) if sec_any > 0 else 0.0,
             "pmc_snapshot": pmc,
@@ -213,7 +228,10 @@ def traversal_roofline(args, ctx, W, mlp, env, g, prof_spp, step_ms, world, pmc)
             # queue entries of the spatial pass that are answered without a traversal (light reservoir with luminance 0: the merge cannot see the answer; the reference
             # traces them). They ARE counted in rays_per_launch / grays_per_s / per_ray (as the one root-box test they cost); MIRRES_SKIP_DEAD=0 traces them
             "rays_not_traced_frac": round(own.get("any_dead", 0) / max(1, rays_any), 4),
-            "traversal_share_of_step": round((ms_any + ms_cl) / prof_spp * args.spp / step_ms * (world if world > 1 else 1), 3)}
+            "traversal_share_of_step": round((ms_any + ms_cl) / prof_spp * args.spp / step_ms * (world if world > 1 else 1), 3),
+            # the rest of the per-sample chain (k_spatial_gen, k_spatial_resolve) and the batched candidate loop (k_initial_gen): hardware counters of one serialised
+            # frame on this mesh (scripts/pmc_chain.sh; snapshot, csrc_sha-gated like the others) — which resource each of them is short of
+            "chain": chain_mesh}
     return roof
 
 
@@ -344,7 +362,13 @@ def main():
         dist.all_reduce(bad, op=dist.ReduceOp.MAX)
         if float(bad.item()) > 0:
             results[sc] = (None, err or "failed on another rank")
+    # Which scheme the line's `value` is: the EXACT one (row strips: the north-star's pixel split, bit-identical to one GPU) whenever it was timed and is at least
+    # within 2 % of the sample-slice scheme; otherwise the faster one. Both are timed the same way (W warm-up + K steps between barriers, max over ranks) and the
+    # other is reported beside it with its ratio, so the choice is visible in the line.
     primary = schemes[0]
+    if len(schemes) > 1 and results[schemes[1]][0] is not None:
+        d_spp, d_str = results["spp"][0], results["strips"][0]
+        primary = "strips" if d_str <= d_spp * 1.02 else "spp"
     dt, out = results[primary]
     value = samples / dt / 1e6
     step_ms = dt / args.steps * 1e3
@@ -380,15 +404,17 @@ def main():
         other = "clustered" if args.mesh == "icosphere" else "icosphere"
         try:
             t2, W2, mlp2, g2 = scene_for(other)
-            d2, o2 = timed("spp", make_step(W2, mlp2, g2), warmup=1, steps=1)
+            d2, o2 = timed("spp", make_step(W2, mlp2, g2))          # the same --steps / --warmup as the headline: a first-class number, not a one-frame aside
+            d2s = d2 / args.steps
             fg2 = float((g2["occ"][:, 0] > 0.5).float().mean().item())
-            rec = {"mesh": other, "triangles": int(len(t2)), "value": round(float(N) * args.spp / d2 / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(d2 * 1e3, 2), "steps": 1, "warmup": 1,
-                   "foreground_frac": round(fg2, 4), "foreground_msamples_per_s": round(float(N) * args.spp * fg2 / d2 / 1e6, 3), "finite": bool(torch.isfinite(o2[0]).all().item())}
+            rec = {"mesh": other, "workload": MESH_WORDS[other], "triangles": int(len(t2)), "value": round(float(N) * args.spp / d2s / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(d2s * 1e3, 2),
+                   "steps": args.steps, "warmup": args.warmup,
+                   "foreground_frac": round(fg2, 4), "foreground_msamples_per_s": round(float(N) * args.spp * fg2 / d2s / 1e6, 3), "finite": bool(torch.isfinite(o2[0]).all().item())}
             if not args.no_roofline:
                 args_o = argparse.Namespace(**vars(args)); args_o.mesh = other
-                r2 = traversal_roofline(args_o, ctx, W2, mlp2, env, g2, 8 if args.spp >= 8 else args.spp, d2 * 1e3, 1, None)
-                rec["traversal"] = {k: r2[k] for k in ("launch_ms", "launches", "rays_per_launch", "grays_per_s", "per_ray", "rays_per_pixel_sample", "private_stack_deepest", "rays_not_traced_frac", "traversal_share_of_step")}
-                rec["traversal"]["own_bytes_per_ray"] = r2["own_bytes"]["bytes_per_ray"]; rec["traversal"]["closest"] = r2["closest"]
+                r2 = traversal_roofline(args_o, ctx, W2, mlp2, env, g2, 8 if args.spp >= 8 else args.spp, d2s * 1e3, 1, pmc)
+                r2.pop("pmc_snapshot", None)                          # (printed once, in the headline's record)
+                rec["roofline"] = r2
             extras[other] = rec
             del W2, mlp2, g2
         except Exception as e_:      # noqa: BLE001 — a sub-record must not take the line with it
@@ -422,8 +448,7 @@ def main():
         fg_frac = float(fgm.float().mean().item())
         par = {"spp": "sample slices + one all-reduce of the six accumulators (statistically equivalent frame)",
                "strips": "row strips + per-sample reservoir halo exchange + all-gather of radiance rows (bit-identical to one GPU)"}
-        mesh_words = {"icosphere": "lego-SIZED synthetic mesh (noise-displaced icosphere + ground, uniformly tessellated: SURVEY 8d)",
-                      "clustered": "lego-LIKE synthetic mesh (brick assembly: studs, cavities, thin plates, triangle areas spread > 1e5 : 1)"}[args.mesh]
+        mesh_words = MESH_WORDS[args.mesh]
         line = {"metric": "Msamples/s (pixels x spp), ReSTIR-DI + %d-bounce path tracing forward render" % (args.bounces + 1),
                 "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(step_ms, 2), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
@@ -441,12 +466,22 @@ def main():
         line.update(extras)
         if parity_failed:
             line["parity_failed"] = parity_failed
-        for sc in schemes[1:]:            # the other sharding scheme, timed the same way in the same run
+        for sc in schemes:                # the other sharding scheme, timed the same way in the same run
+            if sc == primary:
+                continue
             d2, e2 = results[sc]
             if d2 is None:
                 line[sc] = {"value": None, "error": str(e2)[:300], "parallelism": "%s x%d" % (par[sc], world)}
                 continue
-            line[sc] = {"value": round(samples / d2 / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(d2 / args.steps * 1e3, 2), "parallelism": "%s x%d" % (par[sc], world)}
+            line[sc] = {"value": round(samples / d2 / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(d2 / args.steps * 1e3, 2), "parallelism": "%s x%d" % (par[sc], world),
+                        "bit_identical_to_one_gpu": sc == "strips", "ratio_to_value": round(dt / d2, 4)}
+        if world > 1:
+            line["config"]["value_scheme"] = primary
+            line["config"]["bit_identical_to_one_gpu"] = primary == "strips"
+            if balancer is not None and balancer.history:
+                b_, t_ = balancer.history[-1]
+                line["config"]["strip_balance"] = {"bounds": b_, "strip_ms": [round(x, 2) for x in t_], "max_over_mean": round(max(t_) / (sum(t_) / len(t_)), 4),
+                                                   "note": "last exchanged strip render times (dist.StripBalancer): boundaries follow them from frame to frame"}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -254,20 +254,21 @@ def exchange_halos(records, plan, group=None):
 
 
 def gather_rows(own, fy, fx, world, group=None, bounds=None):
-    """All-gather of row strips: `own` = list of [own rows * fx, C] tensors of this rank -> list of [fy * fx, C] tensors on every rank."""
+    """All-gather of row strips: `own` = list of [own rows * fx, C] tensors of this rank (same C, dtype) -> list of [fy * fx, C] tensors on every rank.
+    ONE collective for all buffers (round 5; rounds 1-4: a list all_gather + cat per buffer, two extra copies of each): the rank's buffers are stacked into one
+    [K, tallest strip * fx, C] block (strips differ in height: padded at the end), `all_gather_into_tensor` fills a [world, K, ...] block, and every output is
+    assembled from views of it with one `cat`."""
     import torch.distributed as dist
     b = bounds if bounds is not None else strip_bounds(fy, world)
     rows = [int(b[r + 1] - b[r]) for r in range(world)]
-    mx = max(rows)
-    out = []
-    for t in own:
-        c = t.shape[1]
-        pad = torch.zeros((mx * fx, c), dtype=t.dtype, device=t.device)
-        pad[:t.shape[0]] = t
-        parts = [torch.empty_like(pad) for _ in range(world)]
-        dist.all_gather(parts, pad, group=group)
-        out.append(torch.cat([parts[r][:rows[r] * fx] for r in range(world)], dim=0))
-    return out
+    mx, K, c = max(rows), len(own), own[0].shape[1]
+    send = torch.zeros((K, mx * fx, c), dtype=own[0].dtype, device=own[0].device)
+    for k, t in enumerate(own):
+        send[k, :t.shape[0]] = t
+    recv = torch.empty((world * K,) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)      # concatenation along dim 0: rank r's block = rows [r K, (r + 1) K)
+    dist.all_gather_into_tensor(recv, send, group=group)
+    recv = recv.view((world,) + tuple(send.shape))
+    return [torch.cat([recv[r, k, :rows[r] * fx] for r in range(world)], dim=0) for k in range(K)]
 
 
 def render_strips(ctx_full, worker, mlp_mat, env_map, g, spp, random_offset, rank, world, denoise_iter=2, step_width=2, c_phi=2.0, n_phi=0.1, p_phi=0.001,

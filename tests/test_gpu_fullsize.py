@@ -206,6 +206,80 @@ def test_configs4_shape_1024_8spp_three_bounces_matches_the_oracle(big, scene_mo
     _many_samples_vs_oracle(big, scene_mod, oracle, 1024, 1, 8, 3, 1123, "configs[4] shape 1024x1024 x 8 spp x 3 indirect bounces")
 
 
+def _relight_setup(big, scene_mod, tmp_path, res, ssaa):
+    """BASELINE configs[3]'s one-GPU workload: an EXTERNAL 1024 x 2048 Radiance .hdr map (written by harness.write_hdr, read back by harness.read_hdr as
+    `--envmap_path` does, nerf/network.py:136) and the relighting albedo scale (`use_scale`, renderer_restir.py:404-408; the caller scales the primary albedo,
+    nerf/renderer.py:1086-1089), material field at every vertex."""
+    v, t, W, RR, harness, torch = big
+    import os
+    from mirres_restir_nerf_mesh_amd.render_helper import MLPTexture3D
+    params, w0, w1, w2 = scene_mod.make_matnet_params(seed=0)
+    mn, mx = scene_mod.material_min_max()
+    mlp = MLPTexture3D(torch.tensor([-1, -1, -1, 1, 1, 1], dtype=torch.float32), channels=6, min_max=(torch.from_numpy(mn).cuda(), torch.from_numpy(mx).cuda()), seed=1)
+    with torch.no_grad():
+        mlp.encoder.params.copy_(torch.from_numpy(params).cuda())
+        for i, w in zip((0, 2, 4), (w0, w1, w2)):
+            mlp.net.net[i].weight.copy_(torch.from_numpy(w).cuda())
+    path = os.path.join(str(tmp_path), "bridge_like.hdr")
+    harness.write_hdr(path, scene_mod.make_env(1024, 2048, sun=400.0))      # three decades of dynamic range, as an outdoor map has
+    env_np = harness.read_hdr(path)
+    assert env_np.shape == (1024, 2048, 3) and env_np.dtype == np.float32 and float(env_np.max()) > 100 * float(np.median(env_np))
+    g = harness.build_gbuffer(W, res, res, ssaa, mlp_mat=mlp)
+    scale = (0.9, 0.8, 0.7)
+    kd = (g["kd"] * torch.tensor(scale, device="cuda")[None, :]).contiguous()
+    return mlp, env_np, g, kd, scale
+
+
+def test_configs3_relighting_800x800_8spp_matches_the_oracle(big, scene_mod, oracle, tmp_path):
+    """BASELINE configs[3] on one GPU under the driver's signature: 800 x 800 (ssaa 1), 8 spp, external 1024 x 2048 HDR map, `use_scale` on, material field, two
+    indirect bounces — every pixel of the six outputs BIT-EQUAL to the oracle's frame (~30 s of oracle).  (The builder-run 128-spp frame at ssaa 2:
+    profiles/r03_configs3_relight_parity.txt.)"""
+    v, t, W, RR, harness, torch = big
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from gen_reference_loop import matnet_for
+    from mirres_restir_nerf_mesh_amd._ops import get_ctx
+    mlp, env_np, g, kd, scale = _relight_setup(big, scene_mod, tmp_path, 800, 1)
+    mat, keep, _ = matnet_for(oracle, scene_mod)
+    ctx = get_ctx(g["fx"], g["fy"])
+    outs, _, _ = RR.render_fused(ctx, W, mlp, True, scale, torch.from_numpy(env_np).cuda(), g["occ"].clone(), g["normal"], g["depth"], kd, g["rm"], g["ray_dir"], g["pos"],
+                                 8, 2, 2, 2.0, 0.1, 0.001, 2468)
+    c = lambda x: x.detach().cpu().numpy()
+    info, aabb, _, _ = oracle.bvh_build(v, t)
+    ref = oracle.render(g["fx"], g["fy"], 8, 2468, (info, aabb), v, t, env_np, c(g["occ"])[:, 0], c(g["normal"]), c(g["depth"])[:, 0], c(kd), c(g["rm"]), c(g["ray_dir"]),
+                        c(g["pos"]), mat=mat, use_scale=True, scale=scale)
+    assert np.abs(ref["indirect"]).max() > 0
+    for o_, n_ in zip(outs, ["final_color", "diffuse", "spec", "indirect", "indirect_diff", "indirect_spec"]):
+        pixel_parity(c(o_), ref[n_], "configs[3] relighting 800x800 x 8 spp, 1024x2048 HDR map, albedo scale / " + n_, tol=0.0)
+    # the scale is live: without it the indirect buffer differs
+    plain, _, _ = RR.render_fused(ctx, W, mlp, False, (1, 1, 1), torch.from_numpy(env_np).cuda(), g["occ"].clone(), g["normal"], g["depth"], kd, g["rm"], g["ray_dir"], g["pos"],
+                                  8, 2, 2, 2.0, 0.1, 0.001, 2468)
+    assert not torch.equal(plain[3], outs[3]) and torch.equal(plain[1], outs[1])      # ... and the direct light buffers do not know about it
+
+
+def test_configs3_relighting_512spp_properties(big, scene_mod, tmp_path):
+    """configs[3] at its full sample count on one GPU: 800 x 800 output, ssaa 2 (1600 x 1600 internal), 512 spp, external 1024 x 2048 HDR map, albedo scale, field.
+    No oracle run at this size: finite, background := 1, non-negative radiance, the same seed reproduces the frame bit for bit, a darker albedo scale darkens the
+    indirect buffer and leaves the direct light buffers alone."""
+    v, t, W, RR, harness, torch = big
+    from mirres_restir_nerf_mesh_amd._ops import get_ctx
+    mlp, env_np, g, kd, scale = _relight_setup(big, scene_mod, tmp_path, 800, 2)
+    env = torch.from_numpy(env_np).cuda()
+    ctx = get_ctx(g["fx"], g["fy"])
+    def frame(sc, spp):
+        outs, _, _ = RR.render_fused(ctx, W, mlp, True, sc, env, g["occ"].clone(), g["normal"], g["depth"], kd, g["rm"], g["ray_dir"], g["pos"], spp, 2, 2, 2.0, 0.1, 0.001, 1357)
+        torch.cuda.synchronize()
+        return [o.clone() for o in outs]
+    a = frame(scale, 512)
+    fg = g["occ"][:, 0] > 0.5
+    assert a[0].shape == (1600 * 1600, 3) and all(torch.isfinite(o).all() for o in a) and (a[0][~fg] == 1.0).all() and all((o >= 0).all() for o in a[1:])
+    b = frame(scale, 512)
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    dark = frame((0.45, 0.4, 0.35), 512)
+    assert torch.equal(dark[1], a[1]) and torch.equal(dark[2], a[2])
+    assert float(dark[3][fg].mean()) < 0.8 * float(a[3][fg].mean())
+
+
 def test_schedule_does_not_change_the_frame_at_full_size(big, scene_mod, monkeypatch):
     """The frame loop's scheduling choices — K samples per batched launch, the stages spread over 1 to 5 streams — must not change a single bit
     of any output: 1600 x 1600, 6 samples, K = 1 on one stream against K = 4 / 3 / 2 (ragged batches, uneven path-tracing halves) on 2 .. 5 streams."""

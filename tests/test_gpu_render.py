@@ -360,7 +360,7 @@ def _strip_rank(rank, world, port, out):
     S = M.scene
     v, t = S.make_mesh(3, 8)
     W = RR.restirbvhWorker(torch.from_numpy(v).cuda(), torch.from_numpy(t).cuda()); W.update_mesh(W.vrt, W.v_ind)
-    g = harness.build_gbuffer(W, 64, 128, 1)
+    g = harness.build_gbuffer(W, 96, 128, 1)          # 96 rows: the boundary between two strips of at least 30 rows has room to move (measured balancing below)
     env = torch.from_numpy(S.make_env(16, 32)).cuda()
     ctx = get_ctx(g["fx"], g["fy"])
     outs = D.render_strips(ctx, W, None, env, g, 3, 4321, rank, world)
@@ -375,7 +375,7 @@ def _strip_rank(rank, world, port, out):
     res["balanced"], res["bounds"] = [], []
     for frame in range(3):
         if frame == 1:
-            bal.corr[:g["fy"] // 2] *= 3.0; bal.corr /= bal.corr.mean()      # (and a deliberately lopsided correction, so that the boundary really moves)
+            bal.corr[g["fy"] // 2:] *= 6.0; bal.corr /= bal.corr.mean()      # (and a deliberately lopsided correction, so that the boundary really moves)
         o = D.render_strips(ctx, W, None, env, g, 3, 4321, rank, world, balancer=bal)
         res["balanced"].append([x.cpu() for x in o]); res["bounds"].append(list(bal.last_bounds))
     res["history"] = len(bal.history)
