@@ -75,7 +75,9 @@ int mirres_neighbor_offsets(mirres_ctx_t* ctx, float* out, void* stream);
  * ordered closest-hit kernel handed to the reference-order kernel (instrument bit 0), [11] private-stack overflows of the
  * shadow-ray kernel (always counted; provably 0, bvh_trace.hip MR_ANY_STACK), [12] shadow rays of the spatial pass that were
  * not traced because the merge cannot see their answer (light reservoir with luminance 0; instrument bit 0; they are
- * included in rays_any), [13..15] reserved (0).                                                                           */
+ * included in rays_any), [13..15] shadow-ray kernel, instrument bit 0: wave iterations, wave iterations that ran the leaf
+ * branch, leaf records fetched (how often a wave pays for the leaf branch and for how many lanes: bench.py roofline.leaf_branch).
+ * A private-stack overflow also sets a sticky flag that makes mirres_render / mirres_bvh_trace return MIRRES_E_STATE afterwards.   */
 int mirres_ctx_stats(mirres_ctx_t* ctx, uint64_t* h_out, int reset);
 /* instrument bit 0: traversal kernels count visited nodes into the stats (slower kernels); bit 1: every traversal launch is
  * bracketed by HIP events on its own stream so that mirres_ctx_trace_time can report per-kernel durations; bit 2 (with bit 0):

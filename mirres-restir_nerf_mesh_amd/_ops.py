@@ -55,7 +55,8 @@ class Context:
         check(lib().mirres_ctx_stats(self.h, out, int(reset)), "mirres_ctx_stats")
         v = list(out)
         return dict(rays_any=v[0], rays_closest=v[1], popped=v[2], entered=v[3], leaves=v[4], cl_popped=v[5], cl_entered=v[6], cl_leaves=v[7],
-                    any_max_stack=v[8], cl_max_stack=v[9], cl_redo=v[10], any_stack_overflow=v[11], any_dead=v[12])
+                    any_max_stack=v[8], cl_max_stack=v[9], cl_redo=v[10], any_stack_overflow=v[11], any_dead=v[12],
+                    any_wave_iters=v[13], any_wave_leaf_iters=v[14], any_leaf_visits=v[15])      # shadow-ray kernel, counting mode: wave iterations, those that ran the leaf branch, leaf records fetched
 
     def trace_time(self):
         """(ms_any, launches_any, ms_closest, launches_closest) of the event-timed traversal launches since the last call."""

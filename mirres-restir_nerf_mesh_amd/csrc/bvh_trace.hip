@@ -428,6 +428,13 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_persist(BvhView B, con
 static_assert(MR_ANY_STACK >= 3 * (MR_SAH_LEVELS + (38 - MR_SAH_PREFIX) + 31), "MR_ANY_STACK must cover the deepest private hierarchy (DESIGN.md, stack bounds)");
 static_assert(MR_ANY_LDS >= 3 && MR_ANY_LDS <= MR_ANY_STACK, "the LDS part of the private stack holds at least one node's deferred references");
 #define MR_TOPBIT 0x20000000
+#ifndef MR_CL_SORTNET
+#define MR_CL_SORTNET 1     // ordered closest hit: children sorted by a 5-comparator network (0: the insertion of rounds 1-4)
+#endif
+#ifndef MR_ANY_PARK
+#define MR_ANY_PARK 0      // experiment: leaves wait for a wave-wide leaf round once this many lanes hold one (0 = off: every lane tests its leaf at once)
+#endif
+#define MR_NOCUR 0x7ffffffe   // MR_ANY_PARK: the lane has no node to go on with (only a parked leaf)
 // ---------------------------------------------------------------- shadow rays on the COMPRESSED 4-wide collapse (engine.hpp Node4q / LeafRec)
 // The any-hit bit is the OR over leaves whose own box passes the slab test (above); interior boxes only steer the search and may be any
 // supersets. Node4q stores them as 8-bit outward-rounded offsets (64 B per visit = 4 dwordx4 gathers instead of 8 — the kernel is bound by
@@ -548,6 +555,10 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const
     int cur = 0, sp = 0, sbase = 0; uint32_t ridx = 0;   // the lane's deferred entries live in [sbase, sp)
     uint32_t spill[MR_ANY_STACK - MR_ANY_LDS];
     unsigned long long c_boxes = 0, c_nodes = 0, c_leaves = 0; int c_maxsp = 0;
+    unsigned long long w_iters = 0, w_leaf_iters = 0, w_leaf_lanes = 0;      // COUNT: wave iterations, those that ran the leaf branch, leaf visits (wave-uniform; lane 0 reports)
+#if MR_ANY_PARK
+    int parked = 0;                                   // a leaf reference (< 0) waiting for the wave's next leaf round; 0 = none
+#endif
     MR_PH(long long ph_refill = 0; long long ph_mem = 0; long long ph_cmp = 0; long long ph_iters = 0; const long long ph_begin = MR_PH_NOW();)
     while (true) {
         MR_PH(const long long ph_a = MR_PH_NOW();)
@@ -577,6 +588,9 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const
                     t_min = s_tmin; t_max = s_tmax; ridx = s_ridx;
                     cur = (int)lds[s_base * MR_TRACE_BLOCK + ((threadIdx.x & ~63) | src)];
                     sp = 0; sbase = 0; have = true;
+#if MR_ANY_PARK
+                    parked = 0;
+#endif
                 }
                 if (give) sbase++;
             }
@@ -611,6 +625,9 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const
                       if (dx == 0.f) dx = 0.000001f; if (dy == 0.f) dy = 0.000001f; if (dz == 0.f) dz = 0.000001f;
                       ix = 1.0f / dx; iy = 1.0f / dy; iz = 1.0f / dz; }
                     sp = 0; sbase = 0;
+#if MR_ANY_PARK
+                    parked = 0;
+#endif
                     rc = ray_margins(scene_bs, ox, oy, oz, ix, iy, iz);
                     hit_out[idx] = 0;          // set to 1 by whichever lane finds an occluder (the owner or, in the tail, a helper)
                     const float o3[3] = {ox, oy, oz}, i3[3] = {ix, iy, iz};
@@ -626,16 +643,37 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const
         if (!__ballot(have)) { if (exhausted) break; else continue; }
         do {
             MR_PH(const long long ph_0 = MR_PH_NOW(); long long ph_1 = ph_0; ph_iters++;)
-            if (have) {
+            int ref = cur; bool active = have;
+#if MR_ANY_PARK
+            // Experiment (round 5; -DMR_ANY_PARK=<threshold>): a lane that reaches a leaf does not test it at once. From the counters, a lane is at a
+            // leaf in 5 % (icosphere) / 12 % (lego-like) of its iterations, so with ~50 busy lanes nearly every wave iteration runs the leaf branch (exact slab +
+            // Moller-Trumbore, ~70 instructions) for two or three lanes beside the node branch (~120): a third of the kernel's VALU instructions at 4 % lane
+            // utilisation. Here the lane PARKS the leaf (one reference) and goes on with its next deferred subtree; the wave runs a leaf round when MR_ANY_PARK lanes
+            // hold one, or when a lane cannot go on without its answer (nothing else left, or a second leaf). The answer is an OR over leaves: no bit changes; what it
+            // costs is the traversal an occluded ray does between parking the leaf that would have ended it and the round that tests it.
+            {
+                if (have && cur < 0 && parked == 0) {
+                    parked = cur;
+                    if (sp > sbase) { --sp; cur = (int)((sp < MR_ANY_LDS) ? lds_stack[sp * MR_TRACE_BLOCK] : spill[sp - MR_ANY_LDS]); } else cur = MR_NOCUR;
+                }
+                const bool p_has = have && parked != 0;
+                const bool wants = p_has && (cur < 0 || cur == MR_NOCUR);
+                const bool round = __popcll(__ballot(p_has)) >= MR_ANY_PARK || __ballot(wants) != 0;
+                if (round && p_has) ref = parked;
+                else { ref = cur; active = have && cur >= 0 && cur != MR_NOCUR; }
+            }
+#endif
+            if (COUNT) { const uint64_t lm = __ballot(active && ref < 0); w_iters++; if (lm) { w_leaf_iters++; w_leaf_lanes += (unsigned long long)__popcll(lm); } }
+            if (active) {
                 // one 64-byte record per iteration — a Node4q or a LeafRec — fetched before the type is looked at, so that a wave pays ONE memory
                 // round trip per iteration however its lanes split between nodes and leaves (the slowest lane sets the wave's pace)
                 uint4 h0, h1, h2, rf;
-                const bool leaf = cur < 0;
-                if (TOPN > 0 && !leaf && (cur & MR_TOPBIT)) {
-                    const uint4* nd = s_top + (size_t)(cur & 0xffff) * 4;
+                const bool leaf = ref < 0;
+                if (TOPN > 0 && !leaf && (ref & MR_TOPBIT)) {
+                    const uint4* nd = s_top + (size_t)(ref & 0xffff) * 4;
                     h0 = nd[0]; h1 = nd[1]; h2 = nd[2]; rf = nd[3];
                 } else {
-                    const uint4* __restrict__ nd = leaf ? reinterpret_cast<const uint4*>(B.leaves + ~cur) : reinterpret_cast<const uint4*>(B.nodes4q + cur);
+                    const uint4* __restrict__ nd = leaf ? reinterpret_cast<const uint4*>(B.leaves + ~ref) : reinterpret_cast<const uint4*>(B.nodes4q + ref);
                     h0 = nd[0]; h1 = nd[1]; h2 = nd[2]; rf = nd[3];
                     if (COUNT) c_nodes++;    // 64-byte records fetched from global memory (nodes served from LDS are not charged)
                 }
@@ -707,11 +745,18 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const
                     }
                 }
                 bool done = hit;
+#if MR_ANY_PARK
+                if (leaf) { parked = 0; if (!hit) done = cur == MR_NOCUR; }      // (a second leaf in `cur` is parked at the top of the next iteration)
+                else if (next != 0x7fffffff) cur = next;
+                else if (sp > sbase) { --sp; cur = (int)((sp < MR_ANY_LDS) ? lds_stack[sp * MR_TRACE_BLOCK] : spill[sp - MR_ANY_LDS]); }
+                else { cur = MR_NOCUR; done = parked == 0; }
+#else
                 if (!hit) {
                     if (next != 0x7fffffff) cur = next;
                     else if (sp > sbase) { --sp; cur = (int)((sp < MR_ANY_LDS) ? lds_stack[sp * MR_TRACE_BLOCK] : spill[sp - MR_ANY_LDS]); }
                     else done = true;
                 }
+#endif
                 if (COUNT) c_maxsp = sp > c_maxsp ? sp : c_maxsp;
                 if (done) { have = false; if (hit) hit_out[ridx] = 1; }
             }
@@ -724,7 +769,8 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const
 #endif
     MR_PH(if (B.dbg && (threadIdx.x & 63) == 0) { unsigned long long* o = B.dbg + 5 * (blockIdx.x * (MR_TRACE_BLOCK / 64) + (threadIdx.x >> 6));
             o[0] = (unsigned long long)(MR_PH_NOW() - ph_begin); o[1] = (unsigned long long)ph_refill; o[2] = (unsigned long long)ph_mem; o[3] = (unsigned long long)ph_cmp; o[4] = (unsigned long long)ph_iters; })
-    if (COUNT && stats) { atomicAdd(&stats[2], c_boxes); atomicAdd(&stats[3], c_nodes); atomicAdd(&stats[4], c_leaves); atomicMax(&stats[8], (unsigned long long)c_maxsp); }
+    if (COUNT && stats) { atomicAdd(&stats[2], c_boxes); atomicAdd(&stats[3], c_nodes); atomicAdd(&stats[4], c_leaves); atomicMax(&stats[8], (unsigned long long)c_maxsp);
+                          if (lane == 0) { atomicAdd(&stats[13], w_iters); atomicAdd(&stats[14], w_leaf_iters); atomicAdd(&stats[15], w_leaf_lanes); } }
     if (stats && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[0], (unsigned long long)n);
 }
 
@@ -877,6 +923,35 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_closest4(BvhView B, co
                         const int ref[4] = {(int)rf.x, (int)rf.y, (int)rf.z, (int)rf.w};
                         float tn4[4], tf4[4];
                         child_slabs(nc, t_min, tn4, tf4);
+#if MR_CL_SORTNET
+                        // children that may still hold something nearer, nearest first: a five-comparator sorting network over (entry distance, reference), a child that
+                        // cannot matter carrying +inf (round 5; rounds 1-4 inserted one child after the other into a sorted list: sixteen predicated swaps of which the
+                        // compiler keeps all — the node branch of this kernel was nearly twice the shadow-ray kernel's). Any order gives the same minimum (see above).
+                        float sk[4]; int sr[4]; int nn = 0;
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const bool ok = tf4[k] > tn4[k] && closest > tn4[k];   // unused slots: see k_trace_any4q
+                            if (COUNT && ref[k] != ~B.T) c_boxes++;
+                            sk[k] = ok ? tn4[k] : __builtin_inff(); sr[k] = ref[k]; nn += ok ? 1 : 0;
+                        }
+#define MR_CX(a, b) { const bool sw_ = sk[b] < sk[a]; const float ka_ = sw_ ? sk[b] : sk[a], kb_ = sw_ ? sk[a] : sk[b]; const int ra_ = sw_ ? sr[b] : sr[a], rb_ = sw_ ? sr[a] : sr[b]; sk[a] = ka_; sk[b] = kb_; sr[a] = ra_; sr[b] = rb_; }
+                        MR_CX(0, 1) MR_CX(2, 3) MR_CX(0, 2) MR_CX(1, 3) MR_CX(1, 2)
+#undef MR_CX
+                        cur = NONE;
+                        if (nn > 0) {
+                            cur = sr[0];
+#pragma unroll
+                            for (int q = 3; q >= 1; q--) {      // farthest first: the nearest deferred child is popped first
+                                if (q < nn) {
+                                    uint2 e; e.x = (uint32_t)sr[q]; e.y = __float_as_uint(sk[q]);
+                                    if (sp < MR_LDS_STACK) lds_stack[sp * MR_TRACE_BLOCK] = e;
+                                    else if (sp < MR_STACK) spill[sp - MR_LDS_STACK] = e;
+                                    if (sp < MR_STACK) sp++; else need_redo = true;   // a full stack hands the ray to the reference-order kernel, whose stack cannot overflow
+                                }
+                            }
+                            if (COUNT) c_maxsp = sp > c_maxsp ? sp : c_maxsp;
+                        }
+#else
                         // children that may still hold something nearer, kept in descending entry distance (n <= 4)
                         int nref[4]; float ntn[4]; int nn = 0;
 #pragma unroll
@@ -906,6 +981,7 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_closest4(BvhView B, co
                             }
                             if (COUNT) c_maxsp = sp > c_maxsp ? sp : c_maxsp;
                         }
+#endif
                     }
                 }
                 if (done) { have = false; fin = true; }
