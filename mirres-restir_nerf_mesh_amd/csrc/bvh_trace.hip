@@ -222,6 +222,9 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_closest(BvhView B, con
 // are still traversing, idle lanes pull the next rays of the chunk with pure ballot/popcount arithmetic (no atomics). Per-ray
 // arithmetic and visit order are exactly those of traverse<>, so results are bit-identical to the simple kernels.
 #define MR_CHUNK_MAX 1024
+#ifndef MR_CHUNK_DIV
+#define MR_CHUNK_DIV 4      // chunks per launched wave: a chunk is n / (waves x MR_CHUNK_DIV) rays, at least 64
+#endif
 #ifndef MR_REFILL
 #define MR_REFILL 40
 #endif
@@ -278,7 +281,7 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_persist(BvhView B, con
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const int NONE = 0x40000000;
     // chunk size: ~4 chunks per resident wave so that the tail balances, 64..1024 rays (one global atomic per chunk)
-    uint32_t chunk = n / (gridDim.x * (MR_TRACE_BLOCK / 64) * 4);
+    uint32_t chunk = n / (gridDim.x * (MR_TRACE_BLOCK / 64) * MR_CHUNK_DIV);
     chunk = chunk < 64 ? 64 : (chunk > MR_CHUNK_MAX ? MR_CHUNK_MAX : (chunk & ~63u));
     const uint32_t q_per = (((n + MR_NQ - 1) / MR_NQ) + 63u) & ~63u;                                  // rays per sub-queue
     uint32_t q_cur = (blockIdx.x * (MR_TRACE_BLOCK / 64) + (threadIdx.x >> 6)) % MR_NQ, q_fail = 0;   // wave-uniform
@@ -428,6 +431,15 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_persist(BvhView B, con
 static_assert(MR_ANY_STACK >= 3 * (MR_SAH_LEVELS + (38 - MR_SAH_PREFIX) + 31), "MR_ANY_STACK must cover the deepest private hierarchy (DESIGN.md, stack bounds)");
 static_assert(MR_ANY_LDS >= 3 && MR_ANY_LDS <= MR_ANY_STACK, "the LDS part of the private stack holds at least one node's deferred references");
 #define MR_TOPBIT 0x20000000
+#ifndef MR_CL_FASTPUSH
+#define MR_CL_FASTPUSH 1
+#endif
+#ifndef MR_CL_REFILL
+#define MR_CL_REFILL MR_REFILL
+#endif
+#ifndef MR_CL_POP1
+#define MR_CL_POP1 1        // ordered closest hit: deferred entries popped per iteration (0: until one survives, the loop of rounds 1-4; 1: one; 2: two looked at together)
+#endif
 #ifndef MR_CL_SORTNET
 #define MR_CL_SORTNET 1     // ordered closest hit: children sorted by a 5-comparator network (0: the insertion of rounds 1-4)
 #endif
@@ -541,7 +553,7 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const
     const uint32_t n = d_count ? *d_count : n_fixed;
     const int lane = lane_id();
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    uint32_t chunk = n / (gridDim.x * (MR_TRACE_BLOCK / 64) * 4);
+    uint32_t chunk = n / (gridDim.x * (MR_TRACE_BLOCK / 64) * MR_CHUNK_DIV);
     chunk = chunk < 64 ? 64 : (chunk > MR_CHUNK_MAX ? MR_CHUNK_MAX : (chunk & ~63u));
     const uint32_t q_per = (((n + MR_NQ - 1) / MR_NQ) + 63u) & ~63u;                                  // rays per sub-queue
     uint32_t q_cur = (blockIdx.x * (MR_TRACE_BLOCK / 64) + (threadIdx.x >> 6)) % MR_NQ, q_fail = 0;   // wave-uniform
@@ -808,7 +820,7 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_closest4(BvhView B, co
     const uint32_t n = d_count ? *d_count : n_fixed;
     const int lane = lane_id();
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    uint32_t chunk = n / (gridDim.x * (MR_TRACE_BLOCK / 64) * 4);
+    uint32_t chunk = n / (gridDim.x * (MR_TRACE_BLOCK / 64) * MR_CHUNK_DIV);
     chunk = chunk < 64 ? 64 : (chunk > MR_CHUNK_MAX ? MR_CHUNK_MAX : (chunk & ~63u));
     const uint32_t q_per = (((n + MR_NQ - 1) / MR_NQ) + 63u) & ~63u;                                  // rays per sub-queue
     uint32_t q_cur = (blockIdx.x * (MR_TRACE_BLOCK / 64) + (threadIdx.x >> 6)) % MR_NQ, q_fail = 0;   // wave-uniform
@@ -854,9 +866,32 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_closest4(BvhView B, co
         if (!__ballot(have)) { if (exhausted) break; else continue; }
         do {
             if (have) {
-                bool done = false;
+                bool done = false, skip = false;
                 if (cur == NONE) {   // pop the nearest deferred subtree that still beats `closest`
                     bool found = false;
+#if MR_CL_POP1 == 2   // two entries looked at per iteration (both LDS reads in flight together): the first that survives is taken
+                    if (sp > 0) {
+                        const int s1 = sp - 1, s2 = sp > 1 ? sp - 2 : 0;
+                        const uint2 e1 = (s1 < MR_LDS_STACK) ? lds_stack[s1 * MR_TRACE_BLOCK] : spill[s1 - MR_LDS_STACK];
+                        const uint2 e2 = (s2 < MR_LDS_STACK) ? lds_stack[s2 * MR_TRACE_BLOCK] : spill[s2 - MR_LDS_STACK];
+                        const float t1 = __uint_as_float(e1.y), t2 = __uint_as_float(e2.y);
+                        found = true;
+                        if (closest > t1) { cur = (int)e1.x; sp = s1; }
+                        else {
+                            if (closest == t1 && any_hit) need_redo = true;
+                            if (sp > 1 && closest > t2) { cur = (int)e2.x; sp = s2; }
+                            else { if (sp > 1 && closest == t2 && any_hit) need_redo = true; sp = sp > 1 ? s2 : s1; skip = true; }
+                        }
+                    }
+#elif MR_CL_POP1   // at most one pop per iteration: a culled entry costs this lane an iteration instead of making the whole wave wait for the longest run of culled entries
+                    if (sp > 0) {
+                        --sp;
+                        const uint2 e = (sp < MR_LDS_STACK) ? lds_stack[sp * MR_TRACE_BLOCK] : spill[sp - MR_LDS_STACK];
+                        const float etn = __uint_as_float(e.y);
+                        if (closest > etn) { cur = (int)e.x; found = true; }
+                        else { if (closest == etn && any_hit) need_redo = true; found = true; skip = true; }
+                    }
+#else
                     while (sp > 0) {
                         --sp;
                         const uint2 e = (sp < MR_LDS_STACK) ? lds_stack[sp * MR_TRACE_BLOCK] : spill[sp - MR_LDS_STACK];
@@ -864,9 +899,10 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_closest4(BvhView B, co
                         if (closest > etn) { cur = (int)e.x; found = true; break; }
                         if (closest == etn && any_hit) need_redo = true;   // culled on equality: a tie the reference's order could resolve differently
                     }
+#endif
                     if (!found) done = true;
                 }
-                if (!done) {
+                if (!done && !skip) {
                     const bool leaf = cur < 0;
                     const uint4* __restrict__ nd = leaf ? reinterpret_cast<const uint4*>(B.leaves + ~cur) : reinterpret_cast<const uint4*>(B.nodes4q + cur);
                     const uint4 h0 = nd[0], h1 = nd[1], h2 = nd[2], rf = nd[3];
@@ -940,6 +976,12 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_closest4(BvhView B, co
                         cur = NONE;
                         if (nn > 0) {
                             cur = sr[0];
+                            if (MR_CL_FASTPUSH && sp + 3 <= MR_LDS_STACK) {      // all three possible entries fit the LDS part (the usual case): no per-entry range checks
+#pragma unroll
+                                for (int q = 3; q >= 1; q--) {
+                                    if (q < nn) { uint2 e; e.x = (uint32_t)sr[q]; e.y = __float_as_uint(sk[q]); lds_stack[sp * MR_TRACE_BLOCK] = e; sp++; }
+                                }
+                            } else {
 #pragma unroll
                             for (int q = 3; q >= 1; q--) {      // farthest first: the nearest deferred child is popped first
                                 if (q < nn) {
@@ -948,6 +990,7 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_closest4(BvhView B, co
                                     else if (sp < MR_STACK) spill[sp - MR_LDS_STACK] = e;
                                     if (sp < MR_STACK) sp++; else need_redo = true;   // a full stack hands the ray to the reference-order kernel, whose stack cannot overflow
                                 }
+                            }
                             }
                             if (COUNT) c_maxsp = sp > c_maxsp ? sp : c_maxsp;
                         }
@@ -986,7 +1029,7 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_closest4(BvhView B, co
                 }
                 if (done) { have = false; fin = true; }
             }
-        } while (__popcll(__ballot(have)) >= MR_REFILL || (exhausted && __ballot(have)));
+        } while (__popcll(__ballot(have)) >= MR_CL_REFILL || (exhausted && __ballot(have)));
         if (fin) {   // results of the rays that finished in this stretch, written by all of them together
             fin = false;
             if (need_redo) redo[atomicAdd(redo_count, 1u)] = ridx;
