@@ -542,6 +542,9 @@ __global__ void __launch_bounds__(MR_SGEN_BLOCK / MR_SGEN_PX) k_spatial_gen(mirr
     }
 }
 
+#ifndef MR_SRES_HIT2
+#define MR_SRES_HIT2 1
+#endif
 #ifndef MR_SRES_WAVES
 #define MR_SRES_WAVES 0      // experiment: waves per SIMD the register allocator must make room for (0 = its own choice: 140 VGPRs, three waves)
 #endif
@@ -555,8 +558,9 @@ __global__ void __launch_bounds__(MR_SGEN_BLOCK / MR_SGEN_PX) k_spatial_gen(mirr
 template <int MR_MAX_NB>
 MR_DEV bool spatial_pixel(const mirres_config_t& C, const EnvD& E, const GBufD& G, const ResD& PR, const float* __restrict__ noff, uint32_t frameIndex, int fx, int y_off,
                           const float* __restrict__ occ_own, const int32_t* __restrict__ slot, const uint32_t* __restrict__ mask_in, const int32_t* __restrict__ hit,
-                          int pi, Ris& s) {
+                          int pi, Ris& s, GPix* gc_out = nullptr) {
     const GPix gc = load_gpix(G, pi);
+    if (gc_out) *gc_out = gc;          // (the fused temporal merge needs the same record: a second load_gpix after the reservoir store could not be merged with this one)
     if ((occ_own ? occ_own[pi] : gc.occ) < 0.1f) return false;
     const int x = pi % fx, y = pi / fx;
     uint32_t sg = seed_generator((uint32_t)x, (uint32_t)(y + y_off), frameIndex);
@@ -593,7 +597,12 @@ MR_DEV bool spatial_pixel(const mirres_config_t& C, const EnvD& E, const GBufD& 
         ++validNeighbors;
         const v3 ndir = oct_decode(V2(nbr.light_data.y, nbr.light_data.z));
         const float nlum = sample_lum(E, nbr, ndir);
+#if MR_SRES_HIT2   // the two answers of a pair are neighbours in the hit array and a pixel's first slot is even: one 8-byte load instead of two 4-byte ones
+        const int2 hh = reinterpret_cast<const int2*>(hit)[hs >> 1];
+        const float canonicalVis = hh.x ? 0.f : 1.f, candidateVis = hh.y ? 0.f : 1.f;
+#else
         const float canonicalVis = hit[hs] ? 0.f : 1.f, candidateVis = hit[hs + 1] ? 0.f : 1.f;
+#endif
         hs += 2;
         // streamingResampleStepMisUnbiased (res.slang:173-213)
         float candTarget = target_lum(nctx, nlum, ndir);
@@ -643,8 +652,8 @@ __global__ void MR_SRES_ATTR __launch_bounds__(MR_SRES_TILE * MR_SRES_TILE) k_sp
     }
     const int pi = tile_pixel(fx, fy, MR_SRES_TILE, N);
     if (pi >= N || !row_in(rows, pi, fx)) return;
-    Ris s;
-    const bool fg = spatial_pixel<MR_MAX_NB>(C, E, G, PR, noff, frameIndex, fx, y_off, occ_own, slot, mask_in, hit, pi, s);
+    Ris s; GPix gc;
+    const bool fg = spatial_pixel<MR_MAX_NB>(C, E, G, PR, noff, frameIndex, fx, y_off, occ_own, slot, mask_in, hit, pi, s, &gc);
     if (!fg) { store_zero(R, pi); return; }
     store_ris(R, pi, s);
     if (FUSE) {
@@ -653,7 +662,7 @@ __global__ void MR_SRES_ATTR __launch_bounds__(MR_SRES_TILE * MR_SRES_TILE) k_sp
         int ppx, ppy;
         if (!temporal_history_pixel(x, y, 0.f, 0.f, fx, fy, sg, ppx, ppy)) return;
         const int qi = ppy * fx + ppx;
-        GPix gc = load_gpix(G, pi); if (occ_own) gc.occ = occ_own[pi];
+        if (occ_own) gc.occ = occ_own[pi];
         GPix gq = gc; ResV prev;
         if (qi == pi) prev = stored_res(s, true);
         else {

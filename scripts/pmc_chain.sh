@@ -16,6 +16,9 @@ SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ
 SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_INSTS_FLAT SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAVES
 GRBM_GUI_ACTIVE TA_TA_BUSY_sum
 TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum
+TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum
+TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_PENDING_STALL_CYCLES_sum
+TCP_TCR_TCP_STALL_CYCLES_sum TCP_TCP_LATENCY_sum
 SQ_INSTS_VMEM_WR SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_FLAT SQ_INST_LEVEL_VMEM
 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_TRANS_F32
 FETCH_SIZE
@@ -50,6 +53,14 @@ for k, cs in agg.items():
         d['wait_inst_of_wave_cycles'] = d.get('SQ_WAIT_INST_ANY', 0) / d['SQ_WAVE_CYCLES']
     if d.get('TCP_TOTAL_CACHE_ACCESSES_sum'):
         d['l1_hit'] = 1.0 - d.get('TCP_TCC_READ_REQ_sum', 0) / d['TCP_TOTAL_CACHE_ACCESSES_sum']
+    if g:
+        cyc = g / 8.0
+        if 'TA_TA_BUSY_sum' in d: d['ta_busy'] = d['TA_TA_BUSY_sum'] / (256.0 * cyc)
+        if 'TCP_PENDING_STALL_CYCLES_sum' in d: d['tcp_pending_stall'] = d['TCP_PENDING_STALL_CYCLES_sum'] / (256.0 * cyc)
+        if 'TCP_TCR_TCP_STALL_CYCLES_sum' in d: d['tcp_tcr_stall'] = d['TCP_TCR_TCP_STALL_CYCLES_sum'] / (256.0 * cyc)
+        if 'TA_ADDR_STALLED_BY_TC_CYCLES_sum' in d: d['ta_addr_stalled_by_tc'] = d['TA_ADDR_STALLED_BY_TC_CYCLES_sum'] / (256.0 * cyc)
+    if d.get('TCP_TCC_READ_REQ_sum') and d.get('TCP_TCP_LATENCY_sum'):
+        d['l1_miss_latency_cycles'] = d['TCP_TCP_LATENCY_sum'] / d['TCP_TCC_READ_REQ_sum']
     if d.get('SQ_WAVES') and d.get('SQ_INSTS_VALU') is not None:
         d['valu_insts_per_wave'] = d['SQ_INSTS_VALU'] / d['SQ_WAVES']
     if 'FETCH_SIZE' in d:
@@ -57,7 +68,7 @@ for k, cs in agg.items():
     res[k] = d
 json.dump({'mesh': mesh, 'spp': spp, 'command': 'MIRRES_STREAMS=1 rocprofv3 --pmc <set> -- python3 bench.py --mesh %s --spp %d --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-extras' % (mesh, spp), 'kernels': res},
           open(out + '/summary.json', 'w'), indent=1)
-keys = ['_launches', 'kernel_cycles', 'valu_busy', 'lane_util', 'wait_any_of_wave_cycles', 'wait_inst_of_wave_cycles', 'l1_hit', 'valu_insts_per_wave', '_vgpr', '_scratch', 'hbm_bytes_per_launch_fetch2x_plus_write']
+keys = ['_launches', 'kernel_cycles', 'valu_busy', 'lane_util', 'wait_any_of_wave_cycles', 'l1_hit', 'ta_busy', 'tcp_pending_stall', 'tcp_tcr_stall', 'l1_miss_latency_cycles', 'valu_insts_per_wave', '_vgpr', 'hbm_bytes_per_launch_fetch2x_plus_write']
 print('%-48s ' % 'kernel' + ' '.join('%12s' % k[:12] for k in keys))
 for k in sorted(res, key=lambda k: -(res[k].get('kernel_cycles', 0) * res[k]['_launches'])):
     print('%-48s ' % k + ' '.join('%12.4g' % res[k].get(c, float('nan')) for c in keys))
