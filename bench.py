@@ -232,6 +232,14 @@ def traversal_roofline(args, ctx, W, mlp, env, g, prof_spp, step_ms, world, pmc)
             # the rest of the per-sample chain (k_spatial_gen, k_spatial_resolve) and the batched candidate loop (k_initial_gen): hardware counters of one serialised
             # frame on this mesh (scripts/pmc_chain.sh; snapshot, csrc_sha-gated like the others) — which resource each of them is short of
             "chain": chain_mesh}
+    # the STEP against the VALU-issue roof (round 5): wave64 VALU instructions of one sample (counter snapshot of a serialised frame on this mesh) / what 1024 SIMDs can
+    # issue in this run's time per sample at one instruction per 4 cycles and the 2.4 GHz peak clock — the frame's own roofline fraction; a snapshot figure over a live time
+    smp = (chain_mesh or {}).get("_sample") if chain_mesh else None
+    if smp and step_ms > 0:
+        per_sample_s = step_ms * 1e-3 / args.spp * (world if world > 1 else 1)
+        roof["frame_valu_issue"] = {"wave_insts_per_sample": smp["valu_wave_insts_per_sample"], "peak_wave_insts_per_s": 1024 * 2.4e9 / 4,
+                                    "frac": round(smp["valu_wave_insts_per_sample"] / (1024 * 2.4e9 / 4) / per_sample_s, 4),
+                                    "note": "whole-frame VALU-issue utilisation: (VALU wave-instructions per sample, PMC snapshot) / (614.4 G per second x this run's time per sample)"}
     return roof
 
 

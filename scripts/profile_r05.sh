@@ -76,6 +76,13 @@ for mesh in ("icosphere", "clustered"):
                       "l1_hit": round(x.get('l1_hit', 0), 4), "valu_insts_per_wave": round(x.get('valu_insts_per_wave', 0)), "waves": round(x.get('SQ_WAVES', 0)),
                       "vgpr": round(x.get('_vgpr', 0)), "hbm_bytes_per_launch": round(x.get('hbm_bytes_per_launch_fetch2x_plus_write', 0)),
                       "hbm_frac_of_8TBps": round(x.get('hbm_bytes_per_launch_fetch2x_plus_write', 0) / max(us, 1e-9) / 1e6 / 8.0, 4)}
+    # the whole sample against the VALU-issue roof: wave-instructions of every kernel launched once per sample or per batch (per-frame kernels — denoiser, LBVH
+    # build, G-buffer, environment tables — left out: they vanish at 512 spp), per sample of the 8-spp frame
+    per_frame = ('k_eaw', 'k_matnet_fwd', 'k_trace_persist', 'k_sah', 'k_refit', 'k_rs_', 'k_env_', 'k_neighbor', 'k_morton', 'k_elements', 'k_hierarchy', 'k_pack', 'k_emc', 'k_flip', 'k_own_occ',
+                 'k_init_extent', 'k_gbuf', 'k_finish', 'k_average', 'k_composite', 'k_normal_ao', 'k_light_tables')
+    tot = sum(x['SQ_INSTS_VALU'] * x['_launches'] for k, x in d.items() if 'SQ_INSTS_VALU' in x and not k.startswith(per_frame))
+    rec['_sample'] = {"valu_wave_insts_per_sample": round(tot / 8.0), "spp_of_the_profiled_frame": 8,
+                      "note": "sum over the per-sample / per-batch kernels of SQ_INSTS_VALU x launches / 8; the VALU-issue roof is 1024 SIMDs x clock / 4 cycles per wave64 instruction"}
     chain[mesh] = rec
     anyk = [k for k in d if k.startswith('k_trace_any4q<false')]
     tot = sum(d[k].get('hbm_bytes_per_launch_fetch2x_plus_write', 0) * d[k]['_launches'] for k in anyk); n = sum(d[k]['_launches'] for k in anyk)
