@@ -135,6 +135,10 @@ def _frame_vs_oracle(lego, scene_mod, oracle, res, ssaa, spp, seed, what, bounce
         pixel_parity(c(o_), ref[n_], "%s (counted kernels) / %s" % (what, n_), tol=0.0)
         pixel_parity(c(o2), ref[n_], "%s / %s" % (what, n_), tol=0.0)
     assert st["any_stack_overflow"] == 0 and st["any_max_stack"] < 64 and st["cl_max_stack"] < 64
+    # the wave-level counters of the shadow-ray kernel (round 5, stats [13..15]) are consistent with the per-lane ones: a wave iteration fetches at most 64 records and
+    # at least one; a leaf visit is a record; every exact-box pass (triangle test) is a leaf visit; the leaf branch never runs more often than there are leaf visits
+    it, lit, lv = st["any_wave_iters"], st["any_wave_leaf_iters"], st["any_leaf_visits"]
+    assert 0 < lit <= it and it <= st["entered"] <= 64 * it and st["leaves"] <= lv <= st["entered"] and lit <= lv <= 64 * lit, (it, lit, lv, st["entered"], st["leaves"])
     _report("%s: rays any %d closest %d; production visits per shadow ray: boxes %.1f records %.2f leaves %.2f; deepest private stack: shadow %d, ordered closest %d; "
             "ordered closest rays handed to the reference-order kernel: %d (%.4f %%)" % (what, st["rays_any"], st["rays_closest"], st["popped"] / max(1, st["rays_any"]),
             st["entered"] / max(1, st["rays_any"]), st["leaves"] / max(1, st["rays_any"]), st["any_max_stack"], st["cl_max_stack"], st["cl_redo"], 100.0 * st["cl_redo"] / max(1, st["rays_closest"])))
