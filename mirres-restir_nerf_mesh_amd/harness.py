@@ -149,14 +149,15 @@ def build_gbuffer_from_pose(worker, pose, intrinsics, H, W, ssaa=1, mlp_mat=None
 
 
 def test_view(worker, mlp_mat, env_map, pose, intrinsics, H, W, spp, ssaa=1, random_offset=0, de=2, c=2.0, n=0.1, p=0.001, max_bounce=None,
-              albedo_scale=None, shard=None, rank=0, world=1, group=None, return_maps=False):
+              albedo_scale=None, shard=None, rank=0, world=1, group=None, return_maps=False, balancer=None):
     """One `--test --spp N` frame of the BRDF branch (Trainer.test_step -> render_stage1(is_test=True), nerf/renderer.py:1083-1129, 1162-1164,
     1208-1209, 1265-1302): G-buffer for the dataset camera, the fused frame (mirres_render), tone curve, alpha, SSAA down-scale, white background.
     Returns the [H, W, 3] image in [0, 1]; with `return_maps` also the dict of float maps that Trainer.test saves as EXR files (meters.write_test_maps).
     Relighting (`--envmap_path`, :1025-1026, 1086-1089, 1109-1111): pass the external map as `env_map` and `albedo_scale` = (--albedo_scale_x, _y,
     _z): the primary albedo is scaled here and `use_scale` does the same at the indirect hits.
     One view on several GPUs: `shard` = "strips" (exact row strips + halo exchange + all-gather of radiance rows, dist.render_strips) or "spp"
-    (sample slices + all-reduce, dist.render_sharded) with this process's `rank` of `world`; every rank returns the whole image."""
+    (sample slices + all-reduce, dist.render_sharded) with this process's `rank` of `world`; every rank returns the whole image. `balancer`: a
+    dist.StripBalancer kept by the caller across the views of a run — strip boundaries then follow the strips' measured times (same pixels for any boundaries)."""
     from . import renderer_restir as RR
     from . import dist as MD
     from ._ops import get_ctx
@@ -167,7 +168,7 @@ def test_view(worker, mlp_mat, env_map, pose, intrinsics, H, W, spp, ssaa=1, ran
         g["kd"] = (g["kd"] * torch.tensor(scale, dtype=torch.float32, device=g["kd"].device)[None, :]).contiguous()      # :1086-1089
     ctx = get_ctx(g["fx"], g["fy"]) if max_bounce is None else get_ctx(g["fx"], g["fy"], max_bounce=max_bounce)
     if world > 1 and shard == "strips":
-        out = MD.render_strips(ctx, worker, mlp_mat, env_map, g, spp, random_offset, rank, world, de, 2 ** (de - 1), c, n, p, use_scale, scale, group, max_bounce)
+        out = MD.render_strips(ctx, worker, mlp_mat, env_map, g, spp, random_offset, rank, world, de, 2 ** (de - 1), c, n, p, use_scale, scale, group, max_bounce, balancer=balancer)
     elif world > 1 and shard == "spp":
         out = MD.render_sharded(ctx, worker, mlp_mat, env_map, g, spp, random_offset, rank, world, de, 2 ** (de - 1), c, n, p, use_scale, scale, group)
     else:

@@ -25,7 +25,7 @@ import argparse, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import numpy as np, torch
 import mirres_restir_nerf_mesh_amd as M
-from mirres_restir_nerf_mesh_amd import renderer_restir as RR, harness, checkpoint as CK, meters
+from mirres_restir_nerf_mesh_amd import renderer_restir as RR, harness, checkpoint as CK, meters, dist as MD
 from mirres_restir_nerf_mesh_amd.render_helper import MLPTexture3D
 
 
@@ -121,6 +121,8 @@ def main():
         get_ctx(Ww * a.ssaa, Hh * a.ssaa).reserve()
     t_render = 0.0
     n_mine = 0
+    # exact strip sharding: the boundaries follow the strips' measured times from view to view (a test set's cameras move smoothly; same pixels for any boundaries)
+    balancer = MD.StripBalancer(Hh * a.ssaa, world) if (world > 1 and a.shard == "strips") else None
     for i, fr in enumerate(frames):
         if world > 1 and a.shard == "views" and i % world != rank:
             continue
@@ -128,7 +130,7 @@ def main():
         pose = nerf_pose(fr["transform_matrix"], a.scale, a.offset)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         img = harness.test_view(W, mlp, light, torch.from_numpy(pose), intr, Hh, Ww, a.spp, a.ssaa, random_offset=i * 7919, albedo_scale=albedo_scale,
-                                shard=a.shard if world > 1 and a.shard != "views" else None, rank=rank, world=world, return_maps=a.save_maps)
+                                shard=a.shard if world > 1 and a.shard != "views" else None, rank=rank, world=world, return_maps=a.save_maps, balancer=balancer)
         maps = None
         if a.save_maps:
             img, maps = img
