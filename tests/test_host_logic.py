@@ -66,7 +66,11 @@ def _worker(rank, world, port, out):
     g = torch.Generator().manual_seed(100 + rank)
     sums = [torch.rand(50, 3, generator=g) * (spp_slice(10, rank, world)[1] - spp_slice(10, rank, world)[0]) for _ in range(6)]
     red = allreduce_sums([s.clone() for s in sums])
-    torch.save(dict(local=sums, red=red), os.path.join(out, "r%d.pt" % rank))
+    # foreground-only exchange: background rows are zero on every rank (here: rows 10..29) and stay exactly zero; the others get the same sums
+    occ = torch.ones(50); occ[10:30] = 0
+    masked = [s.clone() * occ[:, None] for s in sums]
+    red_fg = allreduce_sums([m.clone() for m in masked], occ=occ)
+    torch.save(dict(local=sums, red=red, masked=masked, red_fg=red_fg), os.path.join(out, "r%d.pt" % rank))
     dist.destroy_process_group()
 
 
@@ -81,6 +85,8 @@ def test_allreduce_exchange_gloo_world2(tmp_path):
         expect = r0["local"][k] + r1["local"][k]
         assert torch.allclose(r0["red"][k], expect) and torch.allclose(r1["red"][k], expect)
         assert r0["red"][k].shape == (50, 3)
+        want = r0["masked"][k] + r1["masked"][k]
+        assert torch.equal(r0["red_fg"][k], want) and torch.equal(r1["red_fg"][k], want) and float(r0["red_fg"][k][10:30].abs().max()) == 0.0
 
 
 def test_strip_partition_and_halo_plan():
