@@ -60,6 +60,8 @@ int mirres_bvh_build(mirres_bvh_t* bvh, const float* vert, int V, const int32_t*
  *         result could depend on the visiting order (t <= 0 hits, exact ties); may grow an internal n-entry buffer on first use.
  * mode 3: occlusion as a conventional ray tracer answers it — some triangle is hit IN FRONT of the origin (t > 0); only `hit` is written.
  *         This is what nerf/render_dump.py:batch_intersector (:8-27) asks of the external `intersector` (intersects_closest(...)[0]).
+ * mode 4: closest hit as a conventional ray tracer answers it — the nearest triangle met at t_min < t <= t_max (outputs as mode 1; no counters). The
+ *         reference has no such query (its bvh_hit accepts triangles behind the origin); mirres_rasterize casts its near-plane rays with it.
  * counters u32[n,4] (popped, entered-internal, leaves-tested, stack-overflow) may be NULL.                   */
 int mirres_bvh_trace(mirres_bvh_t* bvh, const float* rays, int n, int mode, int32_t* hit, float* t, float* pos, float* normal,
                      int32_t* prim, uint32_t* counters, void* stream);
@@ -189,7 +191,7 @@ int mirres_raster_raycast(mirres_bvh_t* bvh, const float* rays, int n, const flo
  * world-space point with x_c = y_c = w_c = 0 (the eye: every pixel's line passes through it).  Pixel (ix, iy) of the W x H
  * image looks along NDC ((2 ix + 1) / W - 1, (2 iy + 1) / H - 1); its world-space line is cast through the BVH (the world-space vert / tri it was built
  * from).  rast f32[H*W,4] = (u, v, z/w, triangle_id + 1) with perspective-correct barycentrics (weights of v0, v1) and the clip-space depth of the hit;
- * rast_db f32[H*W,4] = (du/dX, du/dY, dv/dX, dv/dY) per pixel, or NULL.  Hits behind the near plane or beyond the far plane give an empty record.   */
+ * rast_db f32[H*W,4] = (du/dX, du/dY, dv/dX, dv/dY) per pixel, or NULL.  The ray starts on the near plane (what lies in front of it is clipped away and hides nothing); hits beyond the far plane give an empty record.   */
 int mirres_rasterize(mirres_bvh_t* bvh, const float* vert, const int32_t* tri, const float* h_mvp, const float* h_eye, int W, int H,
                      float* rast, float* rast_db, void* stream);
 int mirres_interpolate(const float* attr, int C, const float* rast, const int32_t* tri, int n, float* out, void* stream);

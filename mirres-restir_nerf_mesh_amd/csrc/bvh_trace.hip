@@ -268,7 +268,7 @@ MR_DEV bool grab_chunk(uint32_t* __restrict__ heads, uint32_t n, uint32_t per, u
     return false;
 }
 
-template <bool ANY>
+template <bool ANY, bool FRONT = false>   // FRONT: a conventional closest hit — only triangles met in (t_min, t_max] count (mirres_bvh_trace mode 4; the reference's own rule is FRONT = false)
 __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_persist(BvhView B, const Ray* __restrict__ rays, const uint32_t* __restrict__ d_count,
                                                                   uint32_t n_fixed, uint32_t* __restrict__ work_head, int32_t* __restrict__ hit_out,
                                                                   HitRec* __restrict__ rec, float* __restrict__ t_out, float* __restrict__ pos_out,
@@ -370,13 +370,15 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_persist(BvhView B, con
                                 const v3 Q = cross(Tv, E1);
                                 const float v = dot(d, Q) * invDet;
                                 if (!(v < 0 || u + v > 1)) {
-                                    any_hit = true;
-                                    if (ANY) done = true;
+                                    if (ANY) { any_hit = true; done = true; }
                                     else {
                                         const float t = dot(E2, Q) * invDet;
-                                        closest = fminf(t, closest);
-                                        if (t <= closest) { best_u = u; best_v = v; best_slot = slot; }
-                                        best_t = closest;
+                                        if (!FRONT || (t > t_min && t <= closest)) {
+                                            any_hit = true;
+                                            closest = fminf(t, closest);
+                                            if (t <= closest) { best_u = u; best_v = v; best_slot = slot; }
+                                            best_t = closest;
+                                        }
                                     }
                                 }
                             }
@@ -1194,7 +1196,7 @@ using namespace mr;
 
 extern "C" int mirres_bvh_trace(mirres_bvh_t* bvh, const float* rays, int n, int mode, int32_t* hit, float* t, float* pos, float* normal,
                                 int32_t* prim, uint32_t* counters, void* stream) {
-    if (!bvh || !rays || n < 0 || mode < 0 || mode > 3) { set_error("mirres_bvh_trace: bad argument"); return MIRRES_E_ARG; }
+    if (!bvh || !rays || n < 0 || mode < 0 || mode > 4) { set_error("mirres_bvh_trace: bad argument"); return MIRRES_E_ARG; }
     if (bvh->T < 2) { set_error("mirres_bvh_trace: BVH not built"); return MIRRES_E_STATE; }
     if (int e = bvh_sticky_error(bvh, "mirres_bvh_trace")) return e;
     if (n == 0) return MIRRES_OK;
@@ -1205,6 +1207,14 @@ extern "C" int mirres_bvh_trace(mirres_bvh_t* bvh, const float* rays, int n, int
     if (mode == 3) {
         if (!hit) { set_error("mirres_bvh_trace: occlusion needs hit[]"); return MIRRES_E_ARG; }
         return trace_any_front_queue(bvh, r, nullptr, (size_t)n, hit, s);
+    }
+    if (mode == 4) {
+        if (counters) { set_error("mirres_bvh_trace: mode 4 has no per-ray counters"); return MIRRES_E_ARG; }
+        MR_HIP(hipMemsetAsync(bvh->work + 3 * MR_WSET, 0, MR_WSET * sizeof(uint32_t), s));
+        k_trace_persist<false, true><<<persist_grid((size_t)n), MR_TRACE_BLOCK, 0, s>>>(bvh->view(), r, nullptr, (uint32_t)n, bvh->work + 3 * MR_WSET, hit, nullptr, t, pos, normal,
+                                                                                       prim, nullptr);
+        MR_LAUNCH_CHECK("mirres_bvh_trace");
+        return MIRRES_OK;
     }
     if (mode == 0) {
         if (!hit) { set_error("mirres_bvh_trace: any-hit needs hit[]"); return MIRRES_E_ARG; }

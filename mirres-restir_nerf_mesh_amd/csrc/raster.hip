@@ -40,8 +40,10 @@ __global__ void __launch_bounds__(MR_BLOCK) k_rast_record(int n, const float* __
 // Pixel (ix, iy) looks along the line NDC (x, y) = ((2 ix + 1) / W - 1, (2 iy + 1) / H - 1): its world-space pre-image, a line through the eye, is the
 // primary ray, cast through the path's BVH (world space: no second hierarchy over projected
 // vertices).  Record: perspective-correct barycentrics (u, v) = weights of v0, v1 — the world-space barycentrics of the hit —, z / w of the hit in clip
-// space (nvdiffrast's third channel), triangle id + 1.  rast_db = (du/dX, du/dY, dv/dX, dv/dY) per pixel step, central differences of the same
-// barycentrics on the hit triangle's plane half a pixel to either side (second-order accurate; nvdiffrast differentiates analytically).
+// space (nvdiffrast's third channel), triangle id + 1.  The ray starts where the pixel's line crosses the near plane (z_c = -w_c), so a triangle that crosses
+// the near plane shows its part beyond it and hides nothing with the part in front — what clipping does for a point-sampled rasteriser; hits beyond the far
+// plane give an empty record.  rast_db = (du/dX, du/dY, dv/dX, dv/dY) per pixel step, analytic: the pixel's direction is affine in NDC (x, y) and the
+// barycentrics on the hit triangle's plane are ratios of linear forms of the direction (rounds 1-4: central differences half a pixel to either side).
 struct Mat4 { float m[16]; };   // row-major
 MR_DEV void mul4(const Mat4& M, float x, float y, float z, float w, float o[4]) {
 #pragma unroll
@@ -51,18 +53,30 @@ MR_DEV void mul4(const Mat4& M, float x, float y, float z, float w, float o[4]) 
 // through the eye (the point where x_c = y_c = w_c = 0, solved on the host in double precision); the direction is the cross product of their normals, turned
 // towards increasing w.  The z row — ill-conditioned for far / near = 2 10^4, and through the inverse matrix it would spoil the directions too — enters the z / w
 // output only.  `eye` travels in Mat4::m[12..14] of the second argument, rows x, y, w in m[0..11].
-MR_DEV void pixel_ray(const Mat4& R, float px, float py, int W, int H, v3& o, v3& d) {
+MR_DEV void pixel_ray(const Mat4& R, float px, float py, int W, int H, v3& o, v3& d, float* sign = nullptr) {
     const float x = (2.f * px) / W - 1.f, y = (2.f * py) / H - 1.f;
     const v3 rx = V3(R.m[0], R.m[1], R.m[2]), ry = V3(R.m[4], R.m[5], R.m[6]), rw = V3(R.m[8], R.m[9], R.m[10]);
     const v3 n1 = rx - rw * x, n2 = ry - rw * y;
     d = cross(n1, n2);
-    if (dot(rw, d) < 0.f) d = -d;
+    const bool flip = dot(rw, d) < 0.f;
+    if (flip) d = -d;
+    if (sign) *sign = flip ? -1.f : 1.f;
     o = V3(R.m[12], R.m[13], R.m[14]);
 }
-__global__ void __launch_bounds__(MR_BLOCK) k_rast_rays(Mat4 R, int W, int H, float* __restrict__ rays) {
+// Where the line o + s d enters the clip volume through the near plane: (z_c + w_c)(P) = (row_z + row_w) . (P, 1) grows along a ray that looks into the
+// scene and vanishes on the near plane.  The origin moves there when that point lies in front of the eye; a matrix whose z row does not behave like a
+// projection's (z_c + w_c not growing along the ray) leaves the ray at the eye.
+MR_DEV v3 near_start(const Mat4& M, v3 o, v3 d) {
+    const v3 nz = V3(M.m[8] + M.m[12], M.m[9] + M.m[13], M.m[10] + M.m[14]);
+    const float a = dot(nz, o) + (M.m[11] + M.m[15]), b = dot(nz, d);
+    if (b > 0.f && a < 0.f) o = o + d * (-a / b);
+    return o;
+}
+__global__ void __launch_bounds__(MR_BLOCK) k_rast_rays(Mat4 M, Mat4 R, int W, int H, float* __restrict__ rays) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= W * H) return;
     v3 o, d; pixel_ray(R, (i % W) + 0.5f, (i / W) + 0.5f, W, H, o, d);
+    o = near_start(M, o, d);
     float4 a, b; a.x = o.x; a.y = o.y; a.z = o.z; a.w = 0.f; b.x = d.x; b.y = d.y; b.z = d.z; b.w = 1e7f;
     reinterpret_cast<float4*>(rays)[2 * (size_t)i] = a; reinterpret_cast<float4*>(rays)[2 * (size_t)i + 1] = b;
 }
@@ -86,20 +100,23 @@ __global__ void __launch_bounds__(MR_BLOCK) k_rast_record_clip(Mat4 M, Mat4 R, i
         const int32_t* ti = tri + 3 * (size_t)p;
         const v3 v0 = ld3(vert, ti[0]), E1 = ld3(vert, ti[1]) - v0, E2 = ld3(vert, ti[2]) - v0;
         const float px = (i % W) + 0.5f, py = (i / W) + 0.5f;
-        v3 o, d; pixel_ray(R, px, py, W, H, o, d);
+        v3 o, d; float sg; pixel_ray(R, px, py, W, H, o, d, &sg);
         float b0, b1; plane_bary(o, d, v0, E1, E2, b0, b1);
-        const v3 P = o + normalize(d) * t[i];                   // bvh_hit normalises the direction: t is a world-space distance
+        const v3 P = near_start(M, o, d) + normalize(d) * t[i];  // bvh_hit normalises the direction: t is a world-space distance from where the ray started
         float c[4]; mul4(M, P.x, P.y, P.z, 1.f, c);
-        const float zw = c[2] / c[3];
-        if (zw >= -1.f && zw <= 1.f) {                          // nearer than the near plane / beyond the far plane: clipped
+        const float zw = fmaxf(c[2] / c[3], -1.f);              // the ray started on the near plane: a hit there is on it, whatever the rounding says
+        if (zw <= 1.f) {                                        // beyond the far plane: clipped
             r = make_float4(b0, b1, zw, (float)(p + 1));
-            float u0, v0_, u1, v1_;
-            pixel_ray(R, px - 0.5f, py, W, H, o, d); plane_bary(o, d, v0, E1, E2, u0, v0_);
-            pixel_ray(R, px + 0.5f, py, W, H, o, d); plane_bary(o, d, v0, E1, E2, u1, v1_);
-            db.x = u1 - u0; db.z = v1_ - v0_;
-            pixel_ray(R, px, py - 0.5f, W, H, o, d); plane_bary(o, d, v0, E1, E2, u0, v0_);
-            pixel_ray(R, px, py + 0.5f, W, H, o, d); plane_bary(o, d, v0, E1, E2, u1, v1_);
-            db.y = u1 - u0; db.w = v1_ - v0_;
+            // d(x, y) = cross(rx - x rw, ry - y rw) = cross(rx, ry) + x cross(ry, rw) + y cross(rw, rx); with A = cross(E2, o - v0), B = cross(o - v0, E1),
+            // N = cross(E2, E1): u = d.A / d.N, v = d.B / d.N, weight of v0 = 1 - u - v, of v1 = u
+            const v3 rx = V3(R.m[0], R.m[1], R.m[2]), ry = V3(R.m[4], R.m[5], R.m[6]), rw = V3(R.m[8], R.m[9], R.m[10]);
+            const v3 dx = cross(ry, rw) * (sg * 2.f / W), dy = cross(rw, rx) * (sg * 2.f / H);           // per pixel step, turned with d
+            const v3 Tv = o - v0, A = cross(E2, Tv), B = cross(Tv, E1), N = cross(E2, E1);
+            const float den = dot(d, N), inv = 1.f / den;
+            const float u = dot(d, A) * inv, v = dot(d, B) * inv;
+            const float ux = (dot(dx, A) - u * dot(dx, N)) * inv, uy = (dot(dy, A) - u * dot(dy, N)) * inv;
+            const float vx = (dot(dx, B) - v * dot(dx, N)) * inv, vy = (dot(dy, B) - v * dot(dy, N)) * inv;
+            db = make_float4(-ux - vx, -uy - vy, ux, uy);
         }
     }
     reinterpret_cast<float4*>(rast)[i] = r;
@@ -231,8 +248,8 @@ extern "C" int mirres_rasterize(mirres_bvh_t* bvh, const float* vert, const int3
     for (int k = 0; k < 16; k++) M.m[k] = h_mvp[k];
     for (int k = 0; k < 4; k++) { R.m[k] = h_mvp[k]; R.m[4 + k] = h_mvp[4 + k]; R.m[8 + k] = h_mvp[12 + k]; }     // rows x, y, w
     R.m[12] = h_eye[0]; R.m[13] = h_eye[1]; R.m[14] = h_eye[2]; R.m[15] = 0.f;
-    k_rast_rays<<<grid_for(n, MR_BLOCK), MR_BLOCK, 0, s>>>(R, W, H, rays);
-    int rc = mirres_bvh_trace(bvh, rays, (int)n, 2, hit, t, nullptr, nullptr, prim, nullptr, stream); if (rc) return rc;
+    k_rast_rays<<<grid_for(n, MR_BLOCK), MR_BLOCK, 0, s>>>(M, R, W, H, rays);
+    int rc = mirres_bvh_trace(bvh, rays, (int)n, 4, hit, t, nullptr, nullptr, prim, nullptr, stream); if (rc) return rc;   // mode 4: the ray starts on the near plane, maybe inside the mesh
     k_rast_record_clip<<<grid_for(n, MR_BLOCK), MR_BLOCK, 0, s>>>(M, R, W, H, hit, t, prim, vert, tri, rast, rast_db);
     MR_LAUNCH_CHECK("rasterize");
     return MIRRES_OK;

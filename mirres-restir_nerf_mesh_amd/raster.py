@@ -43,7 +43,9 @@ def rasterize(glctx, pos, tri, resolution, ranges=None, grad_db=True, mvp=None):
     barycentrics, and (du/dX, du/dY, dv/dX, dv/dY).  `glctx` = RasterizeContext(worker) whose worker holds the same mesh in world space (worker.vrt);
     the model-view-projection matrix is `mvp` [4,4] if given, else recovered from (worker.vrt, pos) — pos is an exact linear image of the vertices, so
     a float64 least-squares fit returns the matrix to rounding.  Not differentiable (neither is nvdiffrast's: gradients enter through dr.interpolate
-    and dr.antialias).  Triangles crossing the near plane are not clipped: a hit nearer than the near plane is discarded, and hides what lies behind it."""
+    and dr.antialias).  Clipping: every pixel's ray starts on the near plane (z_c = -w_c) and takes the nearest triangle in front of that point
+    (mirres_bvh_trace mode 4), so a triangle crossing the near plane shows its far part and hides nothing with its near part; beyond the far plane: empty.
+    rast_db is analytic (csrc/raster.hip)."""
     if ranges is not None:
         raise NotImplementedError("rasterize: range mode (instanced minibatches) is not used by the path")
     worker = glctx.worker if isinstance(glctx, RasterizeContext) else glctx

@@ -189,6 +189,34 @@ def test_traversal_quirks_on_a_hand_made_mesh(torch_cuda, oracle):
     assert np.array_equal(h3.cpu().numpy(), oracle.occluded_front(info, aabb, v, t, rays))
     # the axis-aligned cube faces (triangles 0..11) are never reported: their boxes cannot be entered
     assert not np.isin(ref["prim"][ref["hit"] > 0], np.arange(12)).any()
+    # mode 4, the conventional closest hit (nearest triangle at 0 < t <= t_max; mirres_rasterize's near-plane rays): same bit as the front-only occlusion
+    # query on the long rays, and the reported triangle is the nearest one a float64 Moeller-Trumbore over ALL triangles (the un-enterable cube faces
+    # aside) finds in front of the origin
+    hit = torch.zeros(n, dtype=torch.int32, device="cuda"); tt = torch.zeros(n, device="cuda"); pr = torch.zeros(n, dtype=torch.int32, device="cuda")
+    check(lib().mirres_bvh_trace(w.h, dr.data_ptr(), n, 4, hit.data_ptr(), tt.data_ptr(), None, None, pr.data_ptr(), None, None), "mode 4")
+    h4, t4, p4 = hit.cpu().numpy() > 0, tt.cpu().numpy().astype(np.float64), pr.cpu().numpy()
+    long_ray = tmax > 1
+    assert np.array_equal(h4[long_ray], h3.cpu().numpy()[long_ray] > 0)
+    od = o.astype(np.float64); dd = d.astype(np.float64); dd /= np.linalg.norm(dd, axis=1, keepdims=True)
+    tb = np.full((n, len(t)), np.inf)
+    for k in range(12, len(t)):
+        a, e1, e2 = (v[t[k, 0]].astype(np.float64), v[t[k, 1]].astype(np.float64) - v[t[k, 0]], v[t[k, 2]].astype(np.float64) - v[t[k, 0]])
+        P = np.cross(dd, e2); det = P @ e1
+        with np.errstate(divide="ignore", invalid="ignore"):
+            inv = 1 / det; Tv = od - a; uu = (Tv * P).sum(1) * inv; Q = np.cross(Tv, e1); vv = (dd * Q).sum(1) * inv; tk = (Q @ e2) * inv
+        eps = 1e-5
+        ok = (np.abs(det) > 1e-12) & (uu > eps) & (vv > eps) & (uu + vv < 1 - eps) & (tk > 1e-4)        # clearly inside, clearly in front
+        tb[ok, k] = tk[ok]
+    nearest = tb.min(1)
+    sure = np.isfinite(nearest) & (nearest < tmax * 0.99)
+    assert h4[sure].all() and sure.sum() > 1000
+    assert (t4[h4] > 0).all() and (t4[h4] <= tmax[h4]).all() and (p4[h4] >= 12).all()
+    assert (t4[sure] <= nearest[sure] * (1 + 1e-4) + 1e-5).all()                                     # nothing clearly in front of the reported hit
+    rows = np.nonzero(sure)[0]
+    own = tb[rows, p4[rows]]                                                                          # the reported triangle's own float64 distance
+    agree = np.isfinite(own)
+    assert agree.mean() > 0.95 and np.allclose(own[agree], t4[rows][agree], rtol=1e-4, atol=1e-5)
+    assert (~h4[(~np.isfinite(tb).any(1)) & ~(oracle.occluded_front(info, aabb, v, t, rays) > 0)]).all()
 
 
 def test_fused_interior_slab_test_on_hostile_geometry(torch_cuda, oracle):

@@ -235,6 +235,53 @@ def test_rasterize_with_nvdiffrast_call_shape_matches_a_software_rasteriser(scen
         dr.rasterize(dr.RasterizeCudaContext(None), pos_clip, tri, (H, Wd))
 
 
+def test_rasterize_clips_at_the_near_plane_and_differentiates_analytically(scene_mod):
+    """A near plane that cuts the mesh open (camera 3.1 from the centre of a unit-sized mesh, near = 2.8): the triangles that cross it show the part beyond
+    it, and through the cut the inside of the far half is seen — the same triangle per pixel, the same barycentrics and z/w as a float64 homogeneous
+    rasteriser (tests/util.py:rasterize_ref_homogeneous: covers triangles with vertices behind the eye plane, discards fragments outside -1 <= z/w <= 1),
+    and rast_db equal to its analytic derivatives (two derivations: ratios of linear forms of the ray direction on the device, of the homogeneous edge
+    functions in the test).  The default camera (near 0.05) gets the same rast_db check."""
+    import torch
+    from util import rasterize_ref_homogeneous
+    from mirres_restir_nerf_mesh_amd import renderer_restir as RR, raster, harness
+    dr = raster.dr
+    v, t = scene_mod.make_mesh(2, 4)
+    vert = torch.from_numpy(v).cuda(); tri = torch.from_numpy(t).cuda()
+    W_ = RR.restirbvhWorker(vert, tri); W_.update_mesh(W_.vrt, W_.v_ind)
+    H, Wd = 48, 64
+    pose, intr = harness_pose(), (90.0, 90.0, Wd / 2.0, H / 2.0)
+    glctx = dr.RasterizeCudaContext(W_)
+    for near in (2.8, 0.05):
+        mvp = harness.mvp_from_pose(pose.cuda(), intr, H, Wd, near=near)
+        pos_clip = (torch.cat((vert, torch.ones_like(vert[:, :1])), 1) @ mvp.t()).unsqueeze(0)
+        rast, rast_db = dr.rasterize(glctx, pos_clip, tri, (H, Wd), mvp=mvp)
+        pc = pos_clip[0].cpu().numpy().astype(np.float64)
+        ref, ref_db, edge, gap = rasterize_ref_homogeneous(pc, t, H, Wd)
+        got = rast.view(-1, 4).cpu().numpy(); db = rast_db.view(-1, 4).cpu().numpy()
+        safe = ((edge > 1e-4) | (ref[:, 3] == 0)) & (gap > 1e-4)
+        assert safe.mean() > 0.9 and (ref[:, 3] > 0).mean() > 0.2
+        assert np.array_equal(got[safe, 3], ref[safe, 3])
+        hitm = safe & (ref[:, 3] > 0)
+        np.testing.assert_allclose(got[hitm, :2], ref[hitm, :2], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(got[hitm, 2], ref[hitm, 2], rtol=0, atol=3e-4)
+        assert (got[safe & (ref[:, 3] == 0)] == 0).all() and (db[got[:, 3] == 0] == 0).all()
+        np.testing.assert_allclose(db[hitm], ref_db[hitm], rtol=2e-3, atol=2e-5)
+        assert float(np.abs(ref_db[hitm]).max()) > 0.02                                  # the derivatives are not all tiny: the tolerance means something
+        if near > 1:
+            zw = pc[:, 2] / pc[:, 3]
+            win = t[(ref[hitm, 3] - 1).astype(np.int64)]
+            crossing = ((zw[win] < -1) | (pc[win, 3] <= 0)).any(1)                       # the winner has a vertex in front of the near plane: it was clipped
+            assert crossing.sum() > 20
+            # through the cut the camera sees the inside of the mesh: triangles facing away from it
+            vv = v.astype(np.float64); e1 = vv[win[:, 1]] - vv[win[:, 0]]; e2 = vv[win[:, 2]] - vv[win[:, 0]]
+            ctr = (vv[win[:, 0]] + vv[win[:, 1]] + vv[win[:, 2]]) / 3
+            facing = (np.cross(e1, e2) * (pose[:3, 3].numpy().astype(np.float64) - ctr)).sum(1)
+            assert (facing < 0).sum() > 100 and (facing > 0).sum() > 20
+            # and the record of the default camera differs there (the front of the mesh hides the inside)
+            r0, _ = dr.rasterize(glctx, (torch.cat((vert, torch.ones_like(vert[:, :1])), 1) @ harness.mvp_from_pose(pose.cuda(), intr, H, Wd).t()).unsqueeze(0), tri, (H, Wd))
+            assert float((r0.view(-1, 4)[:, 3] != rast.view(-1, 4)[:, 3]).float().mean()) > 0.1
+
+
 def harness_pose():
     """cam2world pose of a camera at (2.2, -1.6, 1.5) looking at the origin (NeRF-blender convention: camera looks down -z, y up)."""
     import torch

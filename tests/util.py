@@ -243,3 +243,51 @@ def rasterize_ref(pos_clip, tri, H, W):
     with np.errstate(invalid="ignore"):
         gap = second_z - best_z
     return rast, edge, gap
+
+
+def rasterize_ref_homogeneous(pos_clip, tri, H, W):
+    """The same contract by 2-D homogeneous rasterisation (Olano & Greer 1997) in float64, clipping included: for clip-space vertices (x_i, y_i, w_i) the
+    columns of the inverse of [[x0 y0 w0], [x1 y1 w1], [x2 y2 w2]] are the coefficients of three functions a_i(x, y), linear in NDC, with
+    a_i / (a_0 + a_1 + a_2) = the perspective-correct barycentric of vertex i and a_0 + a_1 + a_2 = 1 / w; a pixel centre is covered where all three have the
+    sign of 1 / w > 0, whether or not some vertices lie behind the eye.  Fragments with z / w outside [-1, 1] are discarded one by one — for a point-sampled
+    rasteriser that is what clipping against the near and far planes does.  Returns (rast [n,4], rast_db [n,4] = analytic (du/dX, du/dY, dv/dX, dv/dY) per
+    pixel step, margin [n] = the smallest barycentric of the winner, gap [n] = z/w distance to the runner-up or to the clip planes)."""
+    p = np.asarray(pos_clip, np.float64); t = np.asarray(tri, np.int64)
+    xs = (2 * np.arange(W) + 1) / W - 1; ys = (2 * np.arange(H) + 1) / H - 1
+    px, py = np.meshgrid(xs, ys); px = px.ravel(); py = py.ravel()
+    n = H * W
+    best_z = np.full(n, np.inf); second_z = np.full(n, np.inf); rast = np.zeros((n, 4)); db = np.zeros((n, 4)); edge = np.full(n, np.inf); plane = np.full(n, np.inf)
+    for k in range(len(t)):
+        V = p[t[k]]                                              # rows = vertices, columns x y z w
+        Mx = V[:, [0, 1, 3]]
+        det = np.linalg.det(Mx)
+        if abs(det) < 1e-300:
+            continue
+        Mi = np.linalg.inv(Mx)                                   # (x, y, 1) . Mi[:, i] = a_i
+        a = px[:, None] * Mi[0][None] + py[:, None] * Mi[1][None] + Mi[2][None]
+        s = a.sum(1)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            b = a / s[:, None]
+        inside = (s > 0) & (b >= 0).all(1)
+        if not inside.any():
+            continue
+        with np.errstate(divide="ignore", invalid="ignore"):
+            z = (b @ V[:, 2]) / (b @ V[:, 3])
+        frag = inside & np.isfinite(z)
+        plane = np.where(frag, np.minimum(plane, np.minimum(np.abs(z + 1), np.abs(z - 1))), plane)
+        ok = frag & (z >= -1) & (z <= 1)
+        closer = ok & (z < best_z)
+        second_z = np.where(closer, best_z, np.where(ok & (z < second_z), z, second_z))
+        sx, sy = Mi[0].sum(), Mi[1].sum()
+        with np.errstate(divide="ignore", invalid="ignore"):
+            dbx = (Mi[0][None] - b * sx) / s[:, None] * (2.0 / W)     # d b_i / dX
+            dby = (Mi[1][None] - b * sy) / s[:, None] * (2.0 / H)
+        rec = np.stack([b[:, 0], b[:, 1], z, np.full(n, k + 1.0)], 1)
+        rast[closer] = rec[closer]
+        db[closer] = np.stack([dbx[:, 0], dby[:, 0], dbx[:, 1], dby[:, 1]], 1)[closer]
+        edge = np.where(closer, b.min(1), edge)
+        best_z = np.where(closer, z, best_z)
+    with np.errstate(invalid="ignore"):
+        gap = np.where(np.isfinite(best_z), np.minimum(second_z - best_z, plane), plane)
+    return rast, db, edge, gap
+
