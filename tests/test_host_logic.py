@@ -357,3 +357,45 @@ def test_antialias_reference_statement_on_analytic_edges():
         assert touched == {row * W + c for row in range(H) for c in (inside, outside)}          # only the silhouette pairs; the shared diagonal blends nothing
         changed = np.nonzero(np.abs(out - color).max(1) > 0)[0]
         assert set(changed.tolist()) <= touched
+
+
+def test_the_two_software_rasterisers_of_the_gpu_tests_agree():
+    """tests/util.py holds two float64 rasterisers the GPU tests compare raster.dr.rasterize with: one over projected 2-D triangles (no clipping; triangles with
+    a vertex behind the eye skipped) and a homogeneous one (clipping by per-fragment z/w, analytic barycentric derivatives).  Where nothing needs clipping they
+    must give the same record; the homogeneous one's derivatives must equal finite differences of its own barycentrics taken from a 9 x finer image (pixel
+    (ix, iy) of the coarse image and pixel (9 ix + 4, 9 iy + 4) of the fine one share a centre; their neighbours lie 1/9 pixel away); and a triangle with one
+    vertex behind the eye must show exactly its part beyond the near plane."""
+    from util import rasterize_ref, rasterize_ref_homogeneous
+    rng = np.random.default_rng(5)
+    T = 30
+    v = rng.uniform(-1, 1, (3 * T, 3)); t = np.arange(3 * T).reshape(T, 3)
+    near, far = 0.5, 100.0
+    proj = np.array([[1.2, 0, 0, 0], [0, -1.2, 0, 0], [0, 0, -(far + near) / (far - near), -2 * far * near / (far - near)], [0, 0, -1, 0]])
+    view = np.eye(4); view[2, 3] = -3.0
+    pc = np.concatenate([v, np.ones((3 * T, 1))], 1) @ (proj @ view).T
+    H, W = 20, 24
+    a, ea, ga = rasterize_ref(pc, t, H, W)
+    b, db, eb, gb = rasterize_ref_homogeneous(pc, t, H, W)
+    safe = ((ea > 1e-9) & (ga > 1e-9)) | (a[:, 3] == 0)
+    assert (a[:, 3] > 0).mean() > 0.1 and safe.mean() > 0.95
+    assert np.array_equal(a[safe, 3], b[safe, 3]) and np.abs(a[safe] - b[safe]).max() < 1e-12
+    f, _, _, _ = rasterize_ref_homogeneous(pc, t, 9 * H, 9 * W)
+    f = f.reshape(9 * H, 9 * W, 4); c = b.reshape(H, W, 4); d4 = db.reshape(H, W, 4)
+    ctr = f[4::9, 4::9]; assert np.array_equal(ctr[..., 3], c[..., 3]) and np.abs(ctr - c).max() < 1e-12
+    xm, xp, ym, yp = f[4::9, 3::9], f[4::9, 5::9], f[3::9, 4::9], f[5::9, 4::9]
+    okx = (c[..., 3] > 0) & (xm[..., 3] == c[..., 3]) & (xp[..., 3] == c[..., 3]); oky = (c[..., 3] > 0) & (ym[..., 3] == c[..., 3]) & (yp[..., 3] == c[..., 3])
+    fdx = (xp[..., :2] - xm[..., :2]) * 4.5; fdy = (yp[..., :2] - ym[..., :2]) * 4.5
+    assert okx.sum() > 40 and oky.sum() > 40
+    np.testing.assert_allclose(d4[okx][:, [0, 2]], fdx[okx], rtol=2e-3, atol=1e-6)
+    np.testing.assert_allclose(d4[oky][:, [1, 3]], fdy[oky], rtol=2e-3, atol=1e-6)
+    # one big triangle through the eye plane: vertices at view depths 2, 2 and -1 (behind the eye)
+    tri = np.array([[-1.0, -1.0, -2.0], [1.0, -1.0, -2.0], [0.0, 1.5, 1.0]])
+    pc1 = np.concatenate([tri, np.ones((3, 1))], 1) @ proj.T
+    r1, _, _, _ = rasterize_ref_homogeneous(pc1, np.array([[0, 1, 2]]), 40, 40)
+    r0, _, _ = rasterize_ref(pc1, np.array([[0, 1, 2]]), 40, 40)
+    assert (r0[:, 3] == 0).all() and (r1[:, 3] > 0).mean() > 0.2
+    hit = r1[:, 3] > 0
+    bw = np.stack([r1[:, 0], r1[:, 1], 1 - r1[:, 0] - r1[:, 1]], 1)
+    depth = -(bw @ tri[:, 2])                                   # view depth of the point each covered pixel sees: beyond the near plane, never behind the eye
+    assert (depth[hit] >= near - 1e-9).all() and (depth[hit] <= far).all() and depth[hit].min() < near + 0.05
+    assert (np.abs(r1[hit, 2]) <= 1).all()
