@@ -395,14 +395,28 @@ def _finish_args(ctx, env_map, g, spp, denoise_iter, step_width, c_phi, n_phi, p
 
 
 # ------------------------------------------------------------------------------------------------ training: gradient exchange
-def allreduce_gradients(tensors, group=None, average=True):
+def _grad_algo():
+    a = os.environ.get("MIRRES_GRAD_EXCHANGE", "direct")
+    if a not in ("direct", "allreduce"):
+        raise ValueError("MIRRES_GRAD_EXCHANGE must be 'direct' or 'allreduce', not %r" % a)
+    return a
+
+
+def allreduce_gradients(tensors, group=None, average=True, algo=None):
     """Stage-1 data parallelism (BASELINE configs[4]: 'grads all-reduced over xGMI'): every rank renders its own views / strips and
-    the parameter gradients — hash grid (50 MB fp32), MLP, environment map, vertex offsets — are summed as ONE flat bucket (RCCL rings are bound
-    by the per-link bandwidth of xGMI, so one large collective instead of one per tensor). `tensors` = parameters (their .grad is used; missing
-    grads count as zero) or plain gradient tensors; updated in place."""
+    the parameter gradients — hash grid (50 MB fp32), MLP, environment map, vertex offsets — are summed as ONE flat bucket. `tensors` = parameters
+    (their .grad is used; missing grads count as zero) or plain gradient tensors; updated in place.
+
+    algo 'direct' (default; MIRRES_GRAD_EXCHANGE): xGMI is point-to-point with a link to every peer of the node, so the sum is a reduce-scatter issued
+    as ONE all-to-all — rank r receives slice r of every rank's bucket over its seven links at once — a local sum of the received slices IN RANK ORDER,
+    and one all-gather of the reduced slices. Two collectives of (N - 1) / N of the bucket each, every link busy in both, and the result is the same
+    bits on every rank and from run to run whatever algorithm RCCL would pick for an all-reduce (the order of the additions is fixed here).
+    algo 'allreduce': one flat RCCL all-reduce (rounds 1-4; RCCL chooses ring / tree, the order of the additions with it)."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not _forced()):
         return
+    algo = algo or _grad_algo()
+    world = dist.get_world_size(group)
     grads = []
     for t in tensors:
         if t.requires_grad:         # a parameter or a plain trainable leaf (the reference's `light_base`: EnvironmentLight is not an nn.Module)
@@ -415,11 +429,27 @@ def allreduce_gradients(tensors, group=None, average=True):
     if not grads:
         return
     with torch.no_grad():
-        flat = torch.cat([g.reshape(-1).to(torch.float32) for g in grads])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-        if average:
-            flat /= dist.get_world_size(group)
+        n = sum(g.numel() for g in grads)
+        if algo == "direct":
+            per = -(-n // world)
+            per = -(-per // 64) * 64                                   # 256-byte slices
+            flat = torch.zeros(per * world, dtype=torch.float32, device=grads[0].device)
+            torch.cat([g.reshape(-1).to(torch.float32) for g in grads], out=flat[:n])
+            recv = torch.empty_like(flat)
+            dist.all_to_all_single(recv, flat, group=group)            # recv[i] = slice `rank` of rank i's bucket
+            parts = recv.view(world, per)
+            mine = parts[0].clone()
+            for i in range(1, world):
+                mine += parts[i]                                        # rank order: the same additions wherever and whenever this runs
+            if average:
+                mine /= world
+            dist.all_gather_into_tensor(flat, mine, group=group)
+        else:
+            flat = torch.cat([g.reshape(-1).to(torch.float32) for g in grads])
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+            if average:
+                flat /= world
         o = 0
         for g in grads:
-            n = g.numel()
-            g.copy_(flat[o:o + n].view_as(g)); o += n
+            k = g.numel()
+            g.copy_(flat[o:o + k].view_as(g)); o += k

@@ -158,7 +158,7 @@ def stage1_optimizer_step(loss, optimizer, optimizer_mat=None, optimizer_light=N
     gradient / 8, material and light steps, and the light clamped at 0.01 from below.  (The reference wraps the geometry step in a GradScaler; fp16
     is off on this path, where the scaler is the identity.)  The caller zeroes the three optimisers' gradients before rendering, as :1555-1558 does.
     `grad_sync` (data-parallel training: one view or strip per rank) is called between the backward pass and the first optimiser step — e.g.
-    `lambda: dist.allreduce_gradients([voffsets, *mlp.parameters(), light_base])`, one flat RCCL all-reduce of every parameter gradient."""
+    `lambda: dist.allreduce_gradients([voffsets, *mlp.parameters(), light_base])`, one flat bucket of every parameter gradient (all-to-all of slices + rank-ordered sum + all-gather over RCCL; dist.allreduce_gradients)."""
     loss.backward()
     if grad_sync is not None:
         grad_sync()

@@ -42,11 +42,15 @@ strip_outs = D.render_strips(ctx, W, None, env, g, 3, 4321, rank, world)        
 res["strips_equal_single_gpu"] = all(torch.equal(a, b) for a, b in zip(strip_outs, ref))
 res["spp_equal_single_gpu"] = all(torch.equal(a, b) for a, b in zip(spp_outs, ref))
 res["spp_close_to_single_gpu"] = all(float((a - b).abs().mean()) < 0.05 for a, b in zip(spp_outs, ref))
-# gradient bucket: one flat all-reduce, averaged
+# gradient bucket, averaged: the direct exchange (RCCL all-to-all of slices + rank-ordered sum + all-gather; 1007 values: the bucket is padded) and the flat all-reduce
 p = torch.nn.Parameter(torch.arange(1000, dtype=torch.float32, device="cuda")); p.grad = torch.full_like(p, float(rank + 1))
 q = torch.ones(7, device="cuda", requires_grad=True)                            # a leaf without a gradient on this rank counts as zero
 D.allreduce_gradients([p, q])
 res["grad_bucket"] = [float(p.grad[0]), float(p.grad[-1]), float(q.grad.abs().sum())]
+p2 = torch.nn.Parameter(torch.zeros(1000, device="cuda")); p2.grad = torch.arange(1000, dtype=torch.float32, device="cuda") * (rank + 1)
+p3 = torch.nn.Parameter(torch.zeros(1000, device="cuda")); p3.grad = p2.grad.clone()
+D.allreduce_gradients([p2], algo="direct"); D.allreduce_gradients([p3], algo="allreduce")
+res["grad_algos_agree"] = bool(torch.equal(p2.grad, p3.grad)) and float(p2.grad[999]) == 999.0 * (world + 1) / 2
 if world == 1:
     # point-to-point through RCCL from inside mirres_render's host callback: this rank plays the upper strip of a two-strip frame and "exchanges" with itself
     # (peer = own rank), i.e. its lower halo rows receive a copy of its own last rows; the same frame with the copy done by torch must come out bit-equal
@@ -113,7 +117,7 @@ def test_rccl_collectives_and_halo_exchange_on_one_gpu(tmp_path):
     assert r["backend"] == "nccl" and r["world"] == 1
     assert r["strips_equal_single_gpu"], "strip scheme (halo callback + RCCL all-gather) must reproduce the single-GPU frame bit for bit"
     assert r["spp_equal_single_gpu"], "one rank's slice is the whole frame: the RCCL all-reduce over one rank must be the identity"
-    assert r["grad_bucket"] == [1.0, 1.0, 0.0]
+    assert r["grad_bucket"] == [1.0, 1.0, 0.0] and r["grad_algos_agree"]
     assert r["p2p_in_callback_equal"] and r["p2p_moved_something"]
 
 

@@ -200,7 +200,7 @@ def test_strip_exchange_and_gather_gloo_world2(tmp_path):
             assert torch.equal(d["full"][k], gy[:, :, :3].reshape(-1, 3) * (k + 1))
 
 
-def _grad_worker(rank, world, port, out):
+def _grad_worker(rank, world, port, out, algo):
     import torch
     import torch.distributed as dist
     sys.path.insert(0, ROOT)
@@ -216,19 +216,38 @@ def _grad_worker(rank, world, port, out):
     if rank == 0:
         light.grad = torch.full((3, 2, 3), 4.0)
     raw = torch.full((5,), 10.0 * (rank + 1))
-    allreduce_gradients([w, e, unused, light, raw])
-    torch.save(dict(w=w.grad, e=e.grad, u=unused.grad, light=light.detach(), lg=light.grad, raw=raw), os.path.join(out, "g%d.pt" % rank))
+    allreduce_gradients([w, e, unused, light, raw], algo=algo)
+    # a bucket whose sum depends on the order of the additions (values 2^24 apart in magnitude) and whose length is no multiple of the slice size:
+    # the direct exchange adds in rank order on whichever rank owns the slice, so every rank must hold the bits of ((g0 + g1) + g2)
+    gen = torch.Generator().manual_seed(100 + rank)
+    big = (torch.randn(1000, generator=gen) * torch.tensor([1.0, 3e7, 1e-7]).repeat(334)[:1000]).contiguous()
+    mine = big.clone()
+    allreduce_gradients([big], average=False, algo=algo)
+    torch.save(dict(w=w.grad, e=e.grad, u=unused.grad, light=light.detach(), lg=light.grad, raw=raw, big=big, mine=mine), os.path.join(out, "g%d.pt" % rank))
     dist.destroy_process_group()
 
 
-def test_gradient_allreduce_gloo_world2(tmp_path):
-    """Training exchange: parameter gradients averaged over ranks as one flat bucket; a parameter without a gradient on some rank counts as zero."""
+@pytest.mark.parametrize("algo,world", [("direct", 3), ("direct", 2), ("allreduce", 2)])
+def test_gradient_allreduce_gloo(tmp_path, algo, world):
+    """Training exchange: parameter gradients averaged over ranks as one flat bucket; a parameter without a gradient on some rank counts as zero.
+    'direct' (the default: all-to-all of slices, local sum in rank order, all-gather) on three ranks — an odd world, a bucket that needs padding — gives every
+    rank the same bits, those of the rank-ordered sum; 'allreduce' is the single flat all-reduce of rounds 1-4."""
     import torch
     import torch.multiprocessing as mp
-    port = 35500 + (os.getpid() % 2000)
-    mp.spawn(_grad_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    port = 35500 + (os.getpid() % 2000) + (7 if algo == "direct" else 0) + world
+    mp.spawn(_grad_worker, args=(world, port, str(tmp_path), algo), nprocs=world, join=True)
+    ds = [torch.load(os.path.join(tmp_path, "g%d.pt" % r)) for r in range(world)]
+    want = ds[0]["mine"].clone()
+    for r in range(1, world):
+        want = want + ds[r]["mine"]
+    for r in range(world):
+        assert torch.allclose(ds[r]["big"], want, rtol=1e-6, atol=0) and torch.equal(ds[r]["big"], ds[0]["big"])
+        if algo == "direct":
+            assert torch.equal(ds[r]["big"], want)
+    if world != 2:
+        return
     for r in range(2):
-        d = torch.load(os.path.join(tmp_path, "g%d.pt" % r))
+        d = ds[r]
         assert torch.allclose(d["w"], torch.full((7, 3), 1.5))
         assert torch.allclose(d["e"], torch.arange(60, dtype=torch.float32).reshape(4, 5, 3) * 1.5)
         assert torch.equal(d["u"], torch.zeros(2))
