@@ -33,6 +33,43 @@ def spp_slice(spp, rank, world):
 USED_SUMS = (1, 2, 4, 5)   # the accumulators the finish reads (diffuse / specular light, indirect diffuse / specular: renderer_restir.py:507-549); 0 and 3 (the colour totals) are averaged and dropped
 
 
+def _sum_algo():
+    a = os.environ.get("MIRRES_SUM_EXCHANGE", "direct")
+    if a not in ("direct", "allreduce"):
+        raise ValueError("MIRRES_SUM_EXCHANGE must be 'direct' or 'allreduce', not %r" % a)
+    return a
+
+
+def sum_over_ranks(flat, group=None, algo=None):
+    """The element-wise sum of a flat fp32 bucket over the ranks, the same bits on every rank.
+
+    algo 'direct' (default; MIRRES_SUM_EXCHANGE): xGMI is point-to-point with a link to every peer of the node, so the sum is a reduce-scatter issued as ONE
+    all-to-all — rank r receives slice r of every rank's bucket over its seven links at once —, a local sum of the received slices IN RANK ORDER, and ONE
+    all-gather of the reduced slices: two collectives of (N - 1) / N of the bucket each with every link busy in both, and the order of the additions is fixed
+    here, not by whichever algorithm RCCL picks for an all-reduce (the same bits from run to run). algo 'allreduce': one RCCL all-reduce (rounds 1-4)."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    algo = algo or _sum_algo()
+    if algo == "allreduce":
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        return flat
+    n = flat.numel()
+    per = -(-n // world)
+    per = -(-per // 64) * 64                                       # 256-byte slices
+    if per * world != n:
+        padded = torch.zeros(per * world, dtype=flat.dtype, device=flat.device); padded[:n] = flat
+    else:
+        padded = flat
+    recv = torch.empty_like(padded)
+    dist.all_to_all_single(recv, padded, group=group)              # recv[i] = slice `rank` of rank i's bucket
+    parts = recv.view(world, per)
+    mine = parts[0].clone()
+    for i in range(1, world):
+        mine += parts[i]                                            # rank order: the same additions wherever and whenever this runs
+    dist.all_gather_into_tensor(padded, mine, group=group)
+    return padded[:n]
+
+
 def allreduce_sums(sums, group=None, occ=None, used=None):
     """Sum the six accumulators over ranks as ONE flat collective. `occ` (the replicated occupancy, [N] or [N,1]): only the FOREGROUND pixels' sums travel
     (round 5) — a background pixel's sums are zero on every rank (no stage accumulates into it), so their sum is the zero that is already there; the collective
@@ -48,7 +85,7 @@ def allreduce_sums(sums, group=None, occ=None, used=None):
             idx = None
     sel = list(range(len(sums))) if used is None else [k for k in used if k < len(sums)]
     flat = torch.cat([(sums[k] if idx is None else sums[k][idx]).reshape(-1) for k in sel])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    flat = sum_over_ranks(flat, group)
     out, o = list(sums), 0
     for k in sel:
         s = sums[k]
@@ -395,28 +432,14 @@ def _finish_args(ctx, env_map, g, spp, denoise_iter, step_width, c_phi, n_phi, p
 
 
 # ------------------------------------------------------------------------------------------------ training: gradient exchange
-def _grad_algo():
-    a = os.environ.get("MIRRES_GRAD_EXCHANGE", "direct")
-    if a not in ("direct", "allreduce"):
-        raise ValueError("MIRRES_GRAD_EXCHANGE must be 'direct' or 'allreduce', not %r" % a)
-    return a
-
-
 def allreduce_gradients(tensors, group=None, average=True, algo=None):
     """Stage-1 data parallelism (BASELINE configs[4]: 'grads all-reduced over xGMI'): every rank renders its own views / strips and
-    the parameter gradients — hash grid (50 MB fp32), MLP, environment map, vertex offsets — are summed as ONE flat bucket. `tensors` = parameters
-    (their .grad is used; missing grads count as zero) or plain gradient tensors; updated in place.
-
-    algo 'direct' (default; MIRRES_GRAD_EXCHANGE): xGMI is point-to-point with a link to every peer of the node, so the sum is a reduce-scatter issued
-    as ONE all-to-all — rank r receives slice r of every rank's bucket over its seven links at once — a local sum of the received slices IN RANK ORDER,
-    and one all-gather of the reduced slices. Two collectives of (N - 1) / N of the bucket each, every link busy in both, and the result is the same
-    bits on every rank and from run to run whatever algorithm RCCL would pick for an all-reduce (the order of the additions is fixed here).
-    algo 'allreduce': one flat RCCL all-reduce (rounds 1-4; RCCL chooses ring / tree, the order of the additions with it)."""
+    the parameter gradients — hash grid (50 MB fp32), MLP, environment map, vertex offsets — are summed as ONE flat bucket by sum_over_ranks (direct
+    exchange over the point-to-point links by default; algo / MIRRES_SUM_EXCHANGE = 'allreduce' for the flat RCCL all-reduce). `tensors` = parameters
+    (their .grad is used; missing grads count as zero) or plain gradient tensors; updated in place."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not _forced()):
         return
-    algo = algo or _grad_algo()
-    world = dist.get_world_size(group)
     grads = []
     for t in tensors:
         if t.requires_grad:         # a parameter or a plain trainable leaf (the reference's `light_base`: EnvironmentLight is not an nn.Module)
@@ -429,26 +452,9 @@ def allreduce_gradients(tensors, group=None, average=True, algo=None):
     if not grads:
         return
     with torch.no_grad():
-        n = sum(g.numel() for g in grads)
-        if algo == "direct":
-            per = -(-n // world)
-            per = -(-per // 64) * 64                                   # 256-byte slices
-            flat = torch.zeros(per * world, dtype=torch.float32, device=grads[0].device)
-            torch.cat([g.reshape(-1).to(torch.float32) for g in grads], out=flat[:n])
-            recv = torch.empty_like(flat)
-            dist.all_to_all_single(recv, flat, group=group)            # recv[i] = slice `rank` of rank i's bucket
-            parts = recv.view(world, per)
-            mine = parts[0].clone()
-            for i in range(1, world):
-                mine += parts[i]                                        # rank order: the same additions wherever and whenever this runs
-            if average:
-                mine /= world
-            dist.all_gather_into_tensor(flat, mine, group=group)
-        else:
-            flat = torch.cat([g.reshape(-1).to(torch.float32) for g in grads])
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-            if average:
-                flat /= world
+        flat = sum_over_ranks(torch.cat([g.reshape(-1).to(torch.float32) for g in grads]), group, algo)
+        if average:
+            flat = flat / dist.get_world_size(group)
         o = 0
         for g in grads:
             k = g.numel()

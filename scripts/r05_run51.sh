@@ -1,4 +1,4 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:?}" || exit 1
 mkdir -p gpurun_out/r05
-timeout 900 python3 -m pytest tests/test_gpu_rccl.py -m gpu -x -q 2>&1 | tail -8 | tee gpurun_out/r05/rccl_tests.txt
+timeout 1200 python3 -m pytest tests/test_gpu_rccl.py tests/test_gpu_render.py tests/test_gpu_raster.py -m gpu -x -q 2>&1 | tail -8 | tee gpurun_out/r05/rccl_tests.txt
