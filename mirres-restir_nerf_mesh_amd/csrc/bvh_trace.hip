@@ -433,22 +433,9 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_persist(BvhView B, con
 static_assert(MR_ANY_STACK >= 3 * (MR_SAH_LEVELS + (38 - MR_SAH_PREFIX) + 31), "MR_ANY_STACK must cover the deepest private hierarchy (DESIGN.md, stack bounds)");
 static_assert(MR_ANY_LDS >= 3 && MR_ANY_LDS <= MR_ANY_STACK, "the LDS part of the private stack holds at least one node's deferred references");
 #define MR_TOPBIT 0x20000000
-#ifndef MR_CL_FASTPUSH
-#define MR_CL_FASTPUSH 1
-#endif
 #ifndef MR_CL_REFILL
 #define MR_CL_REFILL MR_REFILL
 #endif
-#ifndef MR_CL_POP1
-#define MR_CL_POP1 1        // ordered closest hit: deferred entries popped per iteration (0: until one survives, the loop of rounds 1-4; 1: one; 2: two looked at together)
-#endif
-#ifndef MR_CL_SORTNET
-#define MR_CL_SORTNET 1     // ordered closest hit: children sorted by a 5-comparator network (0: the insertion of rounds 1-4)
-#endif
-#ifndef MR_ANY_PARK
-#define MR_ANY_PARK 0      // experiment: leaves wait for a wave-wide leaf round once this many lanes hold one (0 = off: every lane tests its leaf at once)
-#endif
-#define MR_NOCUR 0x7ffffffe   // MR_ANY_PARK: the lane has no node to go on with (only a parked leaf)
 // ---------------------------------------------------------------- shadow rays on the COMPRESSED 4-wide collapse (engine.hpp Node4q / LeafRec)
 // The any-hit bit is the OR over leaves whose own box passes the slab test (above); interior boxes only steer the search and may be any
 // supersets. Node4q stores them as 8-bit outward-rounded offsets (64 B per visit = 4 dwordx4 gathers instead of 8 — the kernel is bound by
@@ -528,12 +515,6 @@ MR_DEV bool tri_accepts_regs(float4 a, float4 b, float4 c, v3 ro, v3 d) {
     if (FRONT) return dot(E2, Q) * invDet > 0.f;
     return true;
 }
-#ifdef MR_EXP_PHASES   // experiment: where a shadow-ray wave spends its cycles (s_memtime around the phases; B.dbg gets 5 words per wave)
-#define MR_PH_NOW() ({ asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); (long long)clock64(); })
-#define MR_PH(x) x
-#else
-#define MR_PH(x)
-#endif
 // TIMED = 2: front-only occlusion (nerf/render_dump.py's external `intersector`, a conventional ray tracer) — the same traversal with t > 0 required
 // SRC = 1: the queue holds one pixel pair per two rays and the ray is formed here (engine.hpp RaySrc)
 template <bool COUNT, int TOPN, int TIMED = 0, int SRC = 0>   // TIMED: identical code under a second name, launched by bench.py's event-timed frame so that a rocprofv3
@@ -548,9 +529,7 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const
         for (int i = threadIdx.x; i < TOPN * 4; i += MR_TRACE_BLOCK) s_top[i] = src[i];
         __syncthreads();
     }
-#ifndef MR_EXP_PHASES
     if (B.dbg && (threadIdx.x & 63) == 0) B.dbg[2 * (blockIdx.x * (MR_TRACE_BLOCK / 64) + (threadIdx.x >> 6))] = wall_clock64();
-#endif
     uint32_t* const lds_stack = lds + threadIdx.x;
     const uint32_t n = d_count ? *d_count : n_fixed;
     const int lane = lane_id();
@@ -570,12 +549,7 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const
     uint32_t spill[MR_ANY_STACK - MR_ANY_LDS];
     unsigned long long c_boxes = 0, c_nodes = 0, c_leaves = 0; int c_maxsp = 0;
     unsigned long long w_iters = 0, w_leaf_iters = 0, w_leaf_lanes = 0;      // COUNT: wave iterations, those that ran the leaf branch, leaf visits (wave-uniform; lane 0 reports)
-#if MR_ANY_PARK
-    int parked = 0;                                   // a leaf reference (< 0) waiting for the wave's next leaf round; 0 = none
-#endif
-    MR_PH(long long ph_refill = 0; long long ph_mem = 0; long long ph_cmp = 0; long long ph_iters = 0; const long long ph_begin = MR_PH_NOW();)
     while (true) {
-        MR_PH(const long long ph_a = MR_PH_NOW();)
         const uint64_t need = __ballot(!have);
         if (need && exhausted) {
             // ---- the tail of the launch: the queue is empty and the wave waits for its longest rays. A shadow ray's answer is an OR over subtrees, so
@@ -602,9 +576,6 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const
                     t_min = s_tmin; t_max = s_tmax; ridx = s_ridx;
                     cur = (int)lds[s_base * MR_TRACE_BLOCK + ((threadIdx.x & ~63) | src)];
                     sp = 0; sbase = 0; have = true;
-#if MR_ANY_PARK
-                    parked = 0;
-#endif
                 }
                 if (give) sbase++;
             }
@@ -613,11 +584,7 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const
             if (chunk_next >= chunk_end) exhausted = !grab_chunk(work_head, n, q_per, chunk, q_cur, q_fail, q_known, chunk_next, chunk_end, lane);
             if (!exhausted) {
                 const uint32_t idx0 = chunk_next + (uint32_t)__popcll(need & lt_mask);
-#ifdef MR_EXP_PERMUTE   // experiment: queue position -> ray through a multiplicative permutation, i.e. a wave's lanes hold rays from all over the frame
-                const uint32_t idx = idx0 < n ? (uint32_t)(((unsigned long long)idx0 * 2654435761ull) % n) : idx0;
-#else
                 const uint32_t idx = idx0;
-#endif
                 if (!have && idx0 < chunk_end) {
                     float4 a, b; bool dead = false;
                     if (SRC == 1) {
@@ -627,9 +594,6 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const
                         dead = src.skip_dead && L.w == 0.f;   // engine.hpp RaySrc: the light sample's carried luminance is 0 — nobody can see this ray's answer
                         const v3 dir = oct_decode(V2(L.y, L.z));
                         v3 o = V3(P.x, P.y, P.z) + src.vis_near * dir;          // put_ray (passes.hip): the same two expressions
-#ifdef MR_EXP_REFILL2X   // experiment: what the two dependent gathers of the refill cost — a second pair of them (the pair's other pixel), folded in with weight 0
-                        { const float4 P2 = src.grec[4 * (size_t)lp + 3], L2 = src.rrec[2 * (size_t)op]; o.x += 0.f * (P2.x + L2.y); }
-#endif
                         a.x = o.x; a.y = o.y; a.z = o.z; a.w = 0.f; b.x = dir.x; b.y = dir.y; b.z = dir.z; b.w = 1e7f;
                     } else { a = reinterpret_cast<const float4*>(rays + idx)[0]; b = reinterpret_cast<const float4*>(rays + idx)[1]; }
                     ridx = idx; ro = V3(a.x, a.y, a.z); t_min = a.w; t_max = b.w;
@@ -639,9 +603,6 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const
                       if (dx == 0.f) dx = 0.000001f; if (dy == 0.f) dy = 0.000001f; if (dz == 0.f) dz = 0.000001f;
                       ix = 1.0f / dx; iy = 1.0f / dy; iz = 1.0f / dz; }
                     sp = 0; sbase = 0;
-#if MR_ANY_PARK
-                    parked = 0;
-#endif
                     rc = ray_margins(scene_bs, ox, oy, oz, ix, iy, iz);
                     hit_out[idx] = 0;          // set to 1 by whichever lane finds an occluder (the owner or, in the tail, a helper)
                     const float o3[3] = {ox, oy, oz}, i3[3] = {ix, iy, iz};
@@ -653,30 +614,9 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const
                 chunk_next = (chunk_next + want < chunk_end) ? chunk_next + want : chunk_end;
             }
         }
-        MR_PH(ph_refill += MR_PH_NOW() - ph_a;)
         if (!__ballot(have)) { if (exhausted) break; else continue; }
         do {
-            MR_PH(const long long ph_0 = MR_PH_NOW(); long long ph_1 = ph_0; ph_iters++;)
             int ref = cur; bool active = have;
-#if MR_ANY_PARK
-            // Experiment (round 5; -DMR_ANY_PARK=<threshold>): a lane that reaches a leaf does not test it at once. From the counters, a lane is at a
-            // leaf in 5 % (icosphere) / 12 % (lego-like) of its iterations, so with ~50 busy lanes nearly every wave iteration runs the leaf branch (exact slab +
-            // Moller-Trumbore, ~70 instructions) for two or three lanes beside the node branch (~120): a third of the kernel's VALU instructions at 4 % lane
-            // utilisation. Here the lane PARKS the leaf (one reference) and goes on with its next deferred subtree; the wave runs a leaf round when MR_ANY_PARK lanes
-            // hold one, or when a lane cannot go on without its answer (nothing else left, or a second leaf). The answer is an OR over leaves: no bit changes; what it
-            // costs is the traversal an occluded ray does between parking the leaf that would have ended it and the round that tests it.
-            {
-                if (have && cur < 0 && parked == 0) {
-                    parked = cur;
-                    if (sp > sbase) { --sp; cur = (int)((sp < MR_ANY_LDS) ? lds_stack[sp * MR_TRACE_BLOCK] : spill[sp - MR_ANY_LDS]); } else cur = MR_NOCUR;
-                }
-                const bool p_has = have && parked != 0;
-                const bool wants = p_has && (cur < 0 || cur == MR_NOCUR);
-                const bool round = __popcll(__ballot(p_has)) >= MR_ANY_PARK || __ballot(wants) != 0;
-                if (round && p_has) ref = parked;
-                else { ref = cur; active = have && cur >= 0 && cur != MR_NOCUR; }
-            }
-#endif
             if (COUNT) { const uint64_t lm = __ballot(active && ref < 0); w_iters++; if (lm) { w_leaf_iters++; w_leaf_lanes += (unsigned long long)__popcll(lm); } }
             if (active) {
                 // one 64-byte record per iteration — a Node4q or a LeafRec — fetched before the type is looked at, so that a wave pays ONE memory
@@ -691,7 +631,6 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const
                     h0 = nd[0]; h1 = nd[1]; h2 = nd[2]; rf = nd[3];
                     if (COUNT) c_nodes++;    // 64-byte records fetched from global memory (nodes served from LDS are not charged)
                 }
-                MR_PH(asm volatile("" :: "v"(h0.x), "v"(h1.x), "v"(h2.x), "v"(rf.x), "v"(rf.w)); ph_1 = MR_PH_NOW();)
                 bool hit = false;
                 int next = 0x7fffffff; float next_tn = 0.f;
                 if (leaf) {
@@ -759,30 +698,18 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const
                     }
                 }
                 bool done = hit;
-#if MR_ANY_PARK
-                if (leaf) { parked = 0; if (!hit) done = cur == MR_NOCUR; }      // (a second leaf in `cur` is parked at the top of the next iteration)
-                else if (next != 0x7fffffff) cur = next;
-                else if (sp > sbase) { --sp; cur = (int)((sp < MR_ANY_LDS) ? lds_stack[sp * MR_TRACE_BLOCK] : spill[sp - MR_ANY_LDS]); }
-                else { cur = MR_NOCUR; done = parked == 0; }
-#else
                 if (!hit) {
                     if (next != 0x7fffffff) cur = next;
                     else if (sp > sbase) { --sp; cur = (int)((sp < MR_ANY_LDS) ? lds_stack[sp * MR_TRACE_BLOCK] : spill[sp - MR_ANY_LDS]); }
                     else done = true;
                 }
-#endif
                 if (COUNT) c_maxsp = sp > c_maxsp ? sp : c_maxsp;
                 if (done) { have = false; if (hit) hit_out[ridx] = 1; }
             }
-            MR_PH(ph_mem += ph_1 - ph_0; ph_cmp += MR_PH_NOW() - ph_1;)
             // in the tail leave the loop as soon as an idle lane and a lane with deferred work coexist (hand-over above)
         } while (exhausted ? (__ballot(have) && !(__ballot(!have) && __ballot(have && sp > sbase && sbase < MR_ANY_LDS))) : (__popcll(__ballot(have)) >= MR_REFILL));
     }
-#ifndef MR_EXP_PHASES
     if (B.dbg && (threadIdx.x & 63) == 0) B.dbg[2 * (blockIdx.x * (MR_TRACE_BLOCK / 64) + (threadIdx.x >> 6)) + 1] = wall_clock64();
-#endif
-    MR_PH(if (B.dbg && (threadIdx.x & 63) == 0) { unsigned long long* o = B.dbg + 5 * (blockIdx.x * (MR_TRACE_BLOCK / 64) + (threadIdx.x >> 6));
-            o[0] = (unsigned long long)(MR_PH_NOW() - ph_begin); o[1] = (unsigned long long)ph_refill; o[2] = (unsigned long long)ph_mem; o[3] = (unsigned long long)ph_cmp; o[4] = (unsigned long long)ph_iters; })
     if (COUNT && stats) { atomicAdd(&stats[2], c_boxes); atomicAdd(&stats[3], c_nodes); atomicAdd(&stats[4], c_leaves); atomicMax(&stats[8], (unsigned long long)c_maxsp);
                           if (lane == 0) { atomicAdd(&stats[13], w_iters); atomicAdd(&stats[14], w_leaf_iters); atomicAdd(&stats[15], w_leaf_lanes); } }
     if (stats && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&stats[0], (unsigned long long)n);
@@ -871,21 +798,8 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_closest4(BvhView B, co
                 bool done = false, skip = false;
                 if (cur == NONE) {   // pop the nearest deferred subtree that still beats `closest`
                     bool found = false;
-#if MR_CL_POP1 == 2   // two entries looked at per iteration (both LDS reads in flight together): the first that survives is taken
-                    if (sp > 0) {
-                        const int s1 = sp - 1, s2 = sp > 1 ? sp - 2 : 0;
-                        const uint2 e1 = (s1 < MR_LDS_STACK) ? lds_stack[s1 * MR_TRACE_BLOCK] : spill[s1 - MR_LDS_STACK];
-                        const uint2 e2 = (s2 < MR_LDS_STACK) ? lds_stack[s2 * MR_TRACE_BLOCK] : spill[s2 - MR_LDS_STACK];
-                        const float t1 = __uint_as_float(e1.y), t2 = __uint_as_float(e2.y);
-                        found = true;
-                        if (closest > t1) { cur = (int)e1.x; sp = s1; }
-                        else {
-                            if (closest == t1 && any_hit) need_redo = true;
-                            if (sp > 1 && closest > t2) { cur = (int)e2.x; sp = s2; }
-                            else { if (sp > 1 && closest == t2 && any_hit) need_redo = true; sp = sp > 1 ? s2 : s1; skip = true; }
-                        }
-                    }
-#elif MR_CL_POP1   // at most one pop per iteration: a culled entry costs this lane an iteration instead of making the whole wave wait for the longest run of culled entries
+                    // at most one pop per iteration: a culled entry costs this lane an iteration instead of making the whole wave wait for the longest run of
+                    // culled entries (rounds 1-4 popped until an entry survived)
                     if (sp > 0) {
                         --sp;
                         const uint2 e = (sp < MR_LDS_STACK) ? lds_stack[sp * MR_TRACE_BLOCK] : spill[sp - MR_LDS_STACK];
@@ -893,15 +807,6 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_closest4(BvhView B, co
                         if (closest > etn) { cur = (int)e.x; found = true; }
                         else { if (closest == etn && any_hit) need_redo = true; found = true; skip = true; }
                     }
-#else
-                    while (sp > 0) {
-                        --sp;
-                        const uint2 e = (sp < MR_LDS_STACK) ? lds_stack[sp * MR_TRACE_BLOCK] : spill[sp - MR_LDS_STACK];
-                        const float etn = __uint_as_float(e.y);
-                        if (closest > etn) { cur = (int)e.x; found = true; break; }
-                        if (closest == etn && any_hit) need_redo = true;   // culled on equality: a tie the reference's order could resolve differently
-                    }
-#endif
                     if (!found) done = true;
                 }
                 if (!done && !skip) {
@@ -961,7 +866,6 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_closest4(BvhView B, co
                         const int ref[4] = {(int)rf.x, (int)rf.y, (int)rf.z, (int)rf.w};
                         float tn4[4], tf4[4];
                         child_slabs(nc, t_min, tn4, tf4);
-#if MR_CL_SORTNET
                         // children that may still hold something nearer, nearest first: a five-comparator sorting network over (entry distance, reference), a child that
                         // cannot matter carrying +inf (round 5; rounds 1-4 inserted one child after the other into a sorted list: sixteen predicated swaps of which the
                         // compiler keeps all — the node branch of this kernel was nearly twice the shadow-ray kernel's). Any order gives the same minimum (see above).
@@ -978,7 +882,7 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_closest4(BvhView B, co
                         cur = NONE;
                         if (nn > 0) {
                             cur = sr[0];
-                            if (MR_CL_FASTPUSH && sp + 3 <= MR_LDS_STACK) {      // all three possible entries fit the LDS part (the usual case): no per-entry range checks
+                            if (sp + 3 <= MR_LDS_STACK) {      // all three possible entries fit the LDS part (the usual case): no per-entry range checks
 #pragma unroll
                                 for (int q = 3; q >= 1; q--) {
                                     if (q < nn) { uint2 e; e.x = (uint32_t)sr[q]; e.y = __float_as_uint(sk[q]); lds_stack[sp * MR_TRACE_BLOCK] = e; sp++; }
@@ -996,37 +900,6 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_closest4(BvhView B, co
                             }
                             if (COUNT) c_maxsp = sp > c_maxsp ? sp : c_maxsp;
                         }
-#else
-                        // children that may still hold something nearer, kept in descending entry distance (n <= 4)
-                        int nref[4]; float ntn[4]; int nn = 0;
-#pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            float tn = tn4[k]; const float tf = tf4[k];
-                            if (COUNT && ref[k] != ~B.T) c_boxes++;
-                            if (tf > tn && closest > tn) {   // unused slots: see k_trace_any4q
-                                int r = ref[k];
-#pragma unroll
-                                for (int q = 0; q < 4; q++) {
-                                    if (q < nn && ntn[q] < tn) { const int tr_ = nref[q]; const float tt_ = ntn[q]; nref[q] = r; ntn[q] = tn; r = tr_; tn = tt_; }
-                                }
-                                nref[nn] = r; ntn[nn] = tn; nn++;
-                            }
-                        }
-                        cur = NONE;
-                        if (nn > 0) {
-                            cur = nref[nn - 1];
-#pragma unroll
-                            for (int q = 0; q < 3; q++) {
-                                if (q < nn - 1) {
-                                    uint2 e; e.x = (uint32_t)nref[q]; e.y = __float_as_uint(ntn[q]);
-                                    if (sp < MR_LDS_STACK) lds_stack[sp * MR_TRACE_BLOCK] = e;
-                                    else if (sp < MR_STACK) spill[sp - MR_LDS_STACK] = e;
-                                    if (sp < MR_STACK) sp++; else need_redo = true;   // a full stack hands the ray to the reference-order kernel, whose stack cannot overflow
-                                }
-                            }
-                            if (COUNT) c_maxsp = sp > c_maxsp ? sp : c_maxsp;
-                        }
-#endif
                     }
                 }
                 if (done) { have = false; fin = true; }

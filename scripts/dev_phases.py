@@ -1,4 +1,5 @@
-"""Dev (GPU box, library built with -DMR_EXP_PHASES, MIRRES_LIB=ab/libmirres_PHASES.so): cycles a shadow-ray wave spends per phase."""
+"""Dev (GPU box, library built with -DMR_EXP_PHASES, MIRRES_LIB=ab/libmirres_PHASES.so): cycles a shadow-ray wave spends per phase.
+The instrumentation (MR_EXP_PHASES in bvh_trace.hip) left the tree at the end of round 5; check out commit 8981516 to rebuild it."""
 import ctypes as C, sys, os
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
