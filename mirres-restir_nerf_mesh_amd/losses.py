@@ -117,11 +117,13 @@ def offsets_loss(voffsets, n_inner=None):
     return (voffsets[:n_inner].abs() ** 2).sum(-1).mean() + 0.1 * (voffsets[n_inner:].abs() ** 2).sum(-1).mean()
 
 
-def stage1_loss(outputs, gt_rgb, gt_rgb_linear, opt, vertices=None, voffsets=None, triangles=None, n_inner=None):
+def stage1_loss(outputs, gt_rgb, gt_rgb_linear, opt, vertices=None, voffsets=None, triangles=None, n_inner=None, criterion_lpips=None, frame_hw=None):
     """The stage-1 scalar of Trainer.train_step (nerf/utils.py:1003-1017, 1043-1126) from render_stage1's outputs.
 
-    `opt` carries the reference's --lambda_* fields (main.py:81-113) and use_brdf; missing fields take main.py's defaults.  Mask, LPIPS and
-    refine-error terms of the reference need its data loader / LPIPS network and are outside this path."""
+    `opt` carries the reference's --lambda_* fields (main.py:81-113) and use_brdf; missing fields take main.py's defaults.  The perceptual term
+    (--lambda_lpips > 0, default 0; utils.py:1079-1082) needs `criterion_lpips` (meters.LPIPS with the user's pretrained weights; the reference calls it
+    on the [0, 1] images without `normalize`, kept) and the frame's (H, W); mask and refine-error terms need the reference's data loader and are outside
+    this path."""
     g = lambda k, d: getattr(opt, k, d)
     use_brdf = g("use_brdf", True)
     loss = 0.0
@@ -139,6 +141,15 @@ def stage1_loss(outputs, gt_rgb, gt_rgb_linear, opt, vertices=None, voffsets=Non
                                                lambda_ks=g("lambda_ks", 0.0025), lambda_nrm=g("lambda_nrm", 0.00025))
         if g("lambda_extra_kd", 0.0) > 0:
             loss = loss + material_extra_kd_smoothness_grad(outputs["kd_grad"], outputs["normal_ao"].reshape(outputs["kd_grad"].shape), g("lambda_extra_kd", 0.0))
+    if g("lambda_lpips", 0.0) > 0:
+        if criterion_lpips is None or frame_hw is None:
+            raise ValueError("stage1_loss: lambda_lpips > 0 needs criterion_lpips (meters.LPIPS with pretrained weights) and frame_hw")
+        H, W = frame_hw
+        img4 = lambda x: x.view(1, H, W, 3).permute(0, 3, 1, 2).contiguous()
+        if "image" in outputs:
+            loss = loss + g("lambda_lpips", 0.0) * criterion_lpips(img4(outputs["image"]), img4(gt_rgb)).reshape(())
+        if use_brdf:
+            loss = loss + g("lambda_lpips", 0.0) * criterion_lpips(img4(outputs["image_brdf"]), img4(gt_rgb)).reshape(())
     if vertices is not None and voffsets is not None:
         moved = vertices + voffsets                                                                 # act_voffsets is the identity (utils.py:341-347)
         if g("lambda_lap", 0.001) > 0:

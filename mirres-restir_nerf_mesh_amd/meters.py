@@ -3,8 +3,12 @@
 PSNRMeter is checked against the reference's own class (tests/golden/gen_reference_losses.py).  SSIMMeter calls torchmetrics'
 `structural_similarity_index_measure` in the reference; torchmetrics is not in the reference tree or this image, so `ssim` restates its published
 defaults (Wang et al. 2004: 11 x 11 Gaussian window, sigma 1.5, k1 0.01, k2 0.03, data range = the larger of the two inputs' value ranges, mean over
-the window positions that lie fully inside the image) — unpinned, checked against a direct per-window evaluation.  LPIPS needs its pretrained
-network and is not provided.  Images are written as PNG with the standard library (cv2 / imageio are not dependencies).
+the window positions that lie fully inside the image) — unpinned, checked against a direct per-window evaluation.  LPIPSMeter calls the `lpips`
+package in the reference (net 'vgg'); neither that package, torchvision nor any pretrained weights are in this image, so `LPIPS` restates the published
+network (Zhang et al. 2018, version 0.1: VGG-16 features at relu1_2 ... relu5_3, unit-normalised over channels, squared difference, one non-negative
+1 x 1 head per tap, spatial mean, sum over the taps) and takes its weights from files the user supplies (torchvision's vgg16 state dict + the package's
+vgg.pth, or one state dict of lpips.LPIPS): unpinned, checked against a plain numpy evaluation of the same formula; without weights it refuses to
+construct instead of scoring with random ones.  Images are written as PNG with the standard library (cv2 / imageio are not dependencies).
 """
 import os
 import struct
@@ -13,7 +17,7 @@ import zlib
 import numpy as np
 import torch
 
-__all__ = ["PSNRMeter", "SSIMMeter", "ssim", "to_uint8", "write_png", "write_test_frame"]
+__all__ = ["PSNRMeter", "SSIMMeter", "LPIPSMeter", "LPIPS", "ssim", "to_uint8", "write_png", "write_test_frame"]
 
 
 class PSNRMeter:
@@ -80,6 +84,107 @@ class SSIMMeter:
 
     def report(self):
         return "SSIM = %.6f" % self.measure()
+
+
+# VGG-16 `features` indices of the 13 convolutions (torchvision numbering: ReLUs and the 2 x 2 max-pools take the indices between) and the five taps
+_VGG_CONVS = ((0, 3, 64), (2, 64, 64), (5, 64, 128), (7, 128, 128), (10, 128, 256), (12, 256, 256), (14, 256, 256),
+              (17, 256, 512), (19, 512, 512), (21, 512, 512), (24, 512, 512), (26, 512, 512), (28, 512, 512))
+_VGG_POOL_BEFORE = (5, 10, 17, 24)           # a max-pool precedes these convolutions
+_VGG_TAPS = (2, 7, 14, 21, 28)               # relu1_2, relu2_2, relu3_3, relu4_3, relu5_3 follow these convolutions
+_LPIPS_SHIFT, _LPIPS_SCALE = (-0.030, -0.088, -0.188), (0.458, 0.448, 0.450)
+
+
+class LPIPS(torch.nn.Module):
+    """lpips.LPIPS(net='vgg') (version 0.1, lpips=True, spatial=False) as the reference constructs it (nerf/utils.py:522, 796): forward(in0, in1,
+    normalize=False) -> [B, 1, 1, 1]; inputs [B, 3, H, W] in [-1, 1], or in [0, 1] with normalize=True (what LPIPSMeter passes).
+
+    Weights: `vgg` = torchvision's vgg16 state dict (keys features.<i>.weight / .bias; classifier.* ignored) and `lin` = the package's weights/v0.1/vgg.pth
+    (keys lin<k>.model.1.weight, [1, C, 1, 1]) — each a path for torch.load or a dict —, or `vgg` alone = a state dict of lpips.LPIPS itself
+    (net.slice<k>.<i>.weight ..., lin<k>.model.1.weight).  There are no defaults: a perceptual score from random weights would be a number without meaning."""
+
+    def __init__(self, net="vgg", vgg=None, lin=None):
+        super().__init__()
+        if net != "vgg":
+            raise NotImplementedError("LPIPS: the reference uses net='vgg' (nerf/utils.py:516, 796)")
+        if vgg is None:
+            raise RuntimeError("LPIPS needs pretrained weights (torchvision vgg16 + lpips v0.1 vgg.pth); none ship with this image — pass vgg= / lin=")
+        load = lambda x: torch.load(x, map_location="cpu") if isinstance(x, (str, bytes, os.PathLike)) else dict(x)
+        sd = load(vgg)
+        if lin is not None:
+            sd = dict(sd); sd.update(load(lin))
+        self.convs = torch.nn.ModuleList([torch.nn.Conv2d(ci, co, 3, padding=1) for _, ci, co in _VGG_CONVS])
+        self.lins = torch.nn.ModuleList([torch.nn.Conv2d(c, 1, 1, bias=False) for c in (64, 128, 256, 512, 512)])
+        packaged = any(k.startswith("net.slice") for k in sd)
+        with torch.no_grad():
+            for conv, (idx, ci, co) in zip(self.convs, _VGG_CONVS):
+                if packaged:         # lpips keeps torchvision's layer numbers inside its five slices
+                    sl = 1 + sum(idx >= b - 1 for b in _VGG_POOL_BEFORE)          # the max-pool (index b - 1) opens the next slice
+                    key = "net.slice%d.%d" % (sl, idx)
+                else:
+                    key = "features.%d" % idx
+                if key + ".weight" not in sd:
+                    raise KeyError("LPIPS: %s.weight missing from the VGG-16 weights" % key)
+                w, b = sd[key + ".weight"], sd[key + ".bias"]
+                if tuple(w.shape) != (co, ci, 3, 3):
+                    raise ValueError("LPIPS: %s.weight has shape %s, VGG-16 needs %s" % (key, tuple(w.shape), (co, ci, 3, 3)))
+                conv.weight.copy_(w); conv.bias.copy_(b)
+            for k, l in enumerate(self.lins):
+                key = "lin%d.model.1.weight" % k
+                if key not in sd:
+                    raise KeyError("LPIPS: %s missing (the package's weights/v0.1/vgg.pth holds the five heads)" % key)
+                l.weight.copy_(sd[key].reshape(l.weight.shape))
+        self.register_buffer("shift", torch.tensor(_LPIPS_SHIFT).view(1, 3, 1, 1)); self.register_buffer("scale", torch.tensor(_LPIPS_SCALE).view(1, 3, 1, 1))
+        for q in self.parameters():
+            q.requires_grad_(False)
+
+    def features(self, x):
+        taps = []
+        for conv, (idx, _, _) in zip(self.convs, _VGG_CONVS):
+            if idx in _VGG_POOL_BEFORE:
+                x = torch.nn.functional.max_pool2d(x, 2, 2)
+            x = torch.relu(conv(x))
+            if idx in _VGG_TAPS:
+                taps.append(x)
+        return taps
+
+    def forward(self, in0, in1, normalize=False):
+        if normalize:
+            in0, in1 = 2 * in0 - 1, 2 * in1 - 1
+        f0, f1 = self.features((in0 - self.shift) / self.scale), self.features((in1 - self.shift) / self.scale)
+        val = 0
+        for a, b, l in zip(f0, f1, self.lins):
+            a = a / (torch.sqrt(torch.sum(a * a, dim=1, keepdim=True)) + 1e-10); b = b / (torch.sqrt(torch.sum(b * b, dim=1, keepdim=True)) + 1e-10)
+            val = val + l((a - b) ** 2).mean(dim=(2, 3), keepdim=True)
+        return val
+
+
+class LPIPSMeter:
+    """nerf/utils.py:515-553: [B, H, W, 3] (or [H, W, 3]) inputs in [0, 1]; update() scores fn(truths, preds, normalize=True) and keeps the running mean.
+    `vgg` / `lin` as for LPIPS; when both are None they are taken from MIRRES_LPIPS_VGG / MIRRES_LPIPS_LIN (paths), and without those the meter refuses."""
+
+    def __init__(self, net="vgg", device=None, vgg=None, lin=None):
+        self.net = net
+        self.device = device if device is not None else torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        if vgg is None:
+            vgg, lin = os.environ.get("MIRRES_LPIPS_VGG"), os.environ.get("MIRRES_LPIPS_LIN")
+        self.fn = LPIPS(net=net, vgg=vgg, lin=lin).eval().to(self.device)
+        self.clear()
+
+    def clear(self):
+        self.V = 0.0; self.N = 0
+
+    def update(self, preds, truths):
+        prep = lambda z: (z[None] if z.dim() == 3 else z).permute(0, 3, 1, 2).contiguous().to(self.device, torch.float32)
+        with torch.no_grad():
+            v = self.fn(prep(truths), prep(preds), normalize=True).item()
+        self.V += v; self.N += 1
+        return v
+
+    def measure(self):
+        return self.V / self.N
+
+    def report(self):
+        return "LPIPS (%s) = %.6f" % (self.net, self.measure())
 
 
 def to_uint8(img):

@@ -75,6 +75,8 @@ def main():
     p.add_argument("--envmap_path", default="None", help="main.py --envmap_path: Radiance .hdr environment map for relighting")
     p.add_argument("--albedo_scale_x", type=float, default=1.0); p.add_argument("--albedo_scale_y", type=float, default=1.0); p.add_argument("--albedo_scale_z", type=float, default=1.0)
     p.add_argument("--shard", choices=("views", "strips", "spp"), default="views", help="how N > 1 ranks (torch.distributed.run) divide the work")
+    p.add_argument("--lpips_vgg", default=None, help="torchvision vgg16 state dict (or a state dict of lpips.LPIPS): adds the reference's LPIPS (vgg) meter; no weights ship with the image")
+    p.add_argument("--lpips_lin", default=None, help="the lpips package's weights/v0.1/vgg.pth (the five linear heads)")
     a = p.parse_args()
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
@@ -114,6 +116,7 @@ def main():
     intr = (focal, focal, Ww * 0.5, Hh * 0.5)
     frames = tf["frames"][: a.limit] if a.limit > 0 else tf["frames"]
     pm, sm = meters.PSNRMeter(), meters.SSIMMeter()
+    lm = meters.LPIPSMeter(vgg=a.lpips_vgg, lin=a.lpips_lin) if a.lpips_vgg else None        # main.py:250: [PSNRMeter(), SSIMMeter(), LPIPSMeter(device=device)]
     name = os.path.splitext(os.path.basename(a.ckpt))[0]
     if world == 1 or a.shard == "views":
         # the engine context of the frame size and its batch pool (tens of GB: one hipMalloc + clear) are set up here, not inside the first view's timed region
@@ -149,17 +152,21 @@ def main():
                 gt = gt[..., :3] * gt[..., 3:] + (1 - gt[..., 3:])                      # white background, as the reference's loader composes it
             gt_t = torch.from_numpy(gt).cuda()
             note = "  PSNR %.3f  SSIM %.4f" % (pm.update(img, gt_t), sm.update(img, gt_t))
+            if lm is not None:
+                note += "  LPIPS %.4f" % lm.update(img, gt_t)
         print("[%d/%d] %s%s" % (i + 1, len(frames), os.path.basename(files[0]), note), flush=True)
     n = len(frames)
     if world > 1:      # wall time of the job = the slowest rank; metric sums over the ranks that scored frames
-        red = torch.tensor([t_render, pm.V, float(pm.N), sm.V, float(sm.N)], dtype=torch.float64, device="cuda")
+        red = torch.tensor([t_render, pm.V, float(pm.N), sm.V, float(sm.N), lm.V if lm else 0.0, float(lm.N) if lm else 0.0], dtype=torch.float64, device="cuda")
         tmax = red[:1].clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX); dist.all_reduce(red, op=dist.ReduceOp.SUM)
         t_render = float(tmax.item()); pm.V, pm.N, sm.V, sm.N = float(red[1]), int(red[2]), float(red[3]), int(red[4])
+        if lm:
+            lm.V, lm.N = float(red[5]), int(red[6])
     if rank == 0:
         print("rendered %d views %dx%d ssaa %d spp %d on %d GPU(s)%s: %.1f ms/view (%.1f Msamples/s)" % (
             n, Ww, Hh, a.ssaa, a.spp, world, (" [%s]" % a.shard) if world > 1 else "", 1e3 * t_render / max(n, 1), n * Ww * Hh * a.ssaa ** 2 * a.spp / max(t_render, 1e-9) / 1e6))
         if pm.N:
-            print(pm.report(), sm.report())
+            print(pm.report(), sm.report(), lm.report() if lm and lm.N else "")
     if world > 1:
         dist.destroy_process_group()
 
