@@ -394,7 +394,8 @@ def test_two_rank_strip_render_equals_single_gpu(tmp_path):
     import torch
     import torch.multiprocessing as mp
     port = 33500 + (os.getpid() % 2000)
-    mp.spawn(_strip_rank, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    from util import spawn_ranks
+    spawn_ranks(_strip_rank, (2, port, str(tmp_path)), 2)
     r0 = torch.load(os.path.join(tmp_path, "strip0.pt")); r1 = torch.load(os.path.join(tmp_path, "strip1.pt"))
     for k in range(6):
         assert torch.equal(r0["outs"][k], r0["ref"][k]), "rank 0 buffer %d" % k

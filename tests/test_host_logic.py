@@ -7,6 +7,8 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from util import spawn_ranks  # noqa: E402
 
 
 def test_scene_is_deterministic_and_well_formed(scene_mod):
@@ -79,7 +81,7 @@ def test_allreduce_exchange_gloo_world2(tmp_path):
     import torch
     import torch.multiprocessing as mp
     port = 29500 + (os.getpid() % 2000)
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    spawn_ranks(_worker, (2, port, str(tmp_path)), 2)
     r0 = torch.load(os.path.join(tmp_path, "r0.pt")); r1 = torch.load(os.path.join(tmp_path, "r1.pt"))
     for k in range(6):
         expect = r0["local"][k] + r1["local"][k]
@@ -160,7 +162,7 @@ def _times_worker(rank, world, port, out):
 def test_strip_times_are_gathered_in_rank_order_gloo_world2():
     import torch.multiprocessing as mp
     mgr = mp.Manager(); out = mgr.dict()
-    mp.spawn(_times_worker, args=(2, 29600 + (os.getpid() % 200), out), nprocs=2, join=True)
+    spawn_ranks(_times_worker, (2, 29600 + (os.getpid() % 200), out), 2)
     assert out[0] == [10.0, 11.0] and out[1] == [10.0, 11.0]
 
 
@@ -190,7 +192,7 @@ def test_strip_exchange_and_gather_gloo_world2(tmp_path):
     import torch
     import torch.multiprocessing as mp
     port = 31500 + (os.getpid() % 2000)
-    mp.spawn(_strip_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    spawn_ranks(_strip_worker, (2, port, str(tmp_path)), 2)
     fy, fx = 100, 6
     gy = torch.arange(fy, dtype=torch.float32)[:, None, None] * 1000 + torch.arange(fx, dtype=torch.float32)[None, :, None] * 10 + torch.arange(8, dtype=torch.float32)[None, None, :]
     for r in range(2):
@@ -235,7 +237,7 @@ def test_gradient_allreduce_gloo(tmp_path, algo, world):
     import torch
     import torch.multiprocessing as mp
     port = 35500 + (os.getpid() % 2000) + (7 if algo == "direct" else 0) + world
-    mp.spawn(_grad_worker, args=(world, port, str(tmp_path), algo), nprocs=world, join=True)
+    spawn_ranks(_grad_worker, (world, port, str(tmp_path), algo), world)
     ds = [torch.load(os.path.join(tmp_path, "g%d.pt" % r)) for r in range(world)]
     want = ds[0]["mine"].clone()
     for r in range(1, world):

@@ -291,3 +291,19 @@ def rasterize_ref_homogeneous(pos_clip, tri, H, W):
         gap = np.where(np.isfinite(best_z), np.minimum(second_z - best_z, plane), plane)
     return rast, db, edge, gap
 
+
+def spawn_ranks(fn, args, nprocs, limit=300):
+    """torch.multiprocessing.spawn with a deadline: a rendezvous or an exchange that never completes fails the test instead of hanging the suite (the processes
+    started here are killed by their own handles)."""
+    import time
+    import pytest
+    import torch.multiprocessing as mp
+    pc = mp.spawn(fn, args=args, nprocs=nprocs, join=False)
+    deadline = time.time() + limit
+    while not pc.join(timeout=5):
+        if time.time() > deadline:
+            for pr in pc.processes:
+                if pr.is_alive():
+                    pr.kill()
+            pytest.fail("%d ranks of %s did not finish within %d s" % (nprocs, getattr(fn, "__name__", "worker"), limit))
+
