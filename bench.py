@@ -280,6 +280,10 @@ def train_step_record(S, torch, dev, W, steps=3):
 
 def main():
     args = parse()
+    # stdout carries the ONE JSON line and nothing else: whatever the mirrored reference modules print on the way (load_m_for_restir's "Create neighbor offset time
+    # consumed", as nerf/renderer_restir.py:227 does) goes to stderr
+    out_stream = sys.stdout
+    sys.stdout = sys.stderr
     import numpy as np
     import torch
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -490,7 +494,7 @@ def main():
                 b_, t_ = balancer.history[-1]
                 line["config"]["strip_balance"] = {"bounds": b_, "strip_ms": [round(x, 2) for x in t_], "max_over_mean": round(max(t_) / (sum(t_) / len(t_)), 4),
                                                    "note": "last exchanged strip render times (dist.StripBalancer): boundaries follow them from frame to frame"}
-        print(json.dumps(line), flush=True)
+        print(json.dumps(line), file=out_stream, flush=True)
     if world > 1:
         dist.destroy_process_group()
     if parity_failed:
