@@ -5,4 +5,4 @@ mkdir -p gpurun_out/r05
 SHA=$(python3 -c 'import bench; print(bench.csrc_sha())')
 { echo "csrc_sha $SHA"; timeout -k 10 1500 python3 scripts/dev_parity_big.py --res 1600 --spp 512 2>&1 | grep -v amdgpu.ids; } > gpurun_out/r05/fullsize_512spp_parity_final.txt
 { echo "csrc_sha $SHA"; MIRRES_MESH=clustered timeout -k 10 2400 python3 scripts/dev_parity_big.py --res 1600 --spp 512 2>&1 | grep -v amdgpu.ids; } > gpurun_out/r05/clustered_fullsize_512spp_parity_final.txt
-tail -3 gpurun_out/r05/fullsize_512spp_parity_final.txt gpurun_out/r05/clustered_fullsize_512spp_parity_final.txt
+tail -n 3 gpurun_out/r05/fullsize_512spp_parity_final.txt; tail -n 3 gpurun_out/r05/clustered_fullsize_512spp_parity_final.txt
