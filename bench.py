@@ -458,7 +458,7 @@ def main():
         fc = out[0]
         fgm = g["occ"][:, 0] > 0.5
         fg_frac = float(fgm.float().mean().item())
-        par = {"spp": "sample slices + one all-reduce of the six accumulators (statistically equivalent frame)",
+        par = {"spp": "sample slices + one sum over the ranks of the four accumulators the finish reads, foreground pixels only (all-to-all of slices, rank-ordered local sum, all-gather; statistically equivalent frame)",
                "strips": "row strips + per-sample reservoir halo exchange + all-gather of radiance rows (bit-identical to one GPU)"}
         mesh_words = MESH_WORDS[args.mesh]
         line = {"metric": "Msamples/s (pixels x spp), ReSTIR-DI + %d-bounce path tracing forward render" % (args.bounces + 1),
