@@ -11,8 +11,8 @@ visibility, nvdiffrast's job in the reference) is built once outside the timed r
 
 N > 1: the one frame is shared by the ranks (mirres-restir_nerf_mesh_amd/dist.py) — total work is fixed, i.e. STRONG scaling, as BASELINE's "at
 1/2/4/8 GPU" — and BOTH sharding schemes are timed in the same run: `strips` = the north-star's pixel split (row strips, per-sample reservoir halo exchange,
-all-gather of radiance rows; bit-identical to one GPU; boundaries balanced from the strips' measured times) and `spp` = sample slices + one all-reduce (RCCL) of the
-accumulators (statistically equivalent frame). `value` is the exact scheme's when it wins or is within 2 %, otherwise the faster one's; `config.value_scheme` says
+all-gather of radiance rows; bit-identical to one GPU; boundaries balanced from the strips' measured times) and `spp` = sample slices + one sum over the ranks of the
+accumulators the finish reads (dist.sum_over_ranks: all-to-all of slices, rank-ordered local sum, all-gather over RCCL; statistically equivalent frame). `value` is the exact scheme's when it wins or is within 2 %, otherwise the faster one's; `config.value_scheme` says
 which, and the other scheme is reported beside it with its ratio.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (traversal kernel, measured live with HIP events on the
@@ -43,8 +43,8 @@ def parse():
                         "thin plates, triangle areas spread > 1e5 : 1). The default run reports the other mesh as a sub-record")
     p.add_argument("--no-extras", action="store_true", help="skip the sub-records of the default single-GPU run (the other mesh, the configs[2] training step)")
     p.add_argument("--shard", choices=("both", "strips", "spp"), default="both",
-                   help="N > 1: `spp` = sample slices + one all-reduce (the timed `value`), `strips` = exact row strips + per-sample halo exchange + all-gather (the north-star's "
-                        "tile split, reported as the `strips` sub-record), `both` = time the two schemes one after the other")
+                   help="N > 1: `spp` = sample slices + one sum of the accumulators over the ranks, `strips` = exact row strips + per-sample halo exchange + all-gather (the north-star's "
+                        "tile split), `both` = time the two schemes one after the other; `value` is the exact scheme's when it wins or ties (config.value_scheme)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-roofline", action="store_true")
     p.add_argument("--const-material", action="store_true", help="constant material instead of the hash-grid + MLP field")
