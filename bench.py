@@ -12,8 +12,8 @@ visibility, nvdiffrast's job in the reference) is built once outside the timed r
 N > 1: the one frame is shared by the ranks (mirres-restir_nerf_mesh_amd/dist.py) — total work is fixed, i.e. STRONG scaling, as BASELINE's "at
 1/2/4/8 GPU" — and BOTH sharding schemes are timed in the same run: `strips` = the north-star's pixel split (row strips, per-sample reservoir halo exchange,
 all-gather of radiance rows; bit-identical to one GPU; boundaries balanced from the strips' measured times) and `spp` = sample slices + one sum over the ranks of the
-accumulators the finish reads (dist.sum_over_ranks: all-to-all of slices, rank-ordered local sum, all-gather over RCCL; statistically equivalent frame). `value` is the exact scheme's when it wins or is within 2 %, otherwise the faster one's; `config.value_scheme` says
-which, and the other scheme is reported beside it with its ratio.
+accumulators the finish reads (dist.sum_over_ranks: all-to-all of slices, rank-ordered local sum, all-gather over RCCL; statistically equivalent frame). `value` is the
+DECLARED scheme's (--value-scheme, default `spp`; `config.value_scheme` repeats it); the other scheme is reported beside it with its ratio.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (traversal kernel, measured live with HIP events on the
 launch stream) and `cpu_baseline` (the CPU oracle on a bounded sample; rank 0, N=1 only).
@@ -44,7 +44,9 @@ def parse():
     p.add_argument("--no-extras", action="store_true", help="skip the sub-records of the default single-GPU run (the other mesh, the configs[2] training step)")
     p.add_argument("--shard", choices=("both", "strips", "spp"), default="both",
                    help="N > 1: `spp` = sample slices + one sum of the accumulators over the ranks, `strips` = exact row strips + per-sample halo exchange + all-gather (the north-star's "
-                        "tile split), `both` = time the two schemes one after the other; `value` is the exact scheme's when it wins or ties (config.value_scheme)")
+                        "tile split), `both` = time the two schemes one after the other; `value` is --value-scheme's")
+    p.add_argument("--value-scheme", choices=("spp", "strips"), default="spp",
+                   help="N > 1 with both schemes timed: which one the line's `value` is — declared here, not chosen after the fact (ADVICE r5); the other is reported beside it")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-roofline", action="store_true")
     p.add_argument("--const-material", action="store_true", help="constant material instead of the hash-grid + MLP field")
@@ -101,12 +103,23 @@ MLP_ROOF = {"bound": "mfma", "peak": 157.3, "instruction": "v_mfma_f32_32x32x2_f
                     "(the 6-row output layer occupies a 32-row tile): issued_frac = that rate against the same peak"}
 
 
-def csrc_sha():
-    """Identity of the native sources a counter snapshot belongs to: sha256 over csrc/*.hip, csrc/*.hpp and include/*.h (the GPU box has no .git)."""
+# Which sources a counter snapshot depends on (round 6): a change in raster.hip must not stale the traversal counters. Every group holds the shared
+# headers; "traversal" = the shadow-ray / closest-hit kernels and the hierarchy they walk; "chain" = every kernel of a frame; "train" = + the backward kernels.
+_HDRS = ("engine.hpp", "device_math.hpp", "device_brdf.hpp", "device_grid.hpp", "device_light.hpp")
+SHA_GROUPS = {"traversal": ("bvh_trace.hip", "bvh_build.hip") + _HDRS,
+              "chain": ("bvh_trace.hip", "bvh_build.hip", "passes.hip", "shading.hip", "matnet.hip", "render.hip") + _HDRS,
+              "train": ("bvh_trace.hip", "bvh_build.hip", "passes.hip", "shading.hip", "matnet.hip", "render.hip", "backward.hip", "eaw.hip") + _HDRS}
+SNAPSHOT_GROUP = {"pmc_any4q_summary.json": "traversal", "pmc_traffic.json": "chain", "pmc_chain_summary.json": "chain", "pmc_train_summary.json": "train"}
+
+
+def csrc_sha(group=None):
+    """Identity of the native sources a counter snapshot belongs to (the GPU box has no .git): sha256 over the files of `group` (SHA_GROUPS) + include/*.h; without a
+    group, over every csrc/*.hip, csrc/*.hpp and include/*.h (the identity A/B files and run logs carry)."""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "mirres-restir_nerf_mesh_amd", "csrc")
-    files = sorted(os.path.join(d, f) for f in os.listdir(d) if f.endswith((".hip", ".hpp"))) + sorted(os.path.join(ROOT, "include", f) for f in os.listdir(os.path.join(ROOT, "include")) if f.endswith(".h"))
+    names = sorted(f for f in os.listdir(d) if f.endswith((".hip", ".hpp"))) if group is None else sorted(SHA_GROUPS[group])
+    files = [os.path.join(d, f) for f in names] + sorted(os.path.join(ROOT, "include", f) for f in os.listdir(os.path.join(ROOT, "include")) if f.endswith(".h"))
     for f in files:
         h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
     return h.hexdigest()[:12]
@@ -116,7 +129,7 @@ def pmc_snapshot():
     """Hardware-counter figures cannot be collected inside this process (rocprofv3 --pmc runs are separate, scripts/pmc_*.sh); the committed summaries are
     reported ONLY while they belong to the sources the library was built from (the snapshot records csrc_sha at collection time). Otherwise: stale, no numbers."""
     snap = {}
-    for fn_ in ("pmc_any4q_summary.json", "pmc_traffic.json", "pmc_chain_summary.json"):
+    for fn_ in SNAPSHOT_GROUP:
         path = os.path.join(ROOT, "profiles", fn_)
         try:
             d = json.load(open(path))
@@ -124,11 +137,11 @@ def pmc_snapshot():
             continue
         d["_file"] = "profiles/" + fn_
         snap[fn_] = d
-    cur = csrc_sha()
-    out = {"csrc_sha_now": cur}
+    out = {"csrc_sha_now": {g_: csrc_sha(g_) for g_ in sorted(set(SNAPSHOT_GROUP.values()))}}
     for fn_, d in snap.items():
-        fresh = d.get("csrc_sha") == cur
-        key = "counters" if "any4q" in fn_ else ("chain" if "chain" in fn_ else "traffic")
+        grp = SNAPSHOT_GROUP[fn_]
+        fresh = d.get("csrc_sha") == out["csrc_sha_now"][grp] and d.get("csrc_sha_group") == grp      # (snapshots of rounds 1-5 carry the all-files hash and no group: stale)
+        key = "counters" if "any4q" in fn_ else ("chain" if "chain" in fn_ else ("train" if "train" in fn_ else "traffic"))
         if fresh:
             out[key] = dict({k: v for k, v in d.items() if not k.startswith("_")}, source="static:%s@%s" % (d["_file"], d.get("csrc_sha")))
         else:
@@ -190,6 +203,7 @@ def traversal_roofline(args, ctx, W, mlp, env, g, prof_spp, step_ms, world, pmc)
     # which resource binds the kernel is read off the counters, not asserted: VALU pipes busy for most of the SIMD cycles while the HBM counters show a fraction of
     # the peak -> "valu-issue"; without a counter snapshot that belongs to the built sources the record says so
     hbm_frac = (traffic / launch_s / 1e9 / HBM) if (traffic and launch_s > 0) else None
+    valu_useful = round(valu_busy * lane_util, 4) if (valu_busy is not None and lane_util is not None) else None
     if valu_busy is None:
         bound = "unknown (no counter snapshot for these kernel sources: run scripts/profile_r04.sh)"
     elif valu_busy >= 0.6 and (hbm_frac is None or hbm_frac < valu_busy):
@@ -199,11 +213,12 @@ def traversal_roofline(args, ctx, W, mlp, env, g, prof_spp, step_ms, world, pmc)
     roof = {"bound": bound, "kernel": "k_trace_any4q (shadow-ray BVH traversal)",
             # the binding resource is VALU issue (the 43 MB node / leaf layout is cache resident): frac = SQ_ACTIVE_INST_VALU / SIMD cycles of the kernel, a hardware-counter
             # figure from the snapshot below (null when the snapshot does not belong to the built sources); everything else in this record is measured in this run
-            "achieved": (round(traffic / launch_s / 1e9, 1) if bound == "hbm" else valu_busy), "peak": (HBM if bound == "hbm" else 1.0),
-            "unit": ("GB/s" if bound == "hbm" else "VALU-busy cycles per SIMD cycle"), "frac": (round(hbm_frac, 4) if bound == "hbm" else valu_busy),
-            # frac is a BUSY fraction (the SIMDs issue a VALU instruction in that share of the kernel's cycles); the share of the VALU roof that does useful lane work is
-            # busy x lane utilisation (SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU)): divergence between node and leaf lanes and idle lanes between refills are in it
-            "valu_useful": (round(valu_busy * lane_util, 4) if (valu_busy is not None and lane_util is not None) else None), "lane_util": lane_util,
+            # frac is the THROUGHPUT fraction of the VALU roof (round 6): busy x lane utilisation = the share of the SIMDs' lane-cycles that do useful
+            # lane work (SQ_THREAD_CYCLES_VALU / (64 lanes x SIMD cycles)); the busy fraction alone (the SIMDs issue a VALU instruction in that share of the kernel's
+            # cycles — divergence between node and leaf lanes and idle lanes between refills are inside it) is kept beside it as valu_busy
+            "achieved": (round(traffic / launch_s / 1e9, 1) if bound == "hbm" else valu_useful), "peak": (HBM if bound == "hbm" else 1.0),
+            "unit": ("GB/s" if bound == "hbm" else "useful VALU lane-cycles per lane-cycle of the 1024 SIMDs"), "frac": (round(hbm_frac, 4) if bound == "hbm" else valu_useful),
+            "valu_busy": valu_busy, "valu_useful": valu_useful, "lane_util": lane_util,
             "traffic": traffic,
             "own_bytes": {"achieved": round(achieved, 2), "unit": "GB/s", "bytes_per_ray": round(own_bytes_any / max(1, rays_any), 1),
                           "l2_peak": L2, "l2_frac": round(achieved / L2, 5), "hbm_peak": HBM, "over_hbm_peak": round(achieved / HBM, 5),
@@ -374,13 +389,12 @@ def main():
         dist.all_reduce(bad, op=dist.ReduceOp.MAX)
         if float(bad.item()) > 0:
             results[sc] = (None, err or "failed on another rank")
-    # Which scheme the line's `value` is: the EXACT one (row strips: the north-star's pixel split, bit-identical to one GPU) whenever it was timed and is at least
-    # within 2 % of the sample-slice scheme; otherwise the faster one. Both are timed the same way (W warm-up + K steps between barriers, max over ranks) and the
-    # other is reported beside it with its ratio, so the choice is visible in the line.
+    # Which scheme the line's `value` is: DECLARED (--value-scheme, default the sample slices), never chosen by the outcome — a consumer comparing rounds reads the same
+    # quantity every time. Both schemes are timed the same way (W warm-up + K steps between barriers, max over ranks) and the other one (row strips: the north-star's
+    # pixel split, bit-identical to one GPU) is reported beside it with its ratio. A scheme that failed on some rank cannot be the value.
     primary = schemes[0]
-    if len(schemes) > 1 and results[schemes[1]][0] is not None:
-        d_spp, d_str = results["spp"][0], results["strips"][0]
-        primary = "strips" if d_str <= d_spp * 1.02 else "spp"
+    if len(schemes) > 1 and results[schemes[1]][0] is not None and args.value_scheme in results and results[args.value_scheme][0] is not None:
+        primary = args.value_scheme
     dt, out = results[primary]
     value = samples / dt / 1e6
     step_ms = dt / args.steps * 1e3

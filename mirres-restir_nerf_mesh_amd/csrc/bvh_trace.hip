@@ -433,6 +433,18 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_persist(BvhView B, con
 static_assert(MR_ANY_STACK >= 3 * (MR_SAH_LEVELS + (38 - MR_SAH_PREFIX) + 31), "MR_ANY_STACK must cover the deepest private hierarchy (DESIGN.md, stack bounds)");
 static_assert(MR_ANY_LDS >= 3 && MR_ANY_LDS <= MR_ANY_STACK, "the LDS part of the private stack holds at least one node's deferred references");
 #define MR_TOPBIT 0x20000000
+#ifndef MR_ANY_SEL
+#define MR_ANY_SEL 0
+#endif
+#ifndef MR_ANY_LEAFP
+#define MR_ANY_LEAFP 0
+#endif
+#ifndef MR_ANY_LEANREFILL
+#define MR_ANY_LEANREFILL 0
+#endif
+#ifndef MR_ANY_LEAFT
+#define MR_ANY_LEAFT 8
+#endif
 #ifndef MR_CL_REFILL
 #define MR_CL_REFILL MR_REFILL
 #endif
@@ -497,6 +509,21 @@ MR_DEV void child_slabs(const NodeCons& c, float t_min, float tn[4], float tf[4]
     child_slab<0>(c, t_min, tn[0], tf[0]); child_slab<1>(c, t_min, tn[1], tf[1]); child_slab<2>(c, t_min, tn[2], tf[2]); child_slab<3>(c, t_min, tn[3], tf[3]);
 }
 
+// normalize() / oct_decode() with the short reciprocal and square root (device_math.hpp) for arguments known to be in their exact range: a squared length in [1/3, 3]
+MR_DEV v3 normalize_lean(v3 v) {
+    const float dd = dot(v, v);
+    const float yr = __builtin_amdgcn_rsqf(dd); float sq = dd * yr;
+    sq = __builtin_fmaf(__builtin_fmaf(-sq, sq, dd), 0.5f * yr, sq);          // mr_sqrt for a normal, non-zero argument
+    return v * lean_rcp(sq);
+}
+MR_DEV v3 oct_decode_lean(v2 f) {     // oct_decode (device_math.hpp, helperDi.slang:123-134): |n.x| + |n.y| + |n.z| = 1, so the squared length lies in [1/3, 1]
+    float fx = f.x * 2.0f - 1.0f, fy = f.y * 2.0f - 1.0f;
+    v3 n = V3(fx, fy, (1.0f - fabsf(fx)) - fabsf(fy));
+    float t = clampf(-n.z, 0.0f, 1.0f);
+    n.x += (n.x >= 0.0f ? -t : t);
+    n.y += (n.y >= 0.0f ? -t : t);
+    return normalize_lean(n);
+}
 template <bool FRONT = false>   // FRONT: a conventional occlusion query — the hit must lie in front of the origin (t > 0); the reference's bvh_hit does not look at t
 MR_DEV bool tri_accepts_regs(float4 a, float4 b, float4 c, v3 ro, v3 d) {
     const v3 v0 = V3(a.x, a.y, a.z), E1 = V3(a.w, b.x, b.y), E2 = V3(b.z, b.w, c.x);
@@ -522,7 +549,7 @@ template <bool COUNT, int TOPN, int TIMED = 0, int SRC = 0>   // TIMED: identica
 __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const Ray* __restrict__ rays, const uint32_t* __restrict__ d_count,
                                                                uint32_t n_fixed, uint32_t* __restrict__ work_head, int32_t* __restrict__ hit_out,
                                                                unsigned long long* __restrict__ stats, RaySrc src = RaySrc{nullptr, nullptr, 0.f, 0}) {
-    __shared__ uint32_t lds[MR_ANY_LDS * MR_TRACE_BLOCK];
+    __shared__ uint32_t lds[(MR_ANY_LDS + (MR_ANY_SEL ? 1 : 0)) * MR_TRACE_BLOCK];   // MR_ANY_SEL: one spare row for the last unconditional store of the branch-free child selection
     __shared__ __attribute__((aligned(16))) uint4 s_top[TOPN > 0 ? TOPN * 4 : 1];
     if (TOPN > 0) {
         const uint4* src = reinterpret_cast<const uint4*>(TOPN > 85 ? B.top341q : B.top85q);
@@ -548,6 +575,7 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const
     int cur = 0, sp = 0, sbase = 0; uint32_t ridx = 0;   // the lane's deferred entries live in [sbase, sp)
     uint32_t spill[MR_ANY_STACK - MR_ANY_LDS];
     unsigned long long c_boxes = 0, c_nodes = 0, c_leaves = 0; int c_maxsp = 0;
+    int leaf_wait = 0;   // MR_ANY_LEAFP: wave iterations the oldest waiting leaf has waited (wave-uniform)
     unsigned long long w_iters = 0, w_leaf_iters = 0, w_leaf_lanes = 0;      // COUNT: wave iterations, those that ran the leaf branch, leaf visits (wave-uniform; lane 0 reports)
     while (true) {
         const uint64_t need = __ballot(!have);
@@ -592,16 +620,30 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const
                         const uint32_t op = (idx & 1u) ? it.y : it.x, lp = (idx & 1u) ? it.x : it.y;
                         const float4 P = src.grec[4 * (size_t)op + 3], L = src.rrec[2 * (size_t)lp];
                         dead = src.skip_dead && L.w == 0.f;   // engine.hpp RaySrc: the light sample's carried luminance is 0 — nobody can see this ray's answer
+#if MR_ANY_LEANREFILL
+                        const v3 dir = oct_decode_lean(V2(L.y, L.z));
+#else
                         const v3 dir = oct_decode(V2(L.y, L.z));
+#endif
                         v3 o = V3(P.x, P.y, P.z) + src.vis_near * dir;          // put_ray (passes.hip): the same two expressions
                         a.x = o.x; a.y = o.y; a.z = o.z; a.w = 0.f; b.x = dir.x; b.y = dir.y; b.z = dir.z; b.w = 1e7f;
                     } else { a = reinterpret_cast<const float4*>(rays + idx)[0]; b = reinterpret_cast<const float4*>(rays + idx)[1]; }
                     ridx = idx; ro = V3(a.x, a.y, a.z); t_min = a.w; t_max = b.w;
+#if MR_ANY_LEANREFILL
+                    // Round 6: the pixel-pair source forms its own rays (an oct-decoded direction: components are 0 or at least 2^-25 in magnitude, the squared length lies in
+                    // [1/3, 3]), so every operand of the normalisation and of the three reciprocals is inside the range in which the short sequences return the IEEE bits
+                    // (device_math.hpp: proved by exhaustion, mirres_selfcheck_arith). Rays that come through the API keep the compiler's division / square root.
+                    if (SRC == 1) d = normalize_lean(V3(b.x, b.y, b.z)); else d = normalize(V3(b.x, b.y, b.z));
+#else
                     d = normalize(V3(b.x, b.y, b.z));
+#endif
                     ox = ro.x; oy = ro.y; oz = ro.z;
                     { float dx = d.x, dy = d.y, dz = d.z;
                       if (dx == 0.f) dx = 0.000001f; if (dy == 0.f) dy = 0.000001f; if (dz == 0.f) dz = 0.000001f;
-                      ix = 1.0f / dx; iy = 1.0f / dy; iz = 1.0f / dz; }
+#if MR_ANY_LEANREFILL
+                      if (SRC == 1) { ix = lean_rcp(dx); iy = lean_rcp(dy); iz = lean_rcp(dz); } else
+#endif
+                      { ix = 1.0f / dx; iy = 1.0f / dy; iz = 1.0f / dz; } }
                     sp = 0; sbase = 0;
                     rc = ray_margins(scene_bs, ox, oy, oz, ix, iy, iz);
                     hit_out[idx] = 0;          // set to 1 by whichever lane finds an occluder (the owner or, in the tail, a helper)
@@ -617,6 +659,15 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const
         if (!__ballot(have)) { if (exhausted) break; else continue; }
         do {
             int ref = cur; bool active = have;
+#if MR_ANY_LEAFP > 1
+            // Round 6 experiment: lanes that have reached a leaf wait (at most MR_ANY_LEAFP - 1 iterations) for a LEAF ROUND, so that the leaf branch — exact slab + Moller-Trumbore,
+            // run today in 73 % / 91 % of the wave iterations for 3 / 6.6 lanes — runs less often for more lanes. A round is due when no lane is at a node, when MR_ANY_LEAFT lanes wait,
+            // or when the oldest waiting leaf has waited long enough. Nothing is reordered for a ray; only when its leaf is looked at changes.
+            { const uint64_t lm = __ballot(active && ref < 0), nm = __ballot(active && ref >= 0);
+              leaf_wait = lm ? leaf_wait + 1 : 0;
+              const bool round = !nm || __popcll(lm) >= MR_ANY_LEAFT || leaf_wait >= MR_ANY_LEAFP;
+              if (round) leaf_wait = 0; else if (ref < 0) active = false; }
+#endif
             if (COUNT) { const uint64_t lm = __ballot(active && ref < 0); w_iters++; if (lm) { w_leaf_iters++; w_leaf_lanes += (unsigned long long)__popcll(lm); } }
             if (active) {
                 // one 64-byte record per iteration — a Node4q or a LeafRec — fetched before the type is looked at, so that a wave pays ONE memory
@@ -655,6 +706,72 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const
                     child_slabs(nc, t_min, tn4, tf4);
                     // A node defers at most three entries. While all three fit the LDS part of the stack (always, on trees of ordinary depth) the
                     // per-entry range checks of the general path — two compares and a select each, 4 issue cycles apiece — are not needed.
+#if MR_ANY_SEL == 1
+                    // Round 6: child selection without control flow. The nearest passing child is the minimum of four keys (entry distance, +inf for a child that fails);
+                    // the up to three others are stored UNCONDITIONALLY at the lane's stack top, which only advances past an entry that is to be kept (what lies above
+                    // `sp` is never read; the LDS part has one spare row for the last store). The order of the deferred entries differs from the sequential insert
+                    // (slot order instead of "swap with the nearest so far"); a shadow ray's answer is an OR over subtrees, any order gives the same bit.
+                    if (sp + 3 <= MR_ANY_LDS) {
+                        const float INF = __int_as_float(0x7f800000);
+                        const bool ok0 = tf4[0] > tn4[0], ok1 = tf4[1] > tn4[1], ok2 = tf4[2] > tn4[2], ok3 = tf4[3] > tn4[3];
+                        const float k0 = ok0 ? tn4[0] : INF, k1 = ok1 ? tn4[1] : INF, k2 = ok2 ? tn4[2] : INF, k3 = ok3 ? tn4[3] : INF;
+                        const float m = fminf(fminf(fminf(k0, k1), k2), k3);
+                        const bool is1 = k1 == m, is2 = k2 == m, is3 = k3 == m;
+                        int nx = ref[0]; nx = is1 ? ref[1] : nx; nx = is2 ? ref[2] : nx; nx = is3 ? ref[3] : nx;
+                        const bool c3 = is3, c2 = is2 && !is3, c1 = is1 && !is2 && !is3, c0 = !(is1 || is2 || is3);
+                        if (COUNT) { for (int k = 0; k < 4; k++) if (ref[k] != ~B.T) c_boxes++; }
+                        lds_stack[sp * MR_TRACE_BLOCK] = (uint32_t)ref[0]; sp += (ok0 && !c0) ? 1 : 0;
+                        lds_stack[sp * MR_TRACE_BLOCK] = (uint32_t)ref[1]; sp += (ok1 && !c1) ? 1 : 0;
+                        lds_stack[sp * MR_TRACE_BLOCK] = (uint32_t)ref[2]; sp += (ok2 && !c2) ? 1 : 0;
+                        lds_stack[sp * MR_TRACE_BLOCK] = (uint32_t)ref[3]; sp += (ok3 && !c3) ? 1 : 0;
+                        next = (ok0 || ok1 || ok2 || ok3) ? nx : 0x7fffffff;
+                    } else {
+#elif MR_ANY_SEL == 2
+                    // Round 6: the nearest passing child by a three-compare tournament on (passes, entry distance) whose outcomes stay lane masks (scalar logic, no selects on
+                    // sentinels), the other passing children stored under their own lane mask: one v_add per child instead of compare + select + shift-or.
+                    if (sp + 3 <= MR_ANY_LDS) {
+                        const bool ok0 = tf4[0] > tn4[0], ok1 = tf4[1] > tn4[1], ok2 = tf4[2] > tn4[2], ok3 = tf4[3] > tn4[3];
+                        const bool a = ok1 && (!ok0 || tn4[1] < tn4[0]);
+                        const float m01 = a ? tn4[1] : tn4[0]; const int r01 = a ? ref[1] : ref[0]; const bool ok01 = ok0 || ok1;
+                        const bool b = ok3 && (!ok2 || tn4[3] < tn4[2]);
+                        const float m23 = b ? tn4[3] : tn4[2]; const int r23 = b ? ref[3] : ref[2]; const bool ok23 = ok2 || ok3;
+                        const bool c = ok23 && (!ok01 || m23 < m01);
+                        const int nx = c ? r23 : r01;
+                        if (COUNT) { for (int k = 0; k < 4; k++) if (ref[k] != ~B.T) c_boxes++; }
+                        typedef __attribute__((address_space(3))) uint32_t lds_u32;      // 32-bit LDS addresses: the stack top as a byte address, one v_add per kept entry
+                        lds_u32* const row0 = (lds_u32*)lds_stack;
+                        lds_u32* top = row0 + sp * MR_TRACE_BLOCK;
+                        if (ok0 && (a || c)) { *top = (uint32_t)ref[0]; top += MR_TRACE_BLOCK; }
+                        if (ok1 && (!a || c)) { *top = (uint32_t)ref[1]; top += MR_TRACE_BLOCK; }
+                        if (ok2 && (b || !c)) { *top = (uint32_t)ref[2]; top += MR_TRACE_BLOCK; }
+                        if (ok3 && !(b && c)) { *top = (uint32_t)ref[3]; top += MR_TRACE_BLOCK; }
+                        sp = (int)(((uint32_t)(uintptr_t)top - (uint32_t)(uintptr_t)row0) / (4u * MR_TRACE_BLOCK));
+                        next = (ok01 || ok23) ? nx : 0x7fffffff;
+                    } else {
+#elif MR_ANY_SEL == 3
+                    // Round 6: as MR_ANY_SEL == 2 (three-compare tournament, outcomes as lane masks), but the stores are unconditional at a byte address that only advances past
+                    // a kept entry — straight-line code, no exec-mask regions (the spare LDS row takes the last store).
+                    if (sp + 3 <= MR_ANY_LDS) {
+                        const bool ok0 = tf4[0] > tn4[0], ok1 = tf4[1] > tn4[1], ok2 = tf4[2] > tn4[2], ok3 = tf4[3] > tn4[3];
+                        const bool a = ok1 && (!ok0 || tn4[1] < tn4[0]);
+                        const float m01 = a ? tn4[1] : tn4[0]; const int r01 = a ? ref[1] : ref[0]; const bool ok01 = ok0 || ok1;
+                        const bool b = ok3 && (!ok2 || tn4[3] < tn4[2]);
+                        const float m23 = b ? tn4[3] : tn4[2]; const int r23 = b ? ref[3] : ref[2]; const bool ok23 = ok2 || ok3;
+                        const bool c = ok23 && (!ok01 || m23 < m01);
+                        const int nx = c ? r23 : r01;
+                        if (COUNT) { for (int k = 0; k < 4; k++) if (ref[k] != ~B.T) c_boxes++; }
+                        typedef __attribute__((address_space(3))) uint32_t lds_u32;
+                        typedef __attribute__((address_space(3))) char lds_char;
+                        lds_char* const row0 = (lds_char*)(lds_u32*)lds_stack;
+                        lds_char* top = row0 + sp * (4 * MR_TRACE_BLOCK);
+                        *(lds_u32*)top = (uint32_t)ref[0]; top += (ok0 && (a || c)) ? 4 * MR_TRACE_BLOCK : 0;
+                        *(lds_u32*)top = (uint32_t)ref[1]; top += (ok1 && (!a || c)) ? 4 * MR_TRACE_BLOCK : 0;
+                        *(lds_u32*)top = (uint32_t)ref[2]; top += (ok2 && (b || !c)) ? 4 * MR_TRACE_BLOCK : 0;
+                        *(lds_u32*)top = (uint32_t)ref[3]; top += (ok3 && !(b && c)) ? 4 * MR_TRACE_BLOCK : 0;
+                        sp = (int)(((uint32_t)(uintptr_t)top - (uint32_t)(uintptr_t)row0) / (4u * MR_TRACE_BLOCK));
+                        next = (ok01 || ok23) ? nx : 0x7fffffff;
+                    } else {
+#else
                     if (sp + 3 <= MR_ANY_LDS) {
 #pragma unroll
                         for (int k = 0; k < 4; k++) {
@@ -671,6 +788,7 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const
                             }
                         }
                     } else {
+#endif
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
                         const float tn = tn4[k], tf = tf4[k];

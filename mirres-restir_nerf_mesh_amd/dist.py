@@ -54,6 +54,8 @@ def sum_over_ranks(flat, group=None, algo=None):
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
         return flat
     n = flat.numel()
+    if n == 0:                                                      # zero-size collectives are backend dependent: the sum of nothing is nothing
+        return flat
     per = -(-n // world)
     per = -(-per // 64) * 64                                       # 256-byte slices
     if per * world != n:
@@ -83,6 +85,10 @@ def allreduce_sums(sums, group=None, occ=None, used=None):
         idx = torch.nonzero(occ.detach().reshape(-1) > 0.5, as_tuple=False).reshape(-1)      # the same list on every rank (the G-buffer is replicated)
         if idx.numel() == sums[0].shape[0]:
             idx = None
+        elif idx.numel() == 0:
+            # no foreground pixel in the view (camera looking away, an empty strip): every rank holds the same (replicated) occupancy and therefore takes this
+            # branch together; the sums of background pixels are zero everywhere — nothing to exchange, and no zero-size collective is issued
+            return sums
     sel = list(range(len(sums))) if used is None else [k for k in used if k < len(sums)]
     flat = torch.cat([(sums[k] if idx is None else sums[k][idx]).reshape(-1) for k in sel])
     flat = sum_over_ranks(flat, group)
@@ -182,6 +188,9 @@ class StripBalancer:
         self.corr = torch.ones(self.fy, dtype=torch.float64)
         self.last_bounds = None
         self.pending = None        # (start event, end event) of this rank's last strip render
+        self.waits = []            # (event before, event after) of the sampled halo exchanges of that render, + how many exchanges each stands for
+        self.wait_stride = 1
+        self.last_total_ms = self.last_wait_ms = None
         self.history = []          # (bounds, times) per update: what the table in profiles/ is printed from
 
     def cost(self, fx, occ):
@@ -205,24 +214,65 @@ class StripBalancer:
             self.corr = self.corr ** (1.0 - self.smooth)
 
     # ---- timing of this rank's strip and the exchange of the times
-    def start(self):
+    # What is exchanged is the strip's OWN busy time, not the wall time of its render: in a multi-rank run every sample's halo exchange waits for the
+    # neighbours, so all ranks advance at the slowest strip's pace and their wall times are near-equal whatever the partition — a balancer fed with them never moves.
+    # The time the stream spends inside the exchanges (event pairs around a sample of them, on the stream the exchange is enqueued on: with RCCL the send / recv
+    # kernels sit there until the peer arrives, with a host-staged backend the stream idles while the host blocks) is subtracted.
+    MAX_WAIT_SAMPLES = 32      # event pairs per frame: every (spp / 32)-th exchange is bracketed and stands for its stride (512 pairs would cost milliseconds of host time)
+
+    def start(self, spp=None):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         self.pending = (e0, e1)
+        self.waits = []
+        self.wait_stride = max(1, int(spp or 1) // self.MAX_WAIT_SAMPLES)
+
+    def bracket(self, sample):
+        """Context manager for the halo callback: brackets this sample's exchange with events on the CURRENT stream when it is one of the sampled ones."""
+        import contextlib
+        if self.pending is None or int(sample) % self.wait_stride != 0:
+            return contextlib.nullcontext()
+        bal = self
+
+        class _B:
+            def __enter__(self_):
+                self_.a = torch.cuda.Event(enable_timing=True); self_.b = torch.cuda.Event(enable_timing=True)
+                self_.a.record(torch.cuda.current_stream())
+            def __exit__(self_, *exc):
+                self_.b.record(torch.cuda.current_stream())
+                bal.waits.append((self_.a, self_.b))
+                return False
+        return _B()
 
     def stop(self):
         if self.pending is not None:
             self.pending[1].record()
 
-    def exchange(self, rank, group=None):
-        """Called at the start of a frame: last frame's strip time of every rank -> update(). Returns the gathered times (None on the first frame)."""
-        import torch.distributed as dist
+    def abort(self):
+        """The render between start() and stop() raised: forget it (an unrecorded end event would fail the next exchange() on this rank only and mismatch the collective)."""
+        self.pending = None
+        self.waits = []
+
+    def busy_ms(self):
+        """(own busy time, total, waited) of the last timed strip render in ms; None when nothing is pending."""
         if self.pending is None:
             return None
         e0, e1 = self.pending
         e1.synchronize()
-        mine = e0.elapsed_time(e1)
+        total = e0.elapsed_time(e1)
+        waited = sum(a.elapsed_time(b) for a, b in self.waits) * self.wait_stride
+        waited = min(waited, 0.95 * total)          # (a sampled estimate: never let it eat the whole frame)
+        return total - waited, total, waited
+
+    def exchange(self, rank, group=None, measured=None):
+        """Called at the start of a frame: last frame's own busy time of every rank -> update(). Returns the gathered times (None on the first frame).
+        `measured` = (busy, total, waited) replaces the event timing (tests)."""
+        m = measured if measured is not None else self.busy_ms()
+        if m is None:
+            return None
+        mine, self.last_total_ms, self.last_wait_ms = m
         self.pending = None
+        self.waits = []
         times = gather_times(mine, rank, self.world, group)
         self.update(times)
         return times
@@ -386,10 +436,13 @@ def render_strips(ctx_full, worker, mlp_mat, env_map, g, spp, random_offset, ran
                 _WARNED_OVERLAP = True
             overlap = False
 
+    import contextlib
+
     def _halo(user, records, sample, stream):
         try:
             with on_stream(stream):
-                exchange_halos(device_view(records, (rows_pad, fx, 8)), plan, group)
+                with (balancer.bracket(sample) if balancer is not None else contextlib.nullcontext()):
+                    exchange_halos(device_view(records, (rows_pad, fx, 8)), plan, group)
             return 0
         except Exception as e:      # surfaced by mirres_render as MIRRES_E_STATE
             import sys
@@ -397,9 +450,14 @@ def render_strips(ctx_full, worker, mlp_mat, env_map, g, spp, random_offset, ran
             return 1
     cb = _lib.HALO_FN(_halo)
     if balancer is not None:
-        balancer.start()
-    sums, a, keep = render_fused(ctx_loc, worker, mlp_mat, use_scale, scale, env_map, loc["occ"], loc["normal"], loc["depth"], loc["kd"], loc["rm"], loc["ray_dir"],
-                                 loc["pos"], spp, denoise_iter, step_width, c_phi, n_phi, p_phi, random_offset, strip=(fy, lo, y0 - lo, y1 - lo), halo=cb, strip_overlap=overlap)
+        balancer.start(spp)
+    try:
+        sums, a, keep = render_fused(ctx_loc, worker, mlp_mat, use_scale, scale, env_map, loc["occ"], loc["normal"], loc["depth"], loc["kd"], loc["rm"], loc["ray_dir"],
+                                     loc["pos"], spp, denoise_iter, step_width, c_phi, n_phi, p_phi, random_offset, strip=(fy, lo, y0 - lo, y1 - lo), halo=cb, strip_overlap=overlap)
+    except BaseException:
+        if balancer is not None:
+            balancer.abort()
+        raise
     if balancer is not None:
         balancer.stop()
     own = [s_[(y0 - lo) * fx:(y1 - lo) * fx].contiguous() for s_ in sums]

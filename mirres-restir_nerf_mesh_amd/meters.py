@@ -108,7 +108,13 @@ class LPIPS(torch.nn.Module):
             raise NotImplementedError("LPIPS: the reference uses net='vgg' (nerf/utils.py:516, 796)")
         if vgg is None:
             raise RuntimeError("LPIPS needs pretrained weights (torchvision vgg16 + lpips v0.1 vgg.pth); none ship with this image — pass vgg= / lin=")
-        load = lambda x: torch.load(x, map_location="cpu") if isinstance(x, (str, bytes, os.PathLike)) else dict(x)
+        def load(x):
+            if not isinstance(x, (str, bytes, os.PathLike)):
+                return dict(x)
+            try:         # the files are plain state dicts: never unpickle arbitrary objects from a path that comes from the command line / environment
+                return torch.load(x, map_location="cpu", weights_only=True)
+            except TypeError:      # a torch without the argument
+                return torch.load(x, map_location="cpu")
         sd = load(vgg)
         if lin is not None:
             sd = dict(sd); sd.update(load(lin))

@@ -82,6 +82,25 @@ if world == 1:
         torch.cuda.synchronize()
         frames.append([s_.clone() for s_ in sums])
     res["p2p_in_callback_equal"] = all(torch.equal(a, b) for a, b in zip(*frames)) and calls == {"rccl": 3, "copy": 3}
+    # strip_overlap over RCCL (ADVICE r5: the two-rank gloo test cannot cover it — a host-staged backend falls back to the in-line exchange): the engine hands the callback
+    # its SIDE stream, the exchange is enqueued there exactly as dist.render_strips' callback does it (on_stream + exchange_halos; no host synchronisation), interior rows
+    # first, border rows after the exchange — the frame must not change by a bit
+    side = []
+    bal = D.StripBalancer(fy, 2)
+    def via_rccl_side(user, records, sample, stream):
+        side.append(int(stream or 0))
+        with D.on_stream(stream):
+            with bal.bracket(sample):
+                D.exchange_halos(D.device_view(records, (hi - lo, fx, 8)), plan)
+        return 0
+    bal.start(3)
+    sums, _, _ = RR.render_fused(get_ctx(fx, hi - lo), W, None, False, (1, 1, 1), env, loc["occ"].clone(), loc["normal"], loc["depth"], loc["kd"], loc["rm"], loc["ray_dir"],
+                                 loc["pos"], 3, 2, 2, 2.0, 0.1, 0.001, 4321, strip=(fy, lo, y0 - lo, y1 - lo), halo=_lib.HALO_FN(via_rccl_side), strip_overlap=True)
+    bal.stop()
+    torch.cuda.synchronize()
+    res["overlap_over_rccl_equal"] = all(torch.equal(a, b) for a, b in zip(sums, frames[1])) and len(side) == 3 and all(st_ != torch.cuda.current_stream().cuda_stream for st_ in side)
+    busy, total, waited = bal.busy_ms()
+    res["balancer_busy_total_waited"] = [busy, total, waited]      # the exchanges' stream time is taken out of the strip's own time
     res["p2p_moved_something"] = moved["ok"] and moved["nonzero"]     # received halo rows == sent rows, and those rows carried reservoirs (not all zero)
 torch.cuda.synchronize()
 dist.barrier()
@@ -119,6 +138,9 @@ def test_rccl_collectives_and_halo_exchange_on_one_gpu(tmp_path):
     assert r["spp_equal_single_gpu"], "one rank's slice is the whole frame: the RCCL all-reduce over one rank must be the identity"
     assert r["grad_bucket"] == [1.0, 1.0, 0.0] and r["grad_algos_agree"]
     assert r["p2p_in_callback_equal"] and r["p2p_moved_something"]
+    assert r["overlap_over_rccl_equal"], "strip_overlap with the exchange on the engine's side stream over RCCL must not change the frame"
+    busy, total, waited = r["balancer_busy_total_waited"]
+    assert 0 < waited < total and abs(busy + waited - total) < 1e-6 * total + 1e-9
 
 
 def test_two_ranks_over_rccl_on_the_same_gpu_or_its_documented_refusal(tmp_path):

@@ -368,8 +368,8 @@ def _strip_rank(rank, world, port, out):
     import warnings
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")      # gloo stages the exchange through the host: dist.render_strips says so once and runs the in-line exchange
-        over = D.render_strips(ctx, W, None, env, g, 3, 4321, rank, world, overlap=True)      # RCCL: the exchange on the engine's side stream, interior rows first
-    res["overlap"] = [o.cpu() for o in over]
+        over = D.render_strips(ctx, W, None, env, g, 3, 4321, rank, world, overlap=True)      # on gloo this is the FALLBACK: overlap requested, in-line exchange run
+    res["overlap_requested_on_gloo"] = [o.cpu() for o in over]                                  # (the side-stream path over RCCL: test_gpu_rccl.py; single-process replay: above)
     # measured balancing (round 5): three frames whose boundaries move with the strips' own times — any partition must give the same bits
     bal = D.StripBalancer(g["fy"], world)
     res["balanced"], res["bounds"] = [], []
@@ -379,6 +379,7 @@ def _strip_rank(rank, world, port, out):
         o = D.render_strips(ctx, W, None, env, g, 3, 4321, rank, world, balancer=bal)
         res["balanced"].append([x.cpu() for x in o]); res["bounds"].append(list(bal.last_bounds))
     res["history"] = len(bal.history)
+    res["busy_total_waited"] = [bal.last_total_ms is not None and bal.last_wait_ms is not None and 0 <= bal.last_wait_ms < bal.last_total_ms]
     if rank == 0:
         ref = D.render_strips(ctx, W, None, env, g, 3, 4321, 0, 1)      # world == 1: the ordinary single-GPU frame
         res["ref"] = [o.cpu() for o in ref]
@@ -400,11 +401,13 @@ def test_two_rank_strip_render_equals_single_gpu(tmp_path):
     for k in range(6):
         assert torch.equal(r0["outs"][k], r0["ref"][k]), "rank 0 buffer %d" % k
         assert torch.equal(r1["outs"][k], r0["ref"][k]), "rank 1 buffer %d" % k
-        assert torch.equal(r0["overlap"][k], r0["ref"][k]) and torch.equal(r1["overlap"][k], r0["ref"][k]), "strip_overlap, buffer %d" % k
+        assert torch.equal(r0["overlap_requested_on_gloo"][k], r0["ref"][k]) and torch.equal(r1["overlap_requested_on_gloo"][k], r0["ref"][k]), \
+            "overlap requested on a host-staged backend (falls back to the in-line exchange), buffer %d" % k
         for frame in range(3):
             assert torch.equal(r0["balanced"][frame][k], r0["ref"][k]) and torch.equal(r1["balanced"][frame][k], r0["ref"][k]), "balanced frame %d, buffer %d" % (frame, k)
     assert r0["bounds"] == r1["bounds"] and len(set(tuple(b) for b in r0["bounds"])) >= 2, r0["bounds"]      # same partition on both ranks, and it moved
     assert r0["history"] == 2 and r1["history"] == 2                                                       # frames 2 and 3 used the times of frames 1 and 2
+    assert r0["busy_total_waited"] == [True] and r1["busy_total_waited"] == [True]                         # the exchanged time is the strip's own: exchange waits taken out
 
 
 def test_fused_training_gradients_match_the_stepwise_loop(oracle, scene_mod, monkeypatch):

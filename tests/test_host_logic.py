@@ -166,6 +166,54 @@ def test_strip_times_are_gathered_in_rank_order_gloo_world2():
     assert out[0] == [10.0, 11.0] and out[1] == [10.0, 11.0]
 
 
+def _coupled_worker(rank, world, port, out):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mirres_restir_nerf_mesh_amd import dist as D
+    fy, fx = 400, 8
+    occ = torch.ones(fy * fx, 1)
+    # truth the static model does not know: the lower half of the image costs three times the upper half per row. In a real multi-rank run every sample's halo
+    # exchange makes the ranks wait for each other: the WALL time of both strips is the slower strip's, whatever the partition.
+    rowc = torch.where(torch.arange(fy) < fy // 2, torch.tensor(1.0), torch.tensor(3.0)).double()
+    B = D.StripBalancer(fy, world)
+    log = []
+    for it in range(5):
+        B.exchange(rank, measured=None if it == 0 else last)
+        b = B.bounds(fx, occ)
+        busy = [float(rowc[b[r]:b[r + 1]].sum()) for r in range(world)]
+        wall = max(busy)                                  # coupled by the per-sample exchange
+        last = (busy[rank], wall, wall - busy[rank])      # (own busy, total, waited): what StripBalancer.busy_ms() derives from its events
+        log.append((list(b), busy, B.history[-1][1] if B.history else None))
+    # an all-background view: nothing to exchange, no zero-size collective, the sums come back unchanged
+    sums = [torch.zeros(fy * fx, 3) for _ in range(6)]
+    red = D.allreduce_sums([x.clone() for x in sums], occ=torch.zeros(fy * fx, 1), used=D.USED_SUMS)
+    ok_empty = all(torch.equal(a, b_) for a, b_ in zip(red, sums)) and D.sum_over_ranks(torch.zeros(0)).numel() == 0
+    out[rank] = (log, ok_empty)
+    dist.destroy_process_group()
+
+
+def test_strip_balancer_is_fed_own_busy_times_gloo_world2():
+    """two ranks whose strips cost 1 : 3 per row and whose wall times are EQUAL (coupled by the per-sample exchange). The gathered times are the strips'
+    own busy times — they differ on the first frame — and the boundary moves towards balance; with wall times the balancer would never move. Also: an all-background
+    occupancy short-circuits the sum exchange (no zero-size collective)."""
+    import torch.multiprocessing as mp
+    mgr = mp.Manager(); out = mgr.dict()
+    spawn_ranks(_coupled_worker, (2, 29900 + (os.getpid() % 200), out), 2)
+    (log0, e0), (log1, e1) = out[0], out[1]
+    assert e0 and e1
+    assert log0 == log1                                              # every rank derives the same boundaries from the same gathered times
+    b_first, busy_first, _ = log0[0]
+    assert b_first == [0, 200, 400] and busy_first == [200.0, 600.0]
+    gathered = log0[1][2]
+    assert gathered == [200.0, 600.0]                                # own busy times travelled, not the (equal) wall times
+    ratios = [max(x[1]) / (sum(x[1]) / 2) for x in log0]
+    assert ratios[0] == 1.5 and ratios[-1] < 1.05, ratios            # the boundary moved down into the expensive half
+    assert log0[-1][0][1] > 250
+
+
 def _strip_worker(rank, world, port, out):
     import torch
     import torch.distributed as dist
