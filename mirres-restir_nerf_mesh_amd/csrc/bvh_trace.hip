@@ -436,6 +436,9 @@ static_assert(MR_ANY_LDS >= 3 && MR_ANY_LDS <= MR_ANY_STACK, "the LDS part of th
 #ifndef MR_ANY_SEL
 #define MR_ANY_SEL 0
 #endif
+#ifndef MR_ANY_SEL_ADDC
+#define MR_ANY_SEL_ADDC 0
+#endif
 #ifndef MR_ANY_LEAFP
 #define MR_ANY_LEAFP 0
 #endif
@@ -725,6 +728,54 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const
                         lds_stack[sp * MR_TRACE_BLOCK] = (uint32_t)ref[2]; sp += (ok2 && !c2) ? 1 : 0;
                         lds_stack[sp * MR_TRACE_BLOCK] = (uint32_t)ref[3]; sp += (ok3 && !c3) ? 1 : 0;
                         next = (ok0 || ok1 || ok2 || ok3) ? nx : 0x7fffffff;
+                    } else {
+#elif MR_ANY_SEL == 4
+                    // as MR_ANY_SEL == 1 with the keys compared as signed integers (the bit patterns of floats order like the floats where it matters: non-negative entry
+                    // distances below +inf; a negative one — a caller's negative t_min — merely counts as nearest): no NaN canonicalisation in front of the minimum
+                    if (sp + 3 <= MR_ANY_LDS) {
+                        const int INFI = 0x7f800000;
+                        const bool ok0 = tf4[0] > tn4[0], ok1 = tf4[1] > tn4[1], ok2 = tf4[2] > tn4[2], ok3 = tf4[3] > tn4[3];
+                        const int k0 = ok0 ? __float_as_int(tn4[0]) : INFI, k1 = ok1 ? __float_as_int(tn4[1]) : INFI, k2 = ok2 ? __float_as_int(tn4[2]) : INFI, k3 = ok3 ? __float_as_int(tn4[3]) : INFI;
+                        const int m = min(min(min(k0, k1), k2), k3);
+                        const bool is1 = k1 == m, is2 = k2 == m, is3 = k3 == m;
+                        int nx = ref[0]; nx = is1 ? ref[1] : nx; nx = is2 ? ref[2] : nx; nx = is3 ? ref[3] : nx;
+                        const bool c3 = is3, c2 = is2 && !is3, c1 = is1 && !is2 && !is3, c0 = !(is1 || is2 || is3);
+                        if (COUNT) { for (int k = 0; k < 4; k++) if (ref[k] != ~B.T) c_boxes++; }
+                        lds_stack[sp * MR_TRACE_BLOCK] = (uint32_t)ref[0]; sp += (ok0 && !c0) ? 1 : 0;
+                        lds_stack[sp * MR_TRACE_BLOCK] = (uint32_t)ref[1]; sp += (ok1 && !c1) ? 1 : 0;
+                        lds_stack[sp * MR_TRACE_BLOCK] = (uint32_t)ref[2]; sp += (ok2 && !c2) ? 1 : 0;
+                        lds_stack[sp * MR_TRACE_BLOCK] = (uint32_t)ref[3]; sp += (ok3 && !c3) ? 1 : 0;
+                        next = (ok0 || ok1 || ok2 || ok3) ? nx : 0x7fffffff;
+                    } else {
+#elif MR_ANY_SEL == 5
+                    // as MR_ANY_SEL == 4 with the lane-mask logic spelled out on the 64-bit masks themselves (ballot / inverse ballot: scalar and / andn2, no v_cmp_ne for a negation)
+                    if (sp + 3 <= MR_ANY_LDS) {
+                        const int INFI = 0x7f800000;
+                        const uint64_t o0 = __builtin_amdgcn_ballot_w64(tf4[0] > tn4[0]), o1 = __builtin_amdgcn_ballot_w64(tf4[1] > tn4[1]);
+                        const uint64_t o2 = __builtin_amdgcn_ballot_w64(tf4[2] > tn4[2]), o3 = __builtin_amdgcn_ballot_w64(tf4[3] > tn4[3]);
+                        const int k0 = __builtin_amdgcn_inverse_ballot_w64(o0) ? __float_as_int(tn4[0]) : INFI, k1 = __builtin_amdgcn_inverse_ballot_w64(o1) ? __float_as_int(tn4[1]) : INFI;
+                        const int k2 = __builtin_amdgcn_inverse_ballot_w64(o2) ? __float_as_int(tn4[2]) : INFI, k3 = __builtin_amdgcn_inverse_ballot_w64(o3) ? __float_as_int(tn4[3]) : INFI;
+                        const int m = min(min(min(k0, k1), k2), k3);
+                        const uint64_t e1 = __builtin_amdgcn_ballot_w64(k1 == m), e2 = __builtin_amdgcn_ballot_w64(k2 == m), e3 = __builtin_amdgcn_ballot_w64(k3 == m);
+                        int nx = ref[0]; nx = __builtin_amdgcn_inverse_ballot_w64(e1) ? ref[1] : nx; nx = __builtin_amdgcn_inverse_ballot_w64(e2) ? ref[2] : nx; nx = __builtin_amdgcn_inverse_ballot_w64(e3) ? ref[3] : nx;
+                        // the chosen child: the highest index among the minima; the others that pass are kept
+                        const uint64_t p3 = o3 & ~e3, p2 = o2 & ~(e2 & ~e3), p1 = o1 & ~(e1 & ~(e2 | e3)), p0 = o0 & (e1 | e2 | e3);
+                        if (COUNT) { for (int k = 0; k < 4; k++) if (ref[k] != ~B.T) c_boxes++; }
+#if MR_ANY_SEL_ADDC
+                        // sp += (lane's bit of the mask): one v_addc_co_u32 with the mask as carry-in (the compiler materialises 0 / 1 with a v_cndmask first)
+#define MR_ADDC(SP, MASK) asm("v_addc_co_u32_e64 %0, vcc, %1, 0, %2" : "=v"(SP) : "v"(SP), "s"(MASK) : "vcc")
+                        lds_stack[sp * MR_TRACE_BLOCK] = (uint32_t)ref[0]; MR_ADDC(sp, p0);
+                        lds_stack[sp * MR_TRACE_BLOCK] = (uint32_t)ref[1]; MR_ADDC(sp, p1);
+                        lds_stack[sp * MR_TRACE_BLOCK] = (uint32_t)ref[2]; MR_ADDC(sp, p2);
+                        lds_stack[sp * MR_TRACE_BLOCK] = (uint32_t)ref[3]; MR_ADDC(sp, p3);
+#undef MR_ADDC
+#else
+                        lds_stack[sp * MR_TRACE_BLOCK] = (uint32_t)ref[0]; sp += __builtin_amdgcn_inverse_ballot_w64(p0) ? 1 : 0;
+                        lds_stack[sp * MR_TRACE_BLOCK] = (uint32_t)ref[1]; sp += __builtin_amdgcn_inverse_ballot_w64(p1) ? 1 : 0;
+                        lds_stack[sp * MR_TRACE_BLOCK] = (uint32_t)ref[2]; sp += __builtin_amdgcn_inverse_ballot_w64(p2) ? 1 : 0;
+                        lds_stack[sp * MR_TRACE_BLOCK] = (uint32_t)ref[3]; sp += __builtin_amdgcn_inverse_ballot_w64(p3) ? 1 : 0;
+#endif
+                        next = __builtin_amdgcn_inverse_ballot_w64(o0 | o1 | o2 | o3) ? nx : 0x7fffffff;
                     } else {
 #elif MR_ANY_SEL == 2
                     // Round 6: the nearest passing child by a three-compare tournament on (passes, entry distance) whose outcomes stay lane masks (scalar logic, no selects on
@@ -1115,9 +1166,9 @@ static int any_top() {
 }
 // the spatial pass's queue of (origin pixel, light pixel) pairs: same kernel, rays formed at the refill (head set of lane 0 ... 4 as below)
 int trace_any_items_queue(const mirres_bvh* bvh, const uint2* items, const RaySrc& src, const uint32_t* d_count, size_t capacity, int32_t* hit,
-                          unsigned long long* stats, hipStream_t s, int lane, int timed, bool heads_clean) {
+                          unsigned long long* stats, hipStream_t s, int lane, int timed, bool heads_clean, int head_set) {
     static const int set_of_lane[5] = {0, 7, 9, 11, 15};
-    uint32_t* const heads = bvh->work + set_of_lane[lane] * MR_WSET;
+    uint32_t* const heads = bvh->work + (head_set >= 0 ? head_set : set_of_lane[lane]) * MR_WSET;      // head_set: a unit of the band pipeline (sets 0, 17, 18)
     if (!heads_clean) MR_HIP(hipMemsetAsync(heads, 0, MR_WSET * sizeof(uint32_t), s));
     const Ray* q = reinterpret_cast<const Ray*>(items);
     const int grid = persist_grid(capacity); const uint32_t cap = (uint32_t)capacity;

@@ -9,7 +9,7 @@
 #define MR_NQ 32
 #define MR_QSTRIDE 32
 #define MR_WSET ((MR_NQ + 1) * MR_QSTRIDE)   // + one more line: word MR_NQ * MR_QSTRIDE = bit mask of the sub-queues found empty (grab_chunk)
-#define MR_WSETS 17
+#define MR_WSETS 19
 // Binned-SAH top of the private steering hierarchy (bvh_build.hip): clusters = maximal subtrees whose leaves share MR_SAH_PREFIX key bits (of 38), at most
 // MR_SAH_LEVELS levels rebuilt above them. The shadow-ray kernel's private stack (bvh_trace.hip MR_ANY_STACK) is sized from these two.
 #define MR_SAH_PREFIX 24
@@ -99,13 +99,23 @@ struct mirres_bvh {
     int32_t* p_parent = nullptr; void *sah_state = nullptr, *sah_nodes = nullptr, *sah_bins = nullptr; int32_t *sah_iref = nullptr, *sah_inode = nullptr, *sah_top = nullptr;   // SAH top over prefix clusters (k_sah_*)
     float* root_box = nullptr;      // [6]
     uint32_t* work = nullptr;       // [MR_WSETS * MR_WSET] head sets of the persistent traversal kernels: 0/1 chain, 2/3 API, 4-6 ordered closest + redo, 7/8 bulk stream, 9/10 path-tracing stream,
-                                    // 11 final-stage stream, 12-14 ordered closest + redo and 15/16 any / closest of the second path-tracing stream
+                                    // 11 final-stage stream, 12-14 ordered closest + redo and 15/16 any / closest of the second path-tracing stream, 17/18 the second / third
+                                    // chain stream of the band pipeline (render.hip)
     unsigned long long* dbg = nullptr;   // see BvhView::dbg
     uint32_t* err = nullptr;             // see BvhView::err (hipHostMalloc, mapped: the host reads it without a copy)
     char* dump_pool = nullptr; size_t dump_pool_bytes = 0;   // mirres_dump_render: shadow rays / results / slots of one pixel chunk
     uint32_t* redo[2] = {nullptr, nullptr}; size_t redo_cap[2] = {0, 0};   // ray ids handed back by the ordered closest-hit fast path (one list per path-tracing stream)
     mr::BvhView view() const { mr::BvhView v; v.nodes = nodes; v.tris = tris; v.root_box = root_box; v.T = T; v.nodes4q = nodes4q; v.leaves = leaves; v.top85q = top85q; v.top341q = top341q; v.dbg = dbg; v.err = err; return v; }
 };
+
+// One unit of the band pipeline (round 6, render.hip): the spatial pass of one sample restricted to a band of rows, on queue resources of its own so that units of
+// consecutive samples can be in flight on different streams. set 0 = the context's own buffers and head set 0.
+struct ChainSet {
+    mr::Ray* q = nullptr; int32_t* hit = nullptr; uint32_t* counter = nullptr; int32_t* slot = nullptr; uint32_t* mask = nullptr;
+    int head_set = 0; bool clean = false;      // clean: the set's last resolve left the ray counter and the work heads zeroed
+};
+struct SpatialBand { int y0, y1, gen_y1; ChainSet* set; };   // the resolve covers rows [y0, y1), the generator [y0, gen_y1) (one more row: the fused temporal merge of the
+                                                             // band's last row may recompute the spatial merge of the pixel below, whose rays must be in THIS unit's queue)
 
 struct mirres_ctx {
     int fx = 0, fy = 0; size_t N = 0;
@@ -141,6 +151,9 @@ struct mirres_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join_pt = nullptr, ev_join_pt2 = nullptr, ev_join_fin = nullptr;
     std::vector<hipEvent_t> ev_pt;   // k_pt_reduce hand-over between the two path-tracing streams
     std::vector<hipEvent_t> ev_sync; // cross-stream hand-offs of the batch pipeline (mirres_render)
+    // band pipeline of the per-sample chain (render.hip): up to two more chain streams with their own queue sets, one event per unit of a batch
+    ChainSet chain_sets[3]; void* chain_mem[2] = {nullptr, nullptr}; hipStream_t chain_streams[2] = {nullptr, nullptr};
+    std::vector<hipEvent_t> ev_band;
 };
 
 namespace mr {
@@ -156,7 +169,7 @@ inline int bvh_sticky_error(const mirres_bvh* bvh, const char* who) {
 
 // queue tracing (bvh_trace.hip). count is read on the device; capacity bounds the grid-stride loop.
 int trace_any_items_queue(const mirres_bvh* bvh, const uint2* items, const RaySrc& src, const uint32_t* d_count, size_t capacity, int32_t* hit,
-                          unsigned long long* stats, hipStream_t s, int lane, int timed, bool heads_clean);
+                          unsigned long long* stats, hipStream_t s, int lane, int timed, bool heads_clean, int head_set = -1);
 int trace_any_queue(const mirres_bvh* bvh, const Ray* rays, const uint32_t* d_count, size_t capacity, int32_t* hit,
                     unsigned long long* stats, hipStream_t s, int lane = 0, int timed = 0, bool heads_clean = false);
 int trace_any_front_queue(const mirres_bvh* bvh, const Ray* rays, const uint32_t* d_count, size_t capacity, int32_t* hit, hipStream_t s);
@@ -186,7 +199,7 @@ int launch_initial_batch(mirres_ctx* ctx, mirres_bvh* bvh, const mirres_env_t* e
 int launch_final_batch(mirres_ctx* ctx, mirres_bvh* bvh, const mirres_env_t* env, const float* occ, const float* pos, const float* normal, const float* ray_dir,
                        const float* kd, const float* rm, const mirres_res_t* res, int K, const PtQueues* q, float* color, float* diff, float* spec, float* tape, hipStream_t s);
 int launch_spatial(mirres_ctx* ctx, mirres_bvh* bvh, const mirres_env_t* env, const mirres_gbuf_t* g, const mirres_res_t* res, const mirres_res_t* prev_res,
-                   const float* neighbor_offsets, uint32_t frameIndex, hipStream_t s, const mirres_res_t* next_res, uint32_t next_frame);
+                   const float* neighbor_offsets, uint32_t frameIndex, hipStream_t s, const mirres_res_t* next_res, uint32_t next_frame, const SpatialBand* band = nullptr);
 int trace_any_q(mirres_ctx* ctx, mirres_bvh* bvh, const Ray* rays, const uint32_t* count, size_t cap, int32_t* hit, hipStream_t s, int lane = 0);
 int trace_closest_q(mirres_ctx* ctx, mirres_bvh* bvh, const Ray* rays, const uint32_t* count, size_t cap, HitRec* out, hipStream_t s, int lane = 0);
 inline int grid_for(size_t n, int block) { size_t g = (n + block - 1) / block; return (int)(g < 1 ? 1 : g); }

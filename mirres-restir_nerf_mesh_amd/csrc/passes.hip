@@ -7,6 +7,7 @@
 #ifndef MR_LEAN_FP
 #define MR_LEAN_FP 1      // device_math.hpp: short division / square-root sequences, bit-identical to the compiler's for the renderer's operand range
 #endif
+#include <algorithm>
 #include "engine.hpp"
 #include "device_math.hpp"
 #include "device_light.hpp"
@@ -438,14 +439,16 @@ MR_DEV bool row_in(const RowSet& r, int pi, int fx) { if (r.mode == 0) return tr
 template <int MR_MAX_NB, bool ITEMS = false>   // 5 (the reference's neighbour count) or 8: bounds the unrolled gathers, i.e. the registers held
 __global__ void __launch_bounds__(MR_SGEN_BLOCK / MR_SGEN_PX) k_spatial_gen(mirres_config_t C, GBufD G, ResD PR, const float* __restrict__ noff, uint32_t frameIndex,
                                                           int fx, int fy, int N, int y_off, const float* __restrict__ occ_own, Ray* __restrict__ q,
-                                                          uint32_t* __restrict__ q_count, int32_t* __restrict__ slot_out, uint32_t* __restrict__ mask_out, RowSet rows, unsigned long long* __restrict__ mark_dead) {
+                                                          uint32_t* __restrict__ q_count, int32_t* __restrict__ slot_out, uint32_t* __restrict__ mask_out, RowSet rows, unsigned long long* __restrict__ mark_dead,
+                                                          int band_y0, int band_rows) {      // the launch covers rows [band_y0, band_y0 + band_rows) (whole frame: 0, fy)
     // strip sharding: y_off = global row of local row 0 (seeds), occ_own = occupancy with the halo rows zeroed (which pixels this rank merges);
     // neighbours are tested against the true G-buffer, halo rows included
     const int k = min(C.neighbor_count, MR_MAX_NB);
     int pis[MR_SGEN_PX]; uint32_t masks[MR_SGEN_PX]; int nbs[MR_SGEN_PX][MR_MAX_NB]; uint32_t cnt_all = 0;
 #pragma unroll
     for (int px = 0; px < MR_SGEN_PX; px++) {
-    int pi = tile_pixel_v(fx, fy, MR_SGEN_TILE, N, (int)threadIdx.x + px * (MR_SGEN_BLOCK / MR_SGEN_PX));
+    int pi = tile_pixel_v(fx, band_rows, MR_SGEN_TILE, fx * band_rows, (int)threadIdx.x + px * (MR_SGEN_BLOCK / MR_SGEN_PX));
+    pi = pi < fx * band_rows ? pi + band_y0 * fx : N;
     if (pi < N && !row_in(rows, pi, fx)) pi = N;       // not this launch's rows: no pixel (nothing read, nothing written)
     uint32_t mask = 0, cnt = 0;
     int nb[MR_MAX_NB];
@@ -643,14 +646,16 @@ template <int MR_MAX_NB, bool FUSE>
 __global__ void MR_SRES_ATTR __launch_bounds__(MR_SRES_TILE * MR_SRES_TILE) k_spatial_resolve(mirres_config_t C, EnvD E, GBufD G, ResD R, ResD PR, const float* __restrict__ noff,
                                                               uint32_t frameIndex, int fx, int fy, int N, int y_off, const float* __restrict__ occ_own,
                                                               const int32_t* __restrict__ slot, const uint32_t* __restrict__ mask_in, const int32_t* __restrict__ hit,
-                                                              uint32_t* __restrict__ reset_counter, uint32_t* __restrict__ reset_heads, ResD NR, uint32_t next_frame, RowSet rows) {
+                                                              uint32_t* __restrict__ reset_counter, uint32_t* __restrict__ reset_heads, ResD NR, uint32_t next_frame, RowSet rows,
+                                                              int band_y0, int band_rows) {
     // mirres_render's chain: the shadow-ray launch of this pass has finished (stream order), so the ray counter and the traversal work heads it used
     // are zeroed here for the next sample's pass instead of by two separate fill launches per sample
     if (reset_heads && blockIdx.x == 0) {
         for (int i = threadIdx.x; i < MR_WSET; i += MR_SRES_TILE * MR_SRES_TILE) reset_heads[i] = 0u;
         if (threadIdx.x == 0) *reset_counter = 0u;
     }
-    const int pi = tile_pixel(fx, fy, MR_SRES_TILE, N);
+    int pi = tile_pixel(fx, band_rows, MR_SRES_TILE, fx * band_rows);
+    pi = pi < fx * band_rows ? pi + band_y0 * fx : N;
     if (pi >= N || !row_in(rows, pi, fx)) return;
     Ris s; GPix gc;
     const bool fg = spatial_pixel<MR_MAX_NB>(C, E, G, PR, noff, frameIndex, fx, y_off, occ_own, slot, mask_in, hit, pi, s, &gc);
@@ -860,13 +865,19 @@ int launch_final_batch(mirres_ctx* ctx, mirres_bvh* bvh, const mirres_env_t* env
 
 // spatial pass; next_res != NULL (mirres_render's chain, packed reservoirs): the temporal merge of the next sample is fused into the resolve kernel (k_spatial_resolve<., true>)
 int launch_spatial(mirres_ctx* ctx, mirres_bvh* bvh, const mirres_env_t* env, const mirres_gbuf_t* g, const mirres_res_t* res, const mirres_res_t* prev_res,
-                   const float* neighbor_offsets, uint32_t frameIndex, hipStream_t s, const mirres_res_t* next_res, uint32_t next_frame) {
+                   const float* neighbor_offsets, uint32_t frameIndex, hipStream_t s, const mirres_res_t* next_res, uint32_t next_frame, const SpatialBand* band) {
     if (!ctx || !bvh || !env || !g || !res || !prev_res) { set_error("mirres_restir_spatial: null"); return MIRRES_E_ARG; }
     const int N = (int)ctx->N;
     const float* noff = neighbor_offsets ? neighbor_offsets : ctx->noff;
     const bool fold = ctx->chain_reset;                         // inside mirres_render's chain (its own stream, its own work heads)
-    if (!(fold && ctx->chain_clean)) MR_HIP(hipMemsetAsync(&ctx->counters[0], 0, sizeof(uint32_t), s));
-    uint32_t* const rc_ = fold ? &ctx->counters[0] : nullptr; uint32_t* const rh_ = fold ? bvh->work : nullptr;   // lane 0 = head set 0
+    // a unit of the band pipeline (render.hip) works on rows [y0, y1) with the queue, hit bits, per-pixel slots and work heads of its chain stream's set
+    Ray* const q_rays = band ? band->set->q : ctx->any_rays; int32_t* const q_hit = band ? band->set->hit : ctx->any_hit; uint32_t* const q_count = band ? band->set->counter : &ctx->counters[0];
+    int32_t* const px_slot = band ? band->set->slot : ctx->slot_a; uint32_t* const px_mask = band ? band->set->mask : ctx->mask_a;
+    const int head_set = band ? band->set->head_set : 0;
+    bool& clean = band ? band->set->clean : ctx->chain_clean;
+    const int by0 = band ? band->y0 : 0, gen_rows = band ? band->gen_y1 - band->y0 : ctx->fy, res_rows = band ? band->y1 - band->y0 : ctx->fy;
+    if (!(fold && clean)) MR_HIP(hipMemsetAsync(q_count, 0, sizeof(uint32_t), s));
+    uint32_t* const rc_ = fold ? q_count : nullptr; uint32_t* const rh_ = fold ? bvh->work + (size_t)head_set * MR_WSET : nullptr;
     const bool nb5 = ctx->cfg.neighbor_count <= 5;
     const RowSet rows = {ctx->row_a, ctx->row_b, ctx->row_mode};
     // mirres_render's chain (packed pixel records + packed reservoirs, no per-ray counters wanted): the queue carries pixel pairs and the traversal kernel forms the rays
@@ -875,8 +886,8 @@ int launch_spatial(mirres_ctx* ctx, mirres_bvh* bvh, const mirres_env_t* env, co
     // mode of the chain (32-byte rays, own counters) they are marked instead, so that the counters describe what production traces; never for the reference-order counts
     static const int skip_dead = [] { const char* e = getenv("MIRRES_SKIP_DEAD"); return (e && e[0] == '0') ? 0 : 1; }();
     unsigned long long* const mark_dead = (skip_dead && ctx->grec && resd(prev_res).rec && (ctx->instrument & 1) && !(ctx->instrument & 4)) ? &ctx->stats[12] : nullptr;
-    const dim3 sg_grid(tile_grid(ctx->fx, ctx->fy, MR_SGEN_TILE)), sg_block(MR_SGEN_BLOCK / MR_SGEN_PX);
-#define MR_SGEN_ARGS ctx->cfg, gbufd(g), resd(prev_res), noff, frameIndex, ctx->fx, ctx->fy, N, ctx->y_off, ctx->occ_own, ctx->any_rays, &ctx->counters[0], ctx->slot_a, ctx->mask_a, rows, mark_dead
+    const dim3 sg_grid(tile_grid(ctx->fx, gen_rows, MR_SGEN_TILE)), sg_block(MR_SGEN_BLOCK / MR_SGEN_PX);
+#define MR_SGEN_ARGS ctx->cfg, gbufd(g), resd(prev_res), noff, frameIndex, ctx->fx, ctx->fy, N, ctx->y_off, ctx->occ_own, q_rays, q_count, px_slot, px_mask, rows, mark_dead, by0, gen_rows
     if (nb5 && items) k_spatial_gen<5, true><<<sg_grid, sg_block, 0, s>>>(MR_SGEN_ARGS);
     else if (nb5) k_spatial_gen<5><<<sg_grid, sg_block, 0, s>>>(MR_SGEN_ARGS);
     else if (items) k_spatial_gen<8, true><<<sg_grid, sg_block, 0, s>>>(MR_SGEN_ARGS);
@@ -885,21 +896,31 @@ int launch_spatial(mirres_ctx* ctx, mirres_bvh* bvh, const mirres_env_t* env, co
     int rc;
     if (items) {
         const RaySrc src = {reinterpret_cast<const float4*>(ctx->grec), resd(prev_res).rec, ctx->cfg.vis_near, skip_dead};
-        rc = trace_any_items_q(ctx, bvh, ctx->any_rays, src, &ctx->counters[0], ctx->any_cap, ctx->any_hit, s, 0);
-    } else rc = trace_any(ctx, bvh, ctx->any_cap, s);
+        // the launch is sized by what the rows can produce (two rays per accepted neighbour): a band of a small frame does not start eight thousand waves
+        const size_t cap = band ? std::min(ctx->any_cap, (size_t)gen_rows * ctx->fx * (size_t)(2 * (ctx->cfg.neighbor_count > 1 ? ctx->cfg.neighbor_count : 1))) : ctx->any_cap;
+        if (band) {
+            hipEvent_t *e0 = nullptr, *e1 = nullptr;
+            if (ctx->instrument & 2) { int rce = ev_pair(ctx->ev_any, ctx->ev_any_used, &e0, &e1); if (rce) return rce; MR_HIP(hipEventRecord(*e0, s)); }
+            rc = trace_any_items_queue(bvh, reinterpret_cast<const uint2*>(q_rays), src, q_count, cap, q_hit, ctx->stats, s, 0, (ctx->instrument & 2) != 0, fold && clean, head_set);
+            if (e1) MR_HIP(hipEventRecord(*e1, s));
+        } else rc = trace_any_items_q(ctx, bvh, ctx->any_rays, src, &ctx->counters[0], ctx->any_cap, ctx->any_hit, s, 0);
+    } else {
+        if (band) { set_error("mirres_render: the band pipeline needs the pixel-pair queue"); return MIRRES_E_STATE; }
+        rc = trace_any(ctx, bvh, ctx->any_cap, s);
+    }
     if (rc) return rc;
     GBufD gr = gbufd(g);
     if (ctx->grec) gr.rec = reinterpret_cast<const float4*>(ctx->grec);   // mirres_render: same values, one 64-byte record per neighbour instead of three arrays
     const bool fuse = next_res && resd(next_res).rec && resd(res).rec && gr.rec;
     const ResD NR = fuse ? resd(next_res) : resd(res);
-    const int rg = tile_grid(ctx->fx, ctx->fy, MR_SRES_TILE), rb = MR_SRES_TILE * MR_SRES_TILE;
-#define MR_SRES_ARGS ctx->cfg, envh(env), gr, resd(res), resd(prev_res), noff, frameIndex, ctx->fx, ctx->fy, N, ctx->y_off, ctx->occ_own, ctx->slot_a, ctx->mask_a, ctx->any_hit, rc_, rh_, NR, next_frame, rows
+    const int rg = tile_grid(ctx->fx, res_rows, MR_SRES_TILE), rb = MR_SRES_TILE * MR_SRES_TILE;
+#define MR_SRES_ARGS ctx->cfg, envh(env), gr, resd(res), resd(prev_res), noff, frameIndex, ctx->fx, ctx->fy, N, ctx->y_off, ctx->occ_own, px_slot, px_mask, q_hit, rc_, rh_, NR, next_frame, rows, by0, res_rows
     if (nb5 && fuse) k_spatial_resolve<5, true><<<rg, rb, 0, s>>>(MR_SRES_ARGS);
     else if (nb5) k_spatial_resolve<5, false><<<rg, rb, 0, s>>>(MR_SRES_ARGS);
     else if (fuse) k_spatial_resolve<8, true><<<rg, rb, 0, s>>>(MR_SRES_ARGS);
     else k_spatial_resolve<8, false><<<rg, rb, 0, s>>>(MR_SRES_ARGS);
 #undef MR_SRES_ARGS
-    if (fold) ctx->chain_clean = true;
+    if (fold) clean = true;
     MR_LAUNCH_CHECK("restir_spatial");
     return MIRRES_OK;
 }
@@ -957,6 +978,8 @@ void mirres_ctx_destroy(mirres_ctx_t* c) {
     if (c->ev_join_pt2) (void)hipEventDestroy(c->ev_join_pt2);
     if (c->pt_stream2) (void)hipStreamDestroy(c->pt_stream2);
     for (hipEvent_t e : c->ev_pt) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->ev_band) (void)hipEventDestroy(e);
+    for (int t = 0; t < 2; t++) { if (c->chain_streams[t]) (void)hipStreamDestroy(c->chain_streams[t]); if (c->chain_mem[t]) (void)hipFree(c->chain_mem[t]); }
     if (c->fin_stream) (void)hipStreamDestroy(c->fin_stream);
     for (hipEvent_t e : c->ev_halo) if (e) (void)hipEventDestroy(e);      // created on first use by mirres_render's strip_overlap path (render.hip)
     if (c->halo_stream) (void)hipStreamDestroy(c->halo_stream);

@@ -315,6 +315,47 @@ static int carve_batch(mirres_ctx* ctx, int N, int K, int max_bounce, size_t TS,
     return 0;
 }
 
+// ---- band pipeline of the per-sample chain (round 6)
+// The temporal -> spatial chain is the one dependent sequence of a frame: sample i + 1 needs sample i. The dependence is LOCAL, though: the spatial pass of a pixel reads
+// the (temporal output) reservoirs of pixels within gather_radius = 30 px (SpatialResampling.slang:33-39), and with the temporal merge of sample i + 1 fused into the
+// resolve of sample i, a band of rows of sample i + 1 needs sample i of the band itself and of its two neighbours only. The frame is therefore cut into B bands of rows;
+// unit (i, j) = generate + trace + resolve of sample i on band j; unit (i + 1, j) waits for unit (i, j + 1) — which, the units of a sample running in order on one
+// stream, implies (i, j) and (i, j - 1) — and the samples alternate between S chain streams with queue resources of their own (ChainSet): S samples are in flight, a band
+// or two apart. A full 1600 x 1600 frame fills the device with one sample's launches (B = 1 there, nothing changes); a small frame — the 800 x 800 training frame, a
+// strip — does not: its three dependent launches per sample last as long as their longest rays, and two or three of them side by side fill the idle CUs.
+// Exact for any B and S: every pixel's generator, rays and merge are what the single launch computes (the order of the rays in a queue is the only thing that changes,
+// and one row per band is generated and traced twice: the fused temporal merge of a band's last row may recompute the pixel below it, whose rays must be in the unit's
+// own queue).
+static int band_count(const mirres_ctx* ctx, bool allowed) {   // MIRRES_BANDS: 0 / unset = by frame size, 1 = off, n = n bands (each at least 32 rows, boundaries at multiples of 16 rows)
+    if (!allowed) return 1;
+    const char* e = getenv("MIRRES_BANDS"); int b = e ? atoi(e) : 0;
+    if (b <= 0) b = ((size_t)ctx->fx * ctx->fy >= (size_t)1400 * 1400) ? 1 : ctx->fy / 128;
+    const int most = ctx->fy / 48;
+    if (b > most) b = most; if (b > 16) b = 16; if (b < 1) b = 1;
+    return b;
+}
+static int chain_stream_count() { const char* e = getenv("MIRRES_CHAIN_STREAMS"); const int n = e ? atoi(e) : 2; return n < 1 ? 1 : (n > 3 ? 3 : n); }
+static int ensure_chain_sets(mirres_ctx* ctx, int S) {
+    ChainSet& c0 = ctx->chain_sets[0];
+    c0.q = ctx->any_rays; c0.hit = ctx->any_hit; c0.counter = &ctx->counters[0]; c0.slot = ctx->slot_a; c0.mask = ctx->mask_a; c0.head_set = 0;
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t N = ctx->N, pairs = ctx->any_cap / 2;
+    for (int t = 1; t < S; t++) {
+        if (!ctx->chain_streams[t - 1]) MR_HIP(hipStreamCreateWithFlags(&ctx->chain_streams[t - 1], hipStreamNonBlocking));
+        if (!ctx->chain_mem[t - 1]) {
+            const size_t bytes = al(8 * pairs) + al(4 * ctx->any_cap) + al(4 * N) + al(4 * N) + 256;      // pixel pairs, hit bits, slot, mask, counter
+            char* p = nullptr; MR_HIP(hipMalloc(&p, bytes)); MR_HIP(hipMemset(p, 0, bytes));
+            ctx->chain_mem[t - 1] = p;
+            ChainSet& c = ctx->chain_sets[t];
+            c.q = reinterpret_cast<Ray*>(p); p += al(8 * pairs); c.hit = reinterpret_cast<int32_t*>(p); p += al(4 * ctx->any_cap);
+            c.slot = reinterpret_cast<int32_t*>(p); p += al(4 * N); c.mask = reinterpret_cast<uint32_t*>(p); p += al(4 * N); c.counter = reinterpret_cast<uint32_t*>(p);
+            c.head_set = 16 + t;
+        }
+    }
+    for (int t = 0; t < 3; t++) ctx->chain_sets[t].clean = false;
+    return 0;
+}
+
 static int finish(mirres_ctx* ctx, const mirres_render_args_t* a, float* tot[6], FrameBufs& B, hipStream_t s) {
     const int N = (int)ctx->N; const size_t n3 = 3 * (size_t)N;
     const int spp = a->spp;
@@ -499,6 +540,17 @@ int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args
     if (dbg_sum) { MR_HIP(hipMalloc(&d_sums, 8 * 4096)); MR_HIP(hipMemsetAsync(d_sums, 0, 8 * 4096, s)); }
     auto csum = [&](const void* p, size_t words) { if (dbg_sum && n_sums < 4096) k_checksum<<<1024, MR_BLOCK, 0, s>>>((const uint32_t*)p, words, d_sums + n_sums++); };
     int pt_seq = 0;   // running index of the path-tracing sub-batches
+    // band pipeline of the chain: only inside the streamed schedule (own work heads, packed reservoirs), not for strips (their per-sample halo exchange is a barrier over
+    // the whole local frame), not for the checksum / counting / event-timing modes
+    const int nbands = band_count(ctx, two_streams && !a->halo && !dbg_sum && ctx->instrument == 0 && !(getenv("MIRRES_FUSE_TEMPORAL") && getenv("MIRRES_FUSE_TEMPORAL")[0] == '0') &&
+                                       !(getenv("MIRRES_SPATIAL_RAYS") && getenv("MIRRES_SPATIAL_RAYS")[0] == '1'));
+    const int nchain = nbands > 1 ? chain_stream_count() : 1;
+    hipStream_t cstream[3] = {s, nullptr, nullptr};
+    int band_seq = 0; bool have_last_unit = false; hipEvent_t last_unit_ev = nullptr; hipStream_t last_unit_stream = s;
+    if (nbands > 1) {
+        rc = ensure_chain_sets(ctx, nchain); if (rc) return rc;
+        for (int t = 1; t < nchain; t++) { cstream[t] = ctx->chain_streams[t - 1]; MR_HIP(hipStreamWaitEvent(cstream[t], ctx->ev_fork, 0)); }
+    }
     if (st2) while (ctx->ev_pt.size() < 2) { hipEvent_t e; MR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ctx->ev_pt.push_back(e); }
     rc = initial(0); if (rc) return rc;
     if (two_streams) MR_HIP(hipEventRecord(ev_bulk(-1), sp));
@@ -535,6 +587,46 @@ int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args
             }
         }
         bool merged_already = false;     // this sample's temporal merge ran inside the previous sample's resolve
+        if (nbands > 1) {
+            // ---- band pipeline (see band_count): the batch's samples alternate between the chain streams; unit (k, j) waits for unit (k - 1, j + 1)
+            const int NBv = nbands;
+            while ((int)ctx->ev_band.size() < PB.K * NBv) { hipEvent_t e; MR_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ctx->ev_band.push_back(e); }
+            auto ev_unit = [&](int k, int j) { return ctx->ev_band[(size_t)k * NBv + j]; };
+            auto band_row = [&](int j) { return j >= NBv ? ctx->fy : (int)(((long long)ctx->fy * j / NBv + 8) / 16 * 16); };
+            for (int t = 1; t < nchain; t++) {      // the other chain streams enter the batch where the caller's stream does (I(b) done; F(b - 2) done with the reservoirs C(b) overwrites)
+                if (two_streams) MR_HIP(hipStreamWaitEvent(cstream[t], ev_bulk(b - 1), 0));
+                if (sf != sp && b >= 2) MR_HIP(hipStreamWaitEvent(cstream[t], ev_fin(b - 2), 0));
+            }
+            for (int k = 0; k < kk; k++) {
+                const int i = ib + k, t = band_seq % nchain; band_seq++;
+                hipStream_t cs = cstream[t];
+                const uint32_t base = a->random_offset + passes * (uint32_t)i;
+                uint32_t pass = 3;
+                mirres_res_t rt = res_slot(PB.rinit[b & 1], k, (size_t)N), rs = res_slot(PB.rspat[b & 1], k, (size_t)N);
+                if (i > 0) {
+                    if (k == 0 && i > i0) {
+                        // the batch's first sample merges in a launch of its own over the whole frame (its initial reservoirs come from the bulk stream): after EVERY unit of
+                        // the previous sample, i.e. after its last one (the units of a sample run in order)
+                        if (have_last_unit && last_unit_stream != cs) MR_HIP(hipStreamWaitEvent(cs, last_unit_ev, 0));
+                        mirres_res_t rp = res_slot(PB.rspat[(b - 1) & 1], PB.K - 1, (size_t)N);
+                        rc = mirres_restir_temporal(ctx, &E, &G, &G, &rt, &rp, nullptr, base + pass, cs); if (rc) return rc;
+                    }
+                    pass += 1;
+                }
+                const bool fuse_next = k + 1 < kk;
+                mirres_res_t rn = res_slot(PB.rinit[b & 1], fuse_next ? k + 1 : k, (size_t)N);
+                for (int j = 0; j < NBv; j++) {
+                    if (k > 0 && nchain > 1) MR_HIP(hipStreamWaitEvent(cs, ev_unit(k - 1, j + 1 < NBv ? j + 1 : NBv - 1), 0));
+                    const int y0 = band_row(j), y1 = band_row(j + 1);
+                    SpatialBand band = {y0, y1, (j + 1 < NBv) ? y1 + 1 : y1, &ctx->chain_sets[t]};
+                    rc = launch_spatial(ctx, bvh, &E, &Gt, &rs, &rt, nullptr, base + pass, cs, fuse_next ? &rn : nullptr, a->random_offset + passes * (uint32_t)(i + 1) + 3u, &band); if (rc) return rc;
+                    MR_HIP(hipEventRecord(ev_unit(k, j), cs));
+                }
+                have_last_unit = true; last_unit_ev = ev_unit(k, NBv - 1); last_unit_stream = cs;
+            }
+            // the batch's chain is done when its last unit is (every earlier unit is among that unit's predecessors): the caller's stream carries the hand-off event
+            if (last_unit_stream != s) MR_HIP(hipStreamWaitEvent(s, last_unit_ev, 0));
+        } else
         for (int k = 0; k < kk; k++) {
             const int i = ib + k;
             const uint32_t base = a->random_offset + passes * (uint32_t)i;

@@ -393,6 +393,37 @@ def test_configs2_training_step_800x800_32spp(big, scene_mod, monkeypatch):
         assert cos > 0.999, (nm, cos)
 
 
+def test_band_pipeline_of_the_chain_does_not_change_the_frame(big, scene_mod, monkeypatch):
+    """Round 6: the temporal -> spatial chain cut into B bands of rows whose units (sample, band) run on S chain streams, sample i + 1 of a band starting as soon as
+    sample i of the band and of its neighbours has resolved (render.hip, band pipeline). Exact by construction: an 800 x 800 frame (the training frame's size: the
+    case it is for) of 11 samples in batches of 4 (first-of-batch temporal merges in their own launch, fused ones elsewhere, a ragged last batch) must come out
+    bit-identical in all six buffers for B in {1, 2, 4, 7, 16} and S in {1, 2, 3} — and so must the full 1600 x 1600 frame with the pipeline forced on."""
+    v, t, W, RR, harness, torch = big
+    from mirres_restir_nerf_mesh_amd._ops import get_ctx
+    from mirres_restir_nerf_mesh_amd.render_helper import MLPTexture3D
+    mn, mx = scene_mod.material_min_max()
+    mlp = MLPTexture3D(torch.tensor([-1, -1, -1, 1, 1, 1], dtype=torch.float32), channels=6, min_max=(torch.from_numpy(mn).cuda(), torch.from_numpy(mx).cuda()), seed=3)
+    env = torch.from_numpy(scene_mod.make_env(256, 512)).cuda()
+    monkeypatch.setenv("MIRRES_PT_BATCH", "4")
+    for res, ssaa, spp, cases in ((400, 2, 11, ((2, 2), (4, 2), (7, 3), (16, 3), (4, 1), (0, 2))), (800, 2, 5, ((4, 2), (8, 3)))):
+        g = harness.build_gbuffer(W, res, res, ssaa)
+        ctx = get_ctx(g["fx"], g["fy"])
+        def frame():
+            outs, _, _ = RR.render_fused(ctx, W, mlp, False, (1, 1, 1), env, g["occ"].clone(), g["normal"], g["depth"], g["kd"], g["rm"], g["ray_dir"], g["pos"], spp, 2, 2, 2.0, 0.1, 0.001, 777)
+            torch.cuda.synchronize()
+            return [o.clone() for o in outs]
+        monkeypatch.setenv("MIRRES_BANDS", "1"); monkeypatch.setenv("MIRRES_CHAIN_STREAMS", "1")
+        ref = frame()
+        assert all(bool(torch.isfinite(o).all()) for o in ref)
+        for bands, streams in cases:
+            monkeypatch.setenv("MIRRES_BANDS", str(bands)); monkeypatch.setenv("MIRRES_CHAIN_STREAMS", str(streams))
+            for rep in range(2):      # twice: a race between the chain streams would not repeat itself
+                got = frame()
+                for k, (a, b) in enumerate(zip(ref, got)):
+                    assert torch.equal(a, b), "%d x %d internal, %d bands on %d chain streams (run %d): buffer %d differs in %d values" % (
+                        g["fx"], g["fy"], bands, streams, rep, k, int((a != b).sum()))
+
+
 def test_pixel_pair_queue_and_ray_queue_render_the_same_frame_at_full_size():
     """The spatial pass hands its shadow rays to the traversal kernel as pixel pairs (the kernel forms the rays) or, with MIRRES_SPATIAL_RAYS=1, as 32-byte rays
     formed by the generator — the same expressions on the same inputs, so a 1600 x 1600 frame with the material field must come out with the same bits. The
