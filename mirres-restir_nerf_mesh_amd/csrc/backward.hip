@@ -298,6 +298,19 @@ __global__ void __launch_bounds__(MR_BLOCK) k_matnet_bwd(MatNetB M, GridLevelsB 
         const bool live = i < n;
         float a0[32], h1[32], h2[32], gz2[6], gh2[32], gh1[32], ga0[32];
         float x[3] = {0.f, 0.f, 0.f}, xraw[3] = {0.f, 0.f, 0.f};
+        // Round 6: a tile whose 64 points all carry a zero cotangent (the background pixels of a training view: 60 % of an image; the loss is taken over foreground
+        // pixels) adds exact zeros to every gradient — skipped as a wave; its position gradient is the zero the full computation writes
+        {
+            bool nz = false;
+            if (live) {
+#pragma unroll
+                for (int o = 0; o < 6; o++) nz = nz || gout[6 * (size_t)i + o] != 0.f;
+            }
+            if (!__ballot(nz)) {
+                if (g_pos && live) { g_pos[3 * (size_t)i] = 0.f; g_pos[3 * (size_t)i + 1] = 0.f; g_pos[3 * (size_t)i + 2] = 0.f; }
+                continue;
+            }
+        }
         if (live) {
 #pragma unroll
             for (int d = 0; d < 3; d++) { xraw[d] = (pos[3 * (size_t)i + d] - M.aabb_min[d]) / (M.aabb_max[d] - M.aabb_min[d]); x[d] = fminf(fmaxf(xraw[d], 0.f), 1.f); }

@@ -434,19 +434,10 @@ static_assert(MR_ANY_STACK >= 3 * (MR_SAH_LEVELS + (38 - MR_SAH_PREFIX) + 31), "
 static_assert(MR_ANY_LDS >= 3 && MR_ANY_LDS <= MR_ANY_STACK, "the LDS part of the private stack holds at least one node's deferred references");
 #define MR_TOPBIT 0x20000000
 #ifndef MR_ANY_SEL
-#define MR_ANY_SEL 0
-#endif
-#ifndef MR_ANY_SEL_ADDC
-#define MR_ANY_SEL_ADDC 0
-#endif
-#ifndef MR_ANY_LEAFP
-#define MR_ANY_LEAFP 0
+#define MR_ANY_SEL 1      // straight-line child selection (round 6); 0: round 5's sequential insert
 #endif
 #ifndef MR_ANY_LEANREFILL
-#define MR_ANY_LEANREFILL 0
-#endif
-#ifndef MR_ANY_LEAFT
-#define MR_ANY_LEAFT 8
+#define MR_ANY_LEANREFILL 1      // short division / square root where the pixel-pair source forms its rays (round 6); 0: the compiler's IEEE sequences
 #endif
 #ifndef MR_CL_REFILL
 #define MR_CL_REFILL MR_REFILL
@@ -578,7 +569,6 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const
     int cur = 0, sp = 0, sbase = 0; uint32_t ridx = 0;   // the lane's deferred entries live in [sbase, sp)
     uint32_t spill[MR_ANY_STACK - MR_ANY_LDS];
     unsigned long long c_boxes = 0, c_nodes = 0, c_leaves = 0; int c_maxsp = 0;
-    int leaf_wait = 0;   // MR_ANY_LEAFP: wave iterations the oldest waiting leaf has waited (wave-uniform)
     unsigned long long w_iters = 0, w_leaf_iters = 0, w_leaf_lanes = 0;      // COUNT: wave iterations, those that ran the leaf branch, leaf visits (wave-uniform; lane 0 reports)
     while (true) {
         const uint64_t need = __ballot(!have);
@@ -662,15 +652,6 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const
         if (!__ballot(have)) { if (exhausted) break; else continue; }
         do {
             int ref = cur; bool active = have;
-#if MR_ANY_LEAFP > 1
-            // Round 6 experiment: lanes that have reached a leaf wait (at most MR_ANY_LEAFP - 1 iterations) for a LEAF ROUND, so that the leaf branch — exact slab + Moller-Trumbore,
-            // run today in 73 % / 91 % of the wave iterations for 3 / 6.6 lanes — runs less often for more lanes. A round is due when no lane is at a node, when MR_ANY_LEAFT lanes wait,
-            // or when the oldest waiting leaf has waited long enough. Nothing is reordered for a ray; only when its leaf is looked at changes.
-            { const uint64_t lm = __ballot(active && ref < 0), nm = __ballot(active && ref >= 0);
-              leaf_wait = lm ? leaf_wait + 1 : 0;
-              const bool round = !nm || __popcll(lm) >= MR_ANY_LEAFT || leaf_wait >= MR_ANY_LEAFP;
-              if (round) leaf_wait = 0; else if (ref < 0) active = false; }
-#endif
             if (COUNT) { const uint64_t lm = __ballot(active && ref < 0); w_iters++; if (lm) { w_leaf_iters++; w_leaf_lanes += (unsigned long long)__popcll(lm); } }
             if (active) {
                 // one 64-byte record per iteration — a Node4q or a LeafRec — fetched before the type is looked at, so that a wave pays ONE memory
@@ -709,46 +690,16 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const
                     child_slabs(nc, t_min, tn4, tf4);
                     // A node defers at most three entries. While all three fit the LDS part of the stack (always, on trees of ordinary depth) the
                     // per-entry range checks of the general path — two compares and a select each, 4 issue cycles apiece — are not needed.
-#if MR_ANY_SEL == 1
-                    // Round 6: child selection without control flow. The nearest passing child is the minimum of four keys (entry distance, +inf for a child that fails);
-                    // the up to three others are stored UNCONDITIONALLY at the lane's stack top, which only advances past an entry that is to be kept (what lies above
-                    // `sp` is never read; the LDS part has one spare row for the last store). The order of the deferred entries differs from the sequential insert
-                    // (slot order instead of "swap with the nearest so far"); a shadow ray's answer is an OR over subtrees, any order gives the same bit.
-                    if (sp + 3 <= MR_ANY_LDS) {
-                        const float INF = __int_as_float(0x7f800000);
-                        const bool ok0 = tf4[0] > tn4[0], ok1 = tf4[1] > tn4[1], ok2 = tf4[2] > tn4[2], ok3 = tf4[3] > tn4[3];
-                        const float k0 = ok0 ? tn4[0] : INF, k1 = ok1 ? tn4[1] : INF, k2 = ok2 ? tn4[2] : INF, k3 = ok3 ? tn4[3] : INF;
-                        const float m = fminf(fminf(fminf(k0, k1), k2), k3);
-                        const bool is1 = k1 == m, is2 = k2 == m, is3 = k3 == m;
-                        int nx = ref[0]; nx = is1 ? ref[1] : nx; nx = is2 ? ref[2] : nx; nx = is3 ? ref[3] : nx;
-                        const bool c3 = is3, c2 = is2 && !is3, c1 = is1 && !is2 && !is3, c0 = !(is1 || is2 || is3);
-                        if (COUNT) { for (int k = 0; k < 4; k++) if (ref[k] != ~B.T) c_boxes++; }
-                        lds_stack[sp * MR_TRACE_BLOCK] = (uint32_t)ref[0]; sp += (ok0 && !c0) ? 1 : 0;
-                        lds_stack[sp * MR_TRACE_BLOCK] = (uint32_t)ref[1]; sp += (ok1 && !c1) ? 1 : 0;
-                        lds_stack[sp * MR_TRACE_BLOCK] = (uint32_t)ref[2]; sp += (ok2 && !c2) ? 1 : 0;
-                        lds_stack[sp * MR_TRACE_BLOCK] = (uint32_t)ref[3]; sp += (ok3 && !c3) ? 1 : 0;
-                        next = (ok0 || ok1 || ok2 || ok3) ? nx : 0x7fffffff;
-                    } else {
-#elif MR_ANY_SEL == 4
-                    // as MR_ANY_SEL == 1 with the keys compared as signed integers (the bit patterns of floats order like the floats where it matters: non-negative entry
-                    // distances below +inf; a negative one — a caller's negative t_min — merely counts as nearest): no NaN canonicalisation in front of the minimum
-                    if (sp + 3 <= MR_ANY_LDS) {
-                        const int INFI = 0x7f800000;
-                        const bool ok0 = tf4[0] > tn4[0], ok1 = tf4[1] > tn4[1], ok2 = tf4[2] > tn4[2], ok3 = tf4[3] > tn4[3];
-                        const int k0 = ok0 ? __float_as_int(tn4[0]) : INFI, k1 = ok1 ? __float_as_int(tn4[1]) : INFI, k2 = ok2 ? __float_as_int(tn4[2]) : INFI, k3 = ok3 ? __float_as_int(tn4[3]) : INFI;
-                        const int m = min(min(min(k0, k1), k2), k3);
-                        const bool is1 = k1 == m, is2 = k2 == m, is3 = k3 == m;
-                        int nx = ref[0]; nx = is1 ? ref[1] : nx; nx = is2 ? ref[2] : nx; nx = is3 ? ref[3] : nx;
-                        const bool c3 = is3, c2 = is2 && !is3, c1 = is1 && !is2 && !is3, c0 = !(is1 || is2 || is3);
-                        if (COUNT) { for (int k = 0; k < 4; k++) if (ref[k] != ~B.T) c_boxes++; }
-                        lds_stack[sp * MR_TRACE_BLOCK] = (uint32_t)ref[0]; sp += (ok0 && !c0) ? 1 : 0;
-                        lds_stack[sp * MR_TRACE_BLOCK] = (uint32_t)ref[1]; sp += (ok1 && !c1) ? 1 : 0;
-                        lds_stack[sp * MR_TRACE_BLOCK] = (uint32_t)ref[2]; sp += (ok2 && !c2) ? 1 : 0;
-                        lds_stack[sp * MR_TRACE_BLOCK] = (uint32_t)ref[3]; sp += (ok3 && !c3) ? 1 : 0;
-                        next = (ok0 || ok1 || ok2 || ok3) ? nx : 0x7fffffff;
-                    } else {
-#elif MR_ANY_SEL == 5
-                    // as MR_ANY_SEL == 4 with the lane-mask logic spelled out on the 64-bit masks themselves (ballot / inverse ballot: scalar and / andn2, no v_cmp_ne for a negation)
+#if MR_ANY_SEL
+                    // Round 6: child selection as straight-line code. The nearest passing child is the minimum of four keys — the entry distance's bit pattern
+                    // as a signed integer (floats order like their bits where it matters: non-negative distances below +inf; a negative one, a caller's negative t_min, merely counts
+                    // as nearest; no NaN canonicalisation in front of an integer minimum), +inf for a child that fails — and the highest index among equal minima; the up to three
+                    // other passing children are stored UNCONDITIONALLY at the lane's stack top, which only advances past an entry that is to be kept (what lies above `sp` is
+                    // never read; the LDS part has one spare row for the last store). The lane-mask logic is spelled out on the 64-bit masks themselves (ballot / inverse ballot:
+                    // scalar and / andn2 — the compiler turns a negated compare into a second v_cmp otherwise). The deferred entries are in slot order instead of the sequential
+                    // insert's "swap with the nearest so far"; a shadow ray's answer is an OR over subtrees, any order gives the same bit. Round 5's code: -DMR_ANY_SEL=0.
+                    // Measured (profiles/r06_ab_any_sel*.txt): kernel -4.5 % / -10 % (icosphere / lego-like), frame +2.8 % / +3.5 % with the short refill arithmetic; the
+                    // variants with FEWER VALU instructions — exec-masked stores (2), a compare tournament (3), v_addc on the mask (6) — were all slower than this one.
                     if (sp + 3 <= MR_ANY_LDS) {
                         const int INFI = 0x7f800000;
                         const uint64_t o0 = __builtin_amdgcn_ballot_w64(tf4[0] > tn4[0]), o1 = __builtin_amdgcn_ballot_w64(tf4[1] > tn4[1]);
@@ -761,66 +712,11 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const
                         // the chosen child: the highest index among the minima; the others that pass are kept
                         const uint64_t p3 = o3 & ~e3, p2 = o2 & ~(e2 & ~e3), p1 = o1 & ~(e1 & ~(e2 | e3)), p0 = o0 & (e1 | e2 | e3);
                         if (COUNT) { for (int k = 0; k < 4; k++) if (ref[k] != ~B.T) c_boxes++; }
-#if MR_ANY_SEL_ADDC
-                        // sp += (lane's bit of the mask): one v_addc_co_u32 with the mask as carry-in (the compiler materialises 0 / 1 with a v_cndmask first)
-#define MR_ADDC(SP, MASK) asm("v_addc_co_u32_e64 %0, vcc, %1, 0, %2" : "=v"(SP) : "v"(SP), "s"(MASK) : "vcc")
-                        lds_stack[sp * MR_TRACE_BLOCK] = (uint32_t)ref[0]; MR_ADDC(sp, p0);
-                        lds_stack[sp * MR_TRACE_BLOCK] = (uint32_t)ref[1]; MR_ADDC(sp, p1);
-                        lds_stack[sp * MR_TRACE_BLOCK] = (uint32_t)ref[2]; MR_ADDC(sp, p2);
-                        lds_stack[sp * MR_TRACE_BLOCK] = (uint32_t)ref[3]; MR_ADDC(sp, p3);
-#undef MR_ADDC
-#else
                         lds_stack[sp * MR_TRACE_BLOCK] = (uint32_t)ref[0]; sp += __builtin_amdgcn_inverse_ballot_w64(p0) ? 1 : 0;
                         lds_stack[sp * MR_TRACE_BLOCK] = (uint32_t)ref[1]; sp += __builtin_amdgcn_inverse_ballot_w64(p1) ? 1 : 0;
                         lds_stack[sp * MR_TRACE_BLOCK] = (uint32_t)ref[2]; sp += __builtin_amdgcn_inverse_ballot_w64(p2) ? 1 : 0;
                         lds_stack[sp * MR_TRACE_BLOCK] = (uint32_t)ref[3]; sp += __builtin_amdgcn_inverse_ballot_w64(p3) ? 1 : 0;
-#endif
                         next = __builtin_amdgcn_inverse_ballot_w64(o0 | o1 | o2 | o3) ? nx : 0x7fffffff;
-                    } else {
-#elif MR_ANY_SEL == 2
-                    // Round 6: the nearest passing child by a three-compare tournament on (passes, entry distance) whose outcomes stay lane masks (scalar logic, no selects on
-                    // sentinels), the other passing children stored under their own lane mask: one v_add per child instead of compare + select + shift-or.
-                    if (sp + 3 <= MR_ANY_LDS) {
-                        const bool ok0 = tf4[0] > tn4[0], ok1 = tf4[1] > tn4[1], ok2 = tf4[2] > tn4[2], ok3 = tf4[3] > tn4[3];
-                        const bool a = ok1 && (!ok0 || tn4[1] < tn4[0]);
-                        const float m01 = a ? tn4[1] : tn4[0]; const int r01 = a ? ref[1] : ref[0]; const bool ok01 = ok0 || ok1;
-                        const bool b = ok3 && (!ok2 || tn4[3] < tn4[2]);
-                        const float m23 = b ? tn4[3] : tn4[2]; const int r23 = b ? ref[3] : ref[2]; const bool ok23 = ok2 || ok3;
-                        const bool c = ok23 && (!ok01 || m23 < m01);
-                        const int nx = c ? r23 : r01;
-                        if (COUNT) { for (int k = 0; k < 4; k++) if (ref[k] != ~B.T) c_boxes++; }
-                        typedef __attribute__((address_space(3))) uint32_t lds_u32;      // 32-bit LDS addresses: the stack top as a byte address, one v_add per kept entry
-                        lds_u32* const row0 = (lds_u32*)lds_stack;
-                        lds_u32* top = row0 + sp * MR_TRACE_BLOCK;
-                        if (ok0 && (a || c)) { *top = (uint32_t)ref[0]; top += MR_TRACE_BLOCK; }
-                        if (ok1 && (!a || c)) { *top = (uint32_t)ref[1]; top += MR_TRACE_BLOCK; }
-                        if (ok2 && (b || !c)) { *top = (uint32_t)ref[2]; top += MR_TRACE_BLOCK; }
-                        if (ok3 && !(b && c)) { *top = (uint32_t)ref[3]; top += MR_TRACE_BLOCK; }
-                        sp = (int)(((uint32_t)(uintptr_t)top - (uint32_t)(uintptr_t)row0) / (4u * MR_TRACE_BLOCK));
-                        next = (ok01 || ok23) ? nx : 0x7fffffff;
-                    } else {
-#elif MR_ANY_SEL == 3
-                    // Round 6: as MR_ANY_SEL == 2 (three-compare tournament, outcomes as lane masks), but the stores are unconditional at a byte address that only advances past
-                    // a kept entry — straight-line code, no exec-mask regions (the spare LDS row takes the last store).
-                    if (sp + 3 <= MR_ANY_LDS) {
-                        const bool ok0 = tf4[0] > tn4[0], ok1 = tf4[1] > tn4[1], ok2 = tf4[2] > tn4[2], ok3 = tf4[3] > tn4[3];
-                        const bool a = ok1 && (!ok0 || tn4[1] < tn4[0]);
-                        const float m01 = a ? tn4[1] : tn4[0]; const int r01 = a ? ref[1] : ref[0]; const bool ok01 = ok0 || ok1;
-                        const bool b = ok3 && (!ok2 || tn4[3] < tn4[2]);
-                        const float m23 = b ? tn4[3] : tn4[2]; const int r23 = b ? ref[3] : ref[2]; const bool ok23 = ok2 || ok3;
-                        const bool c = ok23 && (!ok01 || m23 < m01);
-                        const int nx = c ? r23 : r01;
-                        if (COUNT) { for (int k = 0; k < 4; k++) if (ref[k] != ~B.T) c_boxes++; }
-                        typedef __attribute__((address_space(3))) uint32_t lds_u32;
-                        typedef __attribute__((address_space(3))) char lds_char;
-                        lds_char* const row0 = (lds_char*)(lds_u32*)lds_stack;
-                        lds_char* top = row0 + sp * (4 * MR_TRACE_BLOCK);
-                        *(lds_u32*)top = (uint32_t)ref[0]; top += (ok0 && (a || c)) ? 4 * MR_TRACE_BLOCK : 0;
-                        *(lds_u32*)top = (uint32_t)ref[1]; top += (ok1 && (!a || c)) ? 4 * MR_TRACE_BLOCK : 0;
-                        *(lds_u32*)top = (uint32_t)ref[2]; top += (ok2 && (b || !c)) ? 4 * MR_TRACE_BLOCK : 0;
-                        *(lds_u32*)top = (uint32_t)ref[3]; top += (ok3 && !(b && c)) ? 4 * MR_TRACE_BLOCK : 0;
-                        sp = (int)(((uint32_t)(uintptr_t)top - (uint32_t)(uintptr_t)row0) / (4u * MR_TRACE_BLOCK));
-                        next = (ok01 || ok23) ? nx : 0x7fffffff;
                     } else {
 #else
                     if (sp + 3 <= MR_ANY_LDS) {

@@ -326,10 +326,17 @@ static int carve_batch(mirres_ctx* ctx, int N, int K, int max_bounce, size_t TS,
 // Exact for any B and S: every pixel's generator, rays and merge are what the single launch computes (the order of the rays in a queue is the only thing that changes,
 // and one row per band is generated and traced twice: the fused temporal merge of a band's last row may recompute the pixel below it, whose rays must be in the unit's
 // own queue).
-static int band_count(const mirres_ctx* ctx, bool allowed) {   // MIRRES_BANDS: 0 / unset = by frame size, 1 = off, n = n bands (each at least 32 rows, boundaries at multiples of 16 rows)
+// MEASURED (profiles/r06_ab_bands.txt) AND OFF BY DEFAULT: bit-identical for every B and S tried (tests/test_gpu_fullsize.py), and slower everywhere — the 800 x 800
+// training step 30.1 -> 33.4 .. 37.7 ms, an 800 x 800 frame of 128 spp 73.7 -> 83.7 .. 88.2 ms, the full frame -8 % / -5 %. Two reasons. (1) The premise is weaker
+// than it looked: an 800 x 800 frame takes 576 us per sample against 422 us for a quarter of the full frame's sample — the idle share the pipeline could fill is 27 %, not
+// the factor the chain's share of the summed kernel time suggested (the batched stages run beside the chain and slow it: the device is mostly busy). (2) A unit is three
+// dependent launches whose latency does not shrink with the band: a traversal launch lasts as long as its longest rays (~100 us) however few it has, so B bands cost
+// B tails per sample and stream where the single launch pays one; two or three streams overlap them but do not remove them. What would be needed is ONE resident
+// traversal kernel that takes band queues as they become ready — a different engine. MIRRES_BANDS = n switches the pipeline on.
+static int band_count(const mirres_ctx* ctx, bool allowed) {   // MIRRES_BANDS: unset / 0 / 1 = off (default), n = n bands (each at least 48 rows, boundaries at multiples of 16 rows)
     if (!allowed) return 1;
-    const char* e = getenv("MIRRES_BANDS"); int b = e ? atoi(e) : 0;
-    if (b <= 0) b = ((size_t)ctx->fx * ctx->fy >= (size_t)1400 * 1400) ? 1 : ctx->fy / 128;
+    const char* e = getenv("MIRRES_BANDS"); int b = e ? atoi(e) : 1;
+    if (b <= 0) b = 1;
     const int most = ctx->fy / 48;
     if (b > most) b = most; if (b > 16) b = 16; if (b < 1) b = 1;
     return b;

@@ -393,11 +393,37 @@ def test_configs2_training_step_800x800_32spp(big, scene_mod, monkeypatch):
         assert cos > 0.999, (nm, cos)
 
 
+def test_round6_traversal_changes_do_not_change_the_frame():
+    """Round 6 rewrote the shadow-ray kernel's child selection as straight-line code (another order of the deferred entries) and gave the pixel-pair refill the short
+    division / square root. Both are compile-time switches: __graft_entry__.build() also builds the library with round 5's code (ab/libmirres_r5trav.so, built here if it
+    is missing), and a 1600 x 1600 x 6 spp frame with the material field must have the same bits in all six buffers with either library, on both meshes."""
+    import importlib.util, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    variant = os.path.join(root, "ab", "libmirres_r5trav.so")
+    if not os.path.exists(variant):
+        sys.path.insert(0, root)
+        import __graft_entry__ as G
+        spec = importlib.util.spec_from_file_location("mirres_build", os.path.join(root, "mirres-restir_nerf_mesh_amd", "csrc", "build.py"))
+        b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
+        G.build_variant(b, "r5trav", "-DMR_ANY_SEL=0 -DMR_ANY_LEANREFILL=0")
+    assert os.path.exists(variant)
+    for mesh in ("icosphere", "clustered"):
+        lines = []
+        for lib in (None, variant):
+            env = dict(os.environ, MIRRES_MESH=mesh); env.pop("MIRRES_PARITY_REPORT", None); env.pop("MIRRES_LIB", None)
+            if lib: env["MIRRES_LIB"] = lib
+            r = subprocess.run([sys.executable, os.path.join(root, "scripts", "dev_frame_hash.py"), "6"], env=env, capture_output=True, text=True, timeout=900)
+            assert r.returncode == 0, r.stderr[-2000:]
+            lines.append(r.stdout.strip().splitlines()[-1])
+        assert lines[0] == lines[1] and len(lines[0].split()) >= 7, (mesh, lines)
+
+
 def test_band_pipeline_of_the_chain_does_not_change_the_frame(big, scene_mod, monkeypatch):
     """Round 6: the temporal -> spatial chain cut into B bands of rows whose units (sample, band) run on S chain streams, sample i + 1 of a band starting as soon as
     sample i of the band and of its neighbours has resolved (render.hip, band pipeline). Exact by construction: an 800 x 800 frame (the training frame's size: the
     case it is for) of 11 samples in batches of 4 (first-of-batch temporal merges in their own launch, fused ones elsewhere, a ragged last batch) must come out
-    bit-identical in all six buffers for B in {1, 2, 4, 7, 16} and S in {1, 2, 3} — and so must the full 1600 x 1600 frame with the pipeline forced on."""
+    bit-identical in all six buffers for B in {1, 2, 4, 7, 16} and S in {1, 2, 3} — and so must the full 1600 x 1600 frame. (The pipeline is exact and measured SLOWER,
+    profiles/r06_ab_bands.txt: it is off unless MIRRES_BANDS asks for it; the test keeps the exactness claim honest.)"""
     v, t, W, RR, harness, torch = big
     from mirres_restir_nerf_mesh_amd._ops import get_ctx
     from mirres_restir_nerf_mesh_amd.render_helper import MLPTexture3D
@@ -405,7 +431,7 @@ def test_band_pipeline_of_the_chain_does_not_change_the_frame(big, scene_mod, mo
     mlp = MLPTexture3D(torch.tensor([-1, -1, -1, 1, 1, 1], dtype=torch.float32), channels=6, min_max=(torch.from_numpy(mn).cuda(), torch.from_numpy(mx).cuda()), seed=3)
     env = torch.from_numpy(scene_mod.make_env(256, 512)).cuda()
     monkeypatch.setenv("MIRRES_PT_BATCH", "4")
-    for res, ssaa, spp, cases in ((400, 2, 11, ((2, 2), (4, 2), (7, 3), (16, 3), (4, 1), (0, 2))), (800, 2, 5, ((4, 2), (8, 3)))):
+    for res, ssaa, spp, cases in ((400, 2, 11, ((2, 2), (4, 2), (7, 3), (16, 3), (4, 1))), (800, 2, 5, ((4, 2), (8, 3)))):
         g = harness.build_gbuffer(W, res, res, ssaa)
         ctx = get_ctx(g["fx"], g["fy"])
         def frame():
