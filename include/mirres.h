@@ -275,8 +275,26 @@ typedef struct mirres_render_args {
      * rows. Same results bit for bit; the exchange leaves the per-sample critical chain at the price of three more launches per sample (and the next sample's
      * temporal merge is not fused into the resolve kernel). Strips too short to have interior rows fall back to the in-line exchange.                       */
     int strip_overlap;
+    /* Native exchange (round 6): halo_comm = a communicator of mirres_comm_create, or NULL. When set, mirres_render issues the per-sample exchange itself — for each of
+     * the halo_n (<= 2) neighbouring ranks halo_peer[k] one ncclSend of the local rows [halo_send0[k], halo_send1[k]) and one ncclRecv into the local rows
+     * [halo_recv0[k], halo_recv1[k]) of the packed reservoirs, inside one ncclGroupStart / ncclGroupEnd on the chain's stream — and `halo` is not called: no Python on
+     * the per-sample path (the callback costs 56-63 us of host time per sample in the median over RCCL, 240-330 us in the mean: profiles/r06_halo_host_cost*.txt).
+     * halo_time_stride > 0: every halo_time_stride-th exchange is bracketed by events on the stream; mirres_ctx_halo_time sums them (the strip's own busy time =
+     * its render time minus the time spent inside the exchanges, which is where a rank waits for its neighbours: dist.StripBalancer).                              */
+    void* halo_comm;
+    int halo_n, halo_peer[2], halo_send0[2], halo_send1[2], halo_recv0[2], halo_recv1[2];
+    int halo_time_stride;
 } mirres_render_args_t;
 int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args_t* a, void* stream);
+/* The library's own RCCL communicator for the native halo exchange (no reference counterpart: /root/reference is single-GPU). librccl is dlopen-ed —
+ * `librccl_path` (may be NULL / empty) is tried first, the copy already loaded into the process wins. mirres_comm_unique_id: ncclGetUniqueId into 128 bytes (rank 0; the
+ * caller distributes them, e.g. with torch.distributed.broadcast); mirres_comm_create: ncclCommInitRank (collective over the `world` ranks, current device);
+ * mirres_ctx_halo_time: blocks until the last recorded exchange has finished, returns the summed milliseconds of the bracketed exchanges of the last mirres_render on
+ * this context and their number, and forgets them.                                                                                                    */
+int mirres_comm_unique_id(const char* librccl_path, void* id128);
+int mirres_comm_create(void** comm, const char* librccl_path, const void* id128, int world, int rank);
+void mirres_comm_destroy(void* comm);
+int mirres_ctx_halo_time(mirres_ctx_t* ctx, double* ms, int* exchanges);
 /* Backward of the frame's DIRECT lighting sums w.r.t. what the reference differentiates (EvaluateFinalSamples_di.backward +
  * FinalShading.backward summed over the samples, Resampling.py:116-214): from the cotangents of the three direct sums (total colour,
  * diffuse light, specular light — f32[N,3] each) and the tape of the forward call (`samples` samples), gradients w.r.t. normal [N,3],

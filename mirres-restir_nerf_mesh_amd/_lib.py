@@ -52,7 +52,9 @@ class RenderArgs(C.Structure):
                 ("mat", C.POINTER(MatNet)), ("const_kd", C.c_float * 3), ("const_rm", C.c_float * 2),
                 ("denoise_iter", C.c_int), ("step_width", C.c_int), ("c_phi", C.c_float), ("n_phi", C.c_float), ("p_phi", C.c_float),
                 ("outs", vp * 6), ("tape", vp), ("gb_depth", vp), ("spp_begin", C.c_int), ("spp_end", C.c_int),
-                ("strip_full_fy", C.c_int), ("strip_y_off", C.c_int), ("own_y0", C.c_int), ("own_y1", C.c_int), ("halo", vp), ("halo_user", vp), ("strip_overlap", C.c_int)]
+                ("strip_full_fy", C.c_int), ("strip_y_off", C.c_int), ("own_y0", C.c_int), ("own_y1", C.c_int), ("halo", vp), ("halo_user", vp), ("strip_overlap", C.c_int),
+                ("halo_comm", vp), ("halo_n", C.c_int), ("halo_peer", C.c_int * 2), ("halo_send0", C.c_int * 2), ("halo_send1", C.c_int * 2), ("halo_recv0", C.c_int * 2),
+                ("halo_recv1", C.c_int * 2), ("halo_time_stride", C.c_int)]
 
 
 HALO_FN = C.CFUNCTYPE(C.c_int, vp, vp, C.c_int, vp)   # int halo(void* user, float* records, int sample, void* stream)
@@ -69,6 +71,10 @@ SIGNATURES = {
     "mirres_bvh_build": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, vp, vp, vp, vp]),
     "mirres_bvh_trace": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp]),
     "mirres_ctx_create": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, PCFG]),
+    "mirres_comm_unique_id": (C.c_int, [C.c_char_p, vp]),
+    "mirres_comm_create": (C.c_int, [C.POINTER(vp), C.c_char_p, vp, C.c_int, C.c_int]),
+    "mirres_comm_destroy": (None, [vp]),
+    "mirres_ctx_halo_time": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "mirres_ctx_destroy": (None, [vp]),
     "mirres_neighbor_offsets": (C.c_int, [vp, vp, vp]),
     "mirres_ctx_stats": (C.c_int, [vp, C.POINTER(C.c_uint64), C.c_int]),

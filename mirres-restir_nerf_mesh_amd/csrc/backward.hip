@@ -179,16 +179,35 @@ __global__ void __launch_bounds__(MR_BLOCK) k_final_shading_bwd(int N, const flo
 // global atomic per channel at the end; an insert that finds both probes taken by other texels goes to global memory directly.
 #define MR_DBW_SPLIT 8
 #define MR_DBW_TABLE 2048
-MR_DEV void env_grad_add(int* keys, float* vals, float* g_env, int texel, v3 g) {
+#define MR_DBW_LIST 2048
+// Round 6 (profiles/r06_pmc_train.txt, r06_atomic_rate.txt): the kernel ran at the memory side's atomic REQUEST rate — 65 M requests per launch at 17 G/s; MI355X takes
+// 21 G scattered fp32 atomic requests per second whatever the scope (every device-scope atomic leaves the XCD's L2: TCC_EA0_ATOMIC == TCC_ATOMIC), but the lanes of ONE
+// instruction that fall into the same 32-byte sector travel as one request (G consecutive lanes on G consecutive dwords: G x 21 G lane-atomics/s). A texel's three
+// channels are 12 consecutive bytes. So no contribution goes to global memory from the sample loop any more: what the hash table cannot hold (both probes taken by other
+// texels: a flat map spreads a workgroup's 4096 texel updates over as many texels) is appended to an LDS list, and table and list are flushed at the end by FOUR
+// lanes per entry (three channels + an idle lane) — a third of the requests. A full list (cannot happen: 2048 + 2048 entries per workgroup of 4096 updates) still falls
+// back to direct atomics.
+struct EnvScatter { int* keys; float* vals; int* lkeys; float* lvals; int* lcount; };
+MR_DEV void env_grad_add(const EnvScatter& S, float* g_env, int texel, v3 g) {
     uint32_t h = ((uint32_t)texel * 2654435761u) >> (32 - 11);
 #pragma unroll
     for (int probe = 0; probe < 2; probe++) {
-        const int old = atomicCAS(&keys[h], -1, texel);
-        if (old == -1 || old == texel) { atomicAdd(&vals[3 * h], g.x); atomicAdd(&vals[3 * h + 1], g.y); atomicAdd(&vals[3 * h + 2], g.z); return; }
+        const int old = atomicCAS(&S.keys[h], -1, texel);
+        if (old == -1 || old == texel) { atomicAdd(&S.vals[3 * h], g.x); atomicAdd(&S.vals[3 * h + 1], g.y); atomicAdd(&S.vals[3 * h + 2], g.z); return; }
         h = (h + 1) & (MR_DBW_TABLE - 1);
     }
+    const int at = atomicAdd(S.lcount, 1);
+    if (at < MR_DBW_LIST) { S.lkeys[at] = texel; S.lvals[3 * at] = g.x; S.lvals[3 * at + 1] = g.y; S.lvals[3 * at + 2] = g.z; return; }
     float* dst = g_env + 3 * (size_t)texel;
     atomicAdd(dst, g.x); atomicAdd(dst + 1, g.y); atomicAdd(dst + 2, g.z);
+}
+// entries [0, n) of (keys, vals) -> global memory, four lanes per entry: lanes 4 e .. 4 e + 2 add the three channels of one texel in ONE instruction
+MR_DEV void env_grad_flush(const int* keys, const float* vals, int n, float* g_env) {
+    for (int j = threadIdx.x; j < 4 * n; j += MR_BLOCK) {
+        const int e = j >> 2, c = j & 3;
+        const int key = keys[e];
+        if (c < 3 && key >= 0) atomicAdd(g_env + 3 * (size_t)key + c, vals[3 * e + c]);
+    }
 }
 __global__ void __launch_bounds__(MR_BLOCK) k_direct_bwd(EnvD E, int N, int S, const float* __restrict__ occ, const float* __restrict__ normal,
                                                          const float* __restrict__ ray_dir_raw, const float* __restrict__ kd, const float* __restrict__ rm,
@@ -197,8 +216,13 @@ __global__ void __launch_bounds__(MR_BLOCK) k_direct_bwd(EnvD E, int N, int S, c
                                                          float* __restrict__ g_rm, float* __restrict__ g_env) {
     __shared__ int s_keys[MR_DBW_TABLE];
     __shared__ float s_vals[3 * MR_DBW_TABLE];
+    __shared__ int s_lkeys[MR_DBW_LIST];
+    __shared__ float s_lvals[3 * MR_DBW_LIST];
+    __shared__ int s_lcount;
     for (int i = threadIdx.x; i < MR_DBW_TABLE; i += MR_BLOCK) { s_keys[i] = -1; s_vals[3 * i] = 0.f; s_vals[3 * i + 1] = 0.f; s_vals[3 * i + 2] = 0.f; }
+    if (threadIdx.x == 0) s_lcount = 0;
     __syncthreads();
+    const EnvScatter ES = {s_keys, s_vals, s_lkeys, s_lvals, &s_lcount};
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     // lanes l, l + 8, l + 16, ... of a wave hold the same sample phase of consecutive pixels: 8 consecutive tape records per phase
     const int wave_px = (int)(t >> 6) * (64 / MR_DBW_SPLIT);
@@ -227,7 +251,7 @@ __global__ void __launch_bounds__(MR_BLOCK) k_direct_bwd(EnvD E, int N, int S, c
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
                         const int ty = idx[q] / E.W, tx = idx[q] - ty * E.W;
-                        env_grad_add(s_keys, s_vals, g_env, (E.H - 1 - ty) * E.W + tx, V3(gl.x * w[q], gl.y * w[q], gl.z * w[q]));   // tex row ty = caller's row H-1-ty (k_flip_env)
+                        env_grad_add(ES, g_env, (E.H - 1 - ty) * E.W + tx, V3(gl.x * w[q], gl.y * w[q], gl.z * w[q]));   // tex row ty = caller's row H-1-ty (k_flip_env)
                     }
                 }
             }
@@ -242,10 +266,8 @@ __global__ void __launch_bounds__(MR_BLOCK) k_direct_bwd(EnvD E, int N, int S, c
     }
     if (g_env) {
         __syncthreads();
-        for (int i = threadIdx.x; i < MR_DBW_TABLE; i += MR_BLOCK) {
-            const int key = s_keys[i];
-            if (key >= 0) { float* dst = g_env + 3 * (size_t)key; atomicAdd(dst, s_vals[3 * i]); atomicAdd(dst + 1, s_vals[3 * i + 1]); atomicAdd(dst + 2, s_vals[3 * i + 2]); }
-        }
+        env_grad_flush(s_keys, s_vals, MR_DBW_TABLE, g_env);
+        env_grad_flush(s_lkeys, s_lvals, s_lcount < MR_DBW_LIST ? s_lcount : MR_DBW_LIST, g_env);
     }
     if (live && sub == 0) {
         if (g_normal) st3(g_normal, pi, V3(v[0], v[1], v[2]));
@@ -278,7 +300,13 @@ struct MatNetB { const __half2* grid; const float *w0, *w1, *w2; float aabb_min[
 #define MR_BW_COARSE 8
 typedef GridLevels GridLevelsB;
 static GridLevelsB host_levels_b() { return host_levels(nullptr); }
-__global__ void __launch_bounds__(MR_BLOCK) k_matnet_bwd(MatNetB M, GridLevelsB L, const float* __restrict__ pos, int n, const float* __restrict__ gout,
+// Two waves per SIMD (256 registers, the rest in scratch) instead of one (512 + AGPRs): -4 % on the kernel (profiles/r06_ab_matnet_bwd_builds.txt). Forming every layer's
+// weight-gradient outer product right after its adjoint (shorter live ranges in the source) was measured too: the compiler hoists the LDS loads of the fully unrolled
+// mat-vecs either way — +6 % slower with one wave, +-0 with two; not kept.
+#ifndef MR_BW_MINWAVES
+#define MR_BW_MINWAVES 2
+#endif
+__global__ void __launch_bounds__(MR_BLOCK, MR_BW_MINWAVES) k_matnet_bwd(MatNetB M, GridLevelsB L, const float* __restrict__ pos, int n, const float* __restrict__ gout,
                                                          float* __restrict__ g_params, float* __restrict__ g_w0, float* __restrict__ g_w1, float* __restrict__ g_w2,
                                                          float* __restrict__ g_pos) {
     __shared__ float sw0[1024], sw1[1024], sw2[192];
@@ -419,42 +447,53 @@ __global__ void __launch_bounds__(MR_BLOCK) k_matnet_bwd(MatNetB M, GridLevelsB 
         // (with that contention) were what the kernel waited for. Levels < MR_BW_COARSE therefore go through a per-wave LDS table (the wave's
         // staging area, free after the outer products: open addressing, two probes, overflow straight to global memory), flushed per tile.
         if (g_params) {
+            // Round 6 (profiles/r06_atomic_rate.txt): the memory side takes 21 G scattered atomic REQUESTS per second, and the lanes of one instruction that fall into the
+            // same 32-byte sector are one request. A table entry's two features are 8 consecutive bytes: every update is issued by a PAIR of lanes (even lane: feature 0,
+            // odd lane: feature 1 of the same entry; first the even lane's entry, then the odd lane's) — half the requests for the same adds, in the same order per word.
             int* const keys = reinterpret_cast<int*>(U); float* const vals = V;
             for (int e = lane; e < MR_BW_TABLE; e += 64) { keys[e] = -1; vals[2 * e] = 0.f; vals[2 * e + 1] = 0.f; }
             __builtin_amdgcn_wave_barrier();
-            if (live) {
-                for (int lv = 0; lv < MR_LEVELS; lv++) {
-                    const float scale = L.scale[lv]; const uint32_t res = L.res[lv], size = L.size[lv];
-                    float p[3]; uint32_t pg[3];
+            const int odd = lane & 1;
+            for (int lv = 0; lv < MR_LEVELS; lv++) {      // every lane walks every level (a dead or gradient-free lane contributes nothing): the pairs must stay together
+                const float scale = L.scale[lv]; const uint32_t res = L.res[lv], size = L.size[lv];
+                float p[3]; uint32_t pg[3];
 #pragma unroll
-                    for (int d = 0; d < 3; d++) { float q = fmaf(scale, x[d], 0.5f); float fl = floorf(q); pg[d] = (uint32_t)(int)fl; p[d] = q - fl; }
-                    const float g0 = ga0[2 * lv], g1 = ga0[2 * lv + 1];
-                    if (g0 == 0.f && g1 == 0.f) continue;
-                    uint32_t ci[8]; corner_indices(size, res, pg, ci);
+                for (int d = 0; d < 3; d++) { float q = fmaf(scale, x[d], 0.5f); float fl = floorf(q); pg[d] = (uint32_t)(int)fl; p[d] = q - fl; }
+                const float g0 = ga0[2 * lv], g1 = ga0[2 * lv + 1];
+                const bool lvalid = live && !(g0 == 0.f && g1 == 0.f);
+                if (!__ballot(lvalid)) continue;
+                uint32_t ci[8]; corner_indices(size, res, pg, ci);
 #pragma unroll
-                    for (uint32_t idx = 0; idx < 8; idx++) {
-                        float w = 1.f;
+                for (uint32_t idx = 0; idx < 8; idx++) {
+                    float w = 1.f;
 #pragma unroll
-                        for (int d = 0; d < 3; d++) w *= (idx & (1u << d)) == 0 ? 1 - p[d] : p[d];
-                        const size_t e = (size_t)L.offset[lv] + ci[idx];
-                        bool done = false;
-                        if (lv < MR_BW_COARSE) {
-                            uint32_t h = ((uint32_t)e * 2654435761u) >> (32 - MR_BW_TABLE_LOG2);
+                    for (int d = 0; d < 3; d++) w *= (idx & (1u << d)) == 0 ? 1 - p[d] : p[d];
+                    const uint32_t e = L.offset[lv] + ci[idx];
+                    bool direct = lvalid;
+                    if (lv < MR_BW_COARSE && lvalid) {
+                        uint32_t h = (e * 2654435761u) >> (32 - MR_BW_TABLE_LOG2);
 #pragma unroll
-                            for (int probe = 0; probe < 2 && !done; probe++) {
-                                const int old = atomicCAS(&keys[h], -1, (int)e);
-                                if (old == -1 || old == (int)e) { atomicAdd(&vals[2 * h], w * g0); atomicAdd(&vals[2 * h + 1], w * g1); done = true; }
-                                h = (h + 1) & (MR_BW_TABLE - 1);
-                            }
+                        for (int probe = 0; probe < 2 && direct; probe++) {
+                            const int old = atomicCAS(&keys[h], -1, (int)e);
+                            if (old == -1 || old == (int)e) { atomicAdd(&vals[2 * h], w * g0); atomicAdd(&vals[2 * h + 1], w * g1); direct = false; }
+                            h = (h + 1) & (MR_BW_TABLE - 1);
                         }
-                        if (!done) { atomicAdd(&g_params[2 * e], w * g0); atomicAdd(&g_params[2 * e + 1], w * g1); }
+                    }
+                    const float v0 = w * g0, v1 = w * g1;
+#pragma unroll
+                    for (int r = 0; r < 2; r++) {
+                        const int src = (lane & ~1) | r;
+                        const uint32_t e_s = (uint32_t)__shfl((int)e, src, 64);
+                        const int d_s = __shfl(direct ? 1 : 0, src, 64);
+                        const float a_s = __shfl(v0, src, 64), b_s = __shfl(v1, src, 64);
+                        if (d_s) atomicAdd(&g_params[2 * (size_t)e_s + odd], odd ? b_s : a_s);
                     }
                 }
             }
             __builtin_amdgcn_wave_barrier();
-            for (int e = lane; e < MR_BW_TABLE; e += 64) {
-                const int key = keys[e];
-                if (key >= 0) { atomicAdd(&g_params[2 * (size_t)key], vals[2 * e]); atomicAdd(&g_params[2 * (size_t)key + 1], vals[2 * e + 1]); }
+            for (int j = lane; j < 2 * MR_BW_TABLE; j += 64) {      // lane pairs again: entry j / 2, feature j % 2
+                const int key = keys[j >> 1];
+                if (key >= 0) atomicAdd(&g_params[2 * (size_t)key + (j & 1)], vals[j]);
             }
             __builtin_amdgcn_wave_barrier();
         }

@@ -23,7 +23,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # The flags stay for a measured reason, not a hardware claim: a build WITH packed fp32 is 5-6 % slower on the frame (1014 vs 1070 Msamples/s, round 3), and the
 # hash-grid encoder's two-step fp16 rounding is pinned against contraction choices either way. tests/test_abi.py checks that no object contains v_pk_*_f32.
 # MIRRES_ALLOW_PK=1 (experiments only, with MIRRES_BUILD_TAG): leaves both vectorisers on, i.e. lets packed-fp32 instructions into the kernels again
-PER_FILE = {f: ([] if os.environ.get("MIRRES_ALLOW_PK") == "1" else ["-fno-slp-vectorize", "-fno-vectorize"]) for f in ("passes.hip", "shading.hip", "bvh_trace.hip", "bvh_build.hip", "eaw.hip", "render.hip", "backward.hip", "normal.hip", "matnet.hip", "dump.hip", "raster.hip", "antialias.hip", "selfcheck.hip")}
+PER_FILE = {f: ([] if os.environ.get("MIRRES_ALLOW_PK") == "1" else ["-fno-slp-vectorize", "-fno-vectorize"]) for f in ("passes.hip", "shading.hip", "bvh_trace.hip", "bvh_build.hip", "eaw.hip", "render.hip", "backward.hip", "normal.hip", "matnet.hip", "dump.hip", "raster.hip", "antialias.hip", "selfcheck.hip", "comm.hip")}
 # matnet.hip: MFMA accumulators in VGPRs (no v_accvgpr_read between the layers of the register-chained MLP: -15 % VALU in k_mlp_mfma)
 PER_FILE["matnet.hip"] += ["-mllvm", "-amdgpu-mfma-vgpr-form"]
 

@@ -144,6 +144,7 @@ struct mirres_ctx {
     int y_off = 0, full_fy = 0;     // strip sharding (mirres_render): global row of local row 0 and the global height; full_fy == 0: the frame is the whole image
     int row_a = 0, row_b = 0, row_mode = 0;   // spatial pass restricted to local rows: 0 all, 1 inside [row_a, row_b), 2 outside (mirres_render's strip_overlap)
     hipStream_t halo_stream = nullptr; hipEvent_t ev_halo[2] = {nullptr, nullptr};
+    std::vector<hipEvent_t> ev_halo_t; size_t ev_halo_t_used = 0;   // event pairs around the sampled native halo exchanges of the last frame (mirres_ctx_halo_time)
     const float* occ_own = nullptr; // strip sharding: occupancy with the halo rows zeroed (own-pixel tests of the spatial pass); NULL otherwise
     const float* grec = nullptr;    // set by mirres_render for the duration of a frame: packed 64-byte G records for the neighbour gathers of k_spatial_resolve
     bool chain_reset = false, chain_clean = false;   // mirres_render's chain: k_spatial_resolve leaves the ray counter and the lane-0 work heads zeroed for the next sample
@@ -200,6 +201,7 @@ int launch_final_batch(mirres_ctx* ctx, mirres_bvh* bvh, const mirres_env_t* env
                        const float* kd, const float* rm, const mirres_res_t* res, int K, const PtQueues* q, float* color, float* diff, float* spec, float* tape, hipStream_t s);
 int launch_spatial(mirres_ctx* ctx, mirres_bvh* bvh, const mirres_env_t* env, const mirres_gbuf_t* g, const mirres_res_t* res, const mirres_res_t* prev_res,
                    const float* neighbor_offsets, uint32_t frameIndex, hipStream_t s, const mirres_res_t* next_res, uint32_t next_frame, const SpatialBand* band = nullptr);
+int comm_exchange_halos(void* comm, float* rec, int fx, int n, const int* peer, const int* s0, const int* s1, const int* r0, const int* r1, hipStream_t s);   // comm.hip
 int trace_any_q(mirres_ctx* ctx, mirres_bvh* bvh, const Ray* rays, const uint32_t* count, size_t cap, int32_t* hit, hipStream_t s, int lane = 0);
 int trace_closest_q(mirres_ctx* ctx, mirres_bvh* bvh, const Ray* rays, const uint32_t* count, size_t cap, HitRec* out, hipStream_t s, int lane = 0);
 inline int grid_for(size_t n, int block) { size_t g = (n + block - 1) / block; return (int)(g < 1 ? 1 : g); }

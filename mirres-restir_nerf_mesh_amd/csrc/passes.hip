@@ -979,6 +979,7 @@ void mirres_ctx_destroy(mirres_ctx_t* c) {
     if (c->pt_stream2) (void)hipStreamDestroy(c->pt_stream2);
     for (hipEvent_t e : c->ev_pt) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->ev_band) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->ev_halo_t) (void)hipEventDestroy(e);
     for (int t = 0; t < 2; t++) { if (c->chain_streams[t]) (void)hipStreamDestroy(c->chain_streams[t]); if (c->chain_mem[t]) (void)hipFree(c->chain_mem[t]); }
     if (c->fin_stream) (void)hipStreamDestroy(c->fin_stream);
     for (hipEvent_t e : c->ev_halo) if (e) (void)hipEventDestroy(e);      // created on first use by mirres_render's strip_overlap path (render.hip)

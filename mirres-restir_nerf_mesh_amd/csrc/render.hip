@@ -549,7 +549,26 @@ int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args
     int pt_seq = 0;   // running index of the path-tracing sub-batches
     // band pipeline of the chain: only inside the streamed schedule (own work heads, packed reservoirs), not for strips (their per-sample halo exchange is a barrier over
     // the whole local frame), not for the checksum / counting / event-timing modes
-    const int nbands = band_count(ctx, two_streams && !a->halo && !dbg_sum && ctx->instrument == 0 && !(getenv("MIRRES_FUSE_TEMPORAL") && getenv("MIRRES_FUSE_TEMPORAL")[0] == '0') &&
+    // the per-sample halo exchange of a strip: the library's own RCCL send / receive group (halo_comm) or the caller's callback
+    const bool has_halo = a->halo || a->halo_comm;
+    ctx->ev_halo_t_used = 0;
+    auto exchange = [&](float* records, int sample, hipStream_t hs) -> int {
+        if (a->halo_comm) {
+            if (a->halo_n < 0 || a->halo_n > 2) { set_error("mirres_render: halo_n = %d", a->halo_n); return MIRRES_E_ARG; }
+            hipEvent_t *e0 = nullptr, *e1 = nullptr;
+            if (a->halo_time_stride > 0 && sample % a->halo_time_stride == 0) {
+                if (ctx->ev_halo_t_used + 2 > ctx->ev_halo_t.size()) { const size_t old_n = ctx->ev_halo_t.size(); ctx->ev_halo_t.resize(old_n + 64); for (size_t q = old_n; q < ctx->ev_halo_t.size(); q++) MR_HIP(hipEventCreate(&ctx->ev_halo_t[q])); }
+                e0 = &ctx->ev_halo_t[ctx->ev_halo_t_used]; e1 = &ctx->ev_halo_t[ctx->ev_halo_t_used + 1]; ctx->ev_halo_t_used += 2;
+                MR_HIP(hipEventRecord(*e0, hs));
+            }
+            const int rce = comm_exchange_halos(a->halo_comm, records, fx, a->halo_n, a->halo_peer, a->halo_send0, a->halo_send1, a->halo_recv0, a->halo_recv1, hs);
+            if (e1) MR_HIP(hipEventRecord(*e1, hs));
+            return rce;
+        }
+        if (a->halo(a->halo_user, records, sample, (void*)hs)) { set_error("mirres_render: halo exchange callback failed at sample %d", sample); return MIRRES_E_STATE; }
+        return 0;
+    };
+    const int nbands = band_count(ctx, two_streams && !has_halo && !dbg_sum && ctx->instrument == 0 && !(getenv("MIRRES_FUSE_TEMPORAL") && getenv("MIRRES_FUSE_TEMPORAL")[0] == '0') &&
                                        !(getenv("MIRRES_SPATIAL_RAYS") && getenv("MIRRES_SPATIAL_RAYS")[0] == '1'));
     const int nchain = nbands > 1 ? chain_stream_count() : 1;
     hipStream_t cstream[3] = {s, nullptr, nullptr};
@@ -583,7 +602,7 @@ int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args
         static const bool fuse_temporal = [] { const char* e = getenv("MIRRES_FUSE_TEMPORAL"); return !(e && e[0] == '0'); }();
         // strip_overlap: interior rows = own rows at least gather_radius away from every strip edge that has a neighbouring rank behind it
         int in_a = a->own_y0, in_b = a->own_y1; bool overlap = false;
-        if (strip && a->halo && a->strip_overlap) {
+        if (strip && has_halo && a->strip_overlap) {
             const int r = (int)ctx->cfg.gather_radius;
             if (a->strip_y_off + a->own_y0 > 0) in_a += r;
             if (a->strip_y_off + a->own_y1 < a->strip_full_fy) in_b -= r;
@@ -649,11 +668,11 @@ int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args
                 }
                 pass += 1;
             }
-            if (a->halo && overlap) {
+            if (has_halo && overlap) {
                 // strip sharding with the exchange off the chain: the callback enqueues it on the side stream (after this sample's temporal output), the chain does the
                 // interior rows meanwhile, then waits and does the border rows
                 MR_HIP(hipEventRecord(ctx->ev_halo[0], s)); MR_HIP(hipStreamWaitEvent(ctx->halo_stream, ctx->ev_halo[0], 0));
-                if (a->halo(a->halo_user, rt.light_data, i, (void*)ctx->halo_stream)) { set_error("mirres_render: halo exchange callback failed at sample %d", i); return MIRRES_E_STATE; }
+                rc = exchange(rt.light_data, i, ctx->halo_stream); if (rc) return rc;
                 MR_HIP(hipEventRecord(ctx->ev_halo[1], ctx->halo_stream));
                 ctx->row_a = in_a; ctx->row_b = in_b; ctx->row_mode = 1;
                 rc = launch_spatial(ctx, bvh, &E, &Gt, &rs, &rt, nullptr, base + pass, s, nullptr, 0u);
@@ -664,8 +683,8 @@ int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args
                 csum(rs.light_data, 8 * (size_t)N);
                 continue;
             }
-            if (a->halo) {   // strip sharding: the neighbouring ranks' border rows of the temporal output -> this rank's halo rows (and vice versa)
-                if (a->halo(a->halo_user, rt.light_data, i, (void*)s)) { set_error("mirres_render: halo exchange callback failed at sample %d", i); return MIRRES_E_STATE; }
+            if (has_halo) {   // strip sharding: the neighbouring ranks' border rows of the temporal output -> this rank's halo rows (and vice versa)
+                rc = exchange(rt.light_data, i, s); if (rc) return rc;
             }
             const bool fuse_next = fuse_temporal && !dbg_sum && k + 1 < kk;      // (sample i + 1 > i0 >= 0: it always has a temporal pass)
             mirres_res_t rn = res_slot(PB.rinit[b & 1], fuse_next ? k + 1 : k, (size_t)N);
@@ -730,6 +749,19 @@ int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args
         return MIRRES_OK;
     }
     return finish(ctx, a, B.tot, B, s);
+}
+
+int mirres_ctx_halo_time(mirres_ctx_t* ctx, double* ms, int* exchanges) {
+    if (!ctx || !ms || !exchanges) { set_error("mirres_ctx_halo_time: null"); return MIRRES_E_ARG; }
+    double tot = 0.0; int n = 0;
+    for (size_t q = 0; q + 1 < ctx->ev_halo_t_used; q += 2) {
+        MR_HIP(hipEventSynchronize(ctx->ev_halo_t[q + 1]));
+        float t = 0.f; MR_HIP(hipEventElapsedTime(&t, ctx->ev_halo_t[q], ctx->ev_halo_t[q + 1]));
+        tot += t; n++;
+    }
+    ctx->ev_halo_t_used = 0;
+    *ms = tot; *exchanges = n;
+    return MIRRES_OK;
 }
 
 int mirres_render_bwd(mirres_ctx_t* ctx, const mirres_render_args_t* a, int samples, const float* g_color, const float* g_diff, const float* g_spec,

@@ -190,6 +190,7 @@ class StripBalancer:
         self.pending = None        # (start event, end event) of this rank's last strip render
         self.waits = []            # (event before, event after) of the sampled halo exchanges of that render, + how many exchanges each stands for
         self.wait_stride = 1
+        self.native = None         # (context, stride) of a render whose exchanges the library issued and timed itself
         self.last_total_ms = self.last_wait_ms = None
         self.history = []          # (bounds, times) per update: what the table in profiles/ is printed from
 
@@ -252,6 +253,7 @@ class StripBalancer:
         """The render between start() and stop() raised: forget it (an unrecorded end event would fail the next exchange() on this rank only and mismatch the collective)."""
         self.pending = None
         self.waits = []
+        self.native = None
 
     def busy_ms(self):
         """(own busy time, total, waited) of the last timed strip render in ms; None when nothing is pending."""
@@ -261,6 +263,13 @@ class StripBalancer:
         e1.synchronize()
         total = e0.elapsed_time(e1)
         waited = sum(a.elapsed_time(b) for a, b in self.waits) * self.wait_stride
+        if self.native is not None:       # the exchanges were issued by the library (no callback to bracket): it timed every stride-th of them itself
+            from ._lib import lib, check
+            ctx, stride = self.native
+            ms, n = C.c_double(0.0), C.c_int(0)
+            check(lib().mirres_ctx_halo_time(ctx.h, C.byref(ms), C.byref(n)), "mirres_ctx_halo_time")
+            waited += float(ms.value) * max(1, stride)
+            self.native = None
         waited = min(waited, 0.95 * total)          # (a sampled estimate: never let it eat the whole frame)
         return total - waited, total, waited
 
@@ -385,6 +394,42 @@ def gather_rows(own, fy, fx, world, group=None, bounds=None, used=None):
     return full
 
 
+# ---- the library's own RCCL communicator for the native halo exchange (csrc/comm.hip): one per process group, created on first use
+_NATIVE_COMMS = {}
+
+
+def rccl_path():
+    """The librccl the process already holds (torch's); mirres_comm_* prefers a loaded copy over loading a second one."""
+    p = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    return p if os.path.exists(p) else ""
+
+
+def native_comm(group=None):
+    """Communicator handle (int) of mirres_comm_create for `group`: rank 0 draws the unique id, torch.distributed broadcasts its 128 bytes, every rank joins
+    (collective: all ranks of the group must call this together — render_strips does on its first frame). MIRRES_NATIVE_HALO=0 or a non-RCCL backend: None."""
+    import torch.distributed as dist
+    from ._lib import lib, check
+    if os.environ.get("MIRRES_NATIVE_HALO", "1") == "0" or dist.get_backend(group) != "nccl":
+        return None
+    key = id(group) if group is not None else 0
+    if key in _NATIVE_COMMS:
+        return _NATIVE_COMMS[key]
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    path = rccl_path().encode()
+    ident = (C.c_char * 128)()
+    if rank == 0:
+        check(lib().mirres_comm_unique_id(path, C.cast(ident, C.c_void_p)), "mirres_comm_unique_id")
+    t = torch.frombuffer(bytearray(bytes(ident)), dtype=torch.uint8).clone().cuda()
+    dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    raw = bytes(t.cpu().numpy().tobytes())
+    buf = (C.c_char * 128).from_buffer_copy(raw)
+    h = C.c_void_p()
+    torch.cuda.synchronize()
+    check(lib().mirres_comm_create(C.byref(h), path, C.cast(buf, C.c_void_p), world, rank), "mirres_comm_create")
+    _NATIVE_COMMS[key] = h.value
+    return h.value
+
+
 def render_strips(ctx_full, worker, mlp_mat, env_map, g, spp, random_offset, rank, world, denoise_iter=2, step_width=2, c_phi=2.0, n_phi=0.1, p_phi=0.001,
                   use_scale=False, scale=(1.0, 1.0, 1.0), group=None, max_bounce=None, balanced=True, overlap=None, balancer=None):
     """Exact multi-GPU frame: this rank renders its strip (all spp) with per-sample halo exchange, the raw sums are all-gathered by rows and
@@ -449,11 +494,23 @@ def render_strips(ctx_full, worker, mlp_mat, env_map, g, spp, random_offset, ran
             print("[mirres] halo exchange failed:", e, file=sys.stderr)
             return 1
     cb = _lib.HALO_FN(_halo)
+    # over RCCL the library issues the exchange itself (csrc/comm.hip: one send / receive group per sample from C, no Python on the per-sample path); the callback stays
+    # for host-staged backends (gloo: the CPU / single-GPU tests) and MIRRES_NATIVE_HALO=0
+    native = None
+    if world > 1 or _forced():
+        import torch.distributed as dist
+        comm = native_comm(group) if (dist.is_available() and dist.is_initialized()) else None
+        if comm is not None:
+            stride = max(1, int(spp) // StripBalancer.MAX_WAIT_SAMPLES) if balancer is not None else 0
+            native = (comm, plan, stride)
+            if balancer is not None:
+                balancer.native = (ctx_loc, stride)
     if balancer is not None:
         balancer.start(spp)
     try:
         sums, a, keep = render_fused(ctx_loc, worker, mlp_mat, use_scale, scale, env_map, loc["occ"], loc["normal"], loc["depth"], loc["kd"], loc["rm"], loc["ray_dir"],
-                                     loc["pos"], spp, denoise_iter, step_width, c_phi, n_phi, p_phi, random_offset, strip=(fy, lo, y0 - lo, y1 - lo), halo=cb, strip_overlap=overlap)
+                                     loc["pos"], spp, denoise_iter, step_width, c_phi, n_phi, p_phi, random_offset, strip=(fy, lo, y0 - lo, y1 - lo), halo=cb, strip_overlap=overlap,
+                                     halo_native=native)
     except BaseException:
         if balancer is not None:
             balancer.abort()

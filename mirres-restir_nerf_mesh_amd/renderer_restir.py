@@ -278,10 +278,11 @@ def _needs_grad(*ts):
 
 def render_fused(ctx, bvh_restir_worker, mlp_mat, use_scale, scale, env_map, occ_map, normal_map, depth_map, diffuse_map, roughness_specular, ray_dir_map, pos_map,
                  spp, denoise_iter, stepWidth, c_phi, n_phi, p_phi, random_offset, spp_range=None, const_kd=(0.6, 0.6, 0.6), const_rm=(0.5, 0.0),
-                 strip=None, halo=None, gb_depth=None, tape=None, strip_overlap=False):
+                 strip=None, halo=None, gb_depth=None, tape=None, strip_overlap=False, halo_native=None):
     """One C call for the whole frame (mirres_render). Returns the 6 output buffers [N,3] (raw sums when spp_range or strip is given).
     strip = (full_fy, y_off, own_y0, own_y1): `ctx` and all per-pixel inputs describe a rank's LOCAL frame (own rows + halo rows, dist.py);
-    halo = a _lib.HALO_FN called once per sample to exchange the halo rows of the packed reservoirs."""
+    halo = a _lib.HALO_FN called once per sample to exchange the halo rows of the packed reservoirs; halo_native = (communicator handle of mirres_comm_create,
+    plan [(peer, (send rows), (recv rows)), ...] in local rows, time stride): the library issues the exchange itself (RCCL send / receive group, no callback)."""
     N = ctx.N
     a = _lib.RenderArgs()
     keep = []
@@ -320,7 +321,15 @@ def render_fused(ctx, bvh_restir_worker, mlp_mat, use_scale, scale, env_map, occ
         a.spp_begin, a.spp_end = int(spp_range[0]), int(spp_range[1])
     if strip is not None:
         a.strip_full_fy, a.strip_y_off, a.own_y0, a.own_y1 = (int(v) for v in strip)
-        if halo is not None:
+        if halo_native is not None:
+            comm, plan, stride = halo_native
+            if len(plan) > 2:
+                raise _lib.MirresError("a strip has at most two neighbouring ranks")
+            a.halo_comm = int(comm); a.halo_n = len(plan); a.halo_time_stride = int(stride)
+            for k, (peer, (sa, sb), (ra, rb)) in enumerate(plan):
+                a.halo_peer[k], a.halo_send0[k], a.halo_send1[k], a.halo_recv0[k], a.halo_recv1[k] = int(peer), int(sa), int(sb), int(ra), int(rb)
+            a.strip_overlap = 1 if strip_overlap else 0
+        elif halo is not None:
             keep.append(halo)
             a.halo = C.cast(halo, C.c_void_p)
             a.strip_overlap = 1 if strip_overlap else 0

@@ -6,6 +6,7 @@ with the callback doing, per sample:
     none      nothing (the strip's own period)
     copy      the same bytes moved by two torch slice copies on the stream (no RCCL)
     rccl      dist.exchange_halos over RCCL with the peer = this rank (the self exchange of tests/test_gpu_rccl.py: 2 sends + 2 receives of 30 rows x fx x 32 B)
+    native    the same sends / receives issued by mirres_render itself (csrc/comm.hip: ncclSend / ncclRecv in one group, the library's own communicator; no callback)
 and reports: host microseconds per callback (perf_counter inside the callback), device microseconds between two events around the exchange on the callback's stream
 (every 16th sample), and the strip's period per sample with each callback — all against the strip's chain period.
 
@@ -65,20 +66,26 @@ def make_cb(kind):
         return 0
     return _lib.HALO_FN(cb)
 
+comm = D.native_comm()
 def strip(cb):
     W.update_mesh(W.vrt, W.v_ind)
+    kw = {"halo_native": (comm, plan, 16)} if cb == "native" else {"halo": cb}
     RR.render_fused(ctx, W, mlp, False, (1, 1, 1), env, loc["occ"].clone(), loc["normal"], loc["depth"], loc["kd"], loc["rm"], loc["ray_dir"], loc["pos"], spp, 2, 2, 2.0, 0.1, 0.001, 12345,
-                    strip=(fy, lo, y0 - lo, y1 - lo), halo=cb)
+                    strip=(fy, lo, y0 - lo, y1 - lo), **kw)
 
 print("mesh %s, strip %d of %d: own rows [%d, %d), local frame %d rows (padded %d) x %d px, %d spp; the exchange moves %.2f MB per sample in %d send + %d receive; csrc_sha %s" %
       (mesh, rank, world, y0, y1, rows, rows_pad, fx, spp, nbytes / 1e6, len(plan), len(plan), B.csrc_sha()))
 res = {}
-for kind in ("none", "copy", "rccl", "none", "copy", "rccl"):
-    cb = make_cb(kind)
+import ctypes as C
+for kind in ("none", "copy", "rccl", "native", "none", "copy", "rccl", "native"):
+    cb = "native" if kind == "native" else make_cb(kind)
     strip(cb); torch.cuda.synchronize()
     host_us.clear(); dev_pairs.clear()
     t0 = time.perf_counter(); strip(cb); enq = time.perf_counter() - t0; torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    h = np.array(host_us); d = np.array([a.elapsed_time(b) * 1e3 for a, b in dev_pairs]) if dev_pairs else np.array([0.0])
+    h = np.array(host_us) if host_us else np.array([0.0]); d = np.array([a.elapsed_time(b) * 1e3 for a, b in dev_pairs]) if dev_pairs else np.array([0.0])
+    if kind == "native":      # no callback: the host cost is inside the frame's enqueue time; the library timed every 16th exchange
+        ms, n = C.c_double(0.0), C.c_int(0); _lib.check(_lib.lib().mirres_ctx_halo_time(ctx.h, C.byref(ms), C.byref(n)), "halo_time")
+        d = np.array([ms.value * 1e3 / max(1, n.value)] * max(1, n.value))
     print("%-5s period %7.1f us per sample (host enqueue of the frame %7.1f us per sample) | callback on the host: mean %6.1f us, median %6.1f, p95 %6.1f | exchange on the device: mean %6.1f us, median %6.1f (n = %d)" %
           (kind, dt * 1e6 / spp, enq * 1e6 / spp, h.mean(), np.median(h), np.percentile(h, 95), d.mean(), np.median(d), len(d)))
 dist.barrier(); dist.destroy_process_group()

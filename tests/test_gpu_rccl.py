@@ -101,6 +101,19 @@ if world == 1:
     res["overlap_over_rccl_equal"] = all(torch.equal(a, b) for a, b in zip(sums, frames[1])) and len(side) == 3 and all(st_ != torch.cuda.current_stream().cuda_stream for st_ in side)
     busy, total, waited = bal.busy_ms()
     res["balancer_busy_total_waited"] = [busy, total, waited]      # the exchanges' stream time is taken out of the strip's own time
+    # the NATIVE exchange (round 6, csrc/comm.hip): the library's own communicator (unique id broadcast through torch.distributed), ncclSend / ncclRecv in one group per
+    # sample issued by mirres_render itself — no callback; in line and with strip_overlap; every exchange timed by the library
+    comm = D.native_comm()
+    res["native_comm"] = comm is not None
+    import ctypes as C
+    for name, ov in (("native_equal", False), ("native_overlap_equal", True)):
+        sums, _, _ = RR.render_fused(get_ctx(fx, hi - lo), W, None, False, (1, 1, 1), env, loc["occ"].clone(), loc["normal"], loc["depth"], loc["kd"], loc["rm"], loc["ray_dir"],
+                                     loc["pos"], 3, 2, 2, 2.0, 0.1, 0.001, 4321, strip=(fy, lo, y0 - lo, y1 - lo), halo_native=(comm, plan, 1), strip_overlap=ov)
+        torch.cuda.synchronize()
+        res[name] = all(torch.equal(a, b) for a, b in zip(sums, frames[1]))
+        ms, n = C.c_double(0.0), C.c_int(0)
+        _lib.check(_lib.lib().mirres_ctx_halo_time(get_ctx(fx, hi - lo).h, C.byref(ms), C.byref(n)), "mirres_ctx_halo_time")
+        res[name + "_timed"] = [float(ms.value), int(n.value)]
     res["p2p_moved_something"] = moved["ok"] and moved["nonzero"]     # received halo rows == sent rows, and those rows carried reservoirs (not all zero)
 torch.cuda.synchronize()
 dist.barrier()
@@ -139,6 +152,8 @@ def test_rccl_collectives_and_halo_exchange_on_one_gpu(tmp_path):
     assert r["grad_bucket"] == [1.0, 1.0, 0.0] and r["grad_algos_agree"]
     assert r["p2p_in_callback_equal"] and r["p2p_moved_something"]
     assert r["overlap_over_rccl_equal"], "strip_overlap with the exchange on the engine's side stream over RCCL must not change the frame"
+    assert r["native_comm"] and r["native_equal"] and r["native_overlap_equal"], "the library's own RCCL exchange must give the frame of the copy version"
+    assert r["native_equal_timed"][1] == 3 and r["native_equal_timed"][0] > 0 and r["native_overlap_equal_timed"][1] == 3
     busy, total, waited = r["balancer_busy_total_waited"]
     assert 0 < waited < total and abs(busy + waited - total) < 1e-6 * total + 1e-9
 
