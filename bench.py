@@ -258,7 +258,35 @@ def traversal_roofline(args, ctx, W, mlp, env, g, prof_spp, step_ms, world, pmc)
     return roof
 
 
-def train_step_record(S, torch, dev, W, steps=3):
+ATOMIC_ROOF_G = 21.0      # G scattered fp32 atomic REQUESTS per second the memory side of an MI355X takes (scripts/ubench/atomic_rate.hip, profiles/r06_atomic_rate.txt: the same for
+                          # every scope — each device-scope atomic leaves the XCD's L2 —; the lanes of one instruction that fall into one 32-byte sector are one request)
+
+
+def train_roofline(pmc, fg_points, spp):
+    """configs[2]'s backward kernels against the roof that binds them (round 6): both scatter gradients with fp32 atomics — the hash-grid table (k_matnet_bwd: 16 levels x
+    8 corners x 2 features = 256 adds per encoded foreground point) and the environment map (k_direct_bwd: 4 texels x 3 channels = 12 adds per visible final sample) —
+    and run at the memory side's atomic REQUEST rate. Counter snapshot (scripts/pmc_train.sh; csrc_sha-gated like the others) over the measured roof."""
+    tr = (pmc or {}).get("train") or {}
+    if not tr or tr.get("stale"):
+        return {"bound": "atomic-requests", "peak": ATOMIC_ROOF_G, "unit": "G requests/s", "stale_or_missing_snapshot": True, "source": tr.get("source")}
+    out = {"bound": "atomic-requests", "peak": ATOMIC_ROOF_G, "unit": "G atomic requests/s (32-byte sectors) at the memory side", "kernels": {}, "source": tr.get("source"),
+           "algorithmic": {"k_matnet_bwd": "256 fp32 adds per foreground point (%d points): %.1f M adds, two per 8-byte table entry -> %.1f M requests when a lane pair shares an entry" % (fg_points, 256e-6 * fg_points, 128e-6 * fg_points),
+                           "k_direct_bwd": "12 fp32 adds per visible final sample (<= %d x %d samples): <= %.1f M adds, three per 12-byte texel -> a third of the requests when four lanes share a texel" % (fg_points, spp, 12e-6 * fg_points * spp)}}
+    for k in ("k_direct_bwd", "k_matnet_bwd"):
+        c = tr.get(k)
+        if not c:
+            continue
+        req, us = c.get("atomic_requests_per_launch"), c.get("launch_us")
+        out["kernels"][k] = dict(c, achieved=(round(req / us / 1e3, 2) if req and us else None), frac=(round(req / us / 1e3 / ATOMIC_ROOF_G, 4) if req and us else None))
+    ks = out["kernels"]
+    if ks:
+        req = sum(v.get("atomic_requests_per_launch") or 0 for v in ks.values()); us = sum(v.get("launch_us") or 0 for v in ks.values())
+        out["achieved"] = round(req / us / 1e3, 2) if us else None
+        out["frac"] = round(req / us / 1e3 / ATOMIC_ROOF_G, 4) if us else None
+    return out
+
+
+def train_step_record(S, torch, dev, W, steps=3, pmc=None):
     """BASELINE configs[2]: one stage-1 inverse-rendering step — forward + backward through FinalShading / EvaluateFinalSamples_di / EAW / the material field,
     Adam step on field + environment — at 800 x 800, 32 spp (main.py:108), LBVH rebuild per step, on the benched mesh."""
     from mirres_restir_nerf_mesh_amd import renderer_restir as RR, harness
@@ -290,7 +318,8 @@ def train_step_record(S, torch, dev, W, steps=3):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     return {"config": "BASELINE configs[2]: stage-1 training step, 800x800, 32 spp, forward + backward (direct-lighting terms) + Adam, LBVH rebuild per step",
-            "ms_per_step": round(dt * 1e3, 2), "steps": steps, "warmup": 1, "msamples_per_s": round(N * 32 / dt / 1e6, 1), "loss_finite": bool(torch.isfinite(last).item())}
+            "ms_per_step": round(dt * 1e3, 2), "steps": steps, "warmup": 1, "msamples_per_s": round(N * 32 / dt / 1e6, 1), "loss_finite": bool(torch.isfinite(last).item()),
+            "roofline": train_roofline(pmc, int(fg.sum().item()), 32)}
 
 
 def main():
@@ -446,7 +475,7 @@ def main():
         except Exception as e_:      # noqa: BLE001 — a sub-record must not take the line with it
             extras[other] = {"error": "%s: %s" % (type(e_).__name__, str(e_)[:300])}
         try:
-            extras["train_step"] = train_step_record(S, torch, dev, W)
+            extras["train_step"] = train_step_record(S, torch, dev, W, pmc=pmc)
         except Exception as e_:      # noqa: BLE001
             extras["train_step"] = {"error": "%s: %s" % (type(e_).__name__, str(e_)[:300])}
 

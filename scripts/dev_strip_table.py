@@ -3,7 +3,7 @@ dist.render_strips would hand to rank r: own rows + halo rows + padding, no exch
 
     T_r             per-sample time of strip r (spp samples, LBVH rebuild included, best of `reps`)
     balance         max_r T_r / mean_r T_r
-    predicted       T_full / (max_r T_r + exchange) with exchange = EXCH_US per sample exposed on the chain (profiles/r04_strip_overlap.txt: 44-47 us)
+    predicted       T_full / (max_r T_r + exchange) with exchange = EXCH_US per sample exposed on the chain (measured: profiles/r06_halo_host_cost.txt)
 
 Also prints each strip's pixel counts and fits T_r = a + b * foreground px + c * background px over all strips of the mesh (a = per-sample fixed cost of a strip,
 c / b = what dist.strip_bounds calls bg_weight).
@@ -27,8 +27,11 @@ reps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 bgw = None if len(sys.argv) <= 3 or sys.argv[3] == "default" else float(sys.argv[3])
 worlds = [int(x) for x in (sys.argv[4] if len(sys.argv) > 4 else "2,4,8").split(",")]
 iters = int(sys.argv[5]) if len(sys.argv) > 5 else 1
-EXCH_US = 44.0
 mesh = os.environ.get("MIRRES_MESH", "icosphere")
+# what the per-sample exchange adds to a strip's period, MEASURED over RCCL on one rank with the library's own send / receive group (scripts/dev_halo_host_cost.py,
+# profiles/r06_halo_host_cost.txt: strip 4 of 8, 3.07 MB per sample): +43 us (icosphere) / +36 us (lego-like); the Python callback of rounds 1-5 added +95 / +84 us.
+# (rounds 4-5 assumed 44 us.)  MIRRES_EXCH_US overrides.
+EXCH_US = float(os.environ.get("MIRRES_EXCH_US", "43.0" if mesh == "icosphere" else "36.0"))
 dev = torch.device("cuda", 0)
 v, t = S.mesh_by_name(mesh)
 W = RR.restirbvhWorker(torch.from_numpy(v).cuda(), torch.from_numpy(t).cuda()); W.update_mesh(W.vrt, W.v_ind)
