@@ -166,6 +166,8 @@ def traversal_roofline(args, ctx, W, mlp, env, g, prof_spp, step_ms, world, pmc)
     import torch
     from mirres_restir_nerf_mesh_amd import renderer_restir as RR
     N = g["fx"] * g["fy"]
+    if float(N) * args.spp >= W.SAH_TOP_FROM_PIXEL_SAMPLES:
+        W.upgrade()      # the short profiling frames below traverse the hierarchy the benched frame does (round 6: the SAH top is added for long frames only)
     def frame(n):
         occ = g["occ"].clone()
         RR.render_fused(ctx, W, mlp, False, (1, 1, 1), env, occ, g["normal"], g["depth"], g["kd"], g["rm"], g["ray_dir"], g["pos"], n, 2, 2, 2.0, 0.1, 0.001, 12345)

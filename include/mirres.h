@@ -53,6 +53,16 @@ void mirres_bvh_destroy(mirres_bvh_t* bvh);
  * sorted_codes i32[T,2] (code, elementIdx) may be NULL. No host synchronisation.                            */
 int mirres_bvh_build(mirres_bvh_t* bvh, const float* vert, int V, const int32_t* tri, int T, int32_t* info, float* aabb,
                      int32_t* sorted_codes, void* stream);
+/* Round 6. The private steering hierarchy of the shadow-ray / ordered closest-hit kernels (no reference counterpart: the reference traverses its LBVH as built; any
+ * hierarchy over the same leaves gives the same answers) costs 0.2 ms (extended-Morton tree) + 0.9-1.4 ms (binned-SAH top) per build and pays for itself only on a long
+ * frame: a caller that rebuilds every frame (render_stage1 does, nerf/renderer.py:975) builds with private_level = 1 and asks for the SAH top when the frame is long
+ * enough (renderer_restir.py does: from ~1e8 pixel-samples). private_level: 0 = collapsed reference LBVH, 1 = extended-Morton tree, 2 = + SAH top, -1 =
+ * MIRRES_PRIVATE_TREE / default 2 (what mirres_bvh_build does). mirres_bvh_upgrade completes a level-1 build to level 2 (pass the arrays of the build call; a no-op
+ * on any other level); mirres_bvh_private_level reports the level of the last build.                                                                  */
+int mirres_bvh_build_level(mirres_bvh_t* bvh, const float* vert, int V, const int32_t* tri, int T, int32_t* info, float* aabb,
+                           int32_t* sorted_codes, int private_level, void* stream);
+int mirres_bvh_upgrade(mirres_bvh_t* bvh, const float* vert, const int32_t* tri, const int32_t* info, const float* aabb, void* stream);
+int mirres_bvh_private_level(mirres_bvh_t* bvh);
 /* bvh_hit / bvh_hit_with_normal (utils/helperDi.slang:197-274, 313-395) over a batch of rays.
  * rays f32[n,8] = (ox,oy,oz,t_min, dx,dy,dz,t_max). mode 0: any-hit (early exit; only `hit` is written),
  * mode 1: closest by exhaustion in the reference's traversal order (hit,t,pos,normal,prim written; NULL skips).

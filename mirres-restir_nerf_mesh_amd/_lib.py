@@ -69,6 +69,9 @@ SIGNATURES = {
     "mirres_bvh_create": (C.c_int, [C.POINTER(vp), C.c_int]),
     "mirres_bvh_destroy": (None, [vp]),
     "mirres_bvh_build": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, vp, vp, vp, vp]),
+    "mirres_bvh_build_level": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, vp, vp, vp, C.c_int, vp]),
+    "mirres_bvh_upgrade": (C.c_int, [vp, vp, vp, vp, vp, vp]),
+    "mirres_bvh_private_level": (C.c_int, [vp]),
     "mirres_bvh_trace": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp]),
     "mirres_ctx_create": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, PCFG]),
     "mirres_comm_unique_id": (C.c_int, [C.c_char_p, vp]),

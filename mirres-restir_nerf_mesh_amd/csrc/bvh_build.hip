@@ -798,6 +798,45 @@ __global__ void k_init_extent(uint32_t* extent) {
 
 using namespace mr;
 
+// ---- the private steering hierarchy in two steps (round 6: separable, so that a caller that rebuilds per frame can stop after step 1 and ask for step 2 only when the
+// frame is long enough to pay for it: mirres_bvh_upgrade)
+static int private_step1(mirres_bvh* b, int T, const float* aabb, hipStream_t s) {      // extended-Morton tree over the reference leaves
+    const int blk = 256, grd = grid_for(T, blk);
+    k_emc_keys<<<grd, blk, 0, s>>>(T, aabb, b->extent, b->p_keys, b->p_vals);
+    radix_sort_pairs_u32(b->p_keys, b->p_vals, b->keys_in, b->vals_in, (uint32_t*)b->sort_tmp, T, s);      // keys_in / vals_in: idle halves of the first sort's ping-pong
+    k_emc_leaves<<<grd, blk, 0, s>>>(T, b->p_keys, b->p_vals, b->keys_out, aabb, b->p_key64, b->p_info, b->p_aabb);
+    k_hierarchy64<<<grd, blk, 0, s>>>(T, b->p_key64, b->p_info, b->p_range, b->p_parent);
+    RefitLevels Lv; Lv.n = 1; Lv.a[0] = b->p_aabb + 6 * (size_t)(T - 1);
+    int n = T; float* dst = b->lvl;                                                                          // the pyramid of the reference refit is done with
+    while (n > 64 && Lv.n < 5) {
+        const int nd = (n + 63) >> 6;
+        k_refit_level<<<grid_for(nd, blk), blk, 0, s>>>(n, Lv.a[Lv.n - 1], dst);
+        Lv.a[Lv.n++] = dst; dst += 6 * (size_t)nd; n = nd;
+    }
+    k_refit_ranges<<<grd, blk, 0, s>>>(T, b->p_range, Lv, b->p_aabb);
+    MR_LAUNCH_CHECK("bvh_private_step1");
+    return 0;
+}
+static int private_sah_top(mirres_bvh* b, int T, hipStream_t s) {                        // its upper levels rebuilt by binned SAH over the prefix clusters
+    const int blk = 256;
+    SahState* st = reinterpret_cast<SahState*>(b->sah_state); SahNode* sn = reinterpret_cast<SahNode*>(b->sah_nodes); SahBin* sb = reinterpret_cast<SahBin*>(b->sah_bins);
+    k_sah_reset<<<grid_for(2 * MR_SAH_MAXC, blk), blk, 0, s>>>(st, sn, 2 * MR_SAH_MAXC);
+    k_sah_clusters<<<256, blk, 0, s>>>(T, b->p_key64, b->p_range, b->p_parent, b->p_aabb, st, sn, b->sah_iref, b->sah_inode, b->sah_top);
+    for (int level = 0; level < MR_SAH_TAIL; level++) {
+        const bool lds = level < MR_SAH_LDS_LEVELS;                      // <= 2^level nodes in the level
+        const int nodes_max = level < 16 ? (1 << level) : MR_SAH_MAXC;                  // <= 2^level nodes, never more than clusters
+        if (lds) k_sah_bin<true><<<64, blk, 0, s>>>(level, st, sn, b->sah_iref, b->sah_inode, b->p_aabb, sb);
+        else k_sah_bin<false><<<256, blk, 0, s>>>(level, st, sn, b->sah_iref, b->sah_inode, b->p_aabb, sb);
+        k_sah_split<<<grid_for(nodes_max < MR_SAH_MAXC ? nodes_max : MR_SAH_MAXC, blk), blk, 0, s>>>(level, st, sn, sb);
+        if (lds) k_sah_assign<true><<<64, blk, 0, s>>>(level, st, sn, b->sah_iref, b->sah_inode, b->p_aabb);
+        else k_sah_assign<false><<<256, blk, 0, s>>>(level, st, sn, b->sah_iref, b->sah_inode, b->p_aabb);
+    }
+    k_sah_tail<<<1, 1024, 0, s>>>(MR_SAH_TAIL, st, sn, b->sah_iref, b->sah_inode, b->p_aabb, sb);
+    k_sah_install<<<256, blk, 0, s>>>(st, sn, b->sah_top, b->p_info, b->p_aabb);
+    MR_LAUNCH_CHECK("bvh_private_sah_top");
+    return 0;
+}
+
 extern "C" {
 
 const char* mirres_version(void) { return "mirres-mi355x 0.1 (gfx950)"; }
@@ -863,8 +902,8 @@ void mirres_bvh_destroy(mirres_bvh_t* b) {
     delete b;
 }
 
-int mirres_bvh_build(mirres_bvh_t* b, const float* vert, int V, const int32_t* tri, int T, int32_t* info, float* aabb,
-                     int32_t* sorted_codes, void* stream) {
+int mirres_bvh_build_level(mirres_bvh_t* b, const float* vert, int V, const int32_t* tri, int T, int32_t* info, float* aabb,
+                           int32_t* sorted_codes, int private_level, void* stream) {
     if (!b || !vert || !tri) { set_error("mirres_bvh_build: null argument"); return MIRRES_E_ARG; }
     if (T < 2 || T > b->max_tris) { set_error("mirres_bvh_build: T=%d outside [2,%d]", T, b->max_tris); return MIRRES_E_ARG; }
     hipStream_t s = (hipStream_t)stream;
@@ -890,40 +929,42 @@ int mirres_bvh_build(mirres_bvh_t* b, const float* vert, int V, const int32_t* t
     k_pack<<<grd, blk, 0, s>>>(T, info, aabb, vert, tri, b->nodes, b->tris, b->root_box);
     // the 4-wide layout of the shadow-ray / ordered closest-hit kernels: collapsed from the private hierarchy — extended-Morton tree with its upper levels rebuilt by
     // the binned-SAH top (2, default), the plain extended-Morton tree (MIRRES_PRIVATE_TREE=1) — or (0) from the reference LBVH itself
-    static const int private_tree = [] { const char* e = getenv("MIRRES_PRIVATE_TREE"); return e ? atoi(e) : 2; }();
-    if (private_tree >= 1 && T >= 8) {
-        k_emc_keys<<<grd, blk, 0, s>>>(T, aabb, b->extent, b->p_keys, b->p_vals);
-        radix_sort_pairs_u32(b->p_keys, b->p_vals, b->keys_in, b->vals_in, (uint32_t*)b->sort_tmp, T, s);      // keys_in / vals_in: idle halves of the first sort's ping-pong
-        k_emc_leaves<<<grd, blk, 0, s>>>(T, b->p_keys, b->p_vals, b->keys_out, aabb, b->p_key64, b->p_info, b->p_aabb);
-        k_hierarchy64<<<grd, blk, 0, s>>>(T, b->p_key64, b->p_info, b->p_range, b->p_parent);
-        RefitLevels Lv; Lv.n = 1; Lv.a[0] = b->p_aabb + 6 * (size_t)(T - 1);
-        int n = T; float* dst = b->lvl;                                                                          // the pyramid of the reference refit is done with
-        while (n > 64 && Lv.n < 5) {
-            const int nd = (n + 63) >> 6;
-            k_refit_level<<<grid_for(nd, blk), blk, 0, s>>>(n, Lv.a[Lv.n - 1], dst);
-            Lv.a[Lv.n++] = dst; dst += 6 * (size_t)nd; n = nd;
-        }
-        k_refit_ranges<<<grd, blk, 0, s>>>(T, b->p_range, Lv, b->p_aabb);
-        if (private_tree == 2) {
-            SahState* st = reinterpret_cast<SahState*>(b->sah_state); SahNode* sn = reinterpret_cast<SahNode*>(b->sah_nodes); SahBin* sb = reinterpret_cast<SahBin*>(b->sah_bins);
-            k_sah_reset<<<grid_for(2 * MR_SAH_MAXC, blk), blk, 0, s>>>(st, sn, 2 * MR_SAH_MAXC);
-            k_sah_clusters<<<256, blk, 0, s>>>(T, b->p_key64, b->p_range, b->p_parent, b->p_aabb, st, sn, b->sah_iref, b->sah_inode, b->sah_top);
-            for (int level = 0; level < MR_SAH_TAIL; level++) {
-                const bool lds = level < MR_SAH_LDS_LEVELS;                      // <= 2^level nodes in the level
-                const int nodes_max = level < 16 ? (1 << level) : MR_SAH_MAXC;                  // <= 2^level nodes, never more than clusters
-                if (lds) k_sah_bin<true><<<64, blk, 0, s>>>(level, st, sn, b->sah_iref, b->sah_inode, b->p_aabb, sb);
-                else k_sah_bin<false><<<256, blk, 0, s>>>(level, st, sn, b->sah_iref, b->sah_inode, b->p_aabb, sb);
-                k_sah_split<<<grid_for(nodes_max < MR_SAH_MAXC ? nodes_max : MR_SAH_MAXC, blk), blk, 0, s>>>(level, st, sn, sb);
-                if (lds) k_sah_assign<true><<<64, blk, 0, s>>>(level, st, sn, b->sah_iref, b->sah_inode, b->p_aabb);
-                else k_sah_assign<false><<<256, blk, 0, s>>>(level, st, sn, b->sah_iref, b->sah_inode, b->p_aabb);
-            }
-            k_sah_tail<<<1, 1024, 0, s>>>(MR_SAH_TAIL, st, sn, b->sah_iref, b->sah_inode, b->p_aabb, sb);
-            k_sah_install<<<256, blk, 0, s>>>(st, sn, b->sah_top, b->p_info, b->p_aabb);
-        }
+    static const int private_tree_env = [] { const char* e = getenv("MIRRES_PRIVATE_TREE"); return e ? atoi(e) : 2; }();
+    int level = private_level >= 0 ? private_level : private_tree_env;
+    if (level > 2) level = 2;
+    if (T < 8) level = 0;
+    if (level >= 1) {
+        int rc = private_step1(b, T, aabb, s); if (rc) return rc;
+        if (level == 2) { rc = private_sah_top(b, T, s); if (rc) return rc; }
         k_pack4q<true><<<grd, blk, 0, s>>>(T, b->p_info, b->p_aabb, info, aabb, vert, tri, b->nodes4q, b->leaves);
     } else k_pack4q<false><<<grd, blk, 0, s>>>(T, info, aabb, info, aabb, vert, tri, b->nodes4q, b->leaves);
+    b->private_level = level;
     if (T - 1 >= 341 * 4) { k_top4q<<<1, 256, 0, s>>>(T, b->nodes4q, b->top85q, 85); k_top4q<<<1, 256, 0, s>>>(T, b->nodes4q, b->top341q, 341); }
     MR_LAUNCH_CHECK("bvh_build");
+    return MIRRES_OK;
+}
+
+int mirres_bvh_build(mirres_bvh_t* b, const float* vert, int V, const int32_t* tri, int T, int32_t* info, float* aabb,
+                     int32_t* sorted_codes, void* stream) {
+    return mirres_bvh_build_level(b, vert, V, tri, T, info, aabb, sorted_codes, -1, stream);
+}
+
+int mirres_bvh_private_level(mirres_bvh_t* b) { return b ? b->private_level : -1; }
+
+// step 2 on top of a level-1 build (same arrays as the build call): binned-SAH top + the 4-wide collapse again. Every hierarchy gives the same answers.
+int mirres_bvh_upgrade(mirres_bvh_t* b, const float* vert, const int32_t* tri, const int32_t* info, const float* aabb, void* stream) {
+    if (!b || !vert || !tri) { set_error("mirres_bvh_upgrade: null argument"); return MIRRES_E_ARG; }
+    if (b->T < 2) { set_error("mirres_bvh_upgrade: BVH not built"); return MIRRES_E_STATE; }
+    if (b->private_level != 1) return MIRRES_OK;                  // nothing to add (level 2 already, or a level-0 build / tiny mesh that has no private tree)
+    hipStream_t s = (hipStream_t)stream;
+    if (!info) info = b->own_info;
+    if (!aabb) aabb = b->own_aabb;
+    const int T = b->T, blk = 256, grd = grid_for(T, blk);
+    int rc = private_sah_top(b, T, s); if (rc) return rc;
+    k_pack4q<true><<<grd, blk, 0, s>>>(T, b->p_info, b->p_aabb, info, aabb, vert, tri, b->nodes4q, b->leaves);
+    if (T - 1 >= 341 * 4) { k_top4q<<<1, 256, 0, s>>>(T, b->nodes4q, b->top85q, 85); k_top4q<<<1, 256, 0, s>>>(T, b->nodes4q, b->top341q, 341); }
+    b->private_level = 2;
+    MR_LAUNCH_CHECK("bvh_upgrade");
     return MIRRES_OK;
 }
 

@@ -79,6 +79,7 @@ struct RaySrc { const float4* grec; const float4* rrec; float vis_near; int skip
 
 struct mirres_bvh {
     int max_tris = 0, T = 0, V = 0;
+    int private_level = 0;          // what the traversal layout was collapsed from: 0 reference LBVH, 1 extended-Morton tree, 2 + binned-SAH top (mirres_bvh_upgrade)
     // build workspace
     float* ele_aabb = nullptr;      // [T,6]
     uint32_t* extent = nullptr;     // [6] order-preserving uint encoding of min xyz / max xyz

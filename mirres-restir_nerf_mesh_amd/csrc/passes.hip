@@ -159,31 +159,60 @@ __global__ void __launch_bounds__(MR_BLOCK) k_env_weight(const float* __restrict
     float wv = luminance(env_le(ngp_dir(raw), tex, W, H));
     pdf[i] = wv * sin_theta;
 }
-// Row scans + Distribution2D (GenerateLightTiles.py:10-24, make_sampleable.slang:62-86). One thread per row, sequential
-// fp32 sums: the table is tiny (256 x 512) and a fixed summation order keeps it reproducible run to run.
+// Row scans + Distribution2D (GenerateLightTiles.py:10-24, make_sampleable.slang:62-86). Sequential fp32 sums per row: a fixed summation order keeps the table
+// reproducible run to run (and equal to the checker's). Round 6: the sums are the same, in the same order — but one thread per row walking global memory made the
+// kernel a chain of ~3000 dependent memory operations per thread on four waves (353 us per frame for a 256 x 512 map, on the caller's stream before anything else
+// can start: 1.3 % of a training step). Now one workgroup per row: the row moves through LDS in chunks (coalesced loads / stores by 64 lanes), lane 0 forms the
+// running sum from LDS, every lane normalises.
+#define MR_ENV_CHUNK 1024
 __global__ void __launch_bounds__(64) k_env_rows(int W, int H, float* __restrict__ pdf, float* __restrict__ cdf, float* __restrict__ mpdf) {
-    int y = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ float buf[MR_ENV_CHUNK];
+    __shared__ float s_acc;
+    const int t = threadIdx.x, y = blockIdx.x;
     if (y >= H) return;
-    float acc = 0.f;
-    cdf[(size_t)y * (W + 1)] = 0.f;
-    for (int w = 0; w < W; w++) { acc += pdf[(size_t)y * W + w]; cdf[(size_t)y * (W + 1) + w + 1] = acc; }
-    mpdf[y] = acc;
-    const float row_weight = acc;
-    for (int x = 0; x < W; x++) {
-        if (row_weight < 1e-4f) { pdf[(size_t)y * W + x] = 1.0f / W; cdf[(size_t)y * (W + 1) + x] = x / (float)W; }
-        else { pdf[(size_t)y * W + x] /= row_weight; cdf[(size_t)y * (W + 1) + x] /= row_weight; }
+    float* const prow = pdf + (size_t)y * W; float* const crow = cdf + (size_t)y * (W + 1);
+    float acc = 0.f;                                   // lane 0's: the row's running sum
+    for (int w0 = 0; w0 < W; w0 += MR_ENV_CHUNK) {
+        const int n = W - w0 < MR_ENV_CHUNK ? W - w0 : MR_ENV_CHUNK;
+        for (int i = t; i < n; i += 64) buf[i] = prow[w0 + i];
+        __syncthreads();
+        if (t == 0) for (int c = 0; c < n; c++) { acc += buf[c]; buf[c] = acc; }
+        __syncthreads();
+        for (int i = t; i < n; i += 64) crow[w0 + i + 1] = buf[i];
+        __syncthreads();
     }
-    cdf[(size_t)y * (W + 1) + W] = 1.f;
+    if (t == 0) { crow[0] = 0.f; mpdf[y] = acc; s_acc = acc; }
+    __syncthreads();
+    const float row_weight = s_acc;
+    for (int x = t; x < W; x += 64) {
+        if (row_weight < 1e-4f) { prow[x] = 1.0f / W; crow[x] = x / (float)W; }
+        else { prow[x] /= row_weight; crow[x] /= row_weight; }
+    }
+    if (t == 0) crow[W] = 1.f;
 }
-__global__ void k_env_marginal(int H, float* __restrict__ mpdf, float* __restrict__ mcdf) {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+__global__ void __launch_bounds__(64) k_env_marginal(int H, float* __restrict__ mpdf, float* __restrict__ mcdf) {
+    // one workgroup; the same sequential sum by lane 0, from LDS
+    __shared__ float buf[MR_ENV_CHUNK];
+    __shared__ float s_tot;
+    if (blockIdx.x != 0) return;
+    const int t = threadIdx.x;
     float acc = 0.f;
-    mcdf[0] = 0.f;
-    for (int h = 0; h < H; h++) { acc += mpdf[h]; mcdf[h + 1] = acc; }
-    const float total = acc;
-    for (int h = 0; h < H; h++) mpdf[h] = mpdf[h] / total;
-    for (int h = 0; h <= H; h++) mcdf[h] = mcdf[h] / total;
-    mcdf[H] = 1.f;
+    for (int h0 = 0; h0 < H; h0 += MR_ENV_CHUNK) {
+        const int n = H - h0 < MR_ENV_CHUNK ? H - h0 : MR_ENV_CHUNK;
+        for (int i = t; i < n; i += 64) buf[i] = mpdf[h0 + i];
+        __syncthreads();
+        if (t == 0) for (int c = 0; c < n; c++) { acc += buf[c]; buf[c] = acc; }
+        __syncthreads();
+        for (int i = t; i < n; i += 64) mcdf[h0 + i + 1] = buf[i];
+        __syncthreads();
+    }
+    if (t == 0) { mcdf[0] = 0.f; s_tot = acc; }
+    __syncthreads();
+    const float total = s_tot;
+    for (int h = t; h < H; h += 64) mpdf[h] = mpdf[h] / total;
+    for (int h = t; h <= H; h += 64) mcdf[h] = mcdf[h] / total;
+    __syncthreads();
+    if (t == 0) mcdf[H] = 1.f;
 }
 
 // createNeighborOffsetTexture (make_sampleable.slang:186-205) — a serial R2 walk, run once by one thread as in the reference
@@ -1017,7 +1046,7 @@ int mirres_env_make_sampleable(const float* env_tex, int Wc, int Hc, float* pdf,
     if (!env_tex || !pdf || !cdf || !mpdf || !mcdf || Wc <= 0 || Hc <= 0) { set_error("mirres_env_make_sampleable: bad argument"); return MIRRES_E_ARG; }
     hipStream_t s = (hipStream_t)stream;
     k_env_weight<<<grid_for((size_t)Wc * Hc, MR_BLOCK), MR_BLOCK, 0, s>>>(env_tex, Wc, Hc, pdf);
-    k_env_rows<<<grid_for(Hc, 64), 64, 0, s>>>(Wc, Hc, pdf, cdf, mpdf);
+    k_env_rows<<<Hc, 64, 0, s>>>(Wc, Hc, pdf, cdf, mpdf);
     k_env_marginal<<<1, 64, 0, s>>>(Hc, mpdf, mcdf);
     MR_LAUNCH_CHECK("make_sampleable");
     return MIRRES_OK;

@@ -470,8 +470,13 @@ int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args
     // so even a single batch keeps several streams busy; larger batches mean fewer, larger launches (measured at 1600^2: 16 spp in one batch
     // of 16 instead of four of 4: 53.6 -> 50.5 ms; 128 spp in batches of 16 / 32 / 64: 375 / 370 / 367 ms)
     int Kuse = Kmax;
-    { const char* e = getenv("MIRRES_MIN_BATCHES"); const int mb = e ? (atoi(e) > 0 ? atoi(e) : 1) : 1;
-      const int n = i1 - i0; if (n < mb * Kuse) Kuse = (n + mb - 1) / mb; if (Kuse < 1) Kuse = 1; if (Kuse > Kmax) Kuse = Kmax; if (Kuse > n) Kuse = n; }
+    { const char* e = getenv("MIRRES_MIN_BATCHES");
+      const int n = i1 - i0;
+      // a frame whose samples fit ONE batch runs its stages strictly one after the other (initial resampling of all samples, then the whole chain, then the final
+      // stage); two batches let I(1) and F(0) run beside the chain. On a small frame (the 800 x 800 x 32 spp training frame) that is worth 1.3 % of the step
+      // (profiles/r06_ab_train_batch.txt: 16 per batch 25.9 ms, 32: 26.25, 11: 27.2, 8: 28.3); on the full-size frame short batches lose (r05_ab_batch_ramp.txt)
+      const int mb = e ? (atoi(e) > 0 ? atoi(e) : 1) : ((n >= 16 && n <= Kuse && (size_t)N <= (size_t)1024 * 1024) ? 2 : 1);
+      if (n < mb * Kuse) Kuse = (n + mb - 1) / mb; if (Kuse < 1) Kuse = 1; if (Kuse > Kmax) Kuse = Kmax; if (Kuse > n) Kuse = n; }
     PtBatch PB; rc = carve_batch(ctx, N, Kuse, max_bounce, TS, PB); if (rc) return rc;
     // ---- schedule. Per batch b of K samples:
     //   I(b)  initial resampling of the K samples (light tiles, candidates, shadow rays)              bulk stream, K * N slots per launch

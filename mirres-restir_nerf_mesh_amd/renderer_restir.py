@@ -5,6 +5,7 @@ Same names, argument order, in-place mutation and return structure as the refere
   * fused   : one C call (mirres_render) enqueues the whole spp loop — used when no input requires grad;
   * stepwise: the reference's per-pass Python loop over the same kernels — used under autograd (stage-1 training)."""
 import ctypes as C
+import os
 import time
 
 import numpy as np
@@ -76,10 +77,28 @@ class restirbvhWorker:
         self._ensure(T)
         info = torch.empty((2 * T - 1, 3), dtype=torch.int32, device=vrt.device)
         aabb = torch.empty((2 * T - 1, 6), dtype=torch.float32, device=vrt.device)
-        check(lib().mirres_bvh_build(self.h, vrt.data_ptr(), vrt.shape[0], v_ind.data_ptr(), T, info.data_ptr(), aabb.data_ptr(), None, stream_ptr()),
-              "mirres_bvh_build")
+        # The private steering hierarchy is built in two steps (round 6): the extended-Morton tree now, its binned-SAH top (0.9-1.4 ms per build) only when a frame is
+        # long enough to pay for it (ensure_hierarchy_for, called by render_fused). MIRRES_PRIVATE_TREE = 0 / 1 / 2 fixes the level at build time as before.
+        env = os.environ.get("MIRRES_PRIVATE_TREE")
+        level = int(env) if env not in (None, "", "auto") else 1
+        check(lib().mirres_bvh_build_level(self.h, vrt.data_ptr(), vrt.shape[0], v_ind.data_ptr(), T, info.data_ptr(), aabb.data_ptr(), None, level, stream_ptr()),
+              "mirres_bvh_build_level")
         self._keep = (vrt, v_ind)
+        self._auto_level = env in (None, "", "auto")
         return info, aabb
+
+    SAH_TOP_FROM_PIXEL_SAMPLES = 1.0e8      # the SAH top returns ~4-7 % of a frame's traversal time: from about 1e8 pixel-samples on that is more than its build (800 x 800 x 32 spp = 2e7: not; 1600 x 1600 x 512 = 1.3e9: yes; profiles/r06_ab_train_tree.txt)
+
+    def upgrade(self):
+        """Completes the private hierarchy (binned-SAH top) on top of the current build; a no-op when it is complete or was fixed by MIRRES_PRIVATE_TREE."""
+        if self.h is None or self.LBVHNode_info is None:
+            return
+        vrt, v_ind = self._keep
+        check(lib().mirres_bvh_upgrade(self.h, vrt.data_ptr(), v_ind.data_ptr(), self.LBVHNode_info.data_ptr(), self.LBVHNode_aabb.data_ptr(), stream_ptr()), "mirres_bvh_upgrade")
+
+    def ensure_hierarchy_for(self, pixel_samples):
+        if getattr(self, "_auto_level", False) and pixel_samples >= self.SAH_TOP_FROM_PIXEL_SAMPLES:
+            self.upgrade()
 
     def update_mesh(self, vt, vt_ind):
         if self.LBVHNode_info is not None:
@@ -333,6 +352,8 @@ def render_fused(ctx, bvh_restir_worker, mlp_mat, use_scale, scale, env_map, occ
             keep.append(halo)
             a.halo = C.cast(halo, C.c_void_p)
             a.strip_overlap = 1 if strip_overlap else 0
+    n_samples = (int(spp_range[1]) - int(spp_range[0])) if spp_range is not None else int(spp)
+    bvh_restir_worker.ensure_hierarchy_for(float(N) * max(0, n_samples))
     check(lib().mirres_render(ctx.h, bvh_restir_worker.h, C.byref(a), stream_ptr()), "mirres_render")
     return outs, a, keep
 

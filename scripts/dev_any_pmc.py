@@ -15,7 +15,7 @@ K = int(sys.argv[2]) if len(sys.argv) > 2 else 7
 L = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 mode = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 v, t = S.mesh_by_name(os.environ.get("MIRRES_MESH", "icosphere"))
-W = RR.restirbvhWorker(torch.from_numpy(v).cuda(), torch.from_numpy(t).cuda()); W.update_mesh(W.vrt, W.v_ind)
+W = RR.restirbvhWorker(torch.from_numpy(v).cuda(), torch.from_numpy(t).cuda()); W.update_mesh(W.vrt, W.v_ind); W.upgrade()      # the hierarchy a long frame traverses (round 6: the SAH top is the build's second step)
 g = harness.build_gbuffer(W, res, res, 1)
 fg = g["occ"][:, 0] > 0.5
 pos, nrm = g["pos"][fg], g["normal"][fg]

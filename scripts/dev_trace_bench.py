@@ -8,7 +8,7 @@ from mirres_restir_nerf_mesh_amd._lib import lib, check
 S = M.scene
 res = int(sys.argv[1]) if len(sys.argv) > 1 else 1600
 v, t = S.mesh_by_name(os.environ.get("MIRRES_MESH", "icosphere"))
-W = RR.restirbvhWorker(torch.from_numpy(v).cuda(), torch.from_numpy(t).cuda()); W.update_mesh(W.vrt, W.v_ind)
+W = RR.restirbvhWorker(torch.from_numpy(v).cuda(), torch.from_numpy(t).cuda()); W.update_mesh(W.vrt, W.v_ind); W.upgrade()      # the hierarchy a long frame traverses (round 6: the SAH top is the build's second step)
 g = harness.build_gbuffer(W, res, res, 1)
 fg = g["occ"][:, 0] > 0.5
 pos, nrm = g["pos"][fg], g["normal"][fg]

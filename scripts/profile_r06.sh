@@ -10,11 +10,15 @@ python3 -c "import bench; print('csrc_sha', bench.csrc_sha(), {g: bench.csrc_sha
 RP="timeout -k 5 600 rocprofv3"
 
 # ---- 1. counters: the shadow-ray kernel alone (both meshes), every kernel of one serialised frame (both meshes), MLP GEMM phase, the training step's backward kernels
+# The counter passes render SHORT frames (8 spp) of the metric's scene: the hierarchy is fixed to the one the metric's 512-spp frame traverses (round 6: update_mesh builds
+# the extended-Morton tree and a long frame adds the SAH top; a short one would not)
+export MIRRES_PRIVATE_TREE=2
 bash scripts/pmc_any.sh any 1600 7 3 0 > $O/${R}_pmc_any4q.txt 2>&1; cp gpurun_out/pmc_any/summary.json $O/${R}_pmc_any4q.json 2>/dev/null
 MIRRES_MESH=clustered bash scripts/pmc_any.sh any_clustered 1600 7 3 0 > $O/${R}_pmc_any4q_clustered.txt 2>&1; cp gpurun_out/pmc_any_clustered/summary.json $O/${R}_pmc_any4q_clustered.json 2>/dev/null
 bash scripts/pmc_chain.sh chain_ico icosphere 8 > $O/${R}_pmc_chain_icosphere.txt 2>&1; cp gpurun_out/pmc_chain_ico/summary.json $O/${R}_pmc_chain_icosphere.json 2>/dev/null
 bash scripts/pmc_chain.sh chain_clu clustered 8 > $O/${R}_pmc_chain_clustered.txt 2>&1; cp gpurun_out/pmc_chain_clu/summary.json $O/${R}_pmc_chain_clustered.json 2>/dev/null
 bash scripts/pmc_mlp.sh > $O/${R}_pmc_mlp.txt 2>&1
+unset MIRRES_PRIVATE_TREE      # the training step and every bench line below: the default (two-step) build
 bash scripts/pmc_train.sh train > $O/${R}_pmc_train.txt 2>&1; cp gpurun_out/pmc_train/summary.json $O/${R}_pmc_train.json 2>/dev/null
 python3 scripts/dev_kernel_regs.py > $O/${R}_kernel_regs.txt 2>&1        # code-object metadata: what occupancy is computed from
 
@@ -137,7 +141,7 @@ rm -rf gpurun_out/pf/kt; $RP --kernel-trace --stats --output-format csv -d gpuru
 find gpurun_out/pf/kt -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/${R}_mlp_kernel_stats.csv; grep -E '^(mlp_mfma|valu)' gpurun_out/pf/log_mlp > $O/${R}_mlp_bench.txt
 rm -rf gpurun_out/pf/kt; $RP --kernel-trace --stats --output-format csv -d gpurun_out/pf/kt -o t -- python3 scripts/train_step_bench.py --steps 3 > gpurun_out/pf/log_tr 2>&1
 find gpurun_out/pf/kt -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/${R}_train_step_kernel_stats.csv; grep '^stage-1' gpurun_out/pf/log_tr > $O/${R}_train_step.txt
-timeout -k 5 300 python3 scripts/dev_leaf_branch.py 4 2>&1 | grep -v amdgpu.ids > $O/${R}_leaf_branch.txt
+MIRRES_PRIVATE_TREE=2 timeout -k 5 300 python3 scripts/dev_leaf_branch.py 4 2>&1 | grep -v amdgpu.ids > $O/${R}_leaf_branch.txt
 rm -rf gpurun_out/pf
 # ---- 4. the exact strip scheme's table at the bench's own 512 spp, with the MEASURED exchange (profiles/r06_halo_host_cost.txt)
 for mesh in icosphere clustered; do MIRRES_MESH=$mesh timeout -k 5 900 python3 scripts/dev_strip_table.py 512 1 default 2,4,8 3 2>&1 | grep -v amdgpu.ids > $O/${R}_strip_table_512_$mesh.txt; done

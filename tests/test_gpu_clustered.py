@@ -95,13 +95,14 @@ def test_private_hierarchy_is_installed(lego, scene_mod):
     import torch
     from mirres_restir_nerf_mesh_amd import renderer_restir as RR
     from mirres_restir_nerf_mesh_amd._lib import lib
-    if os.environ.get("MIRRES_PRIVATE_TREE", "2") != "2":
+    if os.environ.get("MIRRES_PRIVATE_TREE", "2") not in ("2", "auto", ""):
         pytest.skip("the SAH top is switched off in this process")
     L = lib(); L.mirres_debug_sah_state.argtypes = [C.c_void_p, C.c_void_p]; L.mirres_debug_sah_state.restype = C.c_int
     v2, t2 = scene_mod.mesh_by_name("icosphere")
     W2 = RR.restirbvhWorker(torch.from_numpy(v2).cuda(), torch.from_numpy(t2).cuda()); W2.update_mesh(W2.vrt, W2.v_ind)
     for name, W in (("clustered", lego[2]), ("icosphere", W2)):
         W.update_mesh(W.vrt, W.v_ind)
+        W.upgrade()          # round 6: the SAH top is the second step of the build (what a long frame asks for)
         st = (C.c_uint32 * 8)()
         assert L.mirres_debug_sah_state(W.h, st) == 0
         clusters, above, rebuilt, internal, resolved, fail, levels = st[:7]

@@ -467,8 +467,8 @@ def test_pixel_pair_queue_and_ray_queue_render_the_same_frame_at_full_size():
 
 def test_round4_switches_do_not_change_the_frame_at_full_size():
     """Round 4's restructurings are each behind a switch that is read once per process; every one of them must leave all six output buffers of a 1600 x 1600 x 6 spp
-    frame of the LEGO-LIKE mesh (material field on) with the same bits. Five processes: the defaults; the private hierarchy replaced by the plain extended-Morton
-    tree (MIRRES_PRIVATE_TREE=1) and by the collapsed reference LBVH (=0); every other restructuring switched back AT ONCE — temporal merge in its own launch
+    frame of the LEGO-LIKE mesh (material field on) with the same bits. Six processes: the defaults; the private hierarchy replaced by the plain extended-Morton
+    tree (MIRRES_PRIVATE_TREE=1), by the collapsed reference LBVH (=0) and completed by the binned-SAH top at build time (=2); every other restructuring switched back AT ONCE — temporal merge in its own launch
     (MIRRES_FUSE_TEMPORAL=0), material lookup in slot order (MIRRES_GRID_SORT=0), reference-order closest-hit kernel for every ray (MIRRES_CLOSEST=2), every spatial
     shadow ray traced (MIRRES_SKIP_DEAD=0), 32-byte light-tile records (MIRRES_TILE_COMPACT=0), shadow-ray kernel reading the tree's first four levels from LDS
     (MIRRES_TOPQ=85); and the launch / sort-key / stream defaults of rounds 1-4 with the new kernels. (One process per switch was 11 processes and a fifth of the
@@ -477,6 +477,7 @@ def test_round4_switches_do_not_change_the_frame_at_full_size():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = {}
     for name, extra in (("default", {}), ("collapsed LBVH", {"MIRRES_PRIVATE_TREE": "0"}), ("extended-Morton tree without the SAH top", {"MIRRES_PRIVATE_TREE": "1"}),
+                        ("extended-Morton tree with the binned-SAH top (round 6: the default builds it only for long frames)", {"MIRRES_PRIVATE_TREE": "2"}),
                         ("every other round-4 restructuring switched back", {"MIRRES_FUSE_TEMPORAL": "0", "MIRRES_GRID_SORT": "0", "MIRRES_CLOSEST": "2", "MIRRES_SKIP_DEAD": "0",
                                                                             "MIRRES_TILE_COMPACT": "0", "MIRRES_TOPQ": "85"}),
                         ("15-bit sort keys, three streams, six workgroups per CU (the defaults until the end of round 4)", {"MIRRES_GS_BITS": "5", "MIRRES_STREAMS": "3", "MIRRES_TRACE_BLOCKS_PER_CU": "6"})):

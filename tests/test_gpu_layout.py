@@ -125,10 +125,12 @@ def check_layout(nodes, leaves, top, T, vert, tri, info, aabb):
     return {"levels": len(levels), "reachable_nodes": int(sum(len(l) for l in levels)), "unused_entries": n_unused, "loosest_box_over_node_extent": worst}
 
 
-def _worker(v, t):
+def _worker(v, t, upgrade=True):
     import torch
     from mirres_restir_nerf_mesh_amd import renderer_restir as RR
     W = RR.restirbvhWorker(torch.from_numpy(v).cuda(), torch.from_numpy(t).cuda()); W.update_mesh(W.vrt, W.v_ind)
+    if upgrade:
+        W.upgrade()      # round 6: update_mesh stops after the extended-Morton tree; the binned-SAH top is added when a frame is long enough — or here (a no-op when MIRRES_PRIVATE_TREE fixes the level)
     return W
 
 
@@ -145,10 +147,10 @@ def _meshes(scene_mod):
         yield "soup of %d" % T, (v, np.arange(3 * T, dtype=np.int32).reshape(T, 3))
 
 
-def run_all(scene_mod, oracle):
+def run_all(scene_mod, oracle, upgrade=True):
     out = []
     for name, (v, t) in _meshes(scene_mod):
-        W = _worker(v, t)
+        W = _worker(v, t, upgrade)
         T = int(t.shape[0])
         info, aabb = W.LBVHNode_info.cpu().numpy(), W.LBVHNode_aabb.cpu().numpy()
         o_info, o_aabb, _, _ = oracle.bvh_build(v, t)
@@ -160,8 +162,15 @@ def run_all(scene_mod, oracle):
 
 
 def test_private_layout_is_a_valid_hierarchy(scene_mod, oracle):
-    """Default configuration of this process (MIRRES_PRIVATE_TREE unset = 2: extended-Morton tree with the binned-SAH top)."""
-    lines = run_all(scene_mod, oracle)
+    """Default configuration of this process (MIRRES_PRIVATE_TREE unset): what update_mesh builds (the extended-Morton tree) AND what a long frame upgrades it to
+    (the same tree with the binned-SAH top, mirres_bvh_upgrade)."""
+    from mirres_restir_nerf_mesh_amd._lib import lib
+    lines = run_all(scene_mod, oracle, upgrade=False) + run_all(scene_mod, oracle, upgrade=True)
+    if os.environ.get("MIRRES_PRIVATE_TREE") in (None, "", "auto"):
+        W0 = _worker(*scene_mod.mesh_by_name("icosphere"), upgrade=False)
+        assert lib().mirres_bvh_private_level(W0.h) == 1
+        W0.ensure_hierarchy_for(1.0e7); assert lib().mirres_bvh_private_level(W0.h) == 1          # a short frame keeps the cheap tree
+        W0.ensure_hierarchy_for(1.0e9); assert lib().mirres_bvh_private_level(W0.h) == 2          # a long one completes it
     rep = os.path.join(os.path.dirname(HERE), "gpurun_out")
     if os.path.isdir(rep):
         with open(os.path.join(rep, "layout_check.txt"), "a") as f:
