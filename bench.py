@@ -410,12 +410,32 @@ def main():
             results[sc] = timed(sc)
             continue
         # the second scheme must not take the line of the first one with it: an error that every rank raises (the likely kind: an API the backend refuses)
-        # is caught, agreed on by all ranks and reported in the sub-record
+        # is caught, agreed on by all ranks and reported in the sub-record. A HANG would (the exact scheme's per-sample point-to-point exchange has never run on more
+        # than one GPU: SCALE was skipped in every round): a watchdog prints the line of the first scheme — the declared value — with the second one marked as
+        # timed out, and ends the process, if the second scheme takes more than 30 x the first one's time (at least three minutes).
+        import threading
+        d0 = results[schemes[0]][0]
+        def _bail():
+            if rank == 0:
+                line = {"metric": "Msamples/s (pixels x spp), ReSTIR-DI + %d-bounce path tracing forward render" % (args.bounces + 1),
+                        "value": round(samples / d0 / 1e6, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                        "ms_per_step": round(d0 / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                        "config": {"workload": "BASELINE metric frame, %s mesh, %dx%d output, ssaa %d, %d spp" % (args.mesh, args.res, args.res, args.ssaa, args.spp), "value_scheme": schemes[0],
+                                   "bit_identical_to_one_gpu": schemes[0] == "strips"},
+                        "roofline": None, "cpu_baseline": None, sc: {"value": None, "error": "timed out (watchdog): the scheme did not finish; the line carries the first scheme only"}}
+                print(json.dumps(line), file=out_stream, flush=True)
+            os._exit(0 if rank == 0 else 3)
+        limit = max(180.0, 30.0 * d0 * (args.steps + args.warmup) / max(1, args.steps))
+        if os.environ.get("MIRRES_BENCH_WATCHDOG_S"):      # (tests of the watchdog itself)
+            limit = float(os.environ["MIRRES_BENCH_WATCHDOG_S"])
+        dog = threading.Timer(limit, _bail)
+        dog.daemon = True; dog.start()
         err = None
         try:
             results[sc] = timed(sc)
         except Exception as e:      # noqa: BLE001
             err = "%s: %s" % (type(e).__name__, e)
+        dog.cancel()
         bad = torch.tensor([1.0 if err else 0.0], device=dev)
         dist.all_reduce(bad, op=dist.ReduceOp.MAX)
         if float(bad.item()) > 0:
