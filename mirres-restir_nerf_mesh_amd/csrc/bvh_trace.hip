@@ -436,6 +436,12 @@ static_assert(MR_ANY_LDS >= 3 && MR_ANY_LDS <= MR_ANY_STACK, "the LDS part of th
 #ifndef MR_ANY_SEL
 #define MR_ANY_SEL 1      // straight-line child selection (round 6); 0: round 5's sequential insert
 #endif
+#ifndef MR_ANY_POP
+#define MR_ANY_POP 1      // the pop as straight-line code (round 6: frames +0.3 … +2 % / +0.3 … +0.7 %, profiles/r06_ab_any_pop.txt); 0: round 5's nested ifs
+#endif
+#ifndef MR_CL_SEL
+#define MR_CL_SEL 1      // unconditional pushes in the ordered closest-hit kernel (round 6: kernel -5 %, frames +0.6 % / +1.1 %, profiles/r06_ab_closest_sel.txt); 0: round 5's exec-masked pushes
+#endif
 #ifndef MR_ANY_LEANREFILL
 #define MR_ANY_LEANREFILL 1      // short division / square root where the pixel-pair source forms its rays (round 6); 0: the compiler's IEEE sequences
 #endif
@@ -763,6 +769,18 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_any4q(BvhView B, const
                     }
                 }
                 bool done = hit;
+#if MR_ANY_POP
+                // Round 6: the pop as straight-line code while the entry it would take lies in the LDS part of the stack (sp <= MR_ANY_LDS): the top entry is read
+                // whether or not it is needed (one ds_read per iteration; what it returns for an empty stack is not used), the next reference, the stack pointer and
+                // "done" are selects — no exec-mask region for "descend / pop / finished"
+                if (sp <= MR_ANY_LDS) {
+                    const bool has_next = next != 0x7fffffff, can_pop = sp > sbase;
+                    const int top = (int)lds_stack[(sp > 0 ? sp - 1 : 0) * MR_TRACE_BLOCK];
+                    cur = has_next ? next : top;
+                    sp -= (!has_next && can_pop) ? 1 : 0;
+                    done = hit || (!has_next && !can_pop);
+                } else
+#endif
                 if (!hit) {
                     if (next != 0x7fffffff) cur = next;
                     else if (sp > sbase) { --sp; cur = (int)((sp < MR_ANY_LDS) ? lds_stack[sp * MR_TRACE_BLOCK] : spill[sp - MR_ANY_LDS]); }
@@ -945,6 +963,20 @@ __global__ void __launch_bounds__(MR_TRACE_BLOCK) k_trace_closest4(BvhView B, co
                         MR_CX(0, 1) MR_CX(2, 3) MR_CX(0, 2) MR_CX(1, 3) MR_CX(1, 2)
 #undef MR_CX
                         cur = NONE;
+#if MR_CL_SEL
+                        // Round 6 (as in the shadow-ray kernel): while three entries fit the LDS part the stores are UNCONDITIONAL — farthest first, at a stack top that only
+                        // advances past an entry to be kept. The sorted keys put the children that cannot matter (+inf) last, i.e. FIRST in push order: each is overwritten
+                        // by the next store, and what lies above `sp` is never read. No exec-mask region per entry; the order of the kept entries is the old one.
+                        if (sp + 3 <= MR_LDS_STACK) {
+                            cur = nn > 0 ? sr[0] : NONE;
+#pragma unroll
+                            for (int q = 3; q >= 1; q--) {
+                                uint2 e; e.x = (uint32_t)sr[q]; e.y = __float_as_uint(sk[q]);
+                                lds_stack[sp * MR_TRACE_BLOCK] = e; sp += (q < nn) ? 1 : 0;
+                            }
+                            if (COUNT) c_maxsp = sp > c_maxsp ? sp : c_maxsp;
+                        } else
+#endif
                         if (nn > 0) {
                             cur = sr[0];
                             if (sp + 3 <= MR_LDS_STACK) {      // all three possible entries fit the LDS part (the usual case): no per-entry range checks

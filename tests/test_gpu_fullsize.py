@@ -405,7 +405,7 @@ def test_round6_traversal_changes_do_not_change_the_frame():
         import __graft_entry__ as G
         spec = importlib.util.spec_from_file_location("mirres_build", os.path.join(root, "mirres-restir_nerf_mesh_amd", "csrc", "build.py"))
         b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
-        G.build_variant(b, "r5trav", "-DMR_ANY_SEL=0 -DMR_ANY_LEANREFILL=0")
+        G.build_variant(b, "r5trav", "-DMR_ANY_SEL=0 -DMR_ANY_LEANREFILL=0 -DMR_CL_SEL=0 -DMR_ANY_POP=0")
     assert os.path.exists(variant)
     for mesh in ("icosphere", "clustered"):
         lines = []
