@@ -559,6 +559,11 @@ def main():
                 b_, t_ = balancer.history[-1]
                 line["config"]["strip_balance"] = {"bounds": b_, "strip_ms": [round(x, 2) for x in t_], "max_over_mean": round(max(t_) / (sum(t_) / len(t_)), 4),
                                                    "note": "last exchanged strip render times (dist.StripBalancer): boundaries follow them from frame to frame"}
+                if balancer.last_wait_ms is not None and balancer.last_spp:      # rank 0's stream time inside the per-sample halo exchanges of its last timed strip render
+                    line["config"]["strip_exchange"] = {"path": balancer.last_path, "rank0_frame_ms": round(balancer.last_total_ms, 2), "rank0_in_exchange_ms": round(balancer.last_wait_ms, 2),
+                                                        "exchange_us_per_sample": round(balancer.last_wait_ms * 1e3 / balancer.last_spp, 1),
+                                                        "note": "device time between events around every (spp / 32)-th exchange, scaled; includes waiting for the neighbour strips; "
+                                                                "host cost per exchange: profiles/r06_halo_host_cost.txt"}
         print(json.dumps(line), file=out_stream, flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -192,6 +192,7 @@ class StripBalancer:
         self.wait_stride = 1
         self.native = None         # (context, stride) of a render whose exchanges the library issued and timed itself
         self.last_total_ms = self.last_wait_ms = None
+        self.last_path, self.last_spp = None, None     # how the last strip render exchanged its halos ("native": csrc/comm.hip, "callback": torch.distributed from the host callback)
         self.history = []          # (bounds, times) per update: what the table in profiles/ is printed from
 
     def cost(self, fx, occ):
@@ -506,6 +507,7 @@ def render_strips(ctx_full, worker, mlp_mat, env_map, g, spp, random_offset, ran
             if balancer is not None:
                 balancer.native = (ctx_loc, stride)
     if balancer is not None:
+        balancer.last_path, balancer.last_spp = ("native" if native is not None else "callback"), int(spp)
         balancer.start(spp)
     try:
         sums, a, keep = render_fused(ctx_loc, worker, mlp_mat, use_scale, scale, env_map, loc["occ"], loc["normal"], loc["depth"], loc["kd"], loc["rm"], loc["ray_dir"],
