@@ -3,7 +3,7 @@ import glob, os, re, shutil, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LLVM = "/opt/rocm/lib/llvm/bin/"
 pat = sys.argv[1] if len(sys.argv) > 1 else "."
-for obj in sorted(glob.glob(os.path.join(ROOT, "mirres-restir_nerf_mesh_amd", "csrc", "obj", "*.o"))):
+for obj in sorted(glob.glob(os.path.join(ROOT, "mirres-restir_nerf_mesh_amd", "csrc", os.environ.get("MIRRES_OBJ_DIR", "obj"), "*.o"))):
     tmp = tempfile.mkdtemp(); src = shutil.copy(obj, tmp)
     subprocess.run([LLVM + "llvm-objdump", "--offloading", src], capture_output=True, cwd=tmp)
     for f in glob.glob(src + ".*gfx950"):
