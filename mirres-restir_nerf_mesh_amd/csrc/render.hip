@@ -199,9 +199,11 @@ static PtSet pt_set(const PtBatch& PB, int h, size_t cap, int nb) {
     S.cb = PB.cb + 9 * (size_t)nb * o; S.maskb = PB.maskb + (size_t)nb * o;
     return S;
 }
-static int pt_batch_size() {   // MIRRES_PT_BATCH = samples per batch (default 32: ~86 M slots, ~55 GB of pool at 1600^2; 1 = sample by sample)
+static int pt_batch_size() {   // MIRRES_PT_BATCH = samples per batch (default 64 since the end of round 6: ~164 M slots, ~110 GB of pool at 1600^2 — the device has 288 GB, and
+                               // carve_batch halves the batch when it cannot have them; 32, the default of rounds 1-6: 512-spp frame -0.3 % / -1.2 %, profiles/r06_ab_pt_batch.txt;
+                               // 1 = sample by sample)
     const char* e = getenv("MIRRES_PT_BATCH");   // read per frame (tests switch it)
-    int k = e ? atoi(e) : 32; if (k < 1) k = 1; if (k > 64) k = 64;
+    int k = e ? atoi(e) : 64; if (k < 1) k = 1; if (k > 64) k = 64;
     return k;
 }
 // The bulk stream at the LOWEST priority (MIRRES_BULK_PRIO=low): the sample-by-sample chain on the caller's stream is what bounds a small frame (a strip of a
@@ -475,7 +477,8 @@ int mirres_render(mirres_ctx_t* ctx, mirres_bvh_t* bvh, const mirres_render_args
       // a frame whose samples fit ONE batch runs its stages strictly one after the other (initial resampling of all samples, then the whole chain, then the final
       // stage); two batches let I(1) and F(0) run beside the chain. On a small frame (the 800 x 800 x 32 spp training frame) that is worth 1.3 % of the step
       // (profiles/r06_ab_train_batch.txt: 16 per batch 25.9 ms, 32: 26.25, 11: 27.2, 8: 28.3); on the full-size frame short batches lose (r05_ab_batch_ramp.txt)
-      const int mb = e ? (atoi(e) > 0 ? atoi(e) : 1) : ((n >= 16 && n <= Kuse && (size_t)N <= (size_t)1024 * 1024) ? 2 : 1);
+      // A full-size frame of 33 ... 64 samples (a rank's slice of the 512-spp frame on eight GPUs) keeps the two batches of <= 32 it had while 32 was the batch size.
+      const int mb = e ? (atoi(e) > 0 ? atoi(e) : 1) : ((n >= 16 && n <= Kuse && ((size_t)N <= (size_t)1024 * 1024 || n > 32)) ? 2 : 1);
       if (n < mb * Kuse) Kuse = (n + mb - 1) / mb; if (Kuse < 1) Kuse = 1; if (Kuse > Kmax) Kuse = Kmax; if (Kuse > n) Kuse = n; }
     PtBatch PB; rc = carve_batch(ctx, N, Kuse, max_bounce, TS, PB); if (rc) return rc;
     // ---- schedule. Per batch b of K samples:
