@@ -366,7 +366,10 @@ def main():
     env = torch.from_numpy(S.make_env(256, 512)).to(dev)
     fx, fy = g["fx"], g["fy"]
     ctx = get_ctx(fx, fy, max_bounce=args.bounces)
-    ctx.reserve()                       # the batch pool is sized here, not inside the first frame
+    if world == 1:
+        ctx.reserve()                   # the batch pool is sized here, not inside the first frame
+    # (N > 1: a rank renders spp / N samples, or a strip, in batches the library sizes for them — the warm-up frames carve those pools; reserving the default 64-sample
+    # pool of the whole frame first would hold 113 GB the run never uses, which two dry-run ranks sharing one GPU do not have: scripts/runs/r06_run43.sh)
     N = fx * fy
 
     balancer = MD.StripBalancer(fy, world) if world > 1 else None      # strip boundaries follow the strips' measured times from frame to frame (bit-identical for any partition)
@@ -415,6 +418,7 @@ def main():
         # timed out, and ends the process, if the second scheme takes more than 30 x the first one's time (at least three minutes).
         import threading
         d0 = results[schemes[0]][0]
+        bail_note = ["timed out (watchdog): the scheme did not finish; the line carries the first scheme only"]
         def _bail():
             if rank == 0:
                 line = {"metric": "Msamples/s (pixels x spp), ReSTIR-DI + %d-bounce path tracing forward render" % (args.bounces + 1),
@@ -422,7 +426,7 @@ def main():
                         "ms_per_step": round(d0 / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                         "config": {"workload": "BASELINE metric frame, %s mesh, %dx%d output, ssaa %d, %d spp" % (args.mesh, args.res, args.res, args.ssaa, args.spp), "value_scheme": schemes[0],
                                    "bit_identical_to_one_gpu": schemes[0] == "strips"},
-                        "roofline": None, "cpu_baseline": None, sc: {"value": None, "error": "timed out (watchdog): the scheme did not finish; the line carries the first scheme only"}}
+                        "roofline": None, "cpu_baseline": None, sc: {"value": None, "error": bail_note[0]}}
                 print(json.dumps(line), file=out_stream, flush=True)
             os._exit(0 if rank == 0 else 3)
         limit = max(180.0, 30.0 * d0 * (args.steps + args.warmup) / max(1, args.steps))
@@ -435,9 +439,13 @@ def main():
             results[sc] = timed(sc)
         except Exception as e:      # noqa: BLE001
             err = "%s: %s" % (type(e).__name__, e)
-        dog.cancel()
+            bail_note[0] = "failed on rank %d (%s); the other ranks did not return from it" % (rank, err[:200])
+            print("[bench] rank %d: scheme %s failed: %s" % (rank, sc, err), file=sys.stderr, flush=True)
+        # the watchdog stays armed across the agreement: a rank that failed ALONE leaves the others inside the scheme (a per-sample exchange waits for it), and
+        # this all-reduce would wait for them for ever
         bad = torch.tensor([1.0 if err else 0.0], device=dev)
         dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        dog.cancel()
         if float(bad.item()) > 0:
             results[sc] = (None, err or "failed on another rank")
     # Which scheme the line's `value` is: DECLARED (--value-scheme, default the sample slices), never chosen by the outcome — a consumer comparing rounds reads the same
