@@ -79,7 +79,7 @@ _CTX_CACHE = collections.OrderedDict()      # (device, fx, fy, max_bounce) -> Co
 
 
 def _ctx_cache_limit():
-    """A context lazily owns its batch pool (~670 B x K x N: 55 GB at 1600^2 with K = 32), so the cache is bounded: MIRRES_CTX_CACHE contexts
+    """A context lazily owns its batch pool (~690 B x K x N: 113 GB at 1600^2 with the default K = 64 of a 512-spp frame, less for shorter frames; a pool the device cannot hold is halved), so the cache is bounded: MIRRES_CTX_CACHE contexts
     (default 3) per process, least recently used dropped first.  A dropped context is destroyed (pool freed) as soon as nothing else refers to it —
     module handles returned by load_m_for_restir keep theirs alive."""
     try:
