@@ -31,7 +31,8 @@ static void refit(BTree& B, const Mesh& M) {
     int n = (int)B.l.size(); B.box.assign(n, empty_box());
     std::vector<int> order; order.reserve(n); std::vector<int> st = {B.root};
     while (!st.empty()) { int x = st.back(); st.pop_back(); order.push_back(x); if (B.l[x] >= 0) st.push_back(B.l[x]); if (B.r[x] >= 0) st.push_back(B.r[x]); }
-    for (int i = n - 1; i >= 0; i--) { int x = order[i]; Box a = B.l[x] >= 0 ? B.box[B.l[x]] : M.tb[~B.l[x]], b = B.r[x] >= 0 ? B.box[B.r[x]] : M.tb[~B.r[x]]; B.box[x] = merge(a, b); }
+    for (int i = (int)order.size() - 1; i >= 0; i--) { int x = order[i]; Box a = B.l[x] >= 0 ?      // (nodes a rebuilt top no longer reaches are not in `order`)
+         B.box[B.l[x]] : M.tb[~B.l[x]], b = B.r[x] >= 0 ? B.box[B.r[x]] : M.tb[~B.r[x]]; B.box[x] = merge(a, b); }
 }
 static double sah_binary(const BTree& B, const Mesh& M) {
     double c = 0, ra = area(B.box[B.root]);
@@ -252,8 +253,8 @@ static bool tri_hit(const Mesh& M, int s, const float o[3], const float d[3]) {
     float v = (d[0] * Q[0] + d[1] * Q[1] + d[2] * Q[2]) * id; return !(v < 0 || u + v > 1);
 }
 static Counts replay(const Tree4& Q, const Mesh& M, const std::vector<float>& rays, std::vector<unsigned char>* hits) {
-    int n = (int)rays.size() / 8; std::vector<int> recs(n); Counts C; double rec = 0, box = 0, tri = 0, hit = 0; int maxsp = 0;
-#pragma omp parallel for schedule(dynamic, 1024) reduction(+ : rec, box, tri, hit) reduction(max : maxsp)
+    int n = (int)rays.size() / 8; std::vector<int> recs(n); Counts C; double rec = 0, box = 0, tri = 0, hit = 0, rec_hit = 0; int maxsp = 0;
+#pragma omp parallel for schedule(dynamic, 1024) reduction(+ : rec, box, tri, hit, rec_hit) reduction(max : maxsp)
     for (int i = 0; i < n; i++) {
         const float* r = &rays[8 * i]; float o[3] = {r[0], r[1], r[2]}, d[3] = {r[4], r[5], r[6]}; float l = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]); float inv[3];
         for (int a = 0; a < 3; a++) { d[a] /= l; float di = d[a] == 0.f ? 1e-6f : d[a]; inv[a] = 1.0f / di; }
@@ -262,15 +263,32 @@ static Counts replay(const Tree4& Q, const Mesh& M, const std::vector<float>& ra
             nrec++;
             if (cur < 0) { int s = ~cur; float tn; box += 1; if (slab(M.tb[s], o, inv, r[3], r[7], tn)) { tri += 1; if (tri_hit(M, s, o, d)) { h = true; break; } } if (sp > 0) cur = stack[--sp]; else have = false; continue; }
             const Node4& q = Q.nodes[cur]; int next = 0x7fffffff; float ntn = 0;
+            // TL_ORDER: which passing child is visited first. 0 (the kernel's): the nearest, the others deferred in slot order with the nearest-so-far swap;
+            // 1 largest surface area; 2 nearest, the others sorted too; 3 longest chord (exit - entry); 9 longest chord, the others in slot order; 11 largest exit distance
+            static const int ORDER = getenv("TL_ORDER") ? atoi(getenv("TL_ORDER")) : 0;
+            if (ORDER == 0) {
             for (int k = 0; k < q.n; k++) { float tn; box += 1; if (!slab(q.box[k], o, inv, r[3], 3e38f, tn)) continue;
                 if (next == 0x7fffffff) { next = q.ref[k]; ntn = tn; } else { int far = q.ref[k]; if (tn < ntn) { far = next; next = q.ref[k]; ntn = tn; } if (sp < 256) stack[sp++] = far; } }
+            } else {
+                int cr[4]; float ck[4]; int nc = 0;
+                for (int k = 0; k < q.n; k++) { float tn; box += 1; if (!slab(q.box[k], o, inv, r[3], 3e38f, tn)) continue;
+                    float tf = 3e38f; for (int a = 0; a < 3; a++) { float t0 = (q.box[k].lo[a] - o[a]) * inv[a], t1 = (q.box[k].hi[a] - o[a]) * inv[a]; tf = std::min(tf, std::max(t0, t1)); }
+                    float key = tn;
+                    if (ORDER == 1) key = -area(q.box[k]);
+                    if (ORDER == 3 || ORDER == 9) key = -(tf - tn);
+                    if (ORDER == 11) key = -tf;
+                    cr[nc] = q.ref[k]; ck[nc] = key; nc++; }
+                if (ORDER == 9) { int bi = 0; for (int a = 1; a < nc; a++) if (ck[a] <= ck[bi]) bi = a; if (nc > 0) { next = cr[bi]; for (int a = 0; a < nc; a++) if (a != bi && sp < 256) stack[sp++] = cr[a]; } }
+                else { for (int a = 1; a < nc; a++) for (int b = a; b > 0 && ck[b] < ck[b - 1]; b--) { std::swap(ck[b], ck[b - 1]); std::swap(cr[b], cr[b - 1]); }
+                       if (nc > 0) { next = cr[0]; for (int a = nc - 1; a >= 1; a--) if (sp < 256) stack[sp++] = cr[a]; } }
+            }
             maxsp = std::max(maxsp, sp);
             if (next != 0x7fffffff) cur = next; else if (sp > 0) cur = stack[--sp]; else have = false;
         }
-        recs[i] = nrec; rec += nrec; hit += h; if (hits) (*hits)[i] = h;
+        recs[i] = nrec; rec += nrec; hit += h; if (hits) (*hits)[i] = h; if (h) rec_hit += nrec;
     }
     double wi = 0; for (int w = 0; w + 64 <= n; w += 64) { int m = 0; for (int k = 0; k < 64; k++) m = std::max(m, recs[w + k]); wi += m; }
-    C.rec = rec / n; C.box = box / n; C.tri = tri / n; C.hit = hit / n; C.wave_iter = wi / (n / 64); C.maxsp = maxsp; return C;
+    if (getenv("TL_ORDER")) printf("      records per occluded ray %.2f, per free ray %.2f\n", rec_hit / std::max(1.0, hit), (rec - rec_hit) / std::max(1.0, n - hit)); C.rec = rec / n; C.box = box / n; C.tri = tri / n; C.hit = hit / n; C.wave_iter = wi / (n / 64); C.maxsp = maxsp; return C;
 }
 // child boxes as the GPU stores them (Node4q): offsets from the node's corner in power-of-two steps, `bits` bits per plane, rounded outward
 static Tree4 quantise(Tree4 Q, int bits) {
@@ -310,6 +328,7 @@ int main(int argc, char** argv) {
     trees.push_back({"hybrid 18: object median", build_hybrid(M, 18, 2, 32)});
     trees.push_back({"hybrid 21: SAH 8 bins", build_hybrid(M, 21, 0, 8)});
     trees.push_back({"binned SAH", build_sah(M)});
+    if (const char* only = getenv("TL_ONLY")) { std::vector<std::pair<std::string, BTree>> keep; for (auto& t : trees) if (t.first.find(only) != std::string::npos) keep.push_back(t); trees.swap(keep); }
     std::vector<unsigned char> ref_hits(rays.size() / 8), hits(rays.size() / 8);
     printf("%-26s %-8s %9s %9s %7s %8s %8s %8s %9s %6s %6s\n", "binary hierarchy", "collapse", "SAH(bin)", "SAH(4w)", "depth4", "rec/ray", "box/ray", "tri/ray", "wave-it", "maxsp", "hit");
     bool first = true;
